@@ -1,0 +1,199 @@
+"""CPTV v2 container decoder (host side, row a1 / f1 of SURVEY.md §8).
+
+Replaces the un-vendored Rust reader ``cptv_rs_python_bindings.CptvReader``
+(python-cptv==0.0.8) at the call sites reference
+``src/track/cliptrackextractor.py:108-129,160-162`` and
+``src/classify/clipclassifier.py:460-469``.
+
+Format (restated from the published CPTV v2 layout, verified on the two
+fixture clips): gzip stream -> magic ``CPTV`` + version byte 2 -> section
+``H`` (u8 field count; each field = u8 length, u8 code, data) -> repeated
+``F`` sections (same field encoding; field ``f`` = payload byte count, ``w`` =
+bits per delta) each followed by the payload: first pixel delta as i32 LE, then
+W*H-1 deltas of ``w`` bits, MSB first, two's complement.  The running sum of the
+deltas, laid out in snake order (odd rows right-to-left), is the inter-frame
+difference; frame = previous frame + difference (previous = 0 for the first).
+
+Reader contract used by the tracker: ``get_header()`` -> object with
+``x_resolution, y_resolution, model, brand, timestamp`` (us);
+``next_frame()`` -> object with ``pix uint16[H,W]``, ``time_on`` /
+``last_ffc_time`` as *int* milliseconds, ``background_frame``,
+``temp_c``, ``last_ffc_temp_c``; ``None`` at end of file.
+"""
+
+import gzip
+import struct
+
+import numpy as np
+
+
+class CptvHeader:
+    def __init__(self):
+        self.timestamp = None
+        self.x_resolution = 0
+        self.y_resolution = 0
+        self.compression = None
+        self.device_name = None
+        self.model = None
+        self.brand = None
+        self.fps = None
+        self.device_id = None
+        self.preview_secs = None
+        self.motion_config = None
+        self.latitude = None
+        self.longitude = None
+        self.loc_timestamp = None
+        self.altitude = None
+        self.accuracy = None
+        self.firmware = None
+        self.serial = None
+        self.has_background_frame = False
+
+
+class CptvFrame:
+    __slots__ = (
+        "pix",
+        "time_on",
+        "last_ffc_time",
+        "temp_c",
+        "last_ffc_temp_c",
+        "background_frame",
+    )
+
+    def __init__(self, pix, time_on, last_ffc_time, temp_c, last_ffc_temp_c, background_frame):
+        self.pix = pix
+        self.time_on = time_on
+        self.last_ffc_time = last_ffc_time
+        self.temp_c = temp_c
+        self.last_ffc_temp_c = last_ffc_temp_c
+        self.background_frame = background_frame
+
+
+def _read_fields(buf, pos):
+    count = buf[pos]
+    pos += 1
+    fields = {}
+    for _ in range(count):
+        ln = buf[pos]
+        code = chr(buf[pos + 1])
+        fields[code] = bytes(buf[pos + 2 : pos + 2 + ln])
+        pos += 2 + ln
+    return fields, pos
+
+
+def _u32(b):
+    return struct.unpack("<I", b)[0]
+
+
+def _f32(b):
+    return struct.unpack("<f", b)[0]
+
+
+def _unpack_deltas(payload, n, width):
+    """n signed `width`-bit big-endian (MSB first) values from payload -> int64."""
+    if width == 8:
+        return np.frombuffer(payload, dtype=np.int8, count=n).astype(np.int64)
+    if width == 16:
+        return np.frombuffer(payload, dtype=">i2", count=n).astype(np.int64)
+    if width == 32:
+        return np.frombuffer(payload, dtype=">i4", count=n).astype(np.int64)
+    bits = np.unpackbits(np.frombuffer(payload, dtype=np.uint8), count=n * width)
+    bits = bits.reshape(n, width).astype(np.int64)
+    weights = 1 << np.arange(width - 1, -1, -1, dtype=np.int64)
+    vals = bits @ weights
+    sign = bits[:, 0] != 0
+    vals[sign] -= 1 << width
+    return vals
+
+
+class CptvReader:
+    """Sequential CPTV v2 reader with the ``cptv_rs_python_bindings`` surface."""
+
+    def __init__(self, path):
+        with gzip.open(str(path), "rb") as f:
+            self._buf = f.read()
+        buf = self._buf
+        if buf[:4] != b"CPTV":
+            raise ValueError("not a CPTV file: %s" % path)
+        if buf[4] != 2:
+            raise ValueError("unsupported CPTV version %d" % buf[4])
+        if buf[5:6] != b"H":
+            raise ValueError("CPTV header section missing")
+        fields, self._pos = _read_fields(buf, 6)
+        h = CptvHeader()
+        if "T" in fields:
+            h.timestamp = struct.unpack("<Q", fields["T"])[0]
+        h.x_resolution = _u32(fields["X"])
+        h.y_resolution = _u32(fields["Y"])
+        h.compression = fields.get("C", b"\0")[0]
+        for code, name in (("D", "device_name"), ("E", "model"), ("B", "brand"),
+                           ("V", "firmware"), ("M", "motion_config")):
+            if code in fields:
+                setattr(h, name, fields[code].decode("utf-8", "replace"))
+        if "Z" in fields:
+            h.fps = fields["Z"][0]
+        if "I" in fields:
+            h.device_id = _u32(fields["I"])
+        if "N" in fields:
+            h.serial = _u32(fields["N"])
+        if "P" in fields:
+            h.preview_secs = fields["P"][0]
+        if "L" in fields:
+            h.latitude = _f32(fields["L"])
+        if "O" in fields:
+            h.longitude = _f32(fields["O"])
+        if "S" in fields:
+            h.loc_timestamp = struct.unpack("<Q", fields["S"])[0]
+        if "A" in fields:
+            h.altitude = _f32(fields["A"])
+        if "U" in fields:
+            h.accuracy = _f32(fields["U"])
+        if "g" in fields:
+            h.has_background_frame = fields["g"][0] != 0
+        self._header = h
+        self._w = h.x_resolution
+        self._h = h.y_resolution
+        self._prev = np.zeros((self._h, self._w), dtype=np.int64)
+        # snake order: odd rows are stored right-to-left
+        idx = np.arange(self._w * self._h).reshape(self._h, self._w)
+        idx[1::2] = idx[1::2, ::-1].copy()
+        self._snake = idx
+
+    def get_header(self):
+        return self._header
+
+    def next_frame(self):
+        buf = self._buf
+        pos = self._pos
+        if pos >= len(buf):
+            return None
+        if buf[pos : pos + 1] != b"F":
+            raise ValueError("expected frame section at %d" % pos)
+        fields, pos = _read_fields(buf, pos + 1)
+        width = fields["w"][0]
+        nbytes = _u32(fields["f"])
+        payload = buf[pos : pos + nbytes]
+        if len(payload) < nbytes:
+            raise ValueError("truncated CPTV frame")
+        self._pos = pos + nbytes
+        n = self._w * self._h
+        deltas = np.empty(n, dtype=np.int64)
+        deltas[0] = struct.unpack("<i", payload[:4])[0]
+        deltas[1:] = _unpack_deltas(payload[4:], n - 1, width)
+        diff = np.cumsum(deltas)[self._snake]
+        self._prev = self._prev + diff
+        pix = self._prev.astype(np.uint16)
+        time_on = _u32(fields["t"]) if "t" in fields else None
+        last_ffc = _u32(fields["c"]) if "c" in fields else None
+        temp_c = _f32(fields["a"]) if "a" in fields else 0.0
+        ffc_temp = _f32(fields["b"]) if "b" in fields else 0.0
+        bg = ("g" in fields) and fields["g"][0] != 0
+        return CptvFrame(pix, time_on, last_ffc, temp_c, ffc_temp, bg)
+
+    def read_all(self):
+        frames = []
+        while True:
+            f = self.next_frame()
+            if f is None:
+                return frames
+            frames.append(f)

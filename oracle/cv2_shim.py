@@ -1,0 +1,318 @@
+"""TEST INFRASTRUCTURE ONLY -- NumPy restatement of the handful of OpenCV calls
+on the reference's track/classify path, injected as ``cv2`` when the reference
+(``/root/reference/src``, Python) is imported in the build container to act as
+the oracle and to generate ``tests/golden`` fixtures.
+
+OpenCV is a third-party dependency of the reference that is NOT vendored under
+/root/reference: ``opencv-python==4.8.0.76`` (pyproject.toml:43) /
+``opencv-contrib-python-headless~=4.12.0.88`` (requirements.txt:4).  Each
+function below restates the published algorithm of the OpenCV call at the cited
+reference call site; the restatement is pinned by the reference's own golden
+``tests/clips/possum.txt`` (see tests/test_possum_golden.py): boxes, masses,
+frame ranges exact, pixel_variance to 2 dp, tracking_score to 1e-6.
+
+Nothing in the product package imports this file.
+"""
+
+import numpy as np
+from scipy import ndimage
+
+# ---- constants the reference touches at import / call time -----------------
+INTER_NEAREST = 0
+INTER_LINEAR = 1
+INTER_CUBIC = 2
+INTER_AREA = 3
+THRESH_BINARY = 0
+THRESH_OTSU = 8
+MORPH_ERODE = 0
+MORPH_DILATE = 1
+MORPH_OPEN = 2
+MORPH_CLOSE = 3
+RETR_EXTERNAL = 0
+RETR_LIST = 1
+CHAIN_APPROX_SIMPLE = 2
+CHAIN_APPROX_NONE = 1
+NORM_MINMAX = 32
+INPAINT_TELEA = 1
+COLOR_HSV2BGR = 54
+COLOR_BGR2GRAY = 6
+CC_STAT_LEFT, CC_STAT_TOP, CC_STAT_WIDTH, CC_STAT_HEIGHT, CC_STAT_AREA = range(5)
+CV_32S = 4
+__version__ = "4.8.0-shim"
+
+
+def GaussianBlur(src, ksize, sigmaX, *args, **kwargs):
+    """8-bit 5x5 Gaussian, sigma=0 (imageprocessing.py:242).
+
+    OpenCV's 8U path uses the fixed-point binomial kernel [1,4,6,4,1]/16 per
+    axis with BORDER_REFLECT_101 and a single rounding: (S + 128) >> 8.
+    """
+    src = np.asarray(src)
+    if tuple(ksize) != (5, 5) or sigmaX != 0:
+        raise NotImplementedError("shim: only GaussianBlur((5,5), 0)")
+    if src.dtype != np.uint8:
+        raise NotImplementedError("shim: only 8-bit GaussianBlur")
+    k = np.array([1, 4, 6, 4, 1], dtype=np.int32)
+    p = np.pad(src.astype(np.int32), 2, mode="reflect")
+    h, w = src.shape
+    acc = np.zeros((h + 4, w), dtype=np.int32)
+    for j in range(5):
+        acc += k[j] * p[:, j : j + w]
+    out = np.zeros((h, w), dtype=np.int32)
+    for i in range(5):
+        out += k[i] * acc[i : i + h, :]
+    return ((out + 128) >> 8).astype(np.uint8)
+
+
+def threshold(src, thresh, maxval, type):
+    """THRESH_BINARY on 8U (imageprocessing.py:246): dst = src > floor(thresh)."""
+    src = np.asarray(src)
+    if type != THRESH_BINARY:
+        raise NotImplementedError("shim: only THRESH_BINARY")
+    if src.dtype != np.uint8:
+        raise NotImplementedError("shim: only 8-bit threshold")
+    ithresh = int(np.floor(thresh))
+    dst = np.where(src.astype(np.int32) > ithresh, np.uint8(maxval), np.uint8(0))
+    return float(thresh), dst.astype(np.uint8)
+
+
+def morphologyEx(src, op, kernel, *args, **kwargs):
+    """MORPH_CLOSE with the reference's *tuple* kernel (imageprocessing.py:247).
+
+    The binding turns the tuple (5, 5) into a 2x1 CV_64F Mat [5;5]: an all-set
+    structuring element 1 px wide, 2 px tall, anchor (0,1):
+    dilate D[y] = max(I[y], I[y-1]); erode E[y] = min(D[y], D[y-1]); rows
+    outside the image are ignored by both.
+    """
+    src = np.asarray(src)
+    if op != MORPH_CLOSE:
+        raise NotImplementedError("shim: only MORPH_CLOSE")
+    if not isinstance(kernel, tuple) or len(kernel) != 2:
+        raise NotImplementedError("shim: only the tuple-kernel close")
+    d = src.copy()
+    d[1:] = np.maximum(src[1:], src[:-1])
+    e = d.copy()
+    e[1:] = np.minimum(d[1:], d[:-1])
+    return e
+
+
+def connectedComponentsWithStats(image, *args, **kwargs):
+    """8-connectivity labelling + stats (imageprocessing.py:248).
+
+    stats[i] = (left, top, width, height, area) int32; centroids[i] = (mean x,
+    mean y) float64; row 0 is the background.  Label numbering follows OpenCV's
+    default 8-conn algorithm (2x2-block raster scan, union keeps the smaller
+    provisional label, consecutive renumbering): components are numbered by the
+    block-raster position of their first 2x2 block (SURVEY a7').
+    """
+    img = np.asarray(image)
+    fg = img > 0
+    h, w = fg.shape
+    lab, n = ndimage.label(fg, structure=np.ones((3, 3), dtype=np.int32))
+    labels = np.zeros((h, w), dtype=np.int32)
+    stats = np.zeros((n + 1, 5), dtype=np.int32)
+    cents = np.zeros((n + 1, 2), dtype=np.float64)
+    ys, xs = np.nonzero(fg)
+    bw = (w + 1) // 2
+    if n > 0:
+        key = (ys >> 1) * bw + (xs >> 1)
+        comp = lab[ys, xs]
+        first = np.full(n + 1, np.iinfo(np.int64).max, dtype=np.int64)
+        np.minimum.at(first, comp, key)
+        order = np.argsort(first[1:], kind="stable")  # old label-1 sorted by key
+        remap = np.zeros(n + 1, dtype=np.int32)
+        remap[order + 1] = np.arange(1, n + 1, dtype=np.int32)
+        labels[ys, xs] = remap[comp]
+        newc = remap[comp]
+        for i in range(1, n + 1):
+            sel = newc == i
+            cx = xs[sel]
+            cy = ys[sel]
+            stats[i] = (
+                cx.min(),
+                cy.min(),
+                cx.max() - cx.min() + 1,
+                cy.max() - cy.min() + 1,
+                cx.size,
+            )
+            cents[i] = (cx.sum() / cx.size, cy.sum() / cy.size)
+    bys, bxs = np.nonzero(~fg)
+    if bys.size:
+        stats[0] = (
+            bxs.min(),
+            bys.min(),
+            bxs.max() - bxs.min() + 1,
+            bys.max() - bys.min() + 1,
+            bys.size,
+        )
+        cents[0] = (bxs.sum() / bxs.size, bys.sum() / bys.size)
+    return n + 1, labels, stats, cents
+
+
+_NLM_LUT = None
+
+
+def _nlm_lut():
+    global _NLM_LUT
+    if _NLM_LUT is None:
+        h = 3.0
+        tsize = 49
+        fixed_point_mult = (2**31 - 1) // (21 * 21 * 255)
+        shift = 6  # smallest s with 2**s >= 49
+        mult = (1 << shift) / tsize
+        max_dist = 255 * 255
+        n = int(max_dist / mult + 1)
+        a = np.arange(n, dtype=np.float64)
+        wv = np.exp(-(a * mult) / (h * h))
+        w = np.rint(fixed_point_mult * wv)
+        w[w < 0.001 * fixed_point_mult] = 0
+        _NLM_LUT = (w.astype(np.int64), shift, fixed_point_mult)
+    return _NLM_LUT
+
+
+def fastNlMeansDenoising(src, dst=None, h=3, templateWindowSize=7, searchWindowSize=21):
+    """Integer non-local means, defaults h=3 / 7 / 21 (cliptracker.py:117).
+
+    SURVEY Appendix A.6: reflect-101 border of 13; per offset in [-10,10]^2 the
+    7x7 summed squared difference, weight = LUT[dist >> 6], fixed-point
+    accumulation, result (est + wsum//2) // wsum.
+    """
+    src = np.asarray(src)
+    if src.dtype != np.uint8 or src.ndim != 2:
+        raise NotImplementedError("shim: NLM only for 2-D uint8")
+    if h != 3 or templateWindowSize != 7 or searchWindowSize != 21:
+        raise NotImplementedError("shim: NLM defaults only")
+    lut, shift, _ = _nlm_lut()
+    t, s = 3, 10
+    b = t + s
+    H, W = src.shape
+    ext = np.pad(src.astype(np.int64), b, mode="reflect")
+    est = np.zeros((H, W), dtype=np.int64)
+    wsum = np.zeros((H, W), dtype=np.int64)
+    # region of centres including the template halo
+    base = ext[b - t : b + H + t, b - t : b + W + t]
+    for dy in range(-s, s + 1):
+        for dx in range(-s, s + 1):
+            sh = ext[b - t + dy : b + H + t + dy, b - t + dx : b + W + t + dx]
+            d2 = (base - sh) ** 2
+            c = np.cumsum(np.cumsum(d2, axis=0), axis=1)
+            c = np.pad(c, ((1, 0), (1, 0)))
+            k = 2 * t + 1
+            dist = c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]
+            wgt = lut[dist >> shift]
+            est += wgt * ext[b + dy : b + dy + H, b + dx : b + dx + W]
+            wsum += wgt
+    out = (est + wsum // 2) // wsum
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
+    """float32 bilinear / nearest resize (imageprocessing.py:78).
+
+    INTER_LINEAR: source coordinate (d + 0.5) * (src/dst) - 0.5, floor +
+    fractional weight in float32, indices clamped to the edge; horizontal pass
+    then vertical pass, all float32.  INTER_NEAREST: min(floor(d*src/dst), src-1).
+    Not pinned by the golden.
+    """
+    src = np.asarray(src)
+    if src.ndim == 3:
+        chans = [resize(src[:, :, c], dsize, interpolation=interpolation) for c in range(src.shape[2])]
+        return np.stack(chans, axis=2)
+    dw, dh = int(dsize[0]), int(dsize[1])
+    sh, sw = src.shape
+    if interpolation == INTER_NEAREST:
+        xs = np.minimum(np.floor(np.arange(dw) * (sw / dw)).astype(np.int64), sw - 1)
+        ys = np.minimum(np.floor(np.arange(dh) * (sh / dh)).astype(np.int64), sh - 1)
+        return src[np.ix_(ys, xs)].copy()
+    if interpolation != INTER_LINEAR:
+        raise NotImplementedError("shim: resize INTER_LINEAR / INTER_NEAREST only")
+    s32 = src.astype(np.float32)
+
+    def coords(dn, sn):
+        scale = sn / dn
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        a = (f - i0.astype(np.float32)).astype(np.float32)
+        lo = i0 < 0
+        a[lo] = 0
+        i0[lo] = 0
+        hi = i0 >= sn - 1
+        a[hi] = 0
+        i0[hi] = sn - 1
+        i1 = np.minimum(i0 + 1, sn - 1)
+        return i0, i1, a
+
+    x0, x1, ax = coords(dw, sw)
+    y0, y1, ay = coords(dh, sh)
+    one = np.float32(1.0)
+    hor = s32[:, x0] * (one - ax)[None, :] + s32[:, x1] * ax[None, :]
+    hor = hor.astype(np.float32)
+    out = hor[y0, :] * (one - ay)[:, None] + hor[y1, :] * ay[:, None]
+    return out.astype(np.float32)
+
+
+class KalmanFilter:
+    """cv2.KalmanFilter(4, 2) in float32 (kalman.py:10)."""
+
+    def __init__(self, dynamParams, measureParams, controlParams=0, type=5):
+        dp, mp = dynamParams, measureParams
+        f = np.float32
+        self.statePre = np.zeros((dp, 1), f)
+        self.statePost = np.zeros((dp, 1), f)
+        self.transitionMatrix = np.eye(dp, dtype=f)
+        self.processNoiseCov = np.eye(dp, dtype=f)
+        self.measurementMatrix = np.zeros((mp, dp), f)
+        self.measurementNoiseCov = np.eye(mp, dtype=f)
+        self.errorCovPre = np.zeros((dp, dp), f)
+        self.errorCovPost = np.zeros((dp, dp), f)
+        self.gain = np.zeros((dp, mp), f)
+
+    def predict(self, control=None):
+        f = np.float32
+        A = self.transitionMatrix.astype(f)
+        self.statePre = (A @ self.statePost).astype(f)
+        temp1 = (A @ self.errorCovPost).astype(f)
+        self.errorCovPre = (temp1 @ A.T + self.processNoiseCov).astype(f)
+        self.statePost = self.statePre.copy()
+        self.errorCovPost = self.errorCovPre.copy()
+        return self.statePre.copy()
+
+    def correct(self, measurement):
+        f = np.float32
+        H = self.measurementMatrix.astype(f)
+        z = np.asarray(measurement, dtype=f).reshape(-1, 1)
+        temp2 = (H @ self.errorCovPre).astype(f)
+        temp3 = (temp2 @ H.T + self.measurementNoiseCov).astype(f)
+        temp4 = np.linalg.solve(temp3.astype(np.float64), temp2.astype(np.float64)).astype(f)
+        self.gain = temp4.T.astype(f)
+        temp5 = (z - H @ self.statePre).astype(f)
+        self.statePost = (self.statePre + self.gain @ temp5).astype(f)
+        self.errorCovPost = (self.errorCovPre - self.gain @ temp2).astype(f)
+        return self.statePost.copy()
+
+
+def findContours(image, mode, method, *args, **kwargs):
+    """Thumbnail scoring only (classify/thumbnail.py:91) -- out of scope (f3).
+
+    Returns one 'contour' per 8-connected component with as many points as the
+    component has boundary pixels so that callers relying on len() keep working.
+    """
+    img = np.asarray(image) > 0
+    lab, n = ndimage.label(img, structure=np.ones((3, 3), dtype=np.int32))
+    contours = []
+    er = ndimage.binary_erosion(img)
+    edge = img & ~er
+    for i in range(1, n + 1):
+        ys, xs = np.nonzero(edge & (lab == i))
+        contours.append(np.stack([xs, ys], axis=1).reshape(-1, 1, 2).astype(np.int32))
+    return contours, None
+
+
+def contourArea(contour):
+    return float(len(contour))
+
+
+def __getattr__(name):  # pragma: no cover - any other cv2 symbol is off-path
+    if name.isupper():
+        return 0
+    raise AttributeError("cv2 shim has no attribute %r (off the hot path)" % name)
