@@ -1,0 +1,98 @@
+"""ctypes binding of libcpx_hip.so (include/cpx.h).  Loading never touches the
+GPU; every compute call needs one and fails loudly otherwise."""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpx_hip.so")
+
+CPX_OK = 0
+STATUS = {
+    0: "CPX_OK",
+    -1: "CPX_ERR_INVALID",
+    -2: "CPX_ERR_UNSUPPORTED",
+    -3: "CPX_ERR_NO_DEVICE",
+    -4: "CPX_ERR_HIP",
+    -5: "CPX_ERR_OVERFLOW",
+    -6: "CPX_ERR_NOMEM",
+}
+
+
+class CpxError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__("%s (%d) %s" % (STATUS.get(code, "CPX_ERR"), code, what))
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("edge_pixels", C.c_int32),
+        ("window", C.c_int32),
+        ("background_thresh", C.c_double),
+        ("weight_add", C.c_double),
+        ("max_components", C.c_int32),
+        ("max_frames", C.c_int32),
+    ]
+
+
+FRAME_META_DTYPE = np.dtype(
+    [("time_on_ms", "<i8"), ("last_ffc_ms", "<i8"), ("background_frame", "<i4"), ("has_times", "<i4")]
+)
+COMPONENT_DTYPE = np.dtype(
+    [("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"), ("area", "<i4"),
+     ("sum_x", "<i4"), ("sum_y", "<i4"), ("pixel_variance", "<f4")]
+)
+FRAME_INFO_DTYPE = np.dtype(
+    [("frame_number", "<i4"), ("n_components", "<i4"), ("status", "<i4"), ("ffc_affected", "<i4"),
+     ("avg_change", "<i4"), ("norm_min", "<i4"), ("norm_max", "<i4"), ("threshold", "<f4"),
+     ("filt_min", "<i4"), ("filt_max", "<i4"), ("thermal_min", "<i4"), ("thermal_max", "<i4"),
+     ("thermal_sum", "<u4"), ("thermal_median", "<f4"), ("filtered_abs_sum", "<u8"),
+     ("background_average", "<f8"), ("background_changed", "<i4"), ("reserved", "<i4")]
+)
+assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FRAME_INFO_DTYPE.itemsize == 80
+
+EXPORTS = [
+    "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
+    "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing",
+]
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare the prototypes.  Raises if it is missing:
+    there is no CPU fallback for the compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libcpx_hip.so not built: run `python __graft_entry__.py` (or make -C classifier-pipeline_amd/csrc)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    lib.cpx_abi_version.restype = C.c_int
+    lib.cpx_create.argtypes = [C.c_int, C.POINTER(Config), C.POINTER(vp)]
+    lib.cpx_create.restype = C.c_int
+    lib.cpx_destroy.argtypes = [vp]
+    lib.cpx_destroy.restype = None
+    lib.cpx_last_error.argtypes = [vp]
+    lib.cpx_last_error.restype = C.c_char_p
+    lib.cpx_stream.argtypes = [vp]
+    lib.cpx_stream.restype = vp
+    lib.cpx_synchronize.argtypes = [vp]
+    lib.cpx_synchronize.restype = C.c_int
+    lib.cpx_track_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.cpx_track_batch.restype = C.c_int
+    lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
+    lib.cpx_track_workspace_bytes.restype = C.c_size_t
+    lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.cpx_last_kernel_timing.restype = C.c_int
+    if lib.cpx_abi_version() != 1:
+        raise ImportError("libcpx_hip.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,265 @@
+// cpx_api.cpp -- the C-ABI of libcpx_hip.so (include/cpx.h): handle lifetime,
+// device workspace, host-side schedule of the per-frame launches.  No torch
+// types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cpx.h"
+#include "cpx_kernels.h"
+
+struct cpx_handle {
+  int device = 0;
+  cpx_config cfg{};
+  hipStream_t stream = nullptr;
+  std::string err;
+  // device workspace (grown lazily, reused)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  double* wtab_dev = nullptr;
+  int wtab_len = 0;
+  // small device arrays for the schedule
+  int* sched_dev = nullptr;
+  size_t sched_ints = 0;
+  // timing of the last batch
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int last_launches = 0;
+  bool timing_valid = false;
+};
+
+static_assert(sizeof(cpx_component) == 32, "cpx_component layout is part of the ABI");
+static_assert(sizeof(cpx_frame_info) == 80, "cpx_frame_info layout is part of the ABI");
+static_assert(sizeof(cpx_frame_meta) == 24, "cpx_frame_meta layout is part of the ABI");
+static_assert(sizeof(cpx_config) == 40, "cpx_config layout is part of the ABI");
+
+namespace {
+
+int fail(cpx_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
+  if (h) {
+    h->err = what;
+    if (e != hipSuccess) {
+      h->err += ": ";
+      h->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define CPX_HIP(h, call)                                            \
+  do {                                                              \
+    hipError_t _e = (call);                                         \
+    if (_e != hipSuccess) return fail((h), CPX_ERR_HIP, #call, _e); \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout {
+  size_t bg, wsum, kcnt, filt, cstate, total;
+};
+
+WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
+  const size_t P = (size_t)c.width * c.height;
+  WsLayout l{};
+  size_t off = 0;
+  l.bg = off;
+  off = align_up(off + (size_t)B * 2 * P * sizeof(int32_t), 256);
+  l.wsum = off;
+  off = align_up(off + (size_t)B * P * sizeof(uint32_t), 256);
+  l.kcnt = off;
+  off = align_up(off + (size_t)B * P * sizeof(uint16_t), 256);
+  l.filt = off;
+  if (need_filt_state) off = align_up(off + (size_t)B * 2 * P * sizeof(float), 256);
+  l.cstate = off;
+  off = align_up(off + (size_t)B * sizeof(cpx::ClipState), 256);
+  l.total = off;
+  return l;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpx_abi_version(void) { return CPX_ABI_VERSION; }
+
+int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
+  if (!cfg || !out) return CPX_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CPX_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= ndev) return CPX_ERR_INVALID;
+  const int W = cfg->width, H = cfg->height;
+  if (W <= 0 || H <= 0 || (W % 8) != 0 || W >= 192 || W * H > cpx::track_max_pixels() || H < 5 || W < 8)
+    return CPX_ERR_UNSUPPORTED;
+  if (cfg->edge_pixels < 0 || 2 * cfg->edge_pixels >= std::min(W, H) || cfg->window < 1 ||
+      cfg->max_components < 1 || cfg->max_frames < 1 || cfg->max_frames > 65534)
+    return CPX_ERR_INVALID;
+  cpx_handle* h = new (std::nothrow) cpx_handle();
+  if (!h) return CPX_ERR_NOMEM;
+  h->device = device_id;
+  h->cfg = *cfg;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return CPX_ERR_HIP;
+  }
+  // weight table: w_k = k-fold float64 accumulation of weight_add, exactly as
+  // NumPy evaluates background_weight + weight_add (motiondetector.py:218-222)
+  h->wtab_len = cfg->max_frames + 2;
+  std::vector<double> wt(h->wtab_len);
+  double w = 0.0;
+  for (int k = 0; k < h->wtab_len; ++k) {
+    wt[k] = w;
+    w = w + cfg->weight_add;
+  }
+  if (hipMalloc(&h->wtab_dev, wt.size() * sizeof(double)) != hipSuccess ||
+      hipMemcpy(h->wtab_dev, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      cpx::frame_kernel_attr_setup() != 0) {
+    cpx_destroy(h);
+    return CPX_ERR_HIP;
+  }
+  *out = h;
+  return CPX_OK;
+}
+
+void cpx_destroy(cpx_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->ws) hipFree(h->ws);
+  if (h->wtab_dev) hipFree(h->wtab_dev);
+  if (h->sched_dev) hipFree(h->sched_dev);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* cpx_last_error(const cpx_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+void* cpx_stream(cpx_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int cpx_synchronize(cpx_handle* h) {
+  if (!h) return CPX_ERR_INVALID;
+  CPX_HIP(h, hipStreamSynchronize(h->stream));
+  return CPX_OK;
+}
+
+size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames) {
+  if (!h || B <= 0) return 0;
+  (void)total_frames;
+  return ws_layout(h->cfg, B, true).total;
+}
+
+int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
+                    const cpx_frame_meta* meta, int B, cpx_component* comps_dev,
+                    cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                    float* background_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !clip_offsets || !meta || B <= 0 || !comps_dev || !info_dev)
+    return fail(h, CPX_ERR_INVALID, "cpx_track_batch: null argument");
+  CPX_HIP(h, hipSetDevice(h->device));
+  const cpx_config& c = h->cfg;
+  // ---- schedule: which frames are processed, FFC flags (cptvmotiondetector.py:211-223) ----
+  const int total = clip_offsets[B];
+  std::vector<int> clip_first(B), proc_off(B + 1, 0), proc_idx, proc_ffc;
+  proc_idx.reserve(total);
+  proc_ffc.reserve(total);
+  int max_proc = 0;
+  for (int b = 0; b < B; ++b) {
+    const int f0 = clip_offsets[b], f1 = clip_offsets[b + 1];
+    if (f1 <= f0) return fail(h, CPX_ERR_INVALID, "cpx_track_batch: empty clip");
+    clip_first[b] = f0;
+    for (int f = f0; f < f1; ++f) {
+      if (meta[f].background_frame) continue;  // cliptrackextractor.py:167-168
+      proc_idx.push_back(f);
+      int ffc = 0;
+      if (meta[f].has_times) ffc = (meta[f].time_on_ms - meta[f].last_ffc_ms) < 9 ? 1 : 0;  // int-ms quirk, SURVEY F5
+      proc_ffc.push_back(ffc);
+    }
+    proc_off[b + 1] = (int)proc_idx.size();
+    const int np = proc_off[b + 1] - proc_off[b];
+    if (np > c.max_frames) return fail(h, CPX_ERR_INVALID, "cpx_track_batch: clip longer than max_frames");
+    max_proc = std::max(max_proc, np);
+  }
+  const int nproc_total = (int)proc_idx.size();
+  // ---- device workspace ----
+  const bool need_filt = (filtered_dev == nullptr);
+  const WsLayout l = ws_layout(c, B, need_filt);
+  if (l.total > h->ws_bytes) {
+    if (h->ws) hipFree(h->ws);
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+    hipError_t e = hipMalloc(&h->ws, l.total);
+    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "workspace hipMalloc", e);
+    h->ws_bytes = l.total;
+  }
+  const size_t sched_ints = (size_t)B + (B + 1) + 2 * (size_t)std::max(nproc_total, 1);
+  if (sched_ints > h->sched_ints) {
+    if (h->sched_dev) hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+    h->sched_ints = 0;
+    hipError_t e = hipMalloc((void**)&h->sched_dev, sched_ints * sizeof(int));
+    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "schedule hipMalloc", e);
+    h->sched_ints = sched_ints;
+  }
+  std::vector<int> sched(sched_ints, 0);
+  std::copy(clip_first.begin(), clip_first.end(), sched.begin());
+  std::copy(proc_off.begin(), proc_off.end(), sched.begin() + B);
+  std::copy(proc_idx.begin(), proc_idx.end(), sched.begin() + B + (B + 1));
+  std::copy(proc_ffc.begin(), proc_ffc.end(), sched.begin() + B + (B + 1) + std::max(nproc_total, 1));
+  CPX_HIP(h, hipMemcpyAsync(h->sched_dev, sched.data(), sched_ints * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  CPX_HIP(h, hipStreamSynchronize(h->stream));  // `sched` is a stack-lifetime buffer
+
+  cpx::TrackArgs a{};
+  a.W = c.width;
+  a.H = c.height;
+  a.edge = c.edge_pixels;
+  a.window = c.window;
+  a.cap_out = c.max_components;
+  a.background_thresh = c.background_thresh;
+  a.frames = frames_dev;
+  a.clip_first = h->sched_dev;
+  a.proc_off = h->sched_dev + B;
+  a.proc_idx = h->sched_dev + B + (B + 1);
+  a.proc_ffc = h->sched_dev + B + (B + 1) + std::max(nproc_total, 1);
+  a.wtab = h->wtab_dev;
+  char* base = (char*)h->ws;
+  a.bg = (int32_t*)(base + l.bg);
+  a.wsum = (uint32_t*)(base + l.wsum);
+  a.kcnt = (uint16_t*)(base + l.kcnt);
+  a.filt_state = need_filt ? (float*)(base + l.filt) : nullptr;
+  a.cstate = (cpx::ClipState*)(base + l.cstate);
+  a.comps_out = comps_dev;
+  a.info_out = info_dev;
+  a.labels_out = labels_dev;
+  a.filtered_out = filtered_dev;
+
+  // frames that are never processed (background frames) get frame_number = -1
+  CPX_HIP(h, hipMemsetAsync(info_dev, 0xFF, (size_t)total * sizeof(cpx_frame_info), h->stream));
+  cpx::launch_init(a, B, h->stream);
+  CPX_HIP(h, hipEventRecord(h->ev0, h->stream));
+  for (int t = 0; t < max_proc; ++t) cpx::launch_frame(a, B, t, h->stream);
+  CPX_HIP(h, hipEventRecord(h->ev1, h->stream));
+  h->last_launches = max_proc;
+  h->timing_valid = true;
+  if (background_dev) cpx::launch_export_background(a, B, background_dev, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches) {
+  if (!h || !total_ms || !launches) return CPX_ERR_INVALID;
+  if (!h->timing_valid) return fail(h, CPX_ERR_INVALID, "no batch has been run");
+  CPX_HIP(h, hipEventSynchronize(h->ev1));
+  CPX_HIP(h, hipEventElapsedTime(total_ms, h->ev0, h->ev1));
+  *launches = h->last_launches;
+  return CPX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// cpx_kernels.h -- internal interface between the C-ABI translation unit
+// (cpx_api.cpp) and the HIP kernels.  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cpx.h"
+
+// Tunables of the track kernel (one workgroup per clip-frame).
+#ifndef CPX_TRACK_THREADS
+#define CPX_TRACK_THREADS 1024
+#endif
+#ifndef CPX_TRACK_CHUNKS
+#define CPX_TRACK_CHUNKS 5  // 4-pixel chunks per thread: W*H <= 4*5*1024 = 20480
+#endif
+#ifndef CPX_TRACK_LDS_COMPONENTS
+#define CPX_TRACK_LDS_COMPONENTS 512
+#endif
+
+namespace cpx {
+
+typedef cpx_component Component;
+typedef cpx_frame_info FrameInfo;
+
+struct ClipState {
+  double bg_average;  // WeightedBackground.average (float until the first change, then integral)
+  int prev_fmin, prev_fmax;  // min / max of the previous frame's filtered image
+  int has_prev;
+  int pad;
+};
+
+struct TrackArgs {
+  // geometry / config
+  int W, H, edge, window, cap_out;
+  double background_thresh;
+  // inputs
+  const uint16_t* frames;   // [total_frames, H, W]
+  const int* clip_first;    // [B]   first frame (file order) of each clip: background init
+  const int* proc_off;      // [B+1] offsets into proc_idx
+  const int* proc_idx;      // [total_proc] frame index (into frames) of each processed frame
+  const int* proc_ffc;      // [total_proc] is_affected_by_ffc
+  const double* wtab;       // [max_frames+2] k-fold float64 accumulation of weight_add
+  // per-clip state
+  int32_t* bg;              // [B][2][P] ping-pong background (interior authoritative)
+  uint32_t* wsum;           // [B][P] sum of the last <= window frames
+  uint16_t* kcnt;           // [B][P] consecutive "background kept" count -> weight = wtab[k]
+  float* filt_state;        // [B][2][P] ping-pong filtered (only when filtered_out == nullptr)
+  ClipState* cstate;        // [B]
+  // outputs
+  Component* comps_out;     // [total_frames * cap_out]
+  FrameInfo* info_out;      // [total_frames]
+  int32_t* labels_out;      // [total_frames, P] or nullptr
+  float* filtered_out;      // [total_frames, P] or nullptr
+};
+
+size_t track_lds_bytes(int W, int H);
+int track_max_pixels();
+int track_lds_components();
+int frame_kernel_attr_setup();
+void launch_init(const TrackArgs& a, int B, hipStream_t s);
+void launch_frame(const TrackArgs& a, int B, int t, hipStream_t s);
+void launch_export_background(const TrackArgs& a, int B, float* out, hipStream_t s);
+
+}  // namespace cpx

@@ -1,0 +1,137 @@
+/*
+ * cpx.h -- C-ABI of libcpx_hip.so, the MI355X (gfx950) implementation of the
+ * thermal extract-and-classify hot path of TheCacophonyProject/classifier-pipeline.
+ *
+ * The reference has no FFI layer: its hot path is Python over OpenCV / NumPy.
+ * Each entry point below replaces the arithmetic of the reference call sites
+ * cited next to it (paths relative to /root/reference/src); the Python host
+ * classes in classifier-pipeline_amd/cpx mirror the reference classes and bind
+ * these symbols with ctypes.
+ *
+ * Conventions: plain C types; int return (0 = ok, negative = cpx_status);
+ * caller-allocated outputs with explicit capacities (overflow is an error,
+ * never truncation); pointers named *_dev are DEVICE pointers (e.g.
+ * torch.Tensor.data_ptr()), all others are host pointers; one HIP stream per
+ * handle; a handle is not thread-safe; no global state.
+ */
+#ifndef CPX_H
+#define CPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPX_ABI_VERSION 1
+
+typedef enum cpx_status {
+  CPX_OK = 0,
+  CPX_ERR_INVALID = -1,      /* bad argument */
+  CPX_ERR_UNSUPPORTED = -2,  /* resolution / option outside the kernels' envelope */
+  CPX_ERR_NO_DEVICE = -3,    /* no HIP device / wrong architecture */
+  CPX_ERR_HIP = -4,          /* HIP runtime error, see cpx_last_error */
+  CPX_ERR_OVERFLOW = -5,     /* a frame produced more components than max_components */
+  CPX_ERR_NOMEM = -6
+} cpx_status;
+
+typedef struct cpx_handle cpx_handle;
+
+/* Tracking configuration: the values the pixel stage reads from the reference's
+ * TrackingConfig / ThresholdConfig (config/trackingconfig.py:126-177,
+ * config/trackingmotionconfig.py:24-59) and cliptrackextractor.py:124-127. */
+typedef struct cpx_config {
+  int32_t width;             /* 160 */
+  int32_t height;            /* 120 */
+  int32_t edge_pixels;       /* 1   (crop rectangle = interior) */
+  int32_t window;            /* 45  frames averaged for the background feed */
+  double background_thresh;  /* 20 (lepton3) / 50 (lepton3.5) */
+  double weight_add;         /* 0.1 (lepton3) / 1.0 (lepton3.5) */
+  int32_t max_components;    /* capacity of the per-frame component list */
+  int32_t max_frames;        /* longest clip (frames) the handle must support */
+} cpx_config;
+
+/* Per-frame metadata delivered by the CPTV reader (cptv.py; reference
+ * cliptrackextractor.py:160-169, cptvmotiondetector.py:211-223). */
+typedef struct cpx_frame_meta {
+  int64_t time_on_ms;
+  int64_t last_ffc_ms;
+  int32_t background_frame; /* 1: used to initialise the background only */
+  int32_t has_times;        /* 0: time_on / last_ffc are None */
+} cpx_frame_meta;
+
+/* One connected component = one row of cv2.connectedComponentsWithStats
+ * (imageprocessing.py:248) plus the centroid numerators and the variance of the
+ * inter-frame delta over its bounding box (cliptracker.py:316-318). */
+typedef struct cpx_component {
+  int32_t x, y, width, height, area;
+  int32_t sum_x, sum_y;   /* centroid = (sum_x/area, sum_y/area) in float64 */
+  float pixel_variance;   /* np.var(delta_filtered[bbox]); 0 on a clip's first frame */
+} cpx_component;
+
+/* Per-frame scalars (cliptracker.py:93-122, clip.py:474-487, motiondetector.py:226). */
+typedef struct cpx_frame_info {
+  int32_t frame_number;     /* index among processed frames of the clip; -1 = skipped */
+  int32_t n_components;
+  int32_t status;           /* 0 ok, CPX_ERR_OVERFLOW */
+  int32_t ffc_affected;
+  int32_t avg_change;
+  int32_t norm_min, norm_max; /* min / max of the clipped, shifted frame */
+  float threshold;          /* mapped threshold handed to cv2.threshold */
+  int32_t filt_min, filt_max; /* min / max of thermal - background */
+  int32_t thermal_min, thermal_max;
+  uint32_t thermal_sum;     /* mean = thermal_sum / (W*H) */
+  float thermal_median;     /* np.median(thermal) */
+  uint64_t filtered_abs_sum;
+  double background_average; /* WeightedBackground.average after this frame's update */
+  int32_t background_changed;
+  int32_t reserved;
+} cpx_frame_info;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int cpx_abi_version(void);
+int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out);
+void cpx_destroy(cpx_handle* h);
+const char* cpx_last_error(const cpx_handle* h);
+/* HIP stream of the handle as an opaque pointer (hipStream_t). */
+void* cpx_stream(cpx_handle* h);
+int cpx_synchronize(cpx_handle* h);
+
+/* ---- track stage: background + filtered + threshold + CC + stats ---------
+ * Replaces, for a batch of B independent clips, the per-frame arithmetic of
+ *   ClipTrackExtractor.init_clip / _track_clip / process_frame
+ *                                  (track/cliptrackextractor.py:98-247)
+ *   ClipTracker._get_filtered_frame / get_delta_frame / np.var per region
+ *                                  (track/cliptracker.py:93-122,249-261,316-318)
+ *   detect_objects                 (ml_tools/imageprocessing.py:240-248)
+ *   WeightedBackground.process_frame (piclassifier/motiondetector.py:197-248)
+ *   ClipStats.add_frame            (track/clip.py:474-487)
+ *
+ * frames_dev        uint16 [total_frames, H, W]  every frame of every clip, file order
+ * clip_offsets      host   [B+1]   frame offsets of the clips inside frames_dev
+ * meta              host   [total_frames]
+ * comps_dev         [total_frames * max_components]   component lists (label order)
+ * info_dev          [total_frames]
+ * labels_dev        int32 [total_frames, H, W] or NULL  (Frame.mask)
+ * filtered_dev      float [total_frames, H, W] or NULL  (Frame.filtered)
+ * background_dev    float [B, H, W] or NULL: final background of every clip
+ * Asynchronous on the handle's stream; call cpx_synchronize before reading.
+ */
+int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
+                    const cpx_frame_meta* meta, int B, cpx_component* comps_dev,
+                    cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                    float* background_dev);
+
+/* Bytes of device workspace cpx_track_batch needs for B clips / total frames
+ * (allocated lazily inside the handle and reused). */
+size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames);
+
+/* Duration in ms of the frame kernel launches of the last cpx_track_batch
+ * (HIP events on the handle's stream; valid after cpx_synchronize) and their count. */
+int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPX_H */

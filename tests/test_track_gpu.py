@@ -1,0 +1,247 @@
+"""GPU parity tests of the track stage: HIP kernels (through the C-ABI) against
+(1) the vectors the reference itself produced for its fixture clips and
+(2) the oracle restatement on seeded synthetic clips.  Integer / label / index
+work is compared bit for bit; np.var (float32 in the reference) to 1e-4 rel."""
+import numpy as np
+import pytest
+
+from helpers import crc, load_clip, load_golden
+
+pytestmark = pytest.mark.gpu
+
+VAR_RTOL, VAR_ATOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from cpx.engine import TrackEngine
+
+    made = {}
+
+    def get(model, **kw):
+        key = (model, tuple(sorted(kw.items())))
+        if key not in made:
+            made[key] = TrackEngine(model=model or "lepton3", **kw)
+        return made[key]
+
+    yield get
+    for e in made.values():
+        e.close()
+
+
+def _run_fixture(engine, name, lengths=None):
+    frames, t_on, ffc, bgf, hdr = load_clip(name)
+    n = frames.shape[0]
+    lengths = lengths or [n]
+    offs = [0]
+    chunks, metas = [], []
+    for L in lengths:
+        chunks.append(frames[:L])
+        metas.append(engine.make_meta(L, t_on[:L], ffc[:L], bgf[:L]))
+        offs.append(offs[-1] + L)
+    dev = engine.upload_frames(np.concatenate(chunks))
+    res = engine.track_batch(dev, np.array(offs, np.int32), np.concatenate(metas), want_labels=True,
+                             want_filtered=True, want_background=True)
+    res.check()
+    return res, offs, bgf
+
+
+@pytest.mark.parametrize("name", ["possum", "hedgehog"])
+def test_fixture_clip_matches_reference_vectors(engines, name):
+    z, _ = load_golden(name, 0)
+    kept = [int(k) for k in z["kept"]]
+    frames, t_on, ffc, bgf, hdr = load_clip(name)
+    nb = int(np.sum(bgf))  # background frames precede the processed ones in the fixtures
+    # full clip + truncated copies: final background of each copy == reference background after that frame
+    lengths = [frames.shape[0]] + [k + 1 + nb for k in kept]
+    eng = engines(hdr.model)
+    res, offs, bgf = _run_fixture(eng, name, lengths)
+    info, labels, filt, bgs = res.info, res.labels(), res.filtered(), res.background()
+    proc = [i for i in range(lengths[0]) if not bgf[i]]
+    assert len(proc) == int(z["n_frames"])
+    for q, f in enumerate(proc):
+        fi = info[f]
+        assert fi["frame_number"] == q
+        assert bool(fi["ffc_affected"]) == bool(z["ffc"][q])
+        assert float(fi["threshold"]) == float(np.float32(z["threshold"][q])), q
+        assert fi["background_average"] == z["bg_after_avg"][q], q
+        assert crc(filt[f].astype(np.int32)) == z["crc_filtered"][q], q
+        assert crc(labels[f]) == z["crc_mask"][q], q
+        a, b = z["comp_offsets"][q], z["comp_offsets"][q + 1]
+        assert fi["n_components"] == b - a, q
+        c = res.components(f)
+        got = np.stack([c["x"], c["y"], c["width"], c["height"], c["area"]], axis=1).reshape(-1, 5)
+        assert np.array_equal(got, z["comp_stats"][a:b]), q
+        cent = np.stack([c["sum_x"] / c["area"], c["sum_y"] / c["area"]], axis=1).reshape(-1, 2)
+        assert np.array_equal(cent, z["comp_centroids"][a:b]), q
+    for f in range(lengths[0]):
+        if bgf[f]:
+            assert info[f]["frame_number"] == -1
+    # pixel_variance of the regions the reference kept (regions carry the component id)
+    for q, f in enumerate(proc):
+        a, b = z["region_offsets"][q], z["region_offsets"][q + 1]
+        c = res.components(f)
+        for r in z["regions"][a:b]:
+            cid = int(r[5])
+            assert (int(c["area"][cid]) == int(r[4]))
+            np.testing.assert_allclose(c["pixel_variance"][cid], r[6], rtol=VAR_RTOL, atol=VAR_ATOL)
+    # background after frame k (truncated copies) and after the last frame
+    for j, k in enumerate(kept):
+        assert np.array_equal(bgs[j + 1].astype(np.int32), z["kept_bg_after"][j]), k
+
+
+def _oracle_clip(frames, model, t_on=None, ffc=None, bgf=None):
+    import track_oracle as to
+
+    cfg = to.OracleConfig(model)
+    return to.track_clip(frames, t_on, ffc, bgf, cfg, keep=True, do_tracking=False), cfg
+
+
+def _compare_with_oracle(res, f0, out, frames_of_clip, bgf=None):
+    info, labels, filt = res.info, res.labels(), res.filtered()
+    q = 0
+    import track_oracle as to
+
+    prev = None
+    for i in range(frames_of_clip):
+        f = f0 + i
+        if bgf is not None and bgf[i]:
+            assert info[f]["frame_number"] == -1
+            continue
+        o = out["frames"][q]
+        fi = info[f]
+        assert fi["frame_number"] == q
+        assert fi["avg_change"] == o["avg_change"], (i, q)
+        assert float(fi["threshold"]) == float(np.float32(o["threshold"])), (i, q)
+        assert fi["norm_min"] == int(o["norm_min"]) and fi["norm_max"] == int(o["norm_max"])
+        assert fi["background_average"] == o["bg_after_avg"], (i, q)
+        assert np.array_equal(filt[f].astype(np.int32), o["filtered"]), (i, q)
+        assert np.array_equal(labels[f], o["mask"]), (i, q)
+        assert fi["n_components"] == o["n_components"]
+        c = res.components(f)
+        got = np.stack([c["x"], c["y"], c["width"], c["height"], c["area"]], axis=1).reshape(-1, 5)
+        assert np.array_equal(got, o["stats"]), (i, q)
+        if o["n_components"]:
+            cent = np.stack([c["sum_x"] / c["area"], c["sum_y"] / c["area"]], axis=1)
+            assert np.array_equal(cent, o["centroids"]), (i, q)
+        # np.var of the delta frame over every component's bounding box
+        if prev is not None and o["n_components"]:
+            delta = to.delta_frame(o["filtered"].astype(np.float64), prev.astype(np.float64))
+            for k in range(o["n_components"]):
+                x, y, w, h, _ = o["stats"][k]
+                want = np.var(delta[y:y + h, x:x + w])
+                np.testing.assert_allclose(c["pixel_variance"][k], want, rtol=VAR_RTOL, atol=VAR_ATOL)
+        elif o["n_components"]:
+            assert np.all(c["pixel_variance"] == 0)
+        prev = o["filtered"]
+        # ClipStats inputs
+        th = out["thermal"][q] if "thermal" in out else None
+        q += 1
+    return q
+
+
+@pytest.mark.parametrize("model", ["lepton3", "lepton3.5"])
+def test_synthetic_batch_matches_oracle(engines, model):
+    from cpx import synth
+
+    n_clips, T = 6, 64
+    frames, offs = synth.make_batch(n_clips, T, seed=1234, model=model)
+    eng = engines(model)
+    t_on, ffc = synth.frame_times(T)
+    meta = np.concatenate([eng.make_meta(T, t_on, ffc) for _ in range(n_clips)])
+    res = eng.track_batch(eng.upload_frames(frames), offs, meta, want_labels=True, want_filtered=True,
+                          want_background=True)
+    res.check()
+    bgs = res.background()
+    ncomp = 0
+    for b in range(n_clips):
+        clip = frames[offs[b]:offs[b + 1]]
+        out, _ = _oracle_clip(clip, model, t_on, ffc)
+        _compare_with_oracle(res, int(offs[b]), out, T)
+        assert np.array_equal(bgs[b].astype(np.int32), out["frames"][-1]["bg_after"])
+        ncomp += sum(f["n_components"] for f in out["frames"])
+        # thermal statistics (ClipStats.add_frame, clip.py:474-487)
+        for i in range(T):
+            fi = res.info[offs[b] + i]
+            assert fi["thermal_min"] == clip[i].min() and fi["thermal_max"] == clip[i].max()
+            assert fi["thermal_sum"] == int(clip[i].astype(np.int64).sum())
+            assert fi["filtered_abs_sum"] == int(np.abs(out["frames"][i]["filtered"].astype(np.int64)).sum())
+    assert ncomp > 0  # the comparison must have seen objects
+
+
+def test_ragged_batch_background_frames_and_ffc(engines):
+    """Clips of different lengths (1, 3, 50, 97 > window), background frames in
+    the stream, FFC-flagged frames: same results as the oracle per clip."""
+    from cpx import synth
+
+    rng = np.random.default_rng(7)
+    lens = [1, 3, 50, 97]
+    eng = engines("lepton3")
+    clips, metas, outs, offs = [], [], [], [0]
+    for n in lens:
+        clip = synth.make_clip(rng, n, model="lepton3")
+        t_on, ffc = synth.frame_times(n)
+        bgf = [False] * n
+        if n >= 3:
+            bgf[0] = True  # leading background frame (as in possum.cptv)
+        if n >= 50:
+            bgf[10] = True  # and one in the middle of the stream
+            ffc = list(ffc)
+            ffc[20] = t_on[20] - 5  # frames 20: (time_on - last_ffc) < 9 -> ffc affected
+        clips.append(clip)
+        metas.append(eng.make_meta(n, t_on, ffc, bgf))
+        outs.append((_oracle_clip(clip, "lepton3", t_on, ffc, bgf)[0], bgf))
+        offs.append(offs[-1] + n)
+    res = eng.track_batch(eng.upload_frames(np.concatenate(clips)), np.array(offs, np.int32),
+                          np.concatenate(metas), want_labels=True, want_filtered=True, want_background=True)
+    res.check()
+    for b, n in enumerate(lens):
+        out, bgf = outs[b]
+        nq = _compare_with_oracle(res, offs[b], out, n, bgf)
+        assert nq == len(out["frames"])
+        if nq:
+            assert np.array_equal(res.background()[b].astype(np.int32), out["frames"][-1]["bg_after"])
+        flags = [bool(res.info[offs[b] + i]["ffc_affected"]) for i in range(n) if not bgf[i]]
+        assert flags == [f["ffc"] for f in out["frames"]]
+
+
+def test_degenerate_frames(engines):
+    """Constant frames (max == min paths of normalize), a saturated frame and a
+    checkerboard that overflows the component capacity (error, never truncation)."""
+    from cpx._lib import CpxError
+
+    eng = engines("lepton3")
+    H, W = 120, 160
+    const = np.full((4, H, W), 3000, np.uint16)
+    const[2] += 7  # uniform jump: x - avg_change == 0 everywhere
+    const[3, 40:60, 50:90] = 65535  # saturated block
+    out, _ = _oracle_clip(const, "lepton3")
+    res = eng.track_batch(eng.upload_frames(const), np.array([0, 4], np.int32), eng.make_meta(4),
+                          want_labels=True, want_filtered=True)
+    res.check()
+    _compare_with_oracle(res, 0, out, 4)
+    # 2x2-block checkerboard of hot pixels far above threshold -> thousands of components
+    cb = np.full((2, H, W), 3000, np.uint16)
+    cb[1, 4:116:6, 4:156:6] = 9000
+    res = eng.track_batch(eng.upload_frames(cb), np.array([0, 2], np.int32), eng.make_meta(2), want_labels=True)
+    n = int(res.info[1]["n_components"])
+    out, _ = _oracle_clip(cb, "lepton3")
+    assert n == out["frames"][1]["n_components"]
+    if n > eng.cap:
+        with pytest.raises(CpxError):
+            res.check()
+
+
+def test_no_optional_outputs_same_components(engines):
+    """labels / filtered outputs off (state ping-pong path) gives identical components."""
+    from cpx import synth
+
+    frames, offs = synth.make_batch(3, 40, seed=99)
+    eng = engines("lepton3")
+    meta = eng.make_meta(frames.shape[0])
+    dev = eng.upload_frames(frames)
+    full = eng.track_batch(dev, offs, meta, want_labels=True, want_filtered=True)
+    lean = eng.track_batch(dev, offs, meta)
+    assert np.array_equal(full.info, lean.info)
+    for f in range(frames.shape[0]):
+        assert np.array_equal(full.components(f), lean.components(f))
