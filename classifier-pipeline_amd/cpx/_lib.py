@@ -73,6 +73,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libcpx_hip.so not built: run `python __graft_entry__.py` (or make -C classifier-pipeline_amd/csrc)")
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime of the
+    # process (two runtimes cannot share the device), so load torch before us.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pure ctypes use without torch: the system runtime is fine
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
     lib.cpx_abi_version.restype = C.c_int

@@ -643,7 +643,8 @@ def track_clip(frames, time_on=None, last_ffc=None, background_flags=None, cfg=N
             else:
                 delta = delta_frame(filtered, prev_filtered)
                 regions = regions_of_interest(stats[1:], cents[1:], delta, cur, cfg, crop)
-                apply_matchings(state, regions)
+                if do_tracking != "regions":  # "regions": pixel stage + region lists only
+                    apply_matchings(state, regions)
             region_history.append(regions)
         prev_filtered = filtered
         window.append(thermal)
@@ -664,7 +665,7 @@ def track_clip(frames, time_on=None, last_ffc=None, background_flags=None, cfg=N
             # keep memory bounded: callers that want images pass keep=True
             pass
         out["frames"].append(rec)
-    if do_tracking:
+    if do_tracking and do_tracking != "regions":
         filter_tracks(state)
     out["tracks"] = state["tracks"]
     out["filtered_tracks"] = state["filtered"]
