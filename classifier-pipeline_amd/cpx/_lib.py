@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpx_hip.so")
+LIB_PATH = os.environ.get("CPX_LIB") or os.path.join(_HERE, "libcpx_hip.so")  # CPX_LIB: tuning builds only
 
 CPX_OK = 0
 STATUS = {

@@ -15,7 +15,10 @@
 #define CPX_TRACK_CHUNKS 5  // 4-pixel chunks per thread: W*H <= 4*5*1024 = 20480
 #endif
 #ifndef CPX_TRACK_LDS_COMPONENTS
-#define CPX_TRACK_LDS_COMPONENTS 512
+#define CPX_TRACK_LDS_COMPONENTS 256
+#endif
+#ifndef CPX_TRACK_MIN_WAVES_PER_SIMD
+#define CPX_TRACK_MIN_WAVES_PER_SIMD 8  // __launch_bounds__ 2nd argument (waves per SIMD)
 #endif
 
 namespace cpx {

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a) {
 // ---------------------------------------------------------------------------
 // one processed frame of every clip
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void cpx_frame_kernel(TrackArgs a, int t) {
+__global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_kernel(TrackArgs a, int t) {
   const int b = blockIdx.x;
   const int pbase = a.proc_off[b];
   const int nproc = a.proc_off[b + 1] - pbase;
