@@ -58,7 +58,7 @@ assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FR
 
 EXPORTS = [
     "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
-    "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing",
+    "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
 ]
 
 _lib = None
@@ -94,6 +94,8 @@ def load():
     lib.cpx_synchronize.restype = C.c_int
     lib.cpx_track_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp]
     lib.cpx_track_batch.restype = C.c_int
+    lib.cpx_associate_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cpx_associate_batch.restype = C.c_int
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]

@@ -7,6 +7,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import COMPONENT_DTYPE, FRAME_INFO_DTYPE, FRAME_META_DTYPE, CpxError
+from .tracking import REGION_DTYPE, TRACK_RECORD_DTYPE, make_track_params, track_regions
 
 
 def thresholds_for_model(model):
@@ -61,6 +62,50 @@ class TrackBatchResult:
     def background(self):
         self.engine.synchronize()
         return None if self.background_dev is None else self.background_dev.cpu().numpy()
+
+
+class AssocBatchResult:
+    """Outputs of cpx_associate_batch: every track ever created per clip (untrimmed,
+    unfiltered -- the end-of-clip statistics are host work) + per-frame region lists."""
+
+    def __init__(self, engine, offs, params, pool, tracks, ntracks, status, regions, rcounts):
+        self.engine, self.offs, self.params = engine, offs, params
+        self.pool_dev, self.tracks_dev, self.ntracks_dev, self.status_dev = pool, tracks, ntracks, status
+        self.regions_dev, self.rcounts_dev = regions, rcounts
+        self._host = None
+
+    def _fetch(self):
+        if self._host is None:
+            self.engine.synchronize()
+            ma, mt = self.params.max_active_tracks, self.params.max_tracks
+            pool = self.pool_dev.cpu().numpy().view(REGION_DTYPE).reshape(-1, ma)
+            tracks = self.tracks_dev.cpu().numpy().view(TRACK_RECORD_DTYPE).reshape(-1, mt)
+            ntr = self.ntracks_dev.cpu().numpy()
+            status = self.status_dev.cpu().numpy()
+            regions = rc = None
+            if self.regions_dev is not None:
+                regions = self.regions_dev.cpu().numpy().view(REGION_DTYPE).reshape(-1, self.engine.cap)
+                rc = self.rcounts_dev.cpu().numpy()
+            self._host = (pool, tracks, ntr, status, regions, rc)
+        return self._host
+
+    def check(self):
+        status = self._fetch()[3]
+        bad = np.nonzero(status != 0)[0]
+        if bad.size:
+            raise CpxError(int(status[bad[0]]), "clip %d: track capacity exceeded" % int(bad[0]))
+
+    def clip_tracks(self, b):
+        """-> list of (track_record, regions[n_frames]) for clip b, in creation (id) order."""
+        pool, tracks, ntr, _, _, _ = self._fetch()
+        ma = self.params.max_active_tracks
+        f0, f1 = int(self.offs[b]), int(self.offs[b + 1])
+        cpool = pool[f0:f1].reshape(-1)
+        return [(tracks[b, i], track_regions(cpool, tracks[b, i], ma)) for i in range(int(ntr[b]))]
+
+    def frame_regions(self, f):
+        _, _, _, _, regions, rc = self._fetch()
+        return regions[f, : int(rc[f])]
 
 
 class TrackEngine:
@@ -150,6 +195,33 @@ class TrackEngine:
         if rc != 0:
             raise CpxError(rc, self._err())
         return TrackBatchResult(self, total, self.cap, comps, info, labels, filt, bgo)
+
+    def associate_batch(self, track_result, clip_offsets, meta, params=None, want_regions=True):
+        """Region filter + matching + Kalman for the clips of a track_batch result."""
+        t = self.torch
+        offs = np.ascontiguousarray(clip_offsets, dtype=np.int32)
+        B = offs.size - 1
+        total = int(offs[-1])
+        meta = np.ascontiguousarray(meta, dtype=FRAME_META_DTYPE)
+        params = params or make_track_params(self.width, self.height, self.cfg.edge_pixels)
+        ma, mt = params.max_active_tracks, params.max_tracks
+        pool = t.zeros(total * ma * 14, dtype=t.int32, device=self.device)
+        tracks = t.zeros(B * mt * 8, dtype=t.int32, device=self.device)
+        ntr = t.zeros(B, dtype=t.int32, device=self.device)
+        status = t.zeros(B, dtype=t.int32, device=self.device)
+        regions = t.zeros(total * self.cap * 14, dtype=t.int32, device=self.device) if want_regions else None
+        rcounts = t.zeros(total, dtype=t.int32, device=self.device) if want_regions else None
+        t.cuda.current_stream(self.device).synchronize()
+        rc = self.lib.cpx_associate_batch(
+            self.h, C.byref(params), offs.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(meta.ctypes.data), B,
+            C.c_void_p(track_result.comps_dev.data_ptr()), C.c_void_p(track_result.info_dev.data_ptr()),
+            C.c_void_p(pool.data_ptr()), C.c_void_p(tracks.data_ptr()), C.c_void_p(ntr.data_ptr()),
+            C.c_void_p(status.data_ptr()),
+            C.c_void_p(regions.data_ptr() if regions is not None else None),
+            C.c_void_p(rcounts.data_ptr() if rcounts is not None else None))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        return AssocBatchResult(self, offs, params, pool, tracks, ntr, status, regions, rcounts)
 
     def last_kernel_timing(self):
         ms = C.c_float()

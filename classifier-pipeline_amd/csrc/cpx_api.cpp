@@ -27,6 +27,8 @@ struct cpx_handle {
   // small device arrays for the schedule
   int* sched_dev = nullptr;
   size_t sched_ints = 0;
+  void* ws_assoc = nullptr;
+  size_t ws_assoc_bytes = 0;
   // timing of the last batch
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int last_launches = 0;
@@ -37,6 +39,9 @@ static_assert(sizeof(cpx_component) == 32, "cpx_component layout is part of the 
 static_assert(sizeof(cpx_frame_info) == 80, "cpx_frame_info layout is part of the ABI");
 static_assert(sizeof(cpx_frame_meta) == 24, "cpx_frame_meta layout is part of the ABI");
 static_assert(sizeof(cpx_config) == 40, "cpx_config layout is part of the ABI");
+static_assert(sizeof(cpx_region) == 56, "cpx_region layout is part of the ABI");
+static_assert(sizeof(cpx_track_record) == 32, "cpx_track_record layout is part of the ABI");
+static_assert(sizeof(cpx_track_params) == 120, "cpx_track_params layout is part of the ABI");
 
 namespace {
 
@@ -79,6 +84,60 @@ WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
   off = align_up(off + (size_t)B * sizeof(cpx::ClipState), 256);
   l.total = off;
   return l;
+}
+
+struct Schedule {
+  std::vector<int> clip_first, proc_off, proc_idx, proc_ffc;
+  int total = 0, max_proc = 0;
+};
+
+// which frames are processed (background frames only initialise, cliptrackextractor.py:167-168)
+// and their FFC flags (cptvmotiondetector.py:211-223 with int milliseconds)
+int build_schedule(cpx_handle* h, const int32_t* clip_offsets, const cpx_frame_meta* meta, int B, Schedule* sc) {
+  sc->total = clip_offsets[B];
+  sc->clip_first.resize(B);
+  sc->proc_off.assign(B + 1, 0);
+  sc->proc_idx.reserve(sc->total);
+  sc->proc_ffc.reserve(sc->total);
+  for (int b = 0; b < B; ++b) {
+    const int f0 = clip_offsets[b], f1 = clip_offsets[b + 1];
+    if (f1 <= f0) return fail(h, CPX_ERR_INVALID, "empty clip in batch");
+    sc->clip_first[b] = f0;
+    for (int f = f0; f < f1; ++f) {
+      if (meta[f].background_frame) continue;
+      sc->proc_idx.push_back(f);
+      int ffc = 0;
+      if (meta[f].has_times) ffc = (meta[f].time_on_ms - meta[f].last_ffc_ms) < 9 ? 1 : 0;
+      sc->proc_ffc.push_back(ffc);
+    }
+    sc->proc_off[b + 1] = (int)sc->proc_idx.size();
+    const int np = sc->proc_off[b + 1] - sc->proc_off[b];
+    if (np > h->cfg.max_frames) return fail(h, CPX_ERR_INVALID, "clip longer than max_frames");
+    sc->max_proc = std::max(sc->max_proc, np);
+  }
+  return CPX_OK;
+}
+
+// layout in sched_dev: clip_first[B] | proc_off[B+1] | proc_idx[n] | proc_ffc[n]
+int upload_schedule(cpx_handle* h, const Schedule& sc, int B) {
+  const int n = std::max((int)sc.proc_idx.size(), 1);
+  const size_t ints = (size_t)B + (B + 1) + 2 * (size_t)n;
+  if (ints > h->sched_ints) {
+    if (h->sched_dev) hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+    h->sched_ints = 0;
+    hipError_t e = hipMalloc((void**)&h->sched_dev, ints * sizeof(int));
+    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "schedule hipMalloc", e);
+    h->sched_ints = ints;
+  }
+  std::vector<int> flat(ints, 0);
+  std::copy(sc.clip_first.begin(), sc.clip_first.end(), flat.begin());
+  std::copy(sc.proc_off.begin(), sc.proc_off.end(), flat.begin() + B);
+  std::copy(sc.proc_idx.begin(), sc.proc_idx.end(), flat.begin() + B + (B + 1));
+  std::copy(sc.proc_ffc.begin(), sc.proc_ffc.end(), flat.begin() + B + (B + 1) + n);
+  CPX_HIP(h, hipMemcpyAsync(h->sched_dev, flat.data(), ints * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  CPX_HIP(h, hipStreamSynchronize(h->stream));  // `flat` dies with this scope
+  return CPX_OK;
 }
 
 }  // namespace
@@ -134,6 +193,7 @@ void cpx_destroy(cpx_handle* h) {
   if (h->ws) hipFree(h->ws);
   if (h->wtab_dev) hipFree(h->wtab_dev);
   if (h->sched_dev) hipFree(h->sched_dev);
+  if (h->ws_assoc) hipFree(h->ws_assoc);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -165,29 +225,10 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
     return fail(h, CPX_ERR_INVALID, "cpx_track_batch: null argument");
   CPX_HIP(h, hipSetDevice(h->device));
   const cpx_config& c = h->cfg;
-  // ---- schedule: which frames are processed, FFC flags (cptvmotiondetector.py:211-223) ----
-  const int total = clip_offsets[B];
-  std::vector<int> clip_first(B), proc_off(B + 1, 0), proc_idx, proc_ffc;
-  proc_idx.reserve(total);
-  proc_ffc.reserve(total);
-  int max_proc = 0;
-  for (int b = 0; b < B; ++b) {
-    const int f0 = clip_offsets[b], f1 = clip_offsets[b + 1];
-    if (f1 <= f0) return fail(h, CPX_ERR_INVALID, "cpx_track_batch: empty clip");
-    clip_first[b] = f0;
-    for (int f = f0; f < f1; ++f) {
-      if (meta[f].background_frame) continue;  // cliptrackextractor.py:167-168
-      proc_idx.push_back(f);
-      int ffc = 0;
-      if (meta[f].has_times) ffc = (meta[f].time_on_ms - meta[f].last_ffc_ms) < 9 ? 1 : 0;  // int-ms quirk, SURVEY F5
-      proc_ffc.push_back(ffc);
-    }
-    proc_off[b + 1] = (int)proc_idx.size();
-    const int np = proc_off[b + 1] - proc_off[b];
-    if (np > c.max_frames) return fail(h, CPX_ERR_INVALID, "cpx_track_batch: clip longer than max_frames");
-    max_proc = std::max(max_proc, np);
-  }
-  const int nproc_total = (int)proc_idx.size();
+  Schedule sc;
+  int rc = build_schedule(h, clip_offsets, meta, B, &sc);
+  if (rc != CPX_OK) return rc;
+  const int total = sc.total, max_proc = sc.max_proc;
   // ---- device workspace ----
   const bool need_filt = (filtered_dev == nullptr);
   const WsLayout l = ws_layout(c, B, need_filt);
@@ -199,22 +240,9 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
     if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "workspace hipMalloc", e);
     h->ws_bytes = l.total;
   }
-  const size_t sched_ints = (size_t)B + (B + 1) + 2 * (size_t)std::max(nproc_total, 1);
-  if (sched_ints > h->sched_ints) {
-    if (h->sched_dev) hipFree(h->sched_dev);
-    h->sched_dev = nullptr;
-    h->sched_ints = 0;
-    hipError_t e = hipMalloc((void**)&h->sched_dev, sched_ints * sizeof(int));
-    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "schedule hipMalloc", e);
-    h->sched_ints = sched_ints;
-  }
-  std::vector<int> sched(sched_ints, 0);
-  std::copy(clip_first.begin(), clip_first.end(), sched.begin());
-  std::copy(proc_off.begin(), proc_off.end(), sched.begin() + B);
-  std::copy(proc_idx.begin(), proc_idx.end(), sched.begin() + B + (B + 1));
-  std::copy(proc_ffc.begin(), proc_ffc.end(), sched.begin() + B + (B + 1) + std::max(nproc_total, 1));
-  CPX_HIP(h, hipMemcpyAsync(h->sched_dev, sched.data(), sched_ints * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  CPX_HIP(h, hipStreamSynchronize(h->stream));  // `sched` is a stack-lifetime buffer
+  rc = upload_schedule(h, sc, B);
+  if (rc != CPX_OK) return rc;
+  const int nproc_total = (int)sc.proc_idx.size();
 
   cpx::TrackArgs a{};
   a.W = c.width;
@@ -249,6 +277,68 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
   h->last_launches = max_proc;
   h->timing_valid = true;
   if (background_dev) cpx::launch_export_background(a, B, background_dev, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int32_t* clip_offsets,
+                        const cpx_frame_meta* meta, int B, const cpx_component* comps_dev,
+                        const cpx_frame_info* info_dev, cpx_region* pool_dev,
+                        cpx_track_record* tracks_dev, int32_t* n_tracks_dev, int32_t* status_dev,
+                        cpx_region* regions_dev, int32_t* region_counts_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!params || !clip_offsets || !meta || B <= 0 || !comps_dev || !info_dev || !pool_dev || !tracks_dev ||
+      !n_tracks_dev || !status_dev)
+    return fail(h, CPX_ERR_INVALID, "cpx_associate_batch: null argument");
+  if (params->max_active_tracks < 1 || params->max_tracks < 1)
+    return fail(h, CPX_ERR_INVALID, "cpx_associate_batch: capacities must be positive");
+  CPX_HIP(h, hipSetDevice(h->device));
+  Schedule sc;
+  int rc = build_schedule(h, clip_offsets, meta, B, &sc);
+  if (rc != CPX_OK) return rc;
+  rc = upload_schedule(h, sc, B);
+  if (rc != CPX_OK) return rc;
+  const int n = std::max((int)sc.proc_idx.size(), 1);
+  const int cap = h->cfg.max_components, ma = params->max_active_tracks;
+  size_t off = 0;
+  const size_t o_active = off;
+  off = align_up(off + (size_t)B * ma * cpx::assoc_active_bytes(), 256);
+  const size_t o_regs = off;
+  off = align_up(off + (size_t)B * cap * sizeof(cpx_region), 256);
+  const size_t o_scores = off;
+  off = align_up(off + (size_t)B * cap * ma * cpx::assoc_score_bytes(), 256);
+  const size_t o_used = off;
+  off = align_up(off + (size_t)B * cap, 256);
+  if (off > h->ws_assoc_bytes) {
+    if (h->ws_assoc) hipFree(h->ws_assoc);
+    h->ws_assoc = nullptr;
+    h->ws_assoc_bytes = 0;
+    hipError_t e = hipMalloc(&h->ws_assoc, off);
+    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "association workspace hipMalloc", e);
+    h->ws_assoc_bytes = off;
+  }
+  char* base = (char*)h->ws_assoc;
+  cpx::AssocArgs a{};
+  a.B = B;
+  a.cap = cap;
+  a.params = *params;
+  a.clip_first = h->sched_dev;
+  a.proc_off = h->sched_dev + B;
+  a.proc_idx = h->sched_dev + B + (B + 1);
+  a.proc_ffc = h->sched_dev + B + (B + 1) + n;
+  a.comps = comps_dev;
+  a.info = info_dev;
+  a.pool = pool_dev;
+  a.tracks = tracks_dev;
+  a.n_tracks = n_tracks_dev;
+  a.status = status_dev;
+  a.regions_out = regions_dev;
+  a.region_counts = region_counts_dev;
+  a.active = (cpx::ActiveTrack*)(base + o_active);
+  a.regs = (cpx_region*)(base + o_regs);
+  a.scores = (cpx::ScoreRec*)(base + o_scores);
+  a.used = (unsigned char*)(base + o_used);
+  cpx::launch_assoc(a, h->stream);
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
 }

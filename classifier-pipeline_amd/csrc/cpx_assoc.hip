@@ -1,0 +1,60 @@
+// cpx_assoc.hip -- association stage: one GPU lane per clip walks the clip's
+// processed frames in order (the work is scalar and sequential inside a clip,
+// embarrassingly parallel across clips).  The arithmetic lives in
+// cpx_assoc_core.h.
+#include <hip/hip_runtime.h>
+
+#include "cpx_assoc_core.h"
+#include "cpx_kernels.h"
+
+namespace cpx {
+
+__global__ __launch_bounds__(64) void cpx_assoc_kernel(AssocArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int pbase = a.proc_off[b];
+  const int nproc = a.proc_off[b + 1] - pbase;
+  const int first = a.clip_first[b];
+  AssocClip c;
+  c.p = &a.params;
+  c.cap = a.cap;
+  c.max_active = a.params.max_active_tracks;
+  c.max_tracks = a.params.max_tracks;
+  c.pool = a.pool + (size_t)first * c.max_active;
+  c.active = a.active + (size_t)b * c.max_active;
+  c.n_active = 0;
+  c.tracks = a.tracks + (size_t)b * c.max_tracks;
+  c.n_tracks = 0;
+  c.next_id = 1;  // Track._track_id is reset per Clip (clip.py:57-59)
+  c.regs = a.regs + (size_t)b * a.cap;
+  c.scores = a.scores + (size_t)b * a.cap * c.max_active;
+  c.used = a.used + (size_t)b * a.cap;
+  c.status = 0;
+  for (int t = 0; t < nproc; ++t) {
+    const int fidx = a.proc_idx[pbase + t];
+    const cpx_frame_info& fi = a.info[fidx];
+    int nreg = 0;
+    if (a.proc_ffc[pbase + t]) {
+      c.n_active = 0;  // cliptrackextractor.py:239-240
+    } else {
+      if (fi.status != 0) c.status = fi.status;
+      const int ncomp = fi.status == 0 ? fi.n_components : 0;
+      nreg = build_regions(c, a.comps + (size_t)fidx * a.cap, ncomp, t, t > 0);
+      if (a.regions_out)
+        for (int i = 0; i < nreg; ++i) a.regions_out[(size_t)fidx * a.cap + i] = c.regs[i];
+      assoc_frame(c, nreg, t);
+    }
+    if (a.region_counts) a.region_counts[fidx] = nreg;
+  }
+  a.n_tracks[b] = c.n_tracks;
+  a.status[b] = c.status;
+}
+
+size_t assoc_active_bytes() { return sizeof(ActiveTrack); }
+size_t assoc_score_bytes() { return sizeof(ScoreRec); }
+
+void launch_assoc(const AssocArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_assoc_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+}
+
+}  // namespace cpx

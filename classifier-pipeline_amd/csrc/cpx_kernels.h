@@ -57,6 +57,33 @@ struct TrackArgs {
   float* filtered_out;      // [total_frames, P] or nullptr
 };
 
+struct ActiveTrack;
+struct ScoreRec;
+struct AssocArgs {
+  int B, cap;
+  cpx_track_params params;
+  const int* clip_first;
+  const int* proc_off;
+  const int* proc_idx;
+  const int* proc_ffc;
+  const Component* comps;  // [total_frames * cap]
+  const FrameInfo* info;   // [total_frames]
+  cpx_region* pool;        // [total_frames * max_active]
+  cpx_track_record* tracks;  // [B * max_tracks]
+  int* n_tracks;           // [B]
+  int* status;             // [B]
+  cpx_region* regions_out; // [total_frames * cap] or nullptr
+  int* region_counts;      // [total_frames] or nullptr
+  // scratch
+  ActiveTrack* active;     // [B * max_active]
+  cpx_region* regs;        // [B * cap]
+  ScoreRec* scores;        // [B * cap * max_active]
+  unsigned char* used;     // [B * cap]
+};
+void launch_assoc(const AssocArgs& a, hipStream_t s);
+size_t assoc_active_bytes();
+size_t assoc_score_bytes();
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

@@ -89,6 +89,45 @@ typedef struct cpx_frame_info {
   int32_t reserved;
 } cpx_frame_info;
 
+/* One entry of Track.bounds_history / clip.region_history (track/region.py:27-42). */
+#define CPX_REGION_BLANK 1         /* Region.blank */
+#define CPX_REGION_CROPPED 2       /* Region.was_cropped */
+#define CPX_REGION_BORDER 4        /* Region.is_along_border */
+#define CPX_REGION_CENTROID_F32 8  /* centroid came from the float32 Kalman prediction */
+typedef struct cpx_region {
+  int32_t x, y, width, height;
+  int32_t mass;
+  int32_t frame_number;
+  float pixel_variance;
+  int32_t flags;
+  double cx, cy; /* centroid */
+  int32_t id;    /* component index the region came from (Region.id) */
+  int32_t pad;
+} cpx_region;
+
+/* One Track (track/track.py:372): its regions are pool[(start_frame + i) * max_active_tracks + slot],
+ * i in [0, n_frames), relative to the clip's first pool row. */
+typedef struct cpx_track_record {
+  int32_t id, slot, start_frame, n_frames;
+  int32_t blank_frames, since_seen, rt_frames; /* RegionTracker counters (track.py:65-75) */
+  int32_t track_index;
+} cpx_track_record;
+
+/* Region filter + RegionTracker parameters (config/trackingconfig.py:126-177). */
+typedef struct cpx_track_params {
+  int32_t crop_x, crop_y, crop_w, crop_h; /* clip.crop_rectangle (clip.py:396-400) */
+  int32_t frame_padding, min_dimension;
+  int32_t cropped_regions_strategy; /* 0 "cautious", 1 "none", 2 "all" */
+  int32_t filter_regions_pre_match;
+  double aoi_min_mass, aoi_pixel_variance;
+  double base_distance_change, min_mass_change, restrict_mass_after, mass_change_percent;
+  double velocity_multiplier, base_velocity;
+  int32_t has_min_mass_change, has_mass_change_percent; /* 0: the Python value is None */
+  int32_t max_blanks, fps;
+  int32_t max_active_tracks; /* pool slots per frame */
+  int32_t max_tracks;        /* track records per clip */
+} cpx_track_params;
+
 /* ---- lifetime ---------------------------------------------------------- */
 int cpx_abi_version(void);
 int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out);
@@ -122,6 +161,24 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
                     const cpx_frame_meta* meta, int B, cpx_component* comps_dev,
                     cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
                     float* background_dev);
+
+/* ---- association stage: region filter + track matching + Kalman ------------
+ * Replaces, for the same batch, one GPU lane per clip,
+ *   ClipTracker._get_regions_of_interest      (track/cliptracker.py:263-365)
+ *   ClipTracker._apply_region_matchings etc.  (track/cliptracker.py:124-247)
+ *   RegionTracker / Track bookkeeping, Kalman (track/track.py:107-326,646-735; track/kalman.py)
+ * Inputs are the outputs of cpx_track_batch (same clip_offsets / meta).
+ * pool_dev     cpx_region [total_frames * max_active_tracks]  track histories
+ * tracks_dev   cpx_track_record [B * max_tracks], n_tracks_dev int32 [B]
+ * status_dev   int32 [B]: 0 or CPX_ERR_OVERFLOW (more simultaneous / total tracks than capacity)
+ * regions_dev  cpx_region [total_frames * max_components] or NULL (clip.region_history),
+ * region_counts_dev int32 [total_frames] or NULL
+ */
+int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int32_t* clip_offsets,
+                        const cpx_frame_meta* meta, int B, const cpx_component* comps_dev,
+                        const cpx_frame_info* info_dev, cpx_region* pool_dev,
+                        cpx_track_record* tracks_dev, int32_t* n_tracks_dev, int32_t* status_dev,
+                        cpx_region* regions_dev, int32_t* region_counts_dev);
 
 /* Bytes of device workspace cpx_track_batch needs for B clips / total frames
  * (allocated lazily inside the handle and reused). */

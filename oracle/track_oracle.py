@@ -350,8 +350,9 @@ class Track:
         kalman_amount = self.rt_frames - Track.MIN_KALMAN_FRAMES - self.since_seen * 2
         if kalman_amount > 0:
             r = Region(
-                int(self.predicted_mid[0] - last.width / 2.0),
-                int(self.predicted_mid[1] - last.height / 2.0),
+                # the reference's widths are np.int32, so this is float64 arithmetic there
+                int(np.float64(self.predicted_mid[0]) - last.width / 2.0),
+                int(np.float64(self.predicted_mid[1]) - last.height / 2.0),
                 last.width, last.height,
                 centroid=[self.predicted_mid[0], self.predicted_mid[1]],
             )
@@ -605,7 +606,7 @@ def filter_tracks(state):
 
 
 def track_clip(frames, time_on=None, last_ffc=None, background_flags=None, cfg=None,
-               keep=False, do_tracking=True):
+               keep=False, do_tracking=True, apply_filter=True):
     """frames: uint16 [N,H,W] -- every frame of the file in order (the first one
     initialises the background even when it is a background frame,
     cliptrackextractor.py:129-139).  Returns a dict of per-frame results."""
@@ -665,7 +666,7 @@ def track_clip(frames, time_on=None, last_ffc=None, background_flags=None, cfg=N
             # keep memory bounded: callers that want images pass keep=True
             pass
         out["frames"].append(rec)
-    if do_tracking and do_tracking != "regions":
+    if do_tracking and do_tracking != "regions" and apply_filter:
         filter_tracks(state)
     out["tracks"] = state["tracks"]
     out["filtered_tracks"] = state["filtered"]

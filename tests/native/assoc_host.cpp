@@ -1,0 +1,45 @@
+// TEST INFRASTRUCTURE ONLY: host build of classifier-pipeline_amd/csrc/cpx_assoc_core.h so
+// that the association logic can be debugged against the oracle without a GPU
+// (tests/test_assoc_host.py).  The product never loads this; it runs the HIP
+// build of the same header (cpx_assoc.hip).
+#include <vector>
+
+#include "cpx_assoc_core.h"
+
+extern "C" int assoc_host_clip(const cpx_track_params* p, int cap, int nproc, const int* ffc, const int* ncomp,
+                               const cpx_component* comps, cpx_region* pool, cpx_track_record* tracks,
+                               int* n_tracks, cpx_region* regions_out, int* region_counts) {
+  using namespace cpx;
+  std::vector<ActiveTrack> active(p->max_active_tracks);
+  std::vector<RegionRec> regs(cap);
+  std::vector<ScoreRec> scores((size_t)cap * p->max_active_tracks);
+  std::vector<unsigned char> used(cap);
+  AssocClip c;
+  c.p = p;
+  c.cap = cap;
+  c.max_active = p->max_active_tracks;
+  c.max_tracks = p->max_tracks;
+  c.pool = pool;
+  c.active = active.data();
+  c.n_active = 0;
+  c.tracks = tracks;
+  c.n_tracks = 0;
+  c.next_id = 1;
+  c.regs = regs.data();
+  c.scores = scores.data();
+  c.used = used.data();
+  c.status = 0;
+  for (int t = 0; t < nproc; ++t) {
+    int nreg = 0;
+    if (ffc[t]) {
+      c.n_active = 0;
+    } else {
+      nreg = build_regions(c, comps + (size_t)t * cap, ncomp[t], t, t > 0);
+      for (int i = 0; i < nreg; ++i) regions_out[(size_t)t * cap + i] = c.regs[i];
+      assoc_frame(c, nreg, t);
+    }
+    region_counts[t] = nreg;
+  }
+  *n_tracks = c.n_tracks;
+  return c.status;
+}

@@ -245,3 +245,82 @@ def test_no_optional_outputs_same_components(engines):
     assert np.array_equal(full.info, lean.info)
     for f in range(frames.shape[0]):
         assert np.array_equal(full.components(f), lean.components(f))
+
+
+# ---------------------------------------------------------------------------
+# association stage (one GPU lane per clip) against the oracle's tracker
+# ---------------------------------------------------------------------------
+def _compare_assoc(assoc, b, out, f0, proc_frames):
+    from cpx.tracking import REGION_BLANK, REGION_BORDER, REGION_CROPPED
+
+    for q, f in enumerate(proc_frames):
+        regs = out["region_history"][q]
+        got = assoc.frame_regions(f0 + f)
+        assert len(got) == len(regs), (b, q)
+        for g, r in zip(got, regs):
+            assert (g["x"], g["y"], g["width"], g["height"], g["mass"], g["id"]) == (
+                r.x, r.y, r.width, r.height, int(r.mass), r.id), (b, q)
+            assert bool(g["flags"] & REGION_CROPPED) == r.was_cropped
+            assert bool(g["flags"] & REGION_BORDER) == r.is_along_border
+            assert g["cx"] == float(r.centroid[0]) and g["cy"] == float(r.centroid[1])
+            np.testing.assert_allclose(g["pixel_variance"], float(r.pixel_variance), rtol=VAR_RTOL, atol=VAR_ATOL)
+    want = sorted(out["tracks"] + [t for _, t in out.get("filtered_tracks", [])], key=lambda t: t.id)
+    tr = assoc.clip_tracks(b)
+    assert len(tr) == len(want), b
+    nblank = 0
+    for (rec, regs), w in zip(tr, want):
+        assert (rec["id"], rec["start_frame"], rec["n_frames"]) == (w.id, w.start_frame, len(w.bounds)), (b, w.id)
+        assert (rec["blank_frames"], rec["since_seen"], rec["rt_frames"]) == (w.blank_frames, w.since_seen, w.rt_frames)
+        for g, r in zip(regs, w.bounds):
+            assert (g["x"], g["y"], g["width"], g["height"], g["mass"], g["frame_number"]) == (
+                r.x, r.y, r.width, r.height, int(r.mass), r.frame_number), (b, w.id, r.frame_number)
+            assert bool(g["flags"] & REGION_BLANK) == r.blank
+            assert g["cx"] == float(r.centroid[0]) and g["cy"] == float(r.centroid[1]), (b, w.id, r.frame_number)
+            nblank += int(r.blank)
+    return len(tr), nblank
+
+
+def test_association_matches_oracle_on_fixture_clips(engines):
+    import track_oracle as to
+
+    eng = engines("lepton3")
+    clips, metas, offs, outs = [], [], [0], []
+    for name in ("possum", "hedgehog"):
+        frames, t_on, ffc, bgf, hdr = load_clip(name)
+        clips.append(frames)
+        metas.append(eng.make_meta(frames.shape[0], t_on, ffc, bgf))
+        offs.append(offs[-1] + frames.shape[0])
+        outs.append((to.track_clip(frames, t_on, ffc, bgf, to.OracleConfig(hdr.model), keep=True, apply_filter=False), bgf))
+    meta = np.concatenate(metas)
+    offs = np.array(offs, np.int32)
+    res = eng.track_batch(eng.upload_frames(np.concatenate(clips)), offs, meta)
+    res.check()
+    assoc = eng.associate_batch(res, offs, meta)
+    assoc.check()
+    for b, (out, bgf) in enumerate(outs):
+        proc = [i for i in range(len(bgf)) if not bgf[i]]
+        n, _ = _compare_assoc(assoc, b, out, int(offs[b]), proc)
+        assert n == (7 if b == 0 else len(out["tracks"]))
+
+
+def test_association_matches_oracle_on_synthetic(engines):
+    import track_oracle as to
+    from cpx import synth
+
+    eng = engines("lepton3")
+    n_clips, T = 10, 150
+    rng = np.random.default_rng(11)
+    clips = [synth.make_clip(rng, T, max_blobs=3) for _ in range(n_clips)]
+    offs = (np.arange(n_clips + 1) * T).astype(np.int32)
+    meta = eng.make_meta(n_clips * T)
+    res = eng.track_batch(eng.upload_frames(np.concatenate(clips)), offs, meta)
+    res.check()
+    assoc = eng.associate_batch(res, offs, meta)
+    assoc.check()
+    nt = nb = 0
+    for b in range(n_clips):
+        out = to.track_clip(clips[b], cfg=to.OracleConfig("lepton3"), keep=True, apply_filter=False)
+        a, c = _compare_assoc(assoc, b, out, int(offs[b]), list(range(T)))
+        nt += a
+        nb += c
+    assert nt > 10 and nb > 10
