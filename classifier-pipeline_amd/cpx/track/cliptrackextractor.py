@@ -1,0 +1,275 @@
+"""ClipTrackExtractor -- drop-in for the reference class of the same name
+(reference src/track/cliptrackextractor.py:34-247, src/track/cliptracker.py:14-491).
+
+parse_clip() decodes the CPTV on the host, uploads the whole clip and runs it
+through the HIP track stage (cpx_track_batch) and the HIP association stage
+(cpx_associate_batch); the Clip / Frame / Track / Region objects the
+reference's callers read are then built from the device records.  End-of-clip
+filtering (trim, statistics, score ordering, rejects) is host work as in the
+reference.  There is no CPU implementation of the per-frame arithmetic."""
+
+import logging
+import time
+from datetime import datetime
+
+import numpy as np
+
+from ..cptv import CptvReader
+from ..engine import TrackEngine
+from ..ml_tools.rectangle import Rectangle
+from ..tracking import make_track_params
+from .clip import Clip
+from .region import Region
+from .track import Track
+
+_ENGINES = {}
+
+
+def get_engine(width, height, background_thresh, weight_add, edge_pixels=1, device=0, max_frames=4096,
+               max_components=64):
+    """One device engine per (geometry, thresholds) in this process."""
+    key = (width, height, float(background_thresh), float(weight_add), edge_pixels, device, max_components)
+    eng = _ENGINES.get(key)
+    if eng is None or eng.cfg.max_frames < max_frames:
+        if eng is not None:
+            eng.close()
+        eng = TrackEngine(width=width, height=height, device=device, edge_pixels=edge_pixels,
+                          background_thresh=background_thresh, weight_add=weight_add,
+                          max_components=max_components, max_frames=max(max_frames, 1024))
+        _ENGINES[key] = eng
+    return eng
+
+
+class WeightedBackgroundView:
+    """What callers read from ``extractor.background_alg`` after tracking
+    (reference piclassifier/motiondetector.py:178-248): the final background and its average."""
+
+    def __init__(self, background, average, weight_add):
+        self._background = background
+        self.average = average
+        self.weight_add = weight_add
+
+    @property
+    def background(self):
+        return self._background
+
+    def get_average(self):
+        return self.average
+
+
+class ClipTracker:
+    """Configuration handling + end-of-clip filtering shared by the extractors (cliptracker.py:14-491)."""
+
+    def __init__(self, config, cache_to_disk=False, keep_frames=True, calc_stats=True, verbose=False,
+                 do_tracking=True, scale=None, calculate_thumbnail_info=False, max_frames=None):
+        self.max_frames = max_frames
+        config = config.get(self.type)
+        self.scale = scale
+        self.calculate_thumbnail_info = calculate_thumbnail_info
+        self.do_tracking = do_tracking
+        self.verbose = verbose
+        self.config = config
+        self.stats = None
+        self.cache_to_disk = cache_to_disk
+        self.max_tracks = config.max_tracks
+        self.frame_padding = max(3, self.config.frame_padding)
+        self.keep_frames = keep_frames
+        self.calc_stats = calc_stats
+        self._tracking_time = None
+        self.min_dimension = config.min_dimension
+        self.background_alg = None
+
+    def print_if_verbose(self, info_string):
+        if self.verbose:
+            logging.info(info_string)
+
+    def apply_track_filtering(self, clip):
+        filtered_tracks = self.filter_tracks(clip)
+        if self.config.track_smoothing and clip.current_frame > 0:
+            for track in clip.active_tracks:
+                track.smooth(Rectangle(0, 0, clip.res_x, clip.res_y))
+        return filtered_tracks
+
+    def filter_tracks(self, clip):
+        for track in clip.tracks:
+            track.trim()
+            track.set_end_s(clip.frames_per_second)
+        for track in clip.tracks:
+            track.calculate_stats()
+        clip.tracks.sort(reverse=True, key=lambda t: t.stats.score)
+        good, rejected = [], []
+        for track in clip.tracks:
+            (rejected if self.filter_track(clip, track) else good).append(track)
+        clip.tracks = good
+        if self.max_tracks is not None and self.max_tracks < len(clip.tracks):
+            logging.warning(" -using only %s tracks out of %s", self.max_tracks, len(clip.tracks))
+            clip.filtered_tracks.extend(("Too many tracks", t) for t in clip.tracks[self.max_tracks:])
+            clip.tracks = clip.tracks[: self.max_tracks]
+        return rejected
+
+    def filter_track(self, clip, track):
+        """True (and a reason on clip.filtered_tracks) when the track is noise (cliptracker.py:422-486)."""
+        s, cfg = track.stats, self.config
+        reason = None
+        if len(track) < cfg.min_duration_secs * clip.frames_per_second:
+            reason = "Track filtered.  Too short"
+        elif s.max_offset < cfg.track_min_offset or s.frames_moved < cfg.min_moving_frames:
+            reason = "Track filtered.  Didn't move"
+        elif s.blank_percent > cfg.max_blank_percent:
+            reason = "Track filtered. Too Many Blanks"
+        elif s.region_jitter > cfg.max_jitter:
+            reason = "Track filtered.  Too Jittery"
+        elif s.delta_std < clip.track_min_delta:
+            reason = "Track filtered.  Too static"
+        elif s.delta_std > clip.track_max_delta:
+            reason = "Track filtered.  Too Dynamic"
+        elif s.average_mass < cfg.track_min_mass:
+            reason = "Track filtered.  Mass too small"
+        if reason is None:
+            return False
+        self.print_if_verbose("{} (track {})".format(reason, track.get_id()))
+        clip.filtered_tracks.append((reason, track))
+        return True
+
+
+class ClipTrackExtractor(ClipTracker):
+    PREVIEW = "preview"
+    VERSION = 11
+    TYPE = "thermal"
+
+    @property
+    def tracker_version(self):
+        return self.version
+
+    @property
+    def type(self):
+        return ClipTrackExtractor.TYPE
+
+    @property
+    def tracking_time(self):
+        return self._tracking_time
+
+    def __init__(self, config, use_opt_flow, cache_to_disk=False, keep_frames=True, calc_stats=True,
+                 high_quality_optical_flow=False, verbose=False, do_tracking=True, update_background=True,
+                 calculate_filtered=False, calculate_thumbnail_info=False, from_pi=False, max_frames=None,
+                 device=0):
+        super().__init__(config, cache_to_disk, keep_frames=keep_frames, calc_stats=calc_stats, verbose=verbose,
+                         do_tracking=do_tracking, calculate_thumbnail_info=calculate_thumbnail_info,
+                         max_frames=max_frames)
+        if use_opt_flow:
+            raise NotImplementedError("optical flow is outside the cpx hot path")
+        if not update_background:
+            raise NotImplementedError("update_background=False (Pi live loop) is not supported yet")
+        self.version = f"PI-{ClipTrackExtractor.VERSION}" if from_pi else ClipTrackExtractor.VERSION
+        self.use_opt_flow = use_opt_flow
+        self.high_quality_optical_flow = high_quality_optical_flow
+        self.update_background = update_background
+        self.calculate_filtered = calculate_filtered
+        self.weighting_percent = 1
+        self.device = device
+        self._frames = None
+        self._header = None
+        self.timings = {}
+
+    # ---- reference API -------------------------------------------------------------------------
+    def init_clip(self, clip):
+        """Header, resolution, camera thresholds, first frame -> clip background (cliptrackextractor.py:98-139)."""
+        clip.set_frame_buffer(self.high_quality_optical_flow, self.cache_to_disk, self.use_opt_flow,
+                              self.keep_frames, self.max_frames)
+        clip.type = self.type
+        reader = CptvReader(str(clip.source_file))
+        header = reader.get_header()
+        clip.set_res(header.x_resolution, header.y_resolution)
+        if clip.from_metadata:
+            for track in clip.tracks:
+                track.crop_regions()
+        clip.set_model(header.model if header.model else None)
+        start = datetime.fromtimestamp(header.timestamp / 1000000).astimezone(Clip.local_tz)
+        clip.set_video_stats(start)
+        self._frames = reader.read_all()
+        self._header = header
+        if not self._frames:
+            raise Exception("CPTV file has no frames: {}".format(clip.source_file))
+        clip.update_background(self._frames[0].pix)
+        clip._background_calculated()
+
+    def parse_clip(self, clip, process_background=False):
+        self._tracking_time = None
+        start = time.time()
+        self.init_clip(clip)
+        self._track_clip(clip, process_background=process_background)
+        if self.calc_stats:
+            clip.stats.completed()
+        self._tracking_time = time.time() - start
+        return True
+
+    def start_tracking(self, clip, frames, track_frames=True, background_alg=None, **args):
+        raise NotImplementedError("incremental tracking (Pi live loop) is not part of this build yet: use parse_clip")
+
+    def process_frame(self, clip, frame):
+        raise NotImplementedError("incremental tracking (Pi live loop) is not part of this build yet: use parse_clip")
+
+    # ---- device path --------------------------------------------------------------------------------
+    def _track_clip(self, clip, process_background=False):
+        if clip.background is None:
+            raise Exception("Clip has no background have you called init_clip first")
+        if self.config.denoise:
+            raise NotImplementedError(
+                "tracking.denoise=True (cv2.fastNlMeansDenoising) has no HIP kernel yet: set denoise: false")
+        frames = self._frames
+        n = len(frames)
+        cam35 = clip.camera_model == "lepton3.5"
+        weight_add = (1 if cam35 else 0.1) / self.weighting_percent
+        eng = get_engine(clip.res_x, clip.res_y, clip.background_thresh, weight_add, self.config.edge_pixels,
+                         self.device, max_frames=n)
+        t0 = time.time()
+        stack = np.stack([f.pix for f in frames])
+        bgf = [bool(f.background_frame) and not process_background for f in frames]
+        meta = eng.make_meta(n, [f.time_on for f in frames], [f.last_ffc_time for f in frames], bgf)
+        offs = np.array([0, n], np.int32)
+        want_images = self.keep_frames
+        res = eng.track_batch(eng.upload_frames(stack), offs, meta, want_labels=want_images,
+                              want_filtered=want_images or self.calculate_filtered, want_background=True)
+        assoc = None
+        if self.do_tracking and not clip.from_metadata:
+            params = make_track_params(
+                clip.res_x, clip.res_y, self.config.edge_pixels, self.config.frame_padding, self.min_dimension,
+                self.config.cropped_regions_strategy, self.config.filter_regions_pre_match, self.config.aoi_min_mass,
+                self.config.aoi_pixel_variance, self.config.params, clip.frames_per_second)
+            assoc = eng.associate_batch(res, offs, meta, params=params)
+        res.check()
+        self.timings["device_s"] = time.time() - t0
+        info = res.info
+        labels = res.labels() if want_images else None
+        filtered = res.filtered() if (want_images or self.calculate_filtered) else None
+        P = clip.res_x * clip.res_y
+        for f in range(n):
+            fi = info[f]
+            if fi["frame_number"] < 0:
+                continue
+            thermal = frames[f].pix
+            stats = (np.uint16(fi["thermal_min"]), np.uint16(fi["thermal_max"]), np.median(thermal),
+                     fi["thermal_sum"] / P, float(fi["filtered_abs_sum"]))
+            clip.ffc_affected = bool(fi["ffc_affected"])
+            clip.add_frame(thermal, None if filtered is None else filtered[f], None if labels is None else labels[f],
+                           clip.ffc_affected, stats=stats)
+            if assoc is not None:
+                clip.region_history.append([] if clip.ffc_affected else
+                                           [Region.from_record(r) for r in assoc.frame_regions(f)])
+        bg = res.background()[0].astype(np.float64)
+        last = info[[f for f in range(n) if info[f]["frame_number"] >= 0][-1]] if clip.current_frame >= 0 else None
+        self.background_alg = WeightedBackgroundView(bg, None if last is None else last["background_average"], weight_add)
+        if assoc is not None:
+            assoc.check()
+            clip.tracks = [Track.from_device(clip, rec, regs, self.tracker_version, self.config)
+                           for rec, regs in assoc.clip_tracks(0)]
+            last_frame = clip.current_frame
+            clip.active_tracks = set(t for t in clip.tracks if t.end_frame == last_frame and self._still_tracking(t))
+            self.apply_track_filtering(clip)
+
+    @staticmethod
+    def _still_tracking(track):
+        rt = track.tracker
+        if rt.frames_since_target_seen == 0:
+            return True
+        return rt.frames_since_target_seen < min(2 * (rt.frames - rt.frames_since_target_seen), 18)

