@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: two gloo ranks shard clips and all-gather their per-clip records."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_balanced_and_complete():
+    sys.path.insert(0, os.path.join(REPO, "classifier-pipeline_amd"))
+    from cpx.sharding import partition_clips
+
+    rng = np.random.default_rng(0)
+    counts = rng.integers(20, 400, size=101)
+    for world in (1, 2, 4, 8):
+        shards = partition_clips(counts, world)
+        assert sorted(i for s in shards for i in s) == list(range(101))
+        loads = [int(counts[s].sum()) for s in shards]
+        assert max(loads) - min(loads) <= counts.max()
+    assert partition_clips([], 2) == [[], []]
+
+
+WORKER = textwrap.dedent(
+    """
+    import os, sys
+    sys.path.insert(0, os.path.join(%r, "classifier-pipeline_amd"))
+    import numpy as np, torch, torch.distributed as dist
+    from cpx.sharding import partition_clips, gather_records
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    counts = np.random.default_rng(1).integers(20, 400, size=37)
+    mine = partition_clips(counts, world)[rank]
+    rec = torch.tensor([[i, int(counts[i]), i * 7 %% 5, rank] for i in mine], dtype=torch.int32).reshape(-1, 4)
+    out = gather_records(rec, dist)
+    assert out.shape == (37, 4), out.shape
+    assert out[:, 0].tolist() == list(range(37))
+    assert out[:, 1].tolist() == [int(c) for c in counts]
+    owners = {i: r for r, s in enumerate(partition_clips(counts, world)) for i in s}
+    assert out[:, 3].tolist() == [owners[i] for i in range(37)]
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ok_%%d" %% rank), "w").write("ok")
+    """
+)
+
+
+def test_two_rank_gloo_all_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % REPO)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+         "127.0.0.1", "--master-port", str(port), str(script)],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
