@@ -248,7 +248,7 @@ class ClipTrackExtractor(ClipTracker):
             if fi["frame_number"] < 0:
                 continue
             thermal = frames[f].pix
-            stats = (np.uint16(fi["thermal_min"]), np.uint16(fi["thermal_max"]), np.median(thermal),
+            stats = (np.uint16(fi["thermal_min"]), np.uint16(fi["thermal_max"]), np.float64(fi["thermal_median"]),
                      fi["thermal_sum"] / P, float(fi["filtered_abs_sum"]))
             clip.ffc_affected = bool(fi["ffc_affected"])
             clip.add_frame(thermal, None if filtered is None else filtered[f], None if labels is None else labels[f],

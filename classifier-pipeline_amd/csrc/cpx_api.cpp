@@ -251,6 +251,7 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
   a.window = c.window;
   a.cap_out = c.max_components;
   a.background_thresh = c.background_thresh;
+  a.weight_add = c.weight_add;
   a.frames = frames_dev;
   a.clip_first = h->sched_dev;
   a.proc_off = h->sched_dev + B;

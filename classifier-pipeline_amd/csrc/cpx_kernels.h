@@ -21,6 +21,10 @@
 #define CPX_TRACK_MIN_WAVES_PER_SIMD 8  // __launch_bounds__ 2nd argument (waves per SIMD)
 #endif
 
+#ifndef CPX_TRACK_P1B_UNROLL
+#define CPX_TRACK_P1B_UNROLL 1  // unroll factor of the streaming loop (register pressure vs loads in flight)
+#endif
+
 namespace cpx {
 
 typedef cpx_component Component;
@@ -37,6 +41,7 @@ struct TrackArgs {
   // geometry / config
   int W, H, edge, window, cap_out;
   double background_thresh;
+  double weight_add;
   // inputs
   const uint16_t* frames;   // [total_frames, H, W]
   const int* clip_first;    // [B]   first frame (file order) of each clip: background init

@@ -198,10 +198,13 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   int* s_red2 = reinterpret_cast<int*>(s_red + NWAVE);    // [NWAVE][2]
   u32* s_ncomp_p = reinterpret_cast<u32*>(s_red2 + 2 * NWAVE);
   Red1* s_R = reinterpret_cast<Red1*>(s_ncomp_p + 2);
+  u32* s_cnt = reinterpret_cast<u32*>(s_R + 1);  // [2][NWAVE] counts of the median search + [NWAVE] mins
+  int* s_bc = reinterpret_cast<int*>(s_cnt + 3 * NWAVE);  // [0..1] normalisation min / max, [2] median (float)
 
   const int fidx = a.proc_idx[pbase + t];
   const int oidx = (t >= a.window) ? a.proc_idx[pbase + t - a.window] : -1;
   const int nwin = (t + 1 < a.window) ? (t + 1) : a.window;
+  const u64 div_magic = ((1ull << 40) + (u64)nwin - 1ull) / (u64)nwin;
   const uint16_t* F = a.frames + (size_t)fidx * P;
   const uint16_t* O = (oidx >= 0) ? a.frames + (size_t)oidx * P : nullptr;
   const int32_t* bg_old = a.bg + ((size_t)b * 2 + (t & 1)) * P;
@@ -219,25 +222,134 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
   const ClipState cs = a.cstate[b];
 
-  // ---- phase 1: streaming pass ------------------------------------------------
-  int v[NCH][4];
+  // ---- phase 1a: thermal frame -> registers (2 pixels per VGPR), sum / min / max ----------------
+  u32 pk[NCH][2];
+  {
+    u32 sumpix = 0, minpix = 0xFFFFFFFFu, maxpix = 0;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * NT;
+      if (c < nchunk) {
+        const uint2 q = *reinterpret_cast<const uint2*>(F + (c << 2));
+        pk[i][0] = q.x;
+        pk[i][1] = q.y;
+        *reinterpret_cast<uint2*>(s_tmp + (c << 2)) = q;  // phase 1b re-reads it from LDS (rolled loop)
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+          const u32 val = (hh & 1) ? (pk[i][hh >> 1] >> 16) : (pk[i][hh >> 1] & 0xFFFFu);
+          sumpix += val;
+          minpix = min(minpix, val);
+          maxpix = max(maxpix, val);
+        }
+      } else {
+        pk[i][0] = pk[i][1] = 0xFFFFFFFFu;  // padding: 65535, never below a bisection candidate
+      }
+    }
+    sumpix = wave_sum(sumpix);
+    minpix = wave_min(minpix);
+    maxpix = wave_max(maxpix);
+    if (lane == 0) {
+      s_red[wave].sumpix = sumpix;
+      s_red[wave].minpix = minpix;
+      s_red[wave].maxpix = maxpix;
+    }
+    // zero the bit rows / counters while we are at a barrier anyway
+    for (int i = tid; i < 2 * H * RW; i += NT) s_rowI[i] = 0ull;
+    if (tid == 0) *s_ncomp_p = 0;
+  }
+  __syncthreads();
+  u32 sumpix = 0, minpix = 0xFFFFFFFFu, maxpix = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVE; ++w) {
+    sumpix += s_red[w].sumpix;
+    minpix = min(minpix, s_red[w].minpix);
+    maxpix = max(maxpix, s_red[w].maxpix);
+  }
+  // avg_change = int(round(np.average(thermal) - background.average))  (cliptracker.py:103-105)
+  const double mean_thermal = (double)sumpix / (double)P;
+  const int avg_change = (int)rint(mean_thermal - cs.bg_average);
+
+  // ---- np.median(thermal) (clip.py:475): exact selection by bisection on the value range, counting
+  // in registers; median = mean of the two middle order statistics ---------------------------------
+  {
+    float median;
+    u32 lo = minpix, hi = maxpix;
+    const u32 k1 = (u32)((P - 1) >> 1), k2 = (u32)(P >> 1);
+    int par = 0;
+#ifdef CPX_TIMING_NO_MEDIAN  // timing experiments only: wrong medians
+    lo = hi;
+#endif
+    while (lo < hi) {  // uniform: every thread sees the same block totals
+      const u32 mid = (lo + hi) >> 1;
+      u32 cnt = 0;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        cnt += ((pk[i][0] & 0xFFFFu) <= mid) + ((pk[i][0] >> 16) <= mid) + ((pk[i][1] & 0xFFFFu) <= mid) +
+               ((pk[i][1] >> 16) <= mid);
+      }
+      cnt = wave_sum(cnt);
+      if (lane == 0) s_cnt[par * NWAVE + wave] = cnt;
+      __syncthreads();
+      u32 tot = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) tot += s_cnt[par * NWAVE + w];
+      par ^= 1;
+      if (tot >= k1 + 1) hi = mid;
+      else lo = mid + 1;
+    }
+    // lo = value of rank k1; rank k2 is the same value unless exactly k1+1 pixels are <= lo
+    u32 cnt = 0, nxt = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        const u32 val = (hh & 1) ? (pk[i][hh >> 1] >> 16) : (pk[i][hh >> 1] & 0xFFFFu);
+        cnt += (val <= lo);
+        nxt = (val > lo && val < nxt) ? val : nxt;
+      }
+    }
+    cnt = wave_sum(cnt);
+    nxt = wave_min(nxt);
+    if (lane == 0) {
+      s_cnt[par * NWAVE + wave] = cnt;
+      s_cnt[2 * NWAVE + wave] = nxt;
+    }
+    __syncthreads();
+    u32 tot = 0, mnx = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) {
+      tot += s_cnt[par * NWAVE + w];
+      mnx = min(mnx, s_cnt[2 * NWAVE + w]);
+    }
+    // (padding lanes hold 65535: they only count when lo == 65535, where both ranks are 65535 anyway)
+    const u32 v2 = (tot >= k2 + 1 || lo == 65535u) ? lo : mnx;
+    median = 0.5f * (float)(lo + v2);
+    // park it in LDS now: otherwise the compiler sinks this whole reduction to the kernel's end and
+    // spills the 32 partials it needs for it
+    if (tid == 0) reinterpret_cast<float*>(s_bc)[2] = median;
+  }
+
+  // ---- phase 1b: the streaming pass over the clip state -----------------------------------------------
+  // x = max(thermal - background - avg_change, 0) goes to LDS as 17 bits (u16 plane + 1-bit-in-a-byte plane)
   Red1 r;
-  r.sumpix = 0;
-  r.minpix = 0xFFFFFFFFu;
-  r.maxpix = 0;
+  r.sumpix = sumpix;
+  r.minpix = minpix;
+  r.maxpix = maxpix;
   r.fmin = 0x7FFFFFFF;
   r.fmax = -0x7FFFFFFF - 1;
   r.sumbg = 0;
   r.changed = 0;
   r.sumabs = 0;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * NT;
-    if (c < nchunk) {
+  int mn = 0x7FFFFFFF, mx = 0;
+  // deliberately NOT unrolled: the body is long, and an unrolled version keeps 30 precomputed 64-bit
+  // addresses live and spills; 32 waves per CU cover the HBM latency instead
+#pragma unroll CPX_TRACK_P1B_UNROLL
+  for (int c = tid; c < nchunk; c += NT) {
+    {
       const int p0 = c << 2;
       const int y = p0 / W, x0 = p0 - y * W;
-      const ushort4 px = *reinterpret_cast<const ushort4*>(F + p0);
-      const int pix[4] = {px.x, px.y, px.z, px.w};
+      const uint2 pq = *reinterpret_cast<const uint2*>(s_tmp + p0);
+      const int pix[4] = {(int)(pq.x & 0xFFFFu), (int)(pq.x >> 16), (int)(pq.y & 0xFFFFu), (int)(pq.y >> 16)};
       int bgv[4];
       const int cy = clampi(y, e, H - 1 - e);
       const bool row_in = (cy == y);
@@ -259,26 +371,39 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       int kv[4] = {kq.x, kq.y, kq.z, kq.w};
       int nb[4];
       float fo[4];
+      u32 xlo[4], xhi[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int d = pix[j] - bgv[j];  // filtered = float32(pix) - background (cliptrackextractor.py:212)
-        v[i][j] = d;
         fo[j] = (float)d;
-        r.sumpix += (u32)pix[j];
-        r.minpix = min(r.minpix, (u32)pix[j]);
-        r.maxpix = max(r.maxpix, (u32)pix[j]);
         r.fmin = min(r.fmin, d);
         r.fmax = max(r.fmax, d);
         r.sumabs += (u64)(d < 0 ? -d : d);
+        int xs = d - avg_change;  // cliptracker.py:109-114
+        xs = xs < 0 ? 0 : xs;
+        mn = min(mn, xs);
+        mx = max(mx, xs);
+        xlo[j] = (u32)xs & 0xFFFFu;
+        xhi[j] = (u32)xs >> 16;
         // background feed: np.int32(np.mean(last <=45 frames)) == window_sum // n (cliptrackextractor.py:173-176)
         wsv[j] = wsv[j] + (u32)pix[j] - (u32)oldp[j];
-        const int f = (int)(wsv[j] / (u32)nwin);
+        const int f = (int)(((u64)wsv[j] * div_magic) >> 40);  // == wsv / nwin exactly (wsv < 2^22, nwin <= window)
         const int x = x0 + j;
         nb[j] = bgv[j];
         if (row_in && x >= e && x <= W - 1 - e) {
           // motiondetector.py:212-223: bg' = bg if bg < f - w else f ; w' = w + add if (same) else 0
-          const double wgt = a.wtab[kv[j]];
-          const bool keep = (double)bgv[j] < (double)f - wgt;
+          // keep <=> bg < fl64(f - w_k), w_k = k-fold float64 accumulation of weight_add (table).  The table
+          // is only consulted when f - bg is within 1e-5 of k * weight_add, i.e. where rounding can matter.
+          bool keep;
+          if (kv[j] == 0) {
+            keep = bgv[j] < f;
+          } else {
+            const double ap = (double)kv[j] * a.weight_add;
+            const double dd = (double)(f - bgv[j]);
+            if (dd > ap + 1e-5) keep = true;
+            else if (dd < ap - 1e-5) keep = false;
+            else keep = (double)bgv[j] < (double)f - a.wtab[kv[j]];
+          }
           const int nv = keep ? bgv[j] : f;
           kv[j] = keep ? kv[j] + 1 : 0;
           r.changed |= (u32)(nv != bgv[j]);
@@ -286,86 +411,59 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
           nb[j] = nv;
         }
       }
+      *reinterpret_cast<uint2*>(s_tmp + p0) = make_uint2(xlo[0] | (xlo[1] << 16), xlo[2] | (xlo[3] << 16));
+      *reinterpret_cast<u32*>(s_u8 + p0) = xhi[0] | (xhi[1] << 8) | (xhi[2] << 16) | (xhi[3] << 24);
       *reinterpret_cast<float4*>(filt_cur + p0) = make_float4(fo[0], fo[1], fo[2], fo[3]);
       *reinterpret_cast<uint4*>(ws + p0) = make_uint4(wsv[0], wsv[1], wsv[2], wsv[3]);
       *reinterpret_cast<int4*>(bg_new + p0) = make_int4(nb[0], nb[1], nb[2], nb[3]);
       *reinterpret_cast<ushort4*>(kc + p0) =
           make_ushort4((unsigned short)kv[0], (unsigned short)kv[1], (unsigned short)kv[2], (unsigned short)kv[3]);
-      // keep the five chunk bodies from being interleaved: 16 waves per CU already cover the
-      // HBM latency, and interleaving them blows the 128-VGPR budget of a 1024-thread workgroup
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[i][j] = 0;
     }
   }
-  // block reduction of the phase-1 scalars
-  r.sumpix = wave_sum(r.sumpix);
-  r.minpix = wave_min(r.minpix);
-  r.maxpix = wave_max(r.maxpix);
   r.fmin = wave_min(r.fmin);
   r.fmax = wave_max(r.fmax);
   r.sumbg = wave_sum(r.sumbg);
   r.changed = wave_max(r.changed);
   r.sumabs = wave_sum(r.sumabs);
-  if (lane == 0) s_red[wave] = r;
-  // zero the bit rows while we are at a barrier anyway
-  for (int i = tid; i < 2 * H * RW; i += NT) s_rowI[i] = 0ull;
-  if (tid == 0) *s_ncomp_p = 0;
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  if (lane == 0) {
+    s_red[wave] = r;
+    s_red2[2 * wave] = mn;
+    s_red2[2 * wave + 1] = mx;
+  }
   __syncthreads();
   if (wave == 0) {
     // combine the per-wave partials once; the result stays in LDS (s_R) for the later phases
     Red1 q;
-    if (lane < NWAVE) q = s_red[lane];
-    else {
-      q.sumpix = 0; q.minpix = 0xFFFFFFFFu; q.maxpix = 0; q.fmin = 0x7FFFFFFF; q.fmax = -0x7FFFFFFF - 1;
+    int qmn = 0x7FFFFFFF, qmx = 0;
+    if (lane < NWAVE) {
+      q = s_red[lane];
+      qmn = s_red2[2 * lane];
+      qmx = s_red2[2 * lane + 1];
+    } else {
+      q.sumpix = sumpix; q.minpix = minpix; q.maxpix = maxpix; q.fmin = 0x7FFFFFFF; q.fmax = -0x7FFFFFFF - 1;
       q.sumbg = 0; q.changed = 0; q.sumabs = 0;
     }
-    q.sumpix = wave_sum(q.sumpix);
-    q.minpix = wave_min(q.minpix);
-    q.maxpix = wave_max(q.maxpix);
     q.fmin = wave_min(q.fmin);
     q.fmax = wave_max(q.fmax);
     q.sumbg = wave_sum(q.sumbg);
     q.changed = wave_max(q.changed);
     q.sumabs = wave_sum(q.sumabs);
-    if (lane == 0) *s_R = q;
-  }
-  __syncthreads();
-  // avg_change = int(round(np.average(thermal) - background.average))  (cliptracker.py:103-105)
-  const double mean_thermal = (double)s_R->sumpix / (double)P;
-  const int avg_change = (int)rint(mean_thermal - cs.bg_average);
-
-  // ---- phase 2: shifted + clipped frame, min / max ------------------------------
-  int mn = 0x7FFFFFFF, mx = 0;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * NT;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int x = v[i][j] - avg_change;
-      x = x < 0 ? 0 : x;
-      v[i][j] = x;
-      if (c < nchunk) {
-        mn = min(mn, x);
-        mx = max(mx, x);
-      }
+    qmn = wave_min(qmn);
+    qmx = wave_max(qmx);
+    if (lane == 0) {
+      q.sumpix = sumpix;
+      q.minpix = minpix;
+      q.maxpix = maxpix;
+      *s_R = q;
+      s_bc[0] = qmn;
+      s_bc[1] = qmx;
     }
   }
-  mn = wave_min(mn);
-  mx = wave_max(mx);
-  if (lane == 0) {
-    s_red2[2 * wave] = mn;
-    s_red2[2 * wave + 1] = mx;
-  }
   __syncthreads();
-  mn = s_red2[0];
-  mx = s_red2[1];
-#pragma unroll
-  for (int w = 1; w < NWAVE; ++w) {
-    mn = min(mn, s_red2[2 * w]);
-    mx = max(mx, s_red2[2 * w + 1]);
-  }
+  mn = s_bc[0];
+  mx = s_bc[1];
 
   // ---- phase 3: normalise to 0..255 (float32, imageprocessing.py:151-169) -> uint8 in LDS
   float thresh;
@@ -377,10 +475,13 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     } else {
       thresh = __fmul_rn(__fdiv_rn((float)a.background_thresh, span), 255.0f);
     }
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * NT;
-      if (c < nchunk) {
+#pragma unroll 1
+    for (int c = tid; c < nchunk; c += NT) {
+      {
+        const uint2 ql = *reinterpret_cast<const uint2*>(s_tmp + (c << 2));
+        const u32 qh = *reinterpret_cast<const u32*>(s_u8 + (c << 2));
+        const int xv[4] = {(int)((ql.x & 0xFFFFu) | ((qh & 0xFFu) << 16)), (int)((ql.x >> 16) | (((qh >> 8) & 0xFFu) << 16)),
+                           (int)((ql.y & 0xFFFFu) | (((qh >> 16) & 0xFFu) << 16)), (int)((ql.y >> 16) | ((qh >> 24) << 16))};
         unsigned char o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -388,7 +489,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
           if (mx == mn) {
             val = (mx == 0) ? 0.0f : 1.0f;  // zeros, or data / max == 1
           } else {
-            val = __fdiv_rn(__fmul_rn(255.0f, (float)v[i][j] - fmn), span);
+            val = __fdiv_rn(__fmul_rn(255.0f, (float)xv[j] - fmn), span);
           }
           o[j] = (unsigned char)(int)val;  // np.uint8() truncation
         }
@@ -398,6 +499,15 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
   const int ithr = (mx == mn) ? (int)floor(a.background_thresh) : (int)floorf(thresh);
   __syncthreads();
+#define CPX_STOP(n)                                                                                   \
+  if (CPX_TIMING_STOP_AFTER == (n)) {                                                                 \
+    if (tid == 0) a.info_out[fidx].threshold = thresh + (float)ithr + (float)s_u8[avg_change & 1023] + (float)s_rowE[5]; \
+    return;                                                                                           \
+  }
+#ifndef CPX_TIMING_STOP_AFTER
+#define CPX_TIMING_STOP_AFTER 0  // timing experiments only: 3..8 = return after that phase
+#endif
+  CPX_STOP(3)
 
   // ---- phase 4a: horizontal [1 4 6 4 1], BORDER_REFLECT_101 -----------------------
   const int ngroup = P >> 3;
@@ -448,6 +558,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     reinterpret_cast<unsigned char*>(s_rowI)[y * (RW * 8) + (x0 >> 3)] = (unsigned char)bits;
   }
   __syncthreads();
+  CPX_STOP(4)
   // ---- phase 5: MORPH_CLOSE with the 1x2 element ----------------------
   for (int i = tid; i < H * RW; i += NT) {
     const int y = i / RW;
@@ -458,6 +569,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
   __syncthreads();
 
+  CPX_STOP(5)
   // ---- phase 6: 8-connected labelling on runs --------------------------------------
   // parents live on run-start slots (row * SW + start/2); initialise them
   for (int i = tid; i < H * RW; i += NT) {
@@ -526,6 +638,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   const bool overflow = ncomp_all > CAP || ncomp_all > a.cap_out;
   const int ncomp = overflow ? 0 : ncomp_all;
 
+  CPX_STOP(6)
   // ---- phase 7: statistics per component ------------------------------------------------
   // s_stat rows: 0 area, 1 minx, 2 maxx, 3 miny, 4 maxy, 5 sumx, 6 sumy, 7 key
   for (int i = tid; i < ncomp; i += NT) {
@@ -575,6 +688,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
   __syncthreads();
 
+  CPX_STOP(7)
   // ---- phase 8a: label image (Frame.mask) ------------------------------------------------------
   if (a.labels_out) {
     int32_t* Lout = a.labels_out + (size_t)fidx * P;
@@ -600,60 +714,86 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     }
   }
 
-  // ---- phase 8b: np.var(delta_filtered[bbox]) -- one wave per component ---------------------------
+  CPX_STOP(8)
+  // ---- phase 8b: np.var(delta_filtered[bbox]) per component ------------------------------------------
   // delta = |f32(norm255(cur.filtered)) - f32(norm255(prev.filtered))|  (cliptracker.py:249-261);
   // normalize() promotes to float64 for these float64 frames (NumPy >= 2 scalar promotion).
+  // Small boxes: one wave each.  Large boxes: the whole workgroup, partials combined in wave order.
   Component* Cout = a.comps_out + (size_t)fidx * a.cap_out;
   const bool has_prev = cs.has_prev != 0;
   const double cmin = (double)s_R->fmin, cmax = (double)s_R->fmax;
   const double pmin = (double)cs.prev_fmin, pmax = (double)cs.prev_fmax;
-  for (int cidx = wave; cidx < ncomp; cidx += NWAVE) {
+  auto delta_at = [&](int q) -> double {
+    const float cv = filt_cur[q], pv = filt_prev[q];
+    float an, bn;
+    if (cmax == cmin) an = (cmax == 0.0) ? 0.0f : (float)((double)cv / cmax);
+    else an = (float)((255.0 * ((double)cv - cmin)) / (cmax - cmin));
+    if (pmax == pmin) bn = (pmax == 0.0) ? 0.0f : (float)((double)pv / pmax);
+    else bn = (float)((255.0 * ((double)pv - pmin)) / (pmax - pmin));
+    return (double)fabsf(an - bn);
+  };
+  auto emit = [&](int cidx, int bx, int by, int bw, int bh, float var) {
+    Component o;
+    o.x = bx;
+    o.y = by;
+    o.width = bw;
+    o.height = bh;
+    o.area = (int)s_stat[0 * CAP + cidx];
+    o.sum_x = (int)s_stat[5 * CAP + cidx];
+    o.sum_y = (int)s_stat[6 * CAP + cidx];
+    o.pixel_variance = var;
+    Cout[s_rank[cidx]] = o;
+  };
+  constexpr int BIG = 512;  // pixels: above this a box is summed by the whole workgroup
+  double* s_part = reinterpret_cast<double*>(s_rowI);  // [2][NWAVE][2]: the un-closed bit rows are dead by now
+  int par = 0;
+  for (int cidx = 0; cidx < ncomp; ++cidx) {
     const int bx = (int)s_stat[1 * CAP + cidx], by = (int)s_stat[3 * CAP + cidx];
     const int bw = (int)s_stat[2 * CAP + cidx] - bx + 1, bh = (int)s_stat[4 * CAP + cidx] - by + 1;
-    float var = 0.0f;
-    if (has_prev) {
-      const int n = bw * bh;
-      double s1 = 0.0;
-      for (int k = lane; k < n; k += 64) {
-        const int yy = by + k / bw, xx = bx + (k - (k / bw) * bw);
-        const int q = yy * W + xx;
-        const float cv = filt_cur[q], pv = filt_prev[q];
-        float an, bn;
-        if (cmax == cmin) an = (cmax == 0.0) ? 0.0f : (float)((double)cv / cmax);
-        else an = (float)((255.0 * ((double)cv - cmin)) / (cmax - cmin));
-        if (pmax == pmin) bn = (pmax == 0.0) ? 0.0f : (float)((double)pv / pmax);
-        else bn = (float)((255.0 * ((double)pv - pmin)) / (pmax - pmin));
-        s1 += (double)fabsf(an - bn);
-      }
-      s1 = wave_sum(s1);
-      const double mean = s1 / (double)n;
-      double s2 = 0.0;
-      for (int k = lane; k < n; k += 64) {
-        const int yy = by + k / bw, xx = bx + (k - (k / bw) * bw);
-        const int q = yy * W + xx;
-        const float cv = filt_cur[q], pv = filt_prev[q];
-        float an, bn;
-        if (cmax == cmin) an = (cmax == 0.0) ? 0.0f : (float)((double)cv / cmax);
-        else an = (float)((255.0 * ((double)cv - cmin)) / (cmax - cmin));
-        if (pmax == pmin) bn = (pmax == 0.0) ? 0.0f : (float)((double)pv / pmax);
-        else bn = (float)((255.0 * ((double)pv - pmin)) / (pmax - pmin));
-        const double d = (double)fabsf(an - bn) - mean;
+    const int n = bw * bh;
+    if (n > BIG && has_prev) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = tid; k < n; k += NT) {
+        const int yy = k / bw;
+        const double d = delta_at((by + yy) * W + bx + (k - yy * bw));
+        s1 += d;
         s2 += d * d;
       }
+      s1 = wave_sum(s1);
       s2 = wave_sum(s2);
-      var = (float)(s2 / (double)n);
-    }
-    if (lane == 0) {
-      Component o;
-      o.x = bx;
-      o.y = by;
-      o.width = bw;
-      o.height = bh;
-      o.area = (int)s_stat[0 * CAP + cidx];
-      o.sum_x = (int)s_stat[5 * CAP + cidx];
-      o.sum_y = (int)s_stat[6 * CAP + cidx];
-      o.pixel_variance = var;
-      Cout[s_rank[cidx]] = o;
+      if (lane == 0) {
+        s_part[(par * NWAVE + wave) * 2] = s1;
+        s_part[(par * NWAVE + wave) * 2 + 1] = s2;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < NWAVE; ++w) {
+          t1 += s_part[(par * NWAVE + w) * 2];
+          t2 += s_part[(par * NWAVE + w) * 2 + 1];
+        }
+        const double mean = t1 / (double)n;
+        double var = t2 / (double)n - mean * mean;
+        emit(cidx, bx, by, bw, bh, (float)(var < 0.0 ? 0.0 : var));
+      }
+      par ^= 1;
+    } else if ((cidx % NWAVE) == wave) {
+      float var = 0.0f;
+      if (has_prev) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = lane; k < n; k += 64) {
+          const int yy = k / bw;
+          const double d = delta_at((by + yy) * W + bx + (k - yy * bw));
+          s1 += d;
+          s2 += d * d;
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const double mean = s1 / (double)n;
+        const double v = s2 / (double)n - mean * mean;
+        var = (float)(v < 0.0 ? 0.0 : v);
+      }
+      if (lane == 0) emit(cidx, bx, by, bw, bh, var);
     }
   }
 
@@ -674,7 +814,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     fi.thermal_min = (int)R.minpix;
     fi.thermal_max = (int)R.maxpix;
     fi.thermal_sum = R.sumpix;
-    fi.thermal_median = -1.0f;
+    fi.thermal_median = reinterpret_cast<const float*>(s_bc)[2];
     fi.filtered_abs_sum = R.sumabs;
     ClipState ns;
     // motiondetector.py:224-226: average = int(round(np.average(background))) when any pixel changed
@@ -705,7 +845,7 @@ __global__ __launch_bounds__(256) void cpx_export_background_kernel(TrackArgs a,
 
 size_t track_lds_bytes(int W, int H) {
   const size_t P = (size_t)W * H;
-  return 3 * P + 2 * (size_t)H * RW * 8 + (size_t)9 * CAP * 4 + (NWAVE + 1) * sizeof(Red1) + NWAVE * 2 * sizeof(int) + 16;
+  return 3 * P + 2 * (size_t)H * RW * 8 + (size_t)9 * CAP * 4 + (NWAVE + 1) * sizeof(Red1) + NWAVE * 2 * sizeof(int) + 16 + 3 * NWAVE * sizeof(u32) + 16;
 }
 
 void launch_init(const TrackArgs& a, int B, hipStream_t s) { hipLaunchKernelGGL(cpx_init_kernel, dim3(B), dim3(256), 0, s, a); }

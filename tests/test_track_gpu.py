@@ -165,6 +165,7 @@ def test_synthetic_batch_matches_oracle(engines, model):
             fi = res.info[offs[b] + i]
             assert fi["thermal_min"] == clip[i].min() and fi["thermal_max"] == clip[i].max()
             assert fi["thermal_sum"] == int(clip[i].astype(np.int64).sum())
+            assert float(fi["thermal_median"]) == float(np.median(clip[i]))
             assert fi["filtered_abs_sum"] == int(np.abs(out["frames"][i]["filtered"].astype(np.int64)).sum())
     assert ncomp > 0  # the comparison must have seen objects
 
@@ -220,6 +221,17 @@ def test_degenerate_frames(engines):
                           want_labels=True, want_filtered=True)
     res.check()
     _compare_with_oracle(res, 0, out, 4)
+    for i in range(4):
+        assert float(res.info[i]["thermal_median"]) == float(np.median(const[i]))
+    # median with an odd split: half the pixels at 100, half at 201 -> 150.5; and 65535-saturated frames
+    md = np.full((3, H, W), 100, np.uint16)
+    md[0].reshape(-1)[H * W // 2:] = 201
+    md[1][:] = 65535
+    md[2].reshape(-1)[: H * W // 2 - 1] = 7
+    md[2].reshape(-1)[H * W // 2 - 1:] = 65535
+    r2 = eng.track_batch(eng.upload_frames(md), np.array([0, 3], np.int32), eng.make_meta(3))
+    for i in range(3):
+        assert float(r2.info[i]["thermal_median"]) == float(np.median(md[i])), i
     # 2x2-block checkerboard of hot pixels far above threshold -> thousands of components
     cb = np.full((2, H, W), 3000, np.uint16)
     cb[1, 4:116:6, 4:156:6] = 9000
