@@ -81,3 +81,34 @@ def test_oracle_matches_possum_txt():
             assert (r.x, r.y, r.width, r.height, int(r.mass), r.frame_number, r.blank) == (
                 p["x"], p["y"], p["width"], p["height"], p["mass"], p["frame_number"], p["blank"])
             assert abs(round(float(r.pixel_variance), 2) - p["pixel_variance"]) < 1e-3
+
+
+@pytest.mark.parametrize("name,fs", [("possum", 32), ("hedgehog", 32), ("hedgehog", 64)])
+def test_classify_oracle_matches_reference_inputs(name, fs):
+    """oracle/classify_oracle.py against the network inputs the reference's own
+    Interpreter.classify_track built (tests/golden/make_golden_classify.py)."""
+    import classify_oracle as co
+
+    out, frames = _run(name, 0)
+    z = np.load(os.path.join(GOLDEN, "%s_classify_fs%d.npz" % (name, fs)))
+    with open(os.path.join(GOLDEN, "%s_classify_fs%d.json" % (name, fs))) as fh:
+        meta = json.load(fh)
+    fr = out["frames"]
+    proc_thermal = {f["index"]: None for f in fr}
+    _, _, _, bgf, _ = load_clip(name)
+    proc = [i for i in range(frames.shape[0]) if not bgf[i]]
+    thermal_of = lambda q: frames[proc[q]]
+    filtered_of = lambda q: fr[q]["filtered"].astype(np.float64)
+    H, W = frames.shape[1:]
+    crop = (1, 1, W - 2, H - 2)
+    assert len(out["tracks"]) == len(meta["tracks"])
+    for ti, (t, m) in enumerate(zip(out["tracks"], meta["tracks"])):
+        assert t.id == m["track_id"]
+        segs = z["t%d_segments" % ti]
+        by_frame = {r.frame_number: r for r in t.bounds}
+        x, info = co.preprocess_segments(thermal_of, filtered_of, by_frame, t.bounds, segs, fs, crop)
+        want = z["t%d_input" % ti]
+        assert x.shape == want.shape
+        assert np.array_equal(x, want), (name, ti, np.abs(x - want).max())
+        score = co.classified_track(z["t%d_pred" % ti], prediction_frames=segs, labels=meta["labels"])
+        assert np.array_equal(score, np.array(m["class_best_score"]))
