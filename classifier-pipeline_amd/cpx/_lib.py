@@ -54,11 +54,18 @@ FRAME_INFO_DTYPE = np.dtype(
      ("thermal_sum", "<u4"), ("thermal_median", "<f4"), ("filtered_abs_sum", "<u8"),
      ("background_average", "<f8"), ("background_changed", "<i4"), ("reserved", "<i4")]
 )
+REGION_REF_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"),
+                             ("in_segment", "<i4")])
+TRACK_LIMITS_DTYPE = np.dtype([("filt_min", "<f4"), ("filt_max", "<f4"), ("clip_at_zero", "<i4"), ("reserved", "<i4")])
+CROP_REQ_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"),
+                           ("track", "<i4"), ("sample", "<i4"), ("tile", "<i4")])
+assert REGION_REF_DTYPE.itemsize == 24 and TRACK_LIMITS_DTYPE.itemsize == 16 and CROP_REQ_DTYPE.itemsize == 32
 assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FRAME_INFO_DTYPE.itemsize == 80
 
 EXPORTS = [
     "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
+    "cpx_track_limits_batch", "cpx_crop_tile",
 ]
 
 _lib = None
@@ -96,6 +103,10 @@ def load():
     lib.cpx_track_batch.restype = C.c_int
     lib.cpx_associate_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpx_associate_batch.restype = C.c_int
+    lib.cpx_track_limits_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    lib.cpx_track_limits_batch.restype = C.c_int
+    lib.cpx_crop_tile.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
+    lib.cpx_crop_tile.restype = C.c_int
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]

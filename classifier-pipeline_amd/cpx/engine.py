@@ -6,7 +6,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import COMPONENT_DTYPE, FRAME_INFO_DTYPE, FRAME_META_DTYPE, CpxError
+from ._lib import (COMPONENT_DTYPE, CROP_REQ_DTYPE, FRAME_INFO_DTYPE, FRAME_META_DTYPE, REGION_REF_DTYPE,
+                   TRACK_LIMITS_DTYPE, CpxError)
 from .tracking import REGION_DTYPE, TRACK_RECORD_DTYPE, make_track_params, track_regions
 
 
@@ -222,6 +223,47 @@ class TrackEngine:
         if rc != 0:
             raise CpxError(rc, self._err())
         return AssocBatchResult(self, offs, params, pool, tracks, ntr, status, regions, rcounts)
+
+    def _to_dev(self, arr):
+        """structured / plain numpy array -> device int32 tensor holding the same bytes."""
+        a = np.ascontiguousarray(arr)
+        return self.torch.from_numpy(a.view(np.int32).reshape(-1).copy()).to(self.device)
+
+    def preprocess_segments(self, frames_dev, track_result, refs, track_offsets, reqs, n_samples, frame_size=32,
+                            square_width=5, out=None):
+        """get_limits + clip test per track, then crop / resize / normalise / tile every request.
+        refs: REGION_REF_DTYPE [R]; track_offsets: int32 [n_tracks+1]; reqs: CROP_REQ_DTYPE [n].
+        -> (device float tensor [n_samples, sq*fs, sq*fs, 2], limits host array)."""
+        t = self.torch
+        if track_result.filtered_dev is None:
+            raise ValueError("preprocess_segments needs the filtered frames (track_batch(want_filtered=True))")
+        refs = np.ascontiguousarray(refs, dtype=REGION_REF_DTYPE)
+        reqs = np.ascontiguousarray(reqs, dtype=CROP_REQ_DTYPE)
+        offs = np.ascontiguousarray(track_offsets, dtype=np.int32)
+        n_tracks = offs.size - 1
+        refs_dev = self._to_dev(refs) if refs.size else t.zeros(6, dtype=t.int32, device=self.device)
+        offs_dev = t.from_numpy(offs).to(self.device)
+        reqs_dev = self._to_dev(reqs) if reqs.size else t.zeros(8, dtype=t.int32, device=self.device)
+        limits_dev = t.zeros(max(n_tracks, 1) * 4, dtype=t.int32, device=self.device)
+        side = square_width * frame_size
+        if out is None:
+            out = t.empty((n_samples, side, side, 2), dtype=t.float32, device=self.device)
+        t.cuda.current_stream(self.device).synchronize()
+        rc = self.lib.cpx_track_limits_batch(
+            self.h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(track_result.filtered_dev.data_ptr()),
+            C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(refs_dev.data_ptr()),
+            C.c_void_p(offs_dev.data_ptr()), n_tracks, C.c_void_p(limits_dev.data_ptr()))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        rc = self.lib.cpx_crop_tile(
+            self.h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(track_result.filtered_dev.data_ptr()),
+            C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(reqs_dev.data_ptr()), int(reqs.size),
+            C.c_void_p(limits_dev.data_ptr()), frame_size, square_width, C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        self.synchronize()
+        limits = limits_dev.cpu().numpy().view(TRACK_LIMITS_DTYPE).reshape(-1)[:n_tracks]
+        return out, limits
 
     def last_kernel_timing(self):
         ms = C.c_float()

@@ -39,6 +39,8 @@ static_assert(sizeof(cpx_component) == 32, "cpx_component layout is part of the 
 static_assert(sizeof(cpx_frame_info) == 80, "cpx_frame_info layout is part of the ABI");
 static_assert(sizeof(cpx_frame_meta) == 24, "cpx_frame_meta layout is part of the ABI");
 static_assert(sizeof(cpx_config) == 40, "cpx_config layout is part of the ABI");
+static_assert(sizeof(cpx_region_ref) == 24 && sizeof(cpx_track_limits) == 16 && sizeof(cpx_crop_req) == 32,
+              "classification request layouts are part of the ABI");
 static_assert(sizeof(cpx_region) == 56, "cpx_region layout is part of the ABI");
 static_assert(sizeof(cpx_track_record) == 32, "cpx_track_record layout is part of the ABI");
 static_assert(sizeof(cpx_track_params) == 120, "cpx_track_params layout is part of the ABI");
@@ -340,6 +342,62 @@ int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int
   a.scores = (cpx::ScoreRec*)(base + o_scores);
   a.used = (unsigned char*)(base + o_used);
   cpx::launch_assoc(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+static cpx::ClassifyArgs classify_args(const cpx_handle* h) {
+  cpx::ClassifyArgs a{};
+  const cpx_config& c = h->cfg;
+  a.W = c.width;
+  a.H = c.height;
+  a.crop_x = c.edge_pixels;
+  a.crop_y = c.edge_pixels;
+  a.crop_w = c.width - 2 * c.edge_pixels;
+  a.crop_h = c.height - 2 * c.edge_pixels;
+  return a;
+}
+
+int cpx_track_limits_batch(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
+                           const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev,
+                           const int32_t* track_offsets_dev, int n_tracks, cpx_track_limits* limits_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !filtered_dev || !info_dev || !refs_dev || !track_offsets_dev || !limits_dev || n_tracks < 0)
+    return fail(h, CPX_ERR_INVALID, "cpx_track_limits_batch: null argument");
+  if (n_tracks == 0) return CPX_OK;
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::ClassifyArgs a = classify_args(h);
+  a.frames = frames_dev;
+  a.filtered = filtered_dev;
+  a.info = info_dev;
+  a.refs = refs_dev;
+  a.track_offsets = track_offsets_dev;
+  a.limits = limits_dev;
+  cpx::launch_limits(a, n_tracks, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
+                  const cpx_frame_info* info_dev, const cpx_crop_req* reqs_dev, int n_reqs,
+                  const cpx_track_limits* limits_dev, int frame_size, int square_width, float* out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !filtered_dev || !info_dev || !reqs_dev || !limits_dev || !out_dev || n_reqs < 0)
+    return fail(h, CPX_ERR_INVALID, "cpx_crop_tile: null argument");
+  if (frame_size < 1 || frame_size > 128 || square_width < 1 || square_width > 16)
+    return fail(h, CPX_ERR_UNSUPPORTED, "cpx_crop_tile: frame_size must be 1..128, square_width 1..16");
+  if (n_reqs == 0) return CPX_OK;
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::ClassifyArgs a = classify_args(h);
+  a.frames = frames_dev;
+  a.filtered = filtered_dev;
+  a.info = info_dev;
+  a.limits = const_cast<cpx_track_limits*>(limits_dev);
+  a.reqs = reqs_dev;
+  a.out = out_dev;
+  a.frame_size = frame_size;
+  a.square_width = square_width;
+  cpx::launch_crop(a, n_reqs, h->stream);
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
 }

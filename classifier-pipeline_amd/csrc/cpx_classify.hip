@@ -1,0 +1,265 @@
+// cpx_classify.hip -- classification pre-processing kernels (HBM-bound):
+//   cpx_limits_kernel : per track, min / max of the filtered crops + clip_thermals_at_zero
+//   cpx_crop_kernel   : per tile, crop -> bilinear resize -> pad -> median shift / clip ->
+//                       normalise -> write into the 5x5 tiled NHWC sample
+// All arithmetic is float32 in the order NumPy evaluates it in the reference
+// (ml_tools/preprocess.py:56-113, ml_tools/imageprocessing.py:11-82,151-169); cv2.resize
+// semantics are SURVEY.md A.8 (half-pixel centres, float32 weights, edge clamp).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "cpx_kernels.h"
+
+namespace cpx {
+
+namespace {
+typedef unsigned int u32;
+
+template <typename T>
+__device__ __forceinline__ T wsum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wmin(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T w = __shfl_xor(v, o);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wmax(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T w = __shfl_xor(v, o);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+constexpr int LT = 256;  // threads of both kernels
+constexpr int LW = LT / 64;
+
+// block-wide reductions through a small LDS scratch (all threads get the result)
+__device__ __forceinline__ float block_min(float v, float* sc) {
+  v = wmin(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sc[0];
+  for (int w = 1; w < LW; ++w) r = fminf(r, sc[w]);
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sc) {
+  v = wmax(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sc[0];
+  for (int w = 1; w < LW; ++w) r = fmaxf(r, sc[w]);
+  return r;
+}
+__device__ __forceinline__ u32 block_sum_u32(u32 v, u32* sc) {
+  v = wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = v;
+  __syncthreads();
+  u32 r = 0;
+  for (int w = 0; w < LW; ++w) r += sc[w];
+  return r;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// get_limits + the clip_thermals_at_zero test, one workgroup per track
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
+  __shared__ float sc[LW];
+  __shared__ u32 scu[LW];
+  const int t = blockIdx.x;
+  const int r0 = a.track_offsets[t], r1 = a.track_offsets[t + 1];
+  const int W = a.W, P = a.W * a.H;
+  float mn = INFINITY, mx = 0.0f;  // max_diff starts at 0, min_diff at None (interpreter.py:316-317)
+  int clip0 = 1;
+  for (int r = r0; r < r1; ++r) {
+    const cpx_region_ref ref = a.refs[r];
+    if (ref.width <= 0 || ref.height <= 0) continue;
+    const int n = ref.width * ref.height;
+    const float* F = a.filtered + (size_t)ref.frame * P;
+    float lmn = INFINITY, lmx = -INFINITY;
+    for (int k = threadIdx.x; k < n; k += LT) {
+      const int yy = k / ref.width;
+      const float v = F[(ref.y + yy) * W + ref.x + (k - yy * ref.width)];
+      lmn = fminf(lmn, v);
+      lmx = fmaxf(lmx, v);
+    }
+    mn = fminf(mn, lmn);
+    mx = fmaxf(mx, lmx);
+    if (ref.in_segment && clip0) {
+      // np.median(float32(crop) - median) <= 0  <=>  lower + upper middle order statistics <= 2 * median
+      const uint16_t* T = a.frames + (size_t)ref.frame * P;
+      u32 vmin = 0xFFFFFFFFu, vmax = 0;
+      for (int k = threadIdx.x; k < n; k += LT) {
+        const int yy = k / ref.width;
+        const u32 v = T[(ref.y + yy) * W + ref.x + (k - yy * ref.width)];
+        vmin = min(vmin, v);
+        vmax = max(vmax, v);
+      }
+      u32 lo = (u32)block_min((float)vmin, sc), hi = (u32)block_max((float)vmax, sc);  // u16 values: exact in float
+      const u32 k1 = (u32)((n - 1) >> 1), k2 = (u32)(n >> 1);
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        u32 cnt = 0;
+        for (int k = threadIdx.x; k < n; k += LT) {
+          const int yy = k / ref.width;
+          cnt += (u32)T[(ref.y + yy) * W + ref.x + (k - yy * ref.width)] <= mid;
+        }
+        cnt = block_sum_u32(cnt, scu);
+        if (cnt >= k1 + 1) hi = mid;
+        else lo = mid + 1;
+      }
+      u32 cnt = 0, nxt = 0xFFFFFFFFu;
+      for (int k = threadIdx.x; k < n; k += LT) {
+        const int yy = k / ref.width;
+        const u32 v = T[(ref.y + yy) * W + ref.x + (k - yy * ref.width)];
+        cnt += v <= lo;
+        nxt = (v > lo && v < nxt) ? v : nxt;
+      }
+      cnt = block_sum_u32(cnt, scu);
+      const float nx = block_min(nxt == 0xFFFFFFFFu ? 1e9f : (float)nxt, sc);
+      const float v2 = (cnt >= k2 + 1) ? (float)lo : nx;
+      const float med = a.info[ref.frame].thermal_median;
+      // ((lo - med) + (v2 - med)) / 2 <= 0 in float32 (differences of a u16 and a k/2 value are exact)
+      const float m2 = __fmul_rn(__fadd_rn(__fsub_rn((float)lo, med), __fsub_rn(v2, med)), 0.5f);
+      if (m2 <= 0.0f) clip0 = 0;
+    }
+  }
+  mn = block_min(mn, sc);
+  mx = block_max(mx, sc);
+  if (threadIdx.x == 0) {
+    cpx_track_limits o;
+    o.filt_min = mn;
+    o.filt_max = mx;
+    o.clip_at_zero = clip0;
+    o.reserved = 0;
+    a.limits[t] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// one tile per workgroup
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_coord(int d, int dn, int sn, int* i0, int* i1, float* w) {
+  // cv2.resize INTER_LINEAR source coordinate
+  const double scale = (double)sn / (double)dn;
+  const float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  float a = __fsub_rn(f, (float)s);
+  if (s < 0) {
+    a = 0.0f;
+    s = 0;
+  }
+  if (s >= sn - 1) {
+    a = 0.0f;
+    s = sn - 1;
+  }
+  *i0 = s;
+  *i1 = (s + 1 < sn) ? s + 1 : sn - 1;
+  *w = a;
+}
+
+__global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_t = reinterpret_cast<float*>(smem);  // [fs*fs] thermal tile
+  __shared__ float sc[LW];
+  const cpx_crop_req q = a.reqs[blockIdx.x];
+  const int fs = a.frame_size, sq = a.square_width;
+  const int W = a.W, P = a.W * a.H;
+  const uint16_t* T = a.frames + (size_t)q.frame * P;
+  const float* F = a.filtered + (size_t)q.frame * P;
+  const int rw = q.width, rh = q.height;
+  const cpx_track_limits lim = a.limits[q.track];
+  const float median = a.info[q.frame].thermal_median;
+  // ---- resize_and_pad geometry (imageprocessing.py:24-60) ----
+  const double sh = (double)fs / (double)rh, sw = (double)fs / (double)rw;
+  const double scale = sh < sw ? sh : sw;
+  int dw = (int)rint((double)rw * scale), dh = (int)rint((double)rh * scale);  // Python round(): half to even
+  dw = dw < 1 ? 1 : (dw > fs ? fs : dw);
+  dh = dh < 1 ? 1 : (dh > fs ? fs : dh);
+  int ox = (fs - dw) / 2, oy = (fs - dh) / 2;
+  const int cx = a.crop_x, cy = a.crop_y, cr = a.crop_x + a.crop_w, cb = a.crop_y + a.crop_h;
+  if (q.x <= cx) ox = 0;                      // min(edge_offset[0] = 0, fs - dw)
+  else if (q.x + rw >= cr) ox = fs - dw;      // max(fs - 0 - dw, 0)
+  if (q.y <= cy) oy = 0;
+  else if (q.y + rh >= cb) oy = fs - dh;
+  // ---- pad value of the thermal channel: min of the crop (imageprocessing.py:38-39) ----
+  float pmin = INFINITY;
+  for (int k = threadIdx.x; k < rw * rh; k += LT) {
+    const int yy = k / rw;
+    pmin = fminf(pmin, (float)T[(q.y + yy) * W + q.x + (k - yy * rw)]);
+  }
+  pmin = block_min(pmin, sc);
+  // ---- both channels: bilinear sample (two float32 passes), paste, per-pixel ops ----
+  const int n = fs * fs;
+  const int ty = q.tile / sq, tx = q.tile - ty * sq;
+  const int OW = sq * fs;
+  float* out = a.out + ((size_t)q.sample * OW + (size_t)ty * fs) * OW * 2 + (size_t)tx * fs * 2;
+  float tmn = INFINITY, tmx = -INFINITY;
+  const float fspan = __fsub_rn(lim.filt_max, lim.filt_min);
+  for (int k = threadIdx.x; k < n; k += LT) {
+    const int yy = k / fs, xx = k - yy * fs;
+    float tv = pmin, fv = 0.0f;
+    const int ry = yy - oy, rx = xx - ox;
+    if (ry >= 0 && ry < dh && rx >= 0 && rx < dw) {
+      int x0, x1, y0, y1;
+      float ax, ay;
+      lin_coord(rx, dw, rw, &x0, &x1, &ax);
+      lin_coord(ry, dh, rh, &y0, &y1, &ay);
+      const float bx = __fsub_rn(1.0f, ax), by = __fsub_rn(1.0f, ay);
+      const int r0 = (q.y + y0) * W + q.x, r1 = (q.y + y1) * W + q.x;
+      const float t00 = (float)T[r0 + x0], t01 = (float)T[r0 + x1], t10 = (float)T[r1 + x0], t11 = (float)T[r1 + x1];
+      const float th0 = __fadd_rn(__fmul_rn(t00, bx), __fmul_rn(t01, ax));
+      const float th1 = __fadd_rn(__fmul_rn(t10, bx), __fmul_rn(t11, ax));
+      tv = __fadd_rn(__fmul_rn(th0, by), __fmul_rn(th1, ay));
+      const float f00 = F[r0 + x0], f01 = F[r0 + x1], f10 = F[r1 + x0], f11 = F[r1 + x1];
+      const float fh0 = __fadd_rn(__fmul_rn(f00, bx), __fmul_rn(f01, ax));
+      const float fh1 = __fadd_rn(__fmul_rn(f10, bx), __fmul_rn(f11, ax));
+      fv = __fadd_rn(__fmul_rn(fh0, by), __fmul_rn(fh1, ay));
+    }
+    // thermal: -= median ; clip at 0 (preprocess.py:87-90)
+    tv = __fsub_rn(tv, median);
+    if (lim.clip_at_zero && tv < 0.0f) tv = 0.0f;
+    s_t[k] = tv;
+    tmn = fminf(tmn, tv);
+    tmx = fmaxf(tmx, tv);
+    // filtered: normalize(min, max of the track, new_max = 255) (preprocess.py:92-98)
+    float fo;
+    if (lim.filt_max == lim.filt_min) fo = (lim.filt_max == 0.0f) ? 0.0f : __fdiv_rn(fv, lim.filt_max);
+    else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, lim.filt_min)), fspan);
+    out[((size_t)yy * OW + xx) * 2 + 1] = fo;
+  }
+  tmn = block_min(tmn, sc);
+  tmx = block_max(tmx, sc);
+  // thermal: normalize over the tile itself (preprocess.py:99-106)
+  const float tspan = __fsub_rn(tmx, tmn);
+  for (int k = threadIdx.x; k < n; k += LT) {
+    const int yy = k / fs, xx = k - yy * fs;
+    const float tv = s_t[k];
+    float to;
+    if (tmx == tmn) to = (tmx == 0.0f) ? 0.0f : __fdiv_rn(tv, tmx);
+    else to = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(tv, tmn)), tspan);
+    out[((size_t)yy * OW + xx) * 2] = to;
+  }
+}
+
+void launch_limits(const ClassifyArgs& a, int n_tracks, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_limits_kernel, dim3(n_tracks), dim3(LT), 0, s, a);
+}
+void launch_crop(const ClassifyArgs& a, int n_reqs, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_crop_kernel, dim3(n_reqs), dim3(LT), (size_t)a.frame_size * a.frame_size * sizeof(float), s, a);
+}
+
+}  // namespace cpx

@@ -89,6 +89,21 @@ void launch_assoc(const AssocArgs& a, hipStream_t s);
 size_t assoc_active_bytes();
 size_t assoc_score_bytes();
 
+struct ClassifyArgs {
+  int W, H, crop_x, crop_y, crop_w, crop_h;
+  int frame_size, square_width;
+  const uint16_t* frames;
+  const float* filtered;
+  const FrameInfo* info;
+  const cpx_region_ref* refs;
+  const int* track_offsets;
+  cpx_track_limits* limits;
+  const cpx_crop_req* reqs;
+  float* out;
+};
+void launch_limits(const ClassifyArgs& a, int n_tracks, hipStream_t s);
+void launch_crop(const ClassifyArgs& a, int n_reqs, hipStream_t s);
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

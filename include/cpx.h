@@ -180,6 +180,44 @@ int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int
                         cpx_track_record* tracks_dev, int32_t* n_tracks_dev, int32_t* status_dev,
                         cpx_region* regions_dev, int32_t* region_counts_dev);
 
+/* ---- classification pre-processing: limits + crop / resize / normalise / tile ---------
+ * Replaces Interpreter.get_limits / preprocess_segments (ml_tools/interpreter.py:315-474),
+ * preprocess_frame (ml_tools/preprocess.py:56-113), resize_and_pad / resize_cv
+ * (ml_tools/imageprocessing.py:11-82) and preprocess_movement / square_clip
+ * (ml_tools/preprocess.py:151-202, ml_tools/imageprocessing.py:85-104) for channels
+ * (thermal, filtered) with diff_norm = True, thermal_diff_norm = False, keep_edge = True.
+ */
+typedef struct cpx_region_ref { /* one non-blank region of a track */
+  int32_t frame;                /* index into frames_dev / filtered_dev / info_dev */
+  int32_t x, y, width, height;
+  int32_t in_segment;           /* 1: the frame is used by a segment (clip_thermals_at_zero test) */
+} cpx_region_ref;
+
+typedef struct cpx_track_limits { /* per track */
+  float filt_min, filt_max;       /* filtered_norm_limits: min / max over the track's region crops, max >= 0 */
+  int32_t clip_at_zero;           /* clip_thermals_at_zero (interpreter.py:372-399) */
+  int32_t reserved;
+} cpx_track_limits;
+
+typedef struct cpx_crop_req { /* one tile = one frame of one segment */
+  int32_t frame;
+  int32_t x, y, width, height; /* the track's region in that frame */
+  int32_t track;               /* index into limits_dev */
+  int32_t sample;              /* output sample (segment) index */
+  int32_t tile;                /* 0 .. square_width^2 - 1, row-major */
+} cpx_crop_req;
+
+/* refs_dev: regions of all tracks, track t owns [track_offsets[t], track_offsets[t+1]) (device arrays). */
+int cpx_track_limits_batch(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
+                           const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev,
+                           const int32_t* track_offsets_dev, int n_tracks, cpx_track_limits* limits_dev);
+
+/* out_dev: float [n_samples, square_width*frame_size, square_width*frame_size, 2] (NHWC; thermal, filtered).
+ * Every tile of every sample must be covered by exactly one request. */
+int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
+                  const cpx_frame_info* info_dev, const cpx_crop_req* reqs_dev, int n_reqs,
+                  const cpx_track_limits* limits_dev, int frame_size, int square_width, float* out_dev);
+
 /* Bytes of device workspace cpx_track_batch needs for B clips / total frames
  * (allocated lazily inside the handle and reused). */
 size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames);

@@ -1,0 +1,133 @@
+"""GPU parity of the classification pre-processing (limits, crop / resize /
+normalise / 5x5 tiling): HIP kernels against the network inputs the reference's
+own Interpreter.classify_track produced for the fixture clips (bit for bit) and
+against the oracle on synthetic tracks."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_clip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3")
+    yield eng
+    eng.close()
+
+
+def _requests(tracks_regions, segments_per_track, frame_of):
+    """tracks_regions: list of region lists (objects with x,y,width,height,frame_number,blank);
+    segments_per_track: list of [S,25] frame-number arrays -> (refs, offsets, reqs, n_samples)."""
+    from cpx._lib import CROP_REQ_DTYPE, REGION_REF_DTYPE
+
+    refs, offs, reqs = [], [0], []
+    sample = 0
+    for ti, (regions, segs) in enumerate(zip(tracks_regions, segments_per_track)):
+        used = set(int(f) for s in segs for f in s)
+        by_frame = {}
+        for r in regions:
+            by_frame[r.frame_number] = r
+            if r.blank or r.width <= 0 or r.height <= 0:
+                continue
+            refs.append((frame_of(r.frame_number), r.x, r.y, r.width, r.height, 1 if r.frame_number in used else 0))
+        offs.append(len(refs))
+        for s in segs:
+            for tile, fn in enumerate(s):
+                r = by_frame[int(fn)]
+                reqs.append((frame_of(int(fn)), r.x, r.y, r.width, r.height, ti, sample, tile))
+            sample += 1
+    return (np.array(refs, dtype=REGION_REF_DTYPE), np.array(offs, np.int32), np.array(reqs, dtype=CROP_REQ_DTYPE),
+            sample)
+
+
+@pytest.mark.parametrize("name,fs", [("possum", 32), ("hedgehog", 32), ("hedgehog", 64)])
+def test_crop_tile_matches_reference_network_inputs(engine, name, fs):
+    import track_oracle as to
+
+    frames, t_on, ffc, bgf, hdr = load_clip(name)
+    z = np.load(os.path.join(GOLDEN, "%s_classify_fs%d.npz" % (name, fs)))
+    with open(os.path.join(GOLDEN, "%s_classify_fs%d.json" % (name, fs))) as fh:
+        meta = json.load(fh)
+    n = frames.shape[0]
+    dev = engine.upload_frames(frames)
+    offs = np.array([0, n], np.int32)
+    m = engine.make_meta(n, t_on, ffc, bgf)
+    res = engine.track_batch(dev, offs, m, want_filtered=True)
+    res.check()
+    # the tracks (regions) come from the oracle tracker == the reference's tracks (test_oracle_golden)
+    out = to.track_clip(frames, t_on, ffc, bgf, to.OracleConfig(hdr.model), keep=True)
+    proc = [i for i in range(n) if not bgf[i]]
+    regions = [t.bounds for t in out["tracks"]]
+    segs = [z["t%d_segments" % i] for i in range(len(regions))]
+    refs, toffs, reqs, ns = _requests(regions, segs, lambda q: proc[q])
+    x, limits = engine.preprocess_segments(dev, res, refs, toffs, reqs, ns, frame_size=fs)
+    x = x.cpu().numpy()
+    s0 = 0
+    for i in range(len(regions)):
+        want = z["t%d_input" % i]
+        got = x[s0:s0 + want.shape[0]]
+        assert np.array_equal(got, want), (name, i, float(np.abs(got - want).max()))
+        s0 += want.shape[0]
+    assert len(meta["tracks"]) == len(regions)
+
+
+def test_crop_tile_matches_oracle_on_synthetic_tracks(engine):
+    """Synthetic clips: regions from the oracle tracker, random 25-frame segments (with repeats),
+    regions touching the frame edges included."""
+    import classify_oracle as co
+    import track_oracle as to
+    from cpx import synth
+
+    rng = np.random.default_rng(21)
+    clips = [synth.make_clip(rng, 120, max_blobs=3) for _ in range(4)]
+    T = 120
+    offs = (np.arange(5) * T).astype(np.int32)
+    allf = np.concatenate(clips)
+    dev = engine.upload_frames(allf)
+    res = engine.track_batch(dev, offs, engine.make_meta(4 * T), want_filtered=True)
+    res.check()
+    tracks_regions, segs_all, frame_of_track, oracle_x = [], [], [], []
+    for b in range(4):
+        out = to.track_clip(clips[b], cfg=to.OracleConfig("lepton3"), keep=True)
+        fr = out["frames"]
+        for t in out["tracks"]:
+            valid = [r.frame_number for r in t.bounds if not r.blank and r.mass > 0 and r.width > 0 and r.height > 0]
+            if len(valid) < 6:
+                continue
+            segs = [np.sort(rng.choice(valid, 25, replace=True)) for _ in range(2)]
+            by_frame = {r.frame_number: r for r in t.bounds}
+            x, _ = co.preprocess_segments(lambda q: clips[b][q], lambda q: fr[q]["filtered"].astype(np.float64),
+                                          by_frame, t.bounds, segs, 32, (1, 1, 158, 118))
+            tracks_regions.append(t.bounds)
+            segs_all.append(segs)
+            frame_of_track.append(b)
+            oracle_x.append(x)
+    assert len(tracks_regions) >= 3
+    # frame index mapping differs per track (clip b): build requests track by track
+    from cpx._lib import CROP_REQ_DTYPE, REGION_REF_DTYPE
+
+    refs_l, offs_l, reqs_l, sample = [], [0], [], 0
+    for ti, (regions, segs) in enumerate(zip(tracks_regions, segs_all)):
+        base = int(offs[frame_of_track[ti]])
+        r, o, q, ns = _requests([regions], [segs], lambda fn: base + fn)
+        q["track"] = ti
+        q["sample"] += sample
+        sample += ns
+        refs_l.append(r)
+        offs_l.append(offs_l[-1] + len(r))
+        reqs_l.append(q)
+    x, limits = engine.preprocess_segments(dev, res, np.concatenate(refs_l), np.array(offs_l, np.int32),
+                                           np.concatenate(reqs_l), sample)
+    x = x.cpu().numpy()
+    s0 = 0
+    for want in oracle_x:
+        got = x[s0:s0 + want.shape[0]]
+        assert np.array_equal(got, want), float(np.abs(got - want).max())
+        s0 += want.shape[0]
