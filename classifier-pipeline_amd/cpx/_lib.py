@@ -65,7 +65,7 @@ assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FR
 EXPORTS = [
     "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
-    "cpx_track_limits_batch", "cpx_crop_tile",
+    "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
 ]
 
 _lib = None
@@ -107,6 +107,10 @@ def load():
     lib.cpx_track_limits_batch.restype = C.c_int
     lib.cpx_crop_tile.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
     lib.cpx_crop_tile.restype = C.c_int
+    lib.cpx_conv2d.argtypes = [vp, vp]
+    lib.cpx_conv2d.restype = C.c_int
+    lib.cpx_cnn_head.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
+    lib.cpx_cnn_head.restype = C.c_int
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]

@@ -1,0 +1,212 @@
+"""WR-ResNet-22-4 (grouped pre-activation wide ResNet) weights container and the
+device forward pass (reference architecture src/ml_tools/resnet/wr_resnet.py:5-98, head
+src/ml_tools/kerasmodel.py:308-350).
+
+Weights are kept in Keras layouts under the Keras layer names so that an exported model can
+be converted 1:1:
+  conv  '<name>/kernel' [kh, kw, Cin/groups, Cout] (HWIO), '<name>/bias' [Cout]
+  bn    '<name>/gamma|beta|moving_mean|moving_variance' [C]      (epsilon = 1e-3)
+  dense 'prediction/kernel' [C, n_labels], 'prediction/bias'
+Layer names: conv1_1; res{s}b{d}_branch2a|2b, bn{s}b{d}_branch2a|2b for stage s = 2..4, block
+d = 0..2; shortcut{s} (the 1x1 projection of each stage's first block); final_bn; prediction.
+"""
+
+import ctypes as C
+import json
+
+import numpy as np
+
+from .._lib import CpxError
+
+BN_EPS = 1e-3  # tf.keras.layers.BatchNormalization default
+FILTERS = (16, 64, 128, 256)
+GROUPS = 2
+BLOCKS = 3
+
+
+def layer_plan(n_labels):
+    """-> list of (name, kind, shape) in forward order."""
+    plan = [("conv1_1", "conv", (3, 3, 2 // GROUPS, FILTERS[0]))]
+    cin = FILTERS[0]
+    for stage in (2, 3, 4):
+        f = FILTERS[stage - 1]
+        for d in range(BLOCKS):
+            b = "b%d" % d
+            c_in = cin if d == 0 else f
+            plan.append(("bn%d%s_branch2a" % (stage, b), "bn", (c_in,)))
+            plan.append(("res%d%s_branch2a" % (stage, b), "conv", (3, 3, c_in // GROUPS, f)))
+            plan.append(("bn%d%s_branch2b" % (stage, b), "bn", (f,)))
+            plan.append(("res%d%s_branch2b" % (stage, b), "conv", (3, 3, f // GROUPS, f)))
+            if d == 0:
+                plan.append(("shortcut%d" % stage, "conv", (1, 1, c_in // GROUPS, f)))
+        cin = f
+    plan.append(("final_bn", "bn", (cin,)))
+    plan.append(("prediction", "dense", (cin, n_labels)))
+    return plan
+
+
+def random_weights(n_labels=17, seed=0):
+    """Seeded Glorot-uniform kernels, small random biases and BatchNorm statistics (no checkpoint
+    can be downloaded here): same architecture, same layouts."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, kind, shape in layer_plan(n_labels):
+        if kind == "conv":
+            kh, kw, ci, co = shape
+            fan_in, fan_out = kh * kw * ci, kh * kw * co // GROUPS
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            w[name + "/kernel"] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            w[name + "/bias"] = rng.normal(0, 0.05, size=co).astype(np.float32)
+        elif kind == "bn":
+            (c,) = shape
+            w[name + "/gamma"] = rng.uniform(0.7, 1.3, size=c).astype(np.float32)
+            w[name + "/beta"] = rng.normal(0, 0.1, size=c).astype(np.float32)
+            w[name + "/moving_mean"] = rng.normal(0, 0.1, size=c).astype(np.float32)
+            w[name + "/moving_variance"] = rng.uniform(0.5, 1.5, size=c).astype(np.float32)
+        else:
+            ci, co = shape
+            lim = np.sqrt(6.0 / (ci + co))
+            w[name + "/kernel"] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            w[name + "/bias"] = rng.normal(0, 0.05, size=co).astype(np.float32)
+    return w
+
+
+def save_model(path_base, weights, labels, hyperparams=None, thresholds=None, model_type="thermal"):
+    """<path>.npz (weights) + <path>.json (labels / hyperparams sidecar as interpreter.py:23-41 reads it)."""
+    np.savez(str(path_base) + ".npz", **weights)
+    meta = {"labels": list(labels), "hyperparams": dict(hyperparams or {}), "thresholds": thresholds,
+            "type": model_type, "version": "cpx-wr-resnet-22-4"}
+    with open(str(path_base) + ".json", "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+
+def load_weights(path):
+    z = np.load(str(path))
+    return {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+
+
+def bn_affine(w, name):
+    """BatchNorm in inference mode as y = x * scale + shift."""
+    scale = w[name + "/gamma"] / np.sqrt(w[name + "/moving_variance"] + np.float32(BN_EPS))
+    shift = w[name + "/beta"] - w[name + "/moving_mean"] * scale
+    return scale.astype(np.float32), shift.astype(np.float32)
+
+
+def pack_conv(kernel):
+    """Keras HWIO [kh,kw,Cin/g,Cout] -> [g][kh*kw][Cin/g][Cout/g] contiguous."""
+    kh, kw, ci, co = kernel.shape
+    cog = co // GROUPS
+    k = kernel.reshape(kh * kw, ci, GROUPS, cog)
+    return np.ascontiguousarray(np.transpose(k, (2, 0, 1, 3)), dtype=np.float32)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "Cout", "groups", "ksize", "stride", "pad_same", "relu")] + \
+               [(n, C.c_void_p) for n in ("in_dev", "out_dev", "weights_dev", "in_scale_dev", "in_shift_dev",
+                                          "out_scale_dev", "out_shift_dev", "residual_dev")]
+
+
+assert C.sizeof(ConvDesc) == 104
+
+
+class WRResNetDevice:
+    """The network resident on one GPU; forward() runs 23 kernel launches on the engine's stream."""
+
+    def __init__(self, engine, weights, n_labels):
+        self.eng = engine
+        self.lib = engine.lib
+        self.torch = t = engine.torch
+        self.n_labels = n_labels
+        dev = engine.device
+
+        def up(a):
+            return t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        self.p = {}
+        w = weights
+        self.p["conv1_1/w"] = up(pack_conv(w["conv1_1/kernel"]))
+        self.p["conv1_1/b"] = up(w["conv1_1/bias"])
+        for stage in (2, 3, 4):
+            for d in range(BLOCKS):
+                b = "%db%d" % (stage, d)
+                sa, ha = bn_affine(w, "bn%s_branch2a" % b)
+                sb, hb = bn_affine(w, "bn%s_branch2b" % b)
+                self.p["%s/in_scale" % b] = up(sa)
+                self.p["%s/in_shift" % b] = up(ha)
+                self.p["%s/wa" % b] = up(pack_conv(w["res%s_branch2a/kernel" % b]))
+                # conv2a bias + the following BatchNorm folded: (acc + bias) * sb + hb
+                self.p["%s/a_scale" % b] = up(sb)
+                self.p["%s/a_shift" % b] = up(w["res%s_branch2a/bias" % b] * sb + hb)
+                self.p["%s/wb" % b] = up(pack_conv(w["res%s_branch2b/kernel" % b]))
+                self.p["%s/bb" % b] = up(w["res%s_branch2b/bias" % b])
+            self.p["sc%d/w" % stage] = up(pack_conv(w["shortcut%d/kernel" % stage]))
+            self.p["sc%d/b" % stage] = up(w["shortcut%d/bias" % stage])
+        fs, fh = bn_affine(w, "final_bn")
+        self.p["final/scale"], self.p["final/shift"] = up(fs), up(fh)
+        self.p["dense/w"] = up(w["prediction/kernel"])
+        self.p["dense/b"] = up(w["prediction/bias"])
+        self._bufs = {}
+
+    def _buf(self, key, shape):
+        t = self.torch
+        b = self._bufs.get(key)
+        n = int(np.prod(shape))
+        if b is None or b.numel() < n:
+            b = t.empty(n, dtype=t.float32, device=self.eng.device)
+            self._bufs[key] = b
+        return b[:n].view(*shape)
+
+    def _conv(self, x, out, wkey, N, H, W, Cin, Cout, ksize, stride, same, relu, in_affine=None, out_scale=None,
+              out_shift=None, residual=None):
+        ptr = lambda v: None if v is None else C.c_void_p(v.data_ptr())
+        d = ConvDesc(N, H, W, Cin, Cout, GROUPS, ksize, stride, 1 if same else 0, 1 if relu else 0,
+                     ptr(x), ptr(out), ptr(self.p[wkey]),
+                     ptr(self.p[in_affine + "/in_scale"]) if in_affine else None,
+                     ptr(self.p[in_affine + "/in_shift"]) if in_affine else None,
+                     ptr(out_scale), ptr(out_shift), ptr(residual))
+        rc = self.lib.cpx_conv2d(self.eng.h, C.byref(d))
+        if rc != 0:
+            raise CpxError(rc, self.eng._err())
+
+    def forward(self, x, want_probs=True):
+        """x: device float32 [N, S, S, 2] (values 0..255, no input scaling) -> (logits, probs) [N, n_labels]."""
+        t = self.torch
+        N, H, W, cin = x.shape
+        assert cin == 2 and x.dtype == t.float32 and x.is_contiguous()
+        t.cuda.current_stream(self.eng.device).synchronize()
+        cur = self._buf("act0", (N, H, W, FILTERS[0]))
+        self._conv(x, cur, "conv1_1/w", N, H, W, 2, FILTERS[0], 3, 1, True, False, out_shift=self.p["conv1_1/b"])
+        c_in, flip = FILTERS[0], 0
+        for stage in (2, 3, 4):
+            f = FILTERS[stage - 1]
+            stride = stage - 1  # wr_block(stride=stage) with stage index 1..3 (wr_resnet.py:27-30)
+            for d in range(BLOCKS):
+                b = "%db%d" % (stage, d)
+                s = stride if d == 0 else 1
+                Ho, Wo = -(-H // s), -(-W // s)
+                mid = self._buf("mid", (N, Ho, Wo, f))
+                self._conv(cur, mid, "%s/wa" % b, N, H, W, c_in, f, 3, s, True, True, in_affine=b,
+                           out_scale=self.p["%s/a_scale" % b], out_shift=self.p["%s/a_shift" % b])
+                if d == 0:
+                    sc = self._buf("sc", (N, Ho, Wo, f))
+                    self._conv(cur, sc, "sc%d/w" % stage, N, H, W, c_in, f, 1, s, False, False,
+                               out_shift=self.p["sc%d/b" % stage])
+                    res = sc
+                else:
+                    res = cur
+                flip ^= 1
+                nxt = self._buf("act%d" % flip, (N, Ho, Wo, f))
+                self._conv(mid, nxt, "%s/wb" % b, N, Ho, Wo, f, f, 3, 1, True, True, out_shift=self.p["%s/bb" % b],
+                           residual=res)
+                cur, H, W, c_in = nxt, Ho, Wo, f
+        logits = t.empty((N, self.n_labels), dtype=t.float32, device=self.eng.device)
+        probs = t.empty((N, self.n_labels), dtype=t.float32, device=self.eng.device) if want_probs else None
+        rc = self.lib.cpx_cnn_head(self.eng.h, C.c_void_p(cur.data_ptr()), N, H * W, c_in,
+                                   C.c_void_p(self.p["final/scale"].data_ptr()), C.c_void_p(self.p["final/shift"].data_ptr()),
+                                   C.c_void_p(self.p["dense/w"].data_ptr()), C.c_void_p(self.p["dense/b"].data_ptr()),
+                                   self.n_labels, C.c_void_p(logits.data_ptr()),
+                                   C.c_void_p(probs.data_ptr()) if probs is not None else None)
+        if rc != 0:
+            raise CpxError(rc, self.eng._err())
+        self.eng.synchronize()
+        return logits, probs

@@ -402,6 +402,56 @@ int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filter
   return CPX_OK;
 }
 
+int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!d || !d->in_dev || !d->out_dev || !d->weights_dev) return fail(h, CPX_ERR_INVALID, "cpx_conv2d: null argument");
+  if (d->N < 1 || d->H < 1 || d->W < 1 || d->groups < 1 || d->Cin % d->groups || d->Cout % d->groups ||
+      d->ksize < 1 || d->stride < 1 || (d->in_scale_dev == nullptr) != (d->in_shift_dev == nullptr))
+    return fail(h, CPX_ERR_INVALID, "cpx_conv2d: bad descriptor");
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::ConvArgs a{};
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups;
+  a.ksize = d->ksize; a.stride = d->stride; a.relu = d->relu;
+  if (d->pad_same) {  // TensorFlow SAME: out = ceil(in / stride), surplus padding goes to the bottom / right
+    a.Ho = (d->H + d->stride - 1) / d->stride;
+    a.Wo = (d->W + d->stride - 1) / d->stride;
+    const int ph = std::max((a.Ho - 1) * d->stride + d->ksize - d->H, 0);
+    const int pw = std::max((a.Wo - 1) * d->stride + d->ksize - d->W, 0);
+    a.pad_top = ph / 2;
+    a.pad_left = pw / 2;
+  } else {
+    if (d->H < d->ksize || d->W < d->ksize) return fail(h, CPX_ERR_INVALID, "cpx_conv2d: input smaller than kernel");
+    a.Ho = (d->H - d->ksize) / d->stride + 1;
+    a.Wo = (d->W - d->ksize) / d->stride + 1;
+    a.pad_top = a.pad_left = 0;
+  }
+  a.in = d->in_dev; a.out = d->out_dev; a.weights = d->weights_dev;
+  a.in_scale = d->in_scale_dev; a.in_shift = d->in_shift_dev;
+  a.out_scale = d->out_scale_dev; a.out_shift = d->out_shift_dev; a.residual = d->residual_dev;
+  const int rc = cpx::launch_conv(a, h->stream);
+  if (rc == -2) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_conv2d: no kernel for this (channels per group, stride, kernel size)");
+  if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_conv2d: kernel configuration failed");
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
+                 const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
+                 float* logits_dev, float* probs_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!in_dev || !bn_scale_dev || !bn_shift_dev || !dense_w_dev || !dense_b_dev || !logits_dev || N < 1 || HW < 1 ||
+      C < 1 || L < 1 || C > 8192)
+    return fail(h, CPX_ERR_INVALID, "cpx_cnn_head: bad argument");
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::HeadArgs a{};
+  a.N = N; a.HW = HW; a.C = C; a.L = L;
+  a.in = in_dev; a.bn_scale = bn_scale_dev; a.bn_shift = bn_shift_dev;
+  a.dense_w = dense_w_dev; a.dense_b = dense_b_dev; a.logits = logits_dev; a.probs = probs_dev;
+  cpx::launch_head(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches) {
   if (!h || !total_ms || !launches) return CPX_ERR_INVALID;
   if (!h->timing_valid) return fail(h, CPX_ERR_INVALID, "no batch has been run");

@@ -1,0 +1,231 @@
+// cpx_cnn.hip -- WR-ResNet forward on gfx950 matrix cores (reference architecture:
+// ml_tools/resnet/wr_resnet.py:5-98; head ml_tools/kerasmodel.py:308-350).
+//
+// Grouped KxK convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32 in /
+// f32 accumulate: the logits must match the exported TF model to 1e-3):
+//   M = output pixels (one 8x16 tile per workgroup, 32 pixels per wave)
+//   N = output channels of one group (32 per MFMA tile, NTN tiles per wave)
+//   K = KS*KS*Cin_g, walked as (cin chunk of KC) x (tap) x (pair of channels)
+// Activations are NHWC f32.  The pre-activation BatchNorm + ReLU of a block is applied
+// while the input patch is staged into LDS (padding stays exactly 0 afterwards, as in
+// TF); bias, the following BatchNorm (folded on the host into scale / shift), the
+// residual add and ReLU are applied from the accumulators before the single store.
+#include <hip/hip_runtime.h>
+
+#include "cpx_kernels.h"
+
+namespace cpx {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8, TW = 16;  // output tile (pixels) of a workgroup; wave w owns rows 2w, 2w+1
+constexpr int CT = 256;
+
+template <int KC, int NTN, int S, int KS>
+__global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+  constexpr int KP = KC + 1;          // padded channel stride of a patch pixel (bank spread)
+  constexpr int COG = 32 * NTN;       // output channels per group
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* s_patch = lds;                      // [PH*PW][KP]
+  float* s_w = lds + PH * PW * KP;           // [KS*KS][KC][COG]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int txi = bid % tiles_x;
+  bid /= tiles_x;
+  const int tyi = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int g = blockIdx.y;
+  const int cin_g = a.Cin / a.groups;
+  const int oy0 = tyi * TH, ox0 = txi * TW;
+  const int iy0 = oy0 * S - a.pad_top, ix0 = ox0 * S - a.pad_left;
+  const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
+  const float* wg = a.weights + (size_t)g * KS * KS * cin_g * COG;
+
+  f32x16 acc[NTN];
+#pragma unroll
+  for (int t = 0; t < NTN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  // this lane's pixel inside the wave tile and its k half
+  const int pi = lane & 31, kh = lane >> 5;
+  const int prow = 2 * wave + (pi >> 4), pcol = pi & 15;
+  const int a_base = ((prow * S) * PW + pcol * S) * KP + kh;
+  const int b_base = kh * COG + (lane & 31);
+
+  for (int cc = 0; cc < cin_g; cc += KC) {
+    // ---- stage the input patch chunk (BN + ReLU prologue; zero padding) ----
+    for (int idx = tid; idx < PH * PW * KC; idx += CT) {
+      const int c = idx % KC;
+      const int px = idx / KC;
+      const int py = px / PW, pxx = px - py * PW;
+      const int iy = iy0 + py, ix = ix0 + pxx;
+      float v = 0.0f;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        v = in_n[((size_t)iy * a.W + ix) * a.Cin + cc + c];
+        if (a.in_scale) {
+          const int ch = g * cin_g + cc + c;
+          v = fmaxf(v * a.in_scale[ch] + a.in_shift[ch], 0.0f);
+        }
+      }
+      s_patch[px * KP + c] = v;
+    }
+    // ---- stage the weight chunk [tap][KC][COG] ----
+    for (int idx = tid; idx < KS * KS * KC * COG; idx += CT) {
+      const int co = idx % COG;
+      const int r = idx / COG;
+      const int k = r % KC, tap = r / KC;
+      s_w[idx] = wg[((size_t)tap * cin_g + cc + k) * COG + co];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const float* ap = s_patch + a_base + (ky * PW + kx) * KP;
+      const float* bp = s_w + tap * KC * COG + b_base;
+#pragma unroll
+      for (int k2 = 0; k2 < KC / 2; ++k2) {
+        const float av = ap[2 * k2];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+          const float bv = bp[(2 * k2) * COG + t * 32];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: affine (bias / folded BN), residual, ReLU, store NHWC ----
+  float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
+  const float* res_n = a.residual ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+#pragma unroll
+  for (int t = 0; t < NTN; ++t) {
+    const int ch = g * COG + t * 32 + (lane & 31);
+    const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+    const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
+      const int oy = oy0 + 2 * wave + (i >> 4), ox = ox0 + (i & 15);
+      if (oy < a.Ho && ox < a.Wo) {
+        const size_t o = ((size_t)oy * a.Wo + ox) * a.Cout + ch;
+        float v = acc[t][r] * os + ob;
+        if (res_n) v += res_n[o];
+        if (a.relu) v = fmaxf(v, 0.0f);
+        out_n[o] = v;
+      }
+    }
+  }
+}
+
+// first layer: 2 -> 16 channels, one input channel per group (conv1_1, wr_resnet.py:12-20): HBM-bound
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  const size_t total = (size_t)a.N * a.Ho * a.Wo * a.groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % a.groups);
+    size_t p = idx / a.groups;
+    const int ox = (int)(p % a.Wo);
+    p /= a.Wo;
+    const int oy = (int)(p % a.Ho);
+    const int n = (int)(p / a.Ho);
+    float acc[16];
+    for (int co = 0; co < cout_g; ++co) acc[co] = 0.0f;
+    const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + g * cin_g;
+    const float* wg = a.weights + (size_t)g * a.ksize * a.ksize * cin_g * cout_g;
+    for (int ky = 0; ky < a.ksize; ++ky)
+      for (int kx = 0; kx < a.ksize; ++kx) {
+        const int iy = oy * a.stride - a.pad_top + ky, ix = ox * a.stride - a.pad_left + kx;
+        if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;
+        for (int ci = 0; ci < cin_g; ++ci) {
+          float v = in_n[((size_t)iy * a.W + ix) * a.Cin + ci];
+          if (a.in_scale) v = fmaxf(v * a.in_scale[g * cin_g + ci] + a.in_shift[g * cin_g + ci], 0.0f);
+          const float* wr = wg + ((size_t)(ky * a.ksize + kx) * cin_g + ci) * cout_g;
+          for (int co = 0; co < cout_g; ++co) acc[co] += v * wr[co];
+        }
+      }
+    const size_t ob = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + g * cout_g;
+    for (int co = 0; co < cout_g; ++co) {
+      const int ch = g * cout_g + co;
+      float v = acc[co] * (a.out_scale ? a.out_scale[ch] : 1.0f) + (a.out_shift ? a.out_shift[ch] : 0.0f);
+      if (a.residual) v += a.residual[ob + co];
+      if (a.relu) v = fmaxf(v, 0.0f);
+      a.out[ob + co] = v;
+    }
+  }
+}
+
+// final_bn -> ReLU -> GlobalAveragePooling2D -> Dense(n_labels) (+ sigmoid): one workgroup per sample
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_feat[];  // [C]
+  const int n = blockIdx.x;
+  const float* x = a.in + (size_t)n * a.HW * a.C;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    const float sc = a.bn_scale[c], sh = a.bn_shift[c];
+    float s = 0.0f;
+    for (int p = 0; p < a.HW; ++p) s += fmaxf(x[(size_t)p * a.C + c] * sc + sh, 0.0f);
+    s_feat[c] = s / (float)a.HW;
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < a.L; l += blockDim.x) {
+    float s = a.dense_b[l];
+    for (int c = 0; c < a.C; ++c) s += s_feat[c] * a.dense_w[(size_t)c * a.L + l];
+    a.logits[(size_t)n * a.L + l] = s;
+    if (a.probs) a.probs[(size_t)n * a.L + l] = 1.0f / (1.0f + expf(-s));
+  }
+}
+
+template <int KC, int NTN, int S, int KS>
+static int launch_conv_t(const ConvArgs& a, hipStream_t s) {
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+  const size_t lds = ((size_t)PH * PW * (KC + 1) + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
+      return -1;
+    configured = true;
+  }
+  const int tiles = ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
+  hipLaunchKernelGGL((conv_mfma_kernel<KC, NTN, S, KS>), dim3(tiles * a.N, a.groups), dim3(CT), lds, s, a);
+  return 0;
+}
+
+}  // namespace
+
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  if (cin_g < 8) {
+    if (cout_g > 16) return -2;
+    const size_t total = (size_t)a.N * a.Ho * a.Wo * a.groups;
+    const int blocks = (int)((total + 255) / 256 > 65535 * 4 ? 65535 * 4 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv_direct_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return 0;
+  }
+#define CPX_CONV_CASE(KC, NTN, S, KS)                                                        \
+  if (cout_g == 32 * NTN && a.stride == S && a.ksize == KS && (cin_g % KC) == 0 && cin_g >= KC) \
+    return launch_conv_t<KC, NTN, S, KS>(a, s);
+  // (channels per group, stride, kernel) combinations of WR-ResNet-22-4 with groups = 2
+  if (cin_g == 8) { CPX_CONV_CASE(8, 1, 1, 3) CPX_CONV_CASE(8, 1, 1, 1) }
+  CPX_CONV_CASE(32, 1, 1, 3)
+  CPX_CONV_CASE(16, 2, 2, 3)
+  CPX_CONV_CASE(16, 2, 2, 1)
+  CPX_CONV_CASE(16, 2, 1, 3)
+  CPX_CONV_CASE(8, 4, 3, 3)
+  CPX_CONV_CASE(8, 4, 3, 1)
+  CPX_CONV_CASE(8, 4, 1, 3)
+#undef CPX_CONV_CASE
+  return -2;
+}
+
+void launch_head(const HeadArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(head_kernel, dim3(a.N), dim3(256), (size_t)a.C * sizeof(float), s, a);
+}
+
+}  // namespace cpx

@@ -104,6 +104,31 @@ struct ClassifyArgs {
 void launch_limits(const ClassifyArgs& a, int n_tracks, hipStream_t s);
 void launch_crop(const ClassifyArgs& a, int n_reqs, hipStream_t s);
 
+struct ConvArgs {
+  int N, H, W, Cin, Cout, groups, ksize, stride, relu;
+  int Ho, Wo, pad_top, pad_left;
+  const float* in;
+  float* out;
+  const float* weights;
+  const float* in_scale;
+  const float* in_shift;
+  const float* out_scale;
+  const float* out_shift;
+  const float* residual;
+};
+struct HeadArgs {
+  int N, HW, C, L;
+  const float* in;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* dense_w;
+  const float* dense_b;
+  float* logits;
+  float* probs;
+};
+int launch_conv(const ConvArgs& a, hipStream_t s);
+void launch_head(const HeadArgs& a, hipStream_t s);
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

@@ -218,6 +218,29 @@ int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filter
                   const cpx_frame_info* info_dev, const cpx_crop_req* reqs_dev, int n_reqs,
                   const cpx_track_limits* limits_dev, int frame_size, int square_width, float* out_dev);
 
+/* ---- CNN forward building blocks (WR-ResNet, ml_tools/resnet/wr_resnet.py:5-98) -----------
+ * Replaces tf.keras Conv2D(groups) / BatchNormalization / Activation / Add / GlobalAveragePooling2D /
+ * Dense as used by KerasModel.predict (ml_tools/kerasmodel.py:856-859).  Activations NHWC float32.
+ * out = relu?( conv(relu?(in * in_scale + in_shift)) * out_scale + out_shift + residual )
+ * weights_dev is packed [groups][ksize*ksize][Cin/groups][Cout/groups] (Keras HWIO regrouped).
+ * pad_same: 1 = TensorFlow "SAME" (extra padding at the bottom / right), 0 = "valid". */
+typedef struct cpx_conv_desc {
+  int32_t N, H, W, Cin, Cout, groups, ksize, stride, pad_same, relu;
+  const float* in_dev;
+  float* out_dev;
+  const float* weights_dev;
+  const float* in_scale_dev;  /* [Cin] or NULL: BatchNorm + ReLU applied to the input */
+  const float* in_shift_dev;
+  const float* out_scale_dev; /* [Cout] or NULL */
+  const float* out_shift_dev; /* [Cout] or NULL (bias, or bias folded with the following BatchNorm) */
+  const float* residual_dev;  /* [N,Ho,Wo,Cout] or NULL */
+} cpx_conv_desc;
+int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* desc);
+/* relu(in * bn_scale + bn_shift) -> mean over H*W -> dense [C][L] + bias -> logits (and sigmoid probs if not NULL) */
+int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
+                 const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
+                 float* logits_dev, float* probs_dev);
+
 /* Bytes of device workspace cpx_track_batch needs for B clips / total frames
  * (allocated lazily inside the handle and reused). */
 size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames);

@@ -1,0 +1,118 @@
+"""GPU parity of the CNN forward: MFMA implicit-GEMM convolutions and the head against a plain
+PyTorch CPU float32 restatement (oracle/cnn_oracle.py).  Tolerance: the north star's 1e-3 on
+logits (absolute; logits are O(1) with calibrated BatchNorm statistics), checked at 2e-4 here.
+Logits-vs-TensorFlow is parity-unpinned (no TF / weights in the container)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_ATOL = 2e-4  # north star: 1e-3
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3")
+    yield eng
+    eng.close()
+
+
+CASES = [
+    # (Cin, Cout, H, W, ksize, stride, same)  -- every (channels per group, stride, kernel) of WR-ResNet-22-4
+    (2, 16, 20, 24, 3, 1, True),      # conv1_1 (direct kernel)
+    (16, 64, 17, 21, 3, 1, True),     # res2b0_branch2a
+    (16, 64, 17, 21, 1, 1, False),    # shortcut2
+    (64, 64, 16, 33, 3, 1, True),     # res2*
+    (64, 128, 21, 18, 3, 2, True),    # res3b0_branch2a (stride 2, SAME pads bottom/right)
+    (64, 128, 21, 18, 1, 2, False),   # shortcut3
+    (128, 128, 10, 19, 3, 1, True),   # res3*
+    (128, 256, 20, 17, 3, 3, True),   # res4b0_branch2a (stride 3)
+    (128, 256, 20, 17, 1, 3, False),  # shortcut4
+    (256, 256, 9, 11, 3, 1, True),    # res4*
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_matches_torch(engine, case):
+    import torch
+    import torch.nn.functional as F
+
+    from cpx.ml_tools.wrresnet import ConvDesc, pack_conv
+
+    Cin, Cout, H, W, ks, stride, same = case
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    N = 2
+    x = rng.normal(0, 1, size=(N, H, W, Cin)).astype(np.float32)
+    k = rng.normal(0, 0.2, size=(ks, ks, Cin // 2, Cout)).astype(np.float32)
+    in_s = rng.uniform(0.5, 1.5, Cin).astype(np.float32)
+    in_b = rng.normal(0, 0.3, Cin).astype(np.float32)
+    out_s = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    out_b = rng.normal(0, 0.3, Cout).astype(np.float32)
+    Ho = -(-H // stride) if same else (H - ks) // stride + 1
+    Wo = -(-W // stride) if same else (W - ks) // stride + 1
+    res = rng.normal(0, 1, size=(N, Ho, Wo, Cout)).astype(np.float32)
+    for variant in range(3):
+        use_pro = variant in (0, 2)
+        use_res = variant in (1, 2)
+        relu = variant != 1
+        # torch reference
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+        if use_pro:
+            xt = F.relu(xt * torch.from_numpy(in_s)[None, :, None, None] + torch.from_numpy(in_b)[None, :, None, None])
+        if same:
+            ph = max((Ho - 1) * stride + ks - H, 0)
+            pw = max((Wo - 1) * stride + ks - W, 0)
+            xt = F.pad(xt, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+        y = F.conv2d(xt, torch.from_numpy(k).permute(3, 2, 0, 1).contiguous(), None, stride=stride, groups=2)
+        y = y * torch.from_numpy(out_s)[None, :, None, None] + torch.from_numpy(out_b)[None, :, None, None]
+        if use_res:
+            y = y + torch.from_numpy(res).permute(0, 3, 1, 2)
+        if relu:
+            y = F.relu(y)
+        want = y.permute(0, 2, 3, 1).numpy()
+        assert want.shape == (N, Ho, Wo, Cout)
+        # device
+        dev = engine.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        xd, wd = up(x), up(pack_conv(k))
+        isd, ibd, osd, obd, rd = up(in_s), up(in_b), up(out_s), up(out_b), up(res)
+        out = torch.full((N, Ho, Wo, Cout), np.nan, dtype=torch.float32, device=dev)
+        ptr = lambda v: C.c_void_p(v.data_ptr())
+        d = ConvDesc(N, H, W, Cin, Cout, 2, ks, stride, 1 if same else 0, 1 if relu else 0, ptr(xd), ptr(out), ptr(wd),
+                     ptr(isd) if use_pro else None, ptr(ibd) if use_pro else None, ptr(osd), ptr(obd),
+                     ptr(rd) if use_res else None)
+        torch.cuda.synchronize()
+        rc = engine.lib.cpx_conv2d(engine.h, C.byref(d))
+        assert rc == 0, engine._err()
+        engine.synchronize()
+        got = out.cpu().numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.isfinite(got).all()
+        assert float(np.abs(got - want).max()) <= 2e-5 * scale, (case, variant, float(np.abs(got - want).max()))
+
+
+@pytest.mark.parametrize("fs,n", [(32, 3), (64, 1)])
+def test_wrresnet_logits_match_oracle(engine, fs, n):
+    import torch
+
+    import cnn_oracle as co
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(5 + fs)
+    side = 5 * fs
+    x = rng.uniform(0, 255, size=(n, side, side, 2)).astype(np.float32)
+    x[:, ::7, :, 1] = 0.0
+    w = wr.random_weights(17, seed=3)
+    w = co.calibrate_bn(w, x)
+    want_logits, want_probs = co.forward(w, x)
+    net = wr.WRResNetDevice(engine, w, 17)
+    logits, probs = net.forward(torch.from_numpy(x).to(engine.device))
+    got = logits.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert float(np.abs(want_logits).max()) > 0.05  # a non-degenerate comparison
+    assert float(np.abs(got - want_logits).max()) <= LOGIT_ATOL, float(np.abs(got - want_logits).max())
+    np.testing.assert_allclose(probs.cpu().numpy(), want_probs, atol=1e-4)
