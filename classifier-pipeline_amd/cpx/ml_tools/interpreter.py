@@ -1,0 +1,239 @@
+"""Interpreter: per-track classification with the reference's interface
+(reference src/ml_tools/interpreter.py:13-474, 597-628).  Segment pre-processing (limits, crop,
+resize, normalise, 5x5 tiling) and the CNN forward run on the GPU through the C-ABI; segment
+selection and prediction aggregation are host work as in the reference."""
+
+import json
+import logging
+import time
+from pathlib import Path
+
+import numpy as np
+
+from .._lib import CROP_REQ_DTYPE, REGION_REF_DTYPE
+from ..classify.trackprediction import TrackPrediction
+from .datasetstructures import get_segments, segments_from_frames
+from .hyperparams import HyperParams
+
+
+class Interpreter:
+    TYPE = "abstract"
+
+    def __init__(self, model_file, run_over_network=False):
+        self.model_file = Path(model_file)
+        self.load_json(model_file)
+        if run_over_network:
+            raise NotImplementedError("run_over_network (HTTP /predict hop) is outside the cpx hot path")
+        self.run_over_network = False
+        self.port = 8123
+        self.id = None
+        self.seed = None
+
+    def load_json(self, filename):
+        """Model sidecar <model>.json: labels, hyperparams, thresholds, type, version (interpreter.py:23-41)."""
+        filename = Path(filename).with_suffix(".json")
+        logging.info("Loading metadata from %s", filename)
+        with open(filename, "r") as fh:
+            metadata = json.load(fh)
+        self.version = metadata.get("version")
+        self.labels = metadata["labels"]
+        self.params = HyperParams()
+        self.params["remapped_labels"] = metadata.get("remapped_labels")
+        self.params["excluded_labels"] = metadata.get("excluded_labels")
+        self.params.update(metadata.get("hyperparams", {}))
+        self.data_type = metadata.get("type", "thermal")
+        self.mapped_labels = metadata.get("mapped_labels")
+        self.label_probabilities = metadata.get("label_probabilities")
+        self.thresholds = metadata.get("thresholds")
+        if self.params.model_name not in ("wr-resnet", "efficientnetv2b3"):
+            raise NotImplementedError("only models without an input preprocess_fn (wr-resnet) are supported")
+        self.preprocess_fn = None
+
+    def shape(self):
+        raise NotImplementedError
+
+    def predict(self, frames):
+        raise NotImplementedError
+
+    # ---- per-track entry points (interpreter.py:132-176) ----
+    def classify_track(self, clip, track, segment_frames=None, min_segments=None):
+        start = time.time()
+        frames, output, masses = self.predict_track(clip, track, segment_frames=segment_frames,
+                                                    frames_per_classify=self.params.square_width**2,
+                                                    min_segments=min_segments)
+        if output is None:
+            logging.info("Skipping track %s", track.get_id())
+            return None
+        pred = self.track_prediction_from_raw(track.get_id(), frames, output, masses)
+        pred.classify_time = time.time() - start
+        return pred
+
+    def track_prediction_from_raw(self, track_id, prediction_frames, output, masses):
+        pred = TrackPrediction(track_id, self.labels, smooth_preds=self.params.smooth_predictions)
+        pred.classified_track(output, prediction_frames, masses)
+        # a single segment built from very few distinct frames: only 'false-positive' may be confident
+        if len(prediction_frames) == 1 and len(set(prediction_frames[0])) < self.params.square_width**2 / 4:
+            if pred.predicted_tag() != "false-positive":
+                pred.cap_confidences(0.5)
+        return pred
+
+    def predict_track(self, clip, track, **args):
+        samples = self.frames_for_prediction(clip, track, **args)
+        frames, preprocessed, masses = self.preprocess_segments(clip, track, samples)
+        if preprocessed is None or len(preprocessed) == 0:
+            return None, None, None
+        return frames, self.predict(preprocessed), masses
+
+    def predict_recent_frames(self, clip, track, **args):
+        samples = self.frames_for_prediction(clip, track, **args)
+        frames, preprocessed, mass = self.preprocess_segments(clip, track, samples)
+        if preprocessed is None or len(preprocessed) == 0:
+            return None
+        return self.predict(preprocessed), frames, mass
+
+    def frames_for_prediction(self, clip, track, **args):
+        """interpreter.py:178-253 for frames_per_classify > 1."""
+        segment_frames = args.get("segment_frames")
+        dont_filter = args.get("dont_filter", False)
+        predict_from_last = args.get("predict_from_last")
+        regions = track.bounds_history
+        start_frame = track.start_frame
+        if segment_frames is not None:
+            return segments_from_frames(clip.get_id(), track.get_id(), start_frame, regions, segment_frames)
+        if predict_from_last is not None:
+            if predict_from_last == 0:
+                return []
+            available = len(regions) if clip.frames_kept() is None else min(len(regions), clip.frames_kept())
+            want = min(predict_from_last, available)
+            if available > want:
+                valid = 0
+                take = 0
+                for i, r in enumerate(reversed(regions[-available:])):
+                    if r.blank:
+                        continue
+                    valid += 1
+                    take = i + 1
+                    if valid >= want:
+                        break
+                want = take
+            regions = regions[-want:]
+            start_frame = regions[0].frame_number
+        segments, _ = get_segments(
+            clip.get_id(), track.get_id(), start_frame, regions, segment_width=self.params.square_width**2,
+            ffc_frames=[] if dont_filter else clip.ffc_frames, repeats=1, segment_types=self.params.segment_types,
+            max_segments=args.get("num_predictions"), dont_filter=dont_filter, min_segments=args.get("min_segments"),
+            seed=self.seed)
+        return segments
+
+    def get_limits(self, clip, track):
+        """(thermal_norm_limits, filtered_norm_limits) of a track, computed on the GPU (interpreter.py:315-363)."""
+        _, limits = self._device_preprocess(clip, track, [])
+        return None, (limits["filt_min"][0], limits["filt_max"][0])
+
+    # ---- device pre-processing (interpreter.py:365-474) ----
+    def preprocess_segments(self, clip, track, segments, predict_from_last=None):
+        if not segments:
+            return [], None, []
+        sq = self.params.square_width
+        n_tiles = sq * sq
+        for seg in segments:
+            if len(seg.frame_indices) != n_tiles:
+                raise ValueError("segments must hold %d frames" % n_tiles)
+        x, _ = self._device_preprocess(clip, track, segments)
+        return [s.frame_indices for s in segments], x, [s.mass for s in segments]
+
+    def _device_preprocess(self, clip, track, segments):
+        state = getattr(clip, "device_state", None)
+        if state is None:
+            raise RuntimeError("clip was not tracked by cpx.ClipTrackExtractor: no device-resident frames")
+        if self.params.thermal_diff_norm or not self.params.diff_norm:
+            raise NotImplementedError("only diff_norm=True, thermal_diff_norm=False models are supported")
+        if list(self.params.channels) != ["thermal", "filtered"]:
+            raise NotImplementedError("only channels (thermal, filtered) are supported")
+        used = set(int(f) for s in segments for f in s.frame_indices)
+        by_frame = {}
+        refs = []
+        for r in track.bounds_history:
+            by_frame[r.frame_number] = r
+            if r.blank or r.width <= 0 or r.height <= 0:
+                continue
+            if state.frame_index(r.frame_number) is None:
+                continue
+            refs.append((state.frame_index(r.frame_number), r.x, r.y, r.width, r.height,
+                         1 if r.frame_number in used else 0))
+        reqs = []
+        for s, seg in enumerate(segments):
+            for tile, fn in enumerate(seg.frame_indices):
+                fn = int(fn)
+                r = by_frame.get(fn)
+                if r is None or state.frame_index(fn) is None:
+                    raise Exception("Clasifying clip {} track {} can't get frame {}".format(
+                        clip.get_id(), track.get_id(), fn))
+                reqs.append((state.frame_index(fn), r.x, r.y, r.width, r.height, 0, s, tile))
+        x, limits = state.engine.preprocess_segments(
+            state.frames_dev, state.track_result, np.array(refs, dtype=REGION_REF_DTYPE),
+            np.array([0, len(refs)], np.int32), np.array(reqs, dtype=CROP_REQ_DTYPE), len(segments),
+            frame_size=self.params.frame_size, square_width=self.params.square_width)
+        return x, limits
+
+
+class WRResNetInterpreter(Interpreter):
+    """WR-ResNet on the MFMA kernels; model = <name>.npz (Keras-layout weights) + <name>.json."""
+
+    TYPE = "cpx-hip"
+
+    def __init__(self, model_file, run_over_network=False, load_model=True, engine=None):
+        super().__init__(model_file, run_over_network)
+        self._engine = engine
+        self._net = None
+        self._weights = None
+        if load_model:
+            self.load_model()
+
+    def load_model(self):
+        from .wrresnet import load_weights
+
+        self._weights = load_weights(self.model_file.with_suffix(".npz"))
+        n = self._weights["prediction/bias"].shape[0]
+        if n != len(self.labels):
+            raise ValueError("model has %d outputs but %d labels" % (n, len(self.labels)))
+
+    def _network(self, engine):
+        from .wrresnet import WRResNetDevice
+
+        if self._net is None or self._net.eng is not engine:
+            self._net = WRResNetDevice(engine, self._weights, len(self.labels))
+        return self._net
+
+    def shape(self):
+        return 1, (None,) + tuple(self.params.output_dim)
+
+    def predict(self, frames):
+        """frames: device tensor (from preprocess_segments) or host float32 [N,H,W,2] -> numpy [N, n_labels]."""
+        import torch
+
+        from ..track.cliptrackextractor import default_engine
+
+        if isinstance(frames, torch.Tensor) and frames.is_cuda:
+            engine = self._engine or default_engine(frames.device.index or 0)
+            x = frames
+        else:
+            engine = self._engine or default_engine(0)
+            x = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32)).to(engine.device)
+        _, probs = self._network(engine).forward(x.contiguous())
+        return probs.cpu().numpy()
+
+
+def get_interpreter(model, run_over_network=False, load_model=True, seed=None):
+    """Factory with the reference's signature (interpreter.py:597-628)."""
+    suffix = Path(model.model_file).suffix
+    if model.type not in (None, WRResNetInterpreter.TYPE) or suffix not in (".npz", ".json", ""):
+        raise NotImplementedError(
+            "model type %r (%s): cpx runs WR-ResNet models converted to <name>.npz + <name>.json "
+            "(TensorFlow / TFLite / RandomForest runtimes are not part of this build)" % (model.type, model.model_file))
+    classifier = WRResNetInterpreter(model.model_file, run_over_network, load_model)
+    classifier.id = model.id
+    classifier.port = model.port
+    if seed is not None:
+        classifier.seed = seed
+    return classifier

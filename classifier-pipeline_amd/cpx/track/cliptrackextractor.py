@@ -40,6 +40,28 @@ def get_engine(width, height, background_thresh, weight_add, edge_pixels=1, devi
     return eng
 
 
+def default_engine(device=0):
+    """Any live engine on `device` (the CNN kernels do not depend on the tracking thresholds)."""
+    for key, eng in _ENGINES.items():
+        if key[5] == device:
+            return eng
+    return get_engine(160, 120, 20.0, 0.1, device=device)
+
+
+class DeviceClipState:
+    """Device-resident data of a tracked clip that the classifier reads: the frames, the filtered
+    frames and per-frame medians (cpx_frame_info) -- nothing is copied back for classification."""
+
+    def __init__(self, engine, frames_dev, track_result, proc_frames):
+        self.engine = engine
+        self.frames_dev = frames_dev
+        self.track_result = track_result
+        self._index = {q: f for q, f in enumerate(proc_frames)}
+
+    def frame_index(self, frame_number):
+        return self._index.get(int(frame_number))
+
+
 class WeightedBackgroundView:
     """What callers read from ``extractor.background_alg`` after tracking
     (reference piclassifier/motiondetector.py:178-248): the final background and its average."""
@@ -228,8 +250,9 @@ class ClipTrackExtractor(ClipTracker):
         meta = eng.make_meta(n, [f.time_on for f in frames], [f.last_ffc_time for f in frames], bgf)
         offs = np.array([0, n], np.int32)
         want_images = self.keep_frames
-        res = eng.track_batch(eng.upload_frames(stack), offs, meta, want_labels=want_images,
-                              want_filtered=want_images or self.calculate_filtered, want_background=True)
+        frames_dev = eng.upload_frames(stack)
+        res = eng.track_batch(frames_dev, offs, meta, want_labels=want_images, want_filtered=True,
+                              want_background=True)
         assoc = None
         if self.do_tracking and not clip.from_metadata:
             params = make_track_params(
@@ -256,6 +279,7 @@ class ClipTrackExtractor(ClipTracker):
             if assoc is not None:
                 clip.region_history.append([] if clip.ffc_affected else
                                            [Region.from_record(r) for r in assoc.frame_regions(f)])
+        clip.device_state = DeviceClipState(eng, frames_dev, res, [f for f in range(n) if info[f]["frame_number"] >= 0])
         bg = res.background()[0].astype(np.float64)
         last = info[[f for f in range(n) if info[f]["frame_number"] >= 0][-1]] if clip.current_frame >= 0 else None
         self.background_alg = WeightedBackgroundView(bg, None if last is None else last["background_average"], weight_add)

@@ -1,0 +1,96 @@
+"""Drop-in classify API on the GPU: ClipClassifier.process_file(track=True) / Interpreter.classify_track
+with a seeded WR-ResNet, against (a) the reference's own network inputs for explicit segments and
+(b) the oracle chain (NumPy pre-processing + PyTorch CPU forward + aggregation) for the segments chosen."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+LABELS = ["bird", "cat", "deer", "dog", "false-positive", "hedgehog", "human", "kiwi", "leporidae", "mustelid",
+          "penguin", "possum", "rodent", "sheep", "vehicle", "wallaby", "land-bird"]
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    import cnn_oracle as co
+    from cpx.ml_tools import wrresnet as wr
+
+    d = tmp_path_factory.mktemp("model")
+    w = wr.random_weights(len(LABELS), seed=11)
+    z = np.load(os.path.join(GOLDEN, "hedgehog_classify_fs32.npz"))
+    w = co.calibrate_bn(w, z["t0_input"])
+    wr.save_model(d / "wr", w, LABELS, hyperparams={"frame_size": 32})
+    return d, w
+
+
+def _config(model_dir):
+    from cpx.config import Config
+    from cpx.config.config import ModelConfig
+
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    cfg.classify.models = [ModelConfig.load({"id": 7, "name": "wr-test", "model_file": str(model_dir / "wr.npz")})]
+    return cfg
+
+
+@pytest.mark.parametrize("name", ["possum", "hedgehog"])
+def test_process_file_track_and_classify(tmp_path, model_dir, name):
+    import classify_oracle as co
+    import cnn_oracle as cnn
+    from cpx.classify.clipclassifier import ClipClassifier
+    from cpx.track.trackextractor import extract_file
+
+    mdir, w = model_dir
+    src = tmp_path / (name + ".cptv")
+    shutil.copy(os.path.join(GOLDEN, name + ".cptv"), src)
+    cfg = _config(mdir)
+    meta = ClipClassifier(cfg).process_file(str(src), track=True)
+    assert meta and os.path.exists(src.with_suffix(".txt"))
+    assert meta["models"][0]["id"] == 7 and "classify_time" in meta["models"][0]
+    # independent re-computation with the oracle chain on the same segments
+    clip, _, _ = extract_file(src, cfg, False, save_meta=False)
+    H, W = clip.res_y, clip.res_x
+    assert len(meta["tracks"]) == len(clip.tracks) > 0
+    for tm, track in zip(meta["tracks"], clip.tracks):
+        assert tm["id"] == track.get_id()
+        (pm,) = tm["predictions"]
+        assert pm["model_id"] == 7 and set(pm["all_class_confidences"]) == set(LABELS)
+        assert {"tag", "threshold_used", "confident", "confidence", "clarity", "all_class_confidences",
+                "predictions", "classify_time"} <= set(pm)
+        segs = [np.array(p["frames"]) for p in pm["predictions"]]
+        by_frame = {r.frame_number: r for r in track.bounds_history}
+        x, _ = co.preprocess_segments(lambda q: clip.frame_buffer.get_frame(q).thermal,
+                                      lambda q: clip.frame_buffer.get_frame(q).filtered.astype(np.float64),
+                                      by_frame, track.bounds_history, segs, 32, (1, 1, W - 2, H - 2))
+        _, probs = cnn.forward(w, x)
+        score = co.classified_track(probs, prediction_frames=segs, labels=LABELS)
+        got = np.array([pm["all_class_confidences"][l] for l in LABELS])
+        assert np.abs(got - np.round(score, 3)).max() <= 1.5e-3
+        assert pm["tag"] == LABELS[int(np.argmax(score))]
+
+
+def test_classify_track_inputs_equal_reference(tmp_path, model_dir):
+    """Interpreter.classify_track with the reference's segment frames: the tensor handed to predict()
+    is bit-identical to what the reference's own Interpreter built."""
+    from cpx.ml_tools.interpreter import WRResNetInterpreter
+    from cpx.track.trackextractor import extract_file
+
+    mdir, w = model_dir
+    src = tmp_path / "hedgehog.cptv"
+    shutil.copy(os.path.join(GOLDEN, "hedgehog.cptv"), src)
+    clip, _, _ = extract_file(src, _config(mdir), False, save_meta=False)
+    z = np.load(os.path.join(GOLDEN, "hedgehog_classify_fs32.npz"))
+    interp = WRResNetInterpreter(mdir / "wr.npz")
+    seen = {}
+    orig = interp.predict
+    interp.predict = lambda x: seen.setdefault("x", x.cpu().numpy()) is None or orig(x)
+    pred = interp.classify_track(clip, clip.tracks[0], segment_frames=z["t0_segments"])
+    assert np.array_equal(seen["x"], z["t0_input"])
+    assert pred is not None and abs(float(np.sum(pred.class_best_score)) - 1.0) < 1e-5
+    assert [list(p.frames) for p in pred.predictions] == [list(s) for s in z["t0_segments"]]
