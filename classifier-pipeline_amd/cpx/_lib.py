@@ -66,6 +66,7 @@ EXPORTS = [
     "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
+    "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
 ]
 
 _lib = None
@@ -111,6 +112,12 @@ def load():
     lib.cpx_conv2d.restype = C.c_int
     lib.cpx_cnn_head.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.cpx_cnn_head.restype = C.c_int
+    lib.cpx_finalize_tracks.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.cpx_finalize_tracks.restype = C.c_int
+    lib.cpx_plan_segments.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.cpx_plan_segments.restype = C.c_int
+    lib.cpx_aggregate_predictions.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.cpx_aggregate_predictions.restype = C.c_int
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]

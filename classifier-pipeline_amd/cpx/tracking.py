@@ -66,3 +66,42 @@ def track_regions(pool, rec, max_active):
     """Region records of one track: pool is the clip's [n_frames * max_active] array."""
     idx = (int(rec["start_frame"]) + np.arange(int(rec["n_frames"]))) * max_active + int(rec["slot"])
     return pool[idx]
+
+
+TRACK_SUMMARY_DTYPE = np.dtype(
+    [("id", "<i4"), ("slot", "<i4"), ("start_frame", "<i4"), ("n_frames", "<i4"), ("blank_frames", "<i4"),
+     ("since_seen", "<i4"), ("reject", "<i4"), ("rank", "<i4"), ("frames_moved", "<i4"), ("region_jitter", "<i4"),
+     ("jitter_bigger", "<i4"), ("jitter_smaller", "<i4"), ("blank_percent", "<i4"), ("n_segments", "<i4"),
+     ("movement", "<f8"), ("max_offset", "<f8"), ("score", "<f8"), ("average_mass", "<f8"), ("median_mass", "<f8"),
+     ("delta_std", "<f8"), ("mass_std", "<f8"), ("average_velocity", "<f8")]
+)
+assert TRACK_SUMMARY_DTYPE.itemsize == 120
+
+REJECT_REASONS = {
+    1: "Track filtered.  Too short", 2: "Track filtered.  Didn't move", 3: "Track filtered. Too Many Blanks",
+    4: "Track filtered.  Too Jittery", 5: "Track filtered.  Too static", 6: "Track filtered.  Too Dynamic",
+    7: "Track filtered.  Mass too small", 8: "Too many tracks",
+}
+
+
+class FilterParams(C.Structure):
+    _fields_ = [
+        ("min_duration_secs", C.c_double), ("track_min_offset", C.c_double), ("track_min_mass", C.c_double),
+        ("track_min_delta", C.c_double), ("track_max_delta", C.c_double),
+        ("min_moving_frames", C.c_int32), ("max_blank_percent", C.c_int32), ("max_jitter", C.c_int32),
+        ("fps", C.c_int32), ("max_tracks", C.c_int32), ("max_active_tracks", C.c_int32),
+        ("max_tracks_per_clip", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+assert C.sizeof(FilterParams) == 72
+
+
+def make_filter_params(min_duration_secs=0, track_min_offset=4.0, track_min_mass=2.0, track_min_delta=1.0,
+                       track_max_delta=150, min_moving_frames=2, max_blank_percent=30, max_jitter=20, fps=9,
+                       max_tracks=None, max_active_tracks=16, max_tracks_per_clip=128):
+    """Defaults = config/trackingconfig.py:126-177 and trackingmotionconfig.py:24-59 (thermal)."""
+    return FilterParams(float(min_duration_secs), float(track_min_offset), float(track_min_mass),
+                        float(track_min_delta), float(track_max_delta), int(min_moving_frames),
+                        int(max_blank_percent), int(max_jitter), int(fps), -1 if max_tracks is None else int(max_tracks),
+                        int(max_active_tracks), int(max_tracks_per_clip), 0)

@@ -41,6 +41,8 @@ static_assert(sizeof(cpx_frame_meta) == 24, "cpx_frame_meta layout is part of th
 static_assert(sizeof(cpx_config) == 40, "cpx_config layout is part of the ABI");
 static_assert(sizeof(cpx_region_ref) == 24 && sizeof(cpx_track_limits) == 16 && sizeof(cpx_crop_req) == 32,
               "classification request layouts are part of the ABI");
+static_assert(sizeof(cpx_filter_params) == 72 && sizeof(cpx_track_summary) == 120,
+              "end-of-clip layouts are part of the ABI");
 static_assert(sizeof(cpx_region) == 56, "cpx_region layout is part of the ABI");
 static_assert(sizeof(cpx_track_record) == 32, "cpx_track_record layout is part of the ABI");
 static_assert(sizeof(cpx_track_params) == 120, "cpx_track_params layout is part of the ABI");
@@ -448,6 +450,107 @@ int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const
   a.in = in_dev; a.bn_scale = bn_scale_dev; a.bn_shift = bn_shift_dev;
   a.dense_w = dense_w_dev; a.dense_b = dense_b_dev; a.logits = logits_dev; a.probs = probs_dev;
   cpx::launch_head(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+static int final_common(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
+                        const cpx_frame_meta* meta, int B, cpx::FinalArgs* a) {
+  if (params->max_active_tracks < 1 || params->max_tracks_per_clip < 1)
+    return fail(h, CPX_ERR_INVALID, "filter params: capacities must be positive");
+  CPX_HIP(h, hipSetDevice(h->device));
+  Schedule sc;
+  int rc = build_schedule(h, clip_offsets, meta, B, &sc);
+  if (rc != CPX_OK) return rc;
+  rc = upload_schedule(h, sc, B);
+  if (rc != CPX_OK) return rc;
+  const int n = std::max((int)sc.proc_idx.size(), 1);
+  a->B = B;
+  a->params = *params;
+  a->max_frames = h->cfg.max_frames;
+  a->clip_first = h->sched_dev;
+  a->proc_off = h->sched_dev + B;
+  a->proc_idx = h->sched_dev + B + (B + 1);
+  a->proc_ffc = h->sched_dev + B + (B + 1) + n;
+  return CPX_OK;
+}
+
+int cpx_finalize_tracks(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
+                        const cpx_frame_meta* meta, int B, const cpx_region* pool_dev,
+                        const cpx_track_record* tracks_dev, const int32_t* n_tracks_dev,
+                        cpx_track_summary* summaries_dev, int32_t* counts_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!params || !clip_offsets || !meta || B <= 0 || !pool_dev || !tracks_dev || !n_tracks_dev || !summaries_dev ||
+      !counts_dev)
+    return fail(h, CPX_ERR_INVALID, "cpx_finalize_tracks: null argument");
+  cpx::FinalArgs a{};
+  int rc = final_common(h, params, clip_offsets, meta, B, &a);
+  if (rc != CPX_OK) return rc;
+  const size_t need = (size_t)B * h->cfg.max_frames * (2 * sizeof(double) + sizeof(float)) + 512;
+  if (need > h->ws_assoc_bytes) {
+    if (h->ws_assoc) hipFree(h->ws_assoc);
+    h->ws_assoc = nullptr;
+    h->ws_assoc_bytes = 0;
+    hipError_t e = hipMalloc(&h->ws_assoc, need);
+    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "finalize workspace hipMalloc", e);
+    h->ws_assoc_bytes = need;
+  }
+  a.square_width = 5;
+  a.pool = pool_dev;
+  a.tracks = tracks_dev;
+  a.n_tracks = n_tracks_dev;
+  a.summaries = summaries_dev;
+  a.counts = counts_dev;
+  a.scratch_d = (double*)h->ws_assoc;
+  a.scratch_f = (float*)((char*)h->ws_assoc + align_up((size_t)B * h->cfg.max_frames * 2 * sizeof(double), 256));
+  cpx::launch_finalize(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_plan_segments(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
+                      const cpx_frame_meta* meta, int B, const cpx_region* pool_dev,
+                      const cpx_track_summary* summaries_dev, const int32_t* n_tracks_dev,
+                      const int32_t* prefix_dev, int square_width, cpx_region_ref* refs_dev,
+                      int32_t* track_offsets_dev, cpx_crop_req* reqs_dev, int32_t* sample_track_dev,
+                      int32_t* track_clip_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!params || !clip_offsets || !meta || B <= 0 || !pool_dev || !summaries_dev || !n_tracks_dev || !prefix_dev ||
+      !refs_dev || !track_offsets_dev || !reqs_dev || !sample_track_dev || !track_clip_dev)
+    return fail(h, CPX_ERR_INVALID, "cpx_plan_segments: null argument");
+  if (square_width != 5) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_plan_segments: square_width must be 5");
+  cpx::FinalArgs a{};
+  int rc = final_common(h, params, clip_offsets, meta, B, &a);
+  if (rc != CPX_OK) return rc;
+  a.square_width = square_width;
+  a.pool = pool_dev;
+  a.summaries = const_cast<cpx_track_summary*>(summaries_dev);
+  a.n_tracks = n_tracks_dev;
+  a.prefix = prefix_dev;
+  a.refs = refs_dev;
+  a.track_offsets = track_offsets_dev;
+  a.reqs = reqs_dev;
+  a.sample_track = sample_track_dev;
+  a.track_clip = track_clip_dev;
+  cpx::launch_plan(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_aggregate_predictions(cpx_handle* h, const float* probs_dev, const int32_t* sample_track_dev,
+                              int n_samples, const cpx_crop_req* reqs_dev, int n_tracks, int n_labels,
+                              int false_positive_index, int square_width, float* scores_dev, int32_t* best_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (n_tracks == 0) return CPX_OK;
+  if (!probs_dev || !sample_track_dev || !reqs_dev || !scores_dev || !best_dev || n_samples < 0 || n_tracks < 0 ||
+      n_labels < 1)
+    return fail(h, CPX_ERR_INVALID, "cpx_aggregate_predictions: bad argument");
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::AggregateArgs a{};
+  a.n_samples = n_samples; a.n_tracks = n_tracks; a.n_labels = n_labels; a.fp_index = false_positive_index;
+  a.square_width = square_width;
+  a.probs = probs_dev; a.sample_track = sample_track_dev; a.reqs = reqs_dev; a.scores = scores_dev; a.best = best_dev;
+  cpx::launch_aggregate(a, h->stream);
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "cpx_assoc_core.h"
+#include "cpx_final_core.h"
 #include "cpx_kernels.h"
 
 namespace cpx {
@@ -48,6 +49,38 @@ __global__ __launch_bounds__(64) void cpx_assoc_kernel(AssocArgs a) {
   }
   a.n_tracks[b] = c.n_tracks;
   a.status[b] = c.status;
+}
+
+// end of clip: trim / statistics / rejects / score order + the size of the classification plan
+__global__ __launch_bounds__(64) void cpx_finalize_kernel(FinalArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int pbase = a.proc_off[b];
+  const int first = a.clip_first[b];
+  const int ma = a.params.max_active_tracks, mt = a.params.max_tracks_per_clip;
+  FinalScratch sc;
+  sc.d = a.scratch_d + (size_t)b * 2 * a.max_frames;
+  sc.f = a.scratch_f + (size_t)b * a.max_frames;
+  finalize_clip(a.params, a.pool + (size_t)first * ma, a.tracks + (size_t)b * mt, a.n_tracks[b], a.proc_ffc + pbase,
+                a.square_width, a.summaries + (size_t)b * mt, a.counts + 4 * b, sc);
+}
+
+__global__ __launch_bounds__(64) void cpx_plan_kernel(FinalArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int pbase = a.proc_off[b];
+  const int first = a.clip_first[b];
+  const int ma = a.params.max_active_tracks, mt = a.params.max_tracks_per_clip;
+  plan_clip(a.params, a.pool + (size_t)first * ma, a.summaries + (size_t)b * mt, a.n_tracks[b], a.proc_ffc + pbase,
+            a.proc_idx + pbase, a.square_width, b, a.prefix + 4 * b, a.refs, a.track_offsets, a.reqs, a.sample_track,
+            a.track_clip);
+}
+
+void launch_finalize(const FinalArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_finalize_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_plan(const FinalArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_plan_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
 }
 
 size_t assoc_active_bytes() { return sizeof(ActiveTrack); }

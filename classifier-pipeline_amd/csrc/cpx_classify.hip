@@ -255,6 +255,72 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
   }
 }
 
+// class_best_score per track (trackprediction.py:127-171) + low-evidence cap (interpreter.py:151-168)
+__global__ __launch_bounds__(64) void cpx_aggregate_kernel(AggregateArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n_tracks) return;
+  // samples of track t: [s0, s1) in the sorted sample_track array
+  int lo = 0, hi = a.n_samples;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a.sample_track[mid] < t) lo = mid + 1;
+    else hi = mid;
+  }
+  const int s0 = lo;
+  hi = a.n_samples;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a.sample_track[mid] <= t) lo = mid + 1;
+    else hi = mid;
+  }
+  const int s1 = lo;
+  const int L = a.n_labels;
+  float* out = a.scores + (size_t)t * L;
+  float total = 0.0f;
+  // np.sum(predictions, axis=0) over at most a few segments: plain float32 accumulation in segment order
+  for (int l = 0; l < L; ++l) {
+    float s = 0.0f;
+    for (int k = s0; k < s1; ++k) s += a.probs[(size_t)k * L + l];
+    out[l] = s;
+  }
+  // np.sum(class_best_score): pairwise over L <= 128 labels collapses to NumPy's 8-lane scheme; L < 8 is a loop
+  if (L < 8) {
+    for (int l = 0; l < L; ++l) total += out[l];
+  } else {
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = out[j];
+    int i;
+    for (i = 8; i < L - (L % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += out[i + j];
+    total = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < L; ++i) total += out[i];
+  }
+  int best = 0;
+  for (int l = 0; l < L; ++l) {
+    out[l] = (s1 > s0) ? out[l] / total : 0.0f;
+    if (out[l] > out[best]) best = l;
+  }
+  if (s1 - s0 == 1) {
+    const int per = a.square_width * a.square_width;
+    const cpx_crop_req* q = a.reqs + (size_t)s0 * per;
+    int distinct = 0;
+    for (int j = 0; j < per; ++j) distinct += (j == 0 || q[j].frame != q[j - 1].frame);  // frames are sorted
+    if ((float)distinct < (float)per / 4.0f && best != a.fp_index) {
+      float tot2 = 0.0f;
+      for (int l = 0; l < L; ++l) tot2 += out[l];
+      if (tot2 > 0.5f) {
+        const float scale = 0.5f / tot2;
+        for (int l = 0; l < L; ++l) out[l] *= scale;
+      }
+    }
+  }
+  a.best[t] = (s1 > s0) ? best : -1;
+}
+
+void launch_aggregate(const AggregateArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_aggregate_kernel, dim3((a.n_tracks + 63) / 64), dim3(64), 0, s, a);
+}
+
 void launch_limits(const ClassifyArgs& a, int n_tracks, hipStream_t s) {
   hipLaunchKernelGGL(cpx_limits_kernel, dim3(n_tracks), dim3(LT), 0, s, a);
 }

@@ -86,6 +86,30 @@ struct AssocArgs {
   unsigned char* used;     // [B * cap]
 };
 void launch_assoc(const AssocArgs& a, hipStream_t s);
+struct FinalArgs {
+  int B, square_width, max_frames;
+  cpx_filter_params params;
+  const int* clip_first;
+  const int* proc_off;
+  const int* proc_idx;
+  const int* proc_ffc;
+  const cpx_region* pool;
+  const cpx_track_record* tracks;
+  const int* n_tracks;
+  cpx_track_summary* summaries;
+  int* counts;          // [B][4]
+  double* scratch_d;    // [B][2*max_frames]
+  float* scratch_f;     // [B][max_frames]
+  // plan pass
+  const int* prefix;    // [B][4]
+  cpx_region_ref* refs;
+  int* track_offsets;
+  cpx_crop_req* reqs;
+  int* sample_track;
+  int* track_clip;
+};
+void launch_finalize(const FinalArgs& a, hipStream_t s);
+void launch_plan(const FinalArgs& a, hipStream_t s);
 size_t assoc_active_bytes();
 size_t assoc_score_bytes();
 
@@ -101,6 +125,15 @@ struct ClassifyArgs {
   const cpx_crop_req* reqs;
   float* out;
 };
+struct AggregateArgs {
+  int n_samples, n_tracks, n_labels, fp_index, square_width;
+  const float* probs;
+  const int* sample_track;
+  const cpx_crop_req* reqs;
+  float* scores;
+  int* best;
+};
+void launch_aggregate(const AggregateArgs& a, hipStream_t s);
 void launch_limits(const ClassifyArgs& a, int n_tracks, hipStream_t s);
 void launch_crop(const ClassifyArgs& a, int n_reqs, hipStream_t s);
 

@@ -180,6 +180,38 @@ int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int
                         cpx_track_record* tracks_dev, int32_t* n_tracks_dev, int32_t* status_dev,
                         cpx_region* regions_dev, int32_t* region_counts_dev);
 
+/* ---- end of clip: trim, movement statistics, score, rejects (one GPU lane per clip) ----------
+ * Replaces Track.trim / calculate_stats (track/track.py:737-905) and ClipTracker.filter_tracks /
+ * filter_track (track/cliptracker.py:367-486) for every track cpx_associate_batch produced. */
+typedef struct cpx_filter_params {
+  double min_duration_secs, track_min_offset, track_min_mass, track_min_delta, track_max_delta;
+  int32_t min_moving_frames, max_blank_percent, max_jitter, fps;
+  int32_t max_tracks; /* -1: None */
+  int32_t max_active_tracks, max_tracks_per_clip; /* the capacities used by cpx_associate_batch */
+  int32_t reserved;
+} cpx_filter_params;
+
+enum { CPX_TRACK_KEPT = 0, CPX_REJECT_TOO_SHORT = 1, CPX_REJECT_DIDNT_MOVE = 2, CPX_REJECT_TOO_MANY_BLANKS = 3,
+       CPX_REJECT_TOO_JITTERY = 4, CPX_REJECT_TOO_STATIC = 5, CPX_REJECT_TOO_DYNAMIC = 6,
+       CPX_REJECT_MASS_TOO_SMALL = 7, CPX_REJECT_TOO_MANY_TRACKS = 8 };
+
+typedef struct cpx_track_summary {
+  int32_t id, slot, start_frame, n_frames; /* after trim */
+  int32_t blank_frames, since_seen;        /* RegionTracker counters after trim */
+  int32_t reject;                          /* CPX_TRACK_KEPT or a CPX_REJECT_* reason */
+  int32_t rank;                            /* position in the clip's score order (stable, descending) */
+  int32_t frames_moved, region_jitter, jitter_bigger, jitter_smaller, blank_percent;
+  int32_t n_segments;                      /* classification segments planned for it (kept tracks) */
+  double movement, max_offset, score, average_mass, median_mass, delta_std, mass_std, average_velocity;
+} cpx_track_summary;
+
+/* summaries_dev: [B * max_tracks_per_clip] in creation order (parallel to tracks_dev);
+ * counts_dev: int32 [B][4] = kept tracks, region refs, samples (segments), reserved -- per clip. */
+int cpx_finalize_tracks(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
+                        const cpx_frame_meta* meta, int B, const cpx_region* pool_dev,
+                        const cpx_track_record* tracks_dev, const int32_t* n_tracks_dev,
+                        cpx_track_summary* summaries_dev, int32_t* counts_dev);
+
 /* ---- classification pre-processing: limits + crop / resize / normalise / tile ---------
  * Replaces Interpreter.get_limits / preprocess_segments (ml_tools/interpreter.py:315-474),
  * preprocess_frame (ml_tools/preprocess.py:56-113), resize_and_pad / resize_cv
@@ -207,6 +239,19 @@ typedef struct cpx_crop_req { /* one tile = one frame of one segment */
   int32_t tile;                /* 0 .. square_width^2 - 1, row-major */
 } cpx_crop_req;
 
+/* Plans the classification work of a batch on the device (the reference chooses segments at random,
+ * SURVEY F13; this planner is the deterministic member of that family: consecutive runs of
+ * square_width^2 usable frames per kept track, a short tail padded by repeating its frames).
+ * Inputs: outputs of cpx_associate_batch / cpx_finalize_tracks and, per clip, exclusive prefix sums
+ * (device int32 [B][4]) of counts_dev.  Fills refs / track offsets / crop requests / per-sample track
+ * index for cpx_track_limits_batch and cpx_crop_tile; track_clip_dev[t] = (clip, track id). */
+int cpx_plan_segments(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
+                      const cpx_frame_meta* meta, int B, const cpx_region* pool_dev,
+                      const cpx_track_summary* summaries_dev, const int32_t* n_tracks_dev,
+                      const int32_t* prefix_dev, int square_width, struct cpx_region_ref* refs_dev,
+                      int32_t* track_offsets_dev, struct cpx_crop_req* reqs_dev, int32_t* sample_track_dev,
+                      int32_t* track_clip_dev);
+
 /* refs_dev: regions of all tracks, track t owns [track_offsets[t], track_offsets[t+1]) (device arrays). */
 int cpx_track_limits_batch(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
                            const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev,
@@ -217,6 +262,14 @@ int cpx_track_limits_batch(cpx_handle* h, const uint16_t* frames_dev, const floa
 int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
                   const cpx_frame_info* info_dev, const cpx_crop_req* reqs_dev, int n_reqs,
                   const cpx_track_limits* limits_dev, int frame_size, int square_width, float* out_dev);
+
+/* Per-track aggregation of the segment predictions (classify/trackprediction.py:127-171 with
+ * smooth_predictions = False: sum over the track's segments, normalised to sum 1) plus the low-evidence
+ * cap of Interpreter.track_prediction_from_raw (ml_tools/interpreter.py:151-168).  Samples of a track are
+ * contiguous (cpx_plan_segments).  scores_dev float [n_tracks, L]; best_dev int32 [n_tracks] (argmax). */
+int cpx_aggregate_predictions(cpx_handle* h, const float* probs_dev, const int32_t* sample_track_dev,
+                              int n_samples, const struct cpx_crop_req* reqs_dev, int n_tracks, int n_labels,
+                              int false_positive_index, int square_width, float* scores_dev, int32_t* best_dev);
 
 /* ---- CNN forward building blocks (WR-ResNet, ml_tools/resnet/wr_resnet.py:5-98) -----------
  * Replaces tf.keras Conv2D(groups) / BatchNormalization / Activation / Add / GlobalAveragePooling2D /

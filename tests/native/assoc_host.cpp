@@ -43,3 +43,21 @@ extern "C" int assoc_host_clip(const cpx_track_params* p, int cap, int nproc, co
   *n_tracks = c.n_tracks;
   return c.status;
 }
+
+#include "cpx_final_core.h"
+
+// host build of the end-of-clip code (trim / stats / rejects / plan) for one clip
+extern "C" int final_host_clip(const cpx_filter_params* fp, const cpx_region* pool, const cpx_track_record* recs,
+                               int n_tracks, const int* proc_ffc, const int* proc_idx, int max_frames,
+                               cpx_track_summary* out, int* counts, cpx_region_ref* refs, int* track_offsets,
+                               cpx_crop_req* reqs, int* sample_track, int* track_clip) {
+  using namespace cpx;
+  std::vector<double> d(2 * (size_t)max_frames + 16);
+  std::vector<float> f((size_t)max_frames + 16);
+  FinalScratch sc{d.data(), f.data()};
+  finalize_clip(*fp, pool, recs, n_tracks, proc_ffc, 5, out, counts, sc);
+  const int prefix[4] = {0, 0, 0, 0};
+  plan_clip(*fp, pool, out, n_tracks, proc_ffc, proc_idx, 5, 0, prefix, refs, track_offsets, reqs, sample_track, track_clip);
+  track_offsets[counts[0]] = counts[1];
+  return 0;
+}

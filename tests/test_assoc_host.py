@@ -125,3 +125,122 @@ def test_host_assoc_synthetic(host_lib):
             n_kalman += int(np.sum((regs["flags"] & REGION_CENTROID_F32) != 0))
     # the comparison must have exercised tracks, blank frames and Kalman-predicted regions
     assert n_tracks > 10 and n_blank > 10 and n_kalman > 0, (n_tracks, n_blank, n_kalman)
+
+
+# ---------------------------------------------------------------------------
+# end-of-clip code (trim / statistics / rejects / segment plan), host build vs the oracle
+# ---------------------------------------------------------------------------
+def run_final(host_lib, tr_raw, pool, n_frames, ffc, max_active=16, max_tracks=128):
+    from cpx._lib import CROP_REQ_DTYPE, REGION_REF_DTYPE
+    from cpx.tracking import TRACK_RECORD_DTYPE, TRACK_SUMMARY_DTYPE, make_filter_params
+
+    fp = make_filter_params(max_active_tracks=max_active, max_tracks_per_clip=max_tracks)
+    recs = np.array([r for r, _ in tr_raw], dtype=TRACK_RECORD_DTYPE)
+    n = len(recs)
+    out = np.zeros(max(n, 1), TRACK_SUMMARY_DTYPE)
+    counts = np.zeros(4, np.int32)
+    refs = np.zeros(n_frames * max_active + 1, REGION_REF_DTYPE)
+    toffs = np.zeros(max_tracks + 1, np.int32)
+    reqs = np.zeros((n_frames + 25 * max_tracks) * 2, CROP_REQ_DTYPE)
+    st = np.zeros(n_frames + max_tracks, np.int32)
+    tc = np.zeros(2 * max_tracks, np.int32)
+    pidx = np.arange(n_frames, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    host_lib.final_host_clip(C.byref(fp), p(pool), p(recs), n, p(np.asarray(ffc, np.int32)), p(pidx), n_frames,
+                             p(out), p(counts), p(refs), p(toffs), p(reqs), p(st), p(tc))
+    return out[:n], counts, refs, toffs, reqs, st, tc
+
+
+def host_pool(host_lib, out, cap=64, max_active=16, max_tracks=128):
+    """re-run the association keeping the raw pool (run_host slices it per track)."""
+    from cpx.tracking import REGION_DTYPE, TRACK_RECORD_DTYPE
+
+    tr, regions, rcount = run_host(host_lib, out, cap, max_active, max_tracks)
+    n = len(out["frames"])
+    pool = np.zeros(n * max_active, REGION_DTYPE)
+    for rec, regs in tr:
+        idx = (int(rec["start_frame"]) + np.arange(int(rec["n_frames"]))) * max_active + int(rec["slot"])
+        pool[idx] = regs
+    return tr, pool
+
+
+REASON = {"Track filtered.  Too short": 1, "Track filtered.  Didn't move": 2, "Track filtered. Too Many Blanks": 3,
+          "Track filtered.  Too Jittery": 4, "Track filtered.  Too static": 5, "Track filtered.  Too Dynamic": 6,
+          "Track filtered.  Mass too small": 7}
+
+
+def compare_final(summ, out_filtered):
+    """summaries (creation order) vs the oracle after filter_tracks."""
+    kept = {t.id: t for t in out_filtered["tracks"]}
+    rej = {t.id: (reason, t) for reason, t in out_filtered["filtered_tracks"]}
+    order = [t.id for t in sorted(list(kept.values()) + [t for _, t in rej.values()],
+                                  key=lambda t: -t.stats["score"] if not np.isnan(t.stats["score"]) else 0)]
+    for s in summ:
+        tid = int(s["id"])
+        t = kept.get(tid) or rej[tid][1]
+        assert (s["start_frame"], s["n_frames"]) == (t.start_frame, len(t.bounds)), tid
+        assert (s["blank_frames"], s["since_seen"]) == (t.blank_frames, t.since_seen), tid
+        st = t.stats
+        for k in ("frames_moved", "region_jitter", "jitter_bigger", "jitter_smaller", "blank_percent"):
+            assert s[k] == st[k], (tid, k)
+        for k in ("movement", "max_offset", "score", "average_mass", "median_mass", "delta_std", "mass_std",
+                  "average_velocity"):
+            a, b = float(s[k]), float(st[k])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12 * max(1.0, abs(b)), (tid, k, a, b)
+        assert s["reject"] == (0 if tid in kept else REASON[rej[tid][0]]), tid
+    # kept tracks come out in the oracle's order
+    kept_ranked = [int(s["id"]) for s in sorted(summ, key=lambda s: s["rank"]) if s["reject"] == 0]
+    assert kept_ranked == [t.id for t in out_filtered["tracks"]]
+
+
+@pytest.mark.parametrize("name", ["possum", "hedgehog"])
+def test_host_final_fixture(host_lib, name):
+    import track_oracle as to
+
+    frames, t_on, ffc, bgf, hdr = load_clip(name)
+    raw = to.track_clip(frames, t_on, ffc, bgf, to.OracleConfig(hdr.model), keep=True, apply_filter=False)
+    tr, pool = host_pool(host_lib, raw)
+    fin = to.track_clip(frames, t_on, ffc, bgf, to.OracleConfig(hdr.model), keep=True, apply_filter=True)
+    n = len(raw["frames"])
+    summ, counts, refs, toffs, reqs, st, tc = run_final(host_lib, tr, pool, n, [f["ffc"] for f in raw["frames"]])
+    compare_final(summ, fin)
+    assert counts[0] == len(fin["tracks"])
+    # plan: every sample has 25 sorted tiles drawn from the track's usable frames; every usable frame
+    # of the first covered*25 is used; refs cover all non-blank regions
+    nref = 0
+    for ti, t in enumerate(fin["tracks"]):
+        nonblank = [r for r in t.bounds if not r.blank and r.width > 0 and r.height > 0]
+        assert toffs[ti + 1] - toffs[ti] == len(nonblank)
+        nref += len(nonblank)
+        usable = [r.frame_number for r in nonblank if r.mass > 0]
+        nseg = max(1, (len(usable) + 12) // 25) if usable else 0
+        mine = [s for s in range(counts[2]) if st[s] == ti]
+        assert len(mine) == nseg
+        covered = usable[: 25 * nseg]
+        used = []
+        for s in mine:
+            q = reqs[s * 25:(s + 1) * 25]
+            assert list(q["tile"]) == list(range(25)) and np.all(q["sample"] == s) and np.all(q["track"] == ti)
+            fr = list(q["frame"])
+            assert fr == sorted(fr)
+            used += fr
+        assert sorted(set(used)) == covered
+    assert counts[1] == nref
+
+
+def test_host_final_synthetic(host_lib):
+    import track_oracle as to
+    from cpx import synth
+
+    kept = rejected = 0
+    for seed in range(1, 9):
+        rng = np.random.default_rng(100 + seed)
+        clip = synth.make_clip(rng, 150, max_blobs=3)
+        raw = to.track_clip(clip, cfg=to.OracleConfig("lepton3"), keep=True, apply_filter=False)
+        tr, pool = host_pool(host_lib, raw)
+        fin = to.track_clip(clip, cfg=to.OracleConfig("lepton3"), keep=True, apply_filter=True)
+        summ, counts, *_ = run_final(host_lib, tr, pool, 150, [0] * 150)
+        compare_final(summ, fin)
+        kept += len(fin["tracks"])
+        rejected += len(fin["filtered_tracks"])
+    assert kept > 5  # (rejects are exercised by the possum fixture: five "Didn't move" tracks)
