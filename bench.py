@@ -1,25 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X track stage.
+"""bench.py -- headline benchmark: CPTV frames/s end-to-end (track + classify) at 160x120.
 
-    python bench.py --gpus N --steps K --warmup W [--clips B] [--frames T]
+    python bench.py --gpus N --steps K --warmup W [--clips B] [--frames T] [--stage e2e|track]
 
-Workload (BASELINE.json configs[1]): B synthetic
-160x120 uint16 clips of T=270 frames (30 s at 9 fps) per GPU, lepton3
-thresholds, resident in HBM; one *step* = one pass of the track hot path over the
-batch (background update, filtered frame, 8-bit blur / threshold / close,
-8-connected labelling, component statistics + delta variance, label and filtered
-images written).  Whole-job frames/s = N * B * T * K / max-over-ranks time.
+Workload (BASELINE.json metric; configs[1] + [2] chained as in configs[3]): B synthetic 160x120
+uint16 clips of T = 270 frames (30 s at 9 fps) per GPU, lepton3 thresholds, resident in HBM when
+the timed region starts.  One *step* = one pass of the whole hot path over the batch:
+  track stage (background, filtered, blur/threshold/close, labelling, statistics, delta variance)
+  -> association (region filter, matching, Kalman) -> end-of-clip filtering -> segment plan
+  -> crop / resize / normalise / 5x5 tile -> WR-ResNet-22-4 forward (fp32 MFMA, 17 labels, seeded
+  random weights: no checkpoint can be downloaded) -> per-track aggregation.
+value = N * B * T * K / max-over-ranks time (barrier + device sync on both sides).
 
-For N > 1 the driver launches one rank per GPU through torch.distributed.run;
-clips shard across ranks with no data-path collective; the per-clip result
-records are all-gathered once per step over RCCL (north_star).
+N > 1: the driver launches one rank per GPU (torch.distributed.run); clips shard across ranks with
+no data-path collective; the per-track result records are all-gathered once per step over RCCL.
 
-The JSON line also carries
-  roofline     : cpx_frame_kernel, HBM-bound; achieved = 614,400 algorithmic bytes
-                 per frame x B frames per launch / average launch
-                 duration measured with HIP events on the handle's stream
-  cpu_baseline : the NumPy oracle ("port", 1 core) timed on a bounded sample of
-                 the same workload on this host (rank 0, N = 1 only)
+Extra objects on the JSON line:
+  roofline      the dominant kernel of the step.  e2e: the stage-2 3x3 grouped convolution
+                (conv_mfma_kernel<32,1,1,3>), MFMA-bound: algorithmic FLOPs of its launches / their
+                HIP-event time on the handle's stream, against the fp32-MFMA dense peak.  --stage track:
+                cpx_frame_kernel, HBM-bound, 614,400 algorithmic bytes per frame.
+  roofline_track  (e2e) the same HBM accounting for cpx_frame_kernel inside the same run.
+  cpu_baseline  the oracle chain ("port": NumPy tracker + NumPy crop/tile + PyTorch-CPU forward, 1 core)
+                timed on a bounded sample of the same workload on this host (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -32,14 +35,17 @@ for p in (os.path.join(REPO, "classifier-pipeline_amd"), os.path.join(REPO, "ora
     if p not in sys.path:
         sys.path.insert(0, p)
 
-ALGO_BYTES_PER_FRAME = 614400  # 32 B / pixel at 160x120
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ALGO_BYTES_PER_FRAME = 614400  # 32 B / pixel at 160x120 (labels + filtered written)
+LABEL_BYTES_PER_FRAME = 76800  # the int32 label image, not consumed by the classifier
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA
+N_LABELS = 17
 
 
 def synth_on_device(torch, device, n_clips, n_frames, seed, h=120, w=160, chunk=64):
-    """Synthetic clips generated on the GPU (same recipe as cpx.synth): smooth
-    background 2900 +- 40, sensor noise N(0, 4), up to 3 warm Gaussian blobs on
-    a random walk.  -> int16-bit-pattern uint16 tensor [n_clips*n_frames, h, w]."""
+    """Synthetic clips generated on the GPU (same recipe as cpx.synth): smooth background 2900 +- 40,
+    sensor noise N(0, 4), up to 3 warm Gaussian blobs on a random walk.
+    -> int16-bit-pattern uint16 tensor [n_clips*n_frames, h, w]."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     out = torch.empty((n_clips * n_frames, h, w), dtype=torch.int16, device=device)
@@ -75,38 +81,62 @@ def synth_on_device(torch, device, n_clips, n_frames, seed, h=120, w=160, chunk=
     return out
 
 
-def cpu_baseline(n_clips, n_frames, seed):
-    """The oracle restatement (NumPy, single core) over a bounded sample of the same workload."""
+def cpu_baseline(stage, n_clips, n_frames, seed, weights):
+    """The oracle chain (single core) over a bounded sample of the same workload."""
     import numpy as np
+    import torch
 
+    import classify_oracle as co
+    import cnn_oracle as cnn
     import track_oracle as to
     from cpx import synth
 
+    torch.set_num_threads(1)
     frames, offs = synth.make_batch(n_clips, n_frames, seed=seed)
     cfg = to.OracleConfig("lepton3")
+    H, W = frames.shape[1:]
+    n_samples = 0
     t0 = time.perf_counter()
     for b in range(n_clips):
-        to.track_clip(frames[offs[b]:offs[b + 1]], cfg=cfg, keep=True, do_tracking="regions")
+        clip = frames[offs[b]:offs[b + 1]]
+        if stage == "track":
+            to.track_clip(clip, cfg=cfg, keep=True, do_tracking="regions")
+            continue
+        out = to.track_clip(clip, cfg=cfg, keep=True)
+        fr = out["frames"]
+        for t in out["tracks"]:
+            usable = [r.frame_number for r in t.bounds if not r.blank and r.mass > 0 and r.width > 0 and r.height > 0]
+            if not usable:
+                continue
+            nseg = max(1, (len(usable) + 12) // 25)
+            segs = []
+            for s in range(nseg):
+                run = usable[25 * s: 25 * s + 25]
+                segs.append(np.array([run[(j * len(run)) // 25] for j in range(25)]))
+            by_frame = {r.frame_number: r for r in t.bounds}
+            x, _ = co.preprocess_segments(lambda q: clip[q], lambda q: fr[q]["filtered"].astype(np.float64), by_frame,
+                                          t.bounds, segs, 32, (1, 1, W - 2, H - 2))
+            _, probs = cnn.forward(weights, x)
+            co.classified_track(probs, prediction_frames=segs)
+            n_samples += nseg
     dt = time.perf_counter() - t0
-    return {
-        "value": round(n_clips * n_frames / dt, 1),
-        "unit": "frames/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": "%d synthetic clips x %d frames (oracle/track_oracle.py pixel stage + regions, NumPy, %.1f s)"
-        % (n_clips, n_frames, dt),
-    }
+    what = ("pixel stage + regions (NumPy)" if stage == "track" else
+            "track + classify (NumPy tracker, NumPy crop/tile, PyTorch-CPU fp32 forward; %d samples)" % n_samples)
+    return {"value": round(n_clips * n_frames / dt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic clips x %d frames, oracle %s, %.1f s" % (n_clips, n_frames, what, dt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default 4096, reduced if HBM is short)")
     ap.add_argument("--frames", type=int, default=270)
-    ap.add_argument("--cpu-clips", type=int, default=12, help="clips in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-outputs", action="store_true", help="do not write label / filtered images")
+    ap.add_argument("--stage", choices=("e2e", "track"), default="e2e",
+                    help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only")
+    ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cnn-chunk", type=int, default=512, help="samples per CNN forward")
     args = ap.parse_args()
 
     import numpy as np
@@ -125,21 +155,22 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     from cpx.engine import TrackEngine
+    from cpx.ml_tools import wrresnet as wr
+    from cpx.pipeline import BatchPipeline
+    from cpx.sharding import gather_records
 
+    e2e = args.stage == "e2e"
     H, W, T = 120, 160, args.frames
     P = H * W
-    want_out = not args.no_outputs
     B = args.clips or 4096
     free, _ = torch.cuda.mem_get_info(device)
-    per_clip = T * P * 2 + T * 64 * 32 + T * 80 + 6 * P * 4 + (T * P * 8 if want_out else 0)
-    while B > 64 and B * per_clip > 0.80 * free:
+    per_clip = T * P * 2 + T * 64 * 32 + T * 80 + 6 * P * 4 + T * P * 4 + (T * 16 * 56 if e2e else T * P * 4)
+    reserve = (args.cnn_chunk * 30e6) if e2e else 0
+    while B > 64 and B * per_clip + reserve > 0.80 * free:
         B //= 2
-    eng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_components=64,
-                      max_frames=max(T, 45))
+    eng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_components=64, max_frames=max(T, 45))
     frames = synth_on_device(torch, device, B, T, seed=1234 + rank)
     offs = (np.arange(B + 1, dtype=np.int64) * T).astype(np.int32)
     t_on = [100000 + 114 * i for i in range(T)]
@@ -148,22 +179,31 @@ def main():
     total = B * T
     comps = torch.empty(total * 64 * 8, dtype=torch.int32, device=device)
     info = torch.empty(total * 20, dtype=torch.int32, device=device)
-    labels = torch.empty((total, H, W), dtype=torch.int32, device=device) if want_out else None
-    filt = torch.empty((total, H, W), dtype=torch.float32, device=device) if want_out else None
+    filt = torch.empty((total, H, W), dtype=torch.float32, device=device)
+    labels = None if e2e else torch.empty((total, H, W), dtype=torch.int32, device=device)
     outputs = (comps, info, labels, filt, None)
-    gather_in = torch.zeros((B, 4), dtype=torch.int32, device=device)
-    gather_out = torch.empty((world * B, 4), dtype=torch.int32, device=device) if world > 1 else None
+    weights = wr.random_weights(N_LABELS, seed=0)
+    net = wr.WRResNetDevice(eng, weights, N_LABELS) if e2e else None
+    pipe = BatchPipeline(eng, net, n_labels=N_LABELS, fp_index=4, cnn_chunk=args.cnn_chunk)
+    state = {}
 
     def step():
+        if e2e:
+            res = pipe.run(frames, offs, meta, outputs=outputs)
+            state["res"] = res
+            state["track_ms"], state["track_n"] = eng.last_kernel_timing()
+            if world > 1 and res.n_tracks:
+                rec = torch.cat([res.track_clip[:, :1] + rank * B, res.track_clip[:, 1:], res.best.view(-1, 1),
+                                 (res.scores.max(dim=1).values * 1e6).to(torch.int32).view(-1, 1)], dim=1).contiguous()
+                state["gathered"] = gather_records(rec, dist)
+            return res.track
         res = eng.track_batch(frames, offs, meta, outputs=outputs)
         eng.synchronize()
+        state["track_ms"], state["track_n"] = eng.last_kernel_timing()
         if world > 1:
-            # per-clip result records -> every rank (north_star: RCCL all-gather of per-clip results)
-            nc = info.view(total, 20)[:, 1].view(B, T).sum(dim=1)
-            gather_in[:, 0] = rank
-            gather_in[:, 1] = torch.arange(B, device=device, dtype=torch.int32)
-            gather_in[:, 2] = nc.to(torch.int32)
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            nc = info.view(total, 20)[:, 1].view(B, T).sum(dim=1).to(torch.int32)
+            rec = torch.stack([torch.arange(B, device=device, dtype=torch.int32) + rank * B, nc], dim=1)
+            state["gathered"] = gather_records(rec, dist)
         return res
 
     def fence():
@@ -175,29 +215,35 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_ms, kernel_launches = 0.0, 0
+    eng.conv_timing(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-        ms, n = eng.last_kernel_timing()
-        kernel_ms += ms
-        kernel_launches += n
+        kernel_ms += state["track_ms"]
+        kernel_launches += state["track_n"]
     fence()
     elapsed = time.perf_counter() - t0
+    conv = eng.conv_timing() if e2e else {}
+    eng.conv_timing(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     res.check()
-    n_regions = int(res.info["n_components"].sum())
 
     if rank == 0:
         frames_done = world * B * T * args.steps
         avg_launch_s = kernel_ms / 1e3 / max(kernel_launches, 1)
-        bytes_per_launch = (ALGO_BYTES_PER_FRAME if want_out else ALGO_BYTES_PER_FRAME - 76800) * B
-        achieved = bytes_per_launch / avg_launch_s / 1e9
+        bytes_per_launch = (ALGO_BYTES_PER_FRAME - (LABEL_BYTES_PER_FRAME if e2e else 0)) * B
+        hbm = bytes_per_launch / avg_launch_s / 1e9
+        track_roof = {"kernel": "cpx_frame_kernel", "bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4), "traffic": None,
+                      "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": kernel_launches,
+                      "algorithmic_bytes_per_launch": bytes_per_launch}
         line = {
-            "metric": "CPTV frames/s (track stage: background + region-label HIP kernels) at 160x120",
+            "metric": "CPTV frames/s end-to-end (track+classify) at 160x120" if e2e else
+                      "CPTV frames/s (track stage only: background + region-label HIP kernels) at 160x120",
             "value": round(frames_done / elapsed, 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -207,32 +253,46 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u16/i32 (f32 normalise, f64 background weights)",
+            "dtype": "u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 MFMA CNN" if e2e else
+                     "u16/i32 (f32 normalise, f64 background weights)",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[1]: synthetic 160x120 uint16 clips, background + region-label kernels",
+                "workload": ("synthetic 160x120 uint16 clips -> track (BASELINE configs[1]) -> 25-frame segments -> "
+                             "crop/tile + WR-ResNet-22-4 forward (configs[2]/[3]), seeded random weights") if e2e else
+                            "BASELINE.json configs[1]: synthetic 160x120 uint16 clips, background + region-label kernels",
                 "clips_per_gpu": B,
                 "frames_per_clip": T,
                 "camera_model": "lepton3",
-                "outputs": "components + label image + filtered image" if want_out else "components only",
-                "components_found": n_regions,
-                "sharding": "clips across ranks, all_gather of per-clip records" if world > 1 else "single GPU",
-            },
-            "roofline": {
-                "kernel": "cpx_frame_kernel",
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "avg_launch_us": round(avg_launch_s * 1e6, 2),
-                "launches": kernel_launches,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "sharding": "clips across ranks, all_gather of per-track records" if world > 1 else "single GPU",
             },
         }
-        if world == 1 and args.cpu_clips > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_clips, T, seed=1234)
+        if e2e:
+            r = state["res"]
+            line["config"].update({"kept_tracks_per_step": int(r.n_tracks), "classified_segments_per_step": int(r.n_samples),
+                                   "frame_size": 32, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk})
+            key = 32 * 10000 + 32 * 10 + 1  # conv_mfma_kernel<32,1,1,3>: the stage-2 3x3 convolutions
+            if key in conv and conv[key][1] > 0:
+                n, ms, fl = conv[key]
+                tf = fl / (ms / 1e3) / 1e12
+                line["roofline"] = {"kernel": "conv_mfma_kernel<32,1,1,3> (64->64 ch, groups 2, 3x3, 160x160)",
+                                    "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                    "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
+                                    "algorithmic_flops_per_launch": fl / n}
+                tot_ms = sum(v[1] for v in conv.values())
+                tot_fl = sum(v[2] for v in conv.values())
+                line["cnn"] = {"conv_time_ms_per_step": round(tot_ms / args.steps, 2),
+                               "conv_tflops_all_layers": round(tot_fl / (tot_ms / 1e3) / 1e12, 2),
+                               "track_kernel_ms_per_step": round(kernel_ms / args.steps, 2)}
+            else:
+                line["roofline"] = track_roof
+            line["roofline_track"] = track_roof
+        else:
+            line["config"]["outputs"] = "components + label image + filtered image"
+            line["roofline"] = track_roof
+        ncpu = args.cpu_clips if args.cpu_clips >= 0 else (3 if e2e else 12)
+        if world == 1 and ncpu > 0:
+            line["cpu_baseline"] = cpu_baseline(args.stage, ncpu, T, 1234, weights)
         print(json.dumps(line))
     eng.close()
     if world > 1:

@@ -265,6 +265,23 @@ class TrackEngine:
         limits = limits_dev.cpu().numpy().view(TRACK_LIMITS_DTYPE).reshape(-1)[:n_tracks]
         return out, limits
 
+    def conv_timing(self, enable=None):
+        """enable=True/False switches per-launch HIP-event timing of cpx_conv2d; None reports
+        {key: (launches, total_ms, flops)} accumulated since it was enabled."""
+        from ._lib import CONV_TIMING_DTYPE
+
+        if enable is not None:
+            rc = self.lib.cpx_conv_timing_enable(self.h, 1 if enable else 0)
+            if rc != 0:
+                raise CpxError(rc, self._err())
+            return None
+        out = np.zeros(32, CONV_TIMING_DTYPE)
+        n = C.c_int(0)
+        rc = self.lib.cpx_conv_timing_report(self.h, C.c_void_p(out.ctypes.data), 32, C.byref(n))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        return {int(r["key"]): (int(r["launches"]), float(r["total_ms"]), float(r["flops"])) for r in out[: n.value]}
+
     def last_kernel_timing(self):
         ms = C.c_float()
         n = C.c_int()

@@ -27,6 +27,9 @@ struct cpx_handle {
   // small device arrays for the schedule
   int* sched_dev = nullptr;
   size_t sched_ints = 0;
+  struct ConvEv { int key; double flops; hipEvent_t e0, e1; };
+  std::vector<ConvEv> conv_events;
+  bool conv_timing = false;
   void* ws_assoc = nullptr;
   size_t ws_assoc_bytes = 0;
   // timing of the last batch
@@ -198,6 +201,10 @@ void cpx_destroy(cpx_handle* h) {
   if (h->wtab_dev) hipFree(h->wtab_dev);
   if (h->sched_dev) hipFree(h->sched_dev);
   if (h->ws_assoc) hipFree(h->ws_assoc);
+  for (auto& e : h->conv_events) {
+    hipEventDestroy(e.e0);
+    hipEventDestroy(e.e1);
+  }
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -430,7 +437,19 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) {
   a.in = d->in_dev; a.out = d->out_dev; a.weights = d->weights_dev;
   a.in_scale = d->in_scale_dev; a.in_shift = d->in_shift_dev;
   a.out_scale = d->out_scale_dev; a.out_shift = d->out_shift_dev; a.residual = d->residual_dev;
+  cpx_handle::ConvEv ev{};
+  if (h->conv_timing) {
+    ev.key = (a.Cin / a.groups) * 10000 + (a.Cout / a.groups) * 10 + a.stride + (a.ksize == 1 ? 5 : 0);
+    ev.flops = 2.0 * a.N * a.Ho * a.Wo * a.Cout * (double)(a.Cin / a.groups) * a.ksize * a.ksize;
+    if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess)
+      return fail(h, CPX_ERR_HIP, "cpx_conv2d: event creation failed");
+    CPX_HIP(h, hipEventRecord(ev.e0, h->stream));
+  }
   const int rc = cpx::launch_conv(a, h->stream);
+  if (h->conv_timing) {
+    CPX_HIP(h, hipEventRecord(ev.e1, h->stream));
+    h->conv_events.push_back(ev);
+  }
   if (rc == -2) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_conv2d: no kernel for this (channels per group, stride, kernel size)");
   if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_conv2d: kernel configuration failed");
   CPX_HIP(h, hipGetLastError());
@@ -552,6 +571,43 @@ int cpx_aggregate_predictions(cpx_handle* h, const float* probs_dev, const int32
   a.probs = probs_dev; a.sample_track = sample_track_dev; a.reqs = reqs_dev; a.scores = scores_dev; a.best = best_dev;
   cpx::launch_aggregate(a, h->stream);
   CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_conv_timing_enable(cpx_handle* h, int enable) {
+  if (!h) return CPX_ERR_INVALID;
+  for (auto& e : h->conv_events) {
+    hipEventDestroy(e.e0);
+    hipEventDestroy(e.e1);
+  }
+  h->conv_events.clear();
+  h->conv_timing = enable != 0;
+  return CPX_OK;
+}
+
+int cpx_conv_timing_report(cpx_handle* h, cpx_conv_timing* out, int cap, int* n_out) {
+  if (!h || !out || !n_out || cap < 1) return CPX_ERR_INVALID;
+  CPX_HIP(h, hipStreamSynchronize(h->stream));
+  int n = 0;
+  for (auto& e : h->conv_events) {
+    float ms = 0.f;
+    CPX_HIP(h, hipEventElapsedTime(&ms, e.e0, e.e1));
+    int i = 0;
+    for (; i < n; ++i)
+      if (out[i].key == e.key) break;
+    if (i == n) {
+      if (n == cap) return fail(h, CPX_ERR_OVERFLOW, "cpx_conv_timing_report: more kernel variants than capacity");
+      out[n].key = e.key;
+      out[n].launches = 0;
+      out[n].total_ms = 0.0;
+      out[n].flops = 0.0;
+      n += 1;
+    }
+    out[i].launches += 1;
+    out[i].total_ms += ms;
+    out[i].flops += e.flops;
+  }
+  *n_out = n;
   return CPX_OK;
 }
 

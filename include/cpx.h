@@ -294,6 +294,17 @@ int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
                  float* logits_dev, float* probs_dev);
 
+/* Per-kernel timing of cpx_conv2d launches with HIP events on the handle's stream (bench.py's roofline).
+ * cpx_conv_timing_enable(h, 1) starts collecting (and clears); cpx_conv_timing_report synchronises and
+ * returns, per kernel variant, total ms / launches / algorithmic FLOPs.  key = Cin_g*10000 + Cout_g*10 + stride
+ * (+ 5 for 1x1 kernels). */
+typedef struct cpx_conv_timing {
+  int32_t key, launches;
+  double total_ms, flops;
+} cpx_conv_timing;
+int cpx_conv_timing_enable(cpx_handle* h, int enable);
+int cpx_conv_timing_report(cpx_handle* h, cpx_conv_timing* out, int cap, int* n_out);
+
 /* Bytes of device workspace cpx_track_batch needs for B clips / total frames
  * (allocated lazily inside the handle and reused). */
 size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames);
