@@ -30,7 +30,8 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   constexpr int COG = 32 * NTN;       // output channels per group
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* s_patch = lds;                      // [PH*PW][KP]
-  float* s_w = lds + PH * PW * KP;           // [KS*KS][KC][COG]
+  constexpr int PATCH_FLOATS = (PH * PW * KP + 3) / 4 * 4;
+  float* s_w = lds + PATCH_FLOATS;           // [KS*KS][KC][COG], 16-byte aligned
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
@@ -58,29 +59,45 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   const int a_base = ((prow * S) * PW + pcol * S) * KP + kh;
   const int b_base = kh * COG + (lane & 31);
 
+  // staging geometry: a thread always serves the same group of 4 channels (256 % (KC/4) == 0), so the
+  // BatchNorm scale / shift of the prologue sit in registers for a whole chunk; 16-byte global loads
+  constexpr int C4 = KC / 4;                 // float4 groups per pixel
+  constexpr int NITEM = PH * PW * C4;        // float4 items of a patch chunk
+  const int my_c4 = tid % C4;
   for (int cc = 0; cc < cin_g; cc += KC) {
     // ---- stage the input patch chunk (BN + ReLU prologue; zero padding) ----
-    for (int idx = tid; idx < PH * PW * KC; idx += CT) {
-      const int c = idx % KC;
-      const int px = idx / KC;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.in_scale) {
+      const int ch = g * cin_g + cc + 4 * my_c4;
+      psc = *reinterpret_cast<const float4*>(a.in_scale + ch);
+      psh = *reinterpret_cast<const float4*>(a.in_shift + ch);
+    }
+    for (int item = tid; item < NITEM; item += CT) {
+      const int px = item / C4;
       const int py = px / PW, pxx = px - py * PW;
       const int iy = iy0 + py, ix = ix0 + pxx;
-      float v = 0.0f;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-        v = in_n[((size_t)iy * a.W + ix) * a.Cin + cc + c];
+        v = *reinterpret_cast<const float4*>(in_n + ((size_t)iy * a.W + ix) * a.Cin + cc + 4 * my_c4);
         if (a.in_scale) {
-          const int ch = g * cin_g + cc + c;
-          v = fmaxf(v * a.in_scale[ch] + a.in_shift[ch], 0.0f);
+          v.x = fmaxf(v.x * psc.x + psh.x, 0.0f);
+          v.y = fmaxf(v.y * psc.y + psh.y, 0.0f);
+          v.z = fmaxf(v.z * psc.z + psh.z, 0.0f);
+          v.w = fmaxf(v.w * psc.w + psh.w, 0.0f);
         }
       }
-      s_patch[px * KP + c] = v;
+      float* d = s_patch + px * KP + 4 * my_c4;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
     }
-    // ---- stage the weight chunk [tap][KC][COG] ----
-    for (int idx = tid; idx < KS * KS * KC * COG; idx += CT) {
-      const int co = idx % COG;
-      const int r = idx / COG;
-      const int k = r % KC, tap = r / KC;
-      s_w[idx] = wg[((size_t)tap * cin_g + cc + k) * COG + co];
+    // ---- stage the weight chunk [tap][KC][COG]: KC*COG contiguous floats per tap ----
+    constexpr int WV = KC * COG / 4;  // float4 per tap
+    for (int item = tid; item < KS * KS * WV; item += CT) {
+      const int tap = item / WV, r = item - tap * WV;
+      const float4 w4 = *reinterpret_cast<const float4*>(wg + ((size_t)tap * cin_g + cc) * COG + 4 * r);
+      *reinterpret_cast<float4*>(s_w + tap * KC * COG + 4 * r) = w4;
     }
     __syncthreads();
 #pragma unroll
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 template <int KC, int NTN, int S, int KS>
 static int launch_conv_t(const ConvArgs& a, hipStream_t s) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
-  const size_t lds = ((size_t)PH * PW * (KC + 1) + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
+  const size_t lds = (((size_t)PH * PW * (KC + 1) + 3) / 4 * 4 + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS>),
