@@ -137,6 +137,8 @@ def main():
                     help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only")
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cnn-chunk", type=int, default=512, help="samples per CNN forward")
+    ap.add_argument("--denoise", action="store_true",
+                    help="tracking.denoise = true (the reference's default: NLM kernel between normalise and blur)")
     args = ap.parse_args()
 
     import numpy as np
@@ -170,7 +172,8 @@ def main():
     reserve = (args.cnn_chunk * 30e6) if e2e else 0
     while B > 64 and B * per_clip + reserve > 0.80 * free:
         B //= 2
-    eng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_components=64, max_frames=max(T, 45))
+    eng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_components=64, max_frames=max(T, 45),
+                      denoise=args.denoise)
     frames = synth_on_device(torch, device, B, T, seed=1234 + rank)
     offs = (np.arange(B + 1, dtype=np.int64) * T).astype(np.int32)
     t_on = [100000 + 114 * i for i in range(T)]
@@ -263,6 +266,7 @@ def main():
                 "clips_per_gpu": B,
                 "frames_per_clip": T,
                 "camera_model": "lepton3",
+                "denoise": bool(args.denoise),
                 "sharding": "clips across ranks, all_gather of per-track records" if world > 1 else "single GPU",
             },
         }

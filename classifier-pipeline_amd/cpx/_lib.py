@@ -37,6 +37,8 @@ class Config(C.Structure):
         ("weight_add", C.c_double),
         ("max_components", C.c_int32),
         ("max_frames", C.c_int32),
+        ("denoise", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

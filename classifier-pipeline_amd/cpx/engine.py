@@ -111,7 +111,7 @@ class AssocBatchResult:
 
 class TrackEngine:
     def __init__(self, width=160, height=120, model="lepton3", device=0, edge_pixels=1, window=45,
-                 max_components=64, max_frames=4096, background_thresh=None, weight_add=None):
+                 max_components=64, max_frames=4096, background_thresh=None, weight_add=None, denoise=False):
         import torch
 
         self.torch = torch
@@ -122,7 +122,7 @@ class TrackEngine:
         self.cfg = _lib.Config(width, height, edge_pixels, window,
                                float(bt if background_thresh is None else background_thresh),
                                float(wa if weight_add is None else weight_add),
-                               max_components, max_frames)
+                               max_components, max_frames, 1 if denoise else 0, 0)
         self.device = torch.device("cuda", device)
         self.h = C.c_void_p()
         rc = self.lib.cpx_create(device, C.byref(self.cfg), C.byref(self.h))

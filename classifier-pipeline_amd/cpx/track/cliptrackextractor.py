@@ -26,16 +26,17 @@ _ENGINES = {}
 
 
 def get_engine(width, height, background_thresh, weight_add, edge_pixels=1, device=0, max_frames=4096,
-               max_components=64):
-    """One device engine per (geometry, thresholds) in this process."""
-    key = (width, height, float(background_thresh), float(weight_add), edge_pixels, device, max_components)
+               max_components=64, denoise=False):
+    """One device engine per (geometry, thresholds, denoise) in this process."""
+    key = (width, height, float(background_thresh), float(weight_add), edge_pixels, device, max_components,
+           bool(denoise))
     eng = _ENGINES.get(key)
     if eng is None or eng.cfg.max_frames < max_frames:
         if eng is not None:
             eng.close()
         eng = TrackEngine(width=width, height=height, device=device, edge_pixels=edge_pixels,
                           background_thresh=background_thresh, weight_add=weight_add,
-                          max_components=max_components, max_frames=max(max_frames, 1024))
+                          max_components=max_components, max_frames=max(max_frames, 1024), denoise=denoise)
         _ENGINES[key] = eng
     return eng
 
@@ -235,15 +236,12 @@ class ClipTrackExtractor(ClipTracker):
     def _track_clip(self, clip, process_background=False):
         if clip.background is None:
             raise Exception("Clip has no background have you called init_clip first")
-        if self.config.denoise:
-            raise NotImplementedError(
-                "tracking.denoise=True (cv2.fastNlMeansDenoising) has no HIP kernel yet: set denoise: false")
         frames = self._frames
         n = len(frames)
         cam35 = clip.camera_model == "lepton3.5"
         weight_add = (1 if cam35 else 0.1) / self.weighting_percent
         eng = get_engine(clip.res_x, clip.res_y, clip.background_thresh, weight_add, self.config.edge_pixels,
-                         self.device, max_frames=n)
+                         self.device, max_frames=n, denoise=bool(self.config.denoise))
         t0 = time.time()
         stack = np.stack([f.pix for f in frames])
         bgf = [bool(f.background_frame) and not process_background for f in frames]

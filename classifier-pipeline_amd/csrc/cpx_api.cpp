@@ -24,6 +24,7 @@ struct cpx_handle {
   size_t ws_bytes = 0;
   double* wtab_dev = nullptr;
   int wtab_len = 0;
+  int* nlm_lut_dev = nullptr;
   // small device arrays for the schedule
   int* sched_dev = nullptr;
   size_t sched_ints = 0;
@@ -41,7 +42,7 @@ struct cpx_handle {
 static_assert(sizeof(cpx_component) == 32, "cpx_component layout is part of the ABI");
 static_assert(sizeof(cpx_frame_info) == 80, "cpx_frame_info layout is part of the ABI");
 static_assert(sizeof(cpx_frame_meta) == 24, "cpx_frame_meta layout is part of the ABI");
-static_assert(sizeof(cpx_config) == 40, "cpx_config layout is part of the ABI");
+static_assert(sizeof(cpx_config) == 48, "cpx_config layout is part of the ABI");
 static_assert(sizeof(cpx_region_ref) == 24 && sizeof(cpx_track_limits) == 16 && sizeof(cpx_crop_req) == 32,
               "classification request layouts are part of the ABI");
 static_assert(sizeof(cpx_filter_params) == 72 && sizeof(cpx_track_summary) == 120,
@@ -72,7 +73,7 @@ int fail(cpx_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t bg, wsum, kcnt, filt, cstate, total;
+  size_t bg, wsum, kcnt, filt, cstate, u8, carry, total;
 };
 
 WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
@@ -89,6 +90,10 @@ WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
   if (need_filt_state) off = align_up(off + (size_t)B * 2 * P * sizeof(float), 256);
   l.cstate = off;
   off = align_up(off + (size_t)B * sizeof(cpx::ClipState), 256);
+  l.u8 = off;
+  if (c.denoise) off = align_up(off + (size_t)B * P, 256);
+  l.carry = off;
+  if (c.denoise) off = align_up(off + (size_t)B * sizeof(cpx::FrameCarry), 256);
   l.total = off;
   return l;
 }
@@ -183,6 +188,26 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     wt[k] = w;
     w = w + cfg->weight_add;
   }
+  if (cfg->denoise) {
+    if (!cpx::nlm_supported(W, H)) {
+      cpx_destroy(h);
+      return CPX_ERR_UNSUPPORTED;
+    }
+    // fastNlMeansDenoising weight table (h = 3, template 7x7, search 21x21), SURVEY.md Appendix A.6:
+    // w[a] = round(fixed_point_mult * exp(-a * (64/49) / h^2)), zero below 0.001 * fixed_point_mult
+    const int fixed_point_mult = (int)(2147483647LL / (21 * 21 * 255));
+    std::vector<int> lut(64, 0);
+    for (int a2 = 0; a2 < 64; ++a2) {
+      const double wv = std::exp(-((double)a2 * (64.0 / 49.0)) / 9.0);
+      const double wr = std::nearbyint((double)fixed_point_mult * wv);
+      lut[a2] = (wr < 0.001 * fixed_point_mult) ? 0 : (int)wr;
+    }
+    if (lut[63] != 0 || hipMalloc((void**)&h->nlm_lut_dev, 64 * sizeof(int)) != hipSuccess ||
+        hipMemcpy(h->nlm_lut_dev, lut.data(), 64 * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      cpx_destroy(h);
+      return CPX_ERR_HIP;
+    }
+  }
   if (hipMalloc(&h->wtab_dev, wt.size() * sizeof(double)) != hipSuccess ||
       hipMemcpy(h->wtab_dev, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
       cpx::frame_kernel_attr_setup() != 0) {
@@ -199,6 +224,7 @@ void cpx_destroy(cpx_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->ws) hipFree(h->ws);
   if (h->wtab_dev) hipFree(h->wtab_dev);
+  if (h->nlm_lut_dev) hipFree(h->nlm_lut_dev);
   if (h->sched_dev) hipFree(h->sched_dev);
   if (h->ws_assoc) hipFree(h->ws_assoc);
   for (auto& e : h->conv_events) {
@@ -275,6 +301,9 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
   a.kcnt = (uint16_t*)(base + l.kcnt);
   a.filt_state = need_filt ? (float*)(base + l.filt) : nullptr;
   a.cstate = (cpx::ClipState*)(base + l.cstate);
+  a.u8_state = c.denoise ? (unsigned char*)(base + l.u8) : nullptr;
+  a.carry = c.denoise ? (cpx::FrameCarry*)(base + l.carry) : nullptr;
+  a.nlm_lut = h->nlm_lut_dev;
   a.comps_out = comps_dev;
   a.info_out = info_dev;
   a.labels_out = labels_dev;
@@ -284,7 +313,15 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
   CPX_HIP(h, hipMemsetAsync(info_dev, 0xFF, (size_t)total * sizeof(cpx_frame_info), h->stream));
   cpx::launch_init(a, B, h->stream);
   CPX_HIP(h, hipEventRecord(h->ev0, h->stream));
-  for (int t = 0; t < max_proc; ++t) cpx::launch_frame(a, B, t, h->stream);
+  for (int t = 0; t < max_proc; ++t) {
+    if (!c.denoise) {
+      cpx::launch_frame(a, B, t, 0, h->stream);
+    } else {  // front (normalise) -> non-local means -> back (blur / threshold / label / statistics)
+      cpx::launch_frame(a, B, t, 1, h->stream);
+      cpx::launch_nlm(a, B, t, h->stream);
+      cpx::launch_frame(a, B, t, 2, h->stream);
+    }
+  }
   CPX_HIP(h, hipEventRecord(h->ev1, h->stream));
   h->last_launches = max_proc;
   h->timing_valid = true;

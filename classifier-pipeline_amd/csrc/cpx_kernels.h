@@ -37,6 +37,24 @@ struct ClipState {
   int pad;
 };
 
+// block-reduced scalars of the streaming pass
+struct Red1 {
+  unsigned int sumpix;
+  unsigned int minpix, maxpix;
+  int fmin, fmax;
+  unsigned int sumbg;
+  unsigned int changed;
+  unsigned long long sumabs;
+};
+
+// scalars that cross the front / back split of a frame step (denoise)
+struct FrameCarry {
+  Red1 R;
+  int avg_change, mn, mx, ithr;
+  float thresh, median;
+  int pad;
+};
+
 struct TrackArgs {
   // geometry / config
   int W, H, edge, window, cap_out;
@@ -55,6 +73,9 @@ struct TrackArgs {
   uint16_t* kcnt;           // [B][P] consecutive "background kept" count -> weight = wtab[k]
   float* filt_state;        // [B][2][P] ping-pong filtered (only when filtered_out == nullptr)
   ClipState* cstate;        // [B]
+  unsigned char* u8_state;  // [B][P] normalised uint8 image between front / NLM / back (denoise only)
+  FrameCarry* carry;        // [B]
+  const int* nlm_lut;       // [64] fixed-point NLM weights (denoise only)
   // outputs
   Component* comps_out;     // [total_frames * cap_out]
   FrameInfo* info_out;      // [total_frames]
@@ -167,7 +188,10 @@ int track_max_pixels();
 int track_lds_components();
 int frame_kernel_attr_setup();
 void launch_init(const TrackArgs& a, int B, hipStream_t s);
-void launch_frame(const TrackArgs& a, int B, int t, hipStream_t s);
+void launch_frame(const TrackArgs& a, int B, int t, int mode, hipStream_t s);
+void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s);
+size_t nlm_lds_bytes(int W, int H);
+int nlm_supported(int W, int H);
 void launch_export_background(const TrackArgs& a, int B, float* out, hipStream_t s);
 
 }  // namespace cpx

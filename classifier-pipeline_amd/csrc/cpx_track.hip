@@ -118,14 +118,7 @@ __device__ __forceinline__ void uf_union(u32* parent, u32 a, u32 b) {
   }
 }
 
-struct Red1 {
-  u32 sumpix;
-  u32 minpix, maxpix;
-  int fmin, fmax;
-  u32 sumbg;
-  u32 changed;
-  u64 sumabs;
-};
+
 
 }  // namespace
 
@@ -170,7 +163,10 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a) {
 // ---------------------------------------------------------------------------
 // one processed frame of every clip
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_kernel(TrackArgs a, int t) {
+// mode 0: whole frame step.  With denoise the step is split around the NLM kernel: mode 1 = front
+// (phases 1-3: streaming pass, normalised uint8 image -> HBM), mode 2 = back (phases 4-8 on the
+// denoised image); the scalars crossing the split travel in FrameCarry.
+__global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_kernel(TrackArgs a, int t, int mode) {
   const int b = blockIdx.x;
   const int pbase = a.proc_off[b];
   const int nproc = a.proc_off[b + 1] - pbase;
@@ -222,6 +218,9 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
   const ClipState cs = a.cstate[b];
 
+  int avg_change = 0, mn = 0, mx = 0, ithr = 0;
+  float thresh = 0.0f;
+  if (mode != 2) {
   // ---- phase 1a: thermal frame -> registers (2 pixels per VGPR), sum / min / max ----------------
   u32 pk[NCH][2];
   {
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
   // avg_change = int(round(np.average(thermal) - background.average))  (cliptracker.py:103-105)
   const double mean_thermal = (double)sumpix / (double)P;
-  const int avg_change = (int)rint(mean_thermal - cs.bg_average);
+  avg_change = (int)rint(mean_thermal - cs.bg_average);
 
   // ---- np.median(thermal) (clip.py:475): exact selection by bisection on the value range, counting
   // in registers; median = mean of the two middle order statistics ---------------------------------
@@ -340,7 +339,8 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   r.sumbg = 0;
   r.changed = 0;
   r.sumabs = 0;
-  int mn = 0x7FFFFFFF, mx = 0;
+  mn = 0x7FFFFFFF;
+  mx = 0;
   // deliberately NOT unrolled: the body is long, and an unrolled version keeps 30 precomputed 64-bit
   // addresses live and spills; 32 waves per CU cover the HBM latency instead
 #pragma unroll CPX_TRACK_P1B_UNROLL
@@ -466,7 +466,6 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   mx = s_bc[1];
 
   // ---- phase 3: normalise to 0..255 (float32, imageprocessing.py:151-169) -> uint8 in LDS
-  float thresh;
   {
     const float fmn = (float)mn, fmx = (float)mx;
     const float span = fmx - fmn;
@@ -497,8 +496,44 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       }
     }
   }
-  const int ithr = (mx == mn) ? (int)floor(a.background_thresh) : (int)floorf(thresh);
+  ithr = (mx == mn) ? (int)floor(a.background_thresh) : (int)floorf(thresh);
   __syncthreads();
+  } else {
+    // ---- back half of a split step: scalars from the carry, the (denoised) uint8 image from HBM ----
+    const FrameCarry fc = a.carry[b];
+    avg_change = fc.avg_change;
+    mn = fc.mn;
+    mx = fc.mx;
+    ithr = fc.ithr;
+    thresh = fc.thresh;
+    if (tid == 0) {
+      *s_R = fc.R;
+      reinterpret_cast<float*>(s_bc)[2] = fc.median;
+      *s_ncomp_p = 0;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(a.u8_state + (size_t)b * P);
+    for (int i = tid; i < (P >> 4); i += NT) reinterpret_cast<uint4*>(s_u8)[i] = src[i];
+    for (int i = tid; i < 2 * H * RW; i += NT) s_rowI[i] = 0ull;
+    __syncthreads();
+  }
+  if (mode == 1) {
+    // ---- front half: hand the normalised uint8 image and the scalars to the NLM / back kernels ----
+    uint4* dst = reinterpret_cast<uint4*>(a.u8_state + (size_t)b * P);
+    for (int i = tid; i < (P >> 4); i += NT) dst[i] = reinterpret_cast<const uint4*>(s_u8)[i];
+    if (tid == 0) {
+      FrameCarry fc;
+      fc.R = *s_R;
+      fc.avg_change = avg_change;
+      fc.mn = mn;
+      fc.mx = mx;
+      fc.ithr = ithr;
+      fc.thresh = thresh;
+      fc.median = reinterpret_cast<const float*>(s_bc)[2];
+      fc.pad = 0;
+      a.carry[b] = fc;
+    }
+    return;
+  }
 #define CPX_STOP(n)                                                                                   \
   if (CPX_TIMING_STOP_AFTER == (n)) {                                                                 \
     if (tid == 0) a.info_out[fidx].threshold = thresh + (float)ithr + (float)s_u8[avg_change & 1023] + (float)s_rowE[5]; \
@@ -831,6 +866,138 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// cv2.fastNlMeansDenoising(uint8, None) with the defaults h = 3, template 7, search 21
+// (track/cliptracker.py:116-117; integer algorithm of SURVEY.md Appendix A.6): for every pixel and
+// every offset in [-10,10]^2 the 7x7 sum of squared differences, weight = LUT[dist >> 6] (fixed
+// point, 48 non-zero entries), result = (sum w*v + sum w / 2) / sum w.  One workgroup per frame;
+// per offset: row-wise 7-sums of squared differences into LDS (pass A), column-wise sliding 7-sums +
+// weight accumulation in registers (pass B).  In place on the uint8 image between the front and back
+// halves of the frame step.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int NLM_R = 13;   // border = template radius 3 + search radius 10
+constexpr int NLM_BH = 20;  // rows per thread in pass B (register accumulators)
+__device__ __forceinline__ int refl101(int v, int n) { return v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v); }
+}  // namespace
+
+__global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
+  const int b = blockIdx.x;
+  const int nproc = a.proc_off[b + 1] - a.proc_off[b];
+  if (t >= nproc) return;
+  const int W = a.W, H = a.H, P = W * H;
+  const int tid = threadIdx.x;
+  const int EW = W + 2 * NLM_R, EH = H + 2 * NLM_R;
+  const int ES = (EW + 3) & ~3;  // row stride of the padded image (bytes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ext = smem;                                                   // [EH][ES]
+  u32* Hs = reinterpret_cast<u32*>(smem + (((size_t)EH * ES + 15) & ~(size_t)15));  // [(H+6)][W]
+  int* s_lut = reinterpret_cast<int*>(Hs + (size_t)(H + 6) * W);              // [64]
+  unsigned char* img = a.u8_state + (size_t)b * P;
+
+  for (int i = tid; i < EH * ES; i += NT) {
+    const int ey = i / ES, ex = i - ey * ES;
+    unsigned char v = 0;
+    if (ex < EW) v = img[refl101(ey - NLM_R, H) * W + refl101(ex - NLM_R, W)];
+    ext[i] = v;
+  }
+  if (tid < 64) s_lut[tid] = a.nlm_lut[tid];
+  // pass-B role: one image column and a band of NLM_BH rows
+  const int nbands = NT / W;
+  const int bx = tid % W, band = tid / W;
+  const bool active_b = band < nbands && band * NLM_BH < H;
+  int est[NLM_BH], wsum[NLM_BH];
+#pragma unroll
+  for (int i = 0; i < NLM_BH; ++i) est[i] = wsum[i] = 0;
+  __syncthreads();
+
+  const int segs = W >> 3;             // 8-pixel segments per row
+  const int items = (H + 6) * segs;    // pass-A work items
+  for (int off = 0; off < 441; ++off) {
+    const int dy = off / 21 - 10, dx = off - (off / 21) * 21 - 10;
+    // ---- pass A: Hs[r+3][x] = sum_{v=-3..3} (ext(r, x+v) - ext(r+dy, x+dx+v))^2 for r in [-3, H+3) ----
+    for (int it = tid; it < items; it += NT) {
+      const int rr = it / segs, x0 = (it - rr * segs) << 3;  // rr = r + 3
+      // bytes x0-3 .. x0+10 of both rows (14 values); byte address of (r, x) is (r+13)*ES + x + 13
+      const unsigned char* pa = ext + (rr - 3 + NLM_R) * ES + x0 + NLM_R - 3;
+      const unsigned char* pb = ext + (rr - 3 + NLM_R + dy) * ES + x0 + NLM_R - 3 + dx;
+      int d2[14];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        const int d = (int)pa[k] - (int)pb[k];
+        d2[k] = d * d;
+      }
+      u32 hsum[8];
+      u32 acc = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc += (u32)d2[k];
+      hsum[0] = acc;
+#pragma unroll
+      for (int k = 1; k < 8; ++k) {
+        acc += (u32)d2[k + 6] - (u32)d2[k - 1];
+        hsum[k] = acc;
+      }
+      uint4* dst = reinterpret_cast<uint4*>(Hs + (size_t)rr * W + x0);
+      dst[0] = make_uint4(hsum[0], hsum[1], hsum[2], hsum[3]);
+      dst[1] = make_uint4(hsum[4], hsum[5], hsum[6], hsum[7]);
+    }
+    __syncthreads();
+    // ---- pass B: dist(y, x) = sum_{k=0..6} Hs[y+k][x]; weight; accumulate ----
+    if (active_b) {
+      const int y0 = band * NLM_BH;
+      u32 V = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) V += Hs[(size_t)(y0 + k) * W + bx];
+#pragma unroll
+      for (int i = 0; i < NLM_BH; ++i) {
+        const int y = y0 + i;
+        if (y < H) {
+          const u32 aidx = V >> 6;
+          if (aidx < 64u) {
+            const int w = s_lut[aidx];
+            if (w) {
+              est[i] += w * (int)ext[(y + NLM_R + dy) * ES + bx + NLM_R + dx];
+              wsum[i] += w;
+            }
+          }
+          if (y + 1 < H) V += Hs[(size_t)(y + 7) * W + bx] - Hs[(size_t)y * W + bx];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (active_b) {
+#pragma unroll
+    for (int i = 0; i < NLM_BH; ++i) {
+      const int y = band * NLM_BH + i;
+      if (y < H) {
+        const u32 ws = (u32)wsum[i];
+        u32 v = ((u32)est[i] + ws / 2u) / ws;  // the zero offset always contributes LUT[0] > 0
+        img[y * W + bx] = (unsigned char)(v > 255u ? 255u : v);
+      }
+    }
+  }
+}
+
+size_t nlm_lds_bytes(int W, int H) {
+  const size_t ES = ((size_t)W + 2 * NLM_R + 3) & ~(size_t)3;
+  return ((((size_t)H + 2 * NLM_R) * ES + 15) & ~(size_t)15) + ((size_t)H + 6) * W * 4 + 64 * 4;
+}
+int nlm_supported(int W, int H) {
+  const int nbands = NT / W;
+  return nbands >= 1 && nbands * NLM_BH >= H && (W % 8) == 0 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
+}
+void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_nlm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024 - 2048);
+    configured = true;
+  }
+  hipLaunchKernelGGL(cpx_nlm_kernel, dim3(B), dim3(NT), nlm_lds_bytes(a.W, a.H), s, a, t);
+}
+
 // final background of each clip as float, edges replicated (motiondetector.py:239-244)
 __global__ __launch_bounds__(256) void cpx_export_background_kernel(TrackArgs a, float* out) {
   const int b = blockIdx.x;
@@ -849,8 +1016,8 @@ size_t track_lds_bytes(int W, int H) {
 }
 
 void launch_init(const TrackArgs& a, int B, hipStream_t s) { hipLaunchKernelGGL(cpx_init_kernel, dim3(B), dim3(256), 0, s, a); }
-void launch_frame(const TrackArgs& a, int B, int t, hipStream_t s) {
-  hipLaunchKernelGGL(cpx_frame_kernel, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t);
+void launch_frame(const TrackArgs& a, int B, int t, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_frame_kernel, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t, mode);
 }
 void launch_export_background(const TrackArgs& a, int B, float* out, hipStream_t s) {
   hipLaunchKernelGGL(cpx_export_background_kernel, dim3(B), dim3(256), 0, s, a, out);

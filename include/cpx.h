@@ -50,6 +50,8 @@ typedef struct cpx_config {
   double weight_add;         /* 0.1 (lepton3) / 1.0 (lepton3.5) */
   int32_t max_components;    /* capacity of the per-frame component list */
   int32_t max_frames;        /* longest clip (frames) the handle must support */
+  int32_t denoise;           /* 1: cv2.fastNlMeansDenoising (tracking.denoise, the reference's default) */
+  int32_t reserved;
 } cpx_config;
 
 /* Per-frame metadata delivered by the CPTV reader (cptv.py; reference

@@ -34,7 +34,7 @@ def test_create_fails_loudly_without_gpu():
 
     lib = _lib.load()
     h = C.c_void_p()
-    cfg = _lib.Config(160, 120, 1, 45, 20.0, 0.1, 64, 512)
+    cfg = _lib.Config(160, 120, 1, 45, 20.0, 0.1, 64, 512, 0, 0)
     assert lib.cpx_create(0, C.byref(cfg), C.byref(h)) == -3  # CPX_ERR_NO_DEVICE
     from cpx.engine import TrackEngine
 
@@ -45,7 +45,7 @@ def test_create_fails_loudly_without_gpu():
 def test_struct_layouts():
     from cpx import _lib, tracking
 
-    assert C.sizeof(_lib.Config) == 40
+    assert C.sizeof(_lib.Config) == 48
     assert _lib.FRAME_META_DTYPE.itemsize == 24
     assert _lib.COMPONENT_DTYPE.itemsize == 32
     assert _lib.FRAME_INFO_DTYPE.itemsize == 80

@@ -78,12 +78,31 @@ def test_extract_file_matches_reference_tracks(tmp_path, name):
         assert written["algorithm"]["tracker_version"] == gold["algorithm"]["tracker_version"]
 
 
-def test_default_config_denoise_is_refused_loudly(tmp_path):
-    """denoise: true has no kernel yet -> explicit error, never a silent CPU path."""
+def test_default_config_reproduces_the_references_own_golden(tmp_path):
+    """Default configuration (denoise on: the NLM kernel) on possum.cptv against the reference's committed
+    golden tests/clips/possum.txt: every position of both tracks, frame ranges, scores."""
     from cpx.config import Config
     from cpx.track.trackextractor import extract_file
 
     src = tmp_path / "possum.cptv"
     shutil.copy(os.path.join(GOLDEN, "possum.cptv"), src)
-    with pytest.raises(NotImplementedError):
-        extract_file(src, Config.get_defaults(), False)
+    clip, extractor, meta = extract_file(src, Config.get_defaults(), False)
+    with open(os.path.join(GOLDEN, "possum.txt")) as fh:
+        gold = json.load(fh)
+    assert len(clip.tracks) == len(gold["tracks"]) == 2
+    for t, g in zip(clip.tracks, gold["tracks"]):
+        assert (t.get_id(), t.start_frame, t.end_frame, len(t)) == (g["id"], g["frame_start"], g["frame_end"], g["num_frames"])
+        for r, p in zip(t.bounds_history, g["positions"]):
+            assert (r.x, r.y, r.width, r.height, int(r.mass), r.frame_number, r.blank) == (
+                p["x"], p["y"], p["width"], p["height"], p["mass"], p["frame_number"], p["blank"])
+            assert abs(round(float(r.pixel_variance), 2) - p["pixel_variance"]) < 1.5e-2
+        assert abs(t.stats.score - g["tracking_score"]) <= 1e-6 * g["tracking_score"]
+    # and every frame's label image against the vectors the reference produced with denoise on
+    z, gt = load_golden("possum", 1)
+    from helpers import crc
+
+    for q in range(int(z["n_frames"])):
+        fr = clip.frame_buffer.get_frame(q)
+        assert crc(fr.mask) == z["crc_mask"][q], q
+        assert crc(fr.filtered.astype(np.int32)) == z["crc_filtered"][q], q
+    assert [(r, t.get_id()) for r, t in clip.filtered_tracks] == [(f["reason"], f["id"]) for f in gt["filtered"]]

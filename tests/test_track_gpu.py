@@ -336,3 +336,32 @@ def test_association_matches_oracle_on_synthetic(engines):
         nt += a
         nb += c
     assert nt > 10 and nb > 10
+
+
+def test_denoise_matches_oracle_on_synthetic(engines):
+    """tracking.denoise = True (cv2.fastNlMeansDenoising between normalise and blur): label images and
+    components bit-identical to the oracle on synthetic clips (short: the NumPy NLM is slow)."""
+    from cpx import synth
+    import track_oracle as to
+
+    rng = np.random.default_rng(77)
+    clips = [synth.make_clip(rng, 14, max_blobs=3) for _ in range(3)]
+    eng = engines("lepton3", denoise=True)
+    offs = (np.arange(4) * 14).astype(np.int32)
+    res = eng.track_batch(eng.upload_frames(np.concatenate(clips)), offs, eng.make_meta(42), want_labels=True,
+                          want_filtered=True)
+    res.check()
+    labels = res.labels()
+    ncomp = 0
+    for b in range(3):
+        cfg = to.OracleConfig("lepton3")
+        cfg.denoise = True
+        out = to.track_clip(clips[b], cfg=cfg, keep=True, do_tracking=False)
+        for i, o in enumerate(out["frames"]):
+            f = int(offs[b]) + i
+            assert np.array_equal(labels[f], o["mask"]), (b, i)
+            c = res.components(f)
+            got = np.stack([c["x"], c["y"], c["width"], c["height"], c["area"]], axis=1).reshape(-1, 5)
+            assert np.array_equal(got, o["stats"]), (b, i)
+            ncomp += len(c)
+    assert ncomp > 0
