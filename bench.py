@@ -294,7 +294,7 @@ def main():
         else:
             line["config"]["outputs"] = "components + label image + filtered image"
             line["roofline"] = track_roof
-        ncpu = args.cpu_clips if args.cpu_clips >= 0 else (3 if e2e else 12)
+        ncpu = args.cpu_clips if args.cpu_clips >= 0 else (20 if e2e else 16)  # ~15 s of single-core work
         if world == 1 and ncpu > 0:
             line["cpu_baseline"] = cpu_baseline(args.stage, ncpu, T, 1234, weights)
         print(json.dumps(line))
