@@ -118,9 +118,12 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: affine (bias / folded BN), residual, ReLU, store NHWC ----
+  // ---- epilogue: affine (bias / folded BN) from the accumulators, then through LDS so that residual
+  // loads and stores are 16 bytes per lane (8 lanes = one pixel's 128 contiguous bytes): 4x fewer, wider
+  // memory instructions than the accumulator layout (one channel per lane, 4 bytes) would give ----
   float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
   const float* res_n = a.residual ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+  float* s_tile = lds + wave * (32 * 32);  // [32 pixels][32 channels] per wave; patch / weights are dead now
 #pragma unroll
   for (int t = 0; t < NTN; ++t) {
     const int ch = g * COG + t * 32 + (lane & 31);
@@ -129,15 +132,28 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
+      s_tile[i * 32 + (lane & 31)] = acc[t][r] * os + ob;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = it * 64 + lane;         // float4 index inside the tile
+      const int i = f >> 3, c4 = f & 7;
       const int oy = oy0 + 2 * wave + (i >> 4), ox = ox0 + (i & 15);
       if (oy < a.Ho && ox < a.Wo) {
-        const size_t o = ((size_t)oy * a.Wo + ox) * a.Cout + ch;
-        float v = acc[t][r] * os + ob;
-        if (res_n) v += res_n[o];
-        if (a.relu) v = fmaxf(v, 0.0f);
-        out_n[o] = v;
+        float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
+        const size_t o = ((size_t)oy * a.Wo + ox) * a.Cout + g * COG + t * 32 + 4 * c4;
+        if (res_n) {
+          const float4 rv = *reinterpret_cast<const float4*>(res_n + o);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        }
+        *reinterpret_cast<float4*>(out_n + o) = v;
       }
     }
+    if (t + 1 < NTN) __syncthreads();
   }
 }
 
@@ -201,7 +217,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 template <int KC, int NTN, int S, int KS>
 static int launch_conv_t(const ConvArgs& a, hipStream_t s) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
-  const size_t lds = (((size_t)PH * PW * (KC + 1) + 3) / 4 * 4 + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
+  size_t lds = (((size_t)PH * PW * (KC + 1) + 3) / 4 * 4 + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
+  if (lds < 4 * 32 * 32 * sizeof(float)) lds = 4 * 32 * 32 * sizeof(float);  // epilogue tiles
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS>),
