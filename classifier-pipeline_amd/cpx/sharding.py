@@ -26,7 +26,7 @@ def gather_records(records, dist=None, device=None):
     concatenation without padding, sorted by clip id (same on every rank)."""
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         out = records
     else:
         world = dist.get_world_size()
