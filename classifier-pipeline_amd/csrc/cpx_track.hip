@@ -889,7 +889,8 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
   const int W = a.W, H = a.H, P = W * H;
   const int tid = threadIdx.x;
   const int EW = W + 2 * NLM_R, EH = H + 2 * NLM_R;
-  const int ES = (EW + 3) & ~3;  // row stride of the padded image (bytes)
+  const int ES = (EW + 8 + 7) & ~7;  // row stride of the padded image: multiple of 8, 8 bytes of slack for the
+                                     // aligned 24-byte fetch of a shifted row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ext = smem;                                                   // [EH][ES]
   u32* Hs = reinterpret_cast<u32*>(smem + (((size_t)EH * ES + 15) & ~(size_t)15));  // [(H+6)][W]
@@ -919,14 +920,40 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
     // ---- pass A: Hs[r+3][x] = sum_{v=-3..3} (ext(r, x+v) - ext(r+dy, x+dx+v))^2 for r in [-3, H+3) ----
     for (int it = tid; it < items; it += NT) {
       const int rr = it / segs, x0 = (it - rr * segs) << 3;  // rr = r + 3
-      // bytes x0-3 .. x0+10 of both rows (14 values); byte address of (r, x) is (r+13)*ES + x + 13
-      const unsigned char* pa = ext + (rr - 3 + NLM_R) * ES + x0 + NLM_R - 3;
-      const unsigned char* pb = ext + (rr - 3 + NLM_R + dy) * ES + x0 + NLM_R - 3 + dx;
+      // bytes x0-3 .. x0+10 of both rows (14 values); byte address of (r, x) is (r+13)*ES + x + 13.
+      // ES is a multiple of 8 and x0 a multiple of 8, so both rows are fetched with aligned 8-byte LDS
+      // reads (conflict-free at this lane stride) and shifted into place with wave-uniform shifts.
+      const int abase = (rr - 3 + NLM_R) * ES + x0 + 8;           // a-bytes start at abase + 2
+      const uint2 qa0 = *reinterpret_cast<const uint2*>(ext + abase);
+      const uint2 qa1 = *reinterpret_cast<const uint2*>(ext + abase + 8);
+      const u64 a0 = ((u64)qa0.y << 32) | qa0.x, a1 = ((u64)qa1.y << 32) | qa1.x;
+      const u64 alo = (a0 >> 16) | (a1 << 48);                    // bytes 0..7 of the 14
+      const u64 ahi = a1 >> 16;                                   // bytes 8..13
+      const int boff = NLM_R - 3 + dx;                            // 0 .. 20
+      const int bsh = (boff & 7) * 8;
+      const int bbase = (rr - 3 + NLM_R + dy) * ES + x0 + (boff & ~7);
+      const uint2 qb0 = *reinterpret_cast<const uint2*>(ext + bbase);
+      const uint2 qb1 = *reinterpret_cast<const uint2*>(ext + bbase + 8);
+      const uint2 qb2 = *reinterpret_cast<const uint2*>(ext + bbase + 16);
+      const u64 b0 = ((u64)qb0.y << 32) | qb0.x, b1 = ((u64)qb1.y << 32) | qb1.x, b2 = ((u64)qb2.y << 32) | qb2.x;
+      u64 blo, bhi;
+      if (bsh == 0) {
+        blo = b0;
+        bhi = b1;
+      } else {
+        blo = (b0 >> bsh) | (b1 << (64 - bsh));
+        bhi = (b1 >> bsh) | (b2 << (64 - bsh));
+      }
       int d2[14];
 #pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        const int d = (int)pa[k] - (int)pb[k];
+      for (int k = 0; k < 8; ++k) {
+        const int d = (int)((alo >> (8 * k)) & 0xFF) - (int)((blo >> (8 * k)) & 0xFF);
         d2[k] = d * d;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int d = (int)((ahi >> (8 * k)) & 0xFF) - (int)((bhi >> (8 * k)) & 0xFF);
+        d2[8 + k] = d * d;
       }
       u32 hsum[8];
       u32 acc = 0;
@@ -946,9 +973,13 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
     // ---- pass B: dist(y, x) = sum_{k=0..6} Hs[y+k][x]; weight; accumulate ----
     if (active_b) {
       const int y0 = band * NLM_BH;
+      // the band's NLM_BH + 6 row sums of this column, once, into registers; then a sliding 7-sum
+      u32 hv[NLM_BH + 6];
+#pragma unroll
+      for (int k = 0; k < NLM_BH + 6; ++k) hv[k] = (y0 + k < H + 6) ? Hs[(size_t)(y0 + k) * W + bx] : 0u;
       u32 V = 0;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) V += Hs[(size_t)(y0 + k) * W + bx];
+      for (int k = 0; k < 7; ++k) V += hv[k];
 #pragma unroll
       for (int i = 0; i < NLM_BH; ++i) {
         const int y = y0 + i;
@@ -961,8 +992,8 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
               wsum[i] += w;
             }
           }
-          if (y + 1 < H) V += Hs[(size_t)(y + 7) * W + bx] - Hs[(size_t)y * W + bx];
         }
+        if (i + 1 < NLM_BH) V += hv[i + 7] - hv[i];
       }
     }
     __syncthreads();
@@ -981,7 +1012,7 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
 }
 
 size_t nlm_lds_bytes(int W, int H) {
-  const size_t ES = ((size_t)W + 2 * NLM_R + 3) & ~(size_t)3;
+  const size_t ES = ((size_t)W + 2 * NLM_R + 8 + 7) & ~(size_t)7;
   return ((((size_t)H + 2 * NLM_R) * ES + 15) & ~(size_t)15) + ((size_t)H + 6) * W * 4 + 64 * 4;
 }
 int nlm_supported(int W, int H) {
