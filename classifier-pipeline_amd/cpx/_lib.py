@@ -70,7 +70,7 @@ EXPORTS = [
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
-    "cpx_conv_timing_enable", "cpx_conv_timing_report",
+    "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack",
 ]
 
 _lib = None
@@ -126,6 +126,8 @@ def load():
     lib.cpx_conv_timing_enable.restype = C.c_int
     lib.cpx_conv_timing_report.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.cpx_conv_timing_report.restype = C.c_int
+    lib.cpx_cptv_unpack.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    lib.cpx_cptv_unpack.restype = C.c_int
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]

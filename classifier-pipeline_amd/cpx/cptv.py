@@ -21,8 +21,8 @@ Reader contract used by the tracker: ``get_header()`` -> object with
 ``temp_c``, ``last_ffc_temp_c``; ``None`` at end of file.
 """
 
-import gzip
 import struct
+import zlib
 
 import numpy as np
 
@@ -110,8 +110,25 @@ class CptvReader:
     """Sequential CPTV v2 reader with the ``cptv_rs_python_bindings`` surface."""
 
     def __init__(self, path):
-        with gzip.open(str(path), "rb") as f:
-            self._buf = f.read()
+        with open(str(path), "rb") as f:
+            raw = f.read()
+        if raw[:2] == b"\x1f\x8b":
+            # whole-buffer inflate (zlib releases the GIL: decode_clips_on_device runs readers in threads);
+            # concatenated gzip members are followed like gzip.open does
+            out = []
+            while raw:
+                d = zlib.decompressobj(47)
+                try:
+                    out.append(d.decompress(raw))
+                except zlib.error as e:
+                    raise ValueError("corrupt CPTV gzip stream: %s (%s)" % (path, e))
+                if not d.eof:
+                    out.append(d.flush())
+                    break  # truncated stream: the section parser reports it
+                raw = d.unused_data
+            self._buf = b"".join(out)
+        else:
+            self._buf = raw
         buf = self._buf
         if buf[:4] != b"CPTV":
             raise ValueError("not a CPTV file: %s" % path)
@@ -162,7 +179,9 @@ class CptvReader:
     def get_header(self):
         return self._header
 
-    def next_frame(self):
+    def _next_section(self):
+        """Parse the next frame section's fields without touching its payload:
+        (fields, payload offset, payload bytes, bits per delta) or None at the end."""
         buf = self._buf
         pos = self._pos
         if pos >= len(buf):
@@ -172,10 +191,48 @@ class CptvReader:
         fields, pos = _read_fields(buf, pos + 1)
         width = fields["w"][0]
         nbytes = _u32(fields["f"])
-        payload = buf[pos : pos + nbytes]
-        if len(payload) < nbytes:
+        if pos + nbytes > len(buf):
             raise ValueError("truncated CPTV frame")
+        need = 4 + ((self._w * self._h - 1) * width + 7) // 8
+        if nbytes < need or not 1 <= width <= 32:
+            raise ValueError("malformed CPTV frame section at %d" % pos)
         self._pos = pos + nbytes
+        return fields, pos, nbytes, width
+
+    def scan(self):
+        """Index the remaining frame sections for the device decoder
+        (``decode_clips_on_device``): per frame the metadata-only CptvFrame
+        (``pix`` None), payload offset into ``inflated`` and delta width."""
+        frames, offsets, widths = [], [], []
+        while True:
+            sec = self._next_section()
+            if sec is None:
+                break
+            fields, pos, _, width = sec
+            frames.append(self._frame_from_fields(fields, None))
+            offsets.append(pos)
+            widths.append(width)
+        return frames, np.asarray(offsets, np.int64), np.asarray(widths, np.int32)
+
+    @property
+    def inflated(self):
+        return self._buf
+
+    @staticmethod
+    def _frame_from_fields(fields, pix):
+        time_on = _u32(fields["t"]) if "t" in fields else None
+        last_ffc = _u32(fields["c"]) if "c" in fields else None
+        temp_c = _f32(fields["a"]) if "a" in fields else 0.0
+        ffc_temp = _f32(fields["b"]) if "b" in fields else 0.0
+        bg = ("g" in fields) and fields["g"][0] != 0
+        return CptvFrame(pix, time_on, last_ffc, temp_c, ffc_temp, bg)
+
+    def next_frame(self):
+        sec = self._next_section()
+        if sec is None:
+            return None
+        fields, pos, nbytes, width = sec
+        payload = self._buf[pos : pos + nbytes]
         n = self._w * self._h
         deltas = np.empty(n, dtype=np.int64)
         deltas[0] = struct.unpack("<i", payload[:4])[0]
@@ -183,12 +240,7 @@ class CptvReader:
         diff = np.cumsum(deltas)[self._snake]
         self._prev = self._prev + diff
         pix = self._prev.astype(np.uint16)
-        time_on = _u32(fields["t"]) if "t" in fields else None
-        last_ffc = _u32(fields["c"]) if "c" in fields else None
-        temp_c = _f32(fields["a"]) if "a" in fields else 0.0
-        ffc_temp = _f32(fields["b"]) if "b" in fields else 0.0
-        bg = ("g" in fields) and fields["g"][0] != 0
-        return CptvFrame(pix, time_on, last_ffc, temp_c, ffc_temp, bg)
+        return self._frame_from_fields(fields, pix)
 
     def read_all(self):
         frames = []
@@ -197,3 +249,45 @@ class CptvReader:
             if f is None:
                 return frames
             frames.append(f)
+
+
+def decode_clips_on_device(engine, paths, workers=8):
+    """Decode whole CPTV files with ``cpx_cptv_unpack`` (include/cpx.h): the host
+    inflates the gzip stream and indexes the sections, the GPU unpacks the
+    frames.  Returns (headers, per-clip lists of metadata-only CptvFrame,
+    frames_dev uint16 [total, H, W] as a torch int16 tensor, clip_offsets)."""
+    import torch
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    def index(path):
+        reader = CptvReader(path)
+        return (reader,) + reader.scan()
+
+    paths = list(paths)
+    if len(paths) > 1:
+        with ThreadPoolExecutor(max_workers=min(len(paths), workers)) as pool:
+            indexed = list(pool.map(index, paths))
+    else:
+        indexed = [index(p) for p in paths]
+    headers, metas, chunks, offs, widths, clip_offsets = [], [], [], [], [], [0]
+    base = 0
+    for path, (reader, frames, o, w) in zip(paths, indexed):
+        h = reader.get_header()
+        if (h.x_resolution, h.y_resolution) != (engine.width, engine.height):
+            raise ValueError("%s is %dx%d, the engine was created for %dx%d"
+                             % (path, h.x_resolution, h.y_resolution, engine.width, engine.height))
+        headers.append(h)
+        metas.append(frames)
+        chunks.append(np.frombuffer(reader.inflated, np.uint8))
+        offs.append(o + base)
+        widths.append(w)
+        base += len(reader.inflated)
+        clip_offsets.append(clip_offsets[-1] + len(frames))
+    total = clip_offsets[-1]
+    if total == 0:
+        raise ValueError("no frames in %s" % (list(paths),))
+    payload = np.concatenate(chunks + [np.zeros(16, np.uint8)])
+    frames_dev = engine.cptv_unpack(payload, np.concatenate(offs), np.concatenate(widths),
+                                    np.asarray(clip_offsets, np.int32))
+    return headers, metas, frames_dev, np.asarray(clip_offsets, np.int32)

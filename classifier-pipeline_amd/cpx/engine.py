@@ -155,6 +155,27 @@ class TrackEngine:
         a = np.ascontiguousarray(frames, dtype=np.uint16)
         return t.from_numpy(a.view(np.int16)).to(self.device)
 
+    def cptv_unpack(self, payload, frame_offsets, bit_widths, clip_offsets):
+        """Inflated CPTV bytes + section index (cpx.cptv.CptvReader.scan) -> device frames [total,H,W]
+        (uint16 bits in an int16 tensor), decoded by cpx_cptv_unpack."""
+        t = self.torch
+        offs = np.ascontiguousarray(clip_offsets, dtype=np.int32)
+        total = int(offs[-1])
+        fo = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+        bw = np.ascontiguousarray(bit_widths, dtype=np.int32)
+        assert fo.size == total and bw.size == total
+        pay = t.from_numpy(np.array(payload, dtype=np.uint8, copy=True)).to(self.device)
+        fo_d, bw_d, offs_d = (t.from_numpy(a).to(self.device) for a in (fo, bw, offs))
+        out = t.empty((total, self.height, self.width), dtype=t.int16, device=self.device)
+        t.cuda.current_stream(self.device).synchronize()
+        rc = self.lib.cpx_cptv_unpack(self.h, C.c_void_p(pay.data_ptr()), C.c_void_p(fo_d.data_ptr()),
+                                      C.c_void_p(bw_d.data_ptr()), C.c_void_p(offs_d.data_ptr()), offs.size - 1,
+                                      C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        self.synchronize()  # the staging tensors go out of scope here
+        return out
+
     @staticmethod
     def make_meta(n, time_on=None, last_ffc=None, background=None):
         m = np.zeros(n, dtype=FRAME_META_DTYPE)

@@ -1,8 +1,9 @@
 """ClipTrackExtractor -- drop-in for the reference class of the same name
 (reference src/track/cliptrackextractor.py:34-247, src/track/cliptracker.py:14-491).
 
-parse_clip() decodes the CPTV on the host, uploads the whole clip and runs it
-through the HIP track stage (cpx_track_batch) and the HIP association stage
+parse_clip() inflates the CPTV container on the host, decodes the frame payloads on
+the GPU (cpx_cptv_unpack) and runs the clip through the HIP track stage
+(cpx_track_batch) and the HIP association stage
 (cpx_associate_batch); the Clip / Frame / Track / Region objects the
 reference's callers read are then built from the device records.  End-of-clip
 filtering (trim, statistics, score ordering, rejects) is host work as in the
@@ -14,7 +15,7 @@ from datetime import datetime
 
 import numpy as np
 
-from ..cptv import CptvReader
+from ..cptv import CptvReader, decode_clips_on_device
 from ..engine import TrackEngine
 from ..ml_tools.rectangle import Rectangle
 from ..tracking import make_track_params
@@ -191,6 +192,9 @@ class ClipTrackExtractor(ClipTracker):
         self.weighting_percent = 1
         self.device = device
         self._frames = None
+        self._frames_dev = None
+        self._engine = None
+        self._weight_add = None
         self._header = None
         self.timings = {}
 
@@ -209,10 +213,23 @@ class ClipTrackExtractor(ClipTracker):
         clip.set_model(header.model if header.model else None)
         start = datetime.fromtimestamp(header.timestamp / 1000000).astimezone(Clip.local_tz)
         clip.set_video_stats(start)
-        self._frames = reader.read_all()
         self._header = header
-        if not self._frames:
+        cam35 = clip.camera_model == "lepton3.5"
+        self._weight_add = (1 if cam35 else 0.1) / self.weighting_percent
+        frames, offsets, widths = reader.scan()
+        if not frames:
             raise Exception("CPTV file has no frames: {}".format(clip.source_file))
+        eng = get_engine(clip.res_x, clip.res_y, clip.background_thresh, self._weight_add, self.config.edge_pixels,
+                         self.device, max_frames=len(frames), denoise=bool(self.config.denoise))
+        t0 = time.time()
+        self._frames_dev = eng.cptv_unpack(np.frombuffer(reader.inflated + bytes(16), np.uint8), offsets, widths,
+                                           np.array([0, len(frames)], np.int32))
+        pix = self._frames_dev.cpu().numpy().view(np.uint16)
+        self.timings["decode_s"] = time.time() - t0
+        for f, p in zip(frames, pix):
+            f.pix = p
+        self._frames = frames
+        self._engine = eng
         clip.update_background(self._frames[0].pix)
         clip._background_calculated()
 
@@ -238,17 +255,14 @@ class ClipTrackExtractor(ClipTracker):
             raise Exception("Clip has no background have you called init_clip first")
         frames = self._frames
         n = len(frames)
-        cam35 = clip.camera_model == "lepton3.5"
-        weight_add = (1 if cam35 else 0.1) / self.weighting_percent
-        eng = get_engine(clip.res_x, clip.res_y, clip.background_thresh, weight_add, self.config.edge_pixels,
-                         self.device, max_frames=n, denoise=bool(self.config.denoise))
+        weight_add = self._weight_add
+        eng = self._engine
         t0 = time.time()
-        stack = np.stack([f.pix for f in frames])
         bgf = [bool(f.background_frame) and not process_background for f in frames]
         meta = eng.make_meta(n, [f.time_on for f in frames], [f.last_ffc_time for f in frames], bgf)
         offs = np.array([0, n], np.int32)
         want_images = self.keep_frames
-        frames_dev = eng.upload_frames(stack)
+        frames_dev = self._frames_dev
         res = eng.track_batch(frames_dev, offs, meta, want_labels=want_images, want_filtered=True,
                               want_background=True)
         assoc = None

@@ -648,6 +648,28 @@ int cpx_conv_timing_report(cpx_handle* h, cpx_conv_timing* out, int cap, int* n_
   return CPX_OK;
 }
 
+int cpx_cptv_unpack(cpx_handle* h, const uint8_t* payload_dev, const int64_t* frame_offsets_dev,
+                    const int32_t* bit_widths_dev, const int32_t* clip_offsets_dev, int B,
+                    uint16_t* frames_out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!payload_dev || !frame_offsets_dev || !bit_widths_dev || !clip_offsets_dev || !frames_out_dev || B < 1)
+    return fail(h, CPX_ERR_INVALID, "cpx_cptv_unpack: bad argument");
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::CptvArgs a{};
+  a.W = h->cfg.width;
+  a.H = h->cfg.height;
+  a.payload = payload_dev;
+  a.frame_offsets = (const long long*)frame_offsets_dev;
+  a.bit_widths = bit_widths_dev;
+  a.clip_offsets = clip_offsets_dev;
+  a.frames_out = frames_out_dev;
+  const int rc = cpx::launch_cptv_unpack(a, B, h->stream);
+  if (rc == -2) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_cptv_unpack: resolution too large for the unpack kernel");
+  if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_cptv_unpack: kernel configuration failed");
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches) {
   if (!h || !total_ms || !launches) return CPX_ERR_INVALID;
   if (!h->timing_valid) return fail(h, CPX_ERR_INVALID, "no batch has been run");

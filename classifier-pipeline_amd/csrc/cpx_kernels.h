@@ -183,6 +183,16 @@ struct HeadArgs {
 int launch_conv(const ConvArgs& a, hipStream_t s);
 void launch_head(const HeadArgs& a, hipStream_t s);
 
+struct CptvArgs {
+  int W, H;
+  const unsigned char* payload;
+  const long long* frame_offsets;
+  const int* bit_widths;
+  const int* clip_offsets;
+  uint16_t* frames_out;
+};
+int launch_cptv_unpack(const CptvArgs& a, int B, hipStream_t s);
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

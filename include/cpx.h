@@ -139,6 +139,23 @@ const char* cpx_last_error(const cpx_handle* h);
 void* cpx_stream(cpx_handle* h);
 int cpx_synchronize(cpx_handle* h);
 
+/* ---- CPTV v2 frame payload decode ------------------------------------------
+ * Replaces the bit-unpack / running-sum / snake-order / inter-frame accumulation of the Rust CPTV
+ * reader (python-cptv 0.0.8, used at track/cliptrackextractor.py:108-129,160-162) for B clips.
+ * The gzip container is inflated and its section headers parsed on the host (cpx/cptv.py); this call
+ * gets the inflated bytes.  Per frame: int32 LE first value, then W*H-1 signed `bit_width`-bit deltas,
+ * MSB first; their running sum, laid out in snake order (odd rows right to left), is added to the
+ * previous frame of the same clip.
+ * payload_dev        uint8  inflated file bytes of all clips, concatenated
+ * frame_offsets_dev  int64  [total_frames] byte offset of each frame's payload inside payload_dev
+ * bit_widths_dev     int32  [total_frames]
+ * clip_offsets_dev   int32  [B+1] frame ranges of the clips
+ * frames_out_dev     uint16 [total_frames, H, W]
+ */
+int cpx_cptv_unpack(cpx_handle* h, const uint8_t* payload_dev, const int64_t* frame_offsets_dev,
+                    const int32_t* bit_widths_dev, const int32_t* clip_offsets_dev, int B,
+                    uint16_t* frames_out_dev);
+
 /* ---- track stage: background + filtered + threshold + CC + stats ---------
  * Replaces, for a batch of B independent clips, the per-frame arithmetic of
  *   ClipTrackExtractor.init_clip / _track_clip / process_frame

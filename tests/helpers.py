@@ -30,3 +30,48 @@ def load_golden(name, dn):
     with open(os.path.join(GOLDEN, "%s_dn%d_tracks.json" % (name, dn))) as fh:
         tracks = json.load(fh)
     return z, tracks
+
+
+def encode_cptv(path, frames, widths, time_on=None, last_ffc=None, model=b"lepton3", background_first=False):
+    """Write a CPTV v2 file (test-side encoder, the inverse of cpx.cptv): `frames` uint16 [N,H,W],
+    `widths[i]` bits per delta of frame i -- the caller picks widths wide enough for the data."""
+    import gzip
+    import struct
+
+    frames = np.asarray(frames, np.uint16)
+    N, H, W = frames.shape
+
+    def field(code, data):
+        return bytes([len(data)]) + code + data
+
+    out = bytearray(b"CPTV\x02H")
+    hdr = [field(b"T", struct.pack("<Q", 1600000000000000)), field(b"X", struct.pack("<I", W)),
+           field(b"Y", struct.pack("<I", H)), field(b"C", b"\x01"), field(b"D", b"synthetic"),
+           field(b"E", model), field(b"Z", b"\x09")]
+    if background_first:
+        hdr.append(field(b"g", b"\x01"))
+    out += bytes([len(hdr)]) + b"".join(hdr)
+    snake = np.arange(W * H).reshape(H, W)
+    snake[1::2] = snake[1::2, ::-1].copy()
+    order = np.argsort(snake.reshape(-1))  # scan index -> pixel index
+    prev = np.zeros(W * H, np.int64)
+    for i in range(N):
+        cur = frames[i].reshape(-1).astype(np.int64)
+        diff = (cur - prev)[order]
+        prev = cur
+        deltas = np.diff(diff, prepend=0)
+        w = int(widths[i])
+        d = deltas[1:]
+        assert d.min() >= -(1 << (w - 1)) and d.max() < (1 << (w - 1)), "width %d too narrow" % w
+        u = (d & ((1 << w) - 1)).astype(np.uint64)
+        bits = ((u[:, None] >> np.arange(w - 1, -1, -1, dtype=np.uint64)) & 1).astype(np.uint8)
+        packed = np.packbits(bits.reshape(-1)).tobytes()
+        payload = struct.pack("<i", int(deltas[0])) + packed
+        fl = [field(b"w", bytes([w])), field(b"f", struct.pack("<I", len(payload)))]
+        if time_on is not None:
+            fl += [field(b"t", struct.pack("<I", int(time_on[i]))), field(b"c", struct.pack("<I", int(last_ffc[i])))]
+        if background_first and i == 0:
+            fl.append(field(b"g", b"\x01"))
+        out += b"F" + bytes([len(fl)]) + b"".join(fl) + payload
+    with gzip.open(str(path), "wb") as f:
+        f.write(bytes(out))
