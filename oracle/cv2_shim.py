@@ -320,21 +320,262 @@ class KalmanFilter:
         return self.statePost.copy()
 
 
-def findContours(image, mode, method, *args, **kwargs):
-    """Thumbnail scoring only (classify/thumbnail.py:91) -- out of scope (f3).
+CHAIN_APPROX_TC89_L1 = 3
+CHAIN_APPROX_TC89_KCOS = 4
+_CODE_DELTAS = ((1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1))  # code -> (dx, dy)
+_ABS_DIFF = (1, 2, 3, 4, 3, 2, 1, 0, 1, 2, 3, 4, 3, 2, 1)
 
-    Returns one 'contour' per 8-connected component with as many points as the
-    component has boundary pixels so that callers relying on len() keep working.
-    """
-    img = np.asarray(image) > 0
-    lab, n = ndimage.label(img, structure=np.ones((3, 3), dtype=np.int32))
+
+def _trace_border(img, x0, y0):
+    """Suzuki-Abe border following of an outer border starting at (x0, y0) of the zero-padded int8
+    image (OpenCV contours: icvFetchContour with nbd = 2).  Marks the border pixels (2, or -126 where
+    the border has background on its right) and returns the Freeman chain codes."""
+    def at(x, y):
+        return img[y, x]
+
+    s_end = s = 4
+    while True:
+        s = (s - 1) & 7
+        x1, y1 = x0 + _CODE_DELTAS[s][0], y0 + _CODE_DELTAS[s][1]
+        if at(x1, y1) != 0 or s == s_end:
+            break
+    if s == s_end:  # single pixel
+        img[y0, x0] = -126
+        return []
+    chain = []
+    x3, y3 = x0, y0
+    while True:
+        s_end = s
+        while s < 15:
+            s += 1
+            d = _CODE_DELTAS[s & 7]
+            x4, y4 = x3 + d[0], y3 + d[1]
+            if at(x4, y4) != 0:
+                break
+        s &= 7
+        if ((s - 1) & 0xFFFFFFFF) < s_end:  # unsigned compare as in the C source
+            img[y3, x3] = -126
+        elif img[y3, x3] == 1:
+            img[y3, x3] = 2
+        chain.append(s)
+        if (x4, y4) == (x0, y0) and (x3, y3) == (x1, y1):
+            break
+        x3, y3 = x4, y4
+        s = (s + 4) & 7
+    return chain
+
+
+def _approx_chain(chain, origin, method):
+    """Chain codes -> polygon points (CHAIN_APPROX_NONE / SIMPLE / TC89_L1), following OpenCV's
+    Teh-Chin implementation pass by pass (1-curvature, support regions, non-maxima suppression,
+    1-length support removal, pair cleaning)."""
+    n = len(chain)
+    if n == 0:
+        return [origin]
+    pts, svals = [], []
+    x, y = origin
+    for i in range(n):
+        prev_code = chain[i - 1]
+        pts.append((x, y))
+        svals.append(_ABS_DIFF[chain[i] - prev_code + 7])
+        x += _CODE_DELTAS[chain[i]][0]
+        y += _CODE_DELTAS[chain[i]][1]
+    if method == CHAIN_APPROX_NONE:
+        return pts
+    if method == CHAIN_APPROX_SIMPLE:
+        return [p for p, sv in zip(pts, svals) if sv != 0]
+    if method != CHAIN_APPROX_TC89_L1:
+        raise NotImplementedError("contour approximation %r" % method)
+    length = n
+    s = list(svals) + [0]
+    k = [0] * (n + 1)
+    nxt = [None] * (n + 1)           # linked list over array indices; -1 is the list head `temp`
+    pts = pts + [None]
+    head = {"next": None}
+    order = [i for i in range(n) if s[i] != 0]
+    assert order, "closed chain without a corner"
+
+    def link(seq):
+        head["next"] = seq[0] if seq else None
+        for a, b in zip(seq, seq[1:]):
+            nxt[a] = b
+        if seq:
+            nxt[seq[-1]] = None
+
+    link(order)
+    # Pass 1: support region of every remaining point
+    cur = head["next"]
+    while cur is not None:
+        i = cur
+        x0, y0 = pts[i]
+        l = 0
+        d_num = 0
+        kk = 1
+        while True:
+            assert kk <= length
+            i1 = i - kk
+            i1 += length if i1 < 0 else 0
+            i2 = i + kk
+            i2 -= length if i2 >= length else 0
+            dx = pts[i2][0] - pts[i1][0]
+            dy = pts[i2][1] - pts[i1][1]
+            lk = dx * dx + dy * dy
+            dk_num = (x0 - pts[i1][0]) * dy - (y0 - pts[i1][1]) * dx
+            d = float(np.float32(float(d_num) * lk - float(dk_num) * l))
+            if kk > 1 and (l >= lk or (d_num > 0 and d <= 0) or (d_num < 0 and d >= 0)):
+                break
+            d_num = dk_num
+            l = lk
+            kk += 1
+        k[cur] = kk - 1
+        cur = nxt[cur]
+    # Pass 2: non-maxima suppression
+    prev = None
+    cur = head["next"]
+
+    def unlink(prev, cur):
+        if prev is None:
+            head["next"] = nxt[cur]
+        else:
+            nxt[prev] = nxt[cur]
+
+    while cur is not None:
+        k2 = k[cur] >> 1
+        sv = s[cur]
+        i = cur
+        j = 1
+        while j <= k2:
+            i2 = i - j
+            i2 += length if i2 < 0 else 0
+            if s[i2] > sv:
+                break
+            i2 = i + j
+            i2 -= length if i2 >= length else 0
+            if s[i2] > sv:
+                break
+            j += 1
+        if j <= k2:
+            unlink(prev, cur)
+            s[cur] = 0
+        else:
+            prev = cur
+        cur = nxt[cur]
+    # Pass 3: non-dominant points with a 1-length support region
+    prev = None
+    cur = head["next"]
+    assert cur is not None
+    while cur is not None:
+        if k[cur] == 1:
+            sv = s[cur]
+            i = cur
+            i1 = i - 1
+            i1 += length if i1 < 0 else 0
+            i2 = i + 1
+            i2 -= length if i2 >= length else 0
+            if sv <= s[i1] or sv <= s[i2]:
+                unlink(prev, cur)
+                s[cur] = 0
+            else:
+                prev = cur
+        else:
+            prev = cur
+        cur = nxt[cur]
+    # Pass 4: clean the remaining couples of neighbouring points
+    assert head["next"] is not None
+    all_survived = False
+    if s[0] != 0 and s[length - 1] != 0:  # a run of points wraps around the array end
+        i1 = 1
+        while i1 < length and s[i1] != 0:
+            s[i1 - 1] = 0
+            i1 += 1
+        if i1 == length:
+            all_survived = True
+        else:
+            i1 -= 1
+            i2 = length - 2
+            while i2 > 0 and s[i2] != 0:
+                nxt[i2] = None
+                s[i2 + 1] = 0
+                i2 -= 1
+            i2 += 1
+            if i1 == 0 and i2 == length - 1:  # only two points
+                i1 = nxt[0]
+                pts[length] = pts[0]
+                s[length] = s[0]
+                k[length] = k[0]
+                nxt[length] = None
+                nxt[length - 1] = length
+            head["next"] = i1
+    if not all_survived:
+        cur = head["next"]
+        first = prev = None           # None stands for the list head
+        count = 1
+
+        def set_next(node, val):
+            if node is None:
+                head["next"] = val
+            else:
+                nxt[node] = val
+
+        def get_next(node):
+            return head["next"] if node is None else nxt[node]
+
+        while cur is not None:
+            if nxt[cur] is None or nxt[cur] - cur != 1:
+                if count >= 2:
+                    if count == 2:
+                        s1 = 0 if prev is None else s[prev]
+                        s2 = s[cur]
+                        k1 = 0 if prev is None else k[prev]
+                        if s1 > s2 or (s1 == s2 and k1 <= k[cur]):
+                            set_next(prev, nxt[cur])      # remove the second
+                        else:
+                            set_next(first, cur)          # remove the first
+                    else:
+                        set_next(get_next(first), cur)
+                first = cur
+                count = 1
+            else:
+                count += 1
+            prev = cur
+            cur = nxt[cur]
+    out = []
+    cur = head["next"]
+    assert cur is not None
+    while cur is not None:
+        out.append(pts[cur])
+        cur = nxt[cur]
+    return out
+
+
+def findContours(image, mode, method, *args, **kwargs):
+    """cv2.findContours(u8, RETR_EXTERNAL, method): raster scan for outer-border starts (pixel 1 with
+    background on its left) that are not nested inside an already traced outline, Suzuki-Abe border
+    following, then the requested chain approximation.  Returns ([int32 [n,1,2] ...], None)."""
+    if mode != RETR_EXTERNAL:
+        raise NotImplementedError("only RETR_EXTERNAL is on the path (classify/thumbnail.py:91)")
+    src = np.asarray(image)
+    H, W = src.shape
+    img = np.zeros((H + 2, W + 2), np.int8)
+    img[1:-1, 1:-1] = src != 0
     contours = []
-    er = ndimage.binary_erosion(img)
-    edge = img & ~er
-    for i in range(1, n + 1):
-        ys, xs = np.nonzero(edge & (lab == i))
-        contours.append(np.stack([xs, ys], axis=1).reshape(-1, 1, 2).astype(np.int32))
-    return contours, None
+    for y in range(1, H + 1):
+        prev = 0
+        lnbd_x = 0
+        row = img[y]
+        for x in range(1, W + 1):
+            p = int(row[x])
+            if p == prev:
+                continue
+            if prev == 0 and p == 1 and not img[y, lnbd_x] > 0:
+                chain = _trace_border(img, x, y)
+                pts = _approx_chain(chain, (x - 1, y - 1), method)
+                contours.append(np.asarray(pts, np.int32).reshape(-1, 1, 2))
+                p = int(row[x])
+            prev = p
+            if prev & -2:
+                lnbd_x = x
+    return tuple(contours), None
 
 
 def contourArea(contour):

@@ -112,3 +112,60 @@ def test_classify_oracle_matches_reference_inputs(name, fs):
         assert np.array_equal(x, want), (name, ti, np.abs(x - want).max())
         score = co.classified_track(z["t%d_pred" % ti], prediction_frames=segs, labels=meta["labels"])
         assert np.array_equal(score, np.array(m["class_best_score"]))
+
+
+@pytest.mark.parametrize("name,dn", [("possum", 0), ("hedgehog", 0), ("possum", 1)])
+def test_thumbnail_oracle_matches_reference(name, dn):
+    """oracle/thumbnail_oracle.py (+ the findContours / TC89_L1 restatement in cv2_shim) against the
+    per-frame thumbnail statistics the reference produced, and for the default config against the
+    thumbnail entries of the reference's own golden possum.txt."""
+    import thumbnail_oracle as th
+
+    out, frames = _run(name, dn)
+    fr = out["frames"]
+    with open(os.path.join(GOLDEN, "%s_dn%d_thumbs.json" % (name, dn))) as fh:
+        gold = json.load(fh)
+    _, t_on, ffc, bgf, hdr = load_clip(name)
+    proc = [i for i in range(frames.shape[0]) if not bgf[i]]
+    assert len(out["tracks"]) == len(gold["tracks"])
+    for t, g in zip(out["tracks"], gold["tracks"]):
+        stats, max_mass, max_md, min_md, max_contour = th.track_thumb_stats(
+            t.bounds, lambda q: fr[q]["mask"], lambda q: frames[proc[q]])
+        assert [[s.region.frame_number, s.contours, float(s.median_diff)] for s in stats] == g["stats"]
+        assert (max_mass, max_md, min_md, max_contour) == (
+            g["max_mass"], g["max_median_diff"], g["min_median_diff"], g["max_contour"])
+        best, score = th.thumbnail_info(t.bounds, lambda q: fr[q]["mask"], lambda q: frames[proc[q]])
+        gb = g["best"]
+        assert best.region.frame_number == gb["region"]["frame_number"]
+        assert (best.contours, float(best.median_diff), score) == (gb["contours"], gb["median_diff"], gb["score"])
+    if (name, dn) == ("possum", 1):
+        with open(os.path.join(GOLDEN, "possum.txt")) as fh:
+            ref_gold = json.load(fh)
+        for t, g in zip(out["tracks"], ref_gold["tracks"]):
+            best, score = th.thumbnail_info(t.bounds, lambda q: fr[q]["mask"], lambda q: frames[proc[q]])
+            gt = g["thumbnail"]
+            r = best.region
+            assert (r.x, r.y, r.width, r.height, int(r.mass), r.frame_number) == tuple(
+                gt["region"][k] for k in ("x", "y", "width", "height", "mass", "frame_number"))
+            assert (best.contours, float(best.median_diff), round(score)) == (
+                gt["contours"], gt["median_diff"], gt["score"])
+
+
+@pytest.mark.parametrize("name,n", [("possum", 30), ("hedgehog", 8)])
+def test_trackless_thumbnail_oracle_matches_reference(name, n):
+    import thumbnail_oracle as th
+    import track_oracle as to
+
+    frames, t_on, ffc, bgf, hdr = load_clip(name)
+    with open(os.path.join(GOLDEN, "%s_trackless_thumbs.json" % name)) as fh:
+        gold = json.load(fh)
+    frames, t_on, ffc, bgf = frames[:n], t_on[:n], ffc[:n], bgf[:n]
+    out = to.track_clip(frames, t_on, ffc, bgf, to.OracleConfig(hdr.model), keep=True)
+    assert len(out["tracks"]) == 0 and sum(len(r) for r in out["region_history"]) == gold["n_region_history"]
+    proc = [i for i in range(n) if not bgf[i]]
+    means = [frames[i].mean() for i in proc]
+    x, y, w, h, fn, centroid, mass = th.trackless_thumb(out["region_history"], means, lambda q: frames[proc[q]],
+                                                        frames[0])
+    g = gold["trackless"]
+    assert (x, y, w, h, fn, mass) == (g["x"], g["y"], g["width"], g["height"], g["frame_number"], g["mass"])
+    assert [float(centroid[0]), float(centroid[1])] == g["centroid"]
