@@ -61,6 +61,7 @@ REGION_REF_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("wid
 TRACK_LIMITS_DTYPE = np.dtype([("filt_min", "<f4"), ("filt_max", "<f4"), ("clip_at_zero", "<i4"), ("reserved", "<i4")])
 CROP_REQ_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"),
                            ("track", "<i4"), ("sample", "<i4"), ("tile", "<i4")])
+THUMB_STAT_DTYPE = np.dtype([("contours", "<i4"), ("status", "<i4"), ("median_diff", "<f8")])
 CONV_TIMING_DTYPE = np.dtype([("key", "<i4"), ("launches", "<i4"), ("total_ms", "<f8"), ("flops", "<f8")])
 assert REGION_REF_DTYPE.itemsize == 24 and TRACK_LIMITS_DTYPE.itemsize == 16 and CROP_REQ_DTYPE.itemsize == 32
 assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FRAME_INFO_DTYPE.itemsize == 80
@@ -70,7 +71,7 @@ EXPORTS = [
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
-    "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack",
+    "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
 ]
 
 _lib = None
@@ -126,6 +127,10 @@ def load():
     lib.cpx_conv_timing_enable.restype = C.c_int
     lib.cpx_conv_timing_report.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.cpx_conv_timing_report.restype = C.c_int
+    lib.cpx_thumb_stats.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    lib.cpx_thumb_stats.restype = C.c_int
+    lib.cpx_trackless_thumb.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.cpx_trackless_thumb.restype = C.c_int
     lib.cpx_cptv_unpack.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
     lib.cpx_cptv_unpack.restype = C.c_int
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]

@@ -15,6 +15,7 @@ from ..ml_tools.tools import CustomJSONEncoder, load_clip_metadata
 from ..track.clip import Clip
 from ..track.cliptrackextractor import ClipTrackExtractor
 from ..track.trackextractor import extract_file
+from .thumbnail import best_trackless_thumb, get_thumbnail_info
 from .trackprediction import Predictions
 
 
@@ -133,6 +134,19 @@ class ClipClassifier:
             if self.keep_original_predictions:
                 info.extend(meta_track.get("predictions") or [])
             meta_track["predictions"] = info
+            if calculate_thumbnails:
+                best_thumb, best_score = get_thumbnail_info(clip, track)
+                if best_thumb is None:
+                    meta_track["thumbnail"] = None
+                else:
+                    meta_track["thumbnail"] = {
+                        "region": best_thumb.region,
+                        "contours": best_thumb.contours,
+                        "median_diff": best_thumb.median_diff,
+                        "score": round(best_score),
+                    }
+        if calculate_thumbnails and len(clip.tracks) == 0:
+            meta_data["thumbnail_region"] = best_trackless_thumb(clip)  # if no tracks choose a clip thumb
         by_id = {m["id"]: m for m in meta_data.get("models", [])}
         for model in models:
             d = by_id.get(model.id) or model.as_dict()

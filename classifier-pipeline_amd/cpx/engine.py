@@ -7,7 +7,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (COMPONENT_DTYPE, CROP_REQ_DTYPE, FRAME_INFO_DTYPE, FRAME_META_DTYPE, REGION_REF_DTYPE,
-                   TRACK_LIMITS_DTYPE, CpxError)
+                   THUMB_STAT_DTYPE, TRACK_LIMITS_DTYPE, CpxError)
 from .tracking import REGION_DTYPE, TRACK_RECORD_DTYPE, make_track_params, track_regions
 
 
@@ -175,6 +175,44 @@ class TrackEngine:
             raise CpxError(rc, self._err())
         self.synchronize()  # the staging tensors go out of scope here
         return out
+
+    def thumb_stats(self, frames_dev, track_result, refs):
+        """cpx_thumb_stats over REGION_REF_DTYPE refs -> THUMB_STAT_DTYPE array (host)."""
+        t = self.torch
+        if track_result.labels_dev is None:
+            raise ValueError("thumb_stats needs the labels output of track_batch (want_labels=True)")
+        n = len(refs)
+        if n == 0:
+            return np.zeros(0, THUMB_STAT_DTYPE)
+        refs_dev = self._to_dev(np.ascontiguousarray(refs, dtype=REGION_REF_DTYPE))
+        out = t.zeros(n * 4, dtype=t.int32, device=self.device)
+        t.cuda.current_stream(self.device).synchronize()
+        rc = self.lib.cpx_thumb_stats(self.h, C.c_void_p(frames_dev.data_ptr()),
+                                      C.c_void_p(track_result.labels_dev.data_ptr()),
+                                      C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(refs_dev.data_ptr()), n,
+                                      C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        self.synchronize()
+        got = out.cpu().numpy().view(THUMB_STAT_DTYPE)
+        bad = np.nonzero(got["status"] != 0)[0]
+        if bad.size:
+            raise CpxError(int(got["status"][bad[0]]), "region %d: contour longer than the kernel's chain capacity"
+                           % int(bad[0]))
+        return got
+
+    def trackless_thumb(self, frames_dev, frame, background):
+        """cpx_trackless_thumb -> (x, y) of the chosen 64x64 window."""
+        t = self.torch
+        out = t.zeros(2, dtype=t.int32, device=self.device)
+        t.cuda.current_stream(self.device).synchronize()
+        rc = self.lib.cpx_trackless_thumb(self.h, C.c_void_p(frames_dev.data_ptr()), int(frame), int(background),
+                                          C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        self.synchronize()
+        x, y = out.cpu().numpy()
+        return int(x), int(y)
 
     @staticmethod
     def make_meta(n, time_on=None, last_ffc=None, background=None):

@@ -1,7 +1,6 @@
 """TrackExtractor / extract_file -- file-level drivers of the track stage
-(reference src/track/trackextractor.py:25-251).  Thumbnail scoring
-(classify/thumbnail.py) is a later row: `thumbnail` entries
-are None."""
+(reference src/track/trackextractor.py:25-251), including the thumbnail entries
+of the metadata (classify/thumbnail.py via the HIP thumbnail kernels)."""
 
 import json
 import logging
@@ -64,9 +63,22 @@ def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False
 
 
 def get_metadata(existing_metadata, filename, meta_filename, clip, track_extractor, to_stdout=False, save=True):
+    from ..classify.thumbnail import best_trackless_thumb, get_thumbnail_info
+
     metadata = clip.get_metadata()
-    for track_meta in metadata["tracks"]:
-        track_meta["thumbnail"] = None
+    for i, track in enumerate(clip.tracks):
+        best_thumb, best_score = get_thumbnail_info(clip, track)
+        if best_thumb is None:
+            metadata["tracks"][i]["thumbnail"] = None
+            continue
+        metadata["tracks"][i]["thumbnail"] = {
+            "region": best_thumb.region,
+            "contours": best_thumb.contours,
+            "median_diff": best_thumb.median_diff,
+            "score": round(best_score),
+        }
+    if len(clip.tracks) == 0:
+        metadata["thumbnail_region"] = best_trackless_thumb(clip)  # if no tracks choose a clip thumb
     metadata["source"] = str(filename)
     metadata["tracking_time"] = round(track_extractor.tracking_time, 1)
     metadata["algorithm"] = {"tracker_version": track_extractor.tracker_version,

@@ -670,6 +670,49 @@ int cpx_cptv_unpack(cpx_handle* h, const uint8_t* payload_dev, const int64_t* fr
   return CPX_OK;
 }
 
+int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
+                    const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev, int n_refs,
+                    cpx_thumb_stat* out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !labels_dev || !info_dev || !refs_dev || !out_dev || n_refs < 0)
+    return fail(h, CPX_ERR_INVALID, "cpx_thumb_stats: bad argument");
+  if (n_refs == 0) return CPX_OK;
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::ThumbArgs a{};
+  a.W = h->cfg.width;
+  a.H = h->cfg.height;
+  a.chain_cap = 8192;
+  a.frames = frames_dev;
+  a.labels = labels_dev;
+  a.info = info_dev;
+  a.refs = refs_dev;
+  a.out = out_dev;
+  const int rc = cpx::launch_thumb(a, n_refs, h->stream);
+  if (rc == -2) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_thumb_stats: resolution too large for the contour kernel");
+  if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_thumb_stats: kernel configuration failed");
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, int background, int32_t* out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !out_dev || frame < 0 || background < 0)
+    return fail(h, CPX_ERR_INVALID, "cpx_trackless_thumb: bad argument");
+  CPX_HIP(h, hipSetDevice(h->device));
+  cpx::TracklessArgs a{};
+  a.W = h->cfg.width;
+  a.H = h->cfg.height;
+  a.frame = frame;
+  a.background = background;
+  a.frames = frames_dev;
+  a.out = out_dev;
+  const int rc = cpx::launch_trackless(a, h->stream);
+  if (rc == -2) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_trackless_thumb: resolution outside the kernel's envelope");
+  if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_trackless_thumb: kernel configuration failed");
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches) {
   if (!h || !total_ms || !launches) return CPX_ERR_INVALID;
   if (!h->timing_valid) return fail(h, CPX_ERR_INVALID, "no batch has been run");

@@ -193,6 +193,23 @@ struct CptvArgs {
 };
 int launch_cptv_unpack(const CptvArgs& a, int B, hipStream_t s);
 
+struct ThumbArgs {
+  int W, H, chain_cap;
+  const uint16_t* frames;
+  const int32_t* labels;
+  const cpx_frame_info* info;
+  const cpx_region_ref* refs;
+  cpx_thumb_stat* out;
+};
+int launch_thumb(const ThumbArgs& a, int n_refs, hipStream_t s);
+
+struct TracklessArgs {
+  int W, H, frame, background;
+  const uint16_t* frames;
+  int32_t* out;
+};
+int launch_trackless(const TracklessArgs& a, hipStream_t s);
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

@@ -290,6 +290,30 @@ int cpx_aggregate_predictions(cpx_handle* h, const float* probs_dev, const int32
                               int n_samples, const struct cpx_crop_req* reqs_dev, int n_tracks, int n_labels,
                               int false_positive_index, int square_width, float* scores_dev, int32_t* best_dev);
 
+/* ---- thumbnail stage (classify/thumbnail.py:13-188) -------------------------------
+ * cpx_thumb_stats replaces the per-region body of get_track_thumb_stats (thumbnail.py:76-134): for each
+ * region the external contours of np.uint8(region.subimage(frame.mask)) with CHAIN_APPROX_TC89_L1
+ * (cv2.findContours) -> point count of the longest one, and np.median(thermal under the mask) -
+ * np.median(frame.thermal).  The caller passes only non-blank regions with mass > 0 (thumbnail.py:78-79);
+ * scoring / ranking (thumbnail.py:138-197) is a few flops per region and stays with the caller.
+ * labels_dev is cpx_track_batch's labels output; refs_dev[i].in_segment is ignored.
+ * out_dev[i].contours == 0: no contour in the region (the reference skips the frame). */
+typedef struct cpx_thumb_stat {
+  int32_t contours;    /* len(contours[0]) after sorting by length, 0 if none */
+  int32_t status;      /* 0 or CPX_ERR_OVERFLOW (a border longer than the kernel's chain capacity) */
+  double median_diff;  /* masked_median - t_median (thumbnail.py:117-120) */
+} cpx_thumb_stat;
+
+int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
+                    const cpx_frame_info* info_dev, const struct cpx_region_ref* refs_dev, int n_refs,
+                    cpx_thumb_stat* out_dev);
+
+/* best_trackless_thumb's window search (thumbnail.py:26-64) on frame `frame` with the clip background
+ * frames_dev[background] (the clip's first frame, clip.py:152-158): every 64x64 window position of
+ * range(H-64) x range(W-64), mean of the frame and of the uint16-wrapping difference frame - background,
+ * walked in raster order with the reference's update rule.  out_dev int32[2] = x, y of the chosen window. */
+int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, int background, int32_t* out_dev);
+
 /* ---- CNN forward building blocks (WR-ResNet, ml_tools/resnet/wr_resnet.py:5-98) -----------
  * Replaces tf.keras Conv2D(groups) / BatchNormalization / Activation / Add / GlobalAveragePooling2D /
  * Dense as used by KerasModel.predict (ml_tools/kerasmodel.py:856-859).  Activations NHWC float32.

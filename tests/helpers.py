@@ -47,7 +47,9 @@ def encode_cptv(path, frames, widths, time_on=None, last_ffc=None, model=b"lepto
     out = bytearray(b"CPTV\x02H")
     hdr = [field(b"T", struct.pack("<Q", 1600000000000000)), field(b"X", struct.pack("<I", W)),
            field(b"Y", struct.pack("<I", H)), field(b"C", b"\x01"), field(b"D", b"synthetic"),
-           field(b"E", model), field(b"Z", b"\x09")]
+           field(b"Z", b"\x09")]
+    if model:
+        hdr.append(field(b"E", model))
     if background_first:
         hdr.append(field(b"g", b"\x01"))
     out += bytes([len(hdr)]) + b"".join(hdr)
