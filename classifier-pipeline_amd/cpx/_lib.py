@@ -72,6 +72,7 @@ EXPORTS = [
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
     "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
+    "cpx_track_frame", "cpx_associate_frame",
 ]
 
 _lib = None
@@ -127,6 +128,10 @@ def load():
     lib.cpx_conv_timing_enable.restype = C.c_int
     lib.cpx_conv_timing_report.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.cpx_conv_timing_report.restype = C.c_int
+    lib.cpx_track_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.cpx_track_frame.restype = C.c_int
+    lib.cpx_associate_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cpx_associate_frame.restype = C.c_int
     lib.cpx_thumb_stats.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
     lib.cpx_thumb_stats.restype = C.c_int
     lib.cpx_trackless_thumb.argtypes = [vp, vp, C.c_int, C.c_int, vp]

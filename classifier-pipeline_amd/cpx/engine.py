@@ -109,6 +109,97 @@ class AssocBatchResult:
         return regions[f, : int(rc[f])]
 
 
+class TrackStream:
+    """One clip tracked incrementally.  Owns the clip's device buffers (frames, per-frame outputs, region pool,
+    track records); append() uploads a frame and runs the track (+ association) kernels for it."""
+
+    def __init__(self, engine, capacity, params, want_labels):
+        t = engine.torch
+        self.engine, self.cap_frames, self.params = engine, int(capacity), params
+        if self.cap_frames > engine.cfg.max_frames + 1:
+            raise ValueError("stream capacity %d exceeds the engine's max_frames %d"
+                             % (self.cap_frames, engine.cfg.max_frames))
+        dev, H, W, cap = engine.device, engine.height, engine.width, engine.cap
+        n = self.cap_frames
+        self.frames_dev = t.zeros((n, H, W), dtype=t.int16, device=dev)
+        self.comps = t.zeros(n * cap * 8, dtype=t.int32, device=dev)
+        self.info = t.zeros(n * 20, dtype=t.int32, device=dev)
+        self.labels = t.zeros((n, H, W), dtype=t.int32, device=dev) if want_labels else None
+        self.filtered = t.zeros((n, H, W), dtype=t.float32, device=dev)
+        self.background = t.zeros((1, H, W), dtype=t.float32, device=dev)
+        ma, mt = params.max_active_tracks, params.max_tracks
+        self.pool = t.zeros(n * ma * 14, dtype=t.int32, device=dev)
+        self.tracks = t.zeros(mt * 8, dtype=t.int32, device=dev)
+        self.ntracks = t.zeros(1, dtype=t.int32, device=dev)
+        self.status = t.zeros(1, dtype=t.int32, device=dev)
+        self.regions = t.zeros(n * cap * 14, dtype=t.int32, device=dev)
+        self.rcounts = t.zeros(n, dtype=t.int32, device=dev)
+        self.meta = np.zeros(n, dtype=FRAME_META_DTYPE)
+        self.n = 0              # frames in the buffer
+        self.n_tracked = 0      # frames the track kernels have consumed
+        self.result = TrackBatchResult(engine, n, cap, self.comps, self.info, self.labels, self.filtered,
+                                       self.background)
+
+    def _p(self, tensor):
+        return C.c_void_p(tensor.data_ptr() if tensor is not None else None)
+
+    def append(self, pix, time_on=None, last_ffc=None, init_only=False, associate=True):
+        """Upload one frame and process it.  init_only: the frame only initialises the background
+        (a CPTV background frame).  Returns the frame's index in the stream's arrays."""
+        eng, t = self.engine, self.engine.torch
+        if self.n >= self.cap_frames:
+            raise CpxError(-1, "stream is full (%d frames): open the extractor with a larger max_frames"
+                           % self.cap_frames)
+        f = self.n
+        a = np.ascontiguousarray(pix, dtype=np.uint16)
+        self.frames_dev[f].copy_(t.from_numpy(a.view(np.int16)))
+        m = self.meta[f]
+        m["background_frame"] = 1 if init_only else 0
+        if time_on is not None and last_ffc is not None:
+            m["time_on_ms"], m["last_ffc_ms"], m["has_times"] = time_on, last_ffc, 1
+        self.n = f + 1
+        if init_only and f == 0:
+            return f  # consumed together with the first real frame
+        t.cuda.current_stream(eng.device).synchronize()
+        mp = C.c_void_p(self.meta.ctypes.data)
+        rc = eng.lib.cpx_track_frame(eng.h, self._p(self.frames_dev), mp, self.n_tracked, self.n, self._p(self.comps),
+                                     self._p(self.info), self._p(self.labels), self._p(self.filtered),
+                                     self._p(self.background))
+        if rc != 0:
+            raise CpxError(rc, eng._err())
+        n_prev = self.n_tracked
+        self.n_tracked = self.n
+        if associate and not init_only:
+            rc = eng.lib.cpx_associate_frame(eng.h, C.byref(self.params), mp, n_prev, self.n, self._p(self.comps),
+                                             self._p(self.info), self._p(self.pool), self._p(self.tracks),
+                                             self._p(self.ntracks), self._p(self.status), self._p(self.regions),
+                                             self._p(self.rcounts))
+            if rc != 0:
+                raise CpxError(rc, eng._err())
+        eng.synchronize()
+        return f
+
+    def frame_info(self, f):
+        return self.info[f * 20:(f + 1) * 20].cpu().numpy().view(FRAME_INFO_DTYPE)[0]
+
+    def frame_regions(self, f):
+        n = int(self.rcounts[f].item())
+        cap = self.engine.cap
+        return self.regions[f * cap * 14:(f * cap + n) * 14].cpu().numpy().view(REGION_DTYPE)
+
+    def track_records(self):
+        n = int(self.ntracks.item())
+        st = int(self.status.item())
+        if st != 0:
+            raise CpxError(st, "track capacity exceeded")
+        return self.tracks[: n * 8].cpu().numpy().view(TRACK_RECORD_DTYPE)
+
+    def pool_row(self, q):
+        """Regions written for processed frame number q, one per active-track slot."""
+        ma = self.params.max_active_tracks
+        return self.pool[q * ma * 14:(q + 1) * ma * 14].cpu().numpy().view(REGION_DTYPE)
+
+
 class TrackEngine:
     def __init__(self, width=160, height=120, model="lepton3", device=0, edge_pixels=1, window=45,
                  max_components=64, max_frames=4096, background_thresh=None, weight_add=None, denoise=False):
@@ -175,6 +266,12 @@ class TrackEngine:
             raise CpxError(rc, self._err())
         self.synchronize()  # the staging tensors go out of scope here
         return out
+
+    # ---- incremental tracking (one clip, frame by frame) ---------------------------------------------------
+    def open_stream(self, capacity, params=None, want_labels=True):
+        """Device buffers of a frame-by-frame tracked clip (cpx_track_frame / cpx_associate_frame)."""
+        return TrackStream(self, capacity, params or make_track_params(self.width, self.height, self.cfg.edge_pixels),
+                           want_labels)
 
     def thumb_stats(self, frames_dev, track_result, refs):
         """cpx_thumb_stats over REGION_REF_DTYPE refs -> THUMB_STAT_DTYPE array (host)."""

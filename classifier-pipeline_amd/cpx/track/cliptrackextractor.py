@@ -81,6 +81,22 @@ class WeightedBackgroundView:
         return self.average
 
 
+class StreamBackgroundView:
+    """extractor.background_alg during incremental tracking: the device's current background, fetched on demand."""
+
+    def __init__(self, stream, frame_info, weight_add):
+        self._stream = stream
+        self.average = float(frame_info["background_average"])
+        self.weight_add = weight_add
+
+    @property
+    def background(self):
+        return self._stream.background[0].cpu().numpy().astype(np.float64)
+
+    def get_average(self):
+        return self.average
+
+
 class ClipTracker:
     """Configuration handling + end-of-clip filtering shared by the extractors (cliptracker.py:14-491)."""
 
@@ -191,6 +207,7 @@ class ClipTrackExtractor(ClipTracker):
         self.calculate_filtered = calculate_filtered
         self.weighting_percent = 1
         self.device = device
+        self._stream = None
         self._frames = None
         self._frames_dev = None
         self._engine = None
@@ -244,10 +261,104 @@ class ClipTrackExtractor(ClipTracker):
         return True
 
     def start_tracking(self, clip, frames, track_frames=True, background_alg=None, **args):
-        raise NotImplementedError("incremental tracking (Pi live loop) is not part of this build yet: use parse_clip")
+        """Feed `frames` one by one (cliptrackextractor.py:181-193); with track_frames=False they only build the
+        background / frame buffer.  The background model lives on the device: an external background_alg
+        (the Pi motion detector's) cannot be plugged in."""
+        if background_alg is not None:
+            raise NotImplementedError("an external background_alg is not supported: the device keeps the background")
+        do_tracking = self.do_tracking
+        self.do_tracking = self.do_tracking and track_frames
+        new_tracks = []
+        try:
+            for frame in frames:
+                new_tracks.extend(self.process_frame(clip, frame))
+        finally:
+            self.do_tracking = do_tracking
+        return new_tracks
 
     def process_frame(self, clip, frame):
-        raise NotImplementedError("incremental tracking (Pi live loop) is not part of this build yet: use parse_clip")
+        """One frame through the device: the reference's process_frame (cliptrackextractor.py:195-247) followed by
+        the background update its caller does with the 45-frame mean (cliptrackextractor.py:169-176).  The first
+        call opens the stream: the clip background (clip.update_background, else this frame) seeds the model.
+        Returns the tracks created by this frame."""
+        st = self._stream
+        if st is None or st["clip"] is not clip:
+            st = self._open_stream(clip, frame)
+        stream = st["stream"]
+        f = stream.append(frame.pix, frame.time_on, frame.last_ffc_time, associate=self.do_tracking)
+        fi = stream.frame_info(f)
+        thermal = np.array(frame.pix, dtype=np.uint16, copy=True)
+        P = clip.res_x * clip.res_y
+        stats = (np.uint16(fi["thermal_min"]), np.uint16(fi["thermal_max"]), np.float64(fi["thermal_median"]),
+                 fi["thermal_sum"] / P, float(fi["filtered_abs_sum"]))
+        clip.ffc_affected = bool(fi["ffc_affected"])
+        if clip.ffc_affected:
+            self.print_if_verbose("{} ffc_affected".format(clip.current_frame))
+        filtered = stream.filtered[f].cpu().numpy() if (self.keep_frames or self.calculate_filtered) else None
+        mask = stream.labels[f].cpu().numpy() if (self.keep_frames and stream.labels is not None) else None
+        clip.add_frame(thermal, filtered, mask, clip.ffc_affected, stats=stats)
+        st["device_state"]._index[clip.current_frame] = f
+        clip.device_state = st["device_state"]
+        self.background_alg = StreamBackgroundView(stream, fi, st["weight_add"])
+        if not self.do_tracking:
+            return []
+        new_tracks = []
+        if not clip.from_metadata:
+            if clip.ffc_affected:
+                clip.active_tracks = set()
+                clip.region_history.append([])
+                return []
+            clip.region_history.append([Region.from_record(r) for r in stream.frame_regions(f)])
+            q = int(fi["frame_number"])
+            records = stream.track_records()
+            row = stream.pool_row(q)
+            by_id = st["tracks"]
+            active = set()
+            for rec in records:
+                tid = int(rec["id"])
+                last = int(rec["start_frame"]) + int(rec["n_frames"]) - 1
+                if last != q:
+                    continue  # not touched by this frame
+                track = by_id.get(tid)
+                if track is None:
+                    track = Track(clip.get_id(), id=tid, fps=clip.frames_per_second, tracking_config=self.config,
+                                  crop_rectangle=clip.crop_rectangle, tracker_version=self.tracker_version)
+                    track.start_frame = int(rec["start_frame"])
+                    track.start_s = track.start_frame / float(clip.frames_per_second)
+                    by_id[tid] = track
+                    clip.tracks.append(track)
+                    new_tracks.append(track)
+                track.append_from_device(rec, row[int(rec["slot"])])
+                if self._still_tracking(track):
+                    active.add(track)
+            clip.active_tracks = active
+        return new_tracks
+
+    def _open_stream(self, clip, frame):
+        if clip.res_x is None or clip.res_y is None:
+            clip.set_res(frame.pix.shape[1], frame.pix.shape[0])
+        if clip.background_thresh is None:
+            clip.set_model(None)
+        if clip.frame_buffer is None:
+            clip.set_frame_buffer(self.high_quality_optical_flow, self.cache_to_disk, self.use_opt_flow,
+                                  self.keep_frames, self.max_frames)
+        if clip.background is None:
+            clip.update_background(np.array(frame.pix, dtype=np.uint16, copy=True))
+            clip._background_calculated()
+        cam35 = clip.camera_model == "lepton3.5"
+        weight_add = (1 if cam35 else 0.1) / self.weighting_percent
+        capacity = (self.max_frames or 2047) + 1
+        eng = get_engine(clip.res_x, clip.res_y, clip.background_thresh, weight_add, self.config.edge_pixels,
+                         self.device, max_frames=capacity, denoise=bool(self.config.denoise))
+        params = make_track_params(
+            clip.res_x, clip.res_y, self.config.edge_pixels, self.config.frame_padding, self.min_dimension,
+            self.config.cropped_regions_strategy, self.config.filter_regions_pre_match, self.config.aoi_min_mass,
+            self.config.aoi_pixel_variance, self.config.params, clip.frames_per_second)
+        stream = eng.open_stream(capacity, params, want_labels=True)
+        stream.append(clip.background, init_only=True)  # slot 0 seeds the background model, it is not tracked
+        self._stream = dict(clip=clip, stream=stream, tracks={}, weight_add=weight_add,
+                            device_state=DeviceClipState(eng, stream.frames_dev, stream.result, []))
+        return self._stream
 
     # ---- device path --------------------------------------------------------------------------------
     def _track_clip(self, clip, process_background=False):

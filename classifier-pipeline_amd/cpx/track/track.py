@@ -104,6 +104,27 @@ class Track:
         t.prev_frame_num = t.bounds_history[-1].frame_number if t.bounds_history else None
         return t
 
+    def append_from_device(self, record, region_record):
+        """Incremental tracking: the region the device added to this track for the newest frame."""
+        region = Region.from_record(region_record)
+        if self.bounds_history:
+            prv = self.bounds_history[-1]
+            if region.blank and type(region.centroid) is type(prv.centroid) and \
+                    np.array_equal(region.centroid, prv.centroid):
+                region.centroid = prv.centroid
+            self.vel_x.append(region.centroid[0] - prv.centroid[0])
+            self.vel_y.append(region.centroid[1] - prv.centroid[1])
+        else:
+            self.vel_x.append(0)
+            self.vel_y.append(0)
+        self.bounds_history.append(region)
+        rt = self.tracker
+        rt.frames = int(record["rt_frames"])
+        rt._blank_frames = int(record["blank_frames"])
+        rt._frames_since_target_seen = int(record["since_seen"])
+        rt._last_bound = region
+        self.prev_frame_num = region.frame_number
+
     def _velocities_from_history(self):
         """Track.update_velocity (track.py:657-669) for the whole history."""
         self.vel_x, self.vel_y = [], []

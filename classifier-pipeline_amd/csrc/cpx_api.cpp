@@ -37,6 +37,10 @@ struct cpx_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int last_launches = 0;
   bool timing_valid = false;
+  // incremental (one clip, frame by frame) tracking: frames consumed so far, -1 = no stream open
+  int stream_frames = -1;
+  int stream_assoc_frames = -1;
+  bool stream_filt_state = false;
 };
 
 static_assert(sizeof(cpx_component) == 32, "cpx_component layout is part of the ABI");
@@ -253,22 +257,29 @@ size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames) {
   return ws_layout(h->cfg, B, true).total;
 }
 
-int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
-                    const cpx_frame_meta* meta, int B, cpx_component* comps_dev,
-                    cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
-                    float* background_dev) {
-  if (!h) return CPX_ERR_INVALID;
-  if (!frames_dev || !clip_offsets || !meta || B <= 0 || !comps_dev || !info_dev)
-    return fail(h, CPX_ERR_INVALID, "cpx_track_batch: null argument");
+// Track stage for B clips.  n_prev < 0: whole clips (cpx_track_batch).  n_prev >= 0 (B == 1): the clip's first n_prev
+// frames were consumed by earlier calls on this handle and its state is still in the workspace; only the frames
+// [n_prev, clip_offsets[1]) are processed (cpx_track_frame).
+static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
+                     const cpx_frame_meta* meta, int B, int n_prev, cpx_component* comps_dev,
+                     cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                     float* background_dev) {
   CPX_HIP(h, hipSetDevice(h->device));
   const cpx_config& c = h->cfg;
   Schedule sc;
   int rc = build_schedule(h, clip_offsets, meta, B, &sc);
   if (rc != CPX_OK) return rc;
   const int total = sc.total, max_proc = sc.max_proc;
+  const bool resume = n_prev > 0;
+  int t_begin = 0;
+  if (resume)
+    for (int f = 0; f < n_prev; ++f) t_begin += meta[f].background_frame ? 0 : 1;
   // ---- device workspace ----
   const bool need_filt = (filtered_dev == nullptr);
   const WsLayout l = ws_layout(c, B, need_filt);
+  if (resume && (l.total > h->ws_bytes || need_filt != h->stream_filt_state))
+    return fail(h, CPX_ERR_INVALID, "cpx_track_frame: the stream's workspace is gone (optional outputs changed?)");
+  h->stream_filt_state = need_filt;
   if (l.total > h->ws_bytes) {
     if (h->ws) hipFree(h->ws);
     h->ws = nullptr;
@@ -310,10 +321,11 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
   a.filtered_out = filtered_dev;
 
   // frames that are never processed (background frames) get frame_number = -1
-  CPX_HIP(h, hipMemsetAsync(info_dev, 0xFF, (size_t)total * sizeof(cpx_frame_info), h->stream));
-  cpx::launch_init(a, B, h->stream);
+  const int f_new = resume ? n_prev : 0;
+  CPX_HIP(h, hipMemsetAsync(info_dev + f_new, 0xFF, (size_t)(total - f_new) * sizeof(cpx_frame_info), h->stream));
+  if (!resume) cpx::launch_init(a, B, h->stream);
   CPX_HIP(h, hipEventRecord(h->ev0, h->stream));
-  for (int t = 0; t < max_proc; ++t) {
+  for (int t = t_begin; t < max_proc; ++t) {
     if (!c.denoise) {
       cpx::launch_frame(a, B, t, 0, h->stream);
     } else {  // front (normalise) -> non-local means -> back (blur / threshold / label / statistics)
@@ -323,25 +335,54 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
     }
   }
   CPX_HIP(h, hipEventRecord(h->ev1, h->stream));
-  h->last_launches = max_proc;
+  h->last_launches = max_proc - t_begin;
   h->timing_valid = true;
   if (background_dev) cpx::launch_export_background(a, B, background_dev, h->stream);
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
 }
 
-int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int32_t* clip_offsets,
-                        const cpx_frame_meta* meta, int B, const cpx_component* comps_dev,
-                        const cpx_frame_info* info_dev, cpx_region* pool_dev,
-                        cpx_track_record* tracks_dev, int32_t* n_tracks_dev, int32_t* status_dev,
-                        cpx_region* regions_dev, int32_t* region_counts_dev) {
+int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
+                    const cpx_frame_meta* meta, int B, cpx_component* comps_dev,
+                    cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                    float* background_dev) {
   if (!h) return CPX_ERR_INVALID;
-  if (!params || !clip_offsets || !meta || B <= 0 || !comps_dev || !info_dev || !pool_dev || !tracks_dev ||
-      !n_tracks_dev || !status_dev)
-    return fail(h, CPX_ERR_INVALID, "cpx_associate_batch: null argument");
+  if (!frames_dev || !clip_offsets || !meta || B <= 0 || !comps_dev || !info_dev)
+    return fail(h, CPX_ERR_INVALID, "cpx_track_batch: null argument");
+  h->stream_frames = -1;  // the workspace is re-initialised: an open stream ends here
+  return track_run(h, frames_dev, clip_offsets, meta, B, -1, comps_dev, info_dev, labels_dev, filtered_dev,
+                   background_dev);
+}
+
+int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_meta* meta, int n_prev, int n_frames,
+                    cpx_component* comps_dev, cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                    float* background_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !meta || !comps_dev || !info_dev || n_prev < 0 || n_frames <= n_prev)
+    return fail(h, CPX_ERR_INVALID, "cpx_track_frame: bad argument");
+  if (n_prev > 0 && h->stream_frames != n_prev)
+    return fail(h, CPX_ERR_INVALID, "cpx_track_frame: n_prev does not match the frames this handle has consumed");
+  const int32_t offs[2] = {0, n_frames};
+  h->stream_frames = -1;
+  if (n_prev == 0) h->stream_assoc_frames = -1;  // a new clip: its association starts fresh
+  const int rc = track_run(h, frames_dev, offs, meta, 1, n_prev, comps_dev, info_dev, labels_dev, filtered_dev,
+                           background_dev);
+  if (rc == CPX_OK) h->stream_frames = n_frames;
+  return rc;
+}
+
+static int assoc_run(cpx_handle* h, const cpx_track_params* params, const int32_t* clip_offsets,
+                     const cpx_frame_meta* meta, int B, int n_prev, bool fresh, const cpx_component* comps_dev,
+                     const cpx_frame_info* info_dev, cpx_region* pool_dev,
+                     cpx_track_record* tracks_dev, int32_t* n_tracks_dev, int32_t* status_dev,
+                     cpx_region* regions_dev, int32_t* region_counts_dev) {
   if (params->max_active_tracks < 1 || params->max_tracks < 1)
-    return fail(h, CPX_ERR_INVALID, "cpx_associate_batch: capacities must be positive");
+    return fail(h, CPX_ERR_INVALID, "association: capacities must be positive");
   CPX_HIP(h, hipSetDevice(h->device));
+  const bool resume = n_prev > 0 && !fresh;
+  int t_begin = 0;
+  if (n_prev > 0)
+    for (int f = 0; f < n_prev; ++f) t_begin += meta[f].background_frame ? 0 : 1;
   Schedule sc;
   int rc = build_schedule(h, clip_offsets, meta, B, &sc);
   if (rc != CPX_OK) return rc;
@@ -358,6 +399,10 @@ int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int
   off = align_up(off + (size_t)B * cap * ma * cpx::assoc_score_bytes(), 256);
   const size_t o_used = off;
   off = align_up(off + (size_t)B * cap, 256);
+  const size_t o_resume = off;
+  off = align_up(off + (size_t)B * sizeof(cpx::AssocResume), 256);
+  if (resume && off > h->ws_assoc_bytes)
+    return fail(h, CPX_ERR_INVALID, "cpx_associate_frame: the stream's association state is gone");
   if (off > h->ws_assoc_bytes) {
     if (h->ws_assoc) hipFree(h->ws_assoc);
     h->ws_assoc = nullptr;
@@ -387,9 +432,46 @@ int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int
   a.regs = (cpx_region*)(base + o_regs);
   a.scores = (cpx::ScoreRec*)(base + o_scores);
   a.used = (unsigned char*)(base + o_used);
+  a.resume = (cpx::AssocResume*)(base + o_resume);
+  a.t_begin = t_begin;
+  a.fresh = resume ? 0 : 1;
   cpx::launch_assoc(a, h->stream);
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
+}
+
+int cpx_associate_batch(cpx_handle* h, const cpx_track_params* params, const int32_t* clip_offsets,
+                        const cpx_frame_meta* meta, int B, const cpx_component* comps_dev,
+                        const cpx_frame_info* info_dev, cpx_region* pool_dev,
+                        cpx_track_record* tracks_dev, int32_t* n_tracks_dev, int32_t* status_dev,
+                        cpx_region* regions_dev, int32_t* region_counts_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!params || !clip_offsets || !meta || B <= 0 || !comps_dev || !info_dev || !pool_dev || !tracks_dev ||
+      !n_tracks_dev || !status_dev)
+    return fail(h, CPX_ERR_INVALID, "cpx_associate_batch: null argument");
+  h->stream_assoc_frames = -1;
+  return assoc_run(h, params, clip_offsets, meta, B, -1, true, comps_dev, info_dev, pool_dev, tracks_dev, n_tracks_dev,
+                   status_dev, regions_dev, region_counts_dev);
+}
+
+int cpx_associate_frame(cpx_handle* h, const cpx_track_params* params, const cpx_frame_meta* meta, int n_prev,
+                        int n_frames, const cpx_component* comps_dev, const cpx_frame_info* info_dev,
+                        cpx_region* pool_dev, cpx_track_record* tracks_dev, int32_t* n_tracks_dev,
+                        int32_t* status_dev, cpx_region* regions_dev, int32_t* region_counts_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!params || !meta || !comps_dev || !info_dev || !pool_dev || !tracks_dev || !n_tracks_dev || !status_dev ||
+      n_prev < 0 || n_frames <= n_prev)
+    return fail(h, CPX_ERR_INVALID, "cpx_associate_frame: bad argument");
+  // frames in [stream_assoc_frames, n_prev) were never handed to the association: they stay un-tracked
+  const bool fresh = h->stream_assoc_frames < 0;
+  if (!fresh && h->stream_assoc_frames > n_prev)
+    return fail(h, CPX_ERR_INVALID, "cpx_associate_frame: n_prev is behind the frames this handle has consumed");
+  const int32_t offs[2] = {0, n_frames};
+  h->stream_assoc_frames = -1;
+  const int rc = assoc_run(h, params, offs, meta, 1, n_prev, fresh, comps_dev, info_dev, pool_dev, tracks_dev, n_tracks_dev,
+                           status_dev, regions_dev, region_counts_dev);
+  if (rc == CPX_OK) h->stream_assoc_frames = n_frames;
+  return rc;
 }
 
 static cpx::ClassifyArgs classify_args(const cpx_handle* h) {

@@ -31,7 +31,14 @@ __global__ __launch_bounds__(64) void cpx_assoc_kernel(AssocArgs a) {
   c.scores = a.scores + (size_t)b * a.cap * c.max_active;
   c.used = a.used + (size_t)b * a.cap;
   c.status = 0;
-  for (int t = 0; t < nproc; ++t) {
+  if (!a.fresh) {  // incremental call: the clip's association state comes from the previous call
+    const AssocResume r = a.resume[b];
+    c.n_active = r.n_active;
+    c.n_tracks = r.n_tracks;
+    c.next_id = r.next_id;
+    c.status = r.status;
+  }
+  for (int t = a.t_begin; t < nproc; ++t) {
     const int fidx = a.proc_idx[pbase + t];
     const cpx_frame_info& fi = a.info[fidx];
     int nreg = 0;
@@ -49,6 +56,12 @@ __global__ __launch_bounds__(64) void cpx_assoc_kernel(AssocArgs a) {
   }
   a.n_tracks[b] = c.n_tracks;
   a.status[b] = c.status;
+  AssocResume r;
+  r.n_active = c.n_active;
+  r.n_tracks = c.n_tracks;
+  r.next_id = c.next_id;
+  r.status = c.status;
+  a.resume[b] = r;
 }
 
 // end of clip: trim / statistics / rejects / score order + the size of the classification plan

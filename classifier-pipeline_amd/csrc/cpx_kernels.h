@@ -85,8 +85,14 @@ struct TrackArgs {
 
 struct ActiveTrack;
 struct ScoreRec;
+struct AssocResume {  // per clip, carried between cpx_associate_frame calls
+  int n_active, n_tracks, next_id, status;
+};
 struct AssocArgs {
   int B, cap;
+  int t_begin;          // first processed-frame index to handle (0: start of clip)
+  int fresh;            // 1: start with no tracks, 0: continue from `resume`
+  AssocResume* resume;  // [B]
   cpx_track_params params;
   const int* clip_first;
   const int* proc_off;

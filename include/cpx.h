@@ -139,6 +139,27 @@ const char* cpx_last_error(const cpx_handle* h);
 void* cpx_stream(cpx_handle* h);
 int cpx_synchronize(cpx_handle* h);
 
+/* ---- incremental tracking: one clip, frame by frame (the Pi-style caller) ------------------------------
+ * Replaces ClipTrackExtractor.process_frame / start_tracking (track/cliptrackextractor.py:181-247) followed
+ * by the caller's background update (cliptrackextractor.py:169-176): the same kernels as cpx_track_batch /
+ * cpx_associate_batch, run only for the frames [n_prev, n_frames) of ONE clip whose earlier frames were
+ * consumed by previous calls on this handle (its background, window sum, weights and association state
+ * stay in the handle's workspace).  n_prev == 0 opens a new stream.  frames_dev holds the clip so far --
+ * the kernels read the frame leaving the 45-frame window from it -- and the output arrays are indexed by
+ * frame like the batch calls', caller-allocated for the clip's capacity; meta holds all n_frames entries.
+ * Keep the same optional outputs (labels / filtered) for the whole stream.  A cpx_track_batch /
+ * cpx_associate_batch call on the handle ends the stream.  cpx_track_frame: n_prev that does not match the
+ * frames consumed -> CPX_ERR_INVALID.  cpx_associate_frame may skip frames: frames between its previous
+ * n_frames and n_prev are never associated (start_tracking(track_frames=False) preview frames); the first
+ * call after a new cpx_track_frame stream starts with no tracks. */
+int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_meta* meta, int n_prev, int n_frames,
+                    cpx_component* comps_dev, cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                    float* background_dev);
+int cpx_associate_frame(cpx_handle* h, const cpx_track_params* params, const cpx_frame_meta* meta, int n_prev,
+                        int n_frames, const cpx_component* comps_dev, const cpx_frame_info* info_dev,
+                        cpx_region* pool_dev, cpx_track_record* tracks_dev, int32_t* n_tracks_dev,
+                        int32_t* status_dev, cpx_region* regions_dev, int32_t* region_counts_dev);
+
 /* ---- CPTV v2 frame payload decode ------------------------------------------
  * Replaces the bit-unpack / running-sum / snake-order / inter-frame accumulation of the Rust CPTV
  * reader (python-cptv 0.0.8, used at track/cliptrackextractor.py:108-129,160-162) for B clips.
