@@ -66,13 +66,27 @@ CONV_TIMING_DTYPE = np.dtype([("key", "<i4"), ("launches", "<i4"), ("total_ms", 
 assert REGION_REF_DTYPE.itemsize == 24 and TRACK_LIMITS_DTYPE.itemsize == 16 and CROP_REQ_DTYPE.itemsize == 32
 assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FRAME_INFO_DTYPE.itemsize == 80
 
+class WRResNetBlock(C.Structure):  # struct cpx_wrresnet_block
+    _fields_ = [(k, C.c_void_p) for k in ("in_scale", "in_shift", "wa", "a_scale", "a_shift", "wb", "bb")]
+
+
+class WRResNetParams(C.Structure):  # struct cpx_wrresnet_params
+    _fields_ = [("n_labels", C.c_int32), ("blocks_per_stage", C.c_int32), ("groups", C.c_int32),
+                ("in_channels", C.c_int32), ("filters", C.c_int32 * 4),
+                ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p),
+                ("block", (WRResNetBlock * 8) * 3),
+                ("shortcut_w", C.c_void_p * 3), ("shortcut_b", C.c_void_p * 3),
+                ("final_scale", C.c_void_p), ("final_shift", C.c_void_p),
+                ("dense_w", C.c_void_p), ("dense_b", C.c_void_p)]
+
+
 EXPORTS = [
     "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
     "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
-    "cpx_track_frame", "cpx_associate_frame",
+    "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward",
 ]
 
 _lib = None
@@ -128,6 +142,12 @@ def load():
     lib.cpx_conv_timing_enable.restype = C.c_int
     lib.cpx_conv_timing_report.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.cpx_conv_timing_report.restype = C.c_int
+    lib.cpx_cnn_create.argtypes = [vp, C.POINTER(WRResNetParams), C.POINTER(vp)]
+    lib.cpx_cnn_create.restype = C.c_int
+    lib.cpx_cnn_destroy.argtypes = [vp]
+    lib.cpx_cnn_destroy.restype = None
+    lib.cpx_cnn_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.cpx_cnn_forward.restype = C.c_int
     lib.cpx_track_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.cpx_track_frame.restype = C.c_int
     lib.cpx_associate_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -16,7 +16,7 @@ import json
 
 import numpy as np
 
-from .._lib import CpxError
+from .._lib import CpxError, WRResNetParams
 
 BN_EPS = 1e-3  # tf.keras.layers.BatchNormalization default
 FILTERS = (16, 64, 128, 256)
@@ -110,7 +110,8 @@ assert C.sizeof(ConvDesc) == 104
 
 
 class WRResNetDevice:
-    """The network resident on one GPU; forward() runs 23 kernel launches on the engine's stream."""
+    """The network resident on one GPU: the parameters are uploaded once and handed to the native network
+    object (cpx_cnn_create); forward() is one cpx_cnn_forward call = 23 kernel launches on the engine's stream."""
 
     def __init__(self, engine, weights, n_labels):
         self.eng = engine
@@ -146,6 +147,43 @@ class WRResNetDevice:
         self.p["dense/w"] = up(w["prediction/kernel"])
         self.p["dense/b"] = up(w["prediction/bias"])
         self._bufs = {}
+        self._cnn = None
+        self._create_native()
+
+    def _create_native(self):
+        ptr = lambda key: self.p[key].data_ptr()
+        prm = WRResNetParams()
+        prm.n_labels, prm.blocks_per_stage, prm.groups, prm.in_channels = self.n_labels, BLOCKS, GROUPS, 2
+        for i, f in enumerate(FILTERS):
+            prm.filters[i] = f
+        prm.conv1_w, prm.conv1_b = ptr("conv1_1/w"), ptr("conv1_1/b")
+        for si, stage in enumerate((2, 3, 4)):
+            for d in range(BLOCKS):
+                b = "%db%d" % (stage, d)
+                blk = prm.block[si][d]
+                blk.in_scale, blk.in_shift = ptr("%s/in_scale" % b), ptr("%s/in_shift" % b)
+                blk.wa, blk.a_scale, blk.a_shift = ptr("%s/wa" % b), ptr("%s/a_scale" % b), ptr("%s/a_shift" % b)
+                blk.wb, blk.bb = ptr("%s/wb" % b), ptr("%s/bb" % b)
+            prm.shortcut_w[si], prm.shortcut_b[si] = ptr("sc%d/w" % stage), ptr("sc%d/b" % stage)
+        prm.final_scale, prm.final_shift = ptr("final/scale"), ptr("final/shift")
+        prm.dense_w, prm.dense_b = ptr("dense/w"), ptr("dense/b")
+        out = C.c_void_p()
+        rc = self.lib.cpx_cnn_create(self.eng.h, C.byref(prm), C.byref(out))
+        if rc != 0:
+            raise CpxError(rc, self.eng._err())
+        self._cnn = out
+
+    def close(self):
+        if self._cnn is not None:
+            if self.eng.h:  # a closed engine has already freed its networks
+                self.lib.cpx_cnn_destroy(self._cnn)
+            self._cnn = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _buf(self, key, shape):
         t = self.torch
@@ -170,6 +208,22 @@ class WRResNetDevice:
 
     def forward(self, x, want_probs=True):
         """x: device float32 [N, S, S, 2] (values 0..255, no input scaling) -> (logits, probs) [N, n_labels]."""
+        t = self.torch
+        N, H, W, cin = x.shape
+        assert cin == 2 and x.dtype == t.float32 and x.is_contiguous()
+        t.cuda.current_stream(self.eng.device).synchronize()
+        logits = t.empty((N, self.n_labels), dtype=t.float32, device=self.eng.device)
+        probs = t.empty((N, self.n_labels), dtype=t.float32, device=self.eng.device) if want_probs else None
+        rc = self.lib.cpx_cnn_forward(self._cnn, C.c_void_p(x.data_ptr()), N, H, W, C.c_void_p(logits.data_ptr()),
+                                      C.c_void_p(probs.data_ptr()) if probs is not None else None)
+        if rc != 0:
+            raise CpxError(rc, self.eng._err())
+        self.eng.synchronize()
+        return logits, probs
+
+    def forward_layerwise(self, x, want_probs=True):
+        """The same network issued layer by layer through cpx_conv2d / cpx_cnn_head (what a caller binding the
+        building blocks directly would write); tests compare it with forward()."""
         t = self.torch
         N, H, W, cin = x.shape
         assert cin == 2 and x.dtype == t.float32 and x.is_contiguous()

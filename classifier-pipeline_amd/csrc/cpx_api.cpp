@@ -14,6 +14,9 @@
 #include "cpx.h"
 #include "cpx_kernels.h"
 
+struct cpx_cnn;
+static void cnn_free(cpx_cnn* c);
+
 struct cpx_handle {
   int device = 0;
   cpx_config cfg{};
@@ -38,6 +41,7 @@ struct cpx_handle {
   int last_launches = 0;
   bool timing_valid = false;
   // incremental (one clip, frame by frame) tracking: frames consumed so far, -1 = no stream open
+  std::vector<struct cpx_cnn*> cnns;  // networks created on this handle (destroyed with it)
   int stream_frames = -1;
   int stream_assoc_frames = -1;
   bool stream_filt_state = false;
@@ -72,6 +76,14 @@ int fail(cpx_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
   do {                                                              \
     hipError_t _e = (call);                                         \
     if (_e != hipSuccess) return fail((h), CPX_ERR_HIP, #call, _e); \
+  } while (0)
+
+// every entry point: select the handle's device and drop stale errors other HIP users of the process left behind,
+// so that the hipGetLastError() after our launches reports our launches only
+#define CPX_ENTER(h)                           \
+  do {                                         \
+    CPX_HIP((h), hipSetDevice((h)->device));   \
+    (void)hipGetLastError();                   \
   } while (0)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -226,6 +238,8 @@ void cpx_destroy(cpx_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  for (cpx_cnn* c : h->cnns) cnn_free(c);
+  h->cnns.clear();
   if (h->ws) hipFree(h->ws);
   if (h->wtab_dev) hipFree(h->wtab_dev);
   if (h->nlm_lut_dev) hipFree(h->nlm_lut_dev);
@@ -264,7 +278,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
                      const cpx_frame_meta* meta, int B, int n_prev, cpx_component* comps_dev,
                      cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
                      float* background_dev) {
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   const cpx_config& c = h->cfg;
   Schedule sc;
   int rc = build_schedule(h, clip_offsets, meta, B, &sc);
@@ -378,7 +392,7 @@ static int assoc_run(cpx_handle* h, const cpx_track_params* params, const int32_
                      cpx_region* regions_dev, int32_t* region_counts_dev) {
   if (params->max_active_tracks < 1 || params->max_tracks < 1)
     return fail(h, CPX_ERR_INVALID, "association: capacities must be positive");
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   const bool resume = n_prev > 0 && !fresh;
   int t_begin = 0;
   if (n_prev > 0)
@@ -493,7 +507,7 @@ int cpx_track_limits_batch(cpx_handle* h, const uint16_t* frames_dev, const floa
   if (!frames_dev || !filtered_dev || !info_dev || !refs_dev || !track_offsets_dev || !limits_dev || n_tracks < 0)
     return fail(h, CPX_ERR_INVALID, "cpx_track_limits_batch: null argument");
   if (n_tracks == 0) return CPX_OK;
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::ClassifyArgs a = classify_args(h);
   a.frames = frames_dev;
   a.filtered = filtered_dev;
@@ -515,7 +529,7 @@ int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filter
   if (frame_size < 1 || frame_size > 128 || square_width < 1 || square_width > 16)
     return fail(h, CPX_ERR_UNSUPPORTED, "cpx_crop_tile: frame_size must be 1..128, square_width 1..16");
   if (n_reqs == 0) return CPX_OK;
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::ClassifyArgs a = classify_args(h);
   a.frames = frames_dev;
   a.filtered = filtered_dev;
@@ -536,7 +550,7 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) {
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->groups < 1 || d->Cin % d->groups || d->Cout % d->groups ||
       d->ksize < 1 || d->stride < 1 || (d->in_scale_dev == nullptr) != (d->in_shift_dev == nullptr))
     return fail(h, CPX_ERR_INVALID, "cpx_conv2d: bad descriptor");
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::ConvArgs a{};
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups;
   a.ksize = d->ksize; a.stride = d->stride; a.relu = d->relu;
@@ -582,7 +596,7 @@ int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const
   if (!in_dev || !bn_scale_dev || !bn_shift_dev || !dense_w_dev || !dense_b_dev || !logits_dev || N < 1 || HW < 1 ||
       C < 1 || L < 1 || C > 8192)
     return fail(h, CPX_ERR_INVALID, "cpx_cnn_head: bad argument");
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::HeadArgs a{};
   a.N = N; a.HW = HW; a.C = C; a.L = L;
   a.in = in_dev; a.bn_scale = bn_scale_dev; a.bn_shift = bn_shift_dev;
@@ -596,7 +610,7 @@ static int final_common(cpx_handle* h, const cpx_filter_params* params, const in
                         const cpx_frame_meta* meta, int B, cpx::FinalArgs* a) {
   if (params->max_active_tracks < 1 || params->max_tracks_per_clip < 1)
     return fail(h, CPX_ERR_INVALID, "filter params: capacities must be positive");
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   Schedule sc;
   int rc = build_schedule(h, clip_offsets, meta, B, &sc);
   if (rc != CPX_OK) return rc;
@@ -683,7 +697,7 @@ int cpx_aggregate_predictions(cpx_handle* h, const float* probs_dev, const int32
   if (!probs_dev || !sample_track_dev || !reqs_dev || !scores_dev || !best_dev || n_samples < 0 || n_tracks < 0 ||
       n_labels < 1)
     return fail(h, CPX_ERR_INVALID, "cpx_aggregate_predictions: bad argument");
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::AggregateArgs a{};
   a.n_samples = n_samples; a.n_tracks = n_tracks; a.n_labels = n_labels; a.fp_index = false_positive_index;
   a.square_width = square_width;
@@ -736,7 +750,7 @@ int cpx_cptv_unpack(cpx_handle* h, const uint8_t* payload_dev, const int64_t* fr
   if (!h) return CPX_ERR_INVALID;
   if (!payload_dev || !frame_offsets_dev || !bit_widths_dev || !clip_offsets_dev || !frames_out_dev || B < 1)
     return fail(h, CPX_ERR_INVALID, "cpx_cptv_unpack: bad argument");
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::CptvArgs a{};
   a.W = h->cfg.width;
   a.H = h->cfg.height;
@@ -759,7 +773,7 @@ int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* la
   if (!frames_dev || !labels_dev || !info_dev || !refs_dev || !out_dev || n_refs < 0)
     return fail(h, CPX_ERR_INVALID, "cpx_thumb_stats: bad argument");
   if (n_refs == 0) return CPX_OK;
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::ThumbArgs a{};
   a.W = h->cfg.width;
   a.H = h->cfg.height;
@@ -780,7 +794,7 @@ int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, in
   if (!h) return CPX_ERR_INVALID;
   if (!frames_dev || !out_dev || frame < 0 || background < 0)
     return fail(h, CPX_ERR_INVALID, "cpx_trackless_thumb: bad argument");
-  CPX_HIP(h, hipSetDevice(h->device));
+  CPX_ENTER(h);
   cpx::TracklessArgs a{};
   a.W = h->cfg.width;
   a.H = h->cfg.height;
@@ -793,6 +807,132 @@ int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, in
   if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_trackless_thumb: kernel configuration failed");
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
+}
+
+// ---- whole-network forward ------------------------------------------------------------------------------------------
+struct cpx_cnn {
+  cpx_handle* h = nullptr;
+  cpx_wrresnet_params p{};
+  float* arena = nullptr;  // act0 | act1 | mid | sc
+  size_t arena_floats = 0;
+};
+
+static void cnn_free(cpx_cnn* c) {
+  if (c->arena) hipFree(c->arena);
+  delete c;
+}
+
+static_assert(sizeof(cpx_wrresnet_block) == 56 && sizeof(cpx_wrresnet_params) == 1472,
+              "cpx_wrresnet_params layout is part of the ABI");
+
+int cpx_cnn_create(cpx_handle* h, const cpx_wrresnet_params* params, cpx_cnn** out) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!params || !out) return fail(h, CPX_ERR_INVALID, "cpx_cnn_create: null argument");
+  *out = nullptr;
+  const cpx_wrresnet_params& p = *params;
+  if (p.n_labels < 1 || p.blocks_per_stage < 1 || p.blocks_per_stage > CPX_WRRESNET_MAX_BLOCKS || p.groups < 1 ||
+      p.in_channels < 1 || !p.conv1_w || !p.final_scale || !p.final_shift || !p.dense_w || !p.dense_b)
+    return fail(h, CPX_ERR_INVALID, "cpx_cnn_create: bad network description");
+  for (int st = 0; st < 3; ++st) {
+    if (!p.shortcut_w[st]) return fail(h, CPX_ERR_INVALID, "cpx_cnn_create: missing shortcut weights");
+    for (int d = 0; d < p.blocks_per_stage; ++d) {
+      const cpx_wrresnet_block& b = p.block[st][d];
+      if (!b.in_scale || !b.in_shift || !b.wa || !b.wb)
+        return fail(h, CPX_ERR_INVALID, "cpx_cnn_create: missing block parameters");
+    }
+  }
+  cpx_cnn* c = new (std::nothrow) cpx_cnn();
+  if (!c) return fail(h, CPX_ERR_NOMEM, "cpx_cnn_create: out of memory");
+  c->h = h;
+  c->p = p;
+  h->cnns.push_back(c);
+  *out = c;
+  return CPX_OK;
+}
+
+void cpx_cnn_destroy(cpx_cnn* cnn) {
+  if (!cnn) return;
+  cpx_handle* h = cnn->h;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  h->cnns.erase(std::remove(h->cnns.begin(), h->cnns.end(), cnn), h->cnns.end());
+  cnn_free(cnn);
+}
+
+int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, float* logits_dev, float* probs_dev) {
+  if (!cnn) return CPX_ERR_INVALID;
+  cpx_handle* h = cnn->h;
+  if (!in_dev || !logits_dev || N < 1 || H < 1 || W < 1) return fail(h, CPX_ERR_INVALID, "cpx_cnn_forward: bad argument");
+  CPX_ENTER(h);
+  const cpx_wrresnet_params& p = cnn->p;
+  // largest activation: conv1 output (and the stage-2 tensors at stride 1)
+  size_t biggest = 0;
+  {
+    int hh = H, ww = W;
+    biggest = (size_t)N * hh * ww * p.filters[0];
+    for (int st = 0; st < 3; ++st) {
+      const int s = st + 1;
+      hh = (hh + s - 1) / s;
+      ww = (ww + s - 1) / s;
+      biggest = std::max(biggest, (size_t)N * hh * ww * p.filters[st + 1]);
+    }
+  }
+  biggest = align_up(biggest, 64);
+  if (4 * biggest > cnn->arena_floats) {
+    if (cnn->arena) {
+      CPX_HIP(h, hipStreamSynchronize(h->stream));
+      hipFree(cnn->arena);
+    }
+    cnn->arena = nullptr;
+    cnn->arena_floats = 0;
+    hipError_t e = hipMalloc((void**)&cnn->arena, 4 * biggest * sizeof(float));
+    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "cpx_cnn_forward: activation hipMalloc", e);
+    cnn->arena_floats = 4 * biggest;
+  }
+  float* act[2] = {cnn->arena, cnn->arena + biggest};
+  float* mid = cnn->arena + 2 * biggest;
+  float* sc = cnn->arena + 3 * biggest;
+  auto conv = [&](const float* in, float* out, const float* w, int hh, int ww, int cin, int cout, int k, int stride,
+                  int same, int relu, const float* in_scale, const float* in_shift, const float* out_scale,
+                  const float* out_shift, const float* residual) {
+    cpx_conv_desc d{};
+    d.N = N; d.H = hh; d.W = ww; d.Cin = cin; d.Cout = cout; d.groups = p.groups; d.ksize = k; d.stride = stride;
+    d.pad_same = same; d.relu = relu;
+    d.in_dev = in; d.out_dev = out; d.weights_dev = w; d.in_scale_dev = in_scale; d.in_shift_dev = in_shift;
+    d.out_scale_dev = out_scale; d.out_shift_dev = out_shift; d.residual_dev = residual;
+    return cpx_conv2d(h, &d);
+  };
+  int rc = conv(in_dev, act[0], p.conv1_w, H, W, p.in_channels, p.filters[0], 3, 1, 1, 0, nullptr, nullptr, nullptr,
+                p.conv1_b, nullptr);
+  if (rc != CPX_OK) return rc;
+  float* cur = act[0];
+  int flip = 0, c_in = p.filters[0], hh = H, ww = W;
+  for (int st = 0; st < 3; ++st) {
+    const int f = p.filters[st + 1];
+    for (int d = 0; d < p.blocks_per_stage; ++d) {
+      const cpx_wrresnet_block& b = p.block[st][d];
+      const int s = d == 0 ? st + 1 : 1;  // wr_block(stride = stage index), wr_resnet.py:27-30
+      const int ho = (hh + s - 1) / s, wo = (ww + s - 1) / s;
+      rc = conv(cur, mid, b.wa, hh, ww, c_in, f, 3, s, 1, 1, b.in_scale, b.in_shift, b.a_scale, b.a_shift, nullptr);
+      if (rc != CPX_OK) return rc;
+      const float* res = cur;
+      if (d == 0) {
+        rc = conv(cur, sc, p.shortcut_w[st], hh, ww, c_in, f, 1, s, 0, 0, nullptr, nullptr, nullptr, p.shortcut_b[st],
+                  nullptr);
+        if (rc != CPX_OK) return rc;
+        res = sc;
+      }
+      flip ^= 1;
+      rc = conv(mid, act[flip], b.wb, ho, wo, f, f, 3, 1, 1, 1, nullptr, nullptr, nullptr, b.bb, res);
+      if (rc != CPX_OK) return rc;
+      cur = act[flip];
+      hh = ho;
+      ww = wo;
+      c_in = f;
+    }
+  }
+  return cpx_cnn_head(h, cur, N, hh * ww, c_in, p.final_scale, p.final_shift, p.dense_w, p.dense_b, p.n_labels,
+                      logits_dev, probs_dev);
 }
 
 int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches) {

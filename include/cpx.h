@@ -358,6 +358,48 @@ int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
                  float* logits_dev, float* probs_dev);
 
+/* ---- whole-network forward ------------------------------------------------------------------------------
+ * KerasModel.predict (ml_tools/kerasmodel.py:856-859) for the WR-ResNet classifier in one call: conv1, three
+ * stages of `blocks_per_stage` pre-activation blocks (+ 1x1 shortcut in the first block of a stage, strides
+ * 1 / 2 / 3, wr_resnet.py:5-98), final BatchNorm + ReLU, global average pooling, Dense(n_labels) + sigmoid
+ * (kerasmodel.py:308-350).  The parameter struct holds device pointers (float32) laid out as cpx_conv2d /
+ * cpx_cnn_head take them; BatchNorm layers arrive folded to scale / shift.  The object keeps its own
+ * activation buffers (grown to the largest N seen) and enqueues 3 + 6 * 3 + 1 kernels per call on the
+ * handle's stream. */
+typedef struct cpx_wrresnet_block {
+  const float* in_scale;  /* BatchNorm 2a (applied with ReLU to the block input) */
+  const float* in_shift;
+  const float* wa;        /* conv 2a 3x3, packed */
+  const float* a_scale;   /* conv 2a bias folded with BatchNorm 2b */
+  const float* a_shift;
+  const float* wb;        /* conv 2b 3x3, packed */
+  const float* bb;        /* conv 2b bias */
+} cpx_wrresnet_block;
+
+#define CPX_WRRESNET_MAX_BLOCKS 8
+typedef struct cpx_wrresnet_params {
+  int32_t n_labels, blocks_per_stage, groups, in_channels;
+  int32_t filters[4];     /* conv1, stage 2, 3, 4 */
+  const float* conv1_w;
+  const float* conv1_b;
+  cpx_wrresnet_block block[3][CPX_WRRESNET_MAX_BLOCKS];
+  const float* shortcut_w[3];
+  const float* shortcut_b[3];
+  const float* final_scale;
+  const float* final_shift;
+  const float* dense_w;   /* [filters[3]][n_labels] */
+  const float* dense_b;
+} cpx_wrresnet_params;
+
+/* A network belongs to the handle it was created on: cpx_destroy(h) frees the networks still alive, after which
+ * their pointers are invalid (do not call cpx_cnn_destroy on them). */
+typedef struct cpx_cnn cpx_cnn;
+int cpx_cnn_create(cpx_handle* h, const cpx_wrresnet_params* params, cpx_cnn** out);
+void cpx_cnn_destroy(cpx_cnn* cnn);
+/* in_dev float32 [N, H, W, in_channels] (NHWC, values 0..255) -> logits_dev [N, n_labels] and, when not NULL,
+ * probs_dev (sigmoid). */
+int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, float* logits_dev, float* probs_dev);
+
 /* Per-kernel timing of cpx_conv2d launches with HIP events on the handle's stream (bench.py's roofline).
  * cpx_conv_timing_enable(h, 1) starts collecting (and clears); cpx_conv_timing_report synchronises and
  * returns, per kernel variant, total ms / launches / algorithmic FLOPs.  key = Cin_g*10000 + Cout_g*10 + stride

@@ -116,3 +116,10 @@ def test_wrresnet_logits_match_oracle(engine, fs, n):
     assert float(np.abs(want_logits).max()) > 0.05  # a non-degenerate comparison
     assert float(np.abs(got - want_logits).max()) <= LOGIT_ATOL, float(np.abs(got - want_logits).max())
     np.testing.assert_allclose(probs.cpu().numpy(), want_probs, atol=1e-4)
+    # the single-call native forward (cpx_cnn_forward) and the layer-by-layer building blocks are the same kernels
+    l2, p2 = net.forward_layerwise(torch.from_numpy(x).to(engine.device))
+    assert torch.equal(l2, logits) and torch.equal(p2, probs)
+    # a second batch size reuses / regrows the network's activation arena
+    l3, _ = net.forward(torch.from_numpy(np.concatenate([x, x])).to(engine.device))
+    assert torch.equal(l3[:n], logits) and torch.equal(l3[n:], logits)
+    net.close()
