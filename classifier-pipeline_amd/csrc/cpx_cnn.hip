@@ -16,9 +16,10 @@
 
 // input channels staged per chunk for the stride-1 3x3 layers of stage 2 / 3 / 4.  Small chunks keep the
 // workgroup's LDS at 25-30 KB so that 4 workgroups share a CU and hide each other's staging / epilogue
-// latency: measured 63 (32/32/16) -> 79 (32/16/8) -> 92 TFLOP/s (16/8/4) for the whole forward
+// latency: measured 63 (32/32/16) -> 79 (32/16/8) -> 92 TFLOP/s (16/8/4) for the whole forward; with the
+// register prefetch of the next chunk (below) and two bands per workgroup in stage 2: 100 TFLOP/s (8/8/4)
 #ifndef CPX_CONV_KC_S2
-#define CPX_CONV_KC_S2 16
+#define CPX_CONV_KC_S2 8
 #endif
 #ifndef CPX_CONV_KC_S3
 #define CPX_CONV_KC_S3 8
@@ -26,18 +27,33 @@
 #ifndef CPX_CONV_KC_S4
 #define CPX_CONV_KC_S4 4
 #endif
+// 8-row bands of output pixels per workgroup (M tiles per wave) for the same layers: with 2 bands a weight
+// fragment read from LDS feeds two MFMAs, the weight chunk is staged once per 256 pixels and the halo shrinks
+#ifndef CPX_CONV_NTM_S2
+#define CPX_CONV_NTM_S2 2
+#endif
+#ifndef CPX_CONV_NTM_S3
+#define CPX_CONV_NTM_S3 1
+#endif
+#ifndef CPX_CONV_NTM_S4
+#define CPX_CONV_NTM_S4 1
+#endif
 
 namespace cpx {
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef CPX_CONV_ABLATE_STORE
+__device__ __forceinline__ bool v_keep(float x) { return x == 1.2345e-30f; }  // never true: no stores, no residual loads
+#endif
 
-constexpr int TH = 8, TW = 16;  // output tile (pixels) of a workgroup; wave w owns rows 2w, 2w+1
+constexpr int TB = 8, TW = 16;  // a band of output pixels: 8 rows x 16; wave w owns rows 2w, 2w+1 of every band
 constexpr int CT = 256;
 
-template <int KC, int NTN, int S, int KS>
+template <int KC, int NTN, int S, int KS, int NTM>
 __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int TH = TB * NTM;        // output tile of a workgroup: NTM bands
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr int KP = KC + 1;          // padded channel stride of a patch pixel (bank spread)
   constexpr int COG = 32 * NTN;       // output channels per group
@@ -49,6 +65,21 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
   int bid = blockIdx.x;
+#ifdef CPX_CONV_STAGGER
+  {
+    const unsigned hsh = ((unsigned)(blockIdx.x + 7919u * blockIdx.y) * 2654435761u) >> 29;  // 0..7
+    switch (hsh) {
+      case 1: __builtin_amdgcn_s_sleep(CPX_CONV_STAGGER); break;
+      case 2: __builtin_amdgcn_s_sleep(2 * CPX_CONV_STAGGER); break;
+      case 3: __builtin_amdgcn_s_sleep(3 * CPX_CONV_STAGGER); break;
+      case 4: __builtin_amdgcn_s_sleep(4 * CPX_CONV_STAGGER); break;
+      case 5: __builtin_amdgcn_s_sleep(5 * CPX_CONV_STAGGER); break;
+      case 6: __builtin_amdgcn_s_sleep(6 * CPX_CONV_STAGGER); break;
+      case 7: __builtin_amdgcn_s_sleep(7 * CPX_CONV_STAGGER); break;
+      default: break;
+    }
+  }
+#endif
   const int txi = bid % tiles_x;
   bid /= tiles_x;
   const int tyi = bid % tiles_y;
@@ -60,11 +91,13 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
   const float* wg = a.weights + (size_t)g * KS * KS * cin_g * COG;
 
-  f32x16 acc[NTN];
+  f32x16 acc[NTM][NTN];
 #pragma unroll
-  for (int t = 0; t < NTN; ++t)
+  for (int m = 0; m < NTM; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
 
   // this lane's pixel inside the wave tile and its k half
   const int pi = lane & 31, kh = lane >> 5;
@@ -73,62 +106,109 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   const int b_base = kh * COG + (lane & 31);
 
   // staging geometry: a thread always serves the same group of 4 channels (256 % (KC/4) == 0), so the
-  // BatchNorm scale / shift of the prologue sit in registers for a whole chunk; 16-byte global loads
+  // BatchNorm scale / shift of the prologue sit in registers for a whole chunk; 16-byte global loads.
+  // The loads of chunk c+1 are issued before the MFMA loop of chunk c and land in registers while the
+  // matrix cores work; they are written to LDS (BN + ReLU applied, padding kept exactly 0) after the loop.
   constexpr int C4 = KC / 4;                 // float4 groups per pixel
   constexpr int NITEM = PH * PW * C4;        // float4 items of a patch chunk
+  constexpr int NP = (NITEM + CT - 1) / CT;  // ... per thread
+  constexpr int WV = KC * COG / 4;           // float4 per tap of a weight chunk [tap][KC][COG]
+  constexpr int NWI = (KS * KS * WV + CT - 1) / CT;
   const int my_c4 = tid % C4;
-  for (int cc = 0; cc < cin_g; cc += KC) {
-    // ---- stage the input patch chunk (BN + ReLU prologue; zero padding) ----
-    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.in_scale) {
-      const int ch = g * cin_g + cc + 4 * my_c4;
-      psc = *reinterpret_cast<const float4*>(a.in_scale + ch);
-      psh = *reinterpret_cast<const float4*>(a.in_shift + ch);
-    }
-    for (int item = tid; item < NITEM; item += CT) {
-      const int px = item / C4;
-      const int py = px / PW, pxx = px - py * PW;
-      const int iy = iy0 + py, ix = ix0 + pxx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-        v = *reinterpret_cast<const float4*>(in_n + ((size_t)iy * a.W + ix) * a.Cin + cc + 4 * my_c4);
-        if (a.in_scale) {
-          v.x = fmaxf(v.x * psc.x + psh.x, 0.0f);
-          v.y = fmaxf(v.y * psc.y + psh.y, 0.0f);
-          v.z = fmaxf(v.z * psc.z + psh.z, 0.0f);
-          v.w = fmaxf(v.w * psc.w + psh.w, 0.0f);
+  float4 pre_p[NP], pre_w[NWI];
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  // iteration cc = -KC only fetches chunk 0; iteration cc >= 0 commits chunk cc, fetches cc + KC, multiplies cc
+  for (int cc = -KC; cc < cin_g; cc += KC) {
+    if (cc >= 0) {
+      // ---- registers -> LDS: patch chunk (BN + ReLU prologue; zero padding stays 0) and weight chunk ----
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int item = tid + i * CT;
+        if (item < NITEM) {
+          const int px = item / C4;
+          const int py = px / PW, pxx = px - py * PW;
+          const int iy = iy0 + py, ix = ix0 + pxx;
+          float4 v = pre_p[i];
+          if (a.in_scale && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+            v.x = fmaxf(v.x * psc.x + psh.x, 0.0f);
+            v.y = fmaxf(v.y * psc.y + psh.y, 0.0f);
+            v.z = fmaxf(v.z * psc.z + psh.z, 0.0f);
+            v.w = fmaxf(v.w * psc.w + psh.w, 0.0f);
+          }
+          float* d = s_patch + px * KP + 4 * my_c4;
+          d[0] = v.x;
+          d[1] = v.y;
+          d[2] = v.z;
+          d[3] = v.w;
         }
       }
-      float* d = s_patch + px * KP + 4 * my_c4;
-      d[0] = v.x;
-      d[1] = v.y;
-      d[2] = v.z;
-      d[3] = v.w;
-    }
-    // ---- stage the weight chunk [tap][KC][COG]: KC*COG contiguous floats per tap ----
-    constexpr int WV = KC * COG / 4;  // float4 per tap
-    for (int item = tid; item < KS * KS * WV; item += CT) {
-      const int tap = item / WV, r = item - tap * WV;
-      const float4 w4 = *reinterpret_cast<const float4*>(wg + ((size_t)tap * cin_g + cc) * COG + 4 * r);
-      *reinterpret_cast<float4*>(s_w + tap * KC * COG + 4 * r) = w4;
-    }
-    __syncthreads();
 #pragma unroll
-    for (int tap = 0; tap < KS * KS; ++tap) {
-      const int ky = tap / KS, kx = tap - ky * KS;
-      const float* ap = s_patch + a_base + (ky * PW + kx) * KP;
-      const float* bp = s_w + tap * KC * COG + b_base;
-#pragma unroll
-      for (int k2 = 0; k2 < KC / 2; ++k2) {
-        const float av = ap[2 * k2];
-#pragma unroll
-        for (int t = 0; t < NTN; ++t) {
-          const float bv = bp[(2 * k2) * COG + t * 32];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      for (int i = 0; i < NWI; ++i) {
+        const int item = tid + i * CT;
+        if (item < KS * KS * WV) {
+          const int tap = item / WV, r = item - tap * WV;
+          *reinterpret_cast<float4*>(s_w + tap * KC * COG + 4 * r) = pre_w[i];
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
+    if (cc + KC < cin_g) {
+      // ---- global -> registers for the next chunk (in flight during the MFMA loop below) ----
+      const int cn = cc + KC;
+      if (a.in_scale) {
+        const int ch = g * cin_g + cn + 4 * my_c4;
+        psc = *reinterpret_cast<const float4*>(a.in_scale + ch);
+        psh = *reinterpret_cast<const float4*>(a.in_shift + ch);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int item = tid + i * CT;
+        const int px = item / C4;
+        const int py = px / PW, pxx = px - py * PW;
+        const int iy = iy0 + py, ix = ix0 + pxx;
+        pre_p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef CPX_CONV_ABLATE_PATCH_LOAD  // timing experiments only: results are wrong
+        if (iy == -12345)
+#else
+        if (item < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+#endif
+          pre_p[i] = *reinterpret_cast<const float4*>(in_n + ((size_t)iy * a.W + ix) * a.Cin + cn + 4 * my_c4);
+      }
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        const int item = tid + i * CT;
+        const int tap = item / WV, r = item - tap * WV;
+        pre_w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef CPX_CONV_ABLATE_WEIGHT_LOAD
+        pre_w[i] = make_float4(1.f, 2.f, 3.f, (float)item);
+#else
+        if (item < KS * KS * WV)
+          pre_w[i] = *reinterpret_cast<const float4*>(wg + ((size_t)tap * cin_g + cn) * COG + 4 * r);
+#endif
+      }
+    }
+    if (cc >= 0) {
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; ++tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const float* ap = s_patch + a_base + (ky * PW + kx) * KP;
+        const float* bp = s_w + tap * KC * COG + b_base;
+#pragma unroll
+        for (int k2 = 0; k2 < KC / 2; ++k2) {
+          float av[NTM], bv[NTN];
+#pragma unroll
+          for (int m = 0; m < NTM; ++m) av[m] = ap[m * (TB * S * PW * KP) + 2 * k2];
+#pragma unroll
+          for (int t = 0; t < NTN; ++t) bv[t] = bp[(2 * k2) * COG + t * 32];
+#pragma unroll
+          for (int m = 0; m < NTM; ++m)
+#pragma unroll
+            for (int t = 0; t < NTN; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: affine (bias / folded BN) from the accumulators, then through LDS so that residual
@@ -138,35 +218,42 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   const float* res_n = a.residual ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
   float* s_tile = lds + wave * (32 * 32);  // [32 pixels][32 channels] per wave; patch / weights are dead now
 #pragma unroll
-  for (int t = 0; t < NTN; ++t) {
-    const int ch = g * COG + t * 32 + (lane & 31);
-    const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
-    const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
+  for (int m = 0; m < NTM; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
-      s_tile[i * 32 + (lane & 31)] = acc[t][r] * os + ob;
-    }
-    __syncthreads();
+    for (int t = 0; t < NTN; ++t) {
+      const int ch = g * COG + t * 32 + (lane & 31);
+      const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+      const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int f = it * 64 + lane;         // float4 index inside the tile
-      const int i = f >> 3, c4 = f & 7;
-      const int oy = oy0 + 2 * wave + (i >> 4), ox = ox0 + (i & 15);
-      if (oy < a.Ho && ox < a.Wo) {
-        float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
-        const size_t o = ((size_t)oy * a.Wo + ox) * a.Cout + g * COG + t * 32 + 4 * c4;
-        if (res_n) {
-          const float4 rv = *reinterpret_cast<const float4*>(res_n + o);
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        }
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-        }
-        *reinterpret_cast<float4*>(out_n + o) = v;
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
+        s_tile[i * 32 + (lane & 31)] = acc[m][t][r] * os + ob;
       }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int f = it * 64 + lane;         // float4 index inside the tile
+        const int i = f >> 3, c4 = f & 7;
+        const int oy = oy0 + m * TB + 2 * wave + (i >> 4), ox = ox0 + (i & 15);
+#ifdef CPX_CONV_ABLATE_STORE
+        if (oy < a.Ho && ox < a.Wo && v_keep(s_tile[i * 32 + 4 * c4])) {
+#else
+        if (oy < a.Ho && ox < a.Wo) {
+#endif
+          float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
+          const size_t o = ((size_t)oy * a.Wo + ox) * a.Cout + g * COG + t * 32 + 4 * c4;
+          if (res_n) {
+            const float4 rv = *reinterpret_cast<const float4*>(res_n + o);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          }
+          if (a.relu) {
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+          }
+          *reinterpret_cast<float4*>(out_n + o) = v;
+        }
+      }
+      if (m + 1 < NTM || t + 1 < NTN) __syncthreads();
     }
-    if (t + 1 < NTN) __syncthreads();
   }
 }
 
@@ -227,20 +314,21 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   }
 }
 
-template <int KC, int NTN, int S, int KS>
+template <int KC, int NTN, int S, int KS, int NTM>
 static int launch_conv_t(const ConvArgs& a, hipStream_t s) {
+  constexpr int TH = TB * NTM;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   size_t lds = (((size_t)PH * PW * (KC + 1) + 3) / 4 * 4 + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
   if (lds < 4 * 32 * 32 * sizeof(float)) lds = 4 * 32 * 32 * sizeof(float);  // epilogue tiles
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS, NTM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
       return -1;
     configured = true;
   }
   const int tiles = ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
-  hipLaunchKernelGGL((conv_mfma_kernel<KC, NTN, S, KS>), dim3(tiles * a.N, a.groups), dim3(CT), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<KC, NTN, S, KS, NTM>), dim3(tiles * a.N, a.groups), dim3(CT), lds, s, a);
   return 0;
 }
 
@@ -255,18 +343,18 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(conv_direct_kernel, dim3(blocks), dim3(256), 0, s, a);
     return 0;
   }
-#define CPX_CONV_CASE(KC, NTN, S, KS)                                                        \
+#define CPX_CONV_CASE(KC, NTN, S, KS, NTM)                                                   \
   if (cout_g == 32 * NTN && a.stride == S && a.ksize == KS && (cin_g % KC) == 0 && cin_g >= KC) \
-    return launch_conv_t<KC, NTN, S, KS>(a, s);
+    return launch_conv_t<KC, NTN, S, KS, NTM>(a, s);
   // (channels per group, stride, kernel) combinations of WR-ResNet-22-4 with groups = 2
-  if (cin_g == 8) { CPX_CONV_CASE(8, 1, 1, 3) CPX_CONV_CASE(8, 1, 1, 1) }
-  CPX_CONV_CASE(CPX_CONV_KC_S2, 1, 1, 3)
-  CPX_CONV_CASE(8, 2, 2, 3)
-  CPX_CONV_CASE(16, 2, 2, 1)
-  CPX_CONV_CASE(CPX_CONV_KC_S3, 2, 1, 3)
-  CPX_CONV_CASE(8, 4, 3, 3)
-  CPX_CONV_CASE(8, 4, 3, 1)
-  CPX_CONV_CASE(CPX_CONV_KC_S4, 4, 1, 3)
+  if (cin_g == 8) { CPX_CONV_CASE(8, 1, 1, 3, 1) CPX_CONV_CASE(8, 1, 1, 1, 1) }
+  CPX_CONV_CASE(CPX_CONV_KC_S2, 1, 1, 3, CPX_CONV_NTM_S2)
+  CPX_CONV_CASE(8, 2, 2, 3, 1)
+  CPX_CONV_CASE(16, 2, 2, 1, 1)
+  CPX_CONV_CASE(CPX_CONV_KC_S3, 2, 1, 3, CPX_CONV_NTM_S3)
+  CPX_CONV_CASE(8, 4, 3, 3, 1)
+  CPX_CONV_CASE(8, 4, 3, 1, 1)
+  CPX_CONV_CASE(CPX_CONV_KC_S4, 4, 1, 3, CPX_CONV_NTM_S4)
 #undef CPX_CONV_CASE
   return -2;
 }
