@@ -137,6 +137,9 @@ def main():
                     help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only")
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cnn-chunk", type=int, default=512, help="samples per CNN forward")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="groups of clips per step: the track stage of group k+1 is issued on a second stream beside the "
+                         "network of group k (measured: no gain on MI355X, see DESIGN.md section 6; 1 = off)")
     ap.add_argument("--denoise", action="store_true",
                     help="tracking.denoise = true (the reference's default: NLM kernel between normalise and blur)")
     args = ap.parse_args()
@@ -189,15 +192,19 @@ def main():
     labels = None if e2e else torch.empty((total, H, W), dtype=torch.int32, device=device)
     outputs = (comps, info, labels, filt, None)
     weights = wr.random_weights(N_LABELS, seed=0)
-    net = wr.WRResNetDevice(eng, weights, N_LABELS) if e2e else None
+    # the network lives on a second handle (= second HIP stream) so that the HBM-bound track stage of one group of
+    # clips overlaps the MFMA-bound network of the previous group (BatchPipeline sub_batches)
+    overlap = e2e and args.sub_batches > 1
+    ceng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_frames=45) if overlap else eng
+    net = wr.WRResNetDevice(ceng, weights, N_LABELS) if e2e else None
     pipe = BatchPipeline(eng, net, n_labels=N_LABELS, fp_index=4, cnn_chunk=args.cnn_chunk)
     state = {}
 
     def step():
         if e2e:
-            res = pipe.run(frames, offs, meta, outputs=outputs)
+            res = pipe.run(frames, offs, meta, outputs=outputs, sub_batches=args.sub_batches)
             state["res"] = res
-            state["track_ms"], state["track_n"] = eng.last_kernel_timing()
+            state["track_ms"], state["track_n"] = res.track_timing
             if dist is not None and res.n_tracks:
                 rec = torch.cat([res.track_clip[:, :1] + rank * B, res.track_clip[:, 1:], res.best.view(-1, 1),
                                  (res.scores.max(dim=1).values * 1e6).to(torch.int32).view(-1, 1)], dim=1).contiguous()
@@ -221,7 +228,7 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_ms, kernel_launches = 0.0, 0
-    eng.conv_timing(True)
+    ceng.conv_timing(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -230,8 +237,8 @@ def main():
         kernel_launches += state["track_n"]
     fence()
     elapsed = time.perf_counter() - t0
-    conv = eng.conv_timing() if e2e else {}
-    eng.conv_timing(False)
+    conv = ceng.conv_timing() if e2e else {}
+    ceng.conv_timing(False)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -241,7 +248,9 @@ def main():
     if rank == 0:
         frames_done = world * B * T * args.steps
         avg_launch_s = kernel_ms / 1e3 / max(kernel_launches, 1)
-        bytes_per_launch = (ALGO_BYTES_PER_FRAME - (LABEL_BYTES_PER_FRAME if e2e else 0)) * B
+        # a launch handles one frame of every clip of its group (the whole batch, or one of the sub-batches)
+        clips_per_launch = B * T * args.steps / max(kernel_launches, 1)
+        bytes_per_launch = (ALGO_BYTES_PER_FRAME - (LABEL_BYTES_PER_FRAME if e2e else 0)) * clips_per_launch
         hbm = bytes_per_launch / avg_launch_s / 1e9
         track_roof = {"kernel": "cpx_frame_kernel", "bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4), "traffic": None,
@@ -276,7 +285,8 @@ def main():
         if e2e:
             r = state["res"]
             line["config"].update({"kept_tracks_per_step": int(r.n_tracks), "classified_segments_per_step": int(r.n_samples),
-                                   "frame_size": 32, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk})
+                                   "frame_size": 32, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk,
+                                   "sub_batches": args.sub_batches})
             key = 32 * 10000 + 32 * 10 + 1  # conv_mfma_kernel<KC=8,NTN=1,S=1,KS=3,NTM=2>: the stage-2 3x3 convolutions
             if key in conv and conv[key][1] > 0:
                 n, ms, fl = conv[key]

@@ -235,6 +235,12 @@ class TrackEngine:
     def _err(self):
         return (self.lib.cpx_last_error(self.h) or b"").decode()
 
+    def torch_stream(self):
+        """The handle's HIP stream as a torch stream (event record / wait between two engines)."""
+        if getattr(self, "_torch_stream", None) is None:
+            self._torch_stream = self.torch.cuda.ExternalStream(int(self.lib.cpx_stream(self.h)), device=self.device)
+        return self._torch_stream
+
     def synchronize(self):
         rc = self.lib.cpx_synchronize(self.h)
         if rc != 0:

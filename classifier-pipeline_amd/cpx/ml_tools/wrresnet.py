@@ -221,6 +221,16 @@ class WRResNetDevice:
         self.eng.synchronize()
         return logits, probs
 
+    def forward_async(self, x, logits, probs=None):
+        """Enqueue the forward of x into caller-provided outputs on the engine's stream; no host synchronisation
+        (the caller orders x's producer with an event and synchronises the engine before reading)."""
+        N, H, W, cin = x.shape
+        assert cin == 2 and x.is_contiguous() and logits.is_contiguous()
+        rc = self.lib.cpx_cnn_forward(self._cnn, C.c_void_p(x.data_ptr()), N, H, W, C.c_void_p(logits.data_ptr()),
+                                      C.c_void_p(probs.data_ptr()) if probs is not None else None)
+        if rc != 0:
+            raise CpxError(rc, self.eng._err())
+
     def forward_layerwise(self, x, want_probs=True):
         """The same network issued layer by layer through cpx_conv2d / cpx_cnn_head (what a caller binding the
         building blocks directly would write); tests compare it with forward()."""

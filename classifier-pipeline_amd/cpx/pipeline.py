@@ -25,6 +25,11 @@ class BatchResult:
         self.samples_dev = None    # device float [n_samples, S, S, 2] (only when keep_samples)
         self.reqs_dev = None
         self.sample_track_dev = None
+        self.limits_dev = None     # cpx_track_limits [n_tracks]
+        self.probs = None          # device float [n_samples, L]
+        self.parts = None          # overlapped run: the per-group results
+        self.clip0 = 0
+        self.track_timing = (0.0, 0)
 
     def summaries(self, max_tracks):
         return self.summaries_dev.cpu().numpy().view(TRACK_SUMMARY_DTYPE).reshape(-1, max_tracks)
@@ -48,11 +53,63 @@ class BatchPipeline:
         if rc != 0:
             raise CpxError(rc, self.eng._err())
 
-    def run(self, frames_dev, clip_offsets, meta, outputs=None, classify=True, keep_samples=False):
+    def run(self, frames_dev, clip_offsets, meta, outputs=None, classify=True, keep_samples=False, sub_batches=1):
+        """All stages for the clips of one batch.  sub_batches > 1 (and a network living on a second engine, i.e. a
+        second HIP stream): the batch is cut into that many groups of clips and the HBM-bound track stage of group
+        k+1 runs while the MFMA-bound network works on group k."""
+        if sub_batches > 1 and classify and self.net is not None and not keep_samples:
+            return self._run_overlapped(frames_dev, clip_offsets, meta, outputs, sub_batches)
+        eng, t = self.eng, self.eng.torch
+        lib, h = eng.lib, eng.h
+        dev = eng.device
+        out = self._front(frames_dev, clip_offsets, meta, outputs, classify)
+        if not classify or out.n_tracks == 0 or out.n_samples == 0:
+            return out
+        n_tracks, n_samples = out.n_tracks, out.n_samples
+        reqs, limits, per = out.reqs_dev, out.limits_dev, self.sq * self.sq
+        side = self.sq * self.fs
+        probs = t.empty((n_samples, self.n_labels), dtype=t.float32, device=dev)
+        chunk = min(self.cnn_chunk, n_samples)
+        if keep_samples:
+            out.samples_dev = t.empty((n_samples, side, side, 2), dtype=t.float32, device=dev)
+        elif self._sample_buf is None or self._sample_buf.shape[0] < chunk or self._sample_buf.shape[1] != side:
+            self._sample_buf = t.empty((chunk, side, side, 2), dtype=t.float32, device=dev)
+        for s0 in range(0, n_samples, chunk):
+            s1 = min(s0 + chunk, n_samples)
+            buf = out.samples_dev[s0:s1] if keep_samples else self._sample_buf[: s1 - s0]
+            # requests of the chunk address samples relative to s0
+            rq = reqs.view(-1, 8)[s0 * per : s1 * per].clone()
+            rq[:, 6] -= s0
+            t.cuda.current_stream(dev).synchronize()
+            self._check(lib.cpx_crop_tile(
+                h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(out.track.filtered_dev.data_ptr()),
+                C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(rq.data_ptr()), (s1 - s0) * per,
+                C.c_void_p(limits.data_ptr()), self.fs, self.sq, C.c_void_p(buf.data_ptr())))
+            eng.synchronize()
+            if self.net is not None:
+                _, p = self.net.forward(buf)
+                probs[s0:s1] = p
+        if self.net is None:
+            return out
+        # ---- 7. per-track aggregation ----
+        out.scores = t.empty((n_tracks, self.n_labels), dtype=t.float32, device=dev)
+        out.best = t.empty(n_tracks, dtype=t.int32, device=dev)
+        t.cuda.current_stream(dev).synchronize()
+        self._check(lib.cpx_aggregate_predictions(
+            h, C.c_void_p(probs.data_ptr()), C.c_void_p(out.sample_track_dev.data_ptr()), n_samples,
+            C.c_void_p(reqs.data_ptr()), n_tracks, self.n_labels, self.fp_index, self.sq,
+            C.c_void_p(out.scores.data_ptr()), C.c_void_p(out.best.data_ptr())))
+        eng.synchronize()
+        out.probs = probs
+        return out
+
+    def _front(self, frames_dev, clip_offsets, meta, outputs, classify=True):
+        """Stages 1-5a on the track engine: track, association, end-of-clip filtering, segment plan, limits."""
         eng, t = self.eng, self.eng.torch
         lib, h = eng.lib, eng.h
         dev = eng.device
         offs = np.ascontiguousarray(clip_offsets, dtype=np.int32)
+        meta = np.ascontiguousarray(meta)
         B = offs.size - 1
         out = BatchResult()
         # ---- 1. track stage (one launch per time step), 2. association ----
@@ -63,11 +120,13 @@ class BatchPipeline:
         summ = t.zeros(B * mt * 30, dtype=t.int32, device=dev)
         counts = t.zeros((B, 4), dtype=t.int32, device=dev)
         offs_p = offs.ctypes.data_as(C.POINTER(C.c_int32))
+        t.cuda.current_stream(dev).synchronize()
         self._check(lib.cpx_finalize_tracks(
             h, C.byref(self.fp), offs_p, C.c_void_p(meta.ctypes.data), B, C.c_void_p(out.assoc.pool_dev.data_ptr()),
             C.c_void_p(out.assoc.tracks_dev.data_ptr()), C.c_void_p(out.assoc.ntracks_dev.data_ptr()),
             C.c_void_p(summ.data_ptr()), C.c_void_p(counts.data_ptr())))
         eng.synchronize()
+        out.track_timing = eng.last_kernel_timing()  # (ms, launches) of this group's frame-kernel launches
         out.summaries_dev = summ
         prefix = (t.cumsum(counts, dim=0) - counts).to(t.int32).contiguous()
         totals = counts.sum(dim=0).cpu().numpy()
@@ -92,44 +151,102 @@ class BatchPipeline:
         eng.synchronize()
         toffs[n_tracks] = n_refs
         out.track_clip, out.reqs_dev, out.sample_track_dev = track_clip, reqs, sample_track
-        # ---- 5. limits, then crop / tile + 6. CNN in chunks of samples ----
+        # ---- 5a. per-track limits ----
         limits = t.zeros(n_tracks * 4, dtype=t.int32, device=dev)
         t.cuda.current_stream(dev).synchronize()
         self._check(lib.cpx_track_limits_batch(
             h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(out.track.filtered_dev.data_ptr()),
             C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(refs.data_ptr()), C.c_void_p(toffs.data_ptr()),
             n_tracks, C.c_void_p(limits.data_ptr())))
-        side = self.sq * self.fs
-        probs = t.empty((n_samples, self.n_labels), dtype=t.float32, device=dev)
-        chunk = min(self.cnn_chunk, n_samples)
-        if keep_samples:
-            out.samples_dev = t.empty((n_samples, side, side, 2), dtype=t.float32, device=dev)
-        elif self._sample_buf is None or self._sample_buf.shape[0] < chunk or self._sample_buf.shape[1] != side:
-            self._sample_buf = t.empty((chunk, side, side, 2), dtype=t.float32, device=dev)
-        for s0 in range(0, n_samples, chunk):
-            s1 = min(s0 + chunk, n_samples)
-            buf = out.samples_dev[s0:s1] if keep_samples else self._sample_buf[: s1 - s0]
-            # requests of the chunk address samples relative to s0
-            rq = reqs.view(-1, 8)[s0 * per : s1 * per].clone()
-            rq[:, 6] -= s0
-            self._check(lib.cpx_crop_tile(
-                h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(out.track.filtered_dev.data_ptr()),
-                C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(rq.data_ptr()), (s1 - s0) * per,
-                C.c_void_p(limits.data_ptr()), self.fs, self.sq, C.c_void_p(buf.data_ptr())))
-            eng.synchronize()
-            if self.net is not None:
-                _, p = self.net.forward(buf)
-                probs[s0:s1] = p
-        if self.net is None:
-            return out
-        # ---- 7. per-track aggregation ----
-        out.scores = t.empty((n_tracks, self.n_labels), dtype=t.float32, device=dev)
-        out.best = t.empty(n_tracks, dtype=t.int32, device=dev)
-        t.cuda.current_stream(dev).synchronize()
-        self._check(lib.cpx_aggregate_predictions(
-            h, C.c_void_p(probs.data_ptr()), C.c_void_p(sample_track.data_ptr()), n_samples,
-            C.c_void_p(reqs.data_ptr()), n_tracks, self.n_labels, self.fp_index, self.sq,
-            C.c_void_p(out.scores.data_ptr()), C.c_void_p(out.best.data_ptr())))
-        eng.synchronize()
-        out.probs = probs
+        out.limits_dev = limits
+        out._keep = (refs, toffs, prefix)
         return out
+
+    def _run_overlapped(self, frames_dev, clip_offsets, meta, outputs, n_sub):
+        eng, ceng, t = self.eng, self.net.eng, self.eng.torch
+        lib, dev = eng.lib, eng.device
+        offs = np.ascontiguousarray(clip_offsets, dtype=np.int32)
+        meta = np.ascontiguousarray(meta)
+        B = offs.size - 1
+        n_sub = max(1, min(n_sub, B))
+        bounds = [int(round(B * k / n_sub)) for k in range(n_sub + 1)]
+        s_track, s_cnn = eng.torch_stream(), ceng.torch_stream()
+        per, side, cap = self.sq * self.sq, self.sq * self.fs, eng.cap
+        parts = []
+        for k in range(n_sub):
+            b0, b1 = bounds[k], bounds[k + 1]
+            if b1 <= b0:
+                continue
+            f0, f1 = int(offs[b0]), int(offs[b1])
+            sub_out = None
+            if outputs is not None:
+                comps, info, labels, filt, bgo = outputs
+                sub_out = (comps[f0 * cap * 8:f1 * cap * 8], info[f0 * 20:f1 * 20],
+                           None if labels is None else labels[f0:f1], None if filt is None else filt[f0:f1],
+                           None if bgo is None else bgo[b0:b1])
+            fr = frames_dev[f0:f1]
+            part = self._front(fr, offs[b0:b1 + 1] - f0, meta[f0:f1], sub_out)
+            part.clip0 = b0
+            parts.append(part)
+            if part.n_tracks == 0 or part.n_samples == 0:
+                continue
+            ns, nt = part.n_samples, part.n_tracks
+            # ---- 5b. crop / tile every segment of the group (track stream) ----
+            samples = t.empty((ns, side, side, 2), dtype=t.float32, device=dev)
+            part.probs = t.empty((ns, self.n_labels), dtype=t.float32, device=dev)
+            logits = t.empty((ns, self.n_labels), dtype=t.float32, device=dev)
+            part.scores = t.empty((nt, self.n_labels), dtype=t.float32, device=dev)
+            part.best = t.empty(nt, dtype=t.int32, device=dev)
+            t.cuda.current_stream(dev).synchronize()
+            self._check(lib.cpx_crop_tile(
+                eng.h, C.c_void_p(fr.data_ptr()), C.c_void_p(part.track.filtered_dev.data_ptr()),
+                C.c_void_p(part.track.info_dev.data_ptr()), C.c_void_p(part.reqs_dev.data_ptr()), ns * per,
+                C.c_void_p(part.limits_dev.data_ptr()), self.fs, self.sq, C.c_void_p(samples.data_ptr())))
+            ev = t.cuda.Event()
+            ev.record(s_track)
+            s_cnn.wait_event(ev)
+            # ---- 6. network + 7. aggregation (network stream; nothing below blocks the host) ----
+            for s0 in range(0, ns, self.cnn_chunk):
+                s1 = min(s0 + self.cnn_chunk, ns)
+                self.net.forward_async(samples[s0:s1], logits[s0:s1], part.probs[s0:s1])
+            rc = lib.cpx_aggregate_predictions(
+                ceng.h, C.c_void_p(part.probs.data_ptr()), C.c_void_p(part.sample_track_dev.data_ptr()), ns,
+                C.c_void_p(part.reqs_dev.data_ptr()), nt, self.n_labels, self.fp_index, self.sq,
+                C.c_void_p(part.scores.data_ptr()), C.c_void_p(part.best.data_ptr()))
+            if rc != 0:
+                raise CpxError(rc, ceng._err())
+            part._keep2 = (samples, logits, ev)
+        eng.synchronize()
+        ceng.synchronize()
+        # ---- merge the groups ----
+        out = BatchResult()
+        out.parts = parts
+        out.track = parts[0].track if len(parts) == 1 else _MergedCheck([p.track for p in parts])
+        out.assoc = parts[0].assoc if len(parts) == 1 else _MergedCheck([p.assoc for p in parts])
+        out.counts = np.concatenate([p.counts for p in parts])
+        out.track_timing = (sum(p.track_timing[0] for p in parts), sum(p.track_timing[1] for p in parts))
+        out.n_tracks = sum(p.n_tracks for p in parts)
+        out.n_samples = sum(p.n_samples for p in parts)
+        live = [p for p in parts if p.n_tracks and p.n_samples]
+        if live:
+            tcs = []
+            for p in live:
+                tc = p.track_clip.clone()
+                tc[:, 0] += p.clip0
+                tcs.append(tc)
+            out.track_clip = t.cat(tcs)
+            out.scores = t.cat([p.scores for p in live])
+            out.best = t.cat([p.best for p in live])
+            out.probs = t.cat([p.probs for p in live])
+        return out
+
+
+class _MergedCheck:
+    """check() over the per-group results of an overlapped run."""
+
+    def __init__(self, items):
+        self.items = items
+
+    def check(self):
+        for it in self.items:
+            it.check()

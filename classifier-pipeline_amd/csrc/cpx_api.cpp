@@ -190,7 +190,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   if (!h) return CPX_ERR_NOMEM;
   h->device = device_id;
   h->cfg = *cfg;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     delete h;
     return CPX_ERR_HIP;

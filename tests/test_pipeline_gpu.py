@@ -74,3 +74,39 @@ def test_batched_pipeline_matches_oracle_chain():
             total_tracks += 1
     assert ti == res.n_tracks and total_tracks >= 3
     eng.close()
+
+
+def test_overlapped_sub_batches_equal_single_pass():
+    """BatchPipeline(sub_batches=k): the track stage of one group of clips overlaps the network of the previous
+    group on a second stream -- the results must be those of the plain pass, bit for bit."""
+    import torch
+
+    import cnn_oracle as cnn
+    from cpx import synth
+    from cpx.engine import TrackEngine
+    from cpx.ml_tools import wrresnet as wr
+    from cpx.pipeline import BatchPipeline
+
+    K, T = 11, 130
+    frames, offs = synth.make_batch(K, T, seed=5)
+    eng = TrackEngine(model="lepton3", max_frames=T)
+    ceng = TrackEngine(model="lepton3", max_frames=45)
+    rng = np.random.default_rng(3)
+    w = wr.random_weights(17, seed=2)
+    w = cnn.calibrate_bn(w, rng.uniform(0, 255, size=(2, 160, 160, 2)).astype(np.float32))
+    meta = np.concatenate([eng.make_meta(T) for _ in range(K)])
+    dev = eng.upload_frames(frames)
+    plain = BatchPipeline(eng, wr.WRResNetDevice(eng, w, 17), n_labels=17, fp_index=4, cnn_chunk=7).run(dev, offs, meta)
+    assert plain.n_tracks >= 4
+    pipe = BatchPipeline(eng, wr.WRResNetDevice(ceng, w, 17), n_labels=17, fp_index=4, cnn_chunk=7)
+    for n_sub in (2, 3, 11):
+        got = pipe.run(dev, offs, meta, sub_batches=n_sub)
+        got.track.check()
+        got.assoc.check()
+        assert (got.n_tracks, got.n_samples) == (plain.n_tracks, plain.n_samples)
+        assert np.array_equal(got.counts, plain.counts)
+        assert torch.equal(got.track_clip, plain.track_clip)
+        assert torch.equal(got.scores, plain.scores) and torch.equal(got.best, plain.best)
+        assert torch.equal(got.probs, plain.probs)
+    eng.close()
+    ceng.close()
