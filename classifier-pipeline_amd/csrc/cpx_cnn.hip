@@ -65,6 +65,11 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
   int bid = blockIdx.x;
+#ifndef CPX_CONV_NO_XCD_REMAP
+  // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a contiguous run of
+  // tiles so that neighbouring tiles, which share their halo rows / columns, hit the same L2
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+#endif
 #ifdef CPX_CONV_STAGGER
   {
     const unsigned hsh = ((unsigned)(blockIdx.x + 7919u * blockIdx.y) * 2654435761u) >> 29;  // 0..7
@@ -294,6 +299,49 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   }
 }
 
+// conv1_1 as the network uses it (2 input channels, 2 groups of 8 output channels, 3x3, stride 1, SAME, bias
+// only): one thread per pixel computes all 16 output channels -- float2 input loads, four 16-byte stores per
+// pixel (64 contiguous bytes), weights through uniform (scalar) loads.  HBM-bound: 8 B read, 64 B written per pixel.
+__global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
+  const size_t total = (size_t)a.N * a.Ho * a.Wo;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t p = idx;
+    const int ox = (int)(p % a.Wo);
+    p /= a.Wo;
+    const int oy = (int)(p % a.Ho);
+    const int n = (int)(p / a.Ho);
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    const float* in_n = a.in + (size_t)n * a.H * a.W * 2;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy - a.pad_top + ky, ix = ox - a.pad_left + kx;
+        if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;
+        const float2 v = *reinterpret_cast<const float2*>(in_n + ((size_t)iy * a.W + ix) * 2);
+        const float* w0 = a.weights + (ky * 3 + kx) * 8;       // group 0: [tap][1][8]
+        const float* w1 = a.weights + 72 + (ky * 3 + kx) * 8;  // group 1
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          acc[c] += v.x * w0[c];
+          acc[8 + c] += v.y * w1[c];
+        }
+      }
+    float* o = a.out + idx * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 r;
+      r.x = acc[4 * q + 0] + a.out_shift[4 * q + 0];
+      r.y = acc[4 * q + 1] + a.out_shift[4 * q + 1];
+      r.z = acc[4 * q + 2] + a.out_shift[4 * q + 2];
+      r.w = acc[4 * q + 3] + a.out_shift[4 * q + 3];
+      *reinterpret_cast<float4*>(o + 4 * q) = r;
+    }
+  }
+}
+
 // final_bn -> ReLU -> GlobalAveragePooling2D -> Dense(n_labels) (+ sigmoid): one workgroup per sample
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_feat[];  // [C]
@@ -336,6 +384,13 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t s) {
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  if (cin_g == 1 && cout_g == 8 && a.groups == 2 && a.ksize == 3 && a.stride == 1 && !a.in_scale && !a.out_scale &&
+      a.out_shift && !a.residual && !a.relu) {
+    const size_t total = (size_t)a.N * a.Ho * a.Wo;
+    const int blocks = (int)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv1_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return 0;
+  }
   if (cin_g < 8) {
     if (cout_g > 16) return -2;
     const size_t total = (size_t)a.N * a.Ho * a.Wo * a.groups;

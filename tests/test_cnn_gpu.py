@@ -55,10 +55,11 @@ def test_conv2d_matches_torch(engine, case):
     Ho = -(-H // stride) if same else (H - ks) // stride + 1
     Wo = -(-W // stride) if same else (W - ks) // stride + 1
     res = rng.normal(0, 1, size=(N, Ho, Wo, Cout)).astype(np.float32)
-    for variant in range(3):
+    for variant in range(4):  # 3 = bias only (how conv1_1 and the shortcuts are called)
         use_pro = variant in (0, 2)
         use_res = variant in (1, 2)
-        relu = variant != 1
+        relu = variant in (0, 2)
+        use_scale = variant != 3
         # torch reference
         xt = torch.from_numpy(x).permute(0, 3, 1, 2)
         if use_pro:
@@ -68,7 +69,9 @@ def test_conv2d_matches_torch(engine, case):
             pw = max((Wo - 1) * stride + ks - W, 0)
             xt = F.pad(xt, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
         y = F.conv2d(xt, torch.from_numpy(k).permute(3, 2, 0, 1).contiguous(), None, stride=stride, groups=2)
-        y = y * torch.from_numpy(out_s)[None, :, None, None] + torch.from_numpy(out_b)[None, :, None, None]
+        if use_scale:
+            y = y * torch.from_numpy(out_s)[None, :, None, None]
+        y = y + torch.from_numpy(out_b)[None, :, None, None]
         if use_res:
             y = y + torch.from_numpy(res).permute(0, 3, 1, 2)
         if relu:
@@ -83,7 +86,7 @@ def test_conv2d_matches_torch(engine, case):
         out = torch.full((N, Ho, Wo, Cout), np.nan, dtype=torch.float32, device=dev)
         ptr = lambda v: C.c_void_p(v.data_ptr())
         d = ConvDesc(N, H, W, Cin, Cout, 2, ks, stride, 1 if same else 0, 1 if relu else 0, ptr(xd), ptr(out), ptr(wd),
-                     ptr(isd) if use_pro else None, ptr(ibd) if use_pro else None, ptr(osd), ptr(obd),
+                     ptr(isd) if use_pro else None, ptr(ibd) if use_pro else None, ptr(osd) if use_scale else None, ptr(obd),
                      ptr(rd) if use_res else None)
         torch.cuda.synchronize()
         rc = engine.lib.cpx_conv2d(engine.h, C.byref(d))
