@@ -126,6 +126,24 @@ def cpu_baseline(stage, n_clips, n_frames, seed, weights):
             "sample": "%d synthetic clips x %d frames, oracle %s, %.1f s" % (n_clips, n_frames, what, dt)}
 
 
+# algorithmic FLOPs of one stage-2 3x3 convolution per sample as the library counts them (cpx_conv_timing_report):
+# 2 * Ho*Wo * Cout * Cin/groups * k*k = 2 * 160*160 * 64 * 32 * 9
+STAGE2_CONV_FLOPS_PER_SAMPLE = 2.0 * 160 * 160 * 64 * 32 * 9
+
+
+def pmc_traffic(section, units_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r01_e2e_pmc.json: separate FETCH_SIZE /
+    WRITE_SIZE passes over this same bench command, gfx950 correction applied), scaled to this run's launch size.
+    PMC collection needs the profiler, so it cannot be taken live here; None when the summary is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e2e_pmc.json")
+    try:
+        with open(path) as fh:
+            sec = json.load(fh)[section]
+        return round(sec["hbm_traffic_bytes_per_launch"] / sec["units_per_launch"] * units_per_launch, 1)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,7 +271,8 @@ def main():
         bytes_per_launch = (ALGO_BYTES_PER_FRAME - (LABEL_BYTES_PER_FRAME if e2e else 0)) * clips_per_launch
         hbm = bytes_per_launch / avg_launch_s / 1e9
         track_roof = {"kernel": "cpx_frame_kernel", "bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4), "traffic": None,
+                      "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
+                      "traffic": pmc_traffic("frame_kernel_e2e" if e2e else "frame_kernel_track", clips_per_launch),
                       "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": kernel_launches,
                       "algorithmic_bytes_per_launch": bytes_per_launch}
         line = {
@@ -293,7 +312,8 @@ def main():
                 tf = fl / (ms / 1e3) / 1e12
                 line["roofline"] = {"kernel": "conv_mfma_kernel<8,1,1,3,2> (stage-2 3x3 conv, 64->64 ch, groups 2, 160x160)",
                                     "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                                    "traffic": pmc_traffic("conv_stage2", fl / n / STAGE2_CONV_FLOPS_PER_SAMPLE),
                                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
                                     "algorithmic_flops_per_launch": fl / n}
                 tot_ms = sum(v[1] for v in conv.values())

@@ -1,0 +1,57 @@
+"""Builds profiles/r01_e2e_pmc.json from the rocprofv3 counter CSVs of four passes (run on the GPU box from the repo
+root, after `cd /tmp && export TMPDIR=/tmp && cd -`):
+
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_e2e_fetch -- python3 bench.py --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_e2e_write -- python3 bench.py --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_trk_fetch -- python3 bench.py --stage track --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_trk_write -- python3 bench.py --stage track --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
+
+FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-byte read requests at 64 bytes; Infinity-Cache hits are
+counted too); WRITE_SIZE is taken as is.  Values are KiB per dispatch."""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def avg(dirname, counter, kernel_sub, grid=None):
+    path = glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*_counter_collection.csv"))[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]
+            and (grid is None or int(r["Grid_Size"]) == grid)]
+    return sum(vals) / len(vals), len(vals)
+
+
+def section(kernel, fetch_dir, write_dir, kernel_sub, grid, units, unit, algo, note):
+    f, n = avg(fetch_dir, "FETCH_SIZE", kernel_sub, grid)
+    w, _ = avg(write_dir, "WRITE_SIZE", kernel_sub, grid)
+    rd, wr = 2 * f * 1024, w * 1024
+    return {"kernel": kernel, "launches": n, "units_per_launch": units, "unit": unit, "FETCH_SIZE_KiB_avg": f,
+            "WRITE_SIZE_KiB_avg": w, "hbm_read_bytes_per_launch_corrected": rd, "hbm_write_bytes_per_launch": wr,
+            "hbm_traffic_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": algo,
+            "algorithmic_bytes_note": note, "traffic_over_algorithmic": (rd + wr) / algo}
+
+
+out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py [--stage track] "
+                  "--clips 1024 --steps 1 --warmup 0 --cpu-clips 0 (separate passes, scratch/make_pmc_profile.py)",
+       "note": "KiB per dispatch, averaged over the launches named; FETCH_SIZE doubled per MI355X_MICROARCH.md, "
+               "WRITE_SIZE as is"}
+out["conv_stage2"] = section(
+    "conv_mfma_kernel<8,1,1,3,2>, launches of 512 samples (64->64 ch, 160x160)", "pmc_e2e_fetch", "pmc_e2e_write",
+    "conv_mfma_kernel<8, 1, 1, 3, 2>", 512 * 100 * 2 * 256, 512, "samples", 512 * 160 * 160 * 64 * 4 * 2.6,
+    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): 512*160*160*64*4 B * 2.6")
+out["frame_kernel_e2e"] = section(
+    "cpx_frame_kernel, 1024 clip-frames per launch, no label image (end-to-end configuration)", "pmc_e2e_fetch",
+    "pmc_e2e_write", "cpx_frame_kernel", None, 1024, "clip-frames", (614400 - 76800) * 1024,
+    "SURVEY 8(d): 614,400 B per frame minus the 76,800 B label image")
+if glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_trk_fetch", "*", "*_counter_collection.csv")):
+    out["frame_kernel_track"] = section(
+        "cpx_frame_kernel, 1024 clip-frames per launch, label image written (BASELINE configs[1])", "pmc_trk_fetch",
+        "pmc_trk_write", "cpx_frame_kernel", None, 1024, "clip-frames", 614400 * 1024, "SURVEY 8(d): 614,400 B per frame")
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_e2e_pmc.json"), "w"), indent=1)
+for k, v in out.items():
+    if isinstance(v, dict):
+        print(k, "traffic/algorithmic = %.3f" % v["traffic_over_algorithmic"])
