@@ -365,3 +365,41 @@ def test_denoise_matches_oracle_on_synthetic(engines):
             assert np.array_equal(got, o["stats"]), (b, i)
             ncomp += len(c)
     assert ncomp > 0
+
+
+@pytest.mark.parametrize("W,H", [(80, 60), (128, 96), (184, 104)])
+def test_other_resolutions_match_oracle(W, H):
+    """The kernels take the resolution from the handle (the reference reads it from the CPTV header): smaller and
+    non-4:3 frames inside the kernel envelope (W % 8 == 0, W < 192, W*H <= 20480) against the oracle, pixel stage and
+    association."""
+    import track_oracle as to
+    from cpx import synth
+    from cpx.engine import TrackEngine
+
+    n_clips, T = 3, 70
+    frames, offs = synth.make_batch(n_clips, T, seed=W * 1000 + H, h=H, w=W)
+    eng = TrackEngine(width=W, height=H, model="lepton3", max_frames=T)
+    meta = np.concatenate([eng.make_meta(T) for _ in range(n_clips)])
+    res = eng.track_batch(eng.upload_frames(frames), offs, meta, want_labels=True, want_filtered=True,
+                          want_background=True)
+    res.check()
+    assoc = eng.associate_batch(res, offs, meta)
+    assoc.check()
+    ncomp = ntracks = 0
+    for b in range(n_clips):
+        clip = frames[offs[b]:offs[b + 1]]
+        out = to.track_clip(clip, None, None, None, to.OracleConfig("lepton3"), keep=True, apply_filter=False)
+        _compare_with_oracle(res, int(offs[b]), out, T)
+        assert np.array_equal(res.background()[b].astype(np.int32), out["frames"][-1]["bg_after"])
+        ncomp += sum(f["n_components"] for f in out["frames"])
+        got = assoc.clip_tracks(b)
+        assert [int(r["id"]) for r, _ in got] == [t.id for t in out["tracks"]]
+        for (rec, regs), t in zip(got, out["tracks"]):
+            assert int(rec["start_frame"]) == t.start_frame and len(regs) == len(t.bounds)
+            for r, o in zip(regs, t.bounds):
+                assert (r["x"], r["y"], r["width"], r["height"], r["mass"], r["frame_number"]) == (
+                    o.x, o.y, o.width, o.height, int(o.mass), o.frame_number)
+                assert bool(r["flags"] & 1) == bool(o.blank)
+        ntracks += len(got)
+    assert ncomp > 0
+    eng.close()
