@@ -81,7 +81,7 @@ def synth_on_device(torch, device, n_clips, n_frames, seed, h=120, w=160, chunk=
     return out
 
 
-def cpu_baseline(stage, n_clips, n_frames, seed, weights):
+def cpu_baseline(stage, n_clips, n_frames, seed, weights, frame_size=32):
     """The oracle chain (single core) over a bounded sample of the same workload."""
     import numpy as np
     import torch
@@ -115,7 +115,7 @@ def cpu_baseline(stage, n_clips, n_frames, seed, weights):
                 segs.append(np.array([run[(j * len(run)) // 25] for j in range(25)]))
             by_frame = {r.frame_number: r for r in t.bounds}
             x, _ = co.preprocess_segments(lambda q: clip[q], lambda q: fr[q]["filtered"].astype(np.float64), by_frame,
-                                          t.bounds, segs, 32, (1, 1, W - 2, H - 2))
+                                          t.bounds, segs, frame_size, (1, 1, W - 2, H - 2))
             _, probs = cnn.forward(weights, x)
             co.classified_track(probs, prediction_frames=segs)
             n_samples += nseg
@@ -155,6 +155,8 @@ def main():
                     help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only")
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cnn-chunk", type=int, default=512, help="samples per CNN forward")
+    ap.add_argument("--frame-size", type=int, default=32, choices=(32, 64),
+                    help="side of one tile of the 5x5 network input (SURVEY 8(d) config 3 asks for 32 and 64)")
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="groups of clips per step: the track stage of group k+1 is issued on a second stream beside the "
                          "network of group k (measured: no gain on MI355X, see DESIGN.md section 6; 1 = off)")
@@ -215,7 +217,7 @@ def main():
     overlap = e2e and args.sub_batches > 1
     ceng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_frames=45) if overlap else eng
     net = wr.WRResNetDevice(ceng, weights, N_LABELS) if e2e else None
-    pipe = BatchPipeline(eng, net, n_labels=N_LABELS, fp_index=4, cnn_chunk=args.cnn_chunk)
+    pipe = BatchPipeline(eng, net, n_labels=N_LABELS, fp_index=4, cnn_chunk=args.cnn_chunk, frame_size=args.frame_size)
     state = {}
 
     def step():
@@ -304,13 +306,14 @@ def main():
         if e2e:
             r = state["res"]
             line["config"].update({"kept_tracks_per_step": int(r.n_tracks), "classified_segments_per_step": int(r.n_samples),
-                                   "frame_size": 32, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk,
+                                   "frame_size": args.frame_size, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk,
                                    "sub_batches": args.sub_batches})
             key = 32 * 10000 + 32 * 10 + 1  # conv_mfma_kernel<KC=8,NTN=1,S=1,KS=3,NTM=2>: the stage-2 3x3 convolutions
             if key in conv and conv[key][1] > 0:
                 n, ms, fl = conv[key]
                 tf = fl / (ms / 1e3) / 1e12
-                line["roofline"] = {"kernel": "conv_mfma_kernel<8,1,1,3,2> (stage-2 3x3 conv, 64->64 ch, groups 2, 160x160)",
+                line["roofline"] = {"kernel": "conv_mfma_kernel<8,1,1,3,2> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)"
+                                              % (5 * args.frame_size, 5 * args.frame_size),
                                     "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                                     "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                                     "traffic": pmc_traffic("conv_stage2", fl / n / STAGE2_CONV_FLOPS_PER_SAMPLE),
@@ -329,7 +332,7 @@ def main():
             line["roofline"] = track_roof
         ncpu = args.cpu_clips if args.cpu_clips >= 0 else (20 if e2e else 16)  # ~15 s of single-core work
         if world == 1 and ncpu > 0:
-            line["cpu_baseline"] = cpu_baseline(args.stage, ncpu, T, 1234, weights)
+            line["cpu_baseline"] = cpu_baseline(args.stage, ncpu, T, 1234, weights, args.frame_size)
         print(json.dumps(line))
     eng.close()
     if dist is not None:
