@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def avg(dirname, counter, kernel_sub, grid=None):
-    path = glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*_counter_collection.csv"))[0]
+    path = max(glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*_counter_collection.csv")),
+               key=os.path.getmtime)  # the newest pass (gpurun merges outputs, older passes stay around)
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
             if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]
             and (grid is None or int(r["Grid_Size"]) == grid)]
