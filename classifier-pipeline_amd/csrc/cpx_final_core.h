@@ -46,19 +46,34 @@ CPX_HD inline T np_sum(const T* a, int n) {
   return np_pairwise(a, n);
 }
 
-CPX_HD inline void insertion_sort(double* a, int n) {
-  for (int i = 1; i < n; ++i) {
-    const double v = a[i];
-    int j = i - 1;
-    while (j >= 0 && a[j] > v) {
-      a[j + 1] = a[j];
-      --j;
+// np.median without the full sort: quickselect of the upper middle element (reorders `a`), then the largest
+// element below it for even n.  Same value as sorting: the two middle order statistics are what they are.
+CPX_HD inline double np_median_select(double* a, int n) {
+  const int k = n >> 1;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const double pivot = a[(lo + hi) >> 1];
+    int i = lo, j = hi;
+    while (i <= j) {
+      while (a[i] < pivot) ++i;
+      while (a[j] > pivot) --j;
+      if (i <= j) {
+        const double tmp = a[i];
+        a[i] = a[j];
+        a[j] = tmp;
+        ++i;
+        --j;
+      }
     }
-    a[j + 1] = v;
+    if (k <= j) hi = j;
+    else if (k >= i) lo = i;
+    else break;
   }
-}
-CPX_HD inline double np_median_sorted(const double* a, int n) {
-  return (n & 1) ? a[n / 2] : (a[n / 2 - 1] + a[n / 2]) / 2.0;
+  const double upper = a[k];
+  if (n & 1) return upper;
+  double lower = a[0];
+  for (int i = 1; i < k; ++i) lower = a[i] > lower ? a[i] : lower;
+  return (lower + upper) / 2.0;
 }
 
 struct FinalScratch {
@@ -97,8 +112,7 @@ CPX_HD inline void finalize_track(const cpx_filter_params& fp, const RegionRec* 
   // ---- trim (track.py:873-905) ----
   int n = t.n_frames;
   for (int i = 0; i < n; ++i) sc.d[i] = (double)treg(pool, ma, t, i).mass;
-  insertion_sort(sc.d, n);
-  const double median_all = np_median_sorted(sc.d, n);
+  const double median_all = np_median_select(sc.d, n);
   double filter_mass = 0.005 * median_all;
   if (!(filter_mass > 2.0)) filter_mass = 2.0;  // max(filter_mass, 2)
   int start = 0;
@@ -187,12 +201,11 @@ CPX_HD inline void finalize_track(const cpx_filter_params& fp, const RegionRec* 
       dev2[i] = d * d;
     }
     const double mstd = sqrt(np_sum(dev2, n_seen) / (double)n_seen);
-    insertion_sort(sc.d, n_seen);
     t.movement = movement;
     t.max_offset = max_offset;
     t.score = score;
     t.average_mass = mmean;
-    t.median_mass = np_median_sorted(sc.d, n_seen);
+    t.median_mass = np_median_select(sc.d, n_seen);
     t.delta_std = delta_std;
     t.mass_std = mstd;
     t.average_velocity = avg_vel;
