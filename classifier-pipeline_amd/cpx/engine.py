@@ -417,12 +417,13 @@ class TrackEngine:
             C.c_void_p(offs_dev.data_ptr()), n_tracks, C.c_void_p(limits_dev.data_ptr()))
         if rc != 0:
             raise CpxError(rc, self._err())
-        rc = self.lib.cpx_crop_tile(
-            self.h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(track_result.filtered_dev.data_ptr()),
-            C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(reqs_dev.data_ptr()), int(reqs.size),
-            C.c_void_p(limits_dev.data_ptr()), frame_size, square_width, C.c_void_p(out.data_ptr()))
-        if rc != 0:
-            raise CpxError(rc, self._err())
+        if reqs.size:  # limits only when there is nothing to crop
+            rc = self.lib.cpx_crop_tile(
+                self.h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(track_result.filtered_dev.data_ptr()),
+                C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(reqs_dev.data_ptr()), int(reqs.size),
+                C.c_void_p(limits_dev.data_ptr()), frame_size, square_width, C.c_void_p(out.data_ptr()))
+            if rc != 0:
+                raise CpxError(rc, self._err())
         self.synchronize()
         limits = limits_dev.cpu().numpy().view(TRACK_LIMITS_DTYPE).reshape(-1)[:n_tracks]
         return out, limits

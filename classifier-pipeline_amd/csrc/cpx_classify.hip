@@ -77,73 +77,79 @@ __device__ __forceinline__ u32 block_sum_u32(u32 v, u32* sc) {
 // get_limits + the clip_thermals_at_zero test, one workgroup per track
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
-  __shared__ float sc[LW];
-  __shared__ u32 scu[LW];
+  // the track's regions are dealt to the workgroup's waves; a wave handles a region with shuffles only (no
+  // workgroup barrier inside the per-region median bisection), the waves meet once at the end
+  __shared__ float s_mn[LW], s_mx[LW];
+  __shared__ int s_clip[LW];
   const int t = blockIdx.x;
   const int r0 = a.track_offsets[t], r1 = a.track_offsets[t + 1];
   const int W = a.W, P = a.W * a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float mn = INFINITY, mx = 0.0f;  // max_diff starts at 0, min_diff at None (interpreter.py:316-317)
   int clip0 = 1;
-  for (int r = r0; r < r1; ++r) {
+  for (int r = r0 + wave; r < r1; r += LW) {
     const cpx_region_ref ref = a.refs[r];
     if (ref.width <= 0 || ref.height <= 0) continue;
     const int n = ref.width * ref.height;
     const float* F = a.filtered + (size_t)ref.frame * P;
-    float lmn = INFINITY, lmx = -INFINITY;
-    for (int k = threadIdx.x; k < n; k += LT) {
+    for (int k = lane; k < n; k += 64) {
       const int yy = k / ref.width;
       const float v = F[(ref.y + yy) * W + ref.x + (k - yy * ref.width)];
-      lmn = fminf(lmn, v);
-      lmx = fmaxf(lmx, v);
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
     }
-    mn = fminf(mn, lmn);
-    mx = fmaxf(mx, lmx);
     if (ref.in_segment && clip0) {
-      // np.median(float32(crop) - median) <= 0  <=>  lower + upper middle order statistics <= 2 * median
+      // np.median(float32(crop) - median) <= 0  <=>  a + b <= M, with a <= b the two middle order statistics of
+      // the crop (a == b for an odd count) and M = 2 * median (an integer: the frame median is k/2).  One counting
+      // pass decides it: with t = floor(M / 2) and c = #{v <= t},
+      //   c >= k2 + 1        -> b <= t          -> a + b <= 2t <= M           -> true
+      //   c <= k1            -> a >= t + 1      -> a + b >= 2t + 2 > M        -> false
+      //   otherwise (even n) -> a <= t < b, a = max{v <= t}, b = min{v > t}   -> compare a + b with M
+      // (all values are integers below 2^17, so the reference's float32 evaluation has the same sign)
       const uint16_t* T = a.frames + (size_t)ref.frame * P;
-      u32 vmin = 0xFFFFFFFFu, vmax = 0;
-      for (int k = threadIdx.x; k < n; k += LT) {
-        const int yy = k / ref.width;
-        const u32 v = T[(ref.y + yy) * W + ref.x + (k - yy * ref.width)];
-        vmin = min(vmin, v);
-        vmax = max(vmax, v);
-      }
-      u32 lo = (u32)block_min((float)vmin, sc), hi = (u32)block_max((float)vmax, sc);  // u16 values: exact in float
       const u32 k1 = (u32)((n - 1) >> 1), k2 = (u32)(n >> 1);
-      while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        u32 cnt = 0;
-        for (int k = threadIdx.x; k < n; k += LT) {
-          const int yy = k / ref.width;
-          cnt += (u32)T[(ref.y + yy) * W + ref.x + (k - yy * ref.width)] <= mid;
-        }
-        cnt = block_sum_u32(cnt, scu);
-        if (cnt >= k1 + 1) hi = mid;
-        else lo = mid + 1;
-      }
-      u32 cnt = 0, nxt = 0xFFFFFFFFu;
-      for (int k = threadIdx.x; k < n; k += LT) {
+      const u32 M = (u32)(2.0f * a.info[ref.frame].thermal_median);
+      const u32 tt = M >> 1;
+      u32 c = 0, lowmax = 0, highmin = 0xFFFFFFFFu;
+      for (int k = lane; k < n; k += 64) {
         const int yy = k / ref.width;
         const u32 v = T[(ref.y + yy) * W + ref.x + (k - yy * ref.width)];
-        cnt += v <= lo;
-        nxt = (v > lo && v < nxt) ? v : nxt;
+        if (v <= tt) {
+          ++c;
+          lowmax = max(lowmax, v);
+        } else {
+          highmin = min(highmin, v);
+        }
       }
-      cnt = block_sum_u32(cnt, scu);
-      const float nx = block_min(nxt == 0xFFFFFFFFu ? 1e9f : (float)nxt, sc);
-      const float v2 = (cnt >= k2 + 1) ? (float)lo : nx;
-      const float med = a.info[ref.frame].thermal_median;
-      // ((lo - med) + (v2 - med)) / 2 <= 0 in float32 (differences of a u16 and a k/2 value are exact)
-      const float m2 = __fmul_rn(__fadd_rn(__fsub_rn((float)lo, med), __fsub_rn(v2, med)), 0.5f);
+      c = wsum(c);
+      bool le;
+      if (c >= k2 + 1) le = true;
+      else if (c <= k1) le = false;
+      else le = wmax(lowmax) + wmin(highmin) <= M;
+      const float m2 = le ? 0.0f : 1.0f;
       if (m2 <= 0.0f) clip0 = 0;
     }
   }
-  mn = block_min(mn, sc);
-  mx = block_max(mx, sc);
+  mn = wmin(mn);
+  mx = wmax(mx);
+  if (lane == 0) {
+    s_mn[wave] = mn;
+    s_mx[wave] = mx;
+    s_clip[wave] = clip0;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     cpx_track_limits o;
-    o.filt_min = mn;
-    o.filt_max = mx;
-    o.clip_at_zero = clip0;
+    float fmn = s_mn[0], fmx = s_mx[0];
+    int c0 = s_clip[0];
+    for (int w = 1; w < LW; ++w) {
+      fmn = fminf(fmn, s_mn[w]);
+      fmx = fmaxf(fmx, s_mx[w]);
+      c0 &= s_clip[w];
+    }
+    o.filt_min = fmn;
+    o.filt_max = fmx;
+    o.clip_at_zero = c0;
     o.reserved = 0;
     a.limits[t] = o;
   }

@@ -131,3 +131,60 @@ def test_crop_tile_matches_oracle_on_synthetic_tracks(engine):
         got = x[s0:s0 + want.shape[0]]
         assert np.array_equal(got, want), float(np.abs(got - want).max())
         s0 += want.shape[0]
+
+
+def test_limits_and_clip_at_zero_on_crafted_crops(engine):
+    """cpx_track_limits_batch on crafted frames: per 'track' one in-segment region whose crop median sits below, at,
+    just above (by 0.5) and above the frame median, odd and even pixel counts, and the straddling case where the two
+    middle order statistics fall on both sides of the frame median.  Expectation: NumPy, as the reference evaluates
+    it (interpreter.py:372-399: np.median(float32(crop) - np.median(frame)) <= 0 turns clipping off)."""
+    from cpx._lib import CROP_REQ_DTYPE, REGION_REF_DTYPE
+
+    rng = np.random.default_rng(99)
+    H, W = 120, 160
+    cases = []
+    frames = []
+    for trial in range(60):
+        f = rng.integers(2950, 3050, (H, W)).astype(np.uint16)
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        med = np.median(f)
+        kind = trial % 6
+        crop = f[y:y + h, x:x + w]
+        n = w * h
+        if kind == 0:      # clearly above
+            crop += 40
+        elif kind == 1:    # clearly below
+            crop -= 40
+        elif kind == 2:    # constant crop exactly at floor(median)
+            crop[:] = int(np.floor(med))
+        elif kind == 3:    # constant crop one above floor(median)
+            crop[:] = int(np.floor(med)) + 1
+        elif kind == 4 and n >= 2:  # half low, half high around the median: straddle (even n) or decided by the middle
+            flat = np.empty(n, np.uint16)
+            flat[: n // 2] = int(np.floor(med)) - int(rng.integers(0, 3))
+            flat[n // 2:] = int(np.floor(med)) + int(rng.integers(0, 4))
+            crop[:] = rng.permutation(flat).reshape(h, w)
+        frames.append(f)
+        cases.append((x, y, w, h))
+    frames = np.stack(frames)
+    n = len(cases)
+    dev = engine.upload_frames(frames)
+    res = engine.track_batch(dev, np.arange(n + 1, dtype=np.int32), engine.make_meta(n), want_filtered=True)
+    res.check()
+    filt = res.filtered()
+    refs = np.zeros(n, REGION_REF_DTYPE)
+    for i, (x, y, w, h) in enumerate(cases):
+        refs[i] = (i, x, y, w, h, 1)
+    reqs = np.zeros(0, CROP_REQ_DTYPE)
+    _, limits = engine.preprocess_segments(dev, res, refs, np.arange(n + 1, dtype=np.int32), reqs, 0)
+    seen = set()
+    for i, (x, y, w, h) in enumerate(cases):
+        th = frames[i]
+        sub = np.float32(th[y:y + h, x:x + w]) - np.median(th)
+        want_clip = 0 if np.median(sub) <= 0 else 1
+        assert limits[i]["clip_at_zero"] == want_clip, (i, cases[i], float(np.median(sub)))
+        fsub = filt[i][y:y + h, x:x + w]
+        assert limits[i]["filt_min"] == fsub.min() and limits[i]["filt_max"] == max(0.0, float(fsub.max()))
+        seen.add((want_clip, float(np.median(sub)) == 0.0, (w * h) % 2))
+    assert {s[0] for s in seen} == {0, 1} and any(s[1] for s in seen)
