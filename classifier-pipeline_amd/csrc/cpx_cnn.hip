@@ -38,6 +38,9 @@
 #ifndef CPX_CONV_NTM_S4
 #define CPX_CONV_NTM_S4 1
 #endif
+#ifndef CPX_CONV_TW_S4
+#define CPX_CONV_TW_S4 32  // band width of the layers that produce the 27 x 27 maps
+#endif
 
 namespace cpx {
 
@@ -48,11 +51,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ bool v_keep(float x) { return x == 1.2345e-30f; }  // never true: no stores, no residual loads
 #endif
 
-constexpr int TB = 8, TW = 16;  // a band of output pixels: 8 rows x 16; wave w owns rows 2w, 2w+1 of every band
+// a band of output pixels is 128 pixels = 4 waves x 32: TW columns x TB = 128 / TW rows, wave w owns the rows
+// [w * 32 / TW, (w + 1) * 32 / TW) of every band.  TW = 16 (8 x 16 bands) everywhere except the 27 x 27 maps of
+// stage 4, where 4 x 32 bands waste 19 % of the tile pixels instead of 29 %
 constexpr int CT = 256;
 
-template <int KC, int NTN, int S, int KS, int NTM>
+template <int KC, int NTN, int S, int KS, int NTM, int TW>
 __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int TB = 128 / TW;        // rows of a band
+  constexpr int WR = 32 / TW;         // rows of a wave's 32-pixel tile
   constexpr int TH = TB * NTM;        // output tile of a workgroup: NTM bands
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr int KP = KC + 1;          // padded channel stride of a patch pixel (bank spread)
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
 
   // this lane's pixel inside the wave tile and its k half
   const int pi = lane & 31, kh = lane >> 5;
-  const int prow = 2 * wave + (pi >> 4), pcol = pi & 15;
+  const int prow = WR * wave + pi / TW, pcol = pi % TW;
   const int a_base = ((prow * S) * PW + pcol * S) * KP + kh;
   const int b_base = kh * COG + (lane & 31);
 
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
       for (int it = 0; it < 4; ++it) {
         const int f = it * 64 + lane;         // float4 index inside the tile
         const int i = f >> 3, c4 = f & 7;
-        const int oy = oy0 + m * TB + 2 * wave + (i >> 4), ox = ox0 + (i & 15);
+        const int oy = oy0 + m * TB + WR * wave + i / TW, ox = ox0 + i % TW;
 #ifdef CPX_CONV_ABLATE_STORE
         if (oy < a.Ho && ox < a.Wo && v_keep(s_tile[i * 32 + 4 * c4])) {
 #else
@@ -362,21 +369,22 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   }
 }
 
-template <int KC, int NTN, int S, int KS, int NTM>
+template <int KC, int NTN, int S, int KS, int NTM, int TW>
 static int launch_conv_t(const ConvArgs& a, hipStream_t s) {
+  constexpr int TB = 128 / TW;
   constexpr int TH = TB * NTM;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   size_t lds = (((size_t)PH * PW * (KC + 1) + 3) / 4 * 4 + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
   if (lds < 4 * 32 * 32 * sizeof(float)) lds = 4 * 32 * 32 * sizeof(float);  // epilogue tiles
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS, NTM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS, NTM, TW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
       return -1;
     configured = true;
   }
   const int tiles = ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
-  hipLaunchKernelGGL((conv_mfma_kernel<KC, NTN, S, KS, NTM>), dim3(tiles * a.N, a.groups), dim3(CT), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<KC, NTN, S, KS, NTM, TW>), dim3(tiles * a.N, a.groups), dim3(CT), lds, s, a);
   return 0;
 }
 
@@ -398,18 +406,18 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(conv_direct_kernel, dim3(blocks), dim3(256), 0, s, a);
     return 0;
   }
-#define CPX_CONV_CASE(KC, NTN, S, KS, NTM)                                                   \
+#define CPX_CONV_CASE(KC, NTN, S, KS, NTM, TW)                                               \
   if (cout_g == 32 * NTN && a.stride == S && a.ksize == KS && (cin_g % KC) == 0 && cin_g >= KC) \
-    return launch_conv_t<KC, NTN, S, KS, NTM>(a, s);
+    return launch_conv_t<KC, NTN, S, KS, NTM, TW>(a, s);
   // (channels per group, stride, kernel) combinations of WR-ResNet-22-4 with groups = 2
-  if (cin_g == 8) { CPX_CONV_CASE(8, 1, 1, 3, 1) CPX_CONV_CASE(8, 1, 1, 1, 1) }
-  CPX_CONV_CASE(CPX_CONV_KC_S2, 1, 1, 3, CPX_CONV_NTM_S2)
-  CPX_CONV_CASE(8, 2, 2, 3, 1)
-  CPX_CONV_CASE(16, 2, 2, 1, 1)
-  CPX_CONV_CASE(CPX_CONV_KC_S3, 2, 1, 3, CPX_CONV_NTM_S3)
-  CPX_CONV_CASE(8, 4, 3, 3, 1)
-  CPX_CONV_CASE(8, 4, 3, 1, 1)
-  CPX_CONV_CASE(CPX_CONV_KC_S4, 4, 1, 3, CPX_CONV_NTM_S4)
+  if (cin_g == 8) { CPX_CONV_CASE(8, 1, 1, 3, 1, 16) CPX_CONV_CASE(8, 1, 1, 1, 1, 16) }
+  CPX_CONV_CASE(CPX_CONV_KC_S2, 1, 1, 3, CPX_CONV_NTM_S2, 16)
+  CPX_CONV_CASE(8, 2, 2, 3, 1, 16)
+  CPX_CONV_CASE(16, 2, 2, 1, 1, 16)
+  CPX_CONV_CASE(CPX_CONV_KC_S3, 2, 1, 3, CPX_CONV_NTM_S3, 16)
+  CPX_CONV_CASE(8, 4, 3, 3, 1, CPX_CONV_TW_S4)
+  CPX_CONV_CASE(8, 4, 3, 1, 1, CPX_CONV_TW_S4)
+  CPX_CONV_CASE(CPX_CONV_KC_S4, 4, 1, 3, CPX_CONV_NTM_S4, CPX_CONV_TW_S4)
 #undef CPX_CONV_CASE
   return -2;
 }
