@@ -97,7 +97,7 @@ WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
   WsLayout l{};
   size_t off = 0;
   l.bg = off;
-  off = align_up(off + (size_t)B * 2 * P * sizeof(int32_t), 256);
+  off = align_up(off + (size_t)B * 2 * P * sizeof(uint16_t), 256);
   l.wsum = off;
   off = align_up(off + (size_t)B * P * sizeof(uint32_t), 256);
   l.kcnt = off;
@@ -321,7 +321,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.proc_ffc = h->sched_dev + B + (B + 1) + std::max(nproc_total, 1);
   a.wtab = h->wtab_dev;
   char* base = (char*)h->ws;
-  a.bg = (int32_t*)(base + l.bg);
+  a.bg = (uint16_t*)(base + l.bg);
   a.wsum = (uint32_t*)(base + l.wsum);
   a.kcnt = (uint16_t*)(base + l.kcnt);
   a.filt_state = need_filt ? (float*)(base + l.filt) : nullptr;

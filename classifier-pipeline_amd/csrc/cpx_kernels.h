@@ -68,7 +68,8 @@ struct TrackArgs {
   const int* proc_ffc;      // [total_proc] is_affected_by_ffc
   const double* wtab;       // [max_frames+2] k-fold float64 accumulation of weight_add
   // per-clip state
-  int32_t* bg;              // [B][2][P] ping-pong background (interior authoritative)
+  uint16_t* bg;             // [B][2][P] ping-pong background (interior authoritative); the background is a
+                            // floor of a mean of uint16 frames, so 16 bits hold it exactly
   uint32_t* wsum;           // [B][P] sum of the last <= window frames
   uint16_t* kcnt;           // [B][P] consecutive "background kept" count -> weight = wtab[k]
   float* filt_state;        // [B][2][P] ping-pong filtered (only when filtered_out == nullptr)

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a) {
   const int b = blockIdx.x;
   const int W = a.W, H = a.H, P = W * H, e = a.edge;
   const uint16_t* F = a.frames + (size_t)a.clip_first[b] * P;
-  int32_t* bg0 = a.bg + (size_t)b * 2 * P;
+  uint16_t* bg0 = a.bg + (size_t)b * 2 * P;
   u32* ws = a.wsum + (size_t)b * P;
   uint16_t* kc = a.kcnt + (size_t)b * P;
   u64 s = 0;
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a) {
     int y = p / W, x = p - y * W;
     int cy = clampi(y, e, H - 1 - e), cx = clampi(x, e, W - 1 - e);
     int v = F[cy * W + cx];
-    bg0[p] = v;
-    bg0[P + p] = v;
+    bg0[p] = (uint16_t)v;
+    bg0[P + p] = (uint16_t)v;
     ws[p] = 0;
     kc[p] = 0;
     if (cy == y && cx == x) s += (u64)v;
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   const u64 div_magic = ((1ull << 40) + (u64)nwin - 1ull) / (u64)nwin;
   const uint16_t* F = a.frames + (size_t)fidx * P;
   const uint16_t* O = (oidx >= 0) ? a.frames + (size_t)oidx * P : nullptr;
-  const int32_t* bg_old = a.bg + ((size_t)b * 2 + (t & 1)) * P;
-  int32_t* bg_new = a.bg + ((size_t)b * 2 + ((t + 1) & 1)) * P;
+  const uint16_t* bg_old = a.bg + ((size_t)b * 2 + (t & 1)) * P;
+  uint16_t* bg_new = a.bg + ((size_t)b * 2 + ((t + 1) & 1)) * P;
   u32* ws = a.wsum + (size_t)b * P;
   uint16_t* kc = a.kcnt + (size_t)b * P;
   float* filt_cur;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       const int cy = clampi(y, e, H - 1 - e);
       const bool row_in = (cy == y);
       if (row_in && x0 >= e && x0 + 3 <= W - 1 - e) {
-        const int4 q = *reinterpret_cast<const int4*>(bg_old + p0);
+        const ushort4 q = *reinterpret_cast<const ushort4*>(bg_old + p0);
         bgv[0] = q.x; bgv[1] = q.y; bgv[2] = q.z; bgv[3] = q.w;
       } else {
 #pragma unroll
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       *reinterpret_cast<u32*>(s_u8 + p0) = xhi[0] | (xhi[1] << 8) | (xhi[2] << 16) | (xhi[3] << 24);
       *reinterpret_cast<float4*>(filt_cur + p0) = make_float4(fo[0], fo[1], fo[2], fo[3]);
       *reinterpret_cast<uint4*>(ws + p0) = make_uint4(wsv[0], wsv[1], wsv[2], wsv[3]);
-      *reinterpret_cast<int4*>(bg_new + p0) = make_int4(nb[0], nb[1], nb[2], nb[3]);
+      *reinterpret_cast<ushort4*>(bg_new + p0) =
+          make_ushort4((unsigned short)nb[0], (unsigned short)nb[1], (unsigned short)nb[2], (unsigned short)nb[3]);
       *reinterpret_cast<ushort4*>(kc + p0) =
           make_ushort4((unsigned short)kv[0], (unsigned short)kv[1], (unsigned short)kv[2], (unsigned short)kv[3]);
     }
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(256) void cpx_export_background_kernel(TrackArgs a,
   const int b = blockIdx.x;
   const int W = a.W, H = a.H, P = W * H, e = a.edge;
   const int nproc = a.proc_off[b + 1] - a.proc_off[b];
-  const int32_t* bg = a.bg + ((size_t)b * 2 + (nproc & 1)) * P;
+  const uint16_t* bg = a.bg + ((size_t)b * 2 + (nproc & 1)) * P;
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     int y = p / W, x = p - y * W;
     out[(size_t)b * P + p] = (float)bg[clampi(y, e, H - 1 - e) * W + clampi(x, e, W - 1 - e)];
