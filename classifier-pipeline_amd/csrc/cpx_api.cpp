@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,10 @@ struct cpx_handle {
   int last_launches = 0;
   bool timing_valid = false;
   // incremental (one clip, frame by frame) tracking: frames consumed so far, -1 = no stream open
+  // pipelined split of the frame step: back halves run on stream2 one step behind the front halves
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+  int split_min_clips = 0;  // 0 = never split
   std::vector<struct cpx_cnn*> cnns;  // networks created on this handle (destroyed with it)
   int stream_frames = -1;
   int stream_assoc_frames = -1;
@@ -89,7 +94,7 @@ int fail(cpx_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t bg, wsum, kcnt, filt, cstate, u8, carry, total;
+  size_t bg, wsum, kcnt, filt, cstate, u8, carry, bgavg, total;
 };
 
 WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
@@ -106,10 +111,13 @@ WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
   if (need_filt_state) off = align_up(off + (size_t)B * 2 * P * sizeof(float), 256);
   l.cstate = off;
   off = align_up(off + (size_t)B * sizeof(cpx::ClipState), 256);
+  // hand-over buffers of split frame steps (front -> NLM -> back, or front || back pipelined): two slots per clip
   l.u8 = off;
-  if (c.denoise) off = align_up(off + (size_t)B * P, 256);
+  off = align_up(off + (size_t)B * 2 * P, 256);
   l.carry = off;
-  if (c.denoise) off = align_up(off + (size_t)B * sizeof(cpx::FrameCarry), 256);
+  off = align_up(off + (size_t)B * 2 * sizeof(cpx::FrameCarry), 256);
+  l.bgavg = off;
+  off = align_up(off + (size_t)B * sizeof(double), 256);
   l.total = off;
   return l;
 }
@@ -191,8 +199,13 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   h->device = device_id;
   h->cfg = *cfg;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_front[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_front[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_back[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_back[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
-    delete h;
+    cpx_destroy(h);
     return CPX_ERR_HIP;
   }
   // weight table: w_k = k-fold float64 accumulation of weight_add, exactly as
@@ -230,6 +243,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     cpx_destroy(h);
     return CPX_ERR_HIP;
   }
+  if (const char* env = std::getenv("CPX_TRACK_SPLIT_MIN_CLIPS")) h->split_min_clips = std::atoi(env);
   *out = h;
   return CPX_OK;
 }
@@ -248,6 +262,14 @@ void cpx_destroy(cpx_handle* h) {
   for (auto& e : h->conv_events) {
     hipEventDestroy(e.e0);
     hipEventDestroy(e.e1);
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_front[i]) hipEventDestroy(h->ev_front[i]);
+    if (h->ev_back[i]) hipEventDestroy(h->ev_back[i]);
+  }
+  if (h->stream2) {
+    hipStreamSynchronize(h->stream2);
+    hipStreamDestroy(h->stream2);
   }
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -326,8 +348,9 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.kcnt = (uint16_t*)(base + l.kcnt);
   a.filt_state = need_filt ? (float*)(base + l.filt) : nullptr;
   a.cstate = (cpx::ClipState*)(base + l.cstate);
-  a.u8_state = c.denoise ? (unsigned char*)(base + l.u8) : nullptr;
-  a.carry = c.denoise ? (cpx::FrameCarry*)(base + l.carry) : nullptr;
+  a.u8_state = (unsigned char*)(base + l.u8);
+  a.carry = (cpx::FrameCarry*)(base + l.carry);
+  a.bgavg = (double*)(base + l.bgavg);
   a.nlm_lut = h->nlm_lut_dev;
   a.comps_out = comps_dev;
   a.info_out = info_dev;
@@ -339,14 +362,30 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   CPX_HIP(h, hipMemsetAsync(info_dev + f_new, 0xFF, (size_t)(total - f_new) * sizeof(cpx_frame_info), h->stream));
   if (!resume) cpx::launch_init(a, B, h->stream);
   CPX_HIP(h, hipEventRecord(h->ev0, h->stream));
+  // (with the internal ping-pong of filtered frames the back half of step t would read what the front half of
+  // step t+1 overwrites: split only when the caller keeps every filtered frame)
+  const bool split = !c.denoise && !need_filt && h->split_min_clips > 0 && B >= h->split_min_clips &&
+                     max_proc - t_begin > 2;
   for (int t = t_begin; t < max_proc; ++t) {
-    if (!c.denoise) {
+    if (split) {
+      // front(t) reuses the hand-over slot that back(t - 2) read
+      if (t - t_begin >= 2) CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_back[t & 1], 0));
+      cpx::launch_frame(a, B, t, 1, h->stream);
+      CPX_HIP(h, hipEventRecord(h->ev_front[t & 1], h->stream));
+      CPX_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_front[t & 1], 0));
+      cpx::launch_frame(a, B, t, 2, h->stream2);
+      CPX_HIP(h, hipEventRecord(h->ev_back[t & 1], h->stream2));
+    } else if (!c.denoise) {
       cpx::launch_frame(a, B, t, 0, h->stream);
     } else {  // front (normalise) -> non-local means -> back (blur / threshold / label / statistics)
       cpx::launch_frame(a, B, t, 1, h->stream);
       cpx::launch_nlm(a, B, t, h->stream);
       cpx::launch_frame(a, B, t, 2, h->stream);
     }
+  }
+  if (split) {  // everything enqueued later on the handle's stream sees the last back halves
+    CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_back[(max_proc - 1) & 1], 0));
+    if (max_proc - t_begin >= 2) CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_back[(max_proc - 2) & 1], 0));
   }
   CPX_HIP(h, hipEventRecord(h->ev1, h->stream));
   h->last_launches = max_proc - t_begin;

@@ -48,11 +48,12 @@ struct Red1 {
 };
 
 // scalars that cross the front / back split of a frame step (denoise)
-struct FrameCarry {
+struct FrameCarry {  // front half -> (NLM ->) back half of a split frame step; two slots per clip (t & 1)
   Red1 R;
   int avg_change, mn, mx, ithr;
   float thresh, median;
   int pad;
+  double bg_avg_in;  // background average the front half started from
 };
 
 struct TrackArgs {
@@ -68,6 +69,7 @@ struct TrackArgs {
   const int* proc_ffc;      // [total_proc] is_affected_by_ffc
   const double* wtab;       // [max_frames+2] k-fold float64 accumulation of weight_add
   // per-clip state
+  double* bgavg;            // [B] background average after the last front half (split steps only)
   uint16_t* bg;             // [B][2][P] ping-pong background (interior authoritative); the background is a
                             // floor of a mean of uint16 frames, so 16 bits hold it exactly
   uint32_t* wsum;           // [B][P] sum of the last <= window frames

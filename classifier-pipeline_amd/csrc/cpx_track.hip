@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a) {
     st.has_prev = 0;
     st.pad = 0;
     a.cstate[b] = st;
+    if (a.bgavg) a.bgavg[b] = st.bg_average;
   }
 }
 
@@ -216,7 +217,11 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     filt_cur = a.filt_state + ((size_t)b * 2 + (t & 1)) * P;
     filt_prev = a.filt_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
   }
-  const ClipState cs = a.cstate[b];
+  ClipState cs = a.cstate[b];
+  // split steps: the front half of step t+1 may run while the back half of step t has not yet written the clip
+  // state, so the background average travels front -> front (a.bgavg) and front -> back (the carry)
+  const int slot = t & 1;
+  if (mode == 1) cs.bg_average = a.bgavg[b];
 
   int avg_change = 0, mn = 0, mx = 0, ithr = 0;
   float thresh = 0.0f;
@@ -504,7 +509,8 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   __syncthreads();
   } else {
     // ---- back half of a split step: scalars from the carry, the (denoised) uint8 image from HBM ----
-    const FrameCarry fc = a.carry[b];
+    const FrameCarry fc = a.carry[(size_t)b * 2 + slot];
+    cs.bg_average = fc.bg_avg_in;
     avg_change = fc.avg_change;
     mn = fc.mn;
     mx = fc.mx;
@@ -515,14 +521,14 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       reinterpret_cast<float*>(s_bc)[2] = fc.median;
       *s_ncomp_p = 0;
     }
-    const uint4* src = reinterpret_cast<const uint4*>(a.u8_state + (size_t)b * P);
+    const uint4* src = reinterpret_cast<const uint4*>(a.u8_state + ((size_t)b * 2 + slot) * P);
     for (int i = tid; i < (P >> 4); i += NT) reinterpret_cast<uint4*>(s_u8)[i] = src[i];
     for (int i = tid; i < 2 * H * RW; i += NT) s_rowI[i] = 0ull;
     __syncthreads();
   }
   if (mode == 1) {
     // ---- front half: hand the normalised uint8 image and the scalars to the NLM / back kernels ----
-    uint4* dst = reinterpret_cast<uint4*>(a.u8_state + (size_t)b * P);
+    uint4* dst = reinterpret_cast<uint4*>(a.u8_state + ((size_t)b * 2 + slot) * P);
     for (int i = tid; i < (P >> 4); i += NT) dst[i] = reinterpret_cast<const uint4*>(s_u8)[i];
     if (tid == 0) {
       FrameCarry fc;
@@ -534,7 +540,10 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       fc.thresh = thresh;
       fc.median = reinterpret_cast<const float*>(s_bc)[2];
       fc.pad = 0;
-      a.carry[b] = fc;
+      fc.bg_avg_in = cs.bg_average;
+      a.carry[(size_t)b * 2 + slot] = fc;
+      // motiondetector.py:224-226 (same expression as at the end of the back half): the next front half needs it
+      a.bgavg[b] = fc.R.changed ? rint((double)fc.R.sumbg / (double)((W - 2 * e) * (H - 2 * e))) : cs.bg_average;
     }
     return;
   }
@@ -899,7 +908,7 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
   unsigned char* ext = smem;                                                   // [EH][ES]
   u32* Hs = reinterpret_cast<u32*>(smem + (((size_t)EH * ES + 15) & ~(size_t)15));  // [(H+6)][W]
   int* s_lut = reinterpret_cast<int*>(Hs + (size_t)(H + 6) * W);              // [64]
-  unsigned char* img = a.u8_state + (size_t)b * P;
+  unsigned char* img = a.u8_state + ((size_t)b * 2 + (t & 1)) * P;
 
   for (int i = tid; i < EH * ES; i += NT) {
     const int ey = i / ES, ex = i - ey * ES;

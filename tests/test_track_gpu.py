@@ -403,3 +403,29 @@ def test_other_resolutions_match_oracle(W, H):
         ntracks += len(got)
     assert ncomp > 0
     eng.close()
+
+
+def test_pipelined_split_steps_equal_fused(monkeypatch):
+    """CPX_TRACK_SPLIT_MIN_CLIPS (off by default): front halves of the frame step on one stream,
+    back halves one step behind on a second one.  Same bits as the fused kernel."""
+    from cpx import synth
+    from cpx.engine import TrackEngine
+
+    n_clips, T = 5, 60
+    frames, offs = synth.make_batch(n_clips, T, seed=77)
+    outs = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("CPX_TRACK_SPLIT_MIN_CLIPS", split)
+        eng = TrackEngine(model="lepton3", max_frames=T)
+        meta = np.concatenate([eng.make_meta(T) for _ in range(n_clips)])
+        res = eng.track_batch(eng.upload_frames(frames), offs, meta, want_labels=True, want_filtered=True,
+                              want_background=True)
+        res.check()
+        outs.append((res.info.copy(), [res.components(f).copy() for f in range(n_clips * T)], res.labels(),
+                     res.filtered(), res.background()))
+        eng.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0])
+    assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert sum(len(c) for c in a[1]) > 0
