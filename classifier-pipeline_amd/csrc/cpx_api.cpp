@@ -351,6 +351,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.u8_state = (unsigned char*)(base + l.u8);
   a.carry = (cpx::FrameCarry*)(base + l.carry);
   a.bgavg = (double*)(base + l.bgavg);
+  a.nlm_flip = c.denoise ? 1 : 0;
   a.nlm_lut = h->nlm_lut_dev;
   a.comps_out = comps_dev;
   a.info_out = info_dev;

@@ -69,6 +69,7 @@ struct TrackArgs {
   const int* proc_ffc;      // [total_proc] is_affected_by_ffc
   const double* wtab;       // [max_frames+2] k-fold float64 accumulation of weight_add
   // per-clip state
+  int nlm_flip;             // 1: a denoiser wrote the hand-over image into the other slot (back half reads that)
   double* bgavg;            // [B] background average after the last front half (split steps only)
   uint16_t* bg;             // [B][2][P] ping-pong background (interior authoritative); the background is a
                             // floor of a mean of uint16 frames, so 16 bits hold it exactly

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       reinterpret_cast<float*>(s_bc)[2] = fc.median;
       *s_ncomp_p = 0;
     }
-    const uint4* src = reinterpret_cast<const uint4*>(a.u8_state + ((size_t)b * 2 + slot) * P);
+    const uint4* src = reinterpret_cast<const uint4*>(a.u8_state + ((size_t)b * 2 + (slot ^ a.nlm_flip)) * P);
     for (int i = tid; i < (P >> 4); i += NT) reinterpret_cast<uint4*>(s_u8)[i] = src[i];
     for (int i = tid; i < 2 * H * RW; i += NT) s_rowI[i] = 0ull;
     __syncthreads();
@@ -891,52 +891,64 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr int NLM_R = 13;   // border = template radius 3 + search radius 10
-constexpr int NLM_BH = 20;  // rows per thread in pass B (register accumulators)
 __device__ __forceinline__ int refl101(int v, int n) { return v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v); }
 }  // namespace
 
+// BH = output rows per thread in pass B.  A workgroup owns a band of RB = BH * (NT / W) image rows of one frame
+// (blockIdx.y = band): BH = 20 covers a whole 120-row frame with one workgroup -- the throughput configuration for
+// large batches; smaller BH spread a frame over several CUs, which is what the latency of a single clip (one frame
+// per launch) needs.  Reads slot t & 1 of the hand-over image, writes the other slot (the bands of a frame overlap
+// in what they read, so the result cannot go back in place).
+template <int BH>
 __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
   const int b = blockIdx.x;
   const int nproc = a.proc_off[b + 1] - a.proc_off[b];
   if (t >= nproc) return;
   const int W = a.W, H = a.H, P = W * H;
   const int tid = threadIdx.x;
-  const int EW = W + 2 * NLM_R, EH = H + 2 * NLM_R;
+  const int nsub = NT / W;                 // pass-B sub-bands (one image column each per thread)
+  const int RB = BH * nsub;                // rows of this workgroup's band
+  const int yb0 = blockIdx.y * RB;         // first image row of the band
+  if (yb0 >= H) return;
+  const int RBc = (H - yb0 < RB) ? (H - yb0) : RB;
+  const int EW = W + 2 * NLM_R, EHb = RBc + 2 * NLM_R;
   const int ES = (EW + 8 + 7) & ~7;  // row stride of the padded image: multiple of 8, 8 bytes of slack for the
                                      // aligned 24-byte fetch of a shifted row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ext = smem;                                                   // [EH][ES]
-  u32* Hs = reinterpret_cast<u32*>(smem + (((size_t)EH * ES + 15) & ~(size_t)15));  // [(H+6)][W]
-  int* s_lut = reinterpret_cast<int*>(Hs + (size_t)(H + 6) * W);              // [64]
-  unsigned char* img = a.u8_state + ((size_t)b * 2 + (t & 1)) * P;
+  unsigned char* ext = smem;                                                   // [EHb][ES]: padded rows yb0-13 ...
+  const int RBa = RB < H ? RB : H;   // rows the launch sized the LDS for
+  u32* Hs = reinterpret_cast<u32*>(smem + (((size_t)(RBa + 2 * NLM_R) * ES + 15) & ~(size_t)15));  // [(RBa+6)][W]
+  int* s_lut = reinterpret_cast<int*>(Hs + (size_t)(RBa + 6) * W);            // [64]
+  const unsigned char* img = a.u8_state + ((size_t)b * 2 + (t & 1)) * P;
+  unsigned char* out = a.u8_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
 
-  for (int i = tid; i < EH * ES; i += NT) {
+  for (int i = tid; i < EHb * ES; i += NT) {
     const int ey = i / ES, ex = i - ey * ES;
     unsigned char v = 0;
-    if (ex < EW) v = img[refl101(ey - NLM_R, H) * W + refl101(ex - NLM_R, W)];
+    if (ex < EW) v = img[refl101(yb0 + ey - NLM_R, H) * W + refl101(ex - NLM_R, W)];
     ext[i] = v;
   }
   if (tid < 64) s_lut[tid] = a.nlm_lut[tid];
-  // pass-B role: one image column and a band of NLM_BH rows
-  const int nbands = NT / W;
-  const int bx = tid % W, band = tid / W;
-  const bool active_b = band < nbands && band * NLM_BH < H;
-  int est[NLM_BH], wsum[NLM_BH];
+  // pass-B role: one image column and a sub-band of BH rows
+  const int bx = tid % W, sub = tid / W;
+  const bool active_b = sub < nsub && sub * BH < RBc;
+  int est[BH], wsum[BH];
 #pragma unroll
-  for (int i = 0; i < NLM_BH; ++i) est[i] = wsum[i] = 0;
+  for (int i = 0; i < BH; ++i) est[i] = wsum[i] = 0;
   __syncthreads();
 
-  const int segs = W >> 3;             // 8-pixel segments per row
-  const int items = (H + 6) * segs;    // pass-A work items
+  const int segs = W >> 3;              // 8-pixel segments per row
+  const int items = (RBc + 6) * segs;   // pass-A work items
   for (int off = 0; off < 441; ++off) {
     const int dy = off / 21 - 10, dx = off - (off / 21) * 21 - 10;
-    // ---- pass A: Hs[r+3][x] = sum_{v=-3..3} (ext(r, x+v) - ext(r+dy, x+dx+v))^2 for r in [-3, H+3) ----
+    // ---- pass A: Hs[rr][x] = sum_{v=-3..3} (ext(r, x+v) - ext(r+dy, x+dx+v))^2 for r = yb0 + rr - 3 ----
     for (int it = tid; it < items; it += NT) {
-      const int rr = it / segs, x0 = (it - rr * segs) << 3;  // rr = r + 3
-      // bytes x0-3 .. x0+10 of both rows (14 values); byte address of (r, x) is (r+13)*ES + x + 13.
-      // ES is a multiple of 8 and x0 a multiple of 8, so both rows are fetched with aligned 8-byte LDS
-      // reads (conflict-free at this lane stride) and shifted into place with wave-uniform shifts.
-      const int abase = (rr - 3 + NLM_R) * ES + x0 + 8;           // a-bytes start at abase + 2
+      const int rr = it / segs, x0 = (it - rr * segs) << 3;
+      // bytes x0-3 .. x0+10 of both rows (14 values); the local row of image row r is r - yb0 + 13 = rr + 10 and
+      // the byte of column x is x + 13.  ES is a multiple of 8 and x0 a multiple of 8, so both rows are fetched
+      // with aligned 8-byte LDS reads (conflict-free at this lane stride) and shifted into place with
+      // wave-uniform shifts.
+      const int abase = (rr + NLM_R - 3) * ES + x0 + 8;            // a-bytes start at abase + 2
       const uint2 qa0 = *reinterpret_cast<const uint2*>(ext + abase);
       const uint2 qa1 = *reinterpret_cast<const uint2*>(ext + abase + 8);
       const u64 a0 = ((u64)qa0.y << 32) | qa0.x, a1 = ((u64)qa1.y << 32) | qa1.x;
@@ -944,7 +956,7 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
       const u64 ahi = a1 >> 16;                                   // bytes 8..13
       const int boff = NLM_R - 3 + dx;                            // 0 .. 20
       const int bsh = (boff & 7) * 8;
-      const int bbase = (rr - 3 + NLM_R + dy) * ES + x0 + (boff & ~7);
+      const int bbase = (rr + NLM_R - 3 + dy) * ES + x0 + (boff & ~7);
       const uint2 qb0 = *reinterpret_cast<const uint2*>(ext + bbase);
       const uint2 qb1 = *reinterpret_cast<const uint2*>(ext + bbase + 8);
       const uint2 qb2 = *reinterpret_cast<const uint2*>(ext + bbase + 16);
@@ -983,63 +995,84 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
       dst[1] = make_uint4(hsum[4], hsum[5], hsum[6], hsum[7]);
     }
     __syncthreads();
-    // ---- pass B: dist(y, x) = sum_{k=0..6} Hs[y+k][x]; weight; accumulate ----
+    // ---- pass B: dist(y, x) = sum_{k=0..6} Hs[y - yb0 + k][x]; weight; accumulate ----
     if (active_b) {
-      const int y0 = band * NLM_BH;
-      // the band's NLM_BH + 6 row sums of this column, once, into registers; then a sliding 7-sum
-      u32 hv[NLM_BH + 6];
+      const int l0 = sub * BH;  // first band-local row of this thread
+      // the sub-band's BH + 6 row sums of this column, once, into registers; then a sliding 7-sum
+      u32 hv[BH + 6];
 #pragma unroll
-      for (int k = 0; k < NLM_BH + 6; ++k) hv[k] = (y0 + k < H + 6) ? Hs[(size_t)(y0 + k) * W + bx] : 0u;
+      for (int k = 0; k < BH + 6; ++k) hv[k] = (l0 + k < RBc + 6) ? Hs[(size_t)(l0 + k) * W + bx] : 0u;
       u32 V = 0;
 #pragma unroll
       for (int k = 0; k < 7; ++k) V += hv[k];
 #pragma unroll
-      for (int i = 0; i < NLM_BH; ++i) {
-        const int y = y0 + i;
-        if (y < H) {
+      for (int i = 0; i < BH; ++i) {
+        const int l = l0 + i;
+        if (l < RBc) {
           const u32 aidx = V >> 6;
           if (aidx < 64u) {
             const int w = s_lut[aidx];
             if (w) {
-              est[i] += w * (int)ext[(y + NLM_R + dy) * ES + bx + NLM_R + dx];
+              est[i] += w * (int)ext[(l + NLM_R + dy) * ES + bx + NLM_R + dx];
               wsum[i] += w;
             }
           }
         }
-        if (i + 1 < NLM_BH) V += hv[i + 7] - hv[i];
+        if (i + 1 < BH) V += hv[i + 7] - hv[i];
       }
     }
     __syncthreads();
   }
   if (active_b) {
 #pragma unroll
-    for (int i = 0; i < NLM_BH; ++i) {
-      const int y = band * NLM_BH + i;
-      if (y < H) {
+    for (int i = 0; i < BH; ++i) {
+      const int l = sub * BH + i;
+      if (l < RBc) {
         const u32 ws = (u32)wsum[i];
         u32 v = ((u32)est[i] + ws / 2u) / ws;  // the zero offset always contributes LUT[0] > 0
-        img[y * W + bx] = (unsigned char)(v > 255u ? 255u : v);
+        out[(yb0 + l) * W + bx] = (unsigned char)(v > 255u ? 255u : v);
       }
     }
   }
 }
 
-size_t nlm_lds_bytes(int W, int H) {
+namespace {
+size_t nlm_lds_rows(int W, int rows) {
   const size_t ES = ((size_t)W + 2 * NLM_R + 8 + 7) & ~(size_t)7;
-  return ((((size_t)H + 2 * NLM_R) * ES + 15) & ~(size_t)15) + ((size_t)H + 6) * W * 4 + 64 * 4;
+  return ((((size_t)rows + 2 * NLM_R) * ES + 15) & ~(size_t)15) + ((size_t)rows + 6) * W * 4 + 64 * 4;
 }
-int nlm_supported(int W, int H) {
-  const int nbands = NT / W;
-  return nbands >= 1 && nbands * NLM_BH >= H && (W % 8) == 0 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
-}
-void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
+template <int BH>
+void launch_nlm_t(const TrackArgs& a, int B, int t, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_nlm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_nlm_kernel<BH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024 - 2048);
     configured = true;
   }
-  hipLaunchKernelGGL(cpx_nlm_kernel, dim3(B), dim3(NT), nlm_lds_bytes(a.W, a.H), s, a, t);
+  const int RB = BH * (NT / a.W);
+  hipLaunchKernelGGL(cpx_nlm_kernel<BH>, dim3(B, (a.H + RB - 1) / RB), dim3(NT),
+                     nlm_lds_rows(a.W, RB < a.H ? RB : a.H), s, a, t);
+}
+}  // namespace
+
+size_t nlm_lds_bytes(int W, int H) {
+  const int rb = 20 * (NT / W);
+  return nlm_lds_rows(W, rb < H ? rb : H);
+}
+int nlm_supported(int W, int H) {
+  const int nsub = NT / W;
+  // any height works (bands), the width must leave at least one pass-B sub-band per workgroup
+  return nsub >= 1 && (W % 8) == 0 && H >= 1 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
+}
+void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
+  // enough workgroups to fill the chip: whole frames per workgroup for big batches, bands of a frame for small
+  // ones (a single clip is one frame per launch)
+  const int nsub = NT / a.W;
+  const int want = (B >= 384) ? 1 : (512 + B - 1) / B;  // bands per frame that would give ~2 workgroups per CU
+  const int rows = (a.H + want - 1) / want;              // rows per band for that
+  if (rows > 10 * nsub) launch_nlm_t<20>(a, B, t, s);
+  else if (rows > 4 * nsub) launch_nlm_t<10>(a, B, t, s);
+  else launch_nlm_t<4>(a, B, t, s);
 }
 
 // final background of each clip as float, edges replicated (motiondetector.py:239-244)
