@@ -429,3 +429,60 @@ def test_pipelined_split_steps_equal_fused(monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     assert sum(len(c) for c in a[1]) > 0
+
+
+def test_connected_component_torture(engines):
+    """Random blocky hot patterns: many components of irregular shape born in different 2x2 blocks, touching only
+    diagonally, nested, wrapping around others -- label images, label numbering (OpenCV's block-raster order), boxes,
+    areas and centroids against the oracle; frames whose component count exceeds the capacity must report it."""
+    from cpx._lib import CpxError
+
+    eng = engines("lepton3")
+    H, W = 120, 160
+    rng = np.random.default_rng(2024)
+    clips, specs = [], []
+    for k in range(36):
+        cell = int(rng.choice([3, 4, 5, 6, 8, 12]))
+        density = float(rng.uniform(0.12, 0.6))
+        gh, gw = -(-H // cell), -(-W // cell)
+        grid = rng.random((gh, gw)) < density
+        if k % 5 == 0:   # diagonal-only contacts and thin bridges
+            grid = np.zeros((gh, gw), bool)
+            ii, jj = np.indices((gh, gw))
+            grid[(ii + jj) % 2 == 0] = rng.random(((ii + jj) % 2 == 0).sum()) < density * 1.3
+        mask = np.kron(grid, np.ones((cell, cell), bool))[:H, :W]
+        f = np.full((2, H, W), 3000, np.uint16)
+        f[1][mask] += np.uint16(rng.integers(200, 900))
+        f[1] += rng.integers(0, 3, (H, W)).astype(np.uint16)
+        clips.append(f)
+        specs.append((cell, density))
+    frames = np.concatenate(clips)
+    offs = (np.arange(len(clips) + 1) * 2).astype(np.int32)
+    res = eng.track_batch(eng.upload_frames(frames), offs, eng.make_meta(len(frames)), want_labels=True,
+                          want_filtered=True)
+    labels = res.labels()
+    counts, overflowed = [], 0
+    for k, f in enumerate(clips):
+        out, _ = _oracle_clip(f, "lepton3")
+        o = out["frames"][1]
+        fi = res.info[2 * k + 1]
+        n = o["n_components"]
+        counts.append(n)
+        assert fi["n_components"] == n, (k, specs[k])
+        if n > eng.cap:
+            overflowed += 1
+            assert fi["status"] == -5
+            continue
+        assert fi["status"] == 0
+        assert np.array_equal(labels[2 * k + 1], o["mask"]), (k, specs[k], n)
+        c = res.components(2 * k + 1)
+        got = np.stack([c["x"], c["y"], c["width"], c["height"], c["area"]], axis=1).reshape(-1, 5)
+        assert np.array_equal(got, o["stats"]), (k, specs[k])
+        if n:
+            cent = np.stack([c["sum_x"] / c["area"], c["sum_y"] / c["area"]], axis=1)
+            assert np.array_equal(cent, o["centroids"]), (k, specs[k])
+    ok = [n for n in counts if n <= eng.cap]
+    assert len(ok) >= 12 and max(ok) >= 20 and overflowed >= 1, (sorted(counts), overflowed)
+    if overflowed:
+        with pytest.raises(CpxError):
+            res.check()
