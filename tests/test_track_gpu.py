@@ -486,3 +486,29 @@ def test_connected_component_torture(engines):
     if overflowed:
         with pytest.raises(CpxError):
             res.check()
+
+
+def test_association_busy_scenes(engines):
+    """Up to 9 warm objects per clip crossing, overlapping and leaving: matching order, new-track creation under
+    overlap, blank frames with Kalman predictions and track retirement against the oracle; lepton3.5 thresholds too."""
+    import track_oracle as to
+    from cpx import synth
+
+    nt = nb = 0
+    for model, seed in (("lepton3", 5), ("lepton3.5", 6)):
+        eng = engines(model)
+        n_clips, T = 6, 120
+        rng = np.random.default_rng(seed)
+        clips = [synth.make_clip(rng, T, model=model, max_blobs=9) for _ in range(n_clips)]
+        offs = (np.arange(n_clips + 1) * T).astype(np.int32)
+        meta = eng.make_meta(n_clips * T)
+        res = eng.track_batch(eng.upload_frames(np.concatenate(clips)), offs, meta)
+        res.check()
+        assoc = eng.associate_batch(res, offs, meta)
+        assoc.check()
+        for b in range(n_clips):
+            out = to.track_clip(clips[b], cfg=to.OracleConfig(model), keep=True, apply_filter=False)
+            a, c = _compare_assoc(assoc, b, out, int(offs[b]), list(range(T)))
+            nt += a
+            nb += c
+    assert nt > 40 and nb > 40
