@@ -14,7 +14,7 @@ from ..ml_tools.interpreter import get_interpreter
 from ..ml_tools.tools import CustomJSONEncoder, load_clip_metadata
 from ..track.clip import Clip
 from ..track.cliptrackextractor import ClipTrackExtractor
-from ..track.trackextractor import extract_file
+from ..track.trackextractor import extract_file, extract_files
 from .thumbnail import best_trackless_thumb, get_thumbnail_info
 from .trackprediction import Predictions
 
@@ -25,6 +25,7 @@ class ClipClassifier:
     def __init__(self, config, model=None, keep_original_predictions=False, tracking_events=False,
                  model_by_country=True):
         self.keep_original_predictions = keep_original_predictions
+        self.batch_files = 64  # recordings per device batch of process(directory, track=True)
         self.config = config
         self.model = model
         self.model_by_country = model_by_country
@@ -55,11 +56,34 @@ class ClipClassifier:
             self.process_file(source, cache=cache, reuse_frames=reuse_frames, track=track,
                               calculate_thumbnails=calculate_thumbnails)
             return
+        todo = []
         for folder, _, files in os.walk(source):
             for name in sorted(files):
                 if os.path.splitext(name)[1] == ".cptv":
-                    self.process_file(os.path.join(folder, name), cache=cache, reuse_frames=reuse_frames, track=track,
-                                      calculate_thumbnails=calculate_thumbnails)
+                    todo.append(os.path.join(folder, name))
+        if not track:
+            for filename in todo:
+                self.process_file(filename, cache=cache, reuse_frames=reuse_frames, track=False,
+                                  calculate_thumbnails=calculate_thumbnails)
+            return
+        for i in range(0, len(todo), self.batch_files):
+            self.process_files(todo[i:i + self.batch_files], reuse_frames=reuse_frames,
+                               calculate_thumbnails=calculate_thumbnails)
+
+    def process_files(self, filenames, reuse_frames=None, calculate_thumbnails=False):
+        """process_file(track=True) for a list of recordings whose decode / tracking / association run as one device
+        batch (trackextractor.extract_files); classification and metadata per file as in process_file."""
+        results = []
+        tracked = extract_files(filenames, self.config, False, to_stdout=False, save_meta=False)
+        models = [self.model] if self.model else (self.config.classify.models or [])
+        for filename, (clip, track_extractor, meta_data) in zip(filenames, tracked):
+            meta_file = os.path.splitext(str(filename))[0] + ".txt"
+            predictions_per_model = {}
+            for model in models:
+                predictions_per_model[model.id] = self.classify_clip(clip, model, meta_data, reuse_frames=reuse_frames)
+            results.append(self.save_metadata(meta_data, meta_file, clip, predictions_per_model, models,
+                                              calculate_thumbnails=calculate_thumbnails))
+        return results
 
     def process_file(self, filename, cache=None, reuse_frames=None, track=False, calculate_thumbnails=False):
         """Track (optionally) and classify one recording; writes / returns the metadata (clipclassifier.py:145-250)."""

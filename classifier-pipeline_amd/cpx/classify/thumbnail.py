@@ -113,6 +113,6 @@ def best_trackless_thumb(clip):
     if f is None:
         logging.warning("best_trackless_thumb: frame %s is not on the device", best_frame_i)
         return None
-    x, y = st.engine.trackless_thumb(st.frames_dev, f, 0)  # clip.background is the file's first frame
+    x, y = st.engine.trackless_thumb(st.frames_dev, f, st.first_frame)  # clip.background = the file's first frame
     return Region(x, y, THUMBNAIL_SIZE, THUMBNAIL_SIZE, frame_number=best_frame_i,
                   centroid=(x + THUMBNAIL_SIZE // 2, y + THUMBNAIL_SIZE // 2))

@@ -54,7 +54,8 @@ class DeviceClipState:
     """Device-resident data of a tracked clip that the classifier reads: the frames, the filtered
     frames and per-frame medians (cpx_frame_info) -- nothing is copied back for classification."""
 
-    def __init__(self, engine, frames_dev, track_result, proc_frames):
+    def __init__(self, engine, frames_dev, track_result, proc_frames, first_frame=0):
+        self.first_frame = first_frame  # index of the file's first frame (the clip background) in frames_dev
         self.engine = engine
         self.frames_dev = frames_dev
         self.track_result = track_result
@@ -207,6 +208,7 @@ class ClipTrackExtractor(ClipTracker):
         self.calculate_filtered = calculate_filtered
         self.weighting_percent = 1
         self.device = device
+        self.host_images = True  # parse_clips: copy thermal / filtered / mask images into the frame buffer
         self._stream = None
         self._frames = None
         self._frames_dev = None
@@ -216,8 +218,9 @@ class ClipTrackExtractor(ClipTracker):
         self.timings = {}
 
     # ---- reference API -------------------------------------------------------------------------
-    def init_clip(self, clip):
-        """Header, resolution, camera thresholds, first frame -> clip background (cliptrackextractor.py:98-139)."""
+    def _read_header(self, clip):
+        """Open the file, take resolution / model / start time from its header (cliptrackextractor.py:98-127) and
+        index its frame sections.  -> dict(reader, frames (metadata only), offsets, widths, weight_add)."""
         clip.set_frame_buffer(self.high_quality_optical_flow, self.cache_to_disk, self.use_opt_flow,
                               self.keep_frames, self.max_frames)
         clip.type = self.type
@@ -230,17 +233,24 @@ class ClipTrackExtractor(ClipTracker):
         clip.set_model(header.model if header.model else None)
         start = datetime.fromtimestamp(header.timestamp / 1000000).astimezone(Clip.local_tz)
         clip.set_video_stats(start)
-        self._header = header
         cam35 = clip.camera_model == "lepton3.5"
-        self._weight_add = (1 if cam35 else 0.1) / self.weighting_percent
+        weight_add = (1 if cam35 else 0.1) / self.weighting_percent
         frames, offsets, widths = reader.scan()
         if not frames:
             raise Exception("CPTV file has no frames: {}".format(clip.source_file))
+        return dict(reader=reader, header=header, frames=frames, offsets=offsets, widths=widths, weight_add=weight_add)
+
+    def init_clip(self, clip):
+        """Header, resolution, camera thresholds, first frame -> clip background (cliptrackextractor.py:98-139)."""
+        item = self._read_header(clip)
+        reader, frames = item["reader"], item["frames"]
+        self._header = item["header"]
+        self._weight_add = item["weight_add"]
         eng = get_engine(clip.res_x, clip.res_y, clip.background_thresh, self._weight_add, self.config.edge_pixels,
                          self.device, max_frames=len(frames), denoise=bool(self.config.denoise))
         t0 = time.time()
-        self._frames_dev = eng.cptv_unpack(np.frombuffer(reader.inflated + bytes(16), np.uint8), offsets, widths,
-                                           np.array([0, len(frames)], np.int32))
+        self._frames_dev = eng.cptv_unpack(np.frombuffer(reader.inflated + bytes(16), np.uint8), item["offsets"],
+                                           item["widths"], np.array([0, len(frames)], np.int32))
         pix = self._frames_dev.cpu().numpy().view(np.uint16)
         self.timings["decode_s"] = time.time() - t0
         for f, p in zip(frames, pix):
@@ -258,6 +268,81 @@ class ClipTrackExtractor(ClipTracker):
         if self.calc_stats:
             clip.stats.completed()
         self._tracking_time = time.time() - start
+        return True
+
+    def parse_clips(self, clips, process_background=False):
+        """parse_clip for many files at once: the files are inflated in threads, and decoded, tracked and associated
+        on the GPU as ONE batch per camera geometry / threshold group; the per-clip objects (tracks, regions,
+        statistics, end-of-clip filtering) are then built exactly as parse_clip builds them.  With host_images=False
+        the frame buffer gets its entries (frame count, flags) but no host copies of the images: thumbnails and
+        classification read the frames, filtered frames and label masks on the device."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        self._tracking_time = None
+        start = time.time()
+        clips = list(clips)
+        if not clips:
+            return True
+        with ThreadPoolExecutor(max_workers=min(8, len(clips))) as pool:
+            items = list(pool.map(self._read_header, clips))
+        groups = {}
+        for i, (clip, item) in enumerate(zip(clips, items)):
+            key = (clip.res_x, clip.res_y, float(clip.background_thresh), float(item["weight_add"]))
+            groups.setdefault(key, []).append(i)
+        for key, members in groups.items():
+            longest = max(len(items[i]["frames"]) for i in members)
+            eng = get_engine(key[0], key[1], key[2], key[3], self.config.edge_pixels, self.device,
+                             max_frames=longest, denoise=bool(self.config.denoise))
+            t0 = time.time()
+            offs, base, chunks, poffs, widths = [0], 0, [], [], []
+            for i in members:
+                it = items[i]
+                chunks.append(np.frombuffer(it["reader"].inflated, np.uint8))
+                poffs.append(it["offsets"] + base)
+                widths.append(it["widths"])
+                base += len(it["reader"].inflated)
+                offs.append(offs[-1] + len(it["frames"]))
+            offs = np.asarray(offs, np.int32)
+            frames_dev = eng.cptv_unpack(np.concatenate(chunks + [np.zeros(16, np.uint8)]), np.concatenate(poffs),
+                                         np.concatenate(widths), offs)
+            host_images = self.keep_frames and self.host_images
+            if host_images:
+                pix_all = frames_dev.cpu().numpy().view(np.uint16)
+            else:  # only the first frame of every clip is needed on the host (clip.background)
+                firsts = frames_dev[eng.torch.from_numpy(offs[:-1].astype(np.int64)).to(frames_dev.device)]
+                pix_first = firsts.cpu().numpy().view(np.uint16)
+            self.timings["decode_s"] = time.time() - t0
+            metas = []
+            for k, i in enumerate(members):
+                fr = items[i]["frames"]
+                bgf = [bool(f.background_frame) and not process_background for f in fr]
+                metas.append(eng.make_meta(len(fr), [f.time_on for f in fr], [f.last_ffc_time for f in fr], bgf))
+                clips[i].update_background(pix_all[offs[k]] if host_images else pix_first[k])
+                clips[i]._background_calculated()
+            meta = np.concatenate(metas)
+            t0 = time.time()
+            res = eng.track_batch(frames_dev, offs, meta, want_labels=True, want_filtered=True, want_background=True)
+            assoc = None
+            if self.do_tracking and not any(clips[i].from_metadata for i in members):
+                c0 = clips[members[0]]
+                params = make_track_params(
+                    c0.res_x, c0.res_y, self.config.edge_pixels, self.config.frame_padding, self.min_dimension,
+                    self.config.cropped_regions_strategy, self.config.filter_regions_pre_match,
+                    self.config.aoi_min_mass, self.config.aoi_pixel_variance, self.config.params, c0.frames_per_second)
+                assoc = eng.associate_batch(res, offs, meta, params=params)
+            res.check()
+            self.timings["device_s"] = time.time() - t0
+            labels = res.labels() if host_images else None
+            filtered = res.filtered() if (host_images or self.calculate_filtered) else None
+            backgrounds = res.background()
+            for k, i in enumerate(members):
+                f0, n = int(offs[k]), int(offs[k + 1] - offs[k])
+                thermal = pix_all[f0:f0 + n] if host_images else None
+                self._collect_clip(clips[i], k, f0, n, thermal, eng, frames_dev, res, assoc, labels, filtered,
+                                   backgrounds[k], key[3])
+                if self.calc_stats:
+                    clips[i].stats.completed()
+        self._tracking_time = (time.time() - start) / len(clips)
         return True
 
     def start_tracking(self, clip, frames, track_frames=True, background_alg=None, **args):
@@ -366,7 +451,6 @@ class ClipTrackExtractor(ClipTracker):
             raise Exception("Clip has no background have you called init_clip first")
         frames = self._frames
         n = len(frames)
-        weight_add = self._weight_add
         eng = self._engine
         t0 = time.time()
         bgf = [bool(f.background_frame) and not process_background for f in frames]
@@ -385,31 +469,41 @@ class ClipTrackExtractor(ClipTracker):
             assoc = eng.associate_batch(res, offs, meta, params=params)
         res.check()
         self.timings["device_s"] = time.time() - t0
-        info = res.info
         labels = res.labels() if want_images else None
         filtered = res.filtered() if (want_images or self.calculate_filtered) else None
+        thermal = [f.pix for f in frames] if frames and frames[0].pix is not None else None
+        self._collect_clip(clip, 0, 0, n, thermal, eng, frames_dev, res, assoc, labels, filtered,
+                           res.background()[0], self._weight_add)
+
+    def _collect_clip(self, clip, b, f0, n, thermal, eng, frames_dev, res, assoc, labels, filtered, background,
+                      weight_add):
+        """Build what the reference's callers read for clip `b` of a tracked batch (its frames are the batch
+        frames [f0, f0 + n)): frame buffer / statistics, region history, tracks, end-of-clip filtering."""
+        info = res.info
         P = clip.res_x * clip.res_y
-        for f in range(n):
+        proc = []
+        for i in range(n):
+            f = f0 + i
             fi = info[f]
             if fi["frame_number"] < 0:
                 continue
-            thermal = frames[f].pix
+            proc.append(f)
             stats = (np.uint16(fi["thermal_min"]), np.uint16(fi["thermal_max"]), np.float64(fi["thermal_median"]),
                      fi["thermal_sum"] / P, float(fi["filtered_abs_sum"]))
             clip.ffc_affected = bool(fi["ffc_affected"])
-            clip.add_frame(thermal, None if filtered is None else filtered[f], None if labels is None else labels[f],
-                           clip.ffc_affected, stats=stats)
+            clip.add_frame(None if thermal is None else thermal[i], None if filtered is None else filtered[f],
+                           None if labels is None else labels[f], clip.ffc_affected, stats=stats)
             if assoc is not None:
                 clip.region_history.append([] if clip.ffc_affected else
                                            [Region.from_record(r) for r in assoc.frame_regions(f)])
-        clip.device_state = DeviceClipState(eng, frames_dev, res, [f for f in range(n) if info[f]["frame_number"] >= 0])
-        bg = res.background()[0].astype(np.float64)
-        last = info[[f for f in range(n) if info[f]["frame_number"] >= 0][-1]] if clip.current_frame >= 0 else None
-        self.background_alg = WeightedBackgroundView(bg, None if last is None else last["background_average"], weight_add)
+        clip.device_state = DeviceClipState(eng, frames_dev, res, proc, first_frame=f0)
+        last = info[proc[-1]] if proc else None
+        self.background_alg = WeightedBackgroundView(np.asarray(background, dtype=np.float64),
+                                                     None if last is None else last["background_average"], weight_add)
         if assoc is not None:
             assoc.check()
             clip.tracks = [Track.from_device(clip, rec, regs, self.tracker_version, self.config)
-                           for rec, regs in assoc.clip_tracks(0)]
+                           for rec, regs in assoc.clip_tracks(b)]
             last_frame = clip.current_frame
             clip.active_tracks = set(t for t in clip.tracks if t.end_frame == last_frame and self._still_tracking(t))
             self.apply_track_filtering(clip)

@@ -18,6 +18,7 @@ class TrackExtractor:
         self.worker_threads = max(1, config.worker_threads)
         self.retrack = retrack
         self.cache_to_disk = config.classify.cache_to_disk if cache_to_disk is None else cache_to_disk
+        self.batch_files = 64  # files per device batch of extract(directory)
 
     def extract(self, base, to_stdout=False):
         base = Path(base)
@@ -27,11 +28,15 @@ class TrackExtractor:
         if base.is_file():
             extract_file(base, self.config, self.cache_to_disk, self.retrack, to_stdout)
             return
-        # one GPU per process: files of a directory are walked in this process, one device engine reused
+        # one GPU per process (the reference forks a pool of CPU workers, trackextractor.py:60-120): the files of a
+        # directory go through the device in batches -- decoded, tracked and associated together
+        todo = []
         for folder, _, files in os.walk(base):
             for name in sorted(files):
                 if os.path.splitext(name)[1] == ".cptv":
-                    extract_file(os.path.join(folder, name), self.config, self.cache_to_disk, self.retrack, to_stdout)
+                    todo.append(os.path.join(folder, name))
+        for i in range(0, len(todo), self.batch_files):
+            extract_files(todo[i:i + self.batch_files], self.config, self.cache_to_disk, self.retrack, to_stdout)
 
 
 def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True):
@@ -60,6 +65,36 @@ def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False
             track.set_end_s(clip.frames_per_second)
     metadata = get_metadata(existing, filename, meta_filename, clip, track_extractor, to_stdout, save_meta)
     return clip, track_extractor, metadata
+
+
+def extract_files(filenames, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True):
+    """extract_file for a list of files as one device batch (ClipTrackExtractor.parse_clips); same metadata per file.
+    -> list of (clip, track_extractor, metadata)."""
+    filenames = [Path(f) for f in filenames]
+    for filename in filenames:
+        if not filename.is_file():
+            raise Exception("File {} not found.".format(filename))
+        if filename.suffix != ".cptv":
+            raise NotImplementedError("only thermal .cptv clips are handled (IR path: SURVEY section 8 f4)")
+    if retrack:  # existing tracks are re-used per file: no batch form
+        return [extract_file(f, config, cache_to_disk, retrack, to_stdout, max_frames, save_meta) for f in filenames]
+    track_extractor = ClipTrackExtractor(config.tracking, config.use_opt_flow, cache_to_disk, verbose=config.verbose,
+                                         max_frames=max_frames)
+    track_extractor.host_images = False  # the consumers below (thumbnails, classification) read device memory
+    clips, existing = [], []
+    for filename in filenames:
+        logging.info("Tracking %s", filename)
+        clip = Clip(track_extractor.config, filename)
+        clip.frames_per_second = 9
+        meta_filename = filename.with_suffix(".txt")
+        existing.append(tools.load_clip_metadata(meta_filename) if meta_filename.exists() else None)
+        clips.append(clip)
+    track_extractor.parse_clips(clips)
+    out = []
+    for filename, clip, ex in zip(filenames, clips, existing):
+        metadata = get_metadata(ex, filename, filename.with_suffix(".txt"), clip, track_extractor, to_stdout, save_meta)
+        out.append((clip, track_extractor, metadata))
+    return out
 
 
 def get_metadata(existing_metadata, filename, meta_filename, clip, track_extractor, to_stdout=False, save=True):

@@ -1,0 +1,91 @@
+"""Directory / multi-file drivers (extract_files, ClipClassifier.process_files): many recordings decoded, tracked and
+associated as one device batch must give, per file, the metadata of the one-file-at-a-time path."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from helpers import encode_cptv
+
+pytestmark = pytest.mark.gpu
+
+
+def _strip(meta):
+    from cpx.ml_tools.tools import CustomJSONEncoder
+
+    m = json.loads(json.dumps(meta, cls=CustomJSONEncoder))
+    m.pop("tracking_time", None)
+    m.pop("source", None)
+    m.pop("id", None)  # Clip.CLIP_ID: a per-process counter
+    for model in m.get("models", []):
+        model.pop("classify_time", None)
+    for t in m.get("tracks", []):
+        for p in t.get("predictions", []) or []:
+            p.pop("classify_time", None)
+    return m
+
+
+def _files(golden_dir, tmp_path):
+    """The two fixture clips, a lepton3.5 clip and a short synthetic clip without tracks (different lengths, two
+    camera models -> two device groups)."""
+    from cpx import synth
+
+    paths = []
+    for name in ("possum", "hedgehog"):
+        dst = tmp_path / (name + ".cptv")
+        shutil.copy(os.path.join(golden_dir, name + ".cptv"), dst)
+        paths.append(dst)
+    rng = np.random.default_rng(8)
+    for k, (model, n, blobs) in enumerate((("lepton3.5", 70, 3), ("lepton3", 60, 2), ("lepton3", 25, 0))):
+        clip = synth.make_clip(rng, n, model=model, max_blobs=blobs)
+        p = tmp_path / ("synth%d.cptv" % k)
+        t_on = [100000 + 111 * i for i in range(n)]
+        encode_cptv(p, clip, [16] * n, time_on=t_on, last_ffc=[40000] * n, model=model.encode())
+        paths.append(p)
+    return paths
+
+
+@pytest.mark.parametrize("denoise", [False, True])
+def test_extract_files_equals_extract_file(golden_dir, tmp_path, denoise):
+    from cpx.config import Config
+    from cpx.track.trackextractor import extract_file, extract_files
+
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = denoise
+    paths = _files(golden_dir, tmp_path)
+    single = [_strip(extract_file(p, cfg, False, save_meta=False)[2]) for p in paths]
+    batch = extract_files(paths, cfg, False, save_meta=False)
+    assert len(batch) == len(paths)
+    n_tracks = 0
+    for (clip, ex, meta), want in zip(batch, single):
+        got = _strip(meta)
+        assert got == want, clip.source_file
+        n_tracks += len(got["tracks"])
+    assert n_tracks >= 4 and any(len(m["tracks"]) == 0 and m.get("thumbnail_region") is not None for m in single)
+
+
+def test_directory_drivers_write_the_same_files(golden_dir, tmp_path):
+    from cpx.config import Config
+    from cpx.track.trackextractor import TrackExtractor, extract_file
+
+    cfg = Config.get_defaults()
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    for p in _files(golden_dir, a):
+        shutil.copy(p, b / p.name)
+    for p in sorted(a.glob("*.cptv")):
+        extract_file(p, cfg, False)
+    ex = TrackExtractor(cfg)
+    ex.batch_files = 3   # 5 files -> two device batches
+    ex.extract(b)
+    for p in sorted(a.glob("*.txt")):
+        with open(p) as fa, open(b / p.name) as fb:
+            ma, mb = json.load(fa), json.load(fb)
+        for m in (ma, mb):
+            m.pop("tracking_time", None)
+            m.pop("source", None)
+            m.pop("id", None)
+        assert ma == mb, p.name

@@ -94,3 +94,48 @@ def test_classify_track_inputs_equal_reference(tmp_path, model_dir):
     assert np.array_equal(seen["x"], z["t0_input"])
     assert pred is not None and abs(float(np.sum(pred.class_best_score)) - 1.0) < 1e-5
     assert [list(p.frames) for p in pred.predictions] == [list(s) for s in z["t0_segments"]]
+
+
+def test_process_files_equals_process_file(tmp_path, model_dir, monkeypatch):
+    """ClipClassifier.process(directory, track=True): the recordings of a device batch get the metadata files the
+    one-file-at-a-time path writes (segment choice is random as in the reference: the generator is pinned here)."""
+    from cpx.classify.clipclassifier import ClipClassifier
+    from cpx.ml_tools import datasetstructures as ds
+
+    real_rng = np.random.default_rng
+    monkeypatch.setattr(ds.np.random, "default_rng", lambda seed=None: real_rng(1234 if seed is None else seed))
+
+    mdir, w = model_dir
+    cfg = _config(mdir)
+    a, b = tmp_path / "a", tmp_path / "b"
+    for d in (a, b):
+        d.mkdir()
+        for name in ("possum", "hedgehog"):
+            shutil.copy(os.path.join(GOLDEN, name + ".cptv"), d / (name + ".cptv"))
+    np.random.seed(5)
+    for p in sorted(a.glob("*.cptv")):
+        ClipClassifier(cfg).process_file(str(p), track=True, calculate_thumbnails=True)
+    np.random.seed(5)
+    ClipClassifier(cfg).process(str(b), track=True, calculate_thumbnails=True)
+
+    def load(p):
+        with open(p) as fh:
+            m = json.load(fh)
+        for k in ("tracking_time", "source", "id"):
+            m.pop(k, None)
+        for model in m["models"]:
+            model.pop("classify_time", None)
+        for t in m["tracks"]:
+            for pm in t["predictions"]:
+                pm.pop("classify_time", None)
+                for seg in pm.get("predictions", []):
+                    seg.pop("predicted_time", None)  # wall clock
+        return m
+
+    for name in ("possum", "hedgehog"):
+        ma, mb = load(a / (name + ".txt")), load(b / (name + ".txt"))
+        assert len(ma["tracks"]) > 0 and ma["tracks"][0]["predictions"] and ma["tracks"][0]["thumbnail"]
+        for ta, tb in zip(ma["tracks"], mb["tracks"]):
+            for k in ta:
+                assert ta[k] == tb[k], (name, ta["id"], k)
+        assert ma == mb, name
