@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--stage", choices=("e2e", "track"), default="e2e",
                     help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only")
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cnn-chunk", type=int, default=512, help="samples per CNN forward")
+    ap.add_argument("--cnn-chunk", type=int, default=2048, help="samples per CNN forward (54 GB of activations at 2048)")
     ap.add_argument("--frame-size", type=int, default=32, choices=(32, 64),
                     help="side of one tile of the 5x5 network input (SURVEY 8(d) config 3 asks for 32 and 64)")
     ap.add_argument("--sub-batches", type=int, default=1,
