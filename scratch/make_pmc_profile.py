@@ -17,12 +17,21 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def avg(dirname, counter, kernel_sub, grid=None):
+def rows(dirname, counter, kernel_sub):
     path = max(glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*_counter_collection.csv")),
                key=os.path.getmtime)  # the newest pass (gpurun merges outputs, older passes stay around)
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]
-            and (grid is None or int(r["Grid_Size"]) == grid)]
+    return [(int(r["Grid_Size"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path))
+            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
+
+
+def common_grid(dirname, counter, kernel_sub):
+    """the grid size most of the kernel's launches used"""
+    grids = [g for g, _ in rows(dirname, counter, kernel_sub)]
+    return max(set(grids), key=grids.count)
+
+
+def avg(dirname, counter, kernel_sub, grid=None):
+    vals = [v for g, v in rows(dirname, counter, kernel_sub) if grid is None or g == grid]
     return sum(vals) / len(vals), len(vals)
 
 
@@ -40,10 +49,13 @@ out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -
                   "--clips 1024 --steps 1 --warmup 0 --cpu-clips 0 (separate passes, scratch/make_pmc_profile.py)",
        "note": "KiB per dispatch, averaged over the launches named; FETCH_SIZE doubled per MI355X_MICROARCH.md, "
                "WRITE_SIZE as is"}
+CONV = "conv_mfma_kernel<8, 1, 1, 3, 2"
+conv_grid = common_grid("pmc_e2e_fetch", "FETCH_SIZE", CONV)
+conv_n = conv_grid // (100 * 2 * 256)  # 100 tiles of 16 x 16 pixels per 160 x 160 sample, 2 groups, 256 threads
 out["conv_stage2"] = section(
-    "conv_mfma_kernel<8,1,1,3,2>, launches of 512 samples (64->64 ch, 160x160)", "pmc_e2e_fetch", "pmc_e2e_write",
-    "conv_mfma_kernel<8, 1, 1, 3, 2>", 512 * 100 * 2 * 256, 512, "samples", 512 * 160 * 160 * 64 * 4 * 2.6,
-    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): 512*160*160*64*4 B * 2.6")
+    "conv_mfma_kernel<8,1,1,3,2,16>, launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
+    "pmc_e2e_write", CONV, conv_grid, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.6,
+    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
 out["frame_kernel_e2e"] = section(
     "cpx_frame_kernel, 1024 clip-frames per launch, no label image (end-to-end configuration)", "pmc_e2e_fetch",
     "pmc_e2e_write", "cpx_frame_kernel", None, 1024, "clip-frames", (614400 - 76800) * 1024,
