@@ -17,7 +17,7 @@ no data-path collective; the per-track result records are all-gathered once per 
 
 Extra objects on the JSON line:
   roofline      the dominant kernel of the step.  e2e: the stage-2 3x3 grouped convolution
-                (conv_mfma_kernel<8,1,1,3,2> in the rocprof CSV), MFMA-bound: algorithmic FLOPs of its launches / their
+                (conv_mfma_kernel<8,1,1,3,2,16> in the rocprof CSV), MFMA-bound: algorithmic FLOPs of its launches / their
                 HIP-event time on the handle's stream, against the fp32-MFMA dense peak.  --stage track:
                 cpx_frame_kernel, HBM-bound, 614,400 algorithmic bytes per frame.
   roofline_track  (e2e) the same HBM accounting for cpx_frame_kernel inside the same run.
@@ -308,11 +308,11 @@ def main():
             line["config"].update({"kept_tracks_per_step": int(r.n_tracks), "classified_segments_per_step": int(r.n_samples),
                                    "frame_size": args.frame_size, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk,
                                    "sub_batches": args.sub_batches})
-            key = 32 * 10000 + 32 * 10 + 1  # conv_mfma_kernel<KC=8,NTN=1,S=1,KS=3,NTM=2>: the stage-2 3x3 convolutions
+            key = 32 * 10000 + 32 * 10 + 1  # conv_mfma_kernel<KC=8,NTN=1,S=1,KS=3,NTM=2,TW=16>: the stage-2 3x3 convolutions
             if key in conv and conv[key][1] > 0:
                 n, ms, fl = conv[key]
                 tf = fl / (ms / 1e3) / 1e12
-                line["roofline"] = {"kernel": "conv_mfma_kernel<8,1,1,3,2> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)"
+                line["roofline"] = {"kernel": "conv_mfma_kernel<8,1,1,3,2,16> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)"
                                               % (5 * args.frame_size, 5 * args.frame_size),
                                     "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                                     "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
