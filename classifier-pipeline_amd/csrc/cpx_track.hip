@@ -1072,7 +1072,9 @@ void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
   const int rows = (a.H + want - 1) / want;              // rows per band for that
   if (rows > 10 * nsub) launch_nlm_t<20>(a, B, t, s);
   else if (rows > 4 * nsub) launch_nlm_t<10>(a, B, t, s);
-  else launch_nlm_t<4>(a, B, t, s);
+  else if (rows > 2 * nsub) launch_nlm_t<4>(a, B, t, s);
+  else if (rows > nsub) launch_nlm_t<2>(a, B, t, s);
+  else launch_nlm_t<1>(a, B, t, s);
 }
 
 // final background of each clip as float, edges replicated (motiondetector.py:239-244)
