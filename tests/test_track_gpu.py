@@ -512,3 +512,35 @@ def test_association_busy_scenes(engines):
             nt += a
             nb += c
     assert nt > 40 and nb > 40
+
+
+def test_denoise_band_variants_by_batch_size(engines):
+    """The NLM kernel is instantiated for 20 / 10 / 4 / 2 / 1 rows per pass-B thread and picked by batch size (whole
+    frames per workgroup for big batches, bands of a frame for small ones): every variant must give the oracle's
+    label images.  Two distinct short clips, replicated to the batch sizes that select each variant."""
+    import torch
+    import track_oracle as to
+    from cpx import synth
+
+    rng = np.random.default_rng(123)
+    T = 6
+    base = [synth.make_clip(rng, T, max_blobs=3) for _ in range(2)]
+    want = []
+    for clip in base:
+        cfg = to.OracleConfig("lepton3")
+        cfg.denoise = True
+        out = to.track_clip(clip, cfg=cfg, keep=True, do_tracking=False)
+        want.append(np.stack([o["mask"] for o in out["frames"]]))
+    want = np.concatenate(want)                       # [2T, H, W]
+    eng = engines("lepton3", denoise=True)
+    dev_base = eng.upload_frames(np.concatenate(base))
+    for B in (2, 32, 64, 128, 384):                   # -> 1, 2, 4, 10, 20 rows per thread at 160x120
+        reps = B // 2
+        frames = dev_base.unsqueeze(0).expand(reps, -1, -1, -1).reshape(B * T, 120, 160).contiguous()
+        offs = (np.arange(B + 1) * T).astype(np.int32)
+        res = eng.track_batch(frames, offs, eng.make_meta(B * T), want_labels=True)
+        eng.synchronize()
+        lab = res.labels_dev.reshape(reps, 2 * T, 120, 160)
+        assert bool((lab == lab[0:1]).all().item()), B
+        assert torch.equal(lab[0].cpu(), torch.from_numpy(want.astype(np.int32))), B
+    assert want.max() > 0
