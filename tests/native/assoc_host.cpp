@@ -61,3 +61,6 @@ extern "C" int final_host_clip(const cpx_filter_params* fp, const cpx_region* po
   track_offsets[counts[0]] = counts[1];
   return 0;
 }
+
+// np.median restatements of the end-of-clip statistics (cpx_final_core.h), for a direct check against NumPy
+extern "C" double median_select_host(double* a, int n) { return cpx::np_median_select(a, n); }

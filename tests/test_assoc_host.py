@@ -244,3 +244,23 @@ def test_host_final_synthetic(host_lib):
         kept += len(fin["tracks"])
         rejected += len(fin["filtered_tracks"])
     assert kept > 5  # (rejects are exercised by the possum fixture: five "Didn't move" tracks)
+
+
+def test_median_select_equals_numpy(host_lib):
+    """np_median_select (quickselect, used by the finalize kernel) against np.median on adversarial inputs."""
+    rng = np.random.default_rng(0)
+    fn = host_lib.median_select_host
+    fn.restype = C.c_double
+    fn.argtypes = [C.POINTER(C.c_double), C.c_int]
+    cases = [np.array([5.0]), np.array([2.0, 1.0]), np.array([3.0, 3.0, 3.0, 3.0]), np.arange(10, 0, -1.0),
+             np.arange(9.0), np.array([1.0, 2.0, 2.0, 2.0, 9.0, 9.0])]
+    for n in (3, 4, 7, 8, 31, 32, 100, 269, 270):
+        cases.append(rng.integers(0, 5, n).astype(np.float64))        # many duplicates
+        cases.append(rng.integers(0, 100000, n).astype(np.float64))
+        cases.append(np.sort(rng.integers(0, 1000, n)).astype(np.float64))
+        cases.append(np.sort(rng.integers(0, 1000, n))[::-1].astype(np.float64))
+    for a in cases:
+        buf = np.ascontiguousarray(a.copy())
+        got = fn(buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size)
+        assert got == float(np.median(a)), (a[:10], got)
+        assert sorted(buf.tolist()) == sorted(a.tolist())  # a permutation of the input
