@@ -31,7 +31,7 @@
 
 namespace cpx {
 
-enum { RF_BLANK = 1, RF_CROPPED = 2, RF_BORDER = 4, RF_CENTROID_F32 = 8 };
+enum { RF_BLANK = 1, RF_CROPPED = 2, RF_BORDER = 4, RF_CENTROID_F32 = 8, RF_W_PY = 16, RF_H_PY = 32 };
 enum { VK_INT = 0, VK_F64 = 1, VK_F32 = 2 };
 
 typedef cpx_region RegionRec;
@@ -62,17 +62,56 @@ CPX_HD inline int imin(int a, int b) { return a < b ? a : b; }
 CPX_HD inline int imax(int a, int b) { return a > b ? a : b; }
 
 // Rectangle.crop (rectangle.py:91-96; the left/top setters keep right/bottom)
-CPX_HD inline void rect_crop(int& x, int& y, int& w, int& h, int bx, int by, int bw, int bh) {
-  const int bright = bx + bw, bbottom = by + bh;
-  const int right = x + w, bottom = y + h;
-  const int nx = imin(bright, imax(x, bx));
-  x = nx;
-  w = right - nx;
-  const int ny = imin(bbottom, imax(y, by));
-  y = ny;
-  h = bottom - ny;
-  w = imax(bx, imin(x + w, bright)) - x;
-  h = imax(by, imin(y + h, bbottom)) - y;
+// The reference's coordinates are a mix of np.int32 (component statistics) and Python ints (crop rectangle, int()
+// results).  Which of the two a width / height is decides whether `predicted_mid - width / 2.0` of a Kalman blank region
+// is float64 arithmetic (np.int32 / 2.0 -> np.float64) or float32 (a Python float is a weak scalar), so the crop keeps
+// track of it: *_py = "is a Python int in the reference".  Python's max(a, b) is b only if b > a, min(a, b) is b only
+// if b < a; the bounds are Python ints.
+CPX_HD inline void crop_axis(int& pos, bool& pos_py, int& ext, bool& ext_py, int lo, int size) {
+  const int hi = lo + size;
+  // left / top = min(bounds.hi, max(self.pos, bounds.lo)); the setter keeps right / bottom
+  int m = pos;
+  bool m_py = pos_py;
+  if (lo > pos) {
+    m = lo;
+    m_py = true;
+  }
+  int npos = hi;
+  bool npos_py = true;
+  if (m < hi) {
+    npos = m;
+    npos_py = m_py;
+  }
+  const int old_far = pos + ext;
+  const bool old_far_py = pos_py && ext_py;
+  pos = npos;
+  pos_py = npos_py;
+  ext = old_far - pos;
+  ext_py = old_far_py && pos_py;
+  // right / bottom = max(bounds.lo, min(self.far, bounds.hi))
+  const int far = pos + ext;
+  const bool far_py = pos_py && ext_py;
+  int mm = far;
+  bool mm_py = far_py;
+  if (hi < far) {
+    mm = hi;
+    mm_py = true;
+  }
+  int v = lo;
+  bool v_py = true;
+  if (mm > lo) {
+    v = mm;
+    v_py = mm_py;
+  }
+  ext = v - pos;
+  ext_py = v_py && pos_py;
+}
+
+// Rectangle.crop (rectangle.py:91-96; the left/top setters keep right/bottom)
+CPX_HD inline void rect_crop(int& x, int& y, int& w, int& h, bool& x_py, bool& y_py, bool& w_py, bool& h_py, int bx,
+                             int by, int bw, int bh) {
+  crop_axis(x, x_py, w, w_py, bx, bw);
+  crop_axis(y, y_py, h, h_py, by, bh);
 }
 
 CPX_HD inline int overlap_area(const RegionRec& a, const RegionRec& b) {
@@ -216,15 +255,20 @@ CPX_HD inline void track_add_blank(AssocClip& c, ActiveTrack& t) {
   const int kalman_amount = t.rt_frames - 18 - t.since_seen * 2;
   RegionRec r;
   if (kalman_amount > 0) {
-    r.x = (int)((double)t.pm[0] - last.width / 2.0);
-    r.y = (int)((double)t.pm[1] - last.height / 2.0);
+    // int(predicted_mid - last_bound.width / 2.0): float32 when the width is a Python int in the reference, float64
+    // when it is np.int32 (track.py:247-253)
+    bool w_py = (last.flags & RF_W_PY) != 0, h_py = (last.flags & RF_H_PY) != 0;
+    r.x = w_py ? (int)(t.pm[0] - (float)(last.width / 2.0)) : (int)((double)t.pm[0] - last.width / 2.0);
+    r.y = h_py ? (int)(t.pm[1] - (float)(last.height / 2.0)) : (int)((double)t.pm[1] - last.height / 2.0);
     r.width = last.width;
     r.height = last.height;
     r.cx = (double)t.pm[0];
     r.cy = (double)t.pm[1];
-    r.flags = RF_CENTROID_F32;
     r.id = 0;
-    rect_crop(r.x, r.y, r.width, r.height, c.p->crop_x, c.p->crop_y, c.p->crop_w, c.p->crop_h);
+    bool x_py = true, y_py = true;
+    rect_crop(r.x, r.y, r.width, r.height, x_py, y_py, w_py, h_py, c.p->crop_x, c.p->crop_y, c.p->crop_w,
+              c.p->crop_h);
+    r.flags = RF_CENTROID_F32 | (w_py ? RF_W_PY : 0) | (h_py ? RF_H_PY : 0);
   } else {
     r = last;
   }
@@ -364,7 +408,8 @@ CPX_HD inline int build_regions(AssocClip& c, const cpx_component* comps, int nc
     r.pad = 0;
     if (r.width < p.min_dimension || r.height < p.min_dimension) continue;
     const int ox = r.x, oy = r.y, ow = r.width, oh = r.height;
-    rect_crop(r.x, r.y, r.width, r.height, p.crop_x, p.crop_y, p.crop_w, p.crop_h);
+    bool x_py = false, y_py = false, w_py = false, h_py = false;  // component statistics are np.int32
+    rect_crop(r.x, r.y, r.width, r.height, x_py, y_py, w_py, h_py, p.crop_x, p.crop_y, p.crop_w, p.crop_h);
     const bool cropped = (ox != r.x) || (oy != r.y) || (ow != r.width) || (oh != r.height);
     if (cropped) r.flags |= RF_CROPPED;
     if (p.cropped_regions_strategy == 0) {  // cautious
@@ -379,7 +424,9 @@ CPX_HD inline int build_regions(AssocClip& c, const cpx_component* comps, int nc
     r.width += 2 * padding;
     r.y -= padding;
     r.height += 2 * padding;
-    rect_crop(r.x, r.y, r.width, r.height, p.crop_x, p.crop_y, p.crop_w, p.crop_h);
+    rect_crop(r.x, r.y, r.width, r.height, x_py, y_py, w_py, h_py, p.crop_x, p.crop_y, p.crop_w, p.crop_h);
+    if (w_py) r.flags |= RF_W_PY;
+    if (h_py) r.flags |= RF_H_PY;
     // set_is_along_border(bounds = crop_rectangle, edge) -- note: bounds.width / bounds.height, not right / bottom
     if (cropped || r.x <= p.crop_x + edge || r.y <= p.crop_y + edge || r.x + r.width >= p.crop_w - edge ||
         r.y + r.height >= p.crop_h - edge)

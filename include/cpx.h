@@ -96,6 +96,8 @@ typedef struct cpx_frame_info {
 #define CPX_REGION_CROPPED 2       /* Region.was_cropped */
 #define CPX_REGION_BORDER 4        /* Region.is_along_border */
 #define CPX_REGION_CENTROID_F32 8  /* centroid came from the float32 Kalman prediction */
+#define CPX_REGION_WIDTH_PYINT 16  /* width / height are Python ints in the reference (not np.int32): decides the */
+#define CPX_REGION_HEIGHT_PYINT 32 /* dtype of the next Kalman blank region's arithmetic (track.py:247-253) */
 typedef struct cpx_region {
   int32_t x, y, width, height;
   int32_t mass;

@@ -70,13 +70,19 @@ class OracleConfig:
 
 
 class Region:
-    """Plain-int region; mirrors track/region.py:27-42 + rectangle.py:6-13."""
+    """Plain-int region; mirrors track/region.py:27-42 + rectangle.py:6-13.
+
+    The reference's coordinates are a mix of np.int32 (component statistics) and Python ints (the crop rectangle,
+    int() results); which one a width / height is decides whether `predicted_mid - width / 2.0` of a Kalman blank
+    region is evaluated in float64 (np.int32 / 2.0 -> np.float64) or float32 (Python float is a weak scalar).  The
+    values here are Python ints; `py` = (x, y, width, height) records which of them are Python ints in the reference."""
 
     __slots__ = ("x", "y", "width", "height", "centroid", "mass", "frame_number",
-                 "pixel_variance", "id", "was_cropped", "blank", "is_along_border")
+                 "pixel_variance", "id", "was_cropped", "blank", "is_along_border", "py")
 
     def __init__(self, x, y, width, height, centroid=None, mass=0, frame_number=0,
-                 pixel_variance=0, id=0, was_cropped=False, blank=False, is_along_border=False):
+                 pixel_variance=0, id=0, was_cropped=False, blank=False, is_along_border=False,
+                 py=(False, False, False, False)):
         self.x, self.y, self.width, self.height = int(x), int(y), int(width), int(height)
         self.centroid = centroid
         self.mass = mass
@@ -86,6 +92,7 @@ class Region:
         self.was_cropped = was_cropped
         self.blank = blank
         self.is_along_border = is_along_border
+        self.py = tuple(py)
 
     right = property(lambda s: s.x + s.width)
     bottom = property(lambda s: s.y + s.height)
@@ -96,18 +103,30 @@ class Region:
     def copy(self):
         return Region(self.x, self.y, self.width, self.height, self.centroid, self.mass,
                       self.frame_number, self.pixel_variance, self.id, self.was_cropped,
-                      self.blank, self.is_along_border)
+                      self.blank, self.is_along_border, self.py)
+
+    @staticmethod
+    def _crop_axis(pos, pos_py, ext, ext_py, lo, size):
+        """One axis of Rectangle.crop (rectangle.py:91-96, setters :50-70) with Python's max / min operand choice:
+        max(a, b) is b only if b > a, min(a, b) is b only if b < a; the bounds are Python ints."""
+        hi = lo + size
+        # left / top = min(bounds.hi, max(self.pos, bounds.lo)); the setter keeps right / bottom
+        m, m_py = (lo, True) if lo > pos else (pos, pos_py)
+        npos, npos_py = (m, m_py) if m < hi else (hi, True)
+        old_far, old_far_py = pos + ext, pos_py and ext_py
+        pos, pos_py = npos, npos_py
+        ext, ext_py = old_far - pos, old_far_py and pos_py
+        # right / bottom = max(bounds.lo, min(self.far, bounds.hi))
+        far, far_py = pos + ext, pos_py and ext_py
+        mm, mm_py = (hi, True) if hi < far else (far, far_py)
+        v, v_py = (mm, mm_py) if mm > lo else (lo, True)
+        return pos, pos_py, v - pos, v_py and pos_py
 
     def crop(self, bx, by, bw, bh):
         """rectangle.py:91-96 with the left/top setters keeping right/bottom."""
-        bright, bbottom = bx + bw, by + bh
-        right, bottom = self.right, self.bottom
-        nx = min(bright, max(self.x, bx))
-        self.x, self.width = nx, right - nx
-        ny = min(bbottom, max(self.y, by))
-        self.y, self.height = ny, bottom - ny
-        self.width = max(bx, min(self.right, bright)) - self.x
-        self.height = max(by, min(self.bottom, bbottom)) - self.y
+        self.x, xpy, self.width, wpy = self._crop_axis(self.x, self.py[0], self.width, self.py[2], bx, bw)
+        self.y, ypy, self.height, hpy = self._crop_axis(self.y, self.py[1], self.height, self.py[3], by, bh)
+        self.py = (xpy, ypy, wpy, hpy)
 
     def enlarge(self, border, crop):
         """rectangle.py:138-146."""
@@ -349,12 +368,16 @@ class Track:
         last = self.last_bound
         kalman_amount = self.rt_frames - Track.MIN_KALMAN_FRAMES - self.since_seen * 2
         if kalman_amount > 0:
+            # the reference's widths are usually np.int32 (float64 arithmetic); a width that came out of a crop as a
+            # Python int makes it float32 (see Region)
+            half_w = last.width / 2.0 if last.py[2] else np.float64(last.width / 2.0)
+            half_h = last.height / 2.0 if last.py[3] else np.float64(last.height / 2.0)
             r = Region(
-                # the reference's widths are np.int32, so this is float64 arithmetic there
-                int(np.float64(self.predicted_mid[0]) - last.width / 2.0),
-                int(np.float64(self.predicted_mid[1]) - last.height / 2.0),
+                int(np.float32(self.predicted_mid[0]) - half_w),
+                int(np.float32(self.predicted_mid[1]) - half_h),
                 last.width, last.height,
                 centroid=[self.predicted_mid[0], self.predicted_mid[1]],
+                py=(True, True, last.py[2], last.py[3]),
             )
             r.crop(*self.crop)
         else:

@@ -169,3 +169,33 @@ def test_trackless_thumbnail_oracle_matches_reference(name, n):
     g = gold["trackless"]
     assert (x, y, w, h, fn, mass) == (g["x"], g["y"], g["width"], g["height"], g["frame_number"], g["mass"])
     assert [float(centroid[0]), float(centroid[1])] == g["centroid"]
+
+
+def _busy_golden():
+    z = np.load(os.path.join(GOLDEN, "busy_tracks.npz"))
+    return z["seeds"], z["rows"], z["offsets"], int(z["frames"])
+
+
+def busy_clip(seed, T):
+    from cpx import synth
+
+    return synth.make_clip(np.random.default_rng(1000 + int(seed)), T, max_blobs=8)
+
+
+def test_oracle_matches_reference_on_busy_scenes():
+    """Association / Kalman / blank regions beyond the fixture clips: every track the reference created on 11 seeded
+    busy scenes (tests/golden/make_golden_busy.py), bounds and the Python-int typing of widths / heights included."""
+    import track_oracle as to
+
+    seeds, rows, offsets, T = _busy_golden()
+    t_on, ffc = [100000 + 111 * i for i in range(T)], [40000] * T
+    n_py = 0
+    for k, seed in enumerate(seeds):
+        out = to.track_clip(busy_clip(seed, T), t_on, ffc, None, to.OracleConfig("lepton3"), keep=True)
+        mine = sorted(list(out["tracks"]) + [t for _, t in out["filtered_tracks"]], key=lambda t: t.id)
+        got = [(t.id, r.x, r.y, r.width, r.height, int(r.mass), r.frame_number, int(bool(r.blank)), int(r.py[2]),
+                int(r.py[3])) for t in mine for r in t.bounds]
+        want = rows[offsets[k]:offsets[k + 1]]
+        assert np.array_equal(np.asarray(got, np.int32), want), seed
+        n_py += int((want[:, 8] | want[:, 9]).sum())
+    assert n_py > 10

@@ -262,6 +262,9 @@ def test_no_optional_outputs_same_components(engines):
 # ---------------------------------------------------------------------------
 # association stage (one GPU lane per clip) against the oracle's tracker
 # ---------------------------------------------------------------------------
+_PY_SIZED = [0]  # regions whose width / height the reference holds as Python ints, seen by _compare_assoc
+
+
 def _compare_assoc(assoc, b, out, f0, proc_frames):
     from cpx.tracking import REGION_BLANK, REGION_BORDER, REGION_CROPPED
 
@@ -287,8 +290,11 @@ def _compare_assoc(assoc, b, out, f0, proc_frames):
             assert (g["x"], g["y"], g["width"], g["height"], g["mass"], g["frame_number"]) == (
                 r.x, r.y, r.width, r.height, int(r.mass), r.frame_number), (b, w.id, r.frame_number)
             assert bool(g["flags"] & REGION_BLANK) == r.blank
+            # width / height typed as Python ints in the reference (decides the dtype of the next blank region)
+            assert (bool(g["flags"] & 16), bool(g["flags"] & 32)) == (r.py[2], r.py[3]), (b, w.id, r.frame_number)
             assert g["cx"] == float(r.centroid[0]) and g["cy"] == float(r.centroid[1]), (b, w.id, r.frame_number)
             nblank += int(r.blank)
+            _PY_SIZED[0] += int(r.py[2] or r.py[3])
     return len(tr), nblank
 
 
@@ -512,6 +518,7 @@ def test_association_busy_scenes(engines):
             nt += a
             nb += c
     assert nt > 40 and nb > 40
+    assert _PY_SIZED[0] > 0  # the float32 blank-region case was exercised
 
 
 def test_denoise_band_variants_by_batch_size(engines):
@@ -544,3 +551,35 @@ def test_denoise_band_variants_by_batch_size(engines):
         assert bool((lab == lab[0:1]).all().item()), B
         assert torch.equal(lab[0].cpu(), torch.from_numpy(want.astype(np.int32))), B
     assert want.max() > 0
+
+
+def test_association_matches_reference_on_busy_scenes(engines, golden_dir):
+    """The HIP association directly against what the REFERENCE produced on 11 seeded busy scenes
+    (tests/golden/busy_tracks.npz, make_golden_busy.py): all tracks, all bounds, blank flags, Python-int typing."""
+    import os
+
+    from cpx import synth
+
+    z = np.load(os.path.join(golden_dir, "busy_tracks.npz"))
+    seeds, rows, goffs, T = z["seeds"], z["rows"], z["offsets"], int(z["frames"])
+    eng = engines("lepton3")
+    clips = [synth.make_clip(np.random.default_rng(1000 + int(s)), T, max_blobs=8) for s in seeds]
+    offs = (np.arange(len(clips) + 1) * T).astype(np.int32)
+    t_on, ffc = [100000 + 111 * i for i in range(T)], [40000] * T
+    meta = np.concatenate([eng.make_meta(T, t_on, ffc) for _ in clips])
+    res = eng.track_batch(eng.upload_frames(np.concatenate(clips)), offs, meta)
+    res.check()
+    assoc = eng.associate_batch(res, offs, meta)
+    assoc.check()
+    for k in range(len(clips)):
+        got = []
+        for rec, regs in assoc.clip_tracks(k):
+            for g in regs:
+                got.append((rec["id"], g["x"], g["y"], g["width"], g["height"], g["mass"], g["frame_number"],
+                            int(bool(g["flags"] & 1)), int(bool(g["flags"] & 16)), int(bool(g["flags"] & 32))))
+        # the device keeps the untrimmed tracks; the reference's golden holds them after trim()
+        want = rows[goffs[k]:goffs[k + 1]]
+        got = np.asarray(got, np.int32)
+        idx = {tuple(r[[0, 6]]): i for i, r in enumerate(got)}
+        sel = [idx[(int(w[0]), int(w[6]))] for w in want]
+        assert np.array_equal(got[sel], want), int(seeds[k])
