@@ -34,7 +34,7 @@ def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
 
 
-def run(clip_name, denoise, keep_frames):
+def run(clip_name, denoise, keep_frames, path=None):
     rh.install()
     cte = rh.ref("track.cliptrackextractor")
     rec = {"frames": []}
@@ -83,7 +83,7 @@ def run(clip_name, denoise, keep_frames):
         cfg.tracking["thermal"].denoise = bool(denoise)
         clipmod = rh.ref("track.clip")
         ex = cte.ClipTrackExtractor(cfg.tracking, cfg.use_opt_flow, False)
-        clip = clipmod.Clip(cfg.tracking["thermal"], os.path.join(HERE, clip_name + ".cptv"))
+        clip = clipmod.Clip(cfg.tracking["thermal"], path or os.path.join(HERE, clip_name + ".cptv"))
         orig_pf = ex.process_frame
 
         def wrapped(c, fr):

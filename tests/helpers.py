@@ -12,9 +12,41 @@ def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
 
 
+# Seeded synthetic recordings the reference was also run on (tests/golden/make_golden_synth.py): what the two fixture
+# clips do not cover -- lepton3.5 thresholds (weight_add = 1), FFC-affected frames in the middle of a clip.
+SYNTH_CLIPS = {
+    "synth35": dict(seed=3501, model="lepton3.5", frames=80, blobs=4, ffc_at=(30, 31, 32, 33), background_first=True),
+}
+
+
+class _Header:
+    def __init__(self, model):
+        self.model = model
+        self.x_resolution, self.y_resolution = 160, 120
+
+
+def synth_clip(name):
+    """frames, time_on, last_ffc, background flags of a SYNTH_CLIPS recipe (deterministic)."""
+    from cpx import synth
+
+    spec = SYNTH_CLIPS[name]
+    n = spec["frames"]
+    frames = synth.make_clip(np.random.default_rng(spec["seed"]), n, model=spec["model"], max_blobs=spec["blobs"])
+    t_on = [100000 + 111 * i for i in range(n)]
+    ffc = [40000] * n
+    for i in spec["ffc_at"]:   # FFC-affected: integer milliseconds compared with FFC_PERIOD.seconds = 9 (SURVEY F5)
+        ffc[i] = t_on[i] - 5
+    bgf = [False] * n
+    bgf[0] = bool(spec["background_first"])
+    return frames, t_on, ffc, bgf, _Header(spec["model"])
+
+
 def load_clip(name):
     """All frames of a fixture CPTV -> (frames u16 [N,H,W], time_on, last_ffc, background flags, header)."""
     from cpx.cptv import CptvReader
+
+    if name in SYNTH_CLIPS:
+        return synth_clip(name)
 
     r = CptvReader(os.path.join(GOLDEN, name + ".cptv"))
     fr = r.read_all()

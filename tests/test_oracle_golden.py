@@ -20,7 +20,7 @@ def _run(name, dn):
     return to.track_clip(frames, t_on, ffc, bgf, cfg, keep=True), frames
 
 
-@pytest.mark.parametrize("name,dn", [("possum", 0), ("hedgehog", 0), ("possum", 1)])
+@pytest.mark.parametrize("name,dn", [("possum", 0), ("hedgehog", 0), ("possum", 1), ("synth35", 0)])
 def test_oracle_matches_reference_vectors(name, dn):
     out, frames = _run(name, dn)
     z, gt = load_golden(name, dn)

@@ -46,7 +46,7 @@ def _run_fixture(engine, name, lengths=None):
     return res, offs, bgf
 
 
-@pytest.mark.parametrize("name", ["possum", "hedgehog"])
+@pytest.mark.parametrize("name", ["possum", "hedgehog", "synth35"])
 def test_fixture_clip_matches_reference_vectors(engines, name):
     z, _ = load_golden(name, 0)
     kept = [int(k) for k in z["kept"]]
