@@ -188,3 +188,40 @@ def test_limits_and_clip_at_zero_on_crafted_crops(engine):
         assert limits[i]["filt_min"] == fsub.min() and limits[i]["filt_max"] == max(0.0, float(fsub.max()))
         seen.add((want_clip, float(np.median(sub)) == 0.0, (w * h) % 2))
     assert {s[0] for s in seen} == {0, 1} and any(s[1] for s in seen)
+
+
+def test_crop_tile_matches_reference_on_busy_scenes(engine, golden_dir):
+    """cpx_track_limits_batch + cpx_crop_tile against the CRC32 of the network inputs the REFERENCE built for 19
+    tracks of two busy synthetic scenes (tests/golden/busy_classify_fs32.json): regions on every frame border."""
+    import json
+    import os
+
+    import track_oracle as to
+    from cpx import synth
+    from helpers import crc
+
+    with open(os.path.join(golden_dir, "busy_classify_fs32.json")) as fh:
+        gold = json.load(fh)
+    T = gold["frames"]
+    t_on, ffc = [100000 + 111 * i for i in range(T)], [40000] * T
+    n = 0
+    for c in gold["clips"]:
+        frames = synth.make_clip(np.random.default_rng(1000 + c["seed"]), T, max_blobs=8)
+        dev = engine.upload_frames(frames)
+        res = engine.track_batch(dev, np.array([0, T], np.int32), engine.make_meta(T, t_on, ffc), want_filtered=True)
+        res.check()
+        out = to.track_clip(frames, t_on, ffc, None, to.OracleConfig("lepton3"), keep=True)  # tracks / regions only
+        births = {(t.start_frame, t.bounds[0].x, t.bounds[0].y, t.bounds[0].width, t.bounds[0].height): t
+                  for t in out["tracks"]}
+        regions, segs, want = [], [], []
+        for g in c["tracks"]:
+            t = births[(g["start_frame"],) + tuple(g["first"])]
+            regions.append(t.bounds)
+            segs.append([np.array(s) for s in g["segments"]])
+            want.extend(g["crc"])
+        refs, toffs, reqs, ns = _requests(regions, segs, lambda fn: fn)
+        x, _ = engine.preprocess_segments(dev, res, refs, toffs, reqs, ns, frame_size=32)
+        x = x.cpu().numpy()
+        assert [crc(x[i]) for i in range(ns)] == want, c["seed"]
+        n += ns
+    assert n >= 30

@@ -199,3 +199,47 @@ def test_oracle_matches_reference_on_busy_scenes():
         assert np.array_equal(np.asarray(got, np.int32), want), seed
         n_py += int((want[:, 8] | want[:, 9]).sum())
     assert n_py > 10
+
+
+def _busy_classify_cases():
+    """(clip frames, oracle output, [(oracle track, golden track entry)]) per clip of busy_classify_fs32.json; tracks
+    are paired by birth (start frame + first box): the reference numbers same-frame births in set order (F14)."""
+    import track_oracle as to
+
+    with open(os.path.join(GOLDEN, "busy_classify_fs32.json")) as fh:
+        gold = json.load(fh)
+    T = gold["frames"]
+    t_on, ffc = [100000 + 111 * i for i in range(T)], [40000] * T
+    cases = []
+    for c in gold["clips"]:
+        frames = busy_clip(c["seed"], T)
+        out = to.track_clip(frames, t_on, ffc, None, to.OracleConfig("lepton3"), keep=True)
+        births = {(t.start_frame, t.bounds[0].x, t.bounds[0].y, t.bounds[0].width, t.bounds[0].height): t
+                  for t in out["tracks"]}
+        pairs = []
+        for g in c["tracks"]:
+            t = births.get((g["start_frame"],) + tuple(g["first"]))
+            assert t is not None, (c["seed"], g["id"])
+            pairs.append((t, g))
+        assert len(pairs) == len(out["tracks"])
+        cases.append((frames, out, pairs))
+    return cases
+
+
+def test_classify_oracle_matches_reference_on_busy_scenes():
+    """Network inputs for 19 tracks of two busy synthetic scenes (many regions on the frame border: the edge-anchored
+    branches of resize_and_pad) against the CRCs of what the reference's Interpreter.classify_track fed its model."""
+    import classify_oracle as co
+
+    n_samples = n_edge = 0
+    for frames, out, pairs in _busy_classify_cases():
+        fr = out["frames"]
+        for t, g in pairs:
+            by_frame = {r.frame_number: r for r in t.bounds}
+            segs = [np.array(s) for s in g["segments"]]
+            x, _ = co.preprocess_segments(lambda q: frames[q], lambda q: fr[q]["filtered"].astype(np.float64),
+                                          by_frame, t.bounds, segs, 32, (1, 1, 158, 118))
+            assert [crc(x[i]) for i in range(x.shape[0])] == g["crc"], g["id"]
+            n_samples += x.shape[0]
+            n_edge += g["edge_regions"]
+    assert n_samples >= 30 and n_edge > 100
