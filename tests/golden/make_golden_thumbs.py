@@ -24,7 +24,7 @@ def region_dict(r):
                 centroid=None if r.centroid is None else [float(r.centroid[0]), float(r.centroid[1])])
 
 
-def run(clip_name, denoise, max_frames=None):
+def run(clip_name, denoise, max_frames=None, path=None):
     rh.install()
     cte = rh.ref("track.cliptrackextractor")
     clipmod = rh.ref("track.clip")
@@ -33,7 +33,7 @@ def run(clip_name, denoise, max_frames=None):
     cfg.tracking["thermal"].denoise = bool(denoise)
     ex = cte.ClipTrackExtractor(cfg.tracking, cfg.use_opt_flow, False, calculate_thumbnail_info=True,
                                 max_frames=None)
-    clip = clipmod.Clip(cfg.tracking["thermal"], os.path.join(HERE, clip_name + ".cptv"))
+    clip = clipmod.Clip(cfg.tracking["thermal"], path or os.path.join(HERE, clip_name + ".cptv"))
     if max_frames is not None:
         # stop the reader after max_frames frames: a trackless clip for best_trackless_thumb
         import cptv_rs_python_bindings as rs
@@ -64,6 +64,9 @@ def run(clip_name, denoise, max_frames=None):
         best, score = thumb.get_thumbnail_info(clip, track)
         out["tracks"].append({
             "id": int(track.get_id()),
+            "start_frame": int(track.start_frame),
+            "first": [int(v) for v in (track.bounds_history[0].x, track.bounds_history[0].y,
+                                       track.bounds_history[0].width, track.bounds_history[0].height)],
             "stats": [[int(s.region.frame_number), int(s.contours), float(s.median_diff)] for s in stats],
             "max_mass": float(max_mass), "max_median_diff": float(max_md), "min_median_diff": float(min_md),
             "max_contour": int(max_contour),
@@ -91,5 +94,35 @@ def main():
         print(name, "trackless", len(out["tracks"]), out.get("n_region_history"), out.get("trackless"))
 
 
+def busy():
+    """Two seeded busy synthetic scenes (see make_golden_busy.py): ~20 tracks, many contour shapes."""
+    import tempfile
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, os.path.join(REPO, "classifier-pipeline_amd"))
+    from cpx import synth
+    from helpers import encode_cptv
+
+    T = 110
+    clips = []
+    with tempfile.TemporaryDirectory() as td:
+        for seed in (15, 42):
+            frames = synth.make_clip(np.random.default_rng(1000 + seed), T, max_blobs=8)
+            path = os.path.join(td, "c%d.cptv" % seed)
+            encode_cptv(path, frames, [16] * T, time_on=[100000 + 111 * i for i in range(T)], last_ffc=[40000] * T,
+                        model=b"lepton3")
+            out = run("busy%d" % seed, 0, path=path)
+            out["seed"] = seed
+            clips.append(out)
+            print("busy", seed, [(t["id"], len(t["stats"]), t["best"]["contours"]) for t in out["tracks"]])
+    with open(os.path.join(HERE, "busy_thumbs.json"), "w") as f:
+        json.dump({"frames": T, "clips": clips}, f)
+
+
 if __name__ == "__main__":
-    main()
+    if "--busy" in sys.argv:
+        busy()
+    else:
+        main()

@@ -243,3 +243,35 @@ def test_classify_oracle_matches_reference_on_busy_scenes():
             n_samples += x.shape[0]
             n_edge += g["edge_regions"]
     assert n_samples >= 30 and n_edge > 100
+
+
+def test_thumbnail_oracle_matches_reference_on_busy_scenes():
+    """Per-frame contour counts / median differences and the chosen thumbnail for the ~20 tracks of two busy synthetic
+    scenes (tests/golden/busy_thumbs.json: reference run, make_golden_thumbs.py --busy): ~700 more contours for the
+    findContours + TC89_L1 restatement than the fixture clips hold."""
+    import thumbnail_oracle as th
+    import track_oracle as to
+
+    with open(os.path.join(GOLDEN, "busy_thumbs.json")) as fh:
+        gold = json.load(fh)
+    T = gold["frames"]
+    t_on, ffc = [100000 + 111 * i for i in range(T)], [40000] * T
+    n = 0
+    for c in gold["clips"]:
+        frames = busy_clip(c["seed"], T)
+        out = to.track_clip(frames, t_on, ffc, None, to.OracleConfig("lepton3"), keep=True)
+        fr = out["frames"]
+        births = {(t.start_frame, t.bounds[0].x, t.bounds[0].y, t.bounds[0].width, t.bounds[0].height): t
+                  for t in out["tracks"]}
+        assert len(c["tracks"]) == len(out["tracks"])
+        for g in c["tracks"]:
+            t = births[(g["start_frame"],) + tuple(g["first"])]
+            stats, max_mass, max_md, min_md, max_contour = th.track_thumb_stats(
+                t.bounds, lambda q: fr[q]["mask"], lambda q: frames[q])
+            assert [[s.region.frame_number, s.contours, float(s.median_diff)] for s in stats] == g["stats"], g["id"]
+            best, score = th.thumbnail_info(t.bounds, lambda q: fr[q]["mask"], lambda q: frames[q])
+            gb = g["best"]
+            assert (best.region.frame_number, best.contours, float(best.median_diff), score) == (
+                gb["region"]["frame_number"], gb["contours"], gb["median_diff"], gb["score"])
+            n += len(stats)
+    assert n > 500

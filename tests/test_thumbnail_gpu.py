@@ -146,3 +146,37 @@ def test_random_masks_match_oracle():
         assert got[k]["median_diff"] == float(want[1]), (k, boxes[k])
     assert n_with > 200
     eng.close()
+
+
+def test_thumbnail_stats_match_reference_on_busy_scenes(golden_dir, tmp_path):
+    """The thumbnail kernels against the reference's per-frame statistics for ~20 tracks of two busy synthetic scenes
+    (tests/golden/busy_thumbs.json)."""
+    from cpx import synth
+    from cpx.classify.thumbnail import get_thumbnail_info, get_track_thumb_stats
+    from cpx.track.trackextractor import extract_file
+    from helpers import encode_cptv
+
+    with open(os.path.join(golden_dir, "busy_thumbs.json")) as fh:
+        gold = json.load(fh)
+    T = gold["frames"]
+    n = 0
+    for c in gold["clips"]:
+        frames = synth.make_clip(np.random.default_rng(1000 + c["seed"]), T, max_blobs=8)
+        p = tmp_path / ("busy%d.cptv" % c["seed"])
+        encode_cptv(p, frames, [16] * T, time_on=[100000 + 111 * i for i in range(T)], last_ffc=[40000] * T,
+                    model=b"lepton3")
+        clip, ex, meta = extract_file(p, _config(False), cache_to_disk=False, save_meta=False)
+        births = {(t.start_frame, t.bounds_history[0].x, t.bounds_history[0].y, t.bounds_history[0].width,
+                   t.bounds_history[0].height): t for t in clip.tracks}
+        assert len(births) == len(c["tracks"])
+        for g in c["tracks"]:
+            track = births[(g["start_frame"],) + tuple(g["first"])]
+            stats, max_mass, max_md, min_md, max_contour = get_track_thumb_stats(clip, track)
+            assert [[s.region.frame_number, s.contours, float(s.median_diff)] for s in stats] == g["stats"], g["id"]
+            best, score = get_thumbnail_info(clip, track)
+            gb = g["best"]
+            assert (best.region.frame_number, best.contours, float(best.median_diff)) == (
+                gb["region"]["frame_number"], gb["contours"], gb["median_diff"])
+            assert score == pytest.approx(gb["score"], rel=1e-12)
+            n += len(stats)
+    assert n > 500
