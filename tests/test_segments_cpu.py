@@ -1,0 +1,38 @@
+"""Segment selection (host side): cpx.ml_tools.datasetstructures.get_segments against what the
+REFERENCE's get_segments returned for the same seeded tracks with both random sources pinned
+(tests/golden/segments_golden.json, make_golden_segments.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+
+class _R:
+    def __init__(self, mass, blank, width, height, frame_number):
+        self.mass, self.blank, self.width, self.height, self.frame_number = mass, blank, width, height, frame_number
+
+
+def test_get_segments_equals_reference():
+    from cpx.ml_tools import datasetstructures as ds
+
+    with open(os.path.join(GOLDEN, "segments_golden.json")) as fh:
+        cases = json.load(fh)["cases"]
+    n_segments = 0
+    seen_types = set()
+    for c in cases:
+        regions = np.array([_R(m, b, w, h, c["start"] + i) for i, (m, b, w, h) in enumerate(c["regions"])],
+                           dtype=object)
+        np.random.seed(c["seed"])
+        segs, _ = ds.get_segments(7, c["track"] + 1, c["start"], regions=regions, segment_width=25,
+                                  segment_frame_spacing=9, ffc_frames=c["ffc"], repeats=1, min_frames=0,
+                                  segment_types=[ds.SegmentType[c["type"]]], max_segments=c["max_segments"],
+                                  dont_filter=c["dont_filter"], min_segments=c["min_segments"], seed=c["seed"])
+        got = [{"frames": [int(f) for f in s.frame_indices], "mass": int(s.mass), "weight": float(s.weight),
+                "filtered": bool(s.filtered)} for s in segs]
+        assert got == c["segments"], (c["type"], c["track"], c["seed"])
+        n_segments += len(got)
+        seen_types.add(c["type"])
+    assert n_segments > 200 and {"ALL_RANDOM_MASKED", "ALL_RANDOM"} <= seen_types
