@@ -36,3 +36,27 @@ def test_get_segments_equals_reference():
         n_segments += len(got)
         seen_types.add(c["type"])
     assert n_segments > 200 and {"ALL_RANDOM_MASKED", "ALL_RANDOM"} <= seen_types
+
+
+def test_hyperparams_defaults_equal_reference():
+    """cpx.ml_tools.hyperparams.HyperParams against the reference's defaults / derived values
+    (tests/golden/defaults_golden.json, make_golden_defaults.py)."""
+    from enum import Enum
+
+    from cpx.ml_tools.hyperparams import HyperParams
+
+    def plain(v):
+        if isinstance(v, Enum):
+            return v.name
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        return v
+
+    with open(os.path.join(GOLDEN, "defaults_golden.json")) as fh:
+        cases = json.load(fh)
+    for c in cases:
+        h = HyperParams(dict(c["input"]))
+        got = {k: plain(v) for k, v in h.items()}
+        assert got == c["params"], c["input"]
+        if c["output_dim"] is not None:
+            assert list(h.output_dim) == c["output_dim"], c["input"]
