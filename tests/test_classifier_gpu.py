@@ -139,3 +139,32 @@ def test_process_files_equals_process_file(tmp_path, model_dir, monkeypatch):
             for k in ta:
                 assert ta[k] == tb[k], (name, ta["id"], k)
         assert ma == mb, name
+
+
+def test_classify_existing_metadata_reuses_tracks_and_frames(tmp_path, model_dir):
+    """process_file(track=False, reuse_frames=True) (clipclassifier.py:186-214): tracks come from the recording's
+    metadata file, the frames are decoded and background-subtracted on the device without tracking, and the segments of
+    the earlier run are reused -> the same class scores as the run that tracked."""
+    from cpx.classify.clipclassifier import ClipClassifier
+
+    mdir, w = model_dir
+    cfg = _config(mdir)
+    src = tmp_path / "hedgehog.cptv"
+    shutil.copy(os.path.join(GOLDEN, "hedgehog.cptv"), src)
+    first = ClipClassifier(cfg).process_file(str(src), track=True)
+    assert first["tracks"] and first["tracks"][0]["predictions"]
+    # the metadata file as an upstream tracker would leave it: predictions stored as tags with prediction_frames
+    with open(src.with_suffix(".txt")) as fh:
+        meta = json.load(fh)
+    for t in meta["tracks"]:
+        pm = t["predictions"][0]
+        t["tags"] = [{"data": {"name": "wr-test", "prediction_frames": [p["frames"] for p in pm["predictions"]]}}]
+    with open(src.with_suffix(".txt"), "w") as fh:
+        json.dump(meta, fh)
+    second = ClipClassifier(cfg).process_file(str(src), track=False, reuse_frames=True)
+    assert len(second["tracks"]) == len(first["tracks"])
+    for a, b in zip(first["tracks"], second["tracks"]):
+        pa, pb = a["predictions"][0], b["predictions"][0]
+        assert pa["all_class_confidences"] == pb["all_class_confidences"] and pa["tag"] == pb["tag"]
+        assert [list(map(int, p["frames"])) for p in pa["predictions"]] == [
+            list(map(int, p["frames"])) for p in pb["predictions"]]
