@@ -177,3 +177,26 @@ def test_metadata_equals_reference_on_synthetic_recordings(tmp_path, key):
             assert got[k] == want[k], (key, k)
     # same score order
     assert [birth(t) for t in got["tracks"]] == [birth(t) for t in want["tracks"]]
+
+
+def test_retrack_keeps_the_tracks_of_the_metadata_file(tmp_path):
+    """extract_file(retrack=True) (trackextractor.py:150-176): tracks are loaded from the existing <clip>.txt, the frames
+    go through the device without association, and the metadata written again describes the same tracks."""
+    import json
+    import shutil
+
+    from cpx.config import Config
+    from cpx.track.trackextractor import extract_file
+    from helpers import GOLDEN
+
+    cfg = Config.get_defaults()
+    src = tmp_path / "possum.cptv"
+    shutil.copy(os.path.join(GOLDEN, "possum.cptv"), src)
+    clip1, _, meta1 = extract_file(src, cfg, False)
+    clip2, _, meta2 = extract_file(src, cfg, False, retrack=True)
+    assert clip2.from_metadata and len(clip2.tracks) == len(clip1.tracks) > 0
+    m1, m2 = _normalise_meta(meta1), _normalise_meta(meta2)
+    key = lambda t: [(p["x"], p["y"], p["width"], p["height"], p["frame_number"]) for p in t["positions"]]
+    assert [key(t) for t in m1["tracks"]] == [key(t) for t in m2["tracks"]]
+    assert [(t["frame_start"], t["frame_end"]) for t in m1["tracks"]] == [
+        (t["frame_start"], t["frame_end"]) for t in m2["tracks"]]
