@@ -22,9 +22,7 @@ class Interpreter:
     def __init__(self, model_file, run_over_network=False):
         self.model_file = Path(model_file)
         self.load_json(model_file)
-        if run_over_network:
-            raise NotImplementedError("run_over_network (HTTP /predict hop) is outside the cpx hot path")
-        self.run_over_network = False
+        self.run_over_network = bool(run_over_network)
         self.port = 8123
         self.id = None
         self.seed = None
@@ -54,6 +52,17 @@ class Interpreter:
 
     def predict(self, frames):
         raise NotImplementedError
+
+    def predict_over_network(self, data):
+        """POST the samples to a model server on this host (interpreter.py:53-62; server: cpx/servemodel.py)."""
+        import urllib.request
+
+        data = np.ascontiguousarray(data, dtype="<f4")
+        req = urllib.request.Request("http://127.0.0.1:%d/predict" % self.port, data=data.tobytes(),
+                                     headers={"content-type": "application/octet-stream"}, method="POST")
+        with urllib.request.urlopen(req) as resp:
+            body = resp.read()
+        return np.frombuffer(body, dtype=np.float32).reshape(len(data), -1)
 
     # ---- per-track entry points (interpreter.py:132-176) ----
     def classify_track(self, clip, track, segment_frames=None, min_segments=None):
@@ -214,12 +223,15 @@ class WRResNetInterpreter(Interpreter):
 
         from ..track.cliptrackextractor import default_engine
 
+        if self.run_over_network:  # the model lives in another process (cpx/servemodel.py), kerasmodel.py:856-859
+            host = frames.cpu().numpy() if isinstance(frames, torch.Tensor) else np.asarray(frames, dtype=np.float32)
+            return self.predict_over_network(host)
         if isinstance(frames, torch.Tensor) and frames.is_cuda:
             engine = self._engine or default_engine(frames.device.index or 0)
             x = frames
         else:
             engine = self._engine or default_engine(0)
-            x = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32)).to(engine.device)
+            x = torch.from_numpy(np.array(frames, dtype=np.float32, copy=True)).to(engine.device)
         _, probs = self._network(engine).forward(x.contiguous())
         return probs.cpu().numpy()
 

@@ -168,3 +168,42 @@ def test_classify_existing_metadata_reuses_tracks_and_frames(tmp_path, model_dir
         assert pa["all_class_confidences"] == pb["all_class_confidences"] and pa["tag"] == pb["tag"]
         assert [list(map(int, p["frames"])) for p in pa["predictions"]] == [
             list(map(int, p["frames"])) for p in pb["predictions"]]
+
+
+def test_model_server_wire_format(model_dir):
+    """cpx.servemodel: GET /ready, POST /predict with raw float32 [N,H,W,C] -> raw float32 [N,n_labels]
+    (piclassifier/servemodel.py:17-36), and the run_over_network client (interpreter.py:53-62) against it."""
+    import threading
+    import urllib.request
+
+    from cpx import servemodel
+    from cpx.config.config import ModelConfig
+    from cpx.ml_tools.interpreter import get_interpreter
+
+    mdir, w = model_dir
+    local = get_interpreter(ModelConfig.load({"id": 3, "name": "wr", "model_file": str(mdir / "wr.npz")}))
+    server = servemodel.make_server(local, 0)
+    port = server.server_address[1]
+    th = threading.Thread(target=server.serve_forever, daemon=True)
+    th.start()
+    try:
+        with urllib.request.urlopen("http://127.0.0.1:%d/ready" % port) as r:
+            assert json.loads(r.read()) == {"ready": True}
+        rng = np.random.default_rng(2)
+        x = rng.uniform(0, 255, (3, 160, 160, 2)).astype(np.float32)
+        want = local.predict(x)
+        req = urllib.request.Request("http://127.0.0.1:%d/predict" % port, data=x.tobytes(),
+                                     headers={"content-type": "application/octet-stream"}, method="POST")
+        with urllib.request.urlopen(req) as r:
+            assert r.headers["Content-Type"] == "application/octet-stream"
+            got = np.frombuffer(r.read(), dtype=np.float32).reshape(3, -1)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        remote = get_interpreter(ModelConfig.load({"id": 4, "name": "wr-net", "model_file": str(mdir / "wr.npz"),
+                                                   "port": port}), run_over_network=True, load_model=False)
+        assert np.array_equal(remote.predict(x), want)
+        bad = urllib.request.Request("http://127.0.0.1:%d/predict" % port, data=b"123", method="POST")
+        with pytest.raises(urllib.error.HTTPError):
+            urllib.request.urlopen(bad)
+    finally:
+        server.shutdown()
+        server.server_close()
