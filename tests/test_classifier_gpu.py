@@ -207,3 +207,52 @@ def test_model_server_wire_format(model_dir):
     finally:
         server.shutdown()
         server.server_close()
+
+
+def test_classify_service_socket(tmp_path, model_dir):
+    """cpx.classifyservice: one JSON job per Unix-socket connection -> metadata JSON (classifyservice.py:73-122),
+    a malformed job and a failing job -> {"error": ...}; the service survives both."""
+    import socket
+    import threading
+
+    from cpx.classifyservice import ClassifyService
+
+    mdir, w = model_dir
+    cfg = _config(mdir)
+    src = tmp_path / "hedgehog.cptv"
+    shutil.copy(os.path.join(GOLDEN, "hedgehog.cptv"), src)
+    path = str(tmp_path / "svc.sock")
+    service = ClassifyService(cfg)
+    th = threading.Thread(target=service.run, args=(path,), daemon=True)
+    th.start()
+    for _ in range(100):
+        if os.path.exists(path):
+            break
+        import time
+        time.sleep(0.05)
+
+    def ask(payload):
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        s.connect(path)
+        s.sendall(payload)
+        chunks = []
+        while True:
+            b = s.recv(65536)
+            if not b:
+                break
+            chunks.append(b)
+        s.close()
+        return json.loads(b"".join(chunks))
+
+    try:
+        assert "error" in ask(b'{"file": "x"}')                      # missing keys
+        out = ask(json.dumps({"file": str(tmp_path / "missing.cptv"), "cache": None, "track": True,
+                              "calculate_thumbnails": False}).encode())
+        assert out is False or "error" in out                        # the reference's process_file returns False
+        meta = ask(json.dumps({"file": str(src), "cache": None, "track": True,
+                               "calculate_thumbnails": True}).encode())
+        assert len(meta["tracks"]) == 1 and meta["tracks"][0]["predictions"][0]["model_id"] == 7
+        assert meta["tracks"][0]["thumbnail"]["contours"] > 0
+        assert os.path.exists(src.with_suffix(".txt"))
+    finally:
+        service.stop()
