@@ -157,15 +157,17 @@ class TrackingConfig(_Section):
             areas_of_interest=aoi, filter_regions_pre_match=raw["filter_regions_pre_match"],
             min_hist_diff=raw["min_hist_diff"],
         )
-        if type == "IR" and "track_min_offset" not in (raw.get("_explicit") or {}):
-            # the reference's IR defaults set the attribute (20) apart from the dict entry (7)
-            if f["track_min_offset"] == 7:
-                obj.track_min_offset = 20
         return obj
 
     @classmethod
     def get_defaults(cls):
-        return {t: cls.from_dict({}, t) for t in ("thermal", "IR")}
+        out = {t: cls.from_dict({}, t) for t in ("thermal", "IR")}
+        # the reference's in-code IR defaults (trackingconfig.py:179-208) change the filters / areas_of_interest
+        # dictionaries but leave the attributes they were copied to at construction, and set track_min_offset = 20
+        # on the attribute only; a configuration loaded from YAML takes the dictionary values (from_dict above)
+        ir = out["IR"]
+        ir.aoi_min_mass, ir.aoi_pixel_variance, ir.track_min_offset = 4.0, 2.0, 20
+        return out
 
     @classmethod
     def load(cls, tracking):

@@ -60,3 +60,56 @@ def test_hyperparams_defaults_equal_reference():
         assert got == c["params"], c["input"]
         if c["output_dim"] is not None:
             assert list(h.output_dim) == c["output_dim"], c["input"]
+
+
+def _plain(o):
+    from enum import Enum
+    from pathlib import Path
+
+    if isinstance(o, dict):
+        return {str(k): _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_plain(v) for v in o]
+    if isinstance(o, Enum):
+        return o.name
+    if isinstance(o, Path):
+        return str(o)
+    if hasattr(o, "as_dict") and not isinstance(o, (int, float, str, bool, type(None))):
+        return _plain(o.as_dict())
+    if hasattr(o, "__dict__") and not isinstance(o, (int, float, str, bool, type(None))):
+        return {k: _plain(v) for k, v in vars(o).items() if not k.startswith("_")}
+    return o
+
+
+@pytest.mark.parametrize("which", ["defaults", "overrides"])
+def test_config_equals_reference(which):
+    """cpx.config.Config (defaults, and a YAML with overrides in every section) against the reference's Config for the
+    same input (tests/golden/config_golden.json, make_golden_config.py): tracking (thermal + IR) and classify."""
+    import io
+
+    from cpx.config import Config
+
+    with open(os.path.join(GOLDEN, "config_golden.json")) as fh:
+        gold = json.load(fh)
+    cfg = Config.get_defaults() if which == "defaults" else Config.load_from_stream(io.StringIO(gold["overrides_yaml"]))
+    want = gold[which]
+
+    def check(got, exp, path):
+        if isinstance(exp, dict):
+            assert isinstance(got, dict), path
+            for k, v in exp.items():
+                assert k in got, path + "/" + k
+                check(got[k], v, path + "/" + k)
+        elif isinstance(exp, list):
+            assert len(got) == len(exp), path
+            for i, (g, e) in enumerate(zip(got, exp)):
+                check(g, e, "%s[%d]" % (path, i))
+        else:
+            assert got == exp or str(got) == str(exp), (path, got, exp)
+
+    for t in ("thermal", "IR"):
+        check(_plain(cfg.tracking[t]), want["tracking"][t], "tracking/" + t)
+    check(_plain(cfg.classify), want["classify"], "classify")
+    assert list(cfg.labels) == want["labels"]
+    assert (cfg.use_opt_flow, cfg.verbose, cfg.worker_threads, cfg.reprocess) == (
+        want["use_opt_flow"], want["verbose"], want["worker_threads"], want["reprocess"])
