@@ -113,3 +113,39 @@ def test_config_equals_reference(which):
     assert list(cfg.labels) == want["labels"]
     assert (cfg.use_opt_flow, cfg.verbose, cfg.worker_threads, cfg.reprocess) == (
         want["use_opt_flow"], want["verbose"], want["worker_threads"], want["reprocess"])
+
+
+@pytest.mark.parametrize("name,fs", [("possum", 32), ("hedgehog", 32), ("hedgehog", 64)])
+def test_track_prediction_metadata_equals_reference(name, fs):
+    """cpx.classify.trackprediction.TrackPrediction (via Interpreter.track_prediction_from_raw's low-evidence cap) fed
+    with the per-segment predictions of the classify goldens -> the metadata dictionary the reference's
+    TrackPrediction.get_metadata produced (tests/golden/*_classify_fs*.json)."""
+    from cpx.ml_tools.hyperparams import HyperParams
+    from cpx.ml_tools.interpreter import Interpreter
+    from cpx.ml_tools.tools import CustomJSONEncoder
+
+    z = np.load(os.path.join(GOLDEN, "%s_classify_fs%d.npz" % (name, fs)))
+    with open(os.path.join(GOLDEN, "%s_classify_fs%d.json" % (name, fs))) as fh:
+        gold = json.load(fh)
+    for ti, t in enumerate(gold["tracks"]):
+        preds = z["t%d_pred" % ti]
+        segs = z["t%d_segments" % ti]
+        masses = [p["mass"] for p in t["meta"]["predictions"]]
+        # through Interpreter.track_prediction_from_raw (interpreter.py:151-168): aggregation + low-evidence cap
+        class _I:
+            labels = gold["labels"]
+            params = HyperParams({"frame_size": fs})
+
+        tp = Interpreter.track_prediction_from_raw(_I(), t["track_id"], [np.array(s) for s in segs], preds, masses)
+        got = json.loads(json.dumps(tp.get_metadata(None), cls=CustomJSONEncoder))
+        got.pop("classify_time", None)
+        for p in got["predictions"]:
+            p.pop("predicted_time", None)
+        want = t["meta"]
+        assert [p["frames"] for p in got["predictions"]] == [p["frames"] for p in want["predictions"]]
+        for k in ("tag", "threshold_used", "confident", "confidence", "clarity"):
+            assert got[k] == pytest.approx(want[k], abs=1e-9) if isinstance(want[k], float) else got[k] == want[k], (ti, k)
+        for a, b in zip(got["predictions"], want["predictions"]):
+            assert a == b, ti
+        assert got["all_class_confidences"] == pytest.approx(want["all_class_confidences"], abs=1e-9), ti
+        assert np.allclose(tp.class_best_score, np.array(t["class_best_score"]), rtol=0, atol=1e-12)
