@@ -225,3 +225,46 @@ def test_crop_tile_matches_reference_on_busy_scenes(engine, golden_dir):
         assert [crc(x[i]) for i in range(ns)] == want, c["seed"]
         n += ns
     assert n >= 30
+
+
+@pytest.mark.parametrize("name,fs", [("possum", 32), ("hedgehog", 32), ("hedgehog", 64)])
+def test_aggregate_kernel_matches_reference_scores(engine, golden_dir, name, fs):
+    """cpx_aggregate_predictions on the per-segment predictions of the classify goldens -> the class_best_score the
+    reference's TrackPrediction produced (sum over segments, normalisation, low-evidence cap)."""
+    import ctypes as C
+    import json
+    import os
+
+    import torch
+
+    from cpx._lib import CROP_REQ_DTYPE
+
+    z = np.load(os.path.join(golden_dir, "%s_classify_fs%d.npz" % (name, fs)))
+    with open(os.path.join(golden_dir, "%s_classify_fs%d.json" % (name, fs))) as fh:
+        gold = json.load(fh)
+    labels = gold["labels"]
+    probs, sample_track, reqs, want = [], [], [], []
+    for ti, t in enumerate(gold["tracks"]):
+        p, segs = z["t%d_pred" % ti], z["t%d_segments" % ti]
+        for s in range(p.shape[0]):
+            probs.append(p[s])
+            sample_track.append(ti)
+            for tile, fn in enumerate(segs[s]):
+                reqs.append((int(fn), 0, 0, 1, 1, ti, len(probs) - 1, tile))
+        want.append(t["class_best_score"])
+    dev = engine.device
+    probs_d = torch.from_numpy(np.asarray(probs, np.float32)).to(dev)
+    st_d = torch.from_numpy(np.asarray(sample_track, np.int32)).to(dev)
+    reqs_d = engine._to_dev(np.array(reqs, dtype=CROP_REQ_DTYPE))
+    n_tracks, L = len(want), len(labels)
+    scores = torch.zeros((n_tracks, L), dtype=torch.float32, device=dev)
+    best = torch.zeros(n_tracks, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    rc = engine.lib.cpx_aggregate_predictions(
+        engine.h, C.c_void_p(probs_d.data_ptr()), C.c_void_p(st_d.data_ptr()), len(probs), C.c_void_p(reqs_d.data_ptr()),
+        n_tracks, L, labels.index("false-positive"), 5, C.c_void_p(scores.data_ptr()), C.c_void_p(best.data_ptr()))
+    assert rc == 0, engine._err()
+    engine.synchronize()
+    got = scores.cpu().numpy()
+    assert np.abs(got - np.asarray(want)).max() <= 2e-7
+    assert list(best.cpu().numpy()) == [int(np.argmax(w)) for w in want]
