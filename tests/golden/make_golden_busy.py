@@ -38,7 +38,7 @@ def main():
     cte = rh.ref("track.cliptrackextractor")
     clipmod = rh.ref("track.clip")
     tmp = tempfile.mkdtemp()
-    seeds, rows, offsets = [], [], [0]
+    seeds, rows, offsets, info = [], [], [0], []
     seed = 0
     n_plain = 0
     while seed <= LAST_SEED:
@@ -68,12 +68,22 @@ def main():
                 rows.append((t.get_id(), int(r.x), int(r.y), int(r.width), int(r.height), int(r.mass),
                              int(r.frame_number), int(bool(r.blank)), int(type(r.width) is int),
                              int(type(r.height) is int)))
+        info.append({"seed": seed - 1,
+                     "kept": [[int(t.get_id()), float(t.stats.score), int(t.stats.frames_moved),
+                               float(t.stats.max_offset), float(t.stats.average_mass), float(t.stats.delta_std)]
+                              for t in rc.tracks],
+                     "filtered": [[str(reason), int(t.get_id())] for reason, t in rc.filtered_tracks]})
         offsets.append(len(rows))
         print("seed", seed - 1, "tracks", len(tracks), "regions", offsets[-1] - offsets[-2])
     rows = np.asarray(rows, np.int32)
     print("python-int sized regions:", int((rows[:, 8] | rows[:, 9]).sum()), "blank:", int(rows[:, 7].sum()))
     np.savez_compressed(os.path.join(HERE, "busy_tracks.npz"), seeds=np.asarray(seeds, np.int32), rows=rows,
                         offsets=np.asarray(offsets, np.int32), frames=np.int32(T))
+    import json
+
+    with open(os.path.join(HERE, "busy_tracks_info.json"), "w") as fh:
+        json.dump(info, fh)
+    print("filter reasons:", sorted(set(r for c in info for r, _ in c["filtered"])))
 
 
 if __name__ == "__main__":

@@ -275,3 +275,27 @@ def test_thumbnail_oracle_matches_reference_on_busy_scenes():
                 gb["region"]["frame_number"], gb["contours"], gb["median_diff"], gb["score"])
             n += len(stats)
     assert n > 500
+
+
+def test_oracle_track_scores_and_rejects_on_busy_scenes():
+    """End-of-clip statistics, score order and reject reasons of the busy scenes against the reference
+    (tests/golden/busy_tracks_info.json)."""
+    import track_oracle as to
+
+    with open(os.path.join(GOLDEN, "busy_tracks_info.json")) as fh:
+        info = json.load(fh)
+    _, _, _, T = _busy_golden()
+    t_on, ffc = [100000 + 111 * i for i in range(T)], [40000] * T
+    n_rej = 0
+    for c in info:
+        out = to.track_clip(busy_clip(c["seed"], T), t_on, ffc, None, to.OracleConfig("lepton3"), keep=True)
+        got = [[t.id, t.stats["score"], t.stats["frames_moved"], t.stats["max_offset"], t.stats["average_mass"],
+                t.stats["delta_std"]] for t in out["tracks"]]
+        assert len(got) == len(c["kept"])
+        for g, w in zip(got, c["kept"]):
+            assert g[0] == w[0] and g[2] == w[2], c["seed"]
+            assert g[1] == pytest.approx(w[1], rel=1e-12) and g[3] == pytest.approx(w[3], rel=1e-12)
+            assert g[4] == pytest.approx(w[4], rel=1e-12) and g[5] == pytest.approx(w[5], rel=1e-6)
+        assert [[r, t.id] for r, t in out["filtered_tracks"]] == c["filtered"], c["seed"]
+        n_rej += len(c["filtered"])
+    assert n_rej > 0
