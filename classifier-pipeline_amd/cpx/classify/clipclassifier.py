@@ -14,6 +14,7 @@ from ..ml_tools.interpreter import get_interpreter
 from ..ml_tools.tools import CustomJSONEncoder, load_clip_metadata
 from ..track.clip import Clip
 from ..track.cliptrackextractor import ClipTrackExtractor
+from ..sharding import rank_world, shard_files
 from ..track.trackextractor import extract_file, extract_files
 from .thumbnail import best_trackless_thumb, get_thumbnail_info
 from .trackprediction import Predictions
@@ -66,15 +67,17 @@ class ClipClassifier:
                 self.process_file(filename, cache=cache, reuse_frames=reuse_frames, track=False,
                                   calculate_thumbnails=calculate_thumbnails)
             return
+        rank, world, local_rank = rank_world()  # under torchrun: this rank's share of the files, on its own GPU
+        todo = shard_files(todo, rank, world)
         for i in range(0, len(todo), self.batch_files):
             self.process_files(todo[i:i + self.batch_files], reuse_frames=reuse_frames,
-                               calculate_thumbnails=calculate_thumbnails)
+                               calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
 
-    def process_files(self, filenames, reuse_frames=None, calculate_thumbnails=False):
+    def process_files(self, filenames, reuse_frames=None, calculate_thumbnails=False, device=0):
         """process_file(track=True) for a list of recordings whose decode / tracking / association run as one device
         batch (trackextractor.extract_files); classification and metadata per file as in process_file."""
         results = []
-        tracked = extract_files(filenames, self.config, False, to_stdout=False, save_meta=False)
+        tracked = extract_files(filenames, self.config, False, to_stdout=False, save_meta=False, device=device)
         models = [self.model] if self.model else (self.config.classify.models or [])
         for filename, (clip, track_extractor, meta_data) in zip(filenames, tracked):
             meta_file = os.path.splitext(str(filename))[0] + ".txt"

@@ -20,6 +20,28 @@ def partition_clips(frame_counts, world_size):
     return [sorted(s) for s in shards]
 
 
+def rank_world():
+    """(rank, world_size, local_rank) of this process under torchrun / torch.distributed.run, (0, 1, 0) otherwise."""
+    import os
+
+    try:
+        return (int(os.environ.get("RANK", 0)), max(1, int(os.environ.get("WORLD_SIZE", 1))),
+                int(os.environ.get("LOCAL_RANK", 0)))
+    except ValueError:
+        return 0, 1, 0
+
+
+def shard_files(paths, rank, world_size):
+    """This rank's share of a list of recordings: longest-processing-time partition by file size (a CPTV file's size
+    tracks its frame count), identical on every rank; order of `paths` is kept inside a shard."""
+    import os
+
+    if world_size <= 1:
+        return list(paths)
+    sizes = [os.path.getsize(p) for p in paths]
+    return [paths[i] for i in partition_clips(sizes, world_size)[rank]]
+
+
 def gather_records(records, dist=None, device=None):
     """records: int32 tensor [n_local, width] (clip id in column 0).  Pads every
     rank to the global maximum with -1 rows, all_gathers once, returns the

@@ -8,6 +8,7 @@ import os
 from pathlib import Path
 
 from ..ml_tools import tools
+from ..sharding import rank_world, shard_files
 from .clip import Clip
 from .cliptrackextractor import ClipTrackExtractor
 
@@ -35,8 +36,13 @@ class TrackExtractor:
             for name in sorted(files):
                 if os.path.splitext(name)[1] == ".cptv":
                     todo.append(os.path.join(folder, name))
+        # under torchrun (one process per GPU) every rank takes its share of the files and its own device; each file's
+        # metadata is written by the rank that tracked it, no collective is needed
+        rank, world, local_rank = rank_world()
+        todo = shard_files(todo, rank, world)
         for i in range(0, len(todo), self.batch_files):
-            extract_files(todo[i:i + self.batch_files], self.config, self.cache_to_disk, self.retrack, to_stdout)
+            extract_files(todo[i:i + self.batch_files], self.config, self.cache_to_disk, self.retrack, to_stdout,
+                          device=local_rank if world > 1 else 0)
 
 
 def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True):
@@ -67,7 +73,8 @@ def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False
     return clip, track_extractor, metadata
 
 
-def extract_files(filenames, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True):
+def extract_files(filenames, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True,
+                  device=0):
     """extract_file for a list of files as one device batch (ClipTrackExtractor.parse_clips); same metadata per file.
     -> list of (clip, track_extractor, metadata)."""
     filenames = [Path(f) for f in filenames]
@@ -79,7 +86,7 @@ def extract_files(filenames, config, cache_to_disk, retrack=False, to_stdout=Fal
     if retrack:  # existing tracks are re-used per file: no batch form
         return [extract_file(f, config, cache_to_disk, retrack, to_stdout, max_frames, save_meta) for f in filenames]
     track_extractor = ClipTrackExtractor(config.tracking, config.use_opt_flow, cache_to_disk, verbose=config.verbose,
-                                         max_frames=max_frames)
+                                         max_frames=max_frames, device=device)
     track_extractor.host_images = False  # the consumers below (thumbnails, classification) read device memory
     clips, existing = [], []
     for filename in filenames:

@@ -24,6 +24,35 @@ def test_partition_is_balanced_and_complete():
     assert partition_clips([], 2) == [[], []]
 
 
+def test_file_shards_cover_a_directory_once(tmp_path, monkeypatch):
+    """The directory drivers under torchrun: every rank derives the same partition of the files (by size) from the
+    environment and takes its own share."""
+    sys.path.insert(0, os.path.join(REPO, "classifier-pipeline_amd"))
+    from cpx.sharding import rank_world, shard_files
+
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(23):
+        p = tmp_path / ("clip%02d.cptv" % i)
+        p.write_bytes(b"x" * int(rng.integers(1000, 90000)))
+        paths.append(str(p))
+    assert shard_files(paths, 0, 1) == paths
+    for world in (2, 8):
+        shards = [shard_files(paths, r, world) for r in range(world)]
+        assert sorted(p for s in shards for p in s) == sorted(paths)
+        sizes = [sum(os.path.getsize(p) for p in s) for s in shards]
+        assert max(sizes) - min(sizes) <= 90000
+        for s in shards:
+            assert s == sorted(s, key=paths.index)  # directory order kept inside a shard
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert rank_world() == (0, 1, 0)
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert rank_world() == (5, 8, 5)
+
+
 WORKER = textwrap.dedent(
     """
     import os, sys
