@@ -77,23 +77,30 @@ def threshold(src, thresh, maxval, type):
 
 
 def morphologyEx(src, op, kernel, *args, **kwargs):
-    """MORPH_CLOSE with the reference's *tuple* kernel (imageprocessing.py:247).
+    """MORPH_CLOSE / MORPH_OPEN with the reference's *tuple* kernel (imageprocessing.py:189,247).
 
-    The binding turns the tuple (5, 5) into a 2x1 CV_64F Mat [5;5]: an all-set
-    structuring element 1 px wide, 2 px tall, anchor (0,1):
-    dilate D[y] = max(I[y], I[y-1]); erode E[y] = min(D[y], D[y-1]); rows
-    outside the image are ignored by both.
+    The binding turns the tuple (5, 5) or (15, 15) into a 2x1 CV_64F Mat: an all-set structuring element 1 px wide,
+    2 px tall, anchor (0,1): dilate D[y] = max(I[y], I[y-1]); erode E[y] = min(I[y], I[y-1]); rows outside
+    the image are ignored by both.  close = erode(dilate(I)) (pinned by the golden, F3), open = dilate(erode(I)) (the
+    IR path, detect_objects_ir; same element, not covered by a golden).
     """
     src = np.asarray(src)
-    if op != MORPH_CLOSE:
-        raise NotImplementedError("shim: only MORPH_CLOSE")
+    if op not in (MORPH_CLOSE, MORPH_OPEN):
+        raise NotImplementedError("shim: only MORPH_CLOSE / MORPH_OPEN")
     if not isinstance(kernel, tuple) or len(kernel) != 2:
-        raise NotImplementedError("shim: only the tuple-kernel close")
-    d = src.copy()
-    d[1:] = np.maximum(src[1:], src[:-1])
-    e = d.copy()
-    e[1:] = np.minimum(d[1:], d[:-1])
-    return e
+        raise NotImplementedError("shim: only the tuple-kernel form")
+
+    def dilate(a):
+        d = a.copy()
+        d[1:] = np.maximum(a[1:], a[:-1])
+        return d
+
+    def erode(a):
+        e = a.copy()
+        e[1:] = np.minimum(a[1:], a[:-1])
+        return e
+
+    return erode(dilate(src)) if op == MORPH_CLOSE else dilate(erode(src))
 
 
 def connectedComponentsWithStats(image, *args, **kwargs):
@@ -124,18 +131,21 @@ def connectedComponentsWithStats(image, *args, **kwargs):
         remap[order + 1] = np.arange(1, n + 1, dtype=np.int32)
         labels[ys, xs] = remap[comp]
         newc = remap[comp]
+        big = np.iinfo(np.int64).max
+        mnx = np.full(n + 1, big, np.int64)
+        mny = np.full(n + 1, big, np.int64)
+        mxx = np.full(n + 1, -1, np.int64)
+        mxy = np.full(n + 1, -1, np.int64)
+        np.minimum.at(mnx, newc, xs)
+        np.minimum.at(mny, newc, ys)
+        np.maximum.at(mxx, newc, xs)
+        np.maximum.at(mxy, newc, ys)
+        area = np.bincount(newc, minlength=n + 1)
+        sx = np.bincount(newc, weights=xs, minlength=n + 1)  # exact: integer sums far below 2^53
+        sy = np.bincount(newc, weights=ys, minlength=n + 1)
         for i in range(1, n + 1):
-            sel = newc == i
-            cx = xs[sel]
-            cy = ys[sel]
-            stats[i] = (
-                cx.min(),
-                cy.min(),
-                cx.max() - cx.min() + 1,
-                cy.max() - cy.min() + 1,
-                cx.size,
-            )
-            cents[i] = (cx.sum() / cx.size, cy.sum() / cy.size)
+            stats[i] = (mnx[i], mny[i], mxx[i] - mnx[i] + 1, mxy[i] - mny[i] + 1, area[i])
+            cents[i] = (sx[i] / area[i], sy[i] / area[i])
     bys, bxs = np.nonzero(~fg)
     if bys.size:
         stats[0] = (

@@ -109,3 +109,35 @@ def encode_cptv(path, frames, widths, time_on=None, last_ffc=None, model=b"lepto
         out += b"F" + bytes([len(fl)]) + b"".join(fl) + payload
     with gzip.open(str(path), "wb") as f:
         f.write(bytes(out))
+
+
+# Seeded 640x480 foreground images for the IR detection stage (tests/golden/make_golden_ir.py)
+IR_CASES = [dict(seed=1, kind="blobs", n=6), dict(seed=2, kind="blobs", n=25), dict(seed=3, kind="fragments", n=60),
+            dict(seed=4, kind="noise", n=0), dict(seed=5, kind="empty", n=0), dict(seed=6, kind="fragments", n=200),
+            dict(seed=7, kind="stripes", n=0), dict(seed=8, kind="blobs", n=3)]
+
+
+def ir_mask(case, H=480, W=640):
+    """uint8 [H, W]: 0 / 255 foreground as a background subtractor would hand to detect_objects_ir."""
+    rng = np.random.default_rng(1000 + case["seed"])
+    img = np.zeros((H, W), np.uint8)
+    yy, xx = np.mgrid[:H, :W]
+    kind = case["kind"]
+    if kind == "blobs":
+        for _ in range(case["n"]):
+            cy, cx = rng.integers(0, H), rng.integers(0, W)
+            ry, rx = rng.integers(3, 60), rng.integers(3, 80)
+            img[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = 255
+        img[rng.random((H, W)) < 0.002] = 255          # speckle the open removes or keeps by its vertical rule
+    elif kind == "fragments":                           # a fragmented object: many small pieces close together
+        for _ in range(case["n"]):
+            cy, cx = rng.integers(60, H - 60), rng.integers(60, W - 60)
+            h, w = rng.integers(1, 14), rng.integers(1, 22)
+            img[cy:cy + h, cx:cx + w] = 255
+    elif kind == "noise":
+        img[rng.random((H, W)) < 0.08] = 255
+    elif kind == "stripes":
+        img[:, ::3] = 255
+        img[::5, :] = 0
+        img[200:260, :] = 255
+    return img
