@@ -304,6 +304,36 @@ class TrackEngine:
                            % int(bad[0]))
         return got
 
+    def ir_detect(self, images_dev, threshold=0, max_components=1024, want_labels=False):
+        """cpx_ir_detect over uint8 [n, H, W] device frames -> (counts int32[n], components COMPONENT_DTYPE
+        [n, max(counts)] (host; entries past counts[i] are unspecified), labels_dev int32 [n, H, W] or None).
+        Raises CpxError(CPX_ERR_OVERFLOW) when a frame has more than max_components components."""
+        t = self.torch
+        if images_dev.dtype != t.uint8 or images_dev.dim() != 3 or not images_dev.is_contiguous():
+            raise ValueError("ir_detect wants a contiguous uint8 [n, H, W] device tensor")
+        n, H, W = (int(v) for v in images_dev.shape)
+        comps = t.empty((n, max_components, COMPONENT_DTYPE.itemsize // 4), dtype=t.int32, device=self.device)
+        counts = t.zeros(n, dtype=t.int32, device=self.device)
+        status = t.zeros(n, dtype=t.int32, device=self.device)
+        labels = t.empty((n, H, W), dtype=t.int32, device=self.device) if want_labels else None
+        t.cuda.current_stream(self.device).synchronize()
+        rc = self.lib.cpx_ir_detect(self.h, C.c_void_p(images_dev.data_ptr()), n, W, H, int(threshold),
+                                    int(max_components), C.c_void_p(comps.data_ptr()), C.c_void_p(counts.data_ptr()),
+                                    C.c_void_p(status.data_ptr()),
+                                    C.c_void_p(labels.data_ptr()) if want_labels else None)
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        self.synchronize()
+        st = status.cpu().numpy()
+        cnt = counts.cpu().numpy()
+        bad = np.nonzero(st != 0)[0]
+        if bad.size:
+            raise CpxError(int(st[bad[0]]), "frame %d has %d components, max_components is %d"
+                           % (int(bad[0]), int(cnt[bad[0]]), max_components))
+        used = max(1, int(cnt.max()))  # only the filled part of the table crosses PCIe
+        host = comps[:, :used].contiguous().cpu().numpy().view(COMPONENT_DTYPE).reshape(n, used)
+        return cnt, host, labels
+
     def trackless_thumb(self, frames_dev, frame, background):
         """cpx_trackless_thumb -> (x, y) of the chosen 64x64 window."""
         t = self.torch

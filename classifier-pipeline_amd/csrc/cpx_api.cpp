@@ -50,6 +50,9 @@ struct cpx_handle {
   int stream_frames = -1;
   int stream_assoc_frames = -1;
   bool stream_filt_state = false;
+  unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
+  size_t ir_scratch_bytes = 0;
+  uint32_t* ir_bitmap = nullptr;
 };
 
 static_assert(sizeof(cpx_component) == 32, "cpx_component layout is part of the ABI");
@@ -259,6 +262,8 @@ void cpx_destroy(cpx_handle* h) {
   if (h->nlm_lut_dev) hipFree(h->nlm_lut_dev);
   if (h->sched_dev) hipFree(h->sched_dev);
   if (h->ws_assoc) hipFree(h->ws_assoc);
+  if (h->ir_scratch) hipFree(h->ir_scratch);
+  if (h->ir_bitmap) hipFree(h->ir_bitmap);
   for (auto& e : h->conv_events) {
     hipEventDestroy(e.e0);
     hipEventDestroy(e.e1);
@@ -973,6 +978,54 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
   }
   return cpx_cnn_head(h, cur, N, hh * ww, c_in, p.final_scale, p.final_shift, p.dense_w, p.dense_b, p.n_labels,
                       logits_dev, probs_dev);
+}
+
+int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int width, int height, int threshold,
+                  int max_components, cpx_component* comps_dev, int32_t* counts_dev, int32_t* status_dev,
+                  int32_t* labels_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!images_dev || !comps_dev || !counts_dev || !status_dev || n_frames < 1 || max_components < 1 || threshold < 0 ||
+      threshold > 255)
+    return fail(h, CPX_ERR_INVALID, "cpx_ir_detect: bad argument");
+  if (!cpx::ir_supported(width, height))
+    return fail(h, CPX_ERR_UNSUPPORTED, "cpx_ir_detect: width must be a multiple of 64 and width x height at most 640 x 480");
+  CPX_ENTER(h);
+  cpx::IrArgs a{};
+  a.W = width;
+  a.H = height;
+  a.threshold = threshold;
+  a.max_components = max_components;
+  a.images = images_dev;
+  a.comps = comps_dev;
+  a.counts = counts_dev;
+  a.status = status_dev;
+  a.labels = labels_dev;
+  // one slot per frame that can be resident at once (at most one workgroup of this LDS size per CU pair)
+  a.n_slots = n_frames < 256 ? n_frames : 256;
+  a.slot_bytes = cpx::ir_slot_bytes(width, height);
+  const size_t need = a.slot_bytes * (size_t)a.n_slots;
+  if (need > h->ir_scratch_bytes) {
+    CPX_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->ir_scratch) hipFree(h->ir_scratch);
+    h->ir_scratch = nullptr;
+    h->ir_scratch_bytes = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&h->ir_scratch), need) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(h, CPX_ERR_NOMEM, "cpx_ir_detect: scratch allocation failed");
+    }
+    h->ir_scratch_bytes = need;
+  }
+  if (!h->ir_bitmap && hipMalloc(reinterpret_cast<void**>(&h->ir_bitmap), 32) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(h, CPX_ERR_NOMEM, "cpx_ir_detect: scratch allocation failed");
+  }
+  CPX_HIP(h, hipMemsetAsync(h->ir_bitmap, 0, 32, h->stream));
+  a.slots = h->ir_scratch;
+  a.slot_bitmap = h->ir_bitmap;
+  if (cpx::launch_ir_detect(a, n_frames, h->stream) != 0)
+    return fail(h, CPX_ERR_HIP, "cpx_ir_detect: kernel configuration failed");
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
 }
 
 int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches) {

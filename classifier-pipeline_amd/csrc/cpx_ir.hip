@@ -1,0 +1,394 @@
+// cpx_ir.hip -- detection stage of the IR (640x480) tracker, SURVEY section 8 f4: detect_objects_ir
+// (ml_tools/imageprocessing.py:185-199) = uint8 image -> MORPH_OPEN with the reference's tuple kernel (a 1 x 2 element,
+// see cpx_track.hip phase 5 for the close) -> threshold -> 8-connected components with OpenCV's statistics and label
+// numbering (first 2x2 block in block-raster order).
+//
+// One workgroup per frame.  A 640 x 480 frame does not fit LDS as bytes, but everything after the threshold is binary:
+// the frame lives in LDS as bit rows (10 x u64 per row, 38 KB), the open is three word operations per word, and the
+// labelling works on RUNS: run r of row y is identified by row_off[y] + (number of run starts before it in the row),
+// found for any pixel with one popcount (word prefix counts are kept per row).  Union-find (atomicMin) over the runs,
+// per-component statistics with atomics, OpenCV's numbering from a bitmap of first blocks (a component's rank is
+// the number of set bits before its own: one popcount after a word prefix scan, no sort).
+// Tables: up to 8192 runs and 1024 components live in LDS.  A frame with more (dense noise) takes one of the
+// handle's scratch slots in HBM for the table that does not fit -- same code, global atomics -- so the only overflow
+// left is the caller's own max_components.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cpx_kernels.h"
+
+namespace cpx {
+
+namespace {
+typedef unsigned int u32;
+typedef unsigned long long u64;
+constexpr int IT = 1024;     // threads
+constexpr int RCAP = 8192;   // runs per frame held in LDS
+constexpr int CCAP = 1024;   // components per frame held in LDS
+
+struct IrLds {
+  u64* rowI;      // [max(H*NW, 4*CCAP)] thresholded input; dead after the open, reused for the statistics
+  u64* rowO;      // [H*NW] after the open
+  uint16_t* wpre; // [H*NW] run starts of the row before word w
+  u32* row_off;   // [H+1]
+  u32* par;       // [RCAP]
+  u64* kbits;     // [NKW] bitmap of first blocks
+  u32* kpre;      // [NKW] set bits before word k
+  u32* misc;      // [8]: 0 total runs, 1 components, 3 scratch slot + 1
+};
+
+// run starts of word (y, w)
+__device__ __forceinline__ u64 starts_of(const u64* O, int NW, int y, int w) {
+  const u64 o = O[y * NW + w];
+  const u64 carry = w > 0 ? (O[y * NW + w - 1] >> 63) : 0ull;
+  return o & ~((o << 1) | carry);
+}
+// index of the run of row y that contains (or, scanning left, last started at or before) pixel x
+__device__ __forceinline__ int run_index(const IrLds& L, int NW, int y, int x) {
+  const int w = x >> 6, b = x & 63;
+  const u64 s = starts_of(L.rowO, NW, y, w);
+  const u64 m = (b == 63) ? ~0ull : ((2ull << b) - 1ull);
+  return (int)L.row_off[y] + (int)L.wpre[y * NW + w] + __popcll(s & m) - 1;
+}
+__device__ __forceinline__ int uf_find(u32* par, int i) {
+  int p = (int)par[i];
+  while (p != i) {
+    i = p;
+    p = (int)par[i];
+  }
+  return i;
+}
+__device__ __forceinline__ void uf_union(u32* par, int a, int b) {
+  for (;;) {
+    a = uf_find(par, a);
+    b = uf_find(par, b);
+    if (a == b) return;
+    if (a > b) {
+      const int t = a;
+      a = b;
+      b = t;
+    }
+    const u32 old = atomicMin(&par[b], (u32)a);  // a < b
+    if (old == (u32)b) return;
+    b = (int)old;
+  }
+}
+
+// a free scratch slot (thread 0 only); holders never wait on anything, so the spin ends
+__device__ int slot_acquire(u32* bitmap, int nslots) {
+  for (;;) {
+    for (int s = 0; s < nslots; ++s) {
+      const u32 bit = 1u << (s & 31);
+      if (__hip_atomic_load(&bitmap[s >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) continue;
+      if (!(atomicOr(&bitmap[s >> 5], bit) & bit)) return s;
+    }
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+__device__ void slot_release(u32* bitmap, int s) {
+  __threadfence();
+  atomicAnd(&bitmap[s >> 5], ~(1u << (s & 31)));
+}
+
+// ---- labelling: unions at the first pixel of every contact with the row above, flatten, roots -> component slots.
+// Afterwards par[i] = R + (component slot of run i) for every run.
+__device__ __forceinline__ void label_runs(const IrLds& L, u32* par, int R, int W, int H, int NW, int tid) {
+  for (int i = tid; i < R; i += IT) par[i] = (u32)i;
+  __syncthreads();
+  for (int i = tid; i < H * NW; i += IT) {
+    const int y = i / NW, w = i - y * NW;
+    if (y == 0) continue;
+    const u64 oy = L.rowO[i];
+    if (!oy) continue;
+    const u64 up = L.rowO[i - NW];
+    const u64 upl = (up << 1) | (w > 0 ? (L.rowO[i - NW - 1] >> 63) : 0ull);       // pixel x-1 of the row above
+    const u64 upr = (up >> 1) | (w + 1 < NW ? (L.rowO[i - NW + 1] << 63) : 0ull);  // pixel x+1 of the row above
+    const u64 kn = oy & up;
+    const u64 kn_prev = w > 0 ? ((L.rowO[i - 1] & L.rowO[i - NW - 1]) >> 63) : 0ull;
+    u64 first = kn & ~((kn << 1) | kn_prev);  // one union per stretch of vertical contact
+    while (first) {
+      const int b = __ffsll((long long)first) - 1;
+      first &= first - 1;
+      const int x = w * 64 + b;
+      uf_union(par, run_index(L, NW, y, x), run_index(L, NW, y - 1, x));
+    }
+    u64 knw = oy & upl & ~up;  // diagonal-only contacts
+    while (knw) {
+      const int b = __ffsll((long long)knw) - 1;
+      knw &= knw - 1;
+      const int x = w * 64 + b;
+      uf_union(par, run_index(L, NW, y, x), run_index(L, NW, y - 1, x - 1));
+    }
+    u64 kne = oy & upr & ~up;
+    while (kne) {
+      const int b = __ffsll((long long)kne) - 1;
+      kne &= kne - 1;
+      const int x = w * 64 + b;
+      uf_union(par, run_index(L, NW, y, x), run_index(L, NW, y - 1, x + 1));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < R; i += IT) par[i] = (u32)uf_find(par, i);  // roots never change here
+  __syncthreads();
+  for (int i = tid; i < R; i += IT)
+    if (par[i] == (u32)i) par[i] = (u32)R + atomicAdd(&L.misc[1], 1u);  // root: its slot, marked by >= R
+  __syncthreads();
+  for (int i = tid; i < R; i += IT) {
+    const u32 p = par[i];
+    if (p < (u32)R) par[i] = par[p];  // p is a root: already encoded
+  }
+  __syncthreads();
+}
+
+// ---- statistics, numbering, outputs.  st: [8][cs] u32: area (then label), minx, maxx, miny, maxy, sumx, sumy, key
+__device__ __forceinline__ void measure_runs(const IrLds& L, const u32* par, u32* st, int cs, int R, int C, int W, int H,
+                                             int NW, int tid, cpx_component* out, int32_t* lab) {
+  for (int i = tid; i < C; i += IT) {
+    st[0 * cs + i] = 0;
+    st[1 * cs + i] = 0xFFFFFFFFu;
+    st[2 * cs + i] = 0;
+    st[3 * cs + i] = 0xFFFFFFFFu;
+    st[4 * cs + i] = 0;
+    st[5 * cs + i] = 0;
+    st[6 * cs + i] = 0;
+    st[7 * cs + i] = 0xFFFFFFFFu;
+  }
+  const int BW2 = (W + 1) >> 1, NKW = (BW2 * ((H + 1) >> 1) + 63) >> 6;
+  for (int i = tid; i < NKW; i += IT) L.kbits[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < H * NW; i += IT) {
+    const int y = i / NW, w = i - y * NW;
+    u64 s = starts_of(L.rowO, NW, y, w);
+    int k = 0;
+    while (s) {
+      const int b = __ffsll((long long)s) - 1;
+      s &= s - 1;
+      const int xs = w * 64 + b;
+      const u64 rest = ~L.rowO[i] >> b;  // bit 0 <-> pixel xs, which is set: bit 0 of rest is clear
+      int len;
+      if (rest) {
+        len = __ffsll((long long)rest) - 1;
+      } else {
+        len = 64 - b;
+        for (int ww = w + 1; ww < NW; ++ww) {
+          const u64 inv = ~L.rowO[y * NW + ww];
+          if (inv) {
+            len += __ffsll((long long)inv) - 1;
+            break;
+          }
+          len += 64;
+        }
+      }
+      const int xe = xs + len - 1;
+      const int run = (int)L.row_off[y] + (int)L.wpre[i] + k;
+      ++k;
+      const int c = (int)(par[run] - (u32)R);
+      atomicAdd(&st[0 * cs + c], (u32)len);
+      atomicMin(&st[1 * cs + c], (u32)xs);
+      atomicMax(&st[2 * cs + c], (u32)xe);
+      atomicMin(&st[3 * cs + c], (u32)y);
+      atomicMax(&st[4 * cs + c], (u32)y);
+      atomicAdd(&st[5 * cs + c], (u32)((xs + xe) * len / 2));
+      atomicAdd(&st[6 * cs + c], (u32)(y * len));
+      atomicMin(&st[7 * cs + c], (u32)((y >> 1) * BW2 + (xs >> 1)));
+    }
+  }
+  __syncthreads();
+  // OpenCV numbers components by their first 2x2 block in block-raster order; all pixels of a block belong to one
+  // 8-connected component, so the keys are distinct and a component's rank is the number of keys below its own
+  for (int c = tid; c < C; c += IT) {
+    const u32 key = st[7 * cs + c];
+    atomicOr(&L.kbits[key >> 6], 1ull << (key & 63));
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int per = (NKW + 63) >> 6;
+    int sum = 0;
+    for (int k = tid * per; k < min(NKW, (tid + 1) * per); ++k) sum += __popcll(L.kbits[k]);
+    int incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (tid >= d) incl += v;
+    }
+    int run = incl - sum;
+    for (int k = tid * per; k < min(NKW, (tid + 1) * per); ++k) {
+      L.kpre[k] = (u32)run;
+      run += __popcll(L.kbits[k]);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += IT) {
+    const u32 key = st[7 * cs + c];
+    const int rank = (int)L.kpre[key >> 6] + __popcll(L.kbits[key >> 6] & ((1ull << (key & 63)) - 1ull));
+    cpx_component o;
+    o.x = (int)st[1 * cs + c];
+    o.y = (int)st[3 * cs + c];
+    o.width = (int)st[2 * cs + c] - o.x + 1;
+    o.height = (int)st[4 * cs + c] - o.y + 1;
+    o.area = (int)st[0 * cs + c];
+    o.sum_x = (int)st[5 * cs + c];
+    o.sum_y = (int)st[6 * cs + c];
+    o.pixel_variance = 0.0f;
+    out[rank] = o;
+    st[0 * cs + c] = (u32)(rank + 1);  // the area is written out: its cell carries the label for the image pass
+  }
+  if (!lab) return;
+  __syncthreads();
+  for (int q = tid; q < ((W * H) >> 2); q += IT) {  // every pixel finds its run with one popcount
+    const int p0 = q << 2;
+    const int y = p0 / W, x0 = p0 - y * W;
+    const u64 o = L.rowO[y * NW + (x0 >> 6)];
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = x0 + j;
+      v[j] = 0;
+      if ((o >> (x & 63)) & 1ull) v[j] = (int)st[par[run_index(L, NW, y, x)] - (u32)R];
+    }
+    *reinterpret_cast<int4*>(lab + p0) = make_int4(v[0], v[1], v[2], v[3]);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(IT) void cpx_ir_detect_kernel(IrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int f = blockIdx.x;
+  const int W = a.W, H = a.H, NW = W >> 6, P = W * H;
+  const int tid = threadIdx.x;
+  const int NKW = (((W + 1) >> 1) * ((H + 1) >> 1) + 63) >> 6;
+  IrLds L;
+  L.rowI = reinterpret_cast<u64*>(smem);
+  L.rowO = L.rowI + (H * NW > CCAP * 4 ? H * NW : CCAP * 4);  // the statistics ([8][CCAP] u32) reuse the input rows
+  L.kbits = L.rowO + H * NW;
+  L.kpre = reinterpret_cast<u32*>(L.kbits + NKW);
+  L.par = L.kpre + ((NKW + 1) & ~1);
+  L.row_off = L.par + RCAP;
+  L.misc = L.row_off + ((H + 1 + 3) & ~3);
+  L.wpre = reinterpret_cast<uint16_t*>(L.misc + 8);
+  const unsigned char* img = a.images + (size_t)f * P;
+
+  // ---- 1. np.uint8 image -> bit rows of (pixel > threshold); min / max of the 1 x 2 open commute with the threshold
+  for (int i = tid; i < H * NW; i += IT) {
+    const uint4* src = reinterpret_cast<const uint4*>(img + (size_t)i * 64);
+    u64 bits = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = src[q];
+      const u32 ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+          bits |= (u64)(((ws[k] >> (8 * bb)) & 0xFFu) > (u32)a.threshold) << (q * 16 + k * 4 + bb);
+    }
+    L.rowI[i] = bits;
+  }
+  if (tid < 8) L.misc[tid] = 0;
+  __syncthreads();
+  // ---- 2. MORPH_OPEN with the 1 x 2 element: erode E[y] = I[y] & I[y-1] (E[0] = I[0]), dilate O[y] = E[y] | E[y-1]
+  for (int i = tid; i < H * NW; i += IT) {
+    const int y = i / NW;
+    const u64 i0 = L.rowI[i];
+    const u64 i1 = y >= 1 ? L.rowI[i - NW] : ~0ull;
+    const u64 i2 = y >= 2 ? L.rowI[i - 2 * NW] : ~0ull;
+    const u64 e0 = i0 & i1;                    // E[y]   (row -1 is outside: & with all ones)
+    const u64 e1 = y >= 1 ? (i1 & i2) : 0ull;  // E[y-1] (absent for y = 0)
+    L.rowO[i] = e0 | e1;
+  }
+  __syncthreads();
+  // ---- 3. run starts per row: word prefix counts, row offsets ----
+  for (int y = tid; y < H; y += IT) {
+    int c = 0;
+    for (int w = 0; w < NW; ++w) {
+      L.wpre[y * NW + w] = (uint16_t)c;
+      c += __popcll(starts_of(L.rowO, NW, y, w));
+    }
+    L.row_off[y + 1] = (u32)c;  // per-row count for now
+  }
+  __syncthreads();
+  if (tid == 0) {
+    u32 acc = 0;
+    L.row_off[0] = 0;
+    for (int y = 0; y < H; ++y) {
+      const u32 c = L.row_off[y + 1];
+      acc += c;
+      L.row_off[y + 1] = acc;
+    }
+    L.misc[0] = acc;
+    if (acc > (u32)RCAP) L.misc[3] = (u32)slot_acquire(a.slot_bitmap, a.n_slots) + 1u;
+  }
+  __syncthreads();
+  const int R = (int)L.misc[0];
+  const bool big_runs = R > RCAP;
+  // scratch slot: par u32 [P/2 + 64], statistics u32 [8][cs_big]
+  const int cs_big = ((W + 1) >> 1) * ((H + 1) >> 1);
+  u32* slot = L.misc[3] ? reinterpret_cast<u32*>(a.slots + (size_t)(L.misc[3] - 1) * a.slot_bytes) : nullptr;
+  // ---- 4. labelling ----
+  if (!big_runs)
+    label_runs(L, L.par, R, W, H, NW, tid);
+  else
+    label_runs(L, slot, R, W, H, NW, tid);
+  const int C = (int)L.misc[1];
+  if (C > a.max_components) {  // the caller's table is too small: report, never truncate
+    if (tid == 0) {
+      a.counts[f] = C;
+      a.status[f] = CPX_ERR_OVERFLOW;
+      if (L.misc[3]) slot_release(a.slot_bitmap, (int)L.misc[3] - 1);
+    }
+    return;
+  }
+  const bool big_comps = C > CCAP;
+  if (big_comps && !big_runs) {
+    if (tid == 0) L.misc[3] = (u32)slot_acquire(a.slot_bitmap, a.n_slots) + 1u;
+    __syncthreads();
+    slot = reinterpret_cast<u32*>(a.slots + (size_t)(L.misc[3] - 1) * a.slot_bytes);
+  }
+  // ---- 5. statistics, numbering, outputs ----
+  cpx_component* out = a.comps + (size_t)f * a.max_components;
+  int32_t* lab = a.labels ? a.labels + (size_t)f * P : nullptr;
+  u32* st_lds = reinterpret_cast<u32*>(L.rowI);
+  u32* st_big = slot + (P / 2 + 64);
+  if (!big_runs && !big_comps)
+    measure_runs(L, L.par, st_lds, CCAP, R, C, W, H, NW, tid, out, lab);
+  else if (big_runs && !big_comps)
+    measure_runs(L, slot, st_lds, CCAP, R, C, W, H, NW, tid, out, lab);
+  else if (!big_runs)
+    measure_runs(L, L.par, st_big, cs_big, R, C, W, H, NW, tid, out, lab);
+  else
+    measure_runs(L, slot, st_big, cs_big, R, C, W, H, NW, tid, out, lab);
+  __syncthreads();
+  if (tid == 0) {
+    a.counts[f] = C;
+    a.status[f] = 0;
+    if (L.misc[3]) slot_release(a.slot_bitmap, (int)L.misc[3] - 1);
+  }
+}
+
+size_t ir_lds_bytes(int W, int H) {
+  const size_t NW = (size_t)W >> 6, HW = (size_t)H * NW;
+  const size_t in_words = HW > (size_t)CCAP * 4 ? HW : (size_t)CCAP * 4;
+  const size_t NKW = ((size_t)((W + 1) >> 1) * ((H + 1) >> 1) + 63) >> 6;
+  return (in_words + HW + NKW) * 8 + ((NKW + 1) & ~(size_t)1) * 4 + (size_t)RCAP * 4 + (((size_t)H + 1 + 3) & ~(size_t)3) * 4 +
+         32 + ((HW + 7) & ~(size_t)7) * 2;
+}
+int ir_supported(int W, int H) {
+  return W >= 64 && (W % 64) == 0 && H >= 1 && ir_lds_bytes(W, H) <= 160 * 1024 - 1024;
+}
+size_t ir_slot_bytes(int W, int H) {
+  const size_t P = (size_t)W * H, cs = (size_t)((W + 1) >> 1) * ((H + 1) >> 1);
+  return ((P / 2 + 64 + 8 * cs) * 4 + 255) & ~(size_t)255;
+}
+
+int launch_ir_detect(const IrArgs& a, int n_frames, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_ir_detect_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
+      return -1;
+    configured = true;
+  }
+  hipLaunchKernelGGL(cpx_ir_detect_kernel, dim3(n_frames), dim3(IT), ir_lds_bytes(a.W, a.H), s, a);
+  return 0;
+}
+
+}  // namespace cpx

@@ -220,6 +220,22 @@ struct TracklessArgs {
 };
 int launch_trackless(const TracklessArgs& a, hipStream_t s);
 
+struct IrArgs {
+  int W, H, threshold, max_components;
+  const unsigned char* images;  // [n, H, W]
+  cpx_component* comps;         // [n][max_components]
+  int32_t* counts;              // [n]
+  int32_t* status;              // [n]
+  int32_t* labels;              // [n, H, W] or nullptr
+  unsigned char* slots;         // n_slots scratch slots of slot_bytes for frames whose tables do not fit LDS
+  size_t slot_bytes;
+  uint32_t* slot_bitmap;        // [8] busy bits
+  int n_slots;
+};
+int launch_ir_detect(const IrArgs& a, int n_frames, hipStream_t s);
+int ir_supported(int W, int H);
+size_t ir_slot_bytes(int W, int H);
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

@@ -337,6 +337,20 @@ int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* la
  * walked in raster order with the reference's update rule.  out_dev int32[2] = x, y of the chosen window. */
 int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, int background, int32_t* out_dev);
 
+/* ---- IR detection stage (partial) ------------------------------------------------------
+ * Replaces detect_objects_ir (ml_tools/imageprocessing.py:185-199) for n frames of `width` x `height` uint8 pixels (the
+ * foreground image a background subtractor produced; 640 x 480 in the reference): MORPH_OPEN with the reference's
+ * tuple kernel, threshold (pixel > threshold), 8-connected components with OpenCV's statistics and numbering.
+ * width must be a multiple of 64 (<= 640), height <= 480.  comps_dev [n][max_components] in label order (label i+1 =
+ * entry i; centroid = sum / area), counts_dev [n], status_dev [n] = 0 or CPX_ERR_OVERFLOW (the frame has more than
+ * max_components components; counts_dev then holds the true count and nothing else of the frame is written);
+ * labels_dev optional int32 [n, height, width].  Frames with up to 8192 pixel runs and 1024 components are labelled
+ * entirely in LDS; busier ones use scratch the handle allocates (up to 256 slots of ~3 MB at 640 x 480).  The IR background model (cv2 MOG2) and the merge of fragments
+ * (irtrackextractor.py:324-389, host side in cpx/track/irdetect.py) are not part of this call. */
+int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int width, int height, int threshold,
+                  int max_components, cpx_component* comps_dev, int32_t* counts_dev, int32_t* status_dev,
+                  int32_t* labels_dev);
+
 /* ---- CNN forward building blocks (WR-ResNet, ml_tools/resnet/wr_resnet.py:5-98) -----------
  * Replaces tf.keras Conv2D(groups) / BatchNormalization / Activation / Add / GlobalAveragePooling2D /
  * Dense as used by KerasModel.predict (ml_tools/kerasmodel.py:856-859).  Activations NHWC float32.

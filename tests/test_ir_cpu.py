@@ -27,3 +27,28 @@ def test_ir_oracle_matches_reference():
         assert [[int(v) for v in r] for r in merged] == g["merged"], g["case"]
         merged_total += len(merged)
     assert merged_total > 20
+
+
+def test_host_merge_components_matches_reference():
+    """The product's host-side merge (cpx/track/irdetect.py) on the reference's own component statistics."""
+    from cpx.track import irdetect
+    import ir_oracle as iro
+
+    with open(os.path.join(GOLDEN, "ir_detect_golden.json")) as fh:
+        gold = json.load(fh)
+    n = 0
+    for g in gold:
+        _, _, stats = iro.detect_objects_ir(ir_mask(g["case"]), threshold=0)
+        for scale in (None, 0.5, 2):
+            want = iro.merge_components(stats[1:].copy(), scale)
+            got = irdetect.merge_components(stats[1:].copy(), scale)
+            assert [[int(v) for v in r] for r in got] == [[int(v) for v in r] for r in want], (g["case"], scale)
+            if scale is None:
+                assert [[int(v) for v in r] for r in got] == g["merged"], g["case"]
+        n += len(g["merged"])
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        a = rng.integers(0, 60, 5)
+        b = rng.integers(0, 60, 5)
+        assert irdetect.rect_distance(a, b) == iro.rect_distance(a, b)
+    assert n > 20

@@ -1,0 +1,127 @@
+"""IR detection stage on the GPU: cpx_ir_detect against oracle/ir_oracle.py and against what the
+reference's own detect_objects_ir returned (tests/golden/ir_detect_golden.json); host merge_components against both.
+Integer work: bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, IR_CASES, crc, ir_mask
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3")
+    yield eng
+    eng.close()
+
+
+def _stats_of(comps, n):
+    c = comps[:n]
+    return np.stack([c["x"], c["y"], c["width"], c["height"], c["area"]], axis=1).astype(np.int32)
+
+
+def test_ir_detect_matches_reference_golden(engine):
+    import torch
+
+    from cpx.engine import CpxError
+    from cpx.track import irdetect
+
+    with open(os.path.join(GOLDEN, "ir_detect_golden.json")) as fh:
+        gold = json.load(fh)
+    checked = 0
+    for g in gold:
+        img = ir_mask(g["case"])
+        dev = torch.from_numpy(img).to(engine.device)
+        if g["n"] > 1024:  # the caller's table too small: CPX_ERR_OVERFLOW with the true count, nothing truncated
+            with pytest.raises(CpxError) as ei:
+                engine.ir_detect(dev[None], 0, 1024)
+            assert ei.value.code == -5 and "has %d components" % g["n"] in str(ei.value), ei.value
+        n, labels, stats = irdetect.detect_objects_ir(engine, dev, threshold=0, max_components=20000,
+                                                      want_labels=True)
+        assert n - 1 == g["n"], g["case"]
+        assert crc(labels.cpu().numpy().astype(np.int32)) == g["mask_crc"], g["case"]
+        assert crc(stats[1:].astype(np.int32)) == g["stats_crc"], g["case"]
+        merged = irdetect.merge_components(stats[1:].copy())
+        assert [[int(v) for v in r] for r in merged] == g["merged"], g["case"]
+        checked += 1
+    assert checked == len(IR_CASES)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (120, 192), (33, 64), (480, 64)])
+def test_ir_detect_matches_oracle_random(engine, shape):
+    import torch
+
+    import ir_oracle as iro
+
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    frames = []
+    for k in range(6):
+        img = np.zeros((H, W), np.uint8)
+        dens = [0.0, 0.01, 0.3, 0.6, 0.9, 1.0][k]
+        img[rng.random((H, W)) < dens] = rng.integers(1, 256)
+        if k == 2:  # values at and around a non-zero threshold
+            img = rng.integers(0, 8, size=(H, W)).astype(np.uint8)
+        frames.append(img)
+    thr = 3
+    dev = torch.from_numpy(np.stack(frames)).to(engine.device)
+    for threshold in (0, thr):
+        oracle = [iro.detect_objects_ir(f, threshold=threshold) for f in frames]
+        cap = (H + 1) // 2 * ((W + 1) // 2)  # the most components an 8-connected labelling can have
+        counts, comps, labels = engine.ir_detect(dev, threshold, cap, want_labels=True)  # LDS and scratch frames mixed
+        for i in range(len(frames)):
+            n, mask, stats = oracle[i]
+            assert counts[i] == n - 1, (shape, i, threshold)
+            assert np.array_equal(labels[i].cpu().numpy(), mask.astype(np.int32)), (shape, i, threshold)
+            assert np.array_equal(_stats_of(comps[i], counts[i]), stats[1:, :5].astype(np.int32))
+            if n > 1:  # centroids: OpenCV's are sum / area in float64
+                c = comps[i][: counts[i]]
+                lab = mask.astype(np.int64)
+                yy, xx = np.mgrid[:H, :W]
+                sx = np.bincount(lab.ravel(), weights=xx.ravel(), minlength=n)[1:]
+                sy = np.bincount(lab.ravel(), weights=yy.ravel(), minlength=n)[1:]
+                assert np.array_equal(c["sum_x"], sx.astype(np.int64)) and np.array_equal(c["sum_y"], sy.astype(np.int64))
+
+
+def test_ir_detect_batch_and_arguments(engine):
+    import torch
+
+    from cpx.engine import CpxError
+
+    imgs = np.stack([ir_mask(c) for c in IR_CASES if c["kind"] in ("blobs", "empty")])
+    dev = torch.from_numpy(imgs).to(engine.device)
+    counts, comps, _ = engine.ir_detect(dev, 0, 1024)
+    for i in range(len(imgs)):
+        c1, k1, _ = engine.ir_detect(dev[i:i + 1], 0, 1024)
+        assert c1[0] == counts[i] and np.array_equal(k1[0][: c1[0]], comps[i][: counts[i]])
+    # a caller's own limit below the frame's component count is an overflow, not a truncation
+    busy = int(np.argmax(counts))
+    with pytest.raises(CpxError) as ei:
+        engine.ir_detect(dev[busy:busy + 1], 0, int(counts[busy]) - 1)
+    assert ei.value.code == -5
+    # every table past LDS at once: after the (downward-shifting) open two rows in three are set in every other
+    # column -- 160 x 320 components of two pixels, 51200 runs per frame; three such frames share the scratch slots
+    import ir_oracle as iro
+
+    worst = np.zeros((480, 640), np.uint8)
+    worst[0::3, 0::2] = 255
+    worst[2::3, 0::2] = 255
+    n, mask, stats = iro.detect_objects_ir(worst, threshold=0)
+    assert n - 1 == 160 * 320
+    many = torch.from_numpy(np.stack([worst] * 3 + [imgs[0]])).to(engine.device)
+    counts4, comps4, labels4 = engine.ir_detect(many, 0, 160 * 320, want_labels=True)
+    assert counts4.tolist() == [160 * 320] * 3 + [int(counts[0])]
+    for i in range(3):
+        assert np.array_equal(labels4[i].cpu().numpy(), mask.astype(np.int32))
+        assert np.array_equal(_stats_of(comps4[i], counts4[i]), stats[1:, :5].astype(np.int32))
+    assert np.array_equal(comps4[3][: counts[0]], comps[0][: counts[0]])
+    with pytest.raises(CpxError):  # width not a multiple of 64
+        engine.ir_detect(torch.zeros((1, 48, 100), dtype=torch.uint8, device=engine.device), 0, 16)
+    with pytest.raises(ValueError):
+        engine.ir_detect(torch.zeros((48, 128), dtype=torch.uint8, device=engine.device), 0, 16)
