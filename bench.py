@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--cnn-chunk", type=int, default=2048, help="samples per CNN forward (54 GB of activations at 2048)")
     ap.add_argument("--frame-size", type=int, default=32, choices=(32, 64),
                     help="side of one tile of the 5x5 network input (SURVEY 8(d) config 3 asks for 32 and 64)")
+    ap.add_argument("--cnn-math", choices=("bf16x3", "f32"), default="bf16x3",
+                    help="how the 3x3 stride-1 convolutions multiply their float32 operands (include/cpx.h: cpx_set_cnn_math)")
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="groups of clips per step: the track stage of group k+1 is issued on a second stream beside the "
                          "network of group k (measured: no gain on MI355X, see DESIGN.md section 6; 1 = off)")
@@ -216,6 +218,7 @@ def main():
     # clips overlaps the MFMA-bound network of the previous group (BatchPipeline sub_batches)
     overlap = e2e and args.sub_batches > 1
     ceng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_frames=45) if overlap else eng
+    ceng.set_cnn_math(args.cnn_math)
     net = wr.WRResNetDevice(ceng, weights, N_LABELS) if e2e else None
     pipe = BatchPipeline(eng, net, n_labels=N_LABELS, fp_index=4, cnn_chunk=args.cnn_chunk, frame_size=args.frame_size)
     state = {}
@@ -323,7 +326,9 @@ def main():
                 tot_fl = sum(v[2] for v in conv.values())
                 line["cnn"] = {"conv_time_ms_per_step": round(tot_ms / args.steps, 2),
                                "conv_tflops_all_layers": round(tot_fl / (tot_ms / 1e3) / 1e12, 2),
-                               "track_kernel_ms_per_step": round(kernel_ms / args.steps, 2)}
+                               "track_kernel_ms_per_step": round(kernel_ms / args.steps, 2),
+                               "math": args.cnn_math,
+                               "layers_ms_per_step": {str(k): round(v[1] / args.steps, 2) for k, v in sorted(conv.items())}}
             else:
                 line["roofline"] = track_roof
             line["roofline_track"] = track_roof

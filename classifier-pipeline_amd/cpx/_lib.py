@@ -86,7 +86,7 @@ EXPORTS = [
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
     "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
-    "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect",
+    "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
 ]
 
 _lib = None
@@ -142,6 +142,10 @@ def load():
     lib.cpx_conv_timing_enable.restype = C.c_int
     lib.cpx_conv_timing_report.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.cpx_conv_timing_report.restype = C.c_int
+    lib.cpx_set_cnn_math.argtypes = [vp, C.c_int]
+    lib.cpx_set_cnn_math.restype = C.c_int
+    lib.cpx_get_cnn_math.argtypes = [vp]
+    lib.cpx_get_cnn_math.restype = C.c_int
     lib.cpx_ir_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.cpx_ir_detect.restype = C.c_int
     lib.cpx_cnn_create.argtypes = [vp, C.POINTER(WRResNetParams), C.POINTER(vp)]

@@ -304,6 +304,18 @@ class TrackEngine:
                            % int(bad[0]))
         return got
 
+    CNN_MATH = {"f32": 0, "bf16x3": 1}
+
+    def set_cnn_math(self, mode):
+        """"f32": v_mfma_f32_32x32x2_f32; "bf16x3" (default): exact three-way bf16 split of the float32 operands on
+        the bf16 matrix pipe (include/cpx.h: cpx_set_cnn_math).  Same inputs, outputs and tolerance."""
+        rc = self.lib.cpx_set_cnn_math(self.h, self.CNN_MATH[mode])
+        if rc != 0:
+            raise CpxError(rc, self._err())
+
+    def get_cnn_math(self):
+        return {v: k for k, v in self.CNN_MATH.items()}[self.lib.cpx_get_cnn_math(self.h)]
+
     def ir_detect(self, images_dev, threshold=0, max_components=1024, want_labels=False):
         """cpx_ir_detect over uint8 [n, H, W] device frames -> (counts int32[n], components COMPONENT_DTYPE
         [n, max(counts)] (host; entries past counts[i] are unspecified), labels_dev int32 [n, H, W] or None).

@@ -50,6 +50,9 @@ struct cpx_handle {
   int stream_frames = -1;
   int stream_assoc_frames = -1;
   bool stream_filt_state = false;
+  int cnn_math = CPX_CNN_MATH_BF16X3;    // cpx_set_cnn_math / CPX_CNN_MATH
+  void* bf3_scratch = nullptr;           // split weights of a cpx_conv2d call that brought none
+  size_t bf3_scratch_bytes = 0;
   unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
   size_t ir_scratch_bytes = 0;
   uint32_t* ir_bitmap = nullptr;
@@ -247,6 +250,10 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     return CPX_ERR_HIP;
   }
   if (const char* env = std::getenv("CPX_TRACK_SPLIT_MIN_CLIPS")) h->split_min_clips = std::atoi(env);
+  if (const char* env = std::getenv("CPX_CNN_MATH")) {
+    if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
+    else if (!std::strcmp(env, "bf16x3")) h->cnn_math = CPX_CNN_MATH_BF16X3;
+  }
   *out = h;
   return CPX_OK;
 }
@@ -263,6 +270,7 @@ void cpx_destroy(cpx_handle* h) {
   if (h->sched_dev) hipFree(h->sched_dev);
   if (h->ws_assoc) hipFree(h->ws_assoc);
   if (h->ir_scratch) hipFree(h->ir_scratch);
+  if (h->bf3_scratch) hipFree(h->bf3_scratch);
   if (h->ir_bitmap) hipFree(h->ir_bitmap);
   for (auto& e : h->conv_events) {
     hipEventDestroy(e.e0);
@@ -589,7 +597,8 @@ int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filter
   return CPX_OK;
 }
 
-int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) {
+// split_weights: the bf16 plane image of d->weights_dev if the caller (a cpx_cnn) keeps one, else NULL
+static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_weights) {
   if (!h) return CPX_ERR_INVALID;
   if (!d || !d->in_dev || !d->out_dev || !d->weights_dev) return fail(h, CPX_ERR_INVALID, "cpx_conv2d: null argument");
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->groups < 1 || d->Cin % d->groups || d->Cout % d->groups ||
@@ -623,7 +632,28 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) {
       return fail(h, CPX_ERR_HIP, "cpx_conv2d: event creation failed");
     CPX_HIP(h, hipEventRecord(ev.e0, h->stream));
   }
-  const int rc = cpx::launch_conv(a, h->stream);
+  int rc;
+  if (h->cnn_math == CPX_CNN_MATH_BF16X3 && cpx::conv_bf3_supported(a)) {
+    if (!split_weights) {
+      const size_t need = cpx::conv_bf3_weight_bytes(a);
+      if (need > h->bf3_scratch_bytes) {
+        CPX_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->bf3_scratch) hipFree(h->bf3_scratch);
+        h->bf3_scratch = nullptr;
+        h->bf3_scratch_bytes = 0;
+        if (hipMalloc(&h->bf3_scratch, need) != hipSuccess) {
+          (void)hipGetLastError();
+          return fail(h, CPX_ERR_NOMEM, "cpx_conv2d: weight scratch allocation failed");
+        }
+        h->bf3_scratch_bytes = need;
+      }
+      cpx::launch_split_weights(a, h->bf3_scratch, h->stream);
+      split_weights = h->bf3_scratch;
+    }
+    rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
+  } else {
+    rc = cpx::launch_conv(a, h->stream);
+  }
   if (h->conv_timing) {
     CPX_HIP(h, hipEventRecord(ev.e1, h->stream));
     h->conv_events.push_back(ev);
@@ -633,6 +663,16 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) {
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
 }
+
+int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) { return conv_run(h, d, nullptr); }
+
+int cpx_set_cnn_math(cpx_handle* h, int mode) {
+  if (!h) return CPX_ERR_INVALID;
+  if (mode != CPX_CNN_MATH_F32 && mode != CPX_CNN_MATH_BF16X3) return fail(h, CPX_ERR_INVALID, "cpx_set_cnn_math: unknown mode");
+  h->cnn_math = mode;
+  return CPX_OK;
+}
+int cpx_get_cnn_math(const cpx_handle* h) { return h ? h->cnn_math : CPX_ERR_INVALID; }
 
 int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
@@ -860,10 +900,17 @@ struct cpx_cnn {
   cpx_wrresnet_params p{};
   float* arena = nullptr;  // act0 | act1 | mid | sc
   size_t arena_floats = 0;
+  std::vector<std::pair<const float*, void*>> split;  // bf16 plane images of the 3x3 stride-1 weights
+  const void* split_of(const float* w) const {
+    for (const auto& e : split)
+      if (e.first == w) return e.second;
+    return nullptr;
+  }
 };
 
 static void cnn_free(cpx_cnn* c) {
   if (c->arena) hipFree(c->arena);
+  for (auto& e : c->split) hipFree(e.second);
   delete c;
 }
 
@@ -891,6 +938,37 @@ int cpx_cnn_create(cpx_handle* h, const cpx_wrresnet_params* params, cpx_cnn** o
   c->h = h;
   c->p = p;
   h->cnns.push_back(c);
+  // the weights are constant for the life of the network: split them once (the images are used when the handle's
+  // math mode is bf16x3 at forward time)
+  CPX_ENTER(h);
+  int c_in = p.filters[0];
+  for (int st = 0; st < 3; ++st) {
+    const int f = p.filters[st + 1];
+    for (int d = 0; d < p.blocks_per_stage; ++d) {
+      const cpx_wrresnet_block& b = p.block[st][d];
+      const float* ws[2] = {b.wa, b.wb};
+      for (int k = 0; k < 2; ++k) {
+        cpx::ConvArgs a{};
+        a.Cin = k == 0 ? c_in : f;
+        a.Cout = f;
+        a.groups = p.groups;
+        a.ksize = 3;
+        a.stride = (k == 0 && d == 0) ? st + 1 : 1;
+        a.weights = ws[k];
+        if (a.Cin % a.groups || a.Cout % a.groups || !cpx::conv_bf3_supported(a) || c->split_of(ws[k])) continue;
+        void* img = nullptr;
+        if (hipMalloc(&img, cpx::conv_bf3_weight_bytes(a)) != hipSuccess) {
+          (void)hipGetLastError();
+          cpx_cnn_destroy(c);
+          return fail(h, CPX_ERR_NOMEM, "cpx_cnn_create: weight image allocation failed");
+        }
+        c->split.emplace_back(ws[k], img);
+        cpx::launch_split_weights(a, img, h->stream);
+      }
+      c_in = f;
+    }
+  }
+  CPX_HIP(h, hipGetLastError());
   *out = c;
   return CPX_OK;
 }
@@ -945,7 +1023,7 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
     d.pad_same = same; d.relu = relu;
     d.in_dev = in; d.out_dev = out; d.weights_dev = w; d.in_scale_dev = in_scale; d.in_shift_dev = in_shift;
     d.out_scale_dev = out_scale; d.out_shift_dev = out_shift; d.residual_dev = residual;
-    return cpx_conv2d(h, &d);
+    return conv_run(h, &d, cnn->split_of(w));
   };
   int rc = conv(in_dev, act[0], p.conv1_w, H, W, p.in_channels, p.filters[0], 3, 1, 1, 0, nullptr, nullptr, nullptr,
                 p.conv1_b, nullptr);

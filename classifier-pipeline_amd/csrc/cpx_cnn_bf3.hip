@@ -1,0 +1,406 @@
+// cpx_cnn_bf3.hip -- the 3x3 stride-1 convolutions of WR-ResNet with float32 operands on the bf16 matrix pipe.
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate on gfx950.  A float32 value splits EXACTLY into three
+// bf16 terms (x = x0 + x1 + x2: round to nearest, subtract, repeat; 3 x 8 significant bits plus the signs of the
+// remainders cover the 24-bit significand), every bf16 x bf16 product is exact in float32, and the accumulator is
+// float32 as before.  Of the nine cross products the six with i + j <= 2 are issued; the three dropped ones are below
+// 2^-26 of the product, i.e. below the rounding of a float32 accumulation step, so the result is float32 arithmetic
+// in every respect the 1e-3 logit tolerance (and the 2e-4 of tests/test_cnn_gpu.py) can see -- measured against a
+// float64 convolution it is as close as the float32 MFMA kernel (tests/test_cnn_gpu.py::test_bf16x3_is_f32_accurate).
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each) do the work of eight 32x32x2_f32 (64 cycles each): 2.67x.
+//
+// Same implicit GEMM as cpx_cnn.hip (M = a band of 128 output pixels per workgroup, 32 per wave; N = 32-channel
+// tiles of one group; K walked as 16-channel chunk x tap), same fused prologue (BatchNorm + ReLU while staging, zero
+// padding kept exactly 0) and epilogue (affine, residual, ReLU, one store).  What differs is the operand staging:
+//   patch   LDS [plane 0..2][k half 0..1][pixel] of 16-byte entries (8 bf16 = this pixel's channels 8h..8h+7):
+//           an A fragment is one ds_read_b128 per plane, consecutive lanes on consecutive entries (conflict-free)
+//   weights pre-split on the device into the same entry format, [chunk][plane][tap][k half][column]; staging is
+//           a straight copy and a B fragment is one ds_read_b128 per plane
+// Activations stay float32 in HBM; the split happens on the way into LDS.
+#include <hip/hip_runtime.h>
+
+#include "cpx_kernels.h"
+
+namespace cpx {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// a native vector, not HIP's uint4 struct: struct copies become memcpy calls that keep a staging array in scratch
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  bf16x2 v = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+// two float32 -> their three bf16 planes (packed pairs)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = pack2(a, b);
+  const float ra = a - bf_lo(p0), rb = b - bf_hi(p0);  // exact
+  p1 = pack2(ra, rb);
+  const float sa = ra - bf_lo(p1), sb = rb - bf_hi(p1);  // exact
+  p2 = pack2(sa, sb);
+}
+
+constexpr int KC = 16;  // channels per K step of the bf16 MFMA = per staged chunk
+
+// NB bands of 128 output pixels per workgroup, CT threads: four waves share a band (32 pixels each); with CT = 512
+// the second set of four waves takes every other band, so NTM = NB / (CT / 256) bands per wave
+// q = n / d for n < 2^20, d < 2^12 with a host-computed M = floor(2^40 / d) + 1: two scalar multiplies instead of
+// the ~25-instruction reciprocal sequence a runtime division costs (four of them per workgroup otherwise)
+struct TileDiv {
+  unsigned long long m_nsplit, m_tx, m_ty;
+  int nsplit, tiles_x, tiles_y;
+};
+__device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)n * m) >> 40); }
+
+template <int NTN, int S, int NB, int TW, int CT>
+__global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+  constexpr int KS = 3;
+  constexpr int WSETS = CT / 256;    // sets of four waves
+  constexpr int NTM = NB / WSETS;    // bands per wave
+  static_assert(NTM * WSETS == NB, "bands must divide among the wave sets");
+  constexpr int TB = 128 / TW;   // rows of a band
+  constexpr int WR = 32 / TW;    // rows of a wave's 32-pixel tile
+  constexpr int TH = TB * NB;    // output rows of a workgroup
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+  constexpr int NPX = PH * PW;
+  constexpr int COGW = 32 * NTN;  // output channels of this workgroup
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  uint4* s_patch = lds4;            // [3][2][NPX]
+  uint4* s_w = lds4 + 6 * NPX;      // [3][9][2][COGW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wset = tid >> 8;
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-contiguous tiles (cpx_cnn.hip)
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  int q = div_magic(bid, td.m_nsplit);
+  const int ns = bid - q * td.nsplit;  // the column slices of one tile run next to each other: they share the patch in L2
+  bid = q;
+  q = div_magic(bid, td.m_tx);
+  const int txi = bid - q * td.tiles_x;
+  bid = q;
+  q = div_magic(bid, td.m_ty);
+  const int tyi = bid - q * td.tiles_y;
+  const int n = q;
+  const int g = blockIdx.y;
+  const int oy0 = tyi * TH, ox0 = txi * TW;
+  const int iy0 = oy0 * S - a.pad_top, ix0 = ox0 * S - a.pad_left;
+  const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
+  const int nchunks = cin_g / KC;
+  // weight image: [g][chunk][3][9][2][cout_g] entries
+  const uint4* wg = wimg + (size_t)g * nchunks * 54 * cout_g + (size_t)ns * COGW;
+
+  f32x16 acc[NTM][NTN];
+#pragma unroll
+  for (int m = 0; m < NTM; ++m)
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+
+  const int pi = lane & 31, kh = lane >> 5;
+  const int prow = WR * wave + pi / TW, pcol = pi % TW;
+  const int a_base = kh * NPX + ((prow + wset * TB) * S) * PW + pcol * S;  // band m of this wave: wset + m * WSETS
+  const int b_base = kh * COGW + (lane & 31);
+
+  // staging: an item is (patch pixel, k half) = 8 channels = two float4 loads; a thread keeps its k half
+  constexpr int NITEM = NPX * 2;
+  constexpr int NP = (NITEM + CT - 1) / CT;
+  constexpr int NW = 54 * COGW;               // uint4 entries of a weight chunk
+  constexpr int NWI = (NW + CT - 1) / CT;
+  const int my_h = tid & 1;
+  float4 pre_p[NP][2];
+  u32x4 pre_w[NWI];
+  float4 psc[2], psh[2];
+  for (int cc = -1; cc < nchunks; ++cc) {
+    if (cc >= 0) {
+      // ---- registers -> LDS: BatchNorm + ReLU prologue, split into bf16 planes ----
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int item = tid + i * CT;
+        if (item < NITEM) {
+          const int px = item >> 1;
+          const int py = px / PW, pxx = px - py * PW;
+          const int iy = iy0 + py, ix = ix0 + pxx;
+          float v[8] = {pre_p[i][0].x, pre_p[i][0].y, pre_p[i][0].z, pre_p[i][0].w,
+                        pre_p[i][1].x, pre_p[i][1].y, pre_p[i][1].z, pre_p[i][1].w};
+          // the loads are unconditional (clamped addresses, below): padding pixels are zeroed here, after the
+          // prologue, exactly as TensorFlow pads the activated tensor
+          const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          if (a.in_scale) {
+            const float sc[8] = {psc[0].x, psc[0].y, psc[0].z, psc[0].w, psc[1].x, psc[1].y, psc[1].z, psc[1].w};
+            const float sh[8] = {psh[0].x, psh[0].y, psh[0].z, psh[0].w, psh[1].x, psh[1].y, psh[1].z, psh[1].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j], 0.0f);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
+          uint4 p0, p1, p2;
+#ifdef CPX_BF3_ABLATE_SPLIT
+          p0 = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+          p1 = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+          p2 = p0;
+#else
+          split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+          split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+          split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+          split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+#endif
+          s_patch[(0 * 2 + my_h) * NPX + px] = p0;
+          s_patch[(1 * 2 + my_h) * NPX + px] = p1;
+          s_patch[(2 * 2 + my_h) * NPX + px] = p2;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        const int item = tid + i * CT;
+        if (item < NW) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
+      }
+      __syncthreads();
+    }
+    if (cc + 1 < nchunks) {
+      // ---- global -> registers for the next chunk (in flight during the MFMA loop below) ----
+      const int cn = (cc + 1) * KC;
+      {  // without a prologue any readable 32 bytes do (never used): no branch around the loads
+        const int ch = g * cin_g + cn + 8 * my_h;
+        const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);
+        const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);
+        psc[0] = *reinterpret_cast<const float4*>(scp);
+        psc[1] = *reinterpret_cast<const float4*>(scp + 4);
+        psh[0] = *reinterpret_cast<const float4*>(shp);
+        psh[1] = *reinterpret_cast<const float4*>(shp + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int item = min(tid + i * CT, NITEM - 1);
+        const int px = item >> 1;
+        const int py = px / PW, pxx = px - py * PW;
+        const int iy = iy0 + py, ix = ix0 + pxx;
+        // branch-free: a clamped address is always loaded (conditional loads split the block and make the
+        // compiler wait for all outstanding loads at every join); out-of-image pixels are zeroed at commit
+        const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+#ifdef CPX_BF3_ABLATE_PATCH_LOAD  // timing experiments only: results are wrong
+        pre_p[i][0] = make_float4((float)cy, 1.f, 2.f, 3.f);
+        pre_p[i][1] = make_float4((float)cx, 1.f, 2.f, 3.f);
+#else
+        const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 8 * my_h);  // inside one sample: < 2^31
+        pre_p[i][0] = *reinterpret_cast<const float4*>(src);
+        pre_p[i][1] = *reinterpret_cast<const float4*>(src + 4);
+#endif
+      }
+      const uint4* wc = wg + (size_t)(cc + 1) * 54 * cout_g;
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        const int item = min(tid + i * CT, NW - 1);
+#ifdef CPX_BF3_ABLATE_WEIGHT_LOAD
+        pre_w[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, (unsigned)item};
+#else
+        const int pth = item / COGW, col = item - pth * COGW;
+        pre_w[i] = reinterpret_cast<const u32x4*>(wc)[(size_t)pth * cout_g + col];
+#endif
+      }
+    }
+    if (cc >= 0) {
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; ++tap) {
+#ifdef CPX_BF3_ABLATE_LDSREAD  // timing experiments only: every tap multiplies the fragments of tap 0
+        const int ky = 0, kx = 0;
+#else
+        const int ky = tap / KS, kx = tap - ky * KS;
+#endif
+        bf16x8 av[NTM][3], bv[NTN][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int m = 0; m < NTM; ++m)
+            av[m][p] = __builtin_bit_cast(bf16x8, s_patch[p * 2 * NPX + a_base + m * (WSETS * TB * S * PW) + ky * PW + kx]);
+#pragma unroll
+          for (int t = 0; t < NTN; ++t)
+#ifdef CPX_BF3_ABLATE_LDSREAD
+            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * 9) * 2 * COGW + b_base + t * 32]);
+#else
+            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * 9 + tap) * 2 * COGW + b_base + t * 32]);
+#endif
+        }
+#pragma unroll
+        for (int m = 0; m < NTM; ++m)
+#pragma unroll
+          for (int t = 0; t < NTN; ++t) {
+            // smallest terms first: x1*y1, x0*y2, x2*y0, x0*y1, x1*y0, x0*y0
+#ifndef CPX_BF3_ABLATE_MFMA
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][1], acc[m][t], 0, 0, 0);
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][2], acc[m][t], 0, 0, 0);
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][2], bv[t][0], acc[m][t], 0, 0, 0);
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][1], acc[m][t], 0, 0, 0);
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][0], acc[m][t], 0, 0, 0);
+#endif
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][0], acc[m][t], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (as cpx_cnn.hip): affine from the accumulators, through LDS for 16-byte residual loads / stores.
+  // Each wave transposes through its own 4 KB of LDS (the patch / weights are dead after the loop's last barrier),
+  // and LDS operations of one wave complete in order, so no workgroup barrier is needed here ----
+  float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
+  const float* res_n = a.residual ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+  float* s_tile = reinterpret_cast<float*>(lds4) + (wset * 4 + wave) * (32 * 32);
+  const int ch0 = g * cout_g + ns * COGW;
+#pragma unroll
+  for (int m = 0; m < NTM; ++m) {
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+      const int ch = ch0 + t * 32 + (lane & 31);
+      const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+      const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
+        s_tile[i * 32 + (lane & 31)] = acc[m][t][r] * os + ob;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int f = it * 64 + lane;
+        const int i = f >> 3, c4 = f & 7;
+        const int oy = oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = ox0 + i % TW;
+#ifdef CPX_BF3_ABLATE_STORE
+        if (oy < a.Ho && ox < a.Wo && s_tile[i * 32 + 4 * c4] == 1.2345e-30f) {  // never true: no stores, no residual loads
+#else
+        if (oy < a.Ho && ox < a.Wo) {
+#endif
+          float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
+          const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+          if (res_n) {
+            const float4 rv = *reinterpret_cast<const float4*>(res_n + o);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          }
+          if (a.relu) {
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+          }
+          *reinterpret_cast<float4*>(out_n + o) = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+// packed float32 weights [g][tap][cin_g][cout_g] -> bf16 plane image [g][chunk][3][9][2][cout_g] of 16-byte entries
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
+                                                            int cin_g, int cout_g) {
+  const int nchunks = cin_g / KC;
+  const size_t total = (size_t)groups * nchunks * 9 * 2 * cout_g;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    const int col = (int)(r % cout_g);
+    r /= cout_g;
+    const int h = (int)(r & 1);
+    r >>= 1;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int chunk = (int)(r % nchunks);
+    const int g = (int)(r / nchunks);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = w[(((size_t)g * 9 + tap) * cin_g + chunk * KC + 8 * h + j) * cout_g + col];
+    uint4 p0, p1, p2;
+    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+    const size_t base = ((size_t)g * nchunks + chunk) * 54 * cout_g;
+    out[base + ((size_t)(0 * 9 + tap) * 2 + h) * cout_g + col] = p0;
+    out[base + ((size_t)(1 * 9 + tap) * 2 + h) * cout_g + col] = p1;
+    out[base + ((size_t)(2 * 9 + tap) * 2 + h) * cout_g + col] = p2;
+  }
+}
+
+template <int NTN, int S, int NB, int TW, int CT>
+int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
+  constexpr int TB = 128 / TW, TH = TB * NB;
+  constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
+  size_t lds = ((size_t)6 * PH * PW + (size_t)54 * 32 * NTN) * 16;
+  if (lds < (CT / 64) * 32 * 32 * sizeof(float)) lds = (CT / 64) * 32 * 32 * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
+      return -1;
+    configured = true;
+  }
+  TileDiv td;
+  td.tiles_x = (a.Wo + TW - 1) / TW;
+  td.tiles_y = (a.Ho + TH - 1) / TH;
+  td.nsplit = (a.Cout / a.groups) / (32 * NTN);
+  const long long blocks = (long long)td.tiles_x * td.tiles_y * a.N * td.nsplit;
+  if (blocks >= (1 << 20) || td.tiles_x >= 4096 || td.tiles_y >= 4096) return -3;  // div_magic's range
+  td.m_nsplit = (1ull << 40) / td.nsplit + 1;
+  td.m_tx = (1ull << 40) / td.tiles_x + 1;
+  td.m_ty = (1ull << 40) / td.tiles_y + 1;
+  hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
+  return 0;
+}
+
+}  // namespace
+
+#ifndef CPX_BF3_NTN_S3
+#define CPX_BF3_NTN_S3 1
+#endif
+#ifndef CPX_BF3_NTN_S4
+#define CPX_BF3_NTN_S4 1
+#endif
+#ifndef CPX_BF3_NB_S2
+#define CPX_BF3_NB_S2 2
+#endif
+#ifndef CPX_BF3_NB_S3
+#define CPX_BF3_NB_S3 2
+#endif
+#ifndef CPX_BF3_NB_S4
+#define CPX_BF3_NB_S4 1
+#endif
+#ifndef CPX_BF3_CT_S2
+#define CPX_BF3_CT_S2 256
+#endif
+#ifndef CPX_BF3_CT_S3
+#define CPX_BF3_CT_S3 256
+#endif
+#ifndef CPX_BF3_CT_S4
+#define CPX_BF3_CT_S4 256
+#endif
+
+bool conv_bf3_supported(const ConvArgs& a) {
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  return a.ksize == 3 && a.stride == 1 && cin_g >= KC && (cin_g % KC) == 0 && (cout_g == 32 || cout_g == 64 || cout_g == 128);
+}
+size_t conv_bf3_weight_bytes(const ConvArgs& a) {
+  return (size_t)a.groups * (a.Cin / a.groups / KC) * 54 * (a.Cout / a.groups) * 16;
+}
+void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  const size_t total = (size_t)a.groups * (cin_g / KC) * 18 * cout_g;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
+                     reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g);
+}
+int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
+  const int cout_g = a.Cout / a.groups;
+  const uint4* w = reinterpret_cast<const uint4*>(wimg);
+  if (cout_g == 32) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, 16, CPX_BF3_CT_S2>(a, w, s);
+  if (cout_g == 64) return launch_bf3_t<CPX_BF3_NTN_S3, 1, CPX_BF3_NB_S3, 16, CPX_BF3_CT_S3>(a, w, s);
+  if (cout_g == 128) return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
+  return -2;
+}
+
+}  // namespace cpx

@@ -191,6 +191,11 @@ struct HeadArgs {
   float* probs;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
+// float32 operands as three bf16 planes on the bf16 matrix pipe (cpx_cnn_bf3.hip)
+bool conv_bf3_supported(const ConvArgs& a);
+size_t conv_bf3_weight_bytes(const ConvArgs& a);
+void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s);
+int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s);
 void launch_head(const HeadArgs& a, hipStream_t s);
 
 struct CptvArgs {

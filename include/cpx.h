@@ -369,6 +369,17 @@ typedef struct cpx_conv_desc {
   const float* residual_dev;  /* [N,Ho,Wo,Cout] or NULL */
 } cpx_conv_desc;
 int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* desc);
+/* How the float32 multiplications of the 3x3 stride-1 convolutions (>= 16 input channels per group) are carried out.
+ * Both modes take and return float32, accumulate in float32 and meet the same tolerance against a float64
+ * convolution (tests/test_cnn_gpu.py); every other layer always uses the float32 instruction.
+ *   CPX_CNN_MATH_F32     v_mfma_f32_32x32x2_f32 on the operands as they are
+ *   CPX_CNN_MATH_BF16X3  each operand split exactly into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K step
+ *                        (the cross terms below 2^-26 of a product are dropped); default, 2.67x the MFMA rate
+ * The default can be preset with the environment variable CPX_CNN_MATH=f32|bf16x3 (read by cpx_create). */
+#define CPX_CNN_MATH_F32 0
+#define CPX_CNN_MATH_BF16X3 1
+int cpx_set_cnn_math(cpx_handle* h, int mode);
+int cpx_get_cnn_math(const cpx_handle* h);
 /* relu(in * bn_scale + bn_shift) -> mean over H*W -> dense [C][L] + bias -> logits (and sigmoid probs if not NULL) */
 int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,

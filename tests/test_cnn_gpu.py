@@ -36,8 +36,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def math(engine, request):
+    """Both ways of multiplying float32 operands on the matrix cores (include/cpx.h: cpx_set_cnn_math)."""
+    engine.set_cnn_math(request.param)
+    assert engine.get_cnn_math() == request.param
+    yield request.param
+    engine.set_cnn_math("bf16x3")
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_conv2d_matches_torch(engine, case):
+def test_conv2d_matches_torch(engine, math, case):
     import torch
     import torch.nn.functional as F
 
@@ -98,8 +107,49 @@ def test_conv2d_matches_torch(engine, case):
         assert float(np.abs(got - want).max()) <= 2e-5 * scale, (case, variant, float(np.abs(got - want).max()))
 
 
+def test_bf16x3_is_f32_accurate(engine):
+    """The split-operand path is float32 arithmetic, not reduced precision: against a float64 convolution of the
+    same float32 inputs its error is the float32 MFMA kernel's (both are dominated by the float32 accumulation),
+    on all three stride-1 layer shapes, with wide-range operands."""
+    import torch
+    import torch.nn.functional as F
+
+    from cpx.ml_tools.wrresnet import ConvDesc, pack_conv
+
+    dev = engine.device
+    for Cin, Cout, H, W in ((64, 64, 40, 40), (128, 128, 24, 40), (256, 256, 27, 27)):
+        rng = np.random.default_rng(Cin)
+        x = (rng.normal(0, 1, size=(2, H, W, Cin)) * np.exp(rng.normal(0, 2, size=(2, H, W, Cin)))).astype(np.float32)
+        k = (rng.normal(0, 0.1, size=(3, 3, Cin // 2, Cout)) * np.exp(rng.normal(0, 1, size=(3, 3, Cin // 2, Cout)))
+             ).astype(np.float32)
+        want = F.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(k).double().permute(3, 2, 0, 1),
+                        None, padding=1, groups=2).permute(0, 2, 3, 1).numpy()
+        # magnitude of the sum each output accumulates: the scale float32 rounding errors are relative to
+        mag = F.conv2d(torch.from_numpy(np.abs(x)).double().permute(0, 3, 1, 2),
+                       torch.from_numpy(np.abs(k)).double().permute(3, 2, 0, 1), None, padding=1,
+                       groups=2).permute(0, 2, 3, 1).numpy()
+        errs = {}
+        for mode in ("f32", "bf16x3"):
+            engine.set_cnn_math(mode)
+            xd = torch.from_numpy(x).to(dev)
+            wd = torch.from_numpy(pack_conv(k)).to(dev)
+            out = torch.full((2, H, W, Cout), np.nan, dtype=torch.float32, device=dev)
+            ptr = lambda v: C.c_void_p(v.data_ptr())
+            d = ConvDesc(2, H, W, Cin, Cout, 2, 3, 1, 1, 0, ptr(xd), ptr(out), ptr(wd), None, None, None, None, None)
+            torch.cuda.synchronize()
+            assert engine.lib.cpx_conv2d(engine.h, C.byref(d)) == 0, engine._err()
+            engine.synchronize()
+            got = out.cpu().numpy().astype(np.float64)
+            assert np.isfinite(got).all()
+            errs[mode] = float((np.abs(got - want) / mag).max())
+        engine.set_cnn_math("bf16x3")
+        # float32 accumulation of K = 9 * Cin / 2 terms: a few 2^-24 relative to the accumulated magnitude
+        assert errs["f32"] < 4e-6 and errs["bf16x3"] < 4e-6, errs
+        assert errs["bf16x3"] <= 2.0 * errs["f32"] + 2.0 ** -24, errs
+
+
 @pytest.mark.parametrize("fs,n", [(32, 3), (64, 1)])
-def test_wrresnet_logits_match_oracle(engine, fs, n):
+def test_wrresnet_logits_match_oracle(engine, math, fs, n):
     import torch
 
     import cnn_oracle as co
