@@ -8,7 +8,7 @@ uint16 clips of T = 270 frames (30 s at 9 fps) per GPU, lepton3 thresholds, resi
 the timed region starts.  One *step* = one pass of the whole hot path over the batch:
   track stage (background, filtered, blur/threshold/close, labelling, statistics, delta variance)
   -> association (region filter, matching, Kalman) -> end-of-clip filtering -> segment plan
-  -> crop / resize / normalise / 5x5 tile -> WR-ResNet-22-4 forward (fp32 MFMA, 17 labels, seeded
+  -> crop / resize / normalise / 5x5 tile -> WR-ResNet-22-4 forward (float32, 17 labels, seeded
   random weights: no checkpoint can be downloaded) -> per-track aggregation.
 value = N * B * T * K / max-over-ranks time (barrier + device sync on both sides).
 
@@ -17,8 +17,11 @@ no data-path collective; the per-track result records are all-gathered once per 
 
 Extra objects on the JSON line:
   roofline      the dominant kernel of the step.  e2e: the stage-2 3x3 grouped convolution
-                (conv_mfma_kernel<8,1,1,3,2,16> in the rocprof CSV), MFMA-bound: algorithmic FLOPs of its launches / their
-                HIP-event time on the handle's stream, against the fp32-MFMA dense peak.  --stage track:
+                (conv_bf3_kernel<1,1,2,16,512> in the rocprof CSV, an instantiation the stage-3 3x3 convolutions share:
+                the roofline covers both; conv_mfma_kernel<8,1,1,3,2,16>, stage 2 only, with --cnn-math f32):
+                algorithmic FLOPs (2*M*N*K of the float32 convolution) of its launches / their HIP-event time on the
+                handle's stream.  Peak: with the default bf16x3 math every float32 multiply-add is six bf16 MFMA
+                multiply-adds, so the dense bf16 MFMA peak / 6; with f32 math the fp32-MFMA dense peak.  --stage track:
                 cpx_frame_kernel, HBM-bound, 614,400 algorithmic bytes per frame.
   roofline_track  (e2e) the same HBM accounting for cpx_frame_kernel inside the same run.
   cpu_baseline  the oracle chain ("port": NumPy tracker + NumPy crop/tile + PyTorch-CPU forward, 1 core)
@@ -39,6 +42,8 @@ ALGO_BYTES_PER_FRAME = 614400  # 32 B / pixel at 160x120
 LABEL_BYTES_PER_FRAME = 76800  # the int32 label image, not consumed by the classifier
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA
+BF16X3_PRODUCTS = 6            # bf16 MFMA products per float32 multiply-add (csrc/cpx_cnn_bf3.hip)
 N_LABELS = 17
 
 
@@ -154,7 +159,8 @@ def main():
     ap.add_argument("--stage", choices=("e2e", "track"), default="e2e",
                     help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only")
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cnn-chunk", type=int, default=2048, help="samples per CNN forward (54 GB of activations at 2048)")
+    ap.add_argument("--cnn-chunk", type=int, default=0,
+                    help="samples per CNN forward (default 2048 at frame size 32 = 54 GB of activations, 512 at 64)")
     ap.add_argument("--frame-size", type=int, default=32, choices=(32, 64),
                     help="side of one tile of the 5x5 network input (SURVEY 8(d) config 3 asks for 32 and 64)")
     ap.add_argument("--cnn-math", choices=("bf16x3", "f32"), default="bf16x3",
@@ -197,7 +203,9 @@ def main():
     B = args.clips or 4096
     free, _ = torch.cuda.mem_get_info(device)
     per_clip = T * P * 2 + T * 64 * 32 + T * 80 + 6 * P * 4 + T * P * 4 + (T * 16 * 56 if e2e else T * P * 4)
-    reserve = (args.cnn_chunk * 30e6) if e2e else 0
+    if args.cnn_chunk <= 0:
+        args.cnn_chunk = 2048 if args.frame_size == 32 else 512
+    reserve = (args.cnn_chunk * 30e6 * (args.frame_size / 32) ** 2) if e2e else 0
     while B > 64 and B * per_clip + reserve > 0.80 * free:
         B //= 2
     eng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_components=64, max_frames=max(T, 45),
@@ -292,7 +300,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 MFMA CNN" if e2e else
+            "dtype": ("u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)"
+                      % ("3x3 convs: exact 3-way bf16 operand split, 6 bf16 MFMAs per K step, f32 accumulate"
+                         if args.cnn_math == "bf16x3" else "f32 MFMA")) if e2e else
                      "u16/i32 (f32 normalise, f64 background weights)",
             "data": "synthetic",
             "config": {
@@ -311,17 +321,47 @@ def main():
             line["config"].update({"kept_tracks_per_step": int(r.n_tracks), "classified_segments_per_step": int(r.n_samples),
                                    "frame_size": args.frame_size, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk,
                                    "sub_batches": args.sub_batches})
-            key = 32 * 10000 + 32 * 10 + 1  # conv_mfma_kernel<KC=8,NTN=1,S=1,KS=3,NTM=2,TW=16>: the stage-2 3x3 convolutions
+            key = 32 * 10000 + 32 * 10 + 1  # the stage-2 3x3 convolutions (32 -> 32 channels per group, stride 1)
+            key3 = 64 * 10000 + 64 * 10 + 1  # the stage-3 ones: same FLOPs per sample, half the bytes
             if key in conv and conv[key][1] > 0:
-                n, ms, fl = conv[key]
+                bf3 = args.cnn_math == "bf16x3"
+                area = (args.frame_size / 32.0) ** 2  # map area relative to the 160 x 160 maps of frame size 32
+                side = 5 * args.frame_size
+                # input + output (+ residual in 3 of the 5 launches of a shape per forward), float32 NHWC
+                bytes2 = side * side * 64 * 4 * 2.6
+                if bf3 and key3 in conv:
+                    # stage 2 and stage 3 run the same instantiation (conv_bf3_kernel<1,1,2,16,512>: one row of the
+                    # rocprof CSV), with the same FLOPs per sample: the roofline covers the launches of both
+                    n = conv[key][0] + conv[key3][0]
+                    ms = conv[key][1] + conv[key3][1]
+                    fl = conv[key][2] + conv[key3][2]
+                    samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
+                    algo_bytes = samples_per_launch * bytes2 * 0.75  # stage 3 moves half of stage 2's bytes
+                    t2 = pmc_traffic("conv_stage2", samples_per_launch * area)
+                    t3 = pmc_traffic("conv_stage3", samples_per_launch * area)
+                    traffic = round((t2 + t3) / 2, 1) if t2 is not None and t3 is not None else None
+                    what = "conv_bf3_kernel<1,1,2,16,512> (stage-2 and stage-3 3x3 convs: 64->64 ch at %dx%d, 128->128 ch at %dx%d, groups 2)" % (
+                        side, side, side // 2, side // 2)
+                else:
+                    n, ms, fl = conv[key]
+                    samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
+                    algo_bytes = samples_per_launch * bytes2
+                    traffic = None
+                    what = "conv_mfma_kernel<8,1,1,3,2,16> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)" % (side, side)
                 tf = fl / (ms / 1e3) / 1e12
-                line["roofline"] = {"kernel": "conv_mfma_kernel<8,1,1,3,2,16> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)"
-                                              % (5 * args.frame_size, 5 * args.frame_size),
-                                    "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                                    "traffic": pmc_traffic("conv_stage2", fl / n / STAGE2_CONV_FLOPS_PER_SAMPLE),
+                peak = round(MFMA_BF16_PEAK_TFLOPS / BF16X3_PRODUCTS, 1) if bf3 else MFMA_F32_PEAK_TFLOPS
+                line["roofline"] = {"kernel": what,
+                                    "bound": "mfma", "achieved": round(tf, 2), "peak": peak,
+                                    "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                    "traffic": traffic,
                                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
-                                    "algorithmic_flops_per_launch": fl / n}
+                                    "algorithmic_flops_per_launch": fl / n,
+                                    "algorithmic_bytes_per_launch": algo_bytes,
+                                    "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products per float32 multiply-add"
+                                                  if bf3 else "dense fp32-input MFMA peak"),
+                                    "hbm_GBps_algorithmic": round(algo_bytes / (ms / n / 1e3) / 1e9, 1),
+                                    "hbm_frac": round(algo_bytes / (ms / n / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "stage2_tflops": round(conv[key][2] / (conv[key][1] / 1e3) / 1e12, 2)}
                 tot_ms = sum(v[1] for v in conv.values())
                 tot_fl = sum(v[2] for v in conv.values())
                 line["cnn"] = {"conv_time_ms_per_step": round(tot_ms / args.steps, 2),

@@ -651,6 +651,7 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
       split_weights = h->bf3_scratch;
     }
     rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
+    if (rc == -3) rc = cpx::launch_conv(a, h->stream);  // more tiles than the persistent kernel indexes: float32 path
   } else {
     rc = cpx::launch_conv(a, h->stream);
   }

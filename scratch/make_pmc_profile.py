@@ -17,11 +17,19 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def rows(dirname, counter, kernel_sub):
+def rows(dirname, counter, kernel_sub, phase=None):
+    """(grid, value) of the kernel's dispatches in dispatch order.  phase = (period, keep): the dispatches of the
+    kernel come in runs of `period` per layer group, alternating; keep the runs with (index // period) % 2 == keep."""
     path = max(glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*_counter_collection.csv")),
                key=os.path.getmtime)  # the newest pass (gpurun merges outputs, older passes stay around)
-    return [(int(r["Grid_Size"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path))
-            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
+    rs = [(int(r["Dispatch_Id"]), int(r["Grid_Size"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path))
+          if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
+    rs.sort()
+    out = [(g, v) for _, g, v in rs]
+    if phase is not None:
+        period, keep = phase
+        out = [gv for i, gv in enumerate(out) if (i // period) % 2 == keep]
+    return out
 
 
 def common_grid(dirname, counter, kernel_sub):
@@ -30,14 +38,14 @@ def common_grid(dirname, counter, kernel_sub):
     return max(set(grids), key=grids.count)
 
 
-def avg(dirname, counter, kernel_sub, grid=None):
-    vals = [v for g, v in rows(dirname, counter, kernel_sub) if grid is None or g == grid]
+def avg(dirname, counter, kernel_sub, grid=None, phase=None):
+    vals = [v for g, v in rows(dirname, counter, kernel_sub, phase) if grid is None or g == grid]
     return sum(vals) / len(vals), len(vals)
 
 
-def section(kernel, fetch_dir, write_dir, kernel_sub, grid, units, unit, algo, note):
-    f, n = avg(fetch_dir, "FETCH_SIZE", kernel_sub, grid)
-    w, _ = avg(write_dir, "WRITE_SIZE", kernel_sub, grid)
+def section(kernel, fetch_dir, write_dir, kernel_sub, grid, units, unit, algo, note, phase=None):
+    f, n = avg(fetch_dir, "FETCH_SIZE", kernel_sub, grid, phase)
+    w, _ = avg(write_dir, "WRITE_SIZE", kernel_sub, grid, phase)
     rd, wr = 2 * f * 1024, w * 1024
     return {"kernel": kernel, "launches": n, "units_per_launch": units, "unit": unit, "FETCH_SIZE_KiB_avg": f,
             "WRITE_SIZE_KiB_avg": w, "hbm_read_bytes_per_launch_corrected": rd, "hbm_write_bytes_per_launch": wr,
@@ -49,13 +57,19 @@ out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -
                   "--clips 1024 --steps 1 --warmup 0 --cpu-clips 0 (separate passes, scratch/make_pmc_profile.py)",
        "note": "KiB per dispatch, averaged over the launches named; FETCH_SIZE doubled per MI355X_MICROARCH.md, "
                "WRITE_SIZE as is"}
-CONV = "conv_mfma_kernel<8, 1, 1, 3, 2"
+CONV = "conv_bf3_kernel<1, 1, 2, 16, 512>"
 conv_grid = common_grid("pmc_e2e_fetch", "FETCH_SIZE", CONV)
-conv_n = conv_grid // (100 * 2 * 256)  # 100 tiles of 16 x 16 pixels per 160 x 160 sample, 2 groups, 256 threads
+conv_n = conv_grid // (100 * 2 * 512)  # 100 tiles of 16 x 16 pixels per 160 x 160 sample, 2 groups, 512 threads
+# stage 2 (64->64 ch, 160x160) and stage 3 (128->128 ch, 80x80) run the same instantiation on the same grid
+# (100 * N * nsplit workgroups): per forward five stage-2 launches, then five stage-3 launches, in dispatch order
 out["conv_stage2"] = section(
-    "conv_mfma_kernel<8,1,1,3,2,16>, launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
+    "conv_bf3_kernel<1,1,2,16,512>, stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
     "pmc_e2e_write", CONV, conv_grid, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.6,
-    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
+    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6", (5, 0))
+out["conv_stage3"] = section(
+    "conv_bf3_kernel<1,1,2,16,512>, stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
+    "pmc_e2e_write", CONV, conv_grid, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
+    "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6", (5, 1))
 out["frame_kernel_e2e"] = section(
     "cpx_frame_kernel, 1024 clip-frames per launch, no label image (end-to-end configuration)", "pmc_e2e_fetch",
     "pmc_e2e_write", "cpx_frame_kernel", None, 1024, "clip-frames", (614400 - 76800) * 1024,
