@@ -58,18 +58,21 @@ out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -
        "note": "KiB per dispatch, averaged over the launches named; FETCH_SIZE doubled per MI355X_MICROARCH.md, "
                "WRITE_SIZE as is"}
 CONV = "conv_bf3_kernel<1, 1, 2, 16, 512>"
-conv_grid = common_grid("pmc_e2e_fetch", "FETCH_SIZE", CONV)
-conv_n = conv_grid // (100 * 2 * 512)  # 100 tiles of 16 x 16 pixels per 160 x 160 sample, 2 groups, 512 threads
-# stage 2 (64->64 ch, 160x160) and stage 3 (128->128 ch, 80x80) run the same instantiation on the same grid
-# (100 * N * nsplit workgroups): per forward five stage-2 launches, then five stage-3 launches, in dispatch order
+# stage 2 (64->64 ch, 160x160: 100 tiles per sample) and stage 3 (128->128 ch, 80x80: 25 tiles x 2 column slices) run
+# the same instantiation; their grids differ (100 vs 50 workgroups per sample and group)
+grids = sorted({g for g, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV)}, reverse=True)
+grid2 = max(grids, key=lambda g: sum(1 for gg, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV) if gg == g) * (g in grids[:2]) + g * 1e-12)
+grid2 = grids[0]
+conv_n = grid2 // (100 * 2 * 512)
+grid3 = 50 * 2 * 512 * conv_n
 out["conv_stage2"] = section(
     "conv_bf3_kernel<1,1,2,16,512>, stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
-    "pmc_e2e_write", CONV, conv_grid, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.6,
-    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6", (5, 0))
+    "pmc_e2e_write", CONV, grid2, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.6,
+    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
 out["conv_stage3"] = section(
     "conv_bf3_kernel<1,1,2,16,512>, stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
-    "pmc_e2e_write", CONV, conv_grid, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
-    "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6", (5, 1))
+    "pmc_e2e_write", CONV, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
+    "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
 out["frame_kernel_e2e"] = section(
     "cpx_frame_kernel, 1024 clip-frames per launch, no label image (end-to-end configuration)", "pmc_e2e_fetch",
     "pmc_e2e_write", "cpx_frame_kernel", None, 1024, "clip-frames", (614400 - 76800) * 1024,
