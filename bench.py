@@ -236,9 +236,13 @@ def main():
             res = pipe.run(frames, offs, meta, outputs=outputs, sub_batches=args.sub_batches)
             state["res"] = res
             state["track_ms"], state["track_n"] = res.track_timing
-            if dist is not None and res.n_tracks:
-                rec = torch.cat([res.track_clip[:, :1] + rank * B, res.track_clip[:, 1:], res.best.view(-1, 1),
-                                 (res.scores.max(dim=1).values * 1e6).to(torch.int32).view(-1, 1)], dim=1).contiguous()
+            if dist is not None:  # every rank enters the collective, also one whose clips produced no track
+                if res.n_tracks:
+                    rec = torch.cat([res.track_clip[:, :1] + rank * B, res.track_clip[:, 1:], res.best.view(-1, 1),
+                                     (res.scores.max(dim=1).values * 1e6).to(torch.int32).view(-1, 1)], dim=1).contiguous()
+                    state["rec_width"] = rec.shape[1]
+                else:
+                    rec = torch.empty((0, state.get("rec_width", 4)), dtype=torch.int32, device=device)
                 state["gathered"] = gather_records(rec, dist)
             return res.track
         res = eng.track_batch(frames, offs, meta, outputs=outputs)
