@@ -306,16 +306,27 @@ __global__ __launch_bounds__(IT) void cpx_ir_detect_kernel(IrArgs a) {
     L.row_off[y + 1] = (u32)c;  // per-row count for now
   }
   __syncthreads();
-  if (tid == 0) {
-    u32 acc = 0;
-    L.row_off[0] = 0;
-    for (int y = 0; y < H; ++y) {
-      const u32 c = L.row_off[y + 1];
-      acc += c;
-      L.row_off[y + 1] = acc;
+  if (tid < 64) {  // exclusive scan of the per-row counts by one wave: a few rows per lane, then a shuffle scan
+    const int per = (H + 63) >> 6;
+    const int r0 = tid * per, r1 = min(H, r0 + per);
+    u32 sum = 0;
+    for (int y = r0; y < r1; ++y) sum += L.row_off[y + 1];
+    u32 incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 v = __shfl_up(incl, d, 64);
+      if (tid >= d) incl += v;
     }
-    L.misc[0] = acc;
-    if (acc > (u32)RCAP) L.misc[3] = (u32)slot_acquire(a.slot_bitmap, a.n_slots) + 1u;
+    u32 run = incl - sum;
+    for (int y = r0; y < r1; ++y) {
+      const u32 c = L.row_off[y + 1];
+      run += c;
+      L.row_off[y + 1] = run;  // inclusive: offset of row y + 1 (lanes only touch their own rows)
+    }
+    if (tid == 0) L.row_off[0] = 0;
+    if (tid == 63) {
+      L.misc[0] = incl;
+      if (incl > (u32)RCAP) L.misc[3] = (u32)slot_acquire(a.slot_bitmap, a.n_slots) + 1u;
+    }
   }
   __syncthreads();
   const int R = (int)L.misc[0];

@@ -1,5 +1,6 @@
-import sys, time
-sys.path.insert(0,'classifier-pipeline_amd'); sys.path.insert(0,'oracle')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'classifier-pipeline_amd')); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np, torch
 from cpx.engine import TrackEngine
 from cpx.ml_tools import wrresnet as wr
