@@ -382,7 +382,7 @@ def main():
         ncpu = args.cpu_clips if args.cpu_clips >= 0 else (20 if e2e else 16)  # ~15 s of single-core work
         if world == 1 and ncpu > 0:
             line["cpu_baseline"] = cpu_baseline(args.stage, ncpu, T, 1234, weights, args.frame_size)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
