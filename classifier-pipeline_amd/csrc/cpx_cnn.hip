@@ -47,6 +47,8 @@ namespace cpx {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// a native vector, not HIP's float4 struct: struct copies become memcpy calls that keep a staging array in scratch
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef CPX_CONV_ABLATE_STORE
 __device__ __forceinline__ bool v_keep(float x) { return x == 1.2345e-30f; }  // never true: no stores, no residual loads
 #endif
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   constexpr int WV = KC * COG / 4;           // float4 per tap of a weight chunk [tap][KC][COG]
   constexpr int NWI = (KS * KS * WV + CT - 1) / CT;
   const int my_c4 = tid % C4;
-  float4 pre_p[NP], pre_w[NWI];
+  f32x4 pre_p[NP], pre_w[NWI];
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
   // iteration cc = -KC only fetches chunk 0; iteration cc >= 0 commits chunk cc, fetches cc + KC, multiplies cc
   for (int cc = -KC; cc < cin_g; cc += KC) {
@@ -140,13 +142,18 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
           const int px = item / C4;
           const int py = px / PW, pxx = px - py * PW;
           const int iy = iy0 + py, ix = ix0 + pxx;
-          float4 v = pre_p[i];
-          if (a.in_scale && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          f32x4 v = pre_p[i];
+          const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          if (a.in_scale) {
             v.x = fmaxf(v.x * psc.x + psh.x, 0.0f);
             v.y = fmaxf(v.y * psc.y + psh.y, 0.0f);
             v.z = fmaxf(v.z * psc.z + psh.z, 0.0f);
             v.w = fmaxf(v.w * psc.w + psh.w, 0.0f);
           }
+          v.x = inside ? v.x : 0.0f;  // padding is zero after the prologue, as TensorFlow pads the activated tensor
+          v.y = inside ? v.y : 0.0f;
+          v.z = inside ? v.z : 0.0f;
+          v.w = inside ? v.w : 0.0f;
           float* d = s_patch + px * KP + 4 * my_c4;
           d[0] = v.x;
           d[1] = v.y;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
         const int item = tid + i * CT;
         if (item < KS * KS * WV) {
           const int tap = item / WV, r = item - tap * WV;
-          *reinterpret_cast<float4*>(s_w + tap * KC * COG + 4 * r) = pre_w[i];
+          *reinterpret_cast<f32x4*>(s_w + tap * KC * COG + 4 * r) = pre_w[i];
         }
       }
       __syncthreads();
@@ -167,35 +174,34 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
     if (cc + KC < cin_g) {
       // ---- global -> registers for the next chunk (in flight during the MFMA loop below) ----
       const int cn = cc + KC;
-      if (a.in_scale) {
+      {  // without a prologue any readable 16 bytes do (never used): no branch around the loads
         const int ch = g * cin_g + cn + 4 * my_c4;
-        psc = *reinterpret_cast<const float4*>(a.in_scale + ch);
-        psh = *reinterpret_cast<const float4*>(a.in_shift + ch);
+        psc = *reinterpret_cast<const float4*>(a.in_scale ? a.in_scale + ch : a.weights);
+        psh = *reinterpret_cast<const float4*>(a.in_scale ? a.in_shift + ch : a.weights);
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
-        const int item = tid + i * CT;
+        const int item = min(tid + i * CT, NITEM - 1);
         const int px = item / C4;
         const int py = px / PW, pxx = px - py * PW;
         const int iy = iy0 + py, ix = ix0 + pxx;
-        pre_p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // branch-free: a clamped address is always loaded (conditional loads split the block and make the compiler
+        // wait for every outstanding load at each join); out-of-image pixels are zeroed at commit
+        const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
 #ifdef CPX_CONV_ABLATE_PATCH_LOAD  // timing experiments only: results are wrong
-        if (iy == -12345)
+        pre_p[i] = f32x4{(float)cy, (float)cx, 0.f, 0.f};
 #else
-        if (item < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        pre_p[i] = *reinterpret_cast<const f32x4*>(in_n + ((cy * a.W + cx) * a.Cin + cn + 4 * my_c4));
 #endif
-          pre_p[i] = *reinterpret_cast<const float4*>(in_n + ((size_t)iy * a.W + ix) * a.Cin + cn + 4 * my_c4);
       }
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
-        const int item = tid + i * CT;
+        const int item = min(tid + i * CT, KS * KS * WV - 1);
         const int tap = item / WV, r = item - tap * WV;
-        pre_w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef CPX_CONV_ABLATE_WEIGHT_LOAD
-        pre_w[i] = make_float4(1.f, 2.f, 3.f, (float)item);
+        pre_w[i] = f32x4{1.f, 2.f, 3.f, (float)item};
 #else
-        if (item < KS * KS * WV)
-          pre_w[i] = *reinterpret_cast<const float4*>(wg + ((size_t)tap * cin_g + cn) * COG + 4 * r);
+        pre_w[i] = *reinterpret_cast<const f32x4*>(wg + ((tap * cin_g + cn) * COG + 4 * r));
 #endif
       }
     }
@@ -241,7 +247,11 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
         s_tile[i * 32 + (lane & 31)] = acc[m][t][r] * os + ob;
       }
-      __syncthreads();
+      // each wave transposes through its own 4 KB (the patch / weights are dead after the loop's last barrier) and
+      // the LDS operations of one wave complete in order: no workgroup barrier
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int f = it * 64 + lane;         // float4 index inside the tile
@@ -264,7 +274,9 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
           *reinterpret_cast<float4*>(out_n + o) = v;
         }
       }
-      if (m + 1 < NTM || t + 1 < NTN) __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
 }
