@@ -29,6 +29,29 @@ __global__ __launch_bounds__(256) void k_bf16(const uint4* in, float* out, int i
     for (int r = 0; r < 16; ++r) s += acc[i][r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NACC, int CHAIN>
+__global__ __launch_bounds__(256) void k_bf16_16(const uint4* in, float* out, int iters) {
+  bf16x8 a[3], b[3];
+  for (int p = 0; p < 3; ++p) {
+    a[p] = __builtin_bit_cast(bf16x8, in[(threadIdx.x + 64 * p) & 1023]);
+    b[p] = __builtin_bit_cast(bf16x8, in[(threadIdx.x + 64 * p + 333) & 1023]);
+  }
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+#pragma unroll
+      for (int c = 0; c < CHAIN; ++c) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c % 3], b[(c + 1) % 3], acc[i], 0, 0, 0);
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 4; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 template <int NACC, int CHAIN>
 __global__ __launch_bounds__(256) void k_f32(const float* in, float* out, int iters) {
   float a = in[threadIdx.x], b = in[threadIdx.x + 256];
@@ -81,6 +104,8 @@ int main() {
     printf("bf16 32x32x16, 2 acc x chain 6, %d waves/SIMD: %.1f TFLOP/s\n", wg_per_cu, blocks * 4.0 * iters * 12 * 32768.0 / (ms * 1e-3) / 1e12);
     ms = time_ms([&] { hipLaunchKernelGGL((k_bf16<4, 1>), dim3(blocks), dim3(256), 0, 0, din, dout, iters * 3); });
     printf("bf16 32x32x16, 4 acc x chain 1, %d waves/SIMD: %.1f TFLOP/s\n", wg_per_cu, blocks * 4.0 * iters * 3 * 4 * 32768.0 / (ms * 1e-3) / 1e12);
+    ms = time_ms([&] { hipLaunchKernelGGL((k_bf16_16<8, 6>), dim3(blocks), dim3(256), 0, 0, din, dout, iters); });
+    printf("bf16 16x16x32, 8 acc x chain 6, %d waves/SIMD: %.1f TFLOP/s\n", wg_per_cu, blocks * 4.0 * iters * 48 * 16384.0 / (ms * 1e-3) / 1e12);
     ms = time_ms([&] { hipLaunchKernelGGL((k_f32<2, 8>), dim3(blocks), dim3(256), 0, 0, dinf, dout, iters); });
     printf("f32 32x32x2, 2 acc x chain 8, %d waves/SIMD: %.1f TFLOP/s\n", wg_per_cu, blocks * 4.0 * iters * 16 * 4096.0 / (ms * 1e-3) / 1e12);
   }
