@@ -87,6 +87,7 @@ EXPORTS = [
     "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
     "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
+    "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
 ]
 
 _lib = None
@@ -146,6 +147,14 @@ def load():
     lib.cpx_set_cnn_math.restype = C.c_int
     lib.cpx_get_cnn_math.argtypes = [vp]
     lib.cpx_get_cnn_math.restype = C.c_int
+    lib.cpx_mog2_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(vp)]
+    lib.cpx_mog2_create.restype = C.c_int
+    lib.cpx_mog2_apply.argtypes = [vp, vp, C.c_double, vp]
+    lib.cpx_mog2_apply.restype = C.c_int
+    lib.cpx_mog2_background.argtypes = [vp, vp]
+    lib.cpx_mog2_background.restype = C.c_int
+    lib.cpx_mog2_destroy.argtypes = [vp]
+    lib.cpx_mog2_destroy.restype = None
     lib.cpx_ir_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.cpx_ir_detect.restype = C.c_int
     lib.cpx_cnn_create.argtypes = [vp, C.POINTER(WRResNetParams), C.POINTER(vp)]

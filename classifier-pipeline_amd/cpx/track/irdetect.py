@@ -82,3 +82,77 @@ def merge_components(rectangles, scale=None):
             # which restarts from 0 after a merge anyway)
         i = 0 if absorbed else i + 1
     return boxes
+
+
+class MOG2Background:
+    """The IR tracker's background model on the device -- the role of CVBackground("mog2") in the reference
+    (track/cliptracker.py:561-613: cv2.createBackgroundSubtractorMOG2(history=1000, detectShadows=False)), for
+    `n_streams` videos advancing in lockstep.  Frames and results are uint8 device tensors [n_streams, H, W]
+    (or [H, W] for one stream).  OpenCV's algorithm is restated, not linked: see include/cpx.h (parity with cv2 unpinned)."""
+
+    def __init__(self, engine, width, height, n_streams=1, history=1000, var_threshold=16.0):
+        import ctypes as C
+
+        self.eng = engine
+        self.shape = (n_streams, height, width)
+        self._frames = 0
+        self._background = None  # the foreground mask of the last update, as the reference names it
+        m = C.c_void_p()
+        rc = engine.lib.cpx_mog2_create(engine.h, n_streams, width, height, history, float(var_threshold), C.byref(m))
+        if rc != 0:
+            from .._lib import CpxError
+
+            raise CpxError(rc, engine._err())
+        self._m = m
+
+    def _as_batch(self, frame):
+        t = self.eng.torch
+        if frame.dim() == 2:
+            frame = frame[None]
+        if frame.dtype != t.uint8 or tuple(frame.shape) != self.shape or not frame.is_contiguous():
+            raise ValueError("MOG2Background wants contiguous uint8 frames of shape %s" % (self.shape,))
+        return frame
+
+    def set_background(self, background, frames=1):
+        self.update_background(background, learning_rate=1)
+
+    def update_background(self, thermal, filtered=None, learning_rate=-1):
+        import ctypes as C
+
+        t = self.eng.torch
+        single = thermal.dim() == 2
+        frame = self._as_batch(thermal)
+        mask = t.empty(self.shape, dtype=t.uint8, device=self.eng.device)
+        t.cuda.current_stream(self.eng.device).synchronize()
+        rc = self.eng.lib.cpx_mog2_apply(self._m, C.c_void_p(frame.data_ptr()), float(learning_rate),
+                                         C.c_void_p(mask.data_ptr()))
+        if rc != 0:
+            from .._lib import CpxError
+
+            raise CpxError(rc, self.eng._err())
+        self.eng.synchronize()
+        self._background = mask[0] if single else mask
+        self._frames += 1
+        return self._background
+
+    @property
+    def background(self):
+        import ctypes as C
+
+        t = self.eng.torch
+        out = t.empty(self.shape, dtype=t.uint8, device=self.eng.device)
+        rc = self.eng.lib.cpx_mog2_background(self._m, C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            from .._lib import CpxError
+
+            raise CpxError(rc, self.eng._err())
+        self.eng.synchronize()
+        return out[0] if self.shape[0] == 1 else out
+
+    def compute_filtered(self, thermal=None):
+        return self._background
+
+    def close(self):
+        if self._m and self.eng.h:
+            self.eng.lib.cpx_mog2_destroy(self._m)
+        self._m = None

@@ -16,7 +16,9 @@
 #include "cpx_kernels.h"
 
 struct cpx_cnn;
+struct cpx_mog2;
 static void cnn_free(cpx_cnn* c);
+static void mog2_free(cpx_mog2* m);
 
 struct cpx_handle {
   int device = 0;
@@ -47,6 +49,7 @@ struct cpx_handle {
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
   int split_min_clips = 0;  // 0 = never split
   std::vector<struct cpx_cnn*> cnns;  // networks created on this handle (destroyed with it)
+  std::vector<struct cpx_mog2*> mog2s;  // background models created on this handle
   int stream_frames = -1;
   int stream_assoc_frames = -1;
   bool stream_filt_state = false;
@@ -264,6 +267,8 @@ void cpx_destroy(cpx_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (cpx_cnn* c : h->cnns) cnn_free(c);
   h->cnns.clear();
+  for (cpx_mog2* m : h->mog2s) mog2_free(m);
+  h->mog2s.clear();
   if (h->ws) hipFree(h->ws);
   if (h->wtab_dev) hipFree(h->wtab_dev);
   if (h->nlm_lut_dev) hipFree(h->nlm_lut_dev);
@@ -1057,6 +1062,105 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
   }
   return cpx_cnn_head(h, cur, N, hh * ww, c_in, p.final_scale, p.final_shift, p.dense_w, p.dense_b, p.n_labels,
                       logits_dev, probs_dev);
+}
+
+// ---- IR background model ---------------------------------------------------------------------------------------------
+struct cpx_mog2 {
+  cpx_handle* h = nullptr;
+  int n_streams = 0, width = 0, height = 0, history = 0, nframes = 0;
+  float var_threshold = 16.0f;
+  size_t n = 0;
+  float* state = nullptr;        // weight | var | mean, each [5][n]
+  unsigned char* modes = nullptr;
+};
+
+static void mog2_free(cpx_mog2* m) {
+  if (m->state) hipFree(m->state);
+  if (m->modes) hipFree(m->modes);
+  delete m;
+}
+
+int cpx_mog2_create(cpx_handle* h, int n_streams, int width, int height, int history, float var_threshold,
+                    cpx_mog2** out) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!out || n_streams < 1 || width < 1 || height < 1 || !(var_threshold > 0.0f))
+    return fail(h, CPX_ERR_INVALID, "cpx_mog2_create: bad argument");
+  *out = nullptr;
+  CPX_ENTER(h);
+  cpx_mog2* m = new (std::nothrow) cpx_mog2();
+  if (!m) return fail(h, CPX_ERR_NOMEM, "cpx_mog2_create: out of memory");
+  m->h = h;
+  m->n_streams = n_streams;
+  m->width = width;
+  m->height = height;
+  m->history = history > 0 ? history : 500;
+  m->var_threshold = var_threshold;
+  m->n = (size_t)n_streams * width * height;
+  if (hipMalloc(reinterpret_cast<void**>(&m->state), 15 * m->n * sizeof(float)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&m->modes), m->n) != hipSuccess) {
+    (void)hipGetLastError();
+    mog2_free(m);
+    return fail(h, CPX_ERR_NOMEM, "cpx_mog2_create: state allocation failed");
+  }
+  CPX_HIP(h, hipMemsetAsync(m->state, 0, 15 * m->n * sizeof(float), h->stream));
+  CPX_HIP(h, hipMemsetAsync(m->modes, 0, m->n, h->stream));
+  h->mog2s.push_back(m);
+  *out = m;
+  return CPX_OK;
+}
+
+void cpx_mog2_destroy(cpx_mog2* m) {
+  if (!m) return;
+  cpx_handle* h = m->h;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  h->mog2s.erase(std::remove(h->mog2s.begin(), h->mog2s.end(), m), h->mog2s.end());
+  mog2_free(m);
+}
+
+static cpx::Mog2Args mog2_args(const cpx_mog2* m) {
+  cpx::Mog2Args a{};
+  a.n = m->n;
+  a.var_threshold = m->var_threshold;
+  a.background_ratio = 0.9f;
+  a.var_threshold_gen = 9.0f;
+  a.var_init = 15.0f;
+  a.var_min = 4.0f;
+  a.var_max = 75.0f;
+  a.weight = m->state;
+  a.var = m->state + 5 * m->n;
+  a.mean = m->state + 10 * m->n;
+  a.modes = m->modes;
+  return a;
+}
+
+int cpx_mog2_apply(cpx_mog2* m, const uint8_t* frames_dev, double learning_rate, uint8_t* fgmask_dev) {
+  if (!m) return CPX_ERR_INVALID;
+  cpx_handle* h = m->h;
+  if (!frames_dev || !fgmask_dev) return fail(h, CPX_ERR_INVALID, "cpx_mog2_apply: null argument");
+  CPX_ENTER(h);
+  m->nframes += 1;
+  const double rate = (learning_rate >= 0 && m->nframes > 1) ? learning_rate
+                                                            : 1.0 / std::min(2 * m->nframes, m->history);
+  cpx::Mog2Args a = mog2_args(m);
+  a.alphaT = (float)rate;
+  a.alpha1 = 1.0f - a.alphaT;
+  a.prune = (float)(-rate * 0.05f);  // -learningRate * fCT, fCT a float member as in the reference implementation
+  a.frames = frames_dev;
+  a.mask = fgmask_dev;
+  cpx::launch_mog2_apply(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_mog2_background(cpx_mog2* m, uint8_t* out_dev) {
+  if (!m) return CPX_ERR_INVALID;
+  cpx_handle* h = m->h;
+  if (!out_dev) return fail(h, CPX_ERR_INVALID, "cpx_mog2_background: null argument");
+  CPX_ENTER(h);
+  cpx::launch_mog2_background(mog2_args(m), out_dev, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
 }
 
 int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int width, int height, int threshold,

@@ -241,6 +241,20 @@ int launch_ir_detect(const IrArgs& a, int n_frames, hipStream_t s);
 int ir_supported(int W, int H);
 size_t ir_slot_bytes(int W, int H);
 
+struct Mog2Args {
+  size_t n;  // streams * width * height
+  float alphaT, alpha1, prune;
+  float var_threshold, background_ratio, var_threshold_gen, var_init, var_min, var_max;
+  const unsigned char* frames;  // [n]
+  float* weight;                // [5][n] mode-major planes
+  float* var;
+  float* mean;
+  unsigned char* modes;         // [n]
+  unsigned char* mask;          // [n]
+};
+void launch_mog2_apply(const Mog2Args& a, hipStream_t s);
+void launch_mog2_background(const Mog2Args& a, unsigned char* out, hipStream_t s);
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

@@ -351,6 +351,23 @@ int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int wi
                   int max_components, cpx_component* comps_dev, int32_t* counts_dev, int32_t* status_dev,
                   int32_t* labels_dev);
 
+/* ---- IR background model ---------------------------------------------------------------
+ * Replaces CVBackground (track/cliptracker.py:561-613): cv2.createBackgroundSubtractorMOG2(history, varThreshold,
+ * detectShadows=False) for `n_streams` independent 8-bit single-channel videos of `width` x `height` advancing in
+ * lockstep (one frame each per call).  cpx_mog2_apply = .apply(frame, None, learning_rate): frames_dev uint8
+ * [n_streams, height, width] -> fgmask_dev uint8 (0 / 255), the mixture state in the object is updated; a negative
+ * learning_rate (and the first frame) uses 1 / min(2 * frames seen, history), as OpenCV does.
+ * cpx_mog2_background = .getBackgroundImage() -> out_dev uint8 [n_streams, height, width].
+ * The algorithm is OpenCV's (un-vendored: opencv-contrib-python-headless~=4.12, bgfg_gaussmix2.cpp), restated from
+ * the published update: parity with cv2 itself is unpinned (no cv2 / golden here); the HIP kernel is bit-equal to
+ * oracle/mog2_oracle.c.  The object belongs to its handle (freed by cpx_destroy if still alive). */
+typedef struct cpx_mog2 cpx_mog2;
+int cpx_mog2_create(cpx_handle* h, int n_streams, int width, int height, int history, float var_threshold,
+                    cpx_mog2** out);
+int cpx_mog2_apply(cpx_mog2* m, const uint8_t* frames_dev, double learning_rate, uint8_t* fgmask_dev);
+int cpx_mog2_background(cpx_mog2* m, uint8_t* out_dev);
+void cpx_mog2_destroy(cpx_mog2* m);
+
 /* ---- CNN forward building blocks (WR-ResNet, ml_tools/resnet/wr_resnet.py:5-98) -----------
  * Replaces tf.keras Conv2D(groups) / BatchNormalization / Activation / Add / GlobalAveragePooling2D /
  * Dense as used by KerasModel.predict (ml_tools/kerasmodel.py:856-859).  Activations NHWC float32.

@@ -50,6 +50,32 @@ for kind in ("blobs", "noise"):
         dt = (time.perf_counter() - t0) / 5
         res["kernel_%s%s" % (kind, "+labels" if lab is not None else "")] = {"frames_per_s": n / dt, "ms_per_batch": dt * 1e3,
                                                                            "input_GBps": n * 640 * 480 / dt / 1e9}
+# MOG2 background model: 64 streams of 640x480 in lockstep, kernel only
+from cpx.track.irdetect import MOG2Background
+S = 64
+bgm = MOG2Background(eng, 640, 480, n_streams=S)
+vid = (torch.rand((8, S, 480, 640), device=eng.device) * 6 + 100).to(torch.uint8)
+mask = torch.empty((S, 480, 640), dtype=torch.uint8, device=eng.device)
+for t in range(8):
+    bgm.update_background(vid[t])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+reps = 40
+for r in range(reps):
+    rc = eng.lib.cpx_mog2_apply(bgm._m, C.c_void_p(vid[r % 8].data_ptr()), -1.0, C.c_void_p(mask.data_ptr()))
+    assert rc == 0
+eng.synchronize()
+dt = (time.perf_counter() - t0) / reps
+res["kernel_mog2_apply"] = {"frames_per_s": S / dt, "ms_per_batch": dt * 1e3, "streams": S,
+                            "algorithmic_GBps": S * 640 * 480 * 124 / dt / 1e9}
+bgm.close()
+import mog2_oracle as mo
+om = mo.MOG2(640, 480)
+fr = vid[:, 0].cpu().numpy()
+t0 = time.perf_counter()
+for t in range(8):
+    om.apply(fr[t])
+res["mog2_oracle_cpu_frames_per_s"] = 8 / (time.perf_counter() - t0)
 # CPU: the oracle (numpy restatement) on the same masks
 import ir_oracle as iro
 t0 = time.perf_counter()

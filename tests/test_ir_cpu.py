@@ -52,3 +52,31 @@ def test_host_merge_components_matches_reference():
         b = rng.integers(0, 60, 5)
         assert irdetect.rect_distance(a, b) == iro.rect_distance(a, b)
     assert n > 20
+
+
+def test_mog2_oracle_behaviour():
+    """oracle/mog2_oracle.c (parity with cv2 unpinned): the properties the published algorithm guarantees -- the first
+    frame is all foreground (no mode yet), a static noisy scene becomes background, a moving object is foreground,
+    the background image tracks the scene, and learning rate 0 adds no mode."""
+    import mog2_oracle as mo
+
+    H, W = 60, 80
+    rng = np.random.default_rng(4)
+    scene = rng.integers(40, 200, size=(H, W)).astype(np.int32)
+    m = mo.MOG2(W, H)
+    noisy = lambda: np.clip(scene + rng.integers(-2, 3, size=(H, W)), 0, 255).astype(np.uint8)
+    assert (m.apply(noisy()) == 255).all()
+    for _ in range(20):
+        mask = m.apply(noisy())
+    assert (mask > 0).mean() < 0.01
+    assert np.abs(m.getBackgroundImage().astype(int) - scene).max() <= 3
+    f = noisy()
+    f[10:30, 20:50] = 250
+    mask = m.apply(f)
+    assert (mask[10:30, 20:50] == 255).all() and (mask > 0).sum() <= 20 * 30 + 50
+    before = [a.copy() for a in m.state()]
+    m.apply(f, learning_rate=0.0)
+    after = m.state()
+    assert np.array_equal(before[3], after[3])  # learning rate 0: no new modes (and alpha = 0 moves nothing)
+    assert np.allclose(before[2], after[2])
+    m.close()

@@ -125,3 +125,74 @@ def test_ir_detect_batch_and_arguments(engine):
         engine.ir_detect(torch.zeros((1, 48, 100), dtype=torch.uint8, device=engine.device), 0, 16)
     with pytest.raises(ValueError):
         engine.ir_detect(torch.zeros((48, 128), dtype=torch.uint8, device=engine.device), 0, 16)
+
+
+def _ir_video(rng, n, H, W):
+    """uint8 frames: a static textured scene with sensor noise, a bright object crossing it, a lighting step."""
+    scene = rng.integers(40, 200, size=(H, W)).astype(np.int32)
+    frames = []
+    for t in range(n):
+        f = scene + rng.integers(-2, 3, size=(H, W))
+        if t >= n // 2:
+            f = f + 6  # global illumination change: modes drift / new modes appear
+        if 5 <= t:
+            x0 = (7 * t) % (W - 40)
+            f[H // 3:H // 3 + 30, x0:x0 + 40] = 240 - (t % 3)
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+    return np.stack(frames)
+
+
+@pytest.mark.parametrize("shape,rates", [((120, 160), None), ((480, 640), None), ((64, 96), [1, -1, -1, 0.0, 0.01, -1, 0.5, -1])])
+def test_mog2_matches_oracle(engine, shape, rates):
+    """cpx_mog2_apply / cpx_mog2_background against oracle/mog2_oracle.c frame by frame: masks and background images
+    bit for bit (float32 state, same operation order).  Parity with cv2 itself is unpinned."""
+    import torch
+
+    import mog2_oracle as mo
+    from cpx.track.irdetect import MOG2Background
+
+    H, W = shape
+    rng = np.random.default_rng(H + W)
+    n = 24 if H < 400 else 10
+    video = _ir_video(rng, n, H, W)
+    ora = mo.MOG2(W, H, history=1000, var_threshold=16.0)
+    dev = MOG2Background(engine, W, H, n_streams=1, history=1000, var_threshold=16.0)
+    fg_seen = 0
+    for t in range(n):
+        lr = -1 if rates is None else rates[t % len(rates)]
+        want = ora.apply(video[t], lr)
+        got = dev.update_background(torch.from_numpy(video[t]).to(engine.device), learning_rate=lr)
+        assert np.array_equal(got.cpu().numpy(), want), (t, lr)
+        assert np.array_equal(dev.background.cpu().numpy(), ora.getBackgroundImage()), t
+        fg_seen += int((want > 0).sum()) if t > 5 else 0
+    assert fg_seen > 300  # the moving object was detected
+    dev.close()
+    ora.close()
+
+
+def test_mog2_streams_and_detection_chain(engine):
+    """Several streams in lockstep equal the streams one by one, and mask -> cpx_ir_detect -> merge runs on the result."""
+    import torch
+
+    import ir_oracle as iro
+    import mog2_oracle as mo
+    from cpx.track import irdetect
+
+    H, W, S, n = 240, 320, 3, 12
+    rngs = [np.random.default_rng(50 + s) for s in range(S)]
+    videos = [_ir_video(r, n, H, W) for r in rngs]
+    oras = [mo.MOG2(W, H) for _ in range(S)]
+    dev = irdetect.MOG2Background(engine, W, H, n_streams=S)
+    for t in range(n):
+        batch = torch.from_numpy(np.stack([v[t] for v in videos])).to(engine.device)
+        masks = dev.update_background(batch)
+        want = np.stack([o.apply(v[t]) for o, v in zip(oras, videos)])
+        assert np.array_equal(masks.cpu().numpy(), want), t
+    # the last masks through the detection stage
+    res = irdetect.detect_objects_ir(engine, masks.contiguous(), threshold=0, max_components=8192)
+    for s in range(S):
+        n_o, _, stats_o = iro.detect_objects_ir(want[s], threshold=0)
+        assert res[s][0] == n_o and np.array_equal(res[s][2][1:], stats_o[1:, :5].astype(np.int32))
+        merged = irdetect.merge_components(res[s][2][1:].copy())
+        assert [[int(v) for v in r] for r in merged] == [[int(v) for v in r] for r in iro.merge_components(stats_o[1:].copy())]
+    dev.close()
