@@ -6,9 +6,13 @@ from cpx.engine import TrackEngine
 from cpx.ml_tools import wrresnet as wr
 eng = TrackEngine()
 w = wr.random_weights(17, seed=3)
+if os.environ.get('PROBE_ZERO'):
+    w = {k: (np.zeros_like(v) if hasattr(v, 'dtype') and v.dtype == np.float32 else v) for k, v in w.items()}
 net = wr.WRResNetDevice(eng, w, 17)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 x = torch.rand((N,160,160,2), device=eng.device)*255
+if os.environ.get('PROBE_ZERO'):
+    x.zero_()
 net.forward(x)
 eng.conv_timing(True)
 torch.cuda.synchronize(); t=time.time()
