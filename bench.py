@@ -149,6 +149,110 @@ def pmc_traffic(section, units_per_launch):
         return None
 
 
+def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
+    """--stage ir: S synthetic 640x480 uint8 videos per GPU advance in lockstep through cpx_mog2_apply and cpx_ir_detect
+    (frames resident in HBM; the per-frame component counts are what a step produces; the host-side merge of fragments
+    and the tracker behind it are not part of this stage).  value = frames/s; roofline: the MOG2 kernel, HBM-bound,
+    124 algorithmic bytes per pixel (61 B of mixture state read and written, 1 B frame, 1 B mask)."""
+    import ctypes as C
+
+    from cpx.engine import TrackEngine
+    from cpx.track.irdetect import MOG2Background
+
+    H, W = 480, 640
+    S = args.clips or 64
+    T = min(args.frames, 32)
+    eng = TrackEngine(model="lepton3", device=local_rank)
+    g = torch.Generator(device=device)
+    g.manual_seed(99 + rank)
+    scene = torch.randint(40, 200, (S, 1, H, W), generator=g, device=device, dtype=torch.int16)
+    video = (scene + torch.randint(-2, 3, (S, T, H, W), generator=g, device=device, dtype=torch.int16))
+    for t in range(T):  # a bright block crossing every scene
+        x0 = (11 * t) % (W - 60)
+        video[:, t, 150:200, x0:x0 + 60] = 235
+    video = video.clamp_(0, 255).to(torch.uint8).permute(1, 0, 2, 3).contiguous()  # [T, S, H, W]
+    bg = MOG2Background(eng, W, H, n_streams=S)
+    mask = torch.empty((S, H, W), dtype=torch.uint8, device=device)
+    cap = 1024
+    comps = torch.empty((S, cap, 8), dtype=torch.int32, device=device)
+    counts = torch.zeros((T, S), dtype=torch.int32, device=device)
+    status = torch.zeros((T, S), dtype=torch.int32, device=device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    stream = eng.torch_stream() if hasattr(eng, "torch_stream") else None
+
+    def step(timed=False):
+        ms = 0.0
+        for t in range(T):
+            rc = eng.lib.cpx_mog2_apply(bg._m, C.c_void_p(video[t].data_ptr()), -1.0, C.c_void_p(mask.data_ptr()))
+            assert rc == 0, eng._err()
+            rc = eng.lib.cpx_ir_detect(eng.h, C.c_void_p(mask.data_ptr()), S, W, H, 0, cap, C.c_void_p(comps.data_ptr()),
+                                       C.c_void_p(counts[t].data_ptr()), C.c_void_p(status[t].data_ptr()), None)
+            assert rc == 0, eng._err()
+        eng.synchronize()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    torch.cuda.synchronize(device)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    # the MOG2 kernel alone, timed on the handle's stream by wall clock around back-to-back launches
+    eng.synchronize()
+    t0 = time.perf_counter()
+    reps = 4 * T
+    for r in range(reps):
+        eng.lib.cpx_mog2_apply(bg._m, C.c_void_p(video[r % T].data_ptr()), -1.0, C.c_void_p(mask.data_ptr()))
+    eng.synchronize()
+    mog2_s = (time.perf_counter() - t0) / reps
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert int(status.max().item()) == 0 and int(counts[T // 2:].max().item()) >= 1
+    if rank == 0:
+        algo = S * H * W * 124.0
+        gbs = algo / mog2_s / 1e9
+        line = {"metric": "IR 640x480 frames/s through the background model + detection stage (front half of configs[4])",
+                "value": round(world * S * T * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8 frames / masks, f32 mixture state (MOG2), 1-bit rows + i32 statistics (detection)",
+                "data": "synthetic",
+                "config": {"workload": "synthetic 640x480 uint8 videos: cpx_mog2_apply + cpx_ir_detect per frame, "
+                                       "streams in lockstep", "streams_per_gpu": S, "frames_per_stream": T},
+                "roofline": {"kernel": "cpx_mog2_apply_kernel", "bound": "hbm", "achieved": round(gbs, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                             "avg_launch_us": round(mog2_s * 1e6, 2), "algorithmic_bytes_per_launch": algo}}
+        if world == 1 and args.cpu_clips != 0:
+            import ir_oracle as iro
+            import mog2_oracle as mo
+
+            om = mo.MOG2(W, H)
+            host = video[:, 0].cpu().numpy()
+            t0 = time.perf_counter()
+            nfr = min(T, 24)
+            for t in range(nfr):
+                iro.detect_objects_ir(om.apply(host[t]), threshold=0)
+            dt = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": round(nfr / dt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": "%d frames of one stream: oracle MOG2 (C) + detect_objects_ir (NumPy), %.1f s"
+                                              % (nfr, dt)}
+        print(json.dumps(line), flush=True)
+    bg.close()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,8 +260,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default 4096, reduced if HBM is short)")
     ap.add_argument("--frames", type=int, default=270)
-    ap.add_argument("--stage", choices=("e2e", "track"), default="e2e",
-                    help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only")
+    ap.add_argument("--stage", choices=("e2e", "track", "ir"), default="e2e",
+                    help="e2e: track + classify (the BASELINE metric); track: configs[1] kernels only; ir: the 640x480 "
+                         "IR front half of configs[4] (MOG2 background model + detection stage, SURVEY section 8 f4)")
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cnn-chunk", type=int, default=0,
                     help="samples per CNN forward (default 2048 at frame size 32 = 54 GB of activations, 512 at 64)")
@@ -197,6 +302,8 @@ def main():
     from cpx.pipeline import BatchPipeline
     from cpx.sharding import gather_records
 
+    if args.stage == "ir":
+        return bench_ir(args, torch, np, dist, device, rank, world, local_rank)
     e2e = args.stage == "e2e"
     H, W, T = 120, 160, args.frames
     P = H * W

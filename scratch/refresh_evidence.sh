@@ -10,6 +10,7 @@ python3 bench.py --cnn-math f32 --cpu-clips 0 > gpurun_out/ev/r01_bench_e2e_f32m
 python3 bench.py --stage track > gpurun_out/ev/r01_bench_track.json 2>/dev/null
 python3 bench.py --stage track --denoise --cpu-clips 0 > gpurun_out/ev/r01_bench_track_denoise.json 2>/dev/null
 python3 bench.py --frame-size 64 --cpu-clips 0 > gpurun_out/ev/r01_bench_e2e_fs64.json 2>/dev/null
+python3 bench.py --stage ir > gpurun_out/ev/r01_bench_ir.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_e2e -- python3 $ROOT/bench.py --cpu-clips 0 > $ROOT/gpurun_out/ev/prof_e2e.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
