@@ -177,11 +177,8 @@ def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
     comps = torch.empty((S, cap, 8), dtype=torch.int32, device=device)
     counts = torch.zeros((T, S), dtype=torch.int32, device=device)
     status = torch.zeros((T, S), dtype=torch.int32, device=device)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    stream = eng.torch_stream() if hasattr(eng, "torch_stream") else None
 
-    def step(timed=False):
-        ms = 0.0
+    def step():
         for t in range(T):
             rc = eng.lib.cpx_mog2_apply(bg._m, C.c_void_p(video[t].data_ptr()), -1.0, C.c_void_p(mask.data_ptr()))
             assert rc == 0, eng._err()
