@@ -305,6 +305,225 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Flattened tiling for small maps.  The 27 x 27 maps of stage 4 (54 x 54 at frame size 64) fill 4 x 32 bands to only
+// 81 %; here a workgroup takes 128 CONSECUTIVE output positions of a sample in row-major order (729 = 5.7 bands:
+// 95 %), stages the input rows they touch at full width, and every lane derives its pixel from its position.  Same
+// staging format, MFMA loop and epilogue as conv_bf3_kernel; the output offset of a position is simply p * Cout.
+template <int NTN, int NPXC>
+__global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+  constexpr int KS = 3, CT = 256;
+  constexpr int COGW = 32 * NTN;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  uint4* s_patch = lds4;             // [3][2][NPXC]
+  uint4* s_w = lds4 + 6 * NPXC;      // [3][9][2][COGW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  int q = div_magic(bid, td.m_nsplit);
+  const int ns = bid - q * td.nsplit;
+  bid = q;
+  q = div_magic(bid, td.m_tx);
+  const int ti = bid - q * td.tiles_x;  // band of 128 positions inside the sample
+  const int n = q;
+  const int g = blockIdx.y;
+  const int M = a.Ho * a.Wo;
+  const int p0 = ti * 128;
+  const int y_first = p0 / a.Wo, y_last = min(p0 + 127, M - 1) / a.Wo;
+  const int PW = a.W + 2, PH = y_last - y_first + 3;  // stride 1, 3 x 3, SAME: one halo row / column each side
+  const int npx = PH * PW;
+  const int iy0 = y_first - a.pad_top, ix0 = -a.pad_left;
+  const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
+  const int nchunks = cin_g / KC;
+  const uint4* wg = wimg + (size_t)g * nchunks * 54 * cout_g + (size_t)ns * COGW;
+
+  f32x16 acc[NTN];
+#pragma unroll
+  for (int t = 0; t < NTN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const int kh = lane >> 5;
+  const int pl = min(p0 + wave * 32 + (lane & 31), M - 1);  // this lane's output position (clamped: never stored)
+  const int ly = pl / a.Wo, lx = pl - ly * a.Wo;
+  const int a_base = kh * NPXC + (ly - y_first) * PW + lx;
+  const int b_base = kh * COGW + (lane & 31);
+
+  constexpr int NP = (2 * NPXC + CT - 1) / CT;
+  constexpr int NW = 54 * COGW;
+  constexpr int NWI = (NW + CT - 1) / CT;
+  const int my_h = tid & 1;
+  int item_py[NP], item_px[NP], item_e[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int item = min(tid + i * CT, 2 * npx - 1);  // surplus threads repeat the last item (same value, same slot)
+    const int px = item >> 1;
+    item_py[i] = px / PW;
+    item_px[i] = px - item_py[i] * PW;
+    item_e[i] = my_h * NPXC + px;
+  }
+  f32x4 pre_p[NP][2];
+  u32x4 pre_w[NWI];
+  f32x4 psc[2], psh[2];
+  for (int cc = -1; cc < nchunks; ++cc) {
+    if (cc >= 0) {
+      // ---- registers -> LDS: BatchNorm + ReLU prologue, padding zeroed, split into bf16 planes ----
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int iy = iy0 + item_py[i], ix = ix0 + item_px[i];
+        const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pre_p[i][j >> 2][j & 3];
+        if (a.in_scale) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * psc[j >> 2][j & 3] + psh[j >> 2][j & 3], 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
+        unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], q0[j], q1[j], q2[j]);
+        u32x4* sp4 = reinterpret_cast<u32x4*>(s_patch);
+        sp4[0 * 2 * NPXC + item_e[i]] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        sp4[1 * 2 * NPXC + item_e[i]] = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        sp4[2 * 2 * NPXC + item_e[i]] = u32x4{q2[0], q2[1], q2[2], q2[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        const int item = tid + i * CT;
+        if (item < NW) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
+      }
+      __syncthreads();
+    }
+    if (cc + 1 < nchunks) {
+      // ---- global -> registers for the next chunk (in flight during the MFMA loop below), branch-free ----
+      const int cn = (cc + 1) * KC;
+      {
+        const int ch = g * cin_g + cn + 8 * my_h;
+        const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);
+        const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);
+        psc[0] = *reinterpret_cast<const f32x4*>(scp);
+        psc[1] = *reinterpret_cast<const f32x4*>(scp + 4);
+        psh[0] = *reinterpret_cast<const f32x4*>(shp);
+        psh[1] = *reinterpret_cast<const f32x4*>(shp + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int cy = min(max(iy0 + item_py[i], 0), a.H - 1), cx = min(max(ix0 + item_px[i], 0), a.W - 1);
+        const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 8 * my_h);
+        pre_p[i][0] = *reinterpret_cast<const f32x4*>(src);
+        pre_p[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+      const u32x4* wc = reinterpret_cast<const u32x4*>(wg + (size_t)(cc + 1) * 54 * cout_g);
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        const int item = min(tid + i * CT, NW - 1);
+        const int pth = item / COGW, col = item - pth * COGW;
+        pre_w[i] = wc[pth * cout_g + col];
+      }
+    }
+    if (cc >= 0) {
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; ++tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        bf16x8 av[3], bv[NTN][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          av[p] = __builtin_bit_cast(bf16x8, s_patch[p * 2 * NPXC + a_base + ky * PW + kx]);
+#pragma unroll
+          for (int t = 0; t < NTN; ++t)
+            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * 9 + tap) * 2 * COGW + b_base + t * 32]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[t][1], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][2], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[t][0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][1], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[t][0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][0], acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: as conv_bf3_kernel; the NHWC offset of flattened position p is p * Cout ----
+  float* out_n = a.out + (size_t)n * M * a.Cout;
+  const float* res_n = a.residual ? a.residual + (size_t)n * M * a.Cout : nullptr;
+  float* s_tile = reinterpret_cast<float*>(lds4) + wave * (32 * 32);
+  const int ch0 = g * cout_g + ns * COGW;
+#pragma unroll
+  for (int t = 0; t < NTN; ++t) {
+    const int ch = ch0 + t * 32 + (lane & 31);
+    const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+    const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      s_tile[i * 32 + (lane & 31)] = acc[t][r] * os + ob;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = it * 64 + lane;
+      const int i = f >> 3, c4 = f & 7;
+      const int p = p0 + wave * 32 + i;
+      if (p < M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + i * 32 + 4 * c4);
+        const int o = p * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+        if (res_n) v += *reinterpret_cast<const f32x4*>(res_n + o);
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        }
+        *reinterpret_cast<f32x4*>(out_n + o) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+template <int NTN, int NPXC>
+int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
+  const size_t lds = ((size_t)6 * NPXC + (size_t)54 * 32 * NTN) * 16;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
+      return -1;
+    configured = true;
+  }
+  TileDiv td;
+  td.tiles_x = (a.Ho * a.Wo + 127) / 128;
+  td.tiles_y = 1;
+  td.nsplit = (a.Cout / a.groups) / (32 * NTN);
+  const long long blocks = (long long)td.tiles_x * a.N * td.nsplit;
+  if (blocks >= (1 << 22) || td.tiles_x >= 4096) return -3;
+  td.m_nsplit = (1ull << 42) / td.nsplit + 1;
+  td.m_tx = (1ull << 42) / td.tiles_x + 1;
+  td.m_ty = (1ull << 42) + 1;
+  hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC>), dim3((unsigned)blocks, a.groups), dim3(256), lds, s, a, wimg, td);
+  return 0;
+}
+// the flattened tiling applies to stride-1 SAME 3 x 3 layers whose staged rows fit the LDS cap and pays when the
+// rectangular bands waste more than 8 % over it
+static bool flat_pays(const ConvArgs& a, int TW, int TH, int npx_cap) {
+  if (a.stride != 1 || a.ksize != 3 || a.pad_top != 1 || a.pad_left != 1 || a.H != a.Ho || a.W != a.Wo) return false;
+  const int M = a.Ho * a.Wo;
+  const int rows = (127 + a.Wo - 1) / a.Wo + 1;
+  if ((rows + 2) * (a.W + 2) > npx_cap) return false;
+  const double rect = (double)M / ((double)((a.Wo + TW - 1) / TW) * TW * ((a.Ho + TH - 1) / TH) * TH);
+  const double flat = (double)M / ((double)((M + 127) / 128) * 128);
+  return flat > rect + 0.08;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Wave-specialised form of the same convolution (-DCPX_BF3_WS; correct, tests pass, NOT the default: slower).  In the kernel above a workgroup alternates between a VALU / memory
 // phase (fetch, split, stage) and a matrix phase, and two resident workgroups per CU do not hide one another: the
 // phases add up.  Here a persistent 512-thread workgroup gives the two kinds of work to
@@ -1159,6 +1378,11 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
 #endif
   if (cout_g == 32) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2>(a, w, s);
   if (cout_g == 64) return launch_bf3_t<CPX_BF3_NTN_S3, 1, CPX_BF3_NB_S3, CPX_BF3_TW_S3, CPX_BF3_CT_S3>(a, w, s);
+#ifndef CPX_BF3_NO_FLAT
+  // two workgroups per CU either way: 256 staged pixels + two N tiles (80 KB), or 384 pixels + one N tile (65 KB)
+  if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256)) return launch_bf3flat_t<2, 256>(a, w, s);
+  if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 384)) return launch_bf3flat_t<1, 384>(a, w, s);
+#endif
   if (cout_g == 128) return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
   return -2;
 }
