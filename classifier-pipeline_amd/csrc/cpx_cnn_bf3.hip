@@ -1379,9 +1379,10 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   if (cout_g == 32) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2>(a, w, s);
   if (cout_g == 64) return launch_bf3_t<CPX_BF3_NTN_S3, 1, CPX_BF3_NB_S3, CPX_BF3_TW_S3, CPX_BF3_CT_S3>(a, w, s);
 #ifndef CPX_BF3_NO_FLAT
-  // two workgroups per CU either way: 256 staged pixels + two N tiles (80 KB), or 384 pixels + one N tile (65 KB)
+  // 256 staged pixels + two N tiles = 80 KB: two workgroups per CU.  (Wider maps -- 54 x 54 at frame size 64 -- would
+  // need 384 staged pixels and then fit only one N tile per workgroup: measured slower than the rectangular bands,
+  // 399 vs 371 ms, the patch being activated and split by four column slices instead of two.)
   if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256)) return launch_bf3flat_t<2, 256>(a, w, s);
-  if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 384)) return launch_bf3flat_t<1, 384>(a, w, s);
 #endif
   if (cout_g == 128) return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
   return -2;
