@@ -200,3 +200,27 @@ def test_retrack_keeps_the_tracks_of_the_metadata_file(tmp_path):
     assert [key(t) for t in m1["tracks"]] == [key(t) for t in m2["tracks"]]
     assert [(t["frame_start"], t["frame_end"]) for t in m1["tracks"]] == [
         (t["frame_start"], t["frame_end"]) for t in m2["tracks"]]
+
+
+def test_tracking_speed_like_the_reference():
+    """The reference's one asserting test (tests/test_tracking_speed.py:13-44), same shape: ClipTrackExtractor.parse_clip
+    with Config.get_defaults() on the clip without and the clip with a background frame, < 40 ms per frame (the
+    reference's own bound; the device path takes well under 2 ms, first-call initialisation included)."""
+    import time
+
+    from cpx.config import Config
+    from cpx.track.clip import Clip
+    from cpx.track.cliptrackextractor import ClipTrackExtractor
+
+    MAX_FRAME_MS = 40
+    config = Config.get_defaults()
+    track_extractor = ClipTrackExtractor(config.tracking, config.use_opt_flow, cache_to_disk=False, verbose=config.verbose)
+    for name in ("hedgehog.cptv", "possum.cptv"):
+        file_name = os.path.join(GOLDEN, name)
+        start = time.time()
+        clip = Clip(config.tracking["thermal"], file_name)
+        assert track_extractor.parse_clip(clip)
+        ms_per_frame = (time.time() - start) * 1000 / max(1, len(clip.frame_buffer.frames))
+        print("Took {:.1f}ms per frame".format(ms_per_frame))
+        assert ms_per_frame < MAX_FRAME_MS
+        assert len(clip.frame_buffer.frames) > 100
