@@ -388,13 +388,8 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t s) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   size_t lds = (((size_t)PH * PW * (KC + 1) + 3) / 4 * 4 + (size_t)KS * KS * KC * 32 * NTN) * sizeof(float);
   if (lds < 4 * 32 * 32 * sizeof(float)) lds = 4 * 32 * 32 * sizeof(float);  // epilogue tiles
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS, NTM, TW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_mfma_kernel<KC, NTN, S, KS, NTM, TW>), lds_ready, 160 * 1024 - 1024)) return -1;
   const int tiles = ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
   hipLaunchKernelGGL((conv_mfma_kernel<KC, NTN, S, KS, NTM, TW>), dim3(tiles * a.N, a.groups), dim3(CT), lds, s, a);
   return 0;

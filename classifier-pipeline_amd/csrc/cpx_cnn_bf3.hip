@@ -492,13 +492,8 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
 template <int NTN, int NPXC>
 int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = ((size_t)6 * NPXC + (size_t)54 * 32 * NTN) * 16;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Ho * a.Wo + 127) / 128;
   td.tiles_y = 1;
@@ -866,13 +861,8 @@ int launch_bf3ws_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int TB = 128 / TW, TH = TB * NB;
   constexpr int PH = TH + 2, PW = TW + 2;
   const size_t lds = ((size_t)2 * (6 * PH * PW + 54 * 32 * NTN)) * 16 + 4 * 32 * 32 * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3ws_kernel<NTN, NB, TW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3ws_kernel<NTN, NB, TW>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Wo + TW - 1) / TW;
   td.tiles_y = (a.Ho + TH - 1) / TH;
@@ -1231,13 +1221,8 @@ int launch_bf3db_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int TB = 128 / TW, TH = TB * NB;
   constexpr int PH = TH + 2, PW = TW + 2;
   const size_t lds = ((size_t)2 * (6 * PH * PW + 54 * 32 * NTN)) * 16 + 8 * 32 * 32 * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3db_kernel<NTN, NB, TW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3db_kernel<NTN, NB, TW>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Wo + TW - 1) / TW;
   td.tiles_y = (a.Ho + TH - 1) / TH;
@@ -1292,13 +1277,8 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
   size_t lds = ((size_t)6 * PH * PW + (size_t)54 * 32 * NTN) * 16;
   if (lds < (CT / 64) * 32 * 32 * sizeof(float)) lds = (CT / 64) * 32 * 32 * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Wo + TW - 1) / TW;
   td.tiles_y = (a.Ho + TH - 1) / TH;

@@ -86,13 +86,8 @@ __global__ __launch_bounds__(DT) void cpx_cptv_unpack_kernel(CptvArgs a) {
 int launch_cptv_unpack(const CptvArgs& a, int B, hipStream_t s) {
   if (a.W * a.H > DT * DCH) return -2;
   const size_t lds = 4 + ((size_t)(a.W * a.H - 1) * 32 + 7) / 8 + 16;  // worst case: 32-bit fields
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_cptv_unpack_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_cptv_unpack_kernel), lds_ready, 160 * 1024 - 1024)) return -1;
   hipLaunchKernelGGL(cpx_cptv_unpack_kernel, dim3(B), dim3(DT), lds, s, a);
   return 0;
 }

@@ -391,13 +391,8 @@ size_t ir_slot_bytes(int W, int H) {
 }
 
 int launch_ir_detect(const IrArgs& a, int n_frames, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_ir_detect_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_ir_detect_kernel), lds_ready, 160 * 1024 - 1024)) return -1;
   hipLaunchKernelGGL(cpx_ir_detect_kernel, dim3(n_frames), dim3(IT), ir_lds_bytes(a.W, a.H), s, a);
   return 0;
 }

@@ -255,6 +255,18 @@ struct Mog2Args {
 void launch_mog2_apply(const Mog2Args& a, hipStream_t s);
 void launch_mog2_background(const Mog2Args& a, unsigned char* out, hipStream_t s);
 
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// (kernel, device): `done` is a per-kernel array indexed by the current device ordinal.
+inline bool cpx_dyn_lds_ready(const void* fn, bool* done, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done[dev] = true;
+  }
+  return true;
+}
+
 size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();

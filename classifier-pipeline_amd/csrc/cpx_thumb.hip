@@ -316,13 +316,8 @@ size_t thumb_lds_bytes(int W, int H, int cap) {
 int launch_thumb(const ThumbArgs& a, int n_refs, hipStream_t s) {
   const size_t lds = thumb_lds_bytes(a.W, a.H, a.chain_cap);
   if (lds > 160 * 1024) return -2;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_thumb_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_thumb_kernel), lds_ready, 160 * 1024 - 1024)) return -1;
   hipLaunchKernelGGL(cpx_thumb_kernel, dim3(n_refs), dim3(64), lds, s, a);
   return 0;
 }
@@ -391,13 +386,8 @@ int launch_trackless(const TracklessArgs& a, hipStream_t s) {
   if (a.W <= TS || a.H <= TS) return -2;
   const size_t lds = ((size_t)a.H * (a.W - TS + 1) + 2 * (size_t)(a.H - TS) * (a.W - TS)) * 4;
   if (lds > 160 * 1024 - 1024) return -2;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_trackless_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
-      return -1;
-    configured = true;
-  }
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_trackless_kernel), lds_ready, 160 * 1024 - 1024)) return -1;
   hipLaunchKernelGGL(cpx_trackless_kernel, dim3(1), dim3(TT), lds, s, a);
   return 0;
 }

@@ -1043,12 +1043,8 @@ size_t nlm_lds_rows(int W, int rows) {
 }
 template <int BH>
 void launch_nlm_t(const TrackArgs& a, int B, int t, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_nlm_kernel<BH>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024 - 2048);
-    configured = true;
-  }
+  static bool lds_ready[64];
+  (void)cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_nlm_kernel<BH>), lds_ready, 160 * 1024 - 2048);
   const int RB = BH * (NT / a.W);
   hipLaunchKernelGGL(cpx_nlm_kernel<BH>, dim3(B, (a.H + RB - 1) / RB), dim3(NT),
                      nlm_lds_rows(a.W, RB < a.H ? RB : a.H), s, a, t);
