@@ -70,6 +70,10 @@ WORKER = textwrap.dedent(
     assert out[:, 1].tolist() == [int(c) for c in counts]
     owners = {i: r for r, s in enumerate(partition_clips(counts, world)) for i in s}
     assert out[:, 3].tolist() == [owners[i] for i in range(37)]
+    # a rank whose clips produced no record still enters the collective (bench.py does this every step)
+    rec2 = rec if rank == 0 else torch.empty((0, 4), dtype=torch.int32)
+    out2 = gather_records(rec2, dist)
+    assert out2.shape == (len(partition_clips(counts, world)[0]), 4) and (out2[:, 3] == 0).all()
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ok_%%d" %% rank), "w").write("ok")
