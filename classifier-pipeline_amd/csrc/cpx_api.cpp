@@ -54,6 +54,7 @@ struct cpx_handle {
   int stream_assoc_frames = -1;
   bool stream_filt_state = false;
   int cnn_math = CPX_CNN_MATH_BF16X3;    // cpx_set_cnn_math / CPX_CNN_MATH
+  bool fuse_shortcut = true;             // CPX_CNN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts as launches of their own
   void* bf3_scratch = nullptr;           // split weights of a cpx_conv2d call that brought none
   size_t bf3_scratch_bytes = 0;
   unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
@@ -253,6 +254,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     return CPX_ERR_HIP;
   }
   if (const char* env = std::getenv("CPX_TRACK_SPLIT_MIN_CLIPS")) h->split_min_clips = std::atoi(env);
+  if (const char* env = std::getenv("CPX_CNN_FUSE_SHORTCUT")) h->fuse_shortcut = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_MATH")) {
     if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
     else if (!std::strcmp(env, "bf16x3")) h->cnn_math = CPX_CNN_MATH_BF16X3;
@@ -602,8 +604,17 @@ int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filter
   return CPX_OK;
 }
 
+// a 1x1 shortcut convolution folded into the convolution that would have read its output as the residual
+struct conv_fuse {
+  const float* in = nullptr;  // [N, H, W, cin]
+  const float* w = nullptr;
+  const float* bias = nullptr;
+  int H = 0, W = 0, cin = 0, stride = 1;
+};
+static bool conv_can_fuse(const cpx_handle* h, const cpx_conv_desc* d);
+
 // split_weights: the bf16 plane image of d->weights_dev if the caller (a cpx_cnn) keeps one, else NULL
-static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_weights) {
+static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_weights, const conv_fuse* fuse = nullptr) {
   if (!h) return CPX_ERR_INVALID;
   if (!d || !d->in_dev || !d->out_dev || !d->weights_dev) return fail(h, CPX_ERR_INVALID, "cpx_conv2d: null argument");
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->groups < 1 || d->Cin % d->groups || d->Cout % d->groups ||
@@ -629,6 +640,12 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
   a.in = d->in_dev; a.out = d->out_dev; a.weights = d->weights_dev;
   a.in_scale = d->in_scale_dev; a.in_shift = d->in_shift_dev;
   a.out_scale = d->out_scale_dev; a.out_shift = d->out_shift_dev; a.residual = d->residual_dev;
+  if (fuse) {
+    if (!(h->cnn_math == CPX_CNN_MATH_BF16X3 && cpx::conv_bf3_supported(a)) || a.out_scale || a.residual)
+      return fail(h, CPX_ERR_INVALID, "conv_run: shortcut fusion needs the split-operand kernel, no output scale, no residual");
+    a.sc_in = fuse->in; a.sc_w = fuse->w; a.sc_bias = fuse->bias;
+    a.sc_H = fuse->H; a.sc_W = fuse->W; a.sc_cin = fuse->cin; a.sc_stride = fuse->stride;
+  }
   cpx_handle::ConvEv ev{};
   if (h->conv_timing) {
     ev.key = (a.Cin / a.groups) * 10000 + (a.Cout / a.groups) * 10 + a.stride + (a.ksize == 1 ? 5 : 0);
@@ -671,6 +688,14 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
 }
 
 int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) { return conv_run(h, d, nullptr); }
+
+// the 3x3 stride-1 convolution described by d runs on the split-operand kernel (which can absorb a 1x1 shortcut)
+static bool conv_can_fuse(const cpx_handle* h, const cpx_conv_desc* d) {
+  if (h->cnn_math != CPX_CNN_MATH_BF16X3 || d->out_scale_dev || d->groups < 1) return false;
+  cpx::ConvArgs a{};
+  a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups; a.ksize = d->ksize; a.stride = d->stride;
+  return cpx::conv_bf3_supported(a);
+}
 
 int cpx_set_cnn_math(cpx_handle* h, int mode) {
   if (!h) return CPX_ERR_INVALID;
@@ -1045,14 +1070,33 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
       rc = conv(cur, mid, b.wa, hh, ww, c_in, f, 3, s, 1, 1, b.in_scale, b.in_shift, b.a_scale, b.a_shift, nullptr);
       if (rc != CPX_OK) return rc;
       const float* res = cur;
+      bool fused = false;
       if (d == 0) {
-        rc = conv(cur, sc, p.shortcut_w[st], hh, ww, c_in, f, 1, s, 0, 0, nullptr, nullptr, nullptr, p.shortcut_b[st],
-                  nullptr);
-        if (rc != CPX_OK) return rc;
-        res = sc;
+        // the 1x1 shortcut of a stage's first block: folded into the block's second convolution when that one runs
+        // on the split-operand kernel (saves writing and re-reading the shortcut tensor), a launch of its own otherwise
+        cpx_conv_desc probe{};
+        probe.Cin = f; probe.Cout = f; probe.groups = p.groups; probe.ksize = 3; probe.stride = 1;
+        fused = h->fuse_shortcut && conv_can_fuse(h, &probe) && (c_in / p.groups) % 2 == 0;
+        if (!fused) {
+          rc = conv(cur, sc, p.shortcut_w[st], hh, ww, c_in, f, 1, s, 0, 0, nullptr, nullptr, nullptr, p.shortcut_b[st],
+                    nullptr);
+          if (rc != CPX_OK) return rc;
+          res = sc;
+        }
       }
       flip ^= 1;
-      rc = conv(mid, act[flip], b.wb, ho, wo, f, f, 3, 1, 1, 1, nullptr, nullptr, nullptr, b.bb, res);
+      if (fused) {
+        conv_fuse fu;
+        fu.in = cur; fu.w = p.shortcut_w[st]; fu.bias = p.shortcut_b[st];
+        fu.H = hh; fu.W = ww; fu.cin = c_in; fu.stride = s;
+        cpx_conv_desc dd{};
+        dd.N = N; dd.H = ho; dd.W = wo; dd.Cin = f; dd.Cout = f; dd.groups = p.groups; dd.ksize = 3; dd.stride = 1;
+        dd.pad_same = 1; dd.relu = 1;
+        dd.in_dev = mid; dd.out_dev = act[flip]; dd.weights_dev = b.wb; dd.out_shift_dev = b.bb;
+        rc = conv_run(h, &dd, cnn->split_of(b.wb), &fu);
+      } else {
+        rc = conv(mid, act[flip], b.wb, ho, wo, f, f, 3, 1, 1, 1, nullptr, nullptr, nullptr, b.bb, res);
+      }
       if (rc != CPX_OK) return rc;
       cur = act[flip];
       hh = ho;

@@ -253,6 +253,25 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
     }
   }
 
+  // ---- fused 1x1 shortcut of a stage's first block: out += conv1x1(block input, stride) -- K = the block input's
+  // channels per group, on the float32 MFMA (same accumulator layout), operands straight from global memory ----
+  if (a.sc_in) {
+    const int sc_cg = a.sc_cin / a.groups;
+    const float* wsc = a.sc_w + (size_t)g * sc_cg * cout_g + ns * COGW + (lane & 31);
+#pragma unroll
+    for (int m = 0; m < NTM; ++m) {
+      const int oy = min(oy0 + (wset + m * WSETS) * TB + prow, a.Ho - 1), ox = min(ox0 + pcol, a.Wo - 1);
+      const float* psc_in = a.sc_in + (((size_t)n * a.sc_H + oy * a.sc_stride) * a.sc_W + ox * a.sc_stride) * a.sc_cin +
+                            g * sc_cg + kh;
+      for (int k2 = 0; k2 < sc_cg; k2 += 2) {
+        const float av = psc_in[k2];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t)
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wsc[(size_t)(k2 + kh) * cout_g + t * 32], acc[m][t], 0, 0, 0);
+      }
+    }
+  }
+
   // ---- epilogue (as cpx_cnn.hip): affine from the accumulators, through LDS for 16-byte residual loads / stores.
   // Each wave transposes through its own 4 KB of LDS (the patch / weights are dead after the loop's last barrier),
   // and LDS operations of one wave complete in order, so no workgroup barrier is needed here ----
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
     for (int t = 0; t < NTN; ++t) {
       const int ch = ch0 + t * 32 + (lane & 31);
       const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
-      const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
+      const float ob = (a.out_shift ? a.out_shift[ch] : 0.0f) + (a.sc_in && a.sc_bias ? a.sc_bias[ch] : 0.0f);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
@@ -450,6 +469,19 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
     }
   }
 
+  if (a.sc_in) {  // fused 1x1 shortcut (see conv_bf3_kernel)
+    const int sc_cg = a.sc_cin / a.groups;
+    const float* wsc = a.sc_w + (size_t)g * sc_cg * cout_g + ns * COGW + (lane & 31);
+    const float* psc_in = a.sc_in + (((size_t)n * a.sc_H + ly * a.sc_stride) * a.sc_W + lx * a.sc_stride) * a.sc_cin +
+                          g * sc_cg + kh;
+    for (int k2 = 0; k2 < sc_cg; k2 += 2) {
+      const float av = psc_in[k2];
+#pragma unroll
+      for (int t = 0; t < NTN; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wsc[(size_t)(k2 + kh) * cout_g + t * 32], acc[t], 0, 0, 0);
+    }
+  }
+
   // ---- epilogue: as conv_bf3_kernel; the NHWC offset of flattened position p is p * Cout ----
   float* out_n = a.out + (size_t)n * M * a.Cout;
   const float* res_n = a.residual ? a.residual + (size_t)n * M * a.Cout : nullptr;
@@ -459,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   for (int t = 0; t < NTN; ++t) {
     const int ch = ch0 + t * 32 + (lane & 31);
     const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
-    const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
+    const float ob = (a.out_shift ? a.out_shift[ch] : 0.0f) + (a.sc_in && a.sc_bias ? a.sc_bias[ch] : 0.0f);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

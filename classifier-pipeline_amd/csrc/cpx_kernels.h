@@ -179,6 +179,12 @@ struct ConvArgs {
   const float* out_scale;
   const float* out_shift;
   const float* residual;
+  // optional fused 1x1 shortcut (split-operand kernels only): instead of reading a residual tensor the kernel adds
+  // conv1x1(sc_in, stride sc_stride, valid) + sc_bias, accumulated into the same float32 accumulators
+  const float* sc_in;    // [N, sc_H, sc_W, sc_cin] or nullptr
+  const float* sc_w;     // packed [groups][1][sc_cin / groups][Cout / groups]
+  const float* sc_bias;  // [Cout]
+  int sc_H, sc_W, sc_cin, sc_stride;
 };
 struct HeadArgs {
   int N, HW, C, L;

@@ -171,7 +171,10 @@ def test_wrresnet_logits_match_oracle(engine, math, fs, n):
     np.testing.assert_allclose(probs.cpu().numpy(), want_probs, atol=1e-4)
     # the single-call native forward (cpx_cnn_forward) and the layer-by-layer building blocks are the same kernels
     l2, p2 = net.forward_layerwise(torch.from_numpy(x).to(engine.device))
-    assert torch.equal(l2, logits) and torch.equal(p2, probs)
+    if math == "f32":
+        assert torch.equal(l2, logits) and torch.equal(p2, probs)
+    else:  # the native call folds the 1x1 shortcuts into the following convolution: another summation order
+        assert float((l2 - logits).abs().max()) <= 1e-5 and float((p2 - probs).abs().max()) <= 1e-5
     # a second batch size reuses / regrows the network's activation arena
     l3, _ = net.forward(torch.from_numpy(np.concatenate([x, x])).to(engine.device))
     assert torch.equal(l3[:n], logits) and torch.equal(l3[n:], logits)
