@@ -179,3 +179,33 @@ def test_wrresnet_logits_match_oracle(engine, math, fs, n):
     l3, _ = net.forward(torch.from_numpy(np.concatenate([x, x])).to(engine.device))
     assert torch.equal(l3[:n], logits) and torch.equal(l3[n:], logits)
     net.close()
+
+
+def test_fused_shortcut_equals_separate_launch(engine, monkeypatch):
+    """cpx_cnn_forward folds the 1x1 shortcut of a stage's first block into the block's second convolution (default
+    math); an engine created with CPX_CNN_FUSE_SHORTCUT=0 launches it separately.  Same network, same input: the
+    logits differ only by the summation order."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.engine import TrackEngine
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(21)
+    x = rng.uniform(0, 255, size=(2, 160, 160, 2)).astype(np.float32)
+    w = co.calibrate_bn(wr.random_weights(17, seed=5), x)
+    engine.set_cnn_math("bf16x3")
+    net = wr.WRResNetDevice(engine, w, 17)
+    fused, _ = net.forward(torch.from_numpy(x).to(engine.device))
+    net.close()
+    monkeypatch.setenv("CPX_CNN_FUSE_SHORTCUT", "0")
+    eng2 = TrackEngine(model="lepton3")
+    monkeypatch.delenv("CPX_CNN_FUSE_SHORTCUT")
+    net2 = wr.WRResNetDevice(eng2, w, 17)
+    separate, _ = net2.forward(torch.from_numpy(x).to(eng2.device))
+    net2.close()
+    eng2.close()
+    diff = float((fused.cpu() - separate.cpu()).abs().max())
+    assert 0.0 < diff <= 1e-5 or diff == 0.0, diff
+    want, _ = co.forward(w, x)
+    assert float(np.abs(fused.cpu().numpy() - want).max()) <= LOGIT_ATOL
