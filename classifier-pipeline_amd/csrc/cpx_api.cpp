@@ -673,7 +673,11 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
       split_weights = h->bf3_scratch;
     }
     rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
-    if (rc == -3) rc = cpx::launch_conv(a, h->stream);  // more tiles than the persistent kernel indexes: float32 path
+    if (rc == -3) {  // more tiles than the split-operand kernel's tile decomposition indexes: float32 path
+      // the float32 kernel has no fused shortcut: dropping it silently would lose the block's shortcut branch
+      if (fuse) return fail(h, CPX_ERR_UNSUPPORTED, "conv_run: batch too large for the fused-shortcut kernel (split the call)");
+      rc = cpx::launch_conv(a, h->stream);
+    }
   } else {
     rc = cpx::launch_conv(a, h->stream);
   }

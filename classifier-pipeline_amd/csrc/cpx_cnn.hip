@@ -49,9 +49,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // a native vector, not HIP's float4 struct: struct copies become memcpy calls that keep a staging array in scratch
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifdef CPX_CONV_ABLATE_STORE
-__device__ __forceinline__ bool v_keep(float x) { return x == 1.2345e-30f; }  // never true: no stores, no residual loads
-#endif
 
 // a band of output pixels is 128 pixels = 4 waves x 32: TW columns x TB = 128 / TW rows, wave w owns the rows
 // [w * 32 / TW, (w + 1) * 32 / TW) of every band.  TW = 16 (8 x 16 bands) everywhere except the 27 x 27 maps of
@@ -78,21 +75,6 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
   // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a contiguous run of
   // tiles so that neighbouring tiles, which share their halo rows / columns, hit the same L2
   if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-#endif
-#ifdef CPX_CONV_STAGGER
-  {
-    const unsigned hsh = ((unsigned)(blockIdx.x + 7919u * blockIdx.y) * 2654435761u) >> 29;  // 0..7
-    switch (hsh) {
-      case 1: __builtin_amdgcn_s_sleep(CPX_CONV_STAGGER); break;
-      case 2: __builtin_amdgcn_s_sleep(2 * CPX_CONV_STAGGER); break;
-      case 3: __builtin_amdgcn_s_sleep(3 * CPX_CONV_STAGGER); break;
-      case 4: __builtin_amdgcn_s_sleep(4 * CPX_CONV_STAGGER); break;
-      case 5: __builtin_amdgcn_s_sleep(5 * CPX_CONV_STAGGER); break;
-      case 6: __builtin_amdgcn_s_sleep(6 * CPX_CONV_STAGGER); break;
-      case 7: __builtin_amdgcn_s_sleep(7 * CPX_CONV_STAGGER); break;
-      default: break;
-    }
-  }
 #endif
   const int txi = bid % tiles_x;
   bid /= tiles_x;
@@ -188,21 +170,13 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
         // branch-free: a clamped address is always loaded (conditional loads split the block and make the compiler
         // wait for every outstanding load at each join); out-of-image pixels are zeroed at commit
         const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-#ifdef CPX_CONV_ABLATE_PATCH_LOAD  // timing experiments only: results are wrong
-        pre_p[i] = f32x4{(float)cy, (float)cx, 0.f, 0.f};
-#else
         pre_p[i] = *reinterpret_cast<const f32x4*>(in_n + ((cy * a.W + cx) * a.Cin + cn + 4 * my_c4));
-#endif
       }
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, KS * KS * WV - 1);
         const int tap = item / WV, r = item - tap * WV;
-#ifdef CPX_CONV_ABLATE_WEIGHT_LOAD
-        pre_w[i] = f32x4{1.f, 2.f, 3.f, (float)item};
-#else
         pre_w[i] = *reinterpret_cast<const f32x4*>(wg + ((tap * cin_g + cn) * COG + 4 * r));
-#endif
       }
     }
     if (cc >= 0) {
@@ -257,11 +231,7 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
         const int f = it * 64 + lane;         // float4 index inside the tile
         const int i = f >> 3, c4 = f & 7;
         const int oy = oy0 + m * TB + WR * wave + i / TW, ox = ox0 + i % TW;
-#ifdef CPX_CONV_ABLATE_STORE
-        if (oy < a.Ho && ox < a.Wo && v_keep(s_tile[i * 32 + 4 * c4])) {
-#else
         if (oy < a.Ho && ox < a.Wo) {
-#endif
           float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
           const size_t o = ((size_t)oy * a.Wo + ox) * a.Cout + g * COG + t * 32 + 4 * c4;
           if (res_n) {

@@ -48,12 +48,6 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 }
 
 constexpr int KC = 16;  // channels per K step of the bf16 MFMA = per staged chunk
-#ifndef CPX_DB_VALU_PER_GAP
-#define CPX_DB_VALU_PER_GAP 4
-#endif
-#ifndef CPX_BF3_CUS
-#define CPX_BF3_CUS 256  // MI355X
-#endif
 
 // NB bands of 128 output pixels per workgroup, CT threads: four waves share a band (32 pixels each); with CT = 512
 // the second set of four waves takes every other band, so NTM = NB / (CT / 256) bands per wave
@@ -148,16 +142,10 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
           uint4 p0, p1, p2;
-#ifdef CPX_BF3_ABLATE_SPLIT
-          p0 = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-          p1 = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
-          p2 = p0;
-#else
           split_pair(v[0], v[1], p0.x, p1.x, p2.x);
           split_pair(v[2], v[3], p0.y, p1.y, p2.y);
           split_pair(v[4], v[5], p0.z, p1.z, p2.z);
           split_pair(v[6], v[7], p0.w, p1.w, p2.w);
-#endif
           s_patch[(0 * 2 + my_h) * NPX + px] = p0;
           s_patch[(1 * 2 + my_h) * NPX + px] = p1;
           s_patch[(2 * 2 + my_h) * NPX + px] = p2;
@@ -191,35 +179,22 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
         // branch-free: a clamped address is always loaded (conditional loads split the block and make the
         // compiler wait for all outstanding loads at every join); out-of-image pixels are zeroed at commit
         const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-#ifdef CPX_BF3_ABLATE_PATCH_LOAD  // timing experiments only: results are wrong
-        pre_p[i][0] = make_float4((float)cy, 1.f, 2.f, 3.f);
-        pre_p[i][1] = make_float4((float)cx, 1.f, 2.f, 3.f);
-#else
         const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 8 * my_h);  // inside one sample: < 2^31
         pre_p[i][0] = *reinterpret_cast<const float4*>(src);
         pre_p[i][1] = *reinterpret_cast<const float4*>(src + 4);
-#endif
       }
       const uint4* wc = wg + (size_t)(cc + 1) * 54 * cout_g;
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, NW - 1);
-#ifdef CPX_BF3_ABLATE_WEIGHT_LOAD
-        pre_w[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, (unsigned)item};
-#else
         const int pth = item / COGW, col = item - pth * COGW;
         pre_w[i] = reinterpret_cast<const u32x4*>(wc)[(size_t)pth * cout_g + col];
-#endif
       }
     }
     if (cc >= 0) {
 #pragma unroll
       for (int tap = 0; tap < KS * KS; ++tap) {
-#ifdef CPX_BF3_ABLATE_LDSREAD  // timing experiments only: every tap multiplies the fragments of tap 0
-        const int ky = 0, kx = 0;
-#else
         const int ky = tap / KS, kx = tap - ky * KS;
-#endif
         bf16x8 av[NTM][3], bv[NTN][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -228,24 +203,18 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
             av[m][p] = __builtin_bit_cast(bf16x8, s_patch[p * 2 * NPX + a_base + m * (WSETS * TB * S * PW) + ky * PW + kx]);
 #pragma unroll
           for (int t = 0; t < NTN; ++t)
-#ifdef CPX_BF3_ABLATE_LDSREAD
-            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * 9) * 2 * COGW + b_base + t * 32]);
-#else
             bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * 9 + tap) * 2 * COGW + b_base + t * 32]);
-#endif
         }
 #pragma unroll
         for (int m = 0; m < NTM; ++m)
 #pragma unroll
           for (int t = 0; t < NTN; ++t) {
             // smallest terms first: x1*y1, x0*y2, x2*y0, x0*y1, x1*y0, x0*y0
-#ifndef CPX_BF3_ABLATE_MFMA
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][1], acc[m][t], 0, 0, 0);
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][2], acc[m][t], 0, 0, 0);
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][2], bv[t][0], acc[m][t], 0, 0, 0);
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][1], acc[m][t], 0, 0, 0);
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][0], acc[m][t], 0, 0, 0);
-#endif
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][0], acc[m][t], 0, 0, 0);
           }
       }
@@ -299,11 +268,7 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
         const int f = it * 64 + lane;
         const int i = f >> 3, c4 = f & 7;
         const int oy = oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = ox0 + i % TW;
-#ifdef CPX_BF3_ABLATE_STORE
-        if (oy < a.Ho && ox < a.Wo && s_tile[i * 32 + 4 * c4] == 1.2345e-30f) {  // never true: no stores, no residual loads
-#else
         if (oy < a.Ho && ox < a.Wo) {
-#endif
           float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
           const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
           if (res_n) {
@@ -550,728 +515,6 @@ static bool flat_pays(const ConvArgs& a, int TW, int TH, int npx_cap) {
   return flat > rect + 0.08;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-specialised form of the same convolution (-DCPX_BF3_WS; correct, tests pass, NOT the default: slower).  In the kernel above a workgroup alternates between a VALU / memory
-// phase (fetch, split, stage) and a matrix phase, and two resident workgroups per CU do not hide one another: the
-// phases add up.  Here a persistent 512-thread workgroup gives the two kinds of work to
-// different waves: waves 0-3 only load, split and stage (two chunks ahead, into a double-buffered LDS image), waves 4-7
-// only read fragments, issue MFMAs and write results.  Every SIMD hosts one wave of each kind, so the loaders' VALU and
-// memory instructions issue in the shadow of the consumers' MFMAs.  One workgroup barrier per chunk: in iteration s the
-// loaders fill buffer s & 1 with stage s while the consumers multiply stage s - 1 out of the other buffer.
-struct TilePos {
-  int n, oy0, ox0, ns;
-};
-__device__ __forceinline__ TilePos decode_tile(int t, const TileDiv& td, int TH, int TW) {
-  TilePos p;
-  int q = div_magic(t, td.m_nsplit);
-  p.ns = t - q * td.nsplit;  // the column slices of one tile run next to each other: they share the patch in L2
-  t = q;
-  q = div_magic(t, td.m_tx);
-  p.ox0 = (t - q * td.tiles_x) * TW;
-  t = q;
-  q = div_magic(t, td.m_ty);
-  p.oy0 = (t - q * td.tiles_y) * TH;
-  p.n = q;
-  return p;
-}
-
-template <int NTN, int NB, int TW>
-__global__ __launch_bounds__(512) void conv_bf3ws_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td, int ntiles) {
-  constexpr int S = 1, KS = 3;
-  constexpr int TB = 128 / TW;   // rows of a band
-  constexpr int WR = 32 / TW;    // rows of a wave's 32-pixel tile
-  constexpr int TH = TB * NB;    // output rows of a workgroup
-  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
-  constexpr int NPX = PH * PW;
-  constexpr int COGW = 32 * NTN;  // output channels of this workgroup
-  constexpr int BUF = 6 * NPX + 54 * COGW;  // uint4 entries of one stage image: patch [3][2][NPX], weights [3][9][2][COGW]
-  constexpr int LT = 256;         // loader threads
-  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  float* s_tiles = reinterpret_cast<float*>(lds4 + 2 * BUF);  // 4 consumer waves x [32][32]
-
-  const int tid = threadIdx.x;
-  const bool loader = tid < LT;
-  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
-  const int g = blockIdx.y;
-  const int nchunks = cin_g / KC;
-  const size_t in_sample = (size_t)a.H * a.W * a.Cin, out_sample = (size_t)a.Ho * a.Wo * a.Cout;
-  // workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous run of tiles (shared halos hit its L2)
-  int first = blockIdx.x;
-  const int G = gridDim.x;
-  if ((G & 7) == 0) first = (first & 7) * (G >> 3) + (first >> 3);
-  const int my_tiles = first < ntiles ? (ntiles - first + G - 1) / G : 0;
-  const int n_stages = my_tiles * nchunks;
-
-  if (loader) {
-    // ------------------------------------------------ loader waves ------------------------------------------------
-    const float* in_g = a.in + (size_t)g * cin_g;
-    const uint4* wgrp = wimg + (size_t)g * nchunks * 54 * cout_g;
-    constexpr int NITEM = NPX * 2;
-    constexpr int NP = (NITEM + LT - 1) / LT;
-    constexpr int NW = 54 * COGW;
-    constexpr int NWI = (NW + LT - 1) / LT;
-    const int my_h = tid & 1;
-    int item_py[NP], item_px[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int item = min(tid + i * LT, NITEM - 1);
-      const int px = item >> 1;
-      item_py[i] = px / PW;
-      item_px[i] = px - item_py[i] * PW;
-    }
-    float4 pre_p[2][NP][2];
-    u32x4 pre_w[2][NWI];
-    float4 psc[2][2], psh[2][2];
-    // load cursor (two stages ahead) and commit cursor
-    int l_tile = first, l_chunk = 0, c_chunk = 0, c_tile = first;
-    TilePos l_pos = decode_tile(min(l_tile, ntiles - 1), td, TH, TW);
-    TilePos c_pos = l_pos;
-
-#define CPX_WS_LOAD(SET)                                                                                              \
-  {                                                                                                                   \
-    const int cn = l_chunk * KC;                                                                                      \
-    const float* in_n = in_g + (size_t)l_pos.n * in_sample;                                                           \
-    const int iy0 = l_pos.oy0 * S - a.pad_top, ix0 = l_pos.ox0 * S - a.pad_left;                                      \
-    const int ch = g * cin_g + cn + 8 * my_h;                                                                         \
-    const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);                           \
-    const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);                           \
-    psc[SET][0] = *reinterpret_cast<const float4*>(scp);                                                              \
-    psc[SET][1] = *reinterpret_cast<const float4*>(scp + 4);                                                          \
-    psh[SET][0] = *reinterpret_cast<const float4*>(shp);                                                              \
-    psh[SET][1] = *reinterpret_cast<const float4*>(shp + 4);                                                          \
-    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                                  \
-      const int cy = min(max(iy0 + item_py[i], 0), a.H - 1), cx = min(max(ix0 + item_px[i], 0), a.W - 1);             \
-      const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 8 * my_h);                                            \
-      pre_p[SET][i][0] = *reinterpret_cast<const float4*>(src);                                                       \
-      pre_p[SET][i][1] = *reinterpret_cast<const float4*>(src + 4);                                                   \
-    }                                                                                                                 \
-    const u32x4* wc = reinterpret_cast<const u32x4*>(wgrp + (size_t)l_chunk * 54 * cout_g + l_pos.ns * COGW);         \
-    _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                                 \
-      const int item = min(tid + i * LT, NW - 1);                                                                     \
-      const int pth = item / COGW, col = item - pth * COGW;                                                           \
-      pre_w[SET][i] = wc[pth * cout_g + col];                                                                         \
-    }                                                                                                                 \
-    if (++l_chunk == nchunks) {                                                                                       \
-      l_chunk = 0;                                                                                                    \
-      l_tile += G;                                                                                                    \
-      l_pos = decode_tile(min(l_tile, ntiles - 1), td, TH, TW);                                                       \
-    }                                                                                                                 \
-  }
-
-#if defined(CPX_WS_ABLATE_LOADER) || defined(CPX_WS_ABLATE_LOADS)
-#undef CPX_WS_LOAD
-#define CPX_WS_LOAD(SET) { _Pragma("unroll") for (int i = 0; i < NP; ++i) { pre_p[SET][i][0] = make_float4(1.f, 2.f, 3.f, (float)tid); pre_p[SET][i][1] = pre_p[SET][i][0]; } \
-    _Pragma("unroll") for (int i = 0; i < NWI; ++i) pre_w[SET][i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, (unsigned)tid}; \
-    psc[SET][0] = psc[SET][1] = psh[SET][0] = psh[SET][1] = make_float4(1.f, 1.f, 1.f, 1.f); \
-    if (++l_chunk == nchunks) { l_chunk = 0; l_tile += G; l_pos = decode_tile(min(l_tile, ntiles - 1), td, TH, TW); } }
-#endif
-    if (n_stages > 0) CPX_WS_LOAD(0)
-    if (n_stages > 1) CPX_WS_LOAD(1)
-    for (int s0 = 0; s0 <= n_stages; s0 += 2) {
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int s = s0 + par;
-        if (s > n_stages) break;
-#ifdef CPX_WS_ABLATE_LOADER
-        if (s < -1) {
-#else
-        if (s < n_stages) {
-#endif
-          // ---- registers -> LDS image `par`: BatchNorm + ReLU prologue, padding zeroed, split into bf16 planes ----
-          uint4* s_patch = lds4 + par * BUF;
-          uint4* s_w = s_patch + 6 * NPX;
-          const int iy0 = c_pos.oy0 * S - a.pad_top, ix0 = c_pos.ox0 * S - a.pad_left;
-#pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            const int item = tid + i * LT;
-            if (item < NITEM) {
-              const int px = item >> 1;
-              const int iy = iy0 + item_py[i], ix = ix0 + item_px[i];
-              float v[8] = {pre_p[par][i][0].x, pre_p[par][i][0].y, pre_p[par][i][0].z, pre_p[par][i][0].w,
-                            pre_p[par][i][1].x, pre_p[par][i][1].y, pre_p[par][i][1].z, pre_p[par][i][1].w};
-              const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-              if (a.in_scale) {
-                const float sc[8] = {psc[par][0].x, psc[par][0].y, psc[par][0].z, psc[par][0].w,
-                                     psc[par][1].x, psc[par][1].y, psc[par][1].z, psc[par][1].w};
-                const float sh[8] = {psh[par][0].x, psh[par][0].y, psh[par][0].z, psh[par][0].w,
-                                     psh[par][1].x, psh[par][1].y, psh[par][1].z, psh[par][1].w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j], 0.0f);
-              }
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
-              uint4 p0, p1, p2;
-              split_pair(v[0], v[1], p0.x, p1.x, p2.x);
-              split_pair(v[2], v[3], p0.y, p1.y, p2.y);
-              split_pair(v[4], v[5], p0.z, p1.z, p2.z);
-              split_pair(v[6], v[7], p0.w, p1.w, p2.w);
-              s_patch[(0 * 2 + my_h) * NPX + px] = p0;
-              s_patch[(1 * 2 + my_h) * NPX + px] = p1;
-              s_patch[(2 * 2 + my_h) * NPX + px] = p2;
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < NWI; ++i) {
-            const int item = tid + i * LT;
-            if (item < NW) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[par][i];
-          }
-          if (++c_chunk == nchunks) {
-            c_chunk = 0;
-            c_tile += G;
-            c_pos = decode_tile(min(c_tile, ntiles - 1), td, TH, TW);
-          }
-          if (s + 2 < n_stages) CPX_WS_LOAD(par)
-        }
-        __syncthreads();
-      }
-    }
-#undef CPX_WS_LOAD
-  } else {
-    // ----------------------------------------------- consumer waves -----------------------------------------------
-    const int lane = tid & 63, wave = (tid >> 6) & 3;
-    const int pi = lane & 31, kh = lane >> 5;
-    const int prow = WR * wave + pi / TW, pcol = pi % TW;
-    const int a_base = kh * NPX + (prow * S) * PW + pcol * S;
-    const int b_base = kh * COGW + (lane & 31);
-    float* s_tile = s_tiles + wave * (32 * 32);
-    int k_tile = first, k_chunk = 0;
-    TilePos k_pos = decode_tile(min(k_tile, ntiles - 1), td, TH, TW);
-    f32x16 acc[NB][NTN];
-    float4 pre_r[NB][NTN][4];
-    for (int s0 = 0; s0 <= n_stages; s0 += 2) {
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int s = s0 + par;
-        if (s > n_stages) break;
-#ifdef CPX_WS_ABLATE_CONSUMER
-        if (s < -1) {
-#else
-        if (s >= 1) {
-#endif
-          // stage s - 1 sits in image par ^ 1
-          const uint4* s_patch = lds4 + (par ^ 1) * BUF;
-          const uint4* s_w = s_patch + 6 * NPX;
-          const int ch0 = g * cout_g + k_pos.ns * COGW;
-          const bool last = k_chunk == nchunks - 1;
-          if (k_chunk == 0) {
-#pragma unroll
-            for (int m = 0; m < NB; ++m)
-#pragma unroll
-              for (int t = 0; t < NTN; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
-          }
-          if (last) {  // this tile's residual lands while the last chunk is multiplied
-            const float* rb = a.residual ? a.residual + (size_t)k_pos.n * out_sample : a.in;
-#pragma unroll
-            for (int m = 0; m < NB; ++m)
-#pragma unroll
-              for (int t = 0; t < NTN; ++t)
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                  const int f = it * 64 + lane;
-                  const int i = f >> 3, c4 = f & 7;
-                  const int oy = min(k_pos.oy0 + m * TB + WR * wave + i / TW, a.Ho - 1);
-                  const int ox = min(k_pos.ox0 + i % TW, a.Wo - 1);
-                  const int o = a.residual ? (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4 : 0;
-#ifdef CPX_WS_ABLATE_STORE
-                  pre_r[m][t][it] = make_float4((float)o, 0.f, 0.f, 0.f);
-#else
-                  pre_r[m][t][it] = *reinterpret_cast<const float4*>(rb + o);
-#endif
-                }
-          }
-          // fragments are double-buffered in registers: the LDS reads of tap + 1 are issued before the MFMAs of tap,
-          // so a lone wave per SIMD never waits on LDS latency inside the matrix loop
-          bf16x8 av[2][NB][3], bv[2][NTN][3];
-#define CPX_WS_FRAGS(BUFI, TAP)                                                                                       \
-  {                                                                                                                   \
-    const int ky_ = (TAP) / KS, kx_ = (TAP) - ky_ * KS;                                                               \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                   \
-      _Pragma("unroll") for (int m = 0; m < NB; ++m) av[BUFI][m][p] = __builtin_bit_cast(                             \
-          bf16x8, s_patch[p * 2 * NPX + a_base + m * (TB * S * PW) + ky_ * PW + kx_]);                                \
-      _Pragma("unroll") for (int t = 0; t < NTN; ++t) bv[BUFI][t][p] =                                                \
-          __builtin_bit_cast(bf16x8, s_w[(p * 9 + (TAP)) * 2 * COGW + b_base + t * 32]);                              \
-    }                                                                                                                 \
-  }
-          CPX_WS_FRAGS(0, 0)
-#ifdef CPX_WS_ABLATE_LDSREAD
-          CPX_WS_FRAGS(1, 1)
-#endif
-#pragma unroll
-          for (int tap = 0; tap < KS * KS; ++tap) {
-            const int cb = tap & 1;
-#ifndef CPX_WS_ABLATE_LDSREAD
-            if (tap + 1 < KS * KS) CPX_WS_FRAGS(cb ^ 1, tap + 1)
-#endif
-            __builtin_amdgcn_sched_barrier(0);  // keep the order: the machine scheduler would sink the reads to just
-                                                // before their first use and expose their latency again
-#ifdef CPX_WS_INTERLEAVE_ACC
-            // the six products of a tile form a dependent chain: alternate the tiles so that consecutive MFMAs are
-            // independent
-#define CPX_WS_STEP(PA, PB)                                                                              \
-  _Pragma("unroll") for (int m = 0; m < NB; ++m) _Pragma("unroll") for (int t = 0; t < NTN; ++t)          \
-      acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][PA], bv[cb][t][PB], acc[m][t], 0, 0, 0);
-            CPX_WS_STEP(1, 1) CPX_WS_STEP(0, 2) CPX_WS_STEP(2, 0) CPX_WS_STEP(0, 1) CPX_WS_STEP(1, 0) CPX_WS_STEP(0, 0)
-#undef CPX_WS_STEP
-#else
-#pragma unroll
-            for (int m = 0; m < NB; ++m)
-#pragma unroll
-              for (int t = 0; t < NTN; ++t) {
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][1], bv[cb][t][1], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][0], bv[cb][t][2], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][2], bv[cb][t][0], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][0], bv[cb][t][1], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][1], bv[cb][t][0], acc[m][t], 0, 0, 0);
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][0], bv[cb][t][0], acc[m][t], 0, 0, 0);
-              }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#undef CPX_WS_FRAGS
-          if (last) {
-            // ---- epilogue: affine, transpose through this wave's own LDS tile, residual, ReLU, 16-byte stores ----
-            float* out_n = a.out + (size_t)k_pos.n * out_sample;
-#pragma unroll
-            for (int m = 0; m < NB; ++m) {
-#pragma unroll
-              for (int t = 0; t < NTN; ++t) {
-                const int ch = ch0 + t * 32 + (lane & 31);
-                const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
-                const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                  s_tile[i * 32 + (lane & 31)] = acc[m][t][r] * os + ob;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                  const int f = it * 64 + lane;
-                  const int i = f >> 3, c4 = f & 7;
-                  const int oy = k_pos.oy0 + m * TB + WR * wave + i / TW, ox = k_pos.ox0 + i % TW;
-                  float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
-                  if (a.residual) {
-                    const float4 rv = pre_r[m][t][it];
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                  }
-                  if (a.relu) {
-                    v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-                  }
-#ifdef CPX_WS_ABLATE_STORE
-                  if (oy < a.Ho && ox < a.Wo && v.x == 1.2345e-30f) {
-#else
-                  if (oy < a.Ho && ox < a.Wo) {
-#endif
-                    const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;
-                    *reinterpret_cast<float4*>(out_n + o) = v;
-                  }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              }
-            }
-          }
-          if (++k_chunk == nchunks) {
-            k_chunk = 0;
-            k_tile += G;
-            k_pos = decode_tile(min(k_tile, ntiles - 1), td, TH, TW);
-          }
-        }
-        __syncthreads();
-      }
-    }
-  }
-}
-
-template <int NTN, int NB, int TW>
-int launch_bf3ws_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
-  constexpr int TB = 128 / TW, TH = TB * NB;
-  constexpr int PH = TH + 2, PW = TW + 2;
-  const size_t lds = ((size_t)2 * (6 * PH * PW + 54 * 32 * NTN)) * 16 + 4 * 32 * 32 * sizeof(float);
-  static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3ws_kernel<NTN, NB, TW>), lds_ready, 160 * 1024 - 1024)) return -1;
-  TileDiv td;
-  td.tiles_x = (a.Wo + TW - 1) / TW;
-  td.tiles_y = (a.Ho + TH - 1) / TH;
-  td.nsplit = (a.Cout / a.groups) / (32 * NTN);
-  const long long ntiles = (long long)td.tiles_x * td.tiles_y * a.N * td.nsplit;
-  if (ntiles >= (1 << 22) || td.tiles_x >= 4096 || td.tiles_y >= 4096) return -3;  // div_magic's range
-  td.m_nsplit = (1ull << 42) / td.nsplit + 1;
-  td.m_tx = (1ull << 42) / td.tiles_x + 1;
-  td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  long long blocks = CPX_BF3_CUS / a.groups;  // one resident workgroup per CU
-  if (blocks < 1) blocks = 1;
-  if (blocks > ntiles) blocks = ntiles;
-  hipLaunchKernelGGL((conv_bf3ws_kernel<NTN, NB, TW>), dim3((unsigned)blocks, a.groups), dim3(512), lds, s, a, wimg, td,
-                     (int)ntiles);
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Double-buffered form (-DCPX_BF3_DB): every wave both stages and multiplies, and the staging of stage s (activate,
-// split, write the other LDS image) is interleaved INSIDE the MFMA loop of stage s - 1 by sched_group_barrier, a few
-// VALU / LDS instructions per MFMA gap, so that it issues in the shadow of the wave's own queued MFMAs.  Persistent
-// 512-thread workgroups, one per CU (two stage images + transpose tiles = 150 KB of LDS), one barrier per stage.
-template <int NTN, int NB, int TW>
-__global__ __launch_bounds__(512) void conv_bf3db_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td, int ntiles) {
-  constexpr int S = 1, KS = 3, CT = 512;
-  constexpr int WSETS = 2, NTM = NB / WSETS;
-  static_assert(NTM * WSETS == NB, "bands must divide among the wave sets");
-  constexpr int TB = 128 / TW, WR = 32 / TW, TH = TB * NB;
-  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
-  constexpr int NPX = PH * PW;
-  constexpr int COGW = 32 * NTN;
-  constexpr int BUF = 6 * NPX + 54 * COGW;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  float* s_tiles = reinterpret_cast<float*>(lds4 + 2 * BUF);  // 8 waves x [32][32]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wset = tid >> 8;
-  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
-  const int g = blockIdx.y;
-  const int nchunks = cin_g / KC;
-  const size_t in_sample = (size_t)a.H * a.W * a.Cin, out_sample = (size_t)a.Ho * a.Wo * a.Cout;
-  int first = blockIdx.x;
-  const int G = gridDim.x;
-  if ((G & 7) == 0) first = (first & 7) * (G >> 3) + (first >> 3);
-  const int my_tiles = first < ntiles ? (ntiles - first + G - 1) / G : 0;
-  const int n_stages = my_tiles * nchunks;
-
-  // ---- staging side ----
-  const float* in_g = a.in + (size_t)g * cin_g;
-  const uint4* wgrp = wimg + (size_t)g * nchunks * 54 * cout_g;
-  constexpr int NITEM = NPX * 2;
-  constexpr int NP = (NITEM + CT - 1) / CT;
-  constexpr int NW = 54 * COGW;
-  constexpr int NWI = (NW + CT - 1) / CT;
-  const int my_h = tid & 1;
-  int item_py[NP], item_px[NP], item_e[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int item = min(tid + i * CT, NITEM - 1);  // surplus threads repeat the last item (same value, same slot)
-    const int px = item >> 1;
-    item_py[i] = px / PW;
-    item_px[i] = px - item_py[i] * PW;
-    item_e[i] = my_h * NPX + px;
-  }
-  int w_e[NWI], w_src[NWI];
-#pragma unroll
-  for (int i = 0; i < NWI; ++i) {
-    const int item = min(tid + i * CT, NW - 1);
-    const int pth = item / COGW, col = item - pth * COGW;
-    w_e[i] = item;
-    w_src[i] = pth * cout_g + col;
-  }
-  f32x4 pre_p[2][NP][2];
-  u32x4 pre_w[2][NWI];
-  f32x4 psc[2][2], psh[2][2];
-  const float relu_lo = a.in_scale ? 0.0f : -INFINITY;  // no prologue: scale 1, shift 0, max(v, -inf) = v
-  int l_tile = first, l_chunk = 0, c_chunk = 0, c_tile = first, k_tile = first, k_chunk = 0;
-  TilePos l_pos = decode_tile(min(l_tile, ntiles - 1), td, TH, TW);
-  TilePos c_pos = l_pos, k_pos = l_pos;
-
-#define CPX_DB_LOAD(SET)                                                                                              \
-  {                                                                                                                   \
-    const int cn = l_chunk * KC;                                                                                      \
-    const float* in_n = in_g + (size_t)l_pos.n * in_sample;                                                           \
-    const int iy0 = l_pos.oy0 * S - a.pad_top, ix0 = l_pos.ox0 * S - a.pad_left;                                      \
-    const int ch = g * cin_g + cn + 8 * my_h;                                                                         \
-    if (a.in_scale) {                                                                                                 \
-      psc[SET][0] = *reinterpret_cast<const f32x4*>(a.in_scale + ch);                                                 \
-      psc[SET][1] = *reinterpret_cast<const f32x4*>(a.in_scale + ch + 4);                                             \
-      psh[SET][0] = *reinterpret_cast<const f32x4*>(a.in_shift + ch);                                                 \
-      psh[SET][1] = *reinterpret_cast<const f32x4*>(a.in_shift + ch + 4);                                             \
-    } else {                                                                                                          \
-      psc[SET][0] = psc[SET][1] = f32x4{1.f, 1.f, 1.f, 1.f};                                                          \
-      psh[SET][0] = psh[SET][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                                          \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                                  \
-      const int cy = min(max(iy0 + item_py[i], 0), a.H - 1), cx = min(max(ix0 + item_px[i], 0), a.W - 1);             \
-      const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 8 * my_h);                                            \
-      pre_p[SET][i][0] = *reinterpret_cast<const f32x4*>(src);                                                        \
-      pre_p[SET][i][1] = *reinterpret_cast<const f32x4*>(src + 4);                                                    \
-    }                                                                                                                 \
-    const u32x4* wc = reinterpret_cast<const u32x4*>(wgrp + (size_t)l_chunk * 54 * cout_g + l_pos.ns * COGW);         \
-    _Pragma("unroll") for (int i = 0; i < NWI; ++i) pre_w[SET][i] = wc[w_src[i]];                                     \
-    if (++l_chunk == nchunks) {                                                                                       \
-      l_chunk = 0;                                                                                                    \
-      l_tile += G;                                                                                                    \
-      l_pos = decode_tile(min(l_tile, ntiles - 1), td, TH, TW);                                                       \
-    }                                                                                                                 \
-  }
-
-  // registers of set SET -> LDS image IMG, branch-free: BatchNorm + ReLU (or identity), padding zeroed, split
-#define CPX_DB_COMMIT(SET, IMG)                                                                                       \
-  {                                                                                                                   \
-    u32x4* s_patch_w = reinterpret_cast<u32x4*>(lds4 + (IMG) * BUF);                                                  \
-    u32x4* s_w_w = s_patch_w + 6 * NPX;                                                                               \
-    const int iy0 = c_pos.oy0 * S - a.pad_top, ix0 = c_pos.ox0 * S - a.pad_left;                                      \
-    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                                  \
-      const int iy = iy0 + item_py[i], ix = ix0 + item_px[i];                                                         \
-      const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                                                 \
-      float v[8];                                                                                                     \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                 \
-        const float x = pre_p[SET][i][j >> 2][j & 3];                                                                 \
-        const float y = fmaxf(x * psc[SET][j >> 2][j & 3] + psh[SET][j >> 2][j & 3], relu_lo);                        \
-        v[j] = inside ? y : 0.0f;                                                                                     \
-      }                                                                                                               \
-      unsigned q0[4], q1[4], q2[4];                                                                                   \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], q0[j], q1[j], q2[j]);          \
-      s_patch_w[0 * 2 * NPX + item_e[i]] = u32x4{q0[0], q0[1], q0[2], q0[3]};                                         \
-      s_patch_w[1 * 2 * NPX + item_e[i]] = u32x4{q1[0], q1[1], q1[2], q1[3]};                                         \
-      s_patch_w[2 * 2 * NPX + item_e[i]] = u32x4{q2[0], q2[1], q2[2], q2[3]};                                         \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < NWI; ++i) s_w_w[w_e[i]] = pre_w[SET][i];                                    \
-  }
-
-  // ---- multiplying side ----
-  const int pi = lane & 31, kh = lane >> 5;
-  const int prow = WR * wave + pi / TW, pcol = pi % TW;
-  const int a_base = kh * NPX + ((prow + wset * TB) * S) * PW + pcol * S;
-  const int b_base = kh * COGW + (lane & 31);
-  float* s_tile = s_tiles + (wset * 4 + wave) * (32 * 32);
-  f32x16 acc[NTM][NTN];
-  f32x4 pre_r[NTM][NTN][4];
-
-#define CPX_DB_MFMA(IMG)                                                                                              \
-  {                                                                                                                   \
-    const uint4* s_patch = lds4 + (IMG) * BUF;                                                                        \
-    const uint4* s_w = s_patch + 6 * NPX;                                                                             \
-    _Pragma("unroll") for (int tap = 0; tap < KS * KS; ++tap) {                                                       \
-      const int ky = tap / KS, kx = tap - ky * KS;                                                                    \
-      bf16x8 av[NTM][3], bv[NTN][3];                                                                                  \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                 \
-        _Pragma("unroll") for (int m = 0; m < NTM; ++m) av[m][p] = __builtin_bit_cast(                                \
-            bf16x8, s_patch[p * 2 * NPX + a_base + m * (WSETS * TB * S * PW) + ky * PW + kx]);                        \
-        _Pragma("unroll") for (int t = 0; t < NTN; ++t) bv[t][p] =                                                    \
-            __builtin_bit_cast(bf16x8, s_w[(p * 9 + tap) * 2 * COGW + b_base + t * 32]);                              \
-      }                                                                                                               \
-      _Pragma("unroll") for (int m = 0; m < NTM; ++m) _Pragma("unroll") for (int t = 0; t < NTN; ++t) {               \
-        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][1], acc[m][t], 0, 0, 0);                  \
-        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][2], acc[m][t], 0, 0, 0);                  \
-        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][2], bv[t][0], acc[m][t], 0, 0, 0);                  \
-        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][1], acc[m][t], 0, 0, 0);                  \
-        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][0], acc[m][t], 0, 0, 0);                  \
-        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][0], acc[m][t], 0, 0, 0);                  \
-      }                                                                                                               \
-    }                                                                                                                 \
-  }
-
-  // The steady state by hand: after every second MFMA of stage s - 1 one micro-step of the staging of stage s is
-  // issued -- (A) activate a channel pair, (B) split it, (C) write an item's three planes, (W) write a weight entry --
-  // each short enough to issue while the matrix pipe works on the MFMAs already queued; the fragment reads of tap + 1
-  // are issued during tap.  sched_barrier pins the order (the scheduler would otherwise hoist all VALU to the top).
-  constexpr int NSTEPS = 9 * NP + NWI;
-  static_assert(NSTEPS <= 27 * NTM * NTN, "more staging micro-steps than MFMA slots");
-#define CPX_DB_FRAGS(FB, TAP)                                                                                         \
-  {                                                                                                                   \
-    const int ky_ = (TAP) / KS, kx_ = (TAP) - ky_ * KS;                                                               \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                   \
-      _Pragma("unroll") for (int m = 0; m < NTM; ++m) av[FB][m][p] = __builtin_bit_cast(                              \
-          bf16x8, s_patch[p * 2 * NPX + a_base + m * (WSETS * TB * S * PW) + ky_ * PW + kx_]);                        \
-      _Pragma("unroll") for (int t = 0; t < NTN; ++t) bv[FB][t][p] =                                                  \
-          __builtin_bit_cast(bf16x8, s_w[(p * 9 + (TAP)) * 2 * COGW + b_base + t * 32]);                              \
-    }                                                                                                                 \
-  }
-#define CPX_DB_STEP(SET, K)                                                                                           \
-  {                                                                                                                   \
-    if ((K) < 4 * NP) {                                                                                               \
-      const int i_ = (K) / 4, j_ = (K) % 4;                                                                           \
-      const int iy = iy0 + item_py[i_], ix = ix0 + item_px[i_];                                                       \
-      const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                                                 \
-      _Pragma("unroll") for (int e = 2 * j_; e < 2 * j_ + 2; ++e) {                                                   \
-        const float x = pre_p[SET][i_][e >> 2][e & 3];                                                                \
-        const float y = fmaxf(x * psc[SET][e >> 2][e & 3] + psh[SET][e >> 2][e & 3], relu_lo);                        \
-        pre_p[SET][i_][e >> 2][e & 3] = inside ? y : 0.0f;                                                            \
-      }                                                                                                               \
-    } else if ((K) < 8 * NP) {                                                                                        \
-      const int i_ = ((K) - 4 * NP) / 4, j_ = ((K) - 4 * NP) % 4;                                                     \
-      split_pair(pre_p[SET][i_][(2 * j_) >> 2][(2 * j_) & 3], pre_p[SET][i_][(2 * j_ + 1) >> 2][(2 * j_ + 1) & 3],   \
-                 q[i_][0][j_], q[i_][1][j_], q[i_][2][j_]);                                                           \
-    } else if ((K) < 9 * NP) {                                                                                        \
-      const int i_ = (K) - 8 * NP;                                                                                    \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) s_patch_w[p * 2 * NPX + item_e[i_]] =                             \
-          u32x4{q[i_][p][0], q[i_][p][1], q[i_][p][2], q[i_][p][3]};                                                  \
-    } else if ((K) < NSTEPS) {                                                                                        \
-      s_w_w[w_e[(K) - 9 * NP]] = pre_w[SET][(K) - 9 * NP];                                                            \
-    }                                                                                                                 \
-  }
-#define CPX_DB_FUSED(SET, IMGW, IMGR)                                                                                 \
-  {                                                                                                                   \
-    const uint4* s_patch = lds4 + (IMGR) * BUF;                                                                       \
-    const uint4* s_w = s_patch + 6 * NPX;                                                                             \
-    u32x4* s_patch_w = reinterpret_cast<u32x4*>(lds4 + (IMGW) * BUF);                                                 \
-    u32x4* s_w_w = s_patch_w + 6 * NPX;                                                                               \
-    const int iy0 = c_pos.oy0 * S - a.pad_top, ix0 = c_pos.ox0 * S - a.pad_left;                                      \
-    unsigned q[NP][3][4];                                                                                             \
-    bf16x8 av[2][NTM][3], bv[2][NTN][3];                                                                              \
-    CPX_DB_FRAGS(0, 0)                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                \
-    _Pragma("unroll") for (int tap = 0; tap < KS * KS; ++tap) {                                                       \
-      const int cb = tap & 1;                                                                                         \
-      _Pragma("unroll") for (int m = 0; m < NTM; ++m) _Pragma("unroll") for (int t = 0; t < NTN; ++t) {               \
-        _Pragma("unroll") for (int pr = 0; pr < 6; ++pr) {                                                            \
-          const int pa = pr == 0 ? 1 : pr == 1 ? 0 : pr == 2 ? 2 : pr == 3 ? 0 : pr == 4 ? 1 : 0;                     \
-          const int pb = pr == 0 ? 1 : pr == 1 ? 2 : pr == 2 ? 0 : pr == 3 ? 1 : pr == 4 ? 0 : 0;                     \
-          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cb][m][pa], bv[cb][t][pb], acc[m][t], 0, 0, 0);      \
-          __builtin_amdgcn_sched_barrier(0);                                                                          \
-          const int n_ = ((tap * NTM + m) * NTN + t) * 6 + pr;                                                        \
-          if (m == 0 && t == 0 && pr == 1 && tap + 1 < KS * KS) CPX_DB_FRAGS(cb ^ 1, tap + 1)                         \
-          if ((n_ & 1) == 0) CPX_DB_STEP(SET, n_ >> 1)                                                                \
-          __builtin_amdgcn_sched_barrier(0);                                                                          \
-        }                                                                                                             \
-      }                                                                                                               \
-    }                                                                                                                 \
-  }
-
-  if (n_stages > 0) CPX_DB_LOAD(0)
-  if (n_stages > 1) CPX_DB_LOAD(1)
-  for (int s0 = 0; s0 <= n_stages; s0 += 2) {
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int s = s0 + par;
-      if (s > n_stages) break;
-      const bool do_commit = s < n_stages, do_mfma = s >= 1;
-      const int ch0 = g * cout_g + k_pos.ns * COGW;
-      const bool last = do_mfma && k_chunk == nchunks - 1;
-      if (do_mfma && k_chunk == 0) {
-#pragma unroll
-        for (int m = 0; m < NTM; ++m)
-#pragma unroll
-          for (int t = 0; t < NTN; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
-      }
-      if (last) {  // this tile's residual lands while the last chunk is multiplied
-        const float* rb = a.residual ? a.residual + (size_t)k_pos.n * out_sample : a.in;
-#pragma unroll
-        for (int m = 0; m < NTM; ++m)
-#pragma unroll
-          for (int t = 0; t < NTN; ++t)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-              const int f = it * 64 + lane;
-              const int i = f >> 3, c4 = f & 7;
-              const int oy = min(k_pos.oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, a.Ho - 1);
-              const int ox = min(k_pos.ox0 + i % TW, a.Wo - 1);
-              const int o = a.residual ? (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4 : 0;
-              pre_r[m][t][it] = *reinterpret_cast<const f32x4*>(rb + o);
-            }
-      }
-      if (do_commit && do_mfma) {
-        // the steady state: one scheduling region, staging instructions dealt into the MFMA gaps
-#ifdef CPX_DB_HAND
-        CPX_DB_FUSED(par, par, par ^ 1)
-#else
-        __builtin_amdgcn_sched_barrier(0);
-        CPX_DB_COMMIT(par, par)
-        CPX_DB_MFMA(par ^ 1)
-#endif
-#if !defined(CPX_DB_NO_PIPELINE) && !defined(CPX_DB_HAND)
-        __builtin_amdgcn_sched_group_barrier(0x100, 6 * NTM * NTN > 6 ? 6 : 6, 0);  // the first tap's fragments
-#pragma unroll
-        for (int i = 0; i < 54 * NTM * NTN; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, CPX_DB_VALU_PER_GAP, 0);    // staging VALU in its shadow
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // a fragment read of a later tap
-          if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS write of the staging
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      } else if (do_commit) {
-        CPX_DB_COMMIT(par, par)
-      } else if (do_mfma) {
-        CPX_DB_MFMA(par ^ 1)
-      }
-      if (do_commit && ++c_chunk == nchunks) {  // (kept out of the fused region: a branch would split it)
-        c_chunk = 0;
-        c_tile += G;
-        c_pos = decode_tile(min(c_tile, ntiles - 1), td, TH, TW);
-      }
-      if (do_commit && s + 2 < n_stages) CPX_DB_LOAD(par)
-      if (last) {
-        // ---- epilogue: affine, transpose through this wave's own LDS tile, residual, ReLU, 16-byte stores ----
-        float* out_n = a.out + (size_t)k_pos.n * out_sample;
-#pragma unroll
-        for (int m = 0; m < NTM; ++m) {
-#pragma unroll
-          for (int t = 0; t < NTN; ++t) {
-            const int ch = ch0 + t * 32 + (lane & 31);
-            const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
-            const float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              s_tile[i * 32 + (lane & 31)] = acc[m][t][r] * os + ob;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-              const int f = it * 64 + lane;
-              const int i = f >> 3, c4 = f & 7;
-              const int oy = k_pos.oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = k_pos.ox0 + i % TW;
-              f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + i * 32 + 4 * c4);
-              if (a.residual) v += pre_r[m][t][it];
-              if (a.relu) {
-                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-              }
-              if (oy < a.Ho && ox < a.Wo) {
-                const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;
-                *reinterpret_cast<f32x4*>(out_n + o) = v;
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          }
-        }
-      }
-      if (do_mfma && ++k_chunk == nchunks) {
-        k_chunk = 0;
-        k_tile += G;
-        k_pos = decode_tile(min(k_tile, ntiles - 1), td, TH, TW);
-      }
-      __syncthreads();
-    }
-  }
-#undef CPX_DB_LOAD
-#undef CPX_DB_COMMIT
-#undef CPX_DB_MFMA
-#undef CPX_DB_FRAGS
-#undef CPX_DB_STEP
-#undef CPX_DB_FUSED
-}
-
-template <int NTN, int NB, int TW>
-int launch_bf3db_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
-  constexpr int TB = 128 / TW, TH = TB * NB;
-  constexpr int PH = TH + 2, PW = TW + 2;
-  const size_t lds = ((size_t)2 * (6 * PH * PW + 54 * 32 * NTN)) * 16 + 8 * 32 * 32 * sizeof(float);
-  static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3db_kernel<NTN, NB, TW>), lds_ready, 160 * 1024 - 1024)) return -1;
-  TileDiv td;
-  td.tiles_x = (a.Wo + TW - 1) / TW;
-  td.tiles_y = (a.Ho + TH - 1) / TH;
-  td.nsplit = (a.Cout / a.groups) / (32 * NTN);
-  const long long ntiles = (long long)td.tiles_x * td.tiles_y * a.N * td.nsplit;
-  if (ntiles >= (1 << 22) || td.tiles_x >= 4096 || td.tiles_y >= 4096) return -3;
-  td.m_nsplit = (1ull << 42) / td.nsplit + 1;
-  td.m_tx = (1ull << 42) / td.tiles_x + 1;
-  td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  long long blocks = CPX_BF3_CUS / a.groups;  // one resident workgroup per CU
-  if (blocks < 1) blocks = 1;
-  if (blocks > ntiles) blocks = ntiles;
-  hipLaunchKernelGGL((conv_bf3db_kernel<NTN, NB, TW>), dim3((unsigned)blocks, a.groups), dim3(512), lds, s, a, wimg, td,
-                     (int)ntiles);
-  return 0;
-}
-
 // packed float32 weights [g][tap][cin_g][cout_g] -> bf16 plane image [g][chunk][3][9][2][cout_g] of 16-byte entries
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
                                                             int cin_g, int cout_g) {
@@ -1378,24 +621,12 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   const int cout_g = a.Cout / a.groups;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
-#ifdef CPX_BF3_DB  // the double-buffered form with in-loop staging
-  if (cout_g == 32) return launch_bf3db_t<1, 2, CPX_BF3_TW_S2>(a, w, s);
-  if (cout_g == 64) return launch_bf3db_t<1, 2, CPX_BF3_TW_S3>(a, w, s);
-  if (cout_g == 128) return launch_bf3db_t<1, 2, 32>(a, w, s);
-#endif
-#ifdef CPX_BF3_WS  // the wave-specialised form: measured 3-10 % slower than the plain one, off
-  if (cout_g == 32) return launch_bf3ws_t<1, 2, CPX_BF3_TW_S2>(a, w, s);
-  if (cout_g == 64) return launch_bf3ws_t<1, 2, CPX_BF3_TW_S3>(a, w, s);
-  if (cout_g == 128) return launch_bf3ws_t<1, 2, 32>(a, w, s);
-#endif
   if (cout_g == 32) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2>(a, w, s);
   if (cout_g == 64) return launch_bf3_t<CPX_BF3_NTN_S3, 1, CPX_BF3_NB_S3, CPX_BF3_TW_S3, CPX_BF3_CT_S3>(a, w, s);
-#ifndef CPX_BF3_NO_FLAT
   // 256 staged pixels + two N tiles = 80 KB: two workgroups per CU.  (Wider maps -- 54 x 54 at frame size 64 -- would
   // need 384 staged pixels and then fit only one N tile per workgroup: measured slower than the rectangular bands,
   // 399 vs 371 ms, the patch being activated and split by four column slices instead of two.)
   if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256)) return launch_bf3flat_t<2, 256>(a, w, s);
-#endif
   if (cout_g == 128) return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
   return -2;
 }

@@ -1,10 +1,7 @@
 #!/bin/bash
-# runs scratch/cnn_probe.py with every library under cpx/variants (on the GPU box)
+# runs scratch/cnn_probe.py with every library under scratch/bin (on the GPU box); CPX_LIB selects the library
 cd "$(dirname "$0")/.."
-cp classifier-pipeline_amd/cpx/libcpx_hip.so /tmp/libcpx_hip_orig.so
-for v in classifier-pipeline_amd/cpx/variants/libcpx_hip_*.so; do
+for v in scratch/bin/libcpx_hip_*.so; do
   echo "=== $v"
-  cp "$v" classifier-pipeline_amd/cpx/libcpx_hip.so
-  python scratch/cnn_probe.py ${1:-2048} 2>&1 | grep -v amdgpu.ids | head -6
+  CPX_LIB=$PWD/$v python scratch/cnn_probe.py ${1:-2048} 2>&1 | grep -v amdgpu.ids | head -${2:-6}
 done
-cp /tmp/libcpx_hip_orig.so classifier-pipeline_amd/cpx/libcpx_hip.so
