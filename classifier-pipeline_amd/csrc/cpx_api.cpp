@@ -747,6 +747,23 @@ static int final_common(cpx_handle* h, const cpx_filter_params* params, const in
   return CPX_OK;
 }
 
+// per-clip scalar scratch of the end-of-clip kernels: double [B][2 * max_frames] + float [B][max_frames]
+static int final_scratch(cpx_handle* h, int B, cpx::FinalArgs* a) {
+  const size_t need = (size_t)B * h->cfg.max_frames * (2 * sizeof(double) + sizeof(float)) + 512;
+  if (need > h->ws_assoc_bytes) {
+    CPX_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->ws_assoc) hipFree(h->ws_assoc);
+    h->ws_assoc = nullptr;
+    h->ws_assoc_bytes = 0;
+    hipError_t e = hipMalloc(&h->ws_assoc, need);
+    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "finalize workspace hipMalloc", e);
+    h->ws_assoc_bytes = need;
+  }
+  a->scratch_d = (double*)h->ws_assoc;
+  a->scratch_f = (float*)((char*)h->ws_assoc + align_up((size_t)B * h->cfg.max_frames * 2 * sizeof(double), 256));
+  return CPX_OK;
+}
+
 int cpx_finalize_tracks(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
                         const cpx_frame_meta* meta, int B, const cpx_region* pool_dev,
                         const cpx_track_record* tracks_dev, const int32_t* n_tracks_dev,
@@ -758,23 +775,14 @@ int cpx_finalize_tracks(cpx_handle* h, const cpx_filter_params* params, const in
   cpx::FinalArgs a{};
   int rc = final_common(h, params, clip_offsets, meta, B, &a);
   if (rc != CPX_OK) return rc;
-  const size_t need = (size_t)B * h->cfg.max_frames * (2 * sizeof(double) + sizeof(float)) + 512;
-  if (need > h->ws_assoc_bytes) {
-    if (h->ws_assoc) hipFree(h->ws_assoc);
-    h->ws_assoc = nullptr;
-    h->ws_assoc_bytes = 0;
-    hipError_t e = hipMalloc(&h->ws_assoc, need);
-    if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "finalize workspace hipMalloc", e);
-    h->ws_assoc_bytes = need;
-  }
+  rc = final_scratch(h, B, &a);
+  if (rc != CPX_OK) return rc;
   a.square_width = 5;
   a.pool = pool_dev;
   a.tracks = tracks_dev;
   a.n_tracks = n_tracks_dev;
   a.summaries = summaries_dev;
   a.counts = counts_dev;
-  a.scratch_d = (double*)h->ws_assoc;
-  a.scratch_f = (float*)((char*)h->ws_assoc + align_up((size_t)B * h->cfg.max_frames * 2 * sizeof(double), 256));
   cpx::launch_finalize(a, h->stream);
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
@@ -793,6 +801,8 @@ int cpx_plan_segments(cpx_handle* h, const cpx_filter_params* params, const int3
   if (square_width != 5) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_plan_segments: square_width must be 5");
   cpx::FinalArgs a{};
   int rc = final_common(h, params, clip_offsets, meta, B, &a);
+  if (rc != CPX_OK) return rc;
+  rc = final_scratch(h, B, &a);
   if (rc != CPX_OK) return rc;
   a.square_width = square_width;
   a.pool = pool_dev;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void cpx_plan_kernel(FinalArgs a) {
   const int ma = a.params.max_active_tracks, mt = a.params.max_tracks_per_clip;
   plan_clip(a.params, a.pool + (size_t)first * ma, a.summaries + (size_t)b * mt, a.n_tracks[b], a.proc_ffc + pbase,
             a.proc_idx + pbase, a.square_width, b, a.prefix + 4 * b, a.refs, a.track_offsets, a.reqs, a.sample_track,
-            a.track_clip);
+            a.track_clip, reinterpret_cast<unsigned char*>(a.scratch_d + (size_t)b * 2 * a.max_frames));
 }
 
 void launch_finalize(const FinalArgs& a, hipStream_t s) {

@@ -233,13 +233,84 @@ CPX_HD inline bool region_usable(const RegionRec& r, bool has_no_mass, const int
          r.height > 0;
 }
 
-// how many segments ALL_RANDOM_MASKED yields for `usable` frames with min_segments = 1
-// (datasetstructures.py:1150-1226): always one, then one more while at least half a segment remains
-CPX_HD inline int segments_for(int usable, int per) {
-  if (usable <= 0) return 0;
-  const int half = (per + 1) / 2;  // remaining >= per / 2.0
-  const int n = (usable + per - half) / per;
-  return n < 1 ? 1 : n;
+// ---- segment selection (ml_tools/datasetstructures.py:972-1301 as Interpreter.frames_for_prediction calls it through
+// Track.get_segments, ml_tools/interpreter.py:178-243, track/track.py:480-545: ALL_RANDOM_MASKED, segment_width =
+// square_width^2 = 25, segment_frame_spacing 9, min_segments 1, no max_segments, repeats 1, dont_filter False,
+// segment_min_mass None).  The reference draws at random; this is its outcome when every draw is the
+// identity (shuffle keeps the order, choice without replacement takes the first k, choice with replacement cycles
+// through the array) -- pinned against the reference itself run under such draws,
+// tests/golden/segments_identity_golden.json.
+//   positions p = 0 .. n_frames-1 index the (trimmed) track's bounds; U = number of usable positions
+//   segment_count = max(1, U / 9); for segment i the pool is every usable position not yet taken -- and, when
+//   U >= 40, outside the window [25 i, 25 i + 25) (datasetstructures.py:1189-1197); a pool shorter than a quarter
+//   segment, or than half a segment once a segment exists, ends the loop (:1200-1209; the first segment is exempt:
+//   min_segments = 1); the segment takes the first 25 of the pool (:1223-1226); a short one is padded with its own
+//   first frames (:1236-1244) and, if still short, by cycling through the sorted padded list (:1276-1282); a segment
+//   whose mean mass (over the first padding) is below 1 is dropped but keeps its frames taken (:1249-1255).
+// emit(segment index, tile j, position) is called for the 25 sorted frames of every kept segment; `taken` is scratch of
+// n_frames bytes and holds, on return, 1 for positions used by a KEPT segment.  Returns the number of kept segments.
+template <typename Emit>
+CPX_HD inline int plan_track_segments(const cpx_filter_params& fp, const RegionRec* pool, const cpx_track_summary& t,
+                                      const int* proc_ffc, int per, unsigned char* taken, Emit emit) {
+  const int n = t.n_frames;
+  long long msum = 0;
+  for (int i = 0; i < n; ++i) msum += (unsigned short)treg(pool, fp.max_active_tracks, t, i).mass;  // np.uint16 masses
+  const bool has_no_mass = msum == 0;
+  int usable = 0;
+  for (int i = 0; i < n; ++i) {
+    taken[i] = 0;
+    usable += region_usable(treg(pool, fp.max_active_tracks, t, i), has_no_mass, proc_ffc);
+  }
+  if (usable == 0) return 0;  // "Nothing to load"
+  int segment_count = usable / 9;
+  if (segment_count < 1) segment_count = 1;
+  const bool masked = usable >= 40;
+  int made = 0;
+  // bit 1 of taken[]: position consumed by some segment (kept or dropped); bit 0: by a kept one
+  for (int i = 0; i < segment_count; ++i) {
+    const int m0 = masked ? i * 25 : -1, m1 = masked ? i * 25 + 25 : -1;
+    int plen = 0;
+    for (int p = 0; p < n; ++p)
+      if (!(taken[p] & 2) && !(p >= m0 && p < m1) && region_usable(treg(pool, fp.max_active_tracks, t, p), has_no_mass, proc_ffc))
+        plen += 1;
+    if (plen == 0 || made >= 1) {
+      if ((2 * plen < per && made > 0) || 4 * plen < per) break;
+    }
+    int sel[32];
+    int have = 0;
+    for (int p = 0; p < n && have < per; ++p)
+      if (!(taken[p] & 2) && !(p >= m0 && p < m1) && region_usable(treg(pool, fp.max_active_tracks, t, p), has_no_mass, proc_ffc)) {
+        sel[have++] = p;
+        taken[p] |= 2;
+      }
+    // first padding: the first min(remaining, have) frames once more, then sorted (sel is ascending)
+    int fr[32];
+    int len = 0;
+    const int extra = (per - have) < have ? (per - have) : have;
+    for (int j = 0; j < have; ++j) {
+      fr[len++] = sel[j];
+      if (j < extra) fr[len++] = sel[j];
+    }
+    long long smass = 0;
+    for (int j = 0; j < len; ++j) smass += (unsigned short)treg(pool, fp.max_active_tracks, t, fr[j]).mass;
+    if (smass < len) continue;  // segment_avg_mass < 1: dropped ("segment_mass")
+    if (len < per) {
+      // second padding: frames[k % len] of the sorted list for k = 0 .. per-len-1, then sorted again
+      int cnt[32];
+      const int len0 = len, add = per - len0;
+      for (int j = 0; j < len0; ++j) cnt[j] = 1 + add / len0 + (j < add % len0 ? 1 : 0);
+      int tmp[32];
+      for (int j = 0; j < len0; ++j) tmp[j] = fr[j];
+      len = 0;
+      for (int j = 0; j < len0; ++j)
+        for (int c = 0; c < cnt[j]; ++c) fr[len++] = tmp[j];
+    }
+    for (int j = 0; j < have; ++j) taken[sel[j]] |= 1;
+    for (int j = 0; j < per; ++j) emit(made, j, fr[j]);
+    made += 1;
+  }
+  for (int p = 0; p < n; ++p) taken[p] &= 1;
+  return made;
 }
 
 // all tracks of a clip: finalize each, order by score (stable, descending), apply max_tracks,
@@ -282,17 +353,13 @@ CPX_HD inline void finalize_clip(const cpx_filter_params& fp, const RegionRec* p
     cpx_track_summary& t = out[k];
     if (t.reject != CPX_TRACK_KEPT) continue;
     kept += 1;
-    long long msum = 0;
     int nonblank = 0;
     for (int i = 0; i < t.n_frames; ++i) {
       const RegionRec& r = treg(pool, fp.max_active_tracks, t, i);
-      msum += r.mass;
       if (!(r.flags & RF_BLANK) && r.width > 0 && r.height > 0) nonblank += 1;
     }
-    const bool has_no_mass = msum == 0;  // np.sum(np.uint16 masses) == 0 (the sum is taken in 64 bits)
-    int usable = 0;
-    for (int i = 0; i < t.n_frames; ++i) usable += region_usable(treg(pool, fp.max_active_tracks, t, i), has_no_mass, proc_ffc);
-    t.n_segments = segments_for(usable, per);
+    t.n_segments = plan_track_segments(fp, pool, t, proc_ffc, per, reinterpret_cast<unsigned char*>(sc.d),
+                                       [](int, int, int) {});
     refs += nonblank;
     samples += t.n_segments;
   }
@@ -302,11 +369,11 @@ CPX_HD inline void finalize_clip(const cpx_filter_params& fp, const RegionRec* p
   counts[3] = 0;
 }
 
-// fill pass: prefix = exclusive prefix sums of counts over the clips of the batch
+// fill pass: prefix = exclusive prefix sums of counts over the clips of the batch; `taken` is scratch of max_frames bytes
 CPX_HD inline void plan_clip(const cpx_filter_params& fp, const RegionRec* pool, const cpx_track_summary* sums,
                              int n_tracks, const int* proc_ffc, const int* proc_idx, int square_width, int clip,
                              const int* prefix, cpx_region_ref* refs, int* track_offsets, cpx_crop_req* reqs,
-                             int* sample_track, int* track_clip) {
+                             int* sample_track, int* track_clip, unsigned char* taken) {
   int ti = prefix[0], ri = prefix[1], si = prefix[2];
   const int per = square_width * square_width;
   // kept tracks in score order
@@ -316,63 +383,32 @@ CPX_HD inline void plan_clip(const cpx_filter_params& fp, const RegionRec* pool,
       if (sums[j].rank == want) k = j;
     if (k < 0 || sums[k].reject != CPX_TRACK_KEPT) continue;
     const cpx_track_summary& t = sums[k];
-    long long msum = 0;
-    for (int i = 0; i < t.n_frames; ++i) msum += treg(pool, fp.max_active_tracks, t, i).mass;
-    const bool has_no_mass = msum == 0;
-    int usable = 0;
-    for (int i = 0; i < t.n_frames; ++i) usable += region_usable(treg(pool, fp.max_active_tracks, t, i), has_no_mass, proc_ffc);
-    const int covered = (usable < per * t.n_segments) ? usable : per * t.n_segments;
     track_offsets[ti] = ri;
     track_clip[2 * ti] = clip;
     track_clip[2 * ti + 1] = t.id;
-    // refs: every non-blank region (get_limits walks the whole track)
-    int useq = 0;
+    // segments: one crop request per tile, in the sorted frame order of the segment
+    const int made = plan_track_segments(fp, pool, t, proc_ffc, per, taken, [&](int s, int j, int p) {
+      const RegionRec& r = treg(pool, fp.max_active_tracks, t, p);
+      cpx_crop_req q;
+      q.frame = proc_idx[r.frame_number];
+      q.x = r.x; q.y = r.y; q.width = r.width; q.height = r.height;
+      q.track = ti;
+      q.sample = si + s;
+      q.tile = j;
+      reqs[(size_t)(si + s) * per + j] = q;
+    });
+    for (int s = 0; s < made; ++s) sample_track[si + s] = ti;
+    si += made;
+    // refs: every non-blank region (get_limits walks the whole track); in_segment marks the frames a segment uses
+    // (the clip_thermals_at_zero test, interpreter.py:372-399)
     for (int i = 0; i < t.n_frames; ++i) {
       const RegionRec& r = treg(pool, fp.max_active_tracks, t, i);
       if ((r.flags & RF_BLANK) || r.width <= 0 || r.height <= 0) continue;
       cpx_region_ref q;
       q.frame = proc_idx[r.frame_number];
       q.x = r.x; q.y = r.y; q.width = r.width; q.height = r.height;
-      q.in_segment = 0;
-      if (region_usable(r, has_no_mass, proc_ffc)) {
-        q.in_segment = (useq < covered) ? 1 : 0;  // frames past the last segment are not classified
-        useq += 1;
-      }
+      q.in_segment = taken[i] ? 1 : 0;
       refs[ri++] = q;
-    }
-    // segments: consecutive runs of `per` usable frames; a short tail repeats its own frames (sorted)
-    int seen = 0, cursor = 0;
-    for (int s = 0; s < t.n_segments; ++s) {
-      const int have = (covered - seen) < per ? (covered - seen) : per;
-      // tile j takes usable frame floor(j * have / per) of this run: sorted, every frame used, tail repeated
-      int run_start = cursor;
-      for (int j = 0; j < per; ++j) {
-        const int target = (int)(((long long)j * have) / per);
-        int idx = run_start, cnt = -1;
-        for (;; ++idx) {
-          if (region_usable(treg(pool, fp.max_active_tracks, t, idx), has_no_mass, proc_ffc)) {
-            cnt += 1;
-            if (cnt == target) break;
-          }
-        }
-        const RegionRec& r = treg(pool, fp.max_active_tracks, t, idx);
-        cpx_crop_req q;
-        q.frame = proc_idx[r.frame_number];
-        q.x = r.x; q.y = r.y; q.width = r.width; q.height = r.height;
-        q.track = ti;
-        q.sample = si;
-        q.tile = j;
-        reqs[(size_t)si * per + j] = q;
-      }
-      // advance the cursor past `have` usable frames
-      int passed = 0;
-      while (passed < have) {
-        if (region_usable(treg(pool, fp.max_active_tracks, t, cursor), has_no_mass, proc_ffc)) passed += 1;
-        cursor += 1;
-      }
-      seen += have;
-      sample_track[si] = ti;
-      si += 1;
     }
     ti += 1;
   }

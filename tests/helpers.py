@@ -141,3 +141,39 @@ def ir_mask(case, H=480, W=640):
         img[::5, :] = 0
         img[200:260, :] = 255
     return img
+
+
+class _IdentityGenerator:
+    """Stand-in for numpy.random.Generator whose draws are the identity (see IdentityDraws)."""
+
+    def shuffle(self, x):
+        return None
+
+    def choice(self, a, size=None, replace=True):
+        a = np.asarray(a)
+        if size is None:
+            return a[0]
+        size = int(size)
+        if not replace:
+            if size > len(a):
+                raise ValueError("Cannot take a larger sample than population when replace is False")
+            return a[:size].copy()
+        return a[np.arange(size) % len(a)]
+
+
+class IdentityDraws:
+    """Context manager that pins every random draw get_segments makes (the reference's and the host port's alike,
+    datasetstructures.py:1045,1165,1197,1240,1278) to the identity: np.random.default_rng(...) returns a generator
+    whose shuffle leaves the order, whose choice(replace=False) takes the first k and whose choice with replacement
+    cycles through the array; the global np.random.shuffle is a no-op.  cpx_plan_segments plans exactly this member of
+    the reference's random family (tests/golden/make_golden_segments_identity.py)."""
+
+    def __enter__(self):
+        self._rng, self._shuffle = np.random.default_rng, np.random.shuffle
+        np.random.default_rng = lambda *a, **k: _IdentityGenerator()
+        np.random.shuffle = lambda x: None
+        return self
+
+    def __exit__(self, *exc):
+        np.random.default_rng, np.random.shuffle = self._rng, self._shuffle
+        return False

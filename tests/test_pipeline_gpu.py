@@ -1,5 +1,5 @@
 """The batched pipeline (what bench.py times) against the oracle chain, clip by clip: kept tracks and
-their order, the reference's segment-count rule, network inputs (bit-exact vs the NumPy oracle for the
+their order, the segment plan (frames, padding order) of the reference's get_segments under identity draws, network inputs (bit-exact vs the NumPy oracle for the
 planned segments), and the per-track class scores (1e-3)."""
 import numpy as np
 import pytest
@@ -21,7 +21,8 @@ def test_batched_pipeline_matches_oracle_chain():
     from cpx.engine import TrackEngine
     from cpx.ml_tools import wrresnet as wr
     from cpx.pipeline import BatchPipeline
-    from helpers import load_clip
+    from cpx.ml_tools import datasetstructures as ds
+    from helpers import IdentityDraws, load_clip
 
     eng = TrackEngine(model="lepton3")
     rng = np.random.default_rng(31)
@@ -48,7 +49,7 @@ def test_batched_pipeline_matches_oracle_chain():
     reqs = res.reqs_dev.cpu().numpy().view(CROP_REQ_DTYPE).reshape(-1, 25)
     st = res.sample_track_dev.cpu().numpy()
     ti = 0
-    total_tracks = 0
+    total_tracks = n_multi = 0
     for b, clip in enumerate(clips):
         is_pos = b == 5
         out = to.track_clip(clip, t_on if is_pos else None, ffc if is_pos else None, bgf if is_pos else None,
@@ -59,10 +60,17 @@ def test_batched_pipeline_matches_oracle_chain():
         for t in out["tracks"]:
             assert (tc[ti, 0], tc[ti, 1]) == (b, t.id)
             mine = np.nonzero(st == ti)[0]
-            usable = [r.frame_number for r in t.bounds if not r.blank and r.mass > 0 and r.width > 0 and r.height > 0]
-            assert len(mine) == max(1, (len(usable) + 12) // 25)
             # device frame index -> processed frame number of this clip
             segs = [np.array([proc.index(int(f) - int(offs[b])) for f in reqs[s]["frame"]]) for s in mine]
+            # the planner's choice = the host port of the reference's get_segments (pinned by segments_golden.json and,
+            # under these draws, by segments_identity_golden.json) with every random draw the identity
+            with IdentityDraws():
+                want_segs, _ = ds.get_segments(b, t.id, t.bounds[0].frame_number, regions=np.array(t.bounds, dtype=object),
+                                               segment_width=25, segment_frame_spacing=9, ffc_frames=out["ffc_frames"],
+                                               repeats=1, min_frames=0, segment_types=[ds.SegmentType.ALL_RANDOM_MASKED],
+                                               max_segments=None, dont_filter=False, min_segments=1, seed=None)
+            assert [list(map(int, sg)) for sg in segs] == [[int(f) for f in sg.frame_indices] for sg in want_segs], (b, t.id)
+            n_multi += len(segs) > 1
             by_frame = {r.frame_number: r for r in t.bounds}
             x, _ = co.preprocess_segments(lambda q: clip[proc[q]], lambda q: fr[q]["filtered"].astype(np.float64),
                                           by_frame, t.bounds, segs, 32, (1, 1, 158, 118))
@@ -72,7 +80,7 @@ def test_batched_pipeline_matches_oracle_chain():
             assert np.abs(scores[ti] - want).max() <= 1e-3, (b, t.id)
             ti += 1
             total_tracks += 1
-    assert ti == res.n_tracks and total_tracks >= 3
+    assert ti == res.n_tracks and total_tracks >= 3 and n_multi >= 1
     eng.close()
 
 

@@ -38,6 +38,32 @@ def test_get_segments_equals_reference():
     assert n_segments > 200 and {"ALL_RANDOM_MASKED", "ALL_RANDOM"} <= seen_types
 
 
+def test_get_segments_with_identity_draws_equals_reference():
+    """The member of the random family cpx_plan_segments implements: every draw the identity (helpers.IdentityDraws).
+    The host port under those draws must return what the REFERENCE returned under the same draws
+    (tests/golden/segments_identity_golden.json, make_golden_segments_identity.py) -- frame lists incl. padding order,
+    and the segments dropped by the mass test."""
+    from cpx.ml_tools import datasetstructures as ds
+    from helpers import IdentityDraws
+
+    with open(os.path.join(GOLDEN, "segments_identity_golden.json")) as fh:
+        cases = json.load(fh)["cases"]
+    n_segments = dropped = 0
+    for ci, c in enumerate(cases):
+        regions = np.array([_R(m, b, w, h, c["start"] + i) for i, (m, b, w, h) in enumerate(c["regions"])],
+                           dtype=object)
+        with IdentityDraws():
+            segs, stats = ds.get_segments(7, ci + 1, c["start"], regions=regions, segment_width=25,
+                                          segment_frame_spacing=9, ffc_frames=c["ffc"], repeats=1, min_frames=0,
+                                          segment_types=[ds.SegmentType.ALL_RANDOM_MASKED], max_segments=None,
+                                          dont_filter=False, min_segments=1, seed=None)
+        assert [[int(f) for f in s.frame_indices] for s in segs] == c["segments"], ci
+        assert int(stats["segment_mass"]) == c["dropped_for_mass"], ci
+        n_segments += len(segs)
+        dropped += c["dropped_for_mass"]
+    assert n_segments >= 200 and dropped >= 2
+
+
 def test_hyperparams_defaults_equal_reference():
     """cpx.ml_tools.hyperparams.HyperParams against the reference's defaults / derived values
     (tests/golden/defaults_golden.json, make_golden_defaults.py)."""
