@@ -25,7 +25,13 @@ Extra objects on the JSON line:
                 cpx_frame_kernel, HBM-bound, 614,400 algorithmic bytes per frame.
   roofline_track  (e2e) the same HBM accounting for cpx_frame_kernel inside the same run.
   cpu_baseline  the oracle chain ("port": NumPy tracker + NumPy crop/tile + PyTorch-CPU forward, 1 core)
-                timed on a bounded sample of the same workload on this host (rank 0, N = 1 only).
+                timed on a bounded sample of the same workload on this host (rank 0, N = 1 only);
+  cpu_baseline_all_cores  the same chain on min(os.cpu_count(), 64) worker processes (single
+                thread AND all cores).  Both run before this process initialises the GPU.
+
+--config4: BASELINE configs[3] -- 10,000 seeded clips of 90-540 frames, sharded over the
+ranks by greedy longest-processing-time on the frame counts, processed in device batches, one all_gather per step of
+[clip_id, track_id, 17 x f32] records; value = all frames x steps / max-over-ranks time ("scaling": "strong").
 """
 import argparse
 import json
@@ -86,8 +92,9 @@ def synth_on_device(torch, device, n_clips, n_frames, seed, h=120, w=160, chunk=
     return out
 
 
-def cpu_baseline(stage, n_clips, n_frames, seed, weights, frame_size=32):
-    """The oracle chain (single core) over a bounded sample of the same workload."""
+def _oracle_clip(job):
+    """One clip through the oracle chain (a worker of cpu_baseline; imports happen here so that a spawned process
+    needs nothing from the parent).  job = (stage, seed, n_frames, frame_size, weights or None) -> (frames, samples)."""
     import numpy as np
     import torch
 
@@ -96,39 +103,66 @@ def cpu_baseline(stage, n_clips, n_frames, seed, weights, frame_size=32):
     import track_oracle as to
     from cpx import synth
 
+    stage, seed, n_frames, frame_size, weights = job
     torch.set_num_threads(1)
-    frames, offs = synth.make_batch(n_clips, n_frames, seed=seed)
+    clip = synth.make_clip(np.random.default_rng(seed), n_frames)
     cfg = to.OracleConfig("lepton3")
-    H, W = frames.shape[1:]
+    H, W = clip.shape[1:]
+    if stage == "track":
+        to.track_clip(clip, cfg=cfg, keep=True, do_tracking="regions")
+        return n_frames, 0
+    out = to.track_clip(clip, cfg=cfg, keep=True)
+    fr = out["frames"]
     n_samples = 0
-    t0 = time.perf_counter()
-    for b in range(n_clips):
-        clip = frames[offs[b]:offs[b + 1]]
-        if stage == "track":
-            to.track_clip(clip, cfg=cfg, keep=True, do_tracking="regions")
+    for t in out["tracks"]:
+        usable = [r.frame_number for r in t.bounds if not r.blank and r.mass > 0 and r.width > 0 and r.height > 0]
+        if not usable:
             continue
-        out = to.track_clip(clip, cfg=cfg, keep=True)
-        fr = out["frames"]
-        for t in out["tracks"]:
-            usable = [r.frame_number for r in t.bounds if not r.blank and r.mass > 0 and r.width > 0 and r.height > 0]
-            if not usable:
-                continue
-            nseg = max(1, (len(usable) + 12) // 25)
-            segs = []
-            for s in range(nseg):
-                run = usable[25 * s: 25 * s + 25]
-                segs.append(np.array([run[(j * len(run)) // 25] for j in range(25)]))
-            by_frame = {r.frame_number: r for r in t.bounds}
-            x, _ = co.preprocess_segments(lambda q: clip[q], lambda q: fr[q]["filtered"].astype(np.float64), by_frame,
-                                          t.bounds, segs, frame_size, (1, 1, W - 2, H - 2))
-            _, probs = cnn.forward(weights, x)
-            co.classified_track(probs, prediction_frames=segs)
-            n_samples += nseg
+        nseg = max(1, (len(usable) + 12) // 25)
+        segs = []
+        for s in range(nseg):
+            run = usable[25 * s: 25 * s + 25]
+            segs.append(np.array([run[(j * len(run)) // 25] for j in range(25)]))
+        by_frame = {r.frame_number: r for r in t.bounds}
+        x, _ = co.preprocess_segments(lambda q: clip[q], lambda q: fr[q]["filtered"].astype(np.float64), by_frame,
+                                      t.bounds, segs, frame_size, (1, 1, W - 2, H - 2))
+        _, probs = cnn.forward(weights, x)
+        co.classified_track(probs, prediction_frames=segs)
+        n_samples += nseg
+    return n_frames, n_samples
+
+
+def cpu_baseline(stage, lengths, seed, weights, frame_size=32, cores=1):
+    """The oracle chain over a bounded sample of the same workload: clips of `lengths` frames, seeded like the
+    device-side recipe, on `cores` worker processes (1 = in this process).  Runs BEFORE this process touches the GPU
+    (spawned workers and HIP do not mix)."""
+    jobs = [(stage, seed + i, int(n), frame_size, weights) for i, n in enumerate(lengths)]
+    if cores <= 1:
+        _oracle_warm(0)
+        t0 = time.perf_counter()
+        res = [_oracle_clip(j) for j in jobs]
+    else:
+        import multiprocessing as mp
+
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_oracle_warm, range(cores))      # interpreter start + imports are not the baseline
+            t0 = time.perf_counter()
+            res = pool.map(_oracle_clip, jobs, chunksize=1)
     dt = time.perf_counter() - t0
+    frames, n_samples = sum(r[0] for r in res), sum(r[1] for r in res)
     what = ("pixel stage + regions (NumPy)" if stage == "track" else
             "track + classify (NumPy tracker, NumPy crop/tile, PyTorch-CPU fp32 forward; %d samples)" % n_samples)
-    return {"value": round(n_clips * n_frames / dt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic clips x %d frames, oracle %s, %.1f s" % (n_clips, n_frames, what, dt)}
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic clips, %d frames, oracle %s, %.1f s" % (len(jobs), frames, what, dt)}
+
+
+def _oracle_warm(_):
+    import torch  # noqa: F401
+
+    import classify_oracle  # noqa: F401
+    import cnn_oracle  # noqa: F401
+    import track_oracle  # noqa: F401
+    return 0
 
 
 # algorithmic FLOPs of one stage-2 3x3 convolution per sample as the library counts them (cpx_conv_timing_report):
@@ -250,6 +284,148 @@ def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+def config4_lengths(n_clips, seed=1234, lo=90, hi=540):
+    """Frames per clip of the configs[3] workload: seeded, uniform in [lo, hi] (10 s - 60 s at 9 fps)."""
+    import numpy as np
+
+    return np.random.default_rng(seed).integers(lo, hi + 1, size=n_clips).astype(np.int64)
+
+
+class Config4Workload:
+    """BASELINE configs[3] / SURVEY section 8(d) config 4: `n_clips` seeded synthetic clips of varying length, sharded
+    over the ranks by greedy longest-processing-time on the frame counts (cpx.sharding.partition_clips), every rank's
+    shard processed in device batches that fit HBM (plan_sub_batches; frames resident), and ONE all-gather per step of
+    the records [clip_id, track_id, n_labels x f32] (pack_records / gather_records).  A clip's pixels depend only on
+    (seed, clip id), never on the rank that owns it."""
+
+    H, W = 120, 160
+
+    def __init__(self, torch, device, local_rank, rank, world, n_clips, seed=1234, lo=90, hi=540,
+                 sub_frames=2048 * 270, cnn_chunk=2048, frame_size=32, cnn_math="bf16x3", weights=None, n_labels=N_LABELS):
+        import numpy as np
+
+        from cpx.engine import TrackEngine
+        from cpx.ml_tools import wrresnet as wr
+        from cpx.pipeline import BatchPipeline
+        from cpx.sharding import partition_clips, plan_sub_batches
+
+        self.torch, self.np, self.device, self.rank, self.world = torch, np, device, rank, world
+        self.seed, self.n_labels = seed, n_labels
+        self.lengths = config4_lengths(n_clips, seed, lo, hi)
+        self.shards = partition_clips(self.lengths, world)
+        self.mine = self.shards[rank]
+        self.subs = plan_sub_batches(self.lengths, self.mine, sub_frames)
+        self.eng = TrackEngine(width=self.W, height=self.H, model="lepton3", device=local_rank, max_components=64,
+                               max_frames=max(int(hi), 45))
+        self.eng.set_cnn_math(cnn_math)
+        self.weights = weights if weights is not None else wr.random_weights(n_labels, seed=0)
+        self.net = wr.WRResNetDevice(self.eng, self.weights, n_labels)
+        self.pipe = BatchPipeline(self.eng, self.net, n_labels=n_labels, fp_index=4, cnn_chunk=cnn_chunk,
+                                  frame_size=frame_size)
+        self.batches = []  # (clip ids tensor, frames, offs, meta)
+        cap = 0
+        for ids in self.subs:
+            lens = [int(self.lengths[i]) for i in ids]
+            offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            frames = torch.empty((int(offs[-1]), self.H, self.W), dtype=torch.int16, device=device)
+            metas = []
+            for k, i in enumerate(ids):
+                frames[offs[k]:offs[k + 1]] = self.clip_frames(i)
+                metas.append(self.eng.make_meta(lens[k], [100000 + 114 * q for q in range(lens[k])], [40000] * lens[k]))
+            self.batches.append((torch.tensor(ids, dtype=torch.int32, device=device), frames, offs, np.concatenate(metas)))
+            cap = max(cap, int(offs[-1]))
+        self.cap_frames = cap
+        self.comps = torch.empty(max(cap, 1) * 64 * 8, dtype=torch.int32, device=device)
+        self.info = torch.empty(max(cap, 1) * 20, dtype=torch.int32, device=device)
+        self.filt = torch.empty((max(cap, 1), self.H, self.W), dtype=torch.float32, device=device)
+        self.frames_local = int(sum(int(self.lengths[i]) for i in self.mine))
+        self.frames_total = int(self.lengths.sum())
+        self.last = None
+
+    def clip_frames(self, clip_id):
+        """The clip's frames on the device (uint16 bits in int16), a function of (seed, clip id) only."""
+        return synth_on_device(self.torch, self.device, 1, int(self.lengths[clip_id]), seed=self.seed * 1000003 + int(clip_id),
+                               h=self.H, w=self.W, chunk=1)
+
+    def step(self, dist=None):
+        """One pass over this rank's shard + the all-gather.  -> records of ALL ranks, int32 [n_tracks, 2 + n_labels]."""
+        from cpx.sharding import gather_records, pack_records
+
+        t = self.torch
+        recs, results = [], []
+        for ids_dev, frames, offs, meta in self.batches:
+            total = int(offs[-1])
+            outputs = (self.comps[: total * 64 * 8], self.info[: total * 20], None, self.filt[:total], None)
+            res = self.pipe.run(frames, offs, meta, outputs=outputs)
+            results.append(res)
+            if res.n_tracks and res.scores is not None:
+                recs.append(pack_records(ids_dev[res.track_clip[:, 0].long()], res.track_clip[:, 1], res.scores))
+        rec = t.cat(recs) if recs else t.empty((0, 2 + self.n_labels), dtype=t.int32, device=self.device)
+        self.last = results
+        return gather_records(rec, dist)
+
+    def close(self):
+        self.net.close()
+        self.eng.close()
+
+
+def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu):
+    """--config4: see Config4Workload.  value = frames of ALL clips x steps / max-over-ranks time (strong scaling: the
+    clip set is fixed, ranks share it)."""
+    n_clips = args.clips or 10000
+    # every rank needs its shard resident: shrink the clip set when one GPU cannot hold its share
+    free, _ = torch.cuda.mem_get_info(device)
+    budget = 0.42 * free
+    while n_clips > 64 and config4_lengths(n_clips).sum() / world * 38400 > budget:
+        n_clips //= 2
+    wl = Config4Workload(torch, device, local_rank, rank, world, n_clips, sub_frames=args.sub_frames,
+                         cnn_chunk=args.cnn_chunk, frame_size=args.frame_size, cnn_math=args.cnn_math)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        wl.step(dist)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = wl.step(dist)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    for r in wl.last:
+        r.track.check()
+        r.assoc.check()
+    if rank == 0:
+        loads = [int(wl.lengths[s].sum()) for s in wl.shards]
+        line = {"metric": "CPTV frames/s end-to-end (track+classify) at 160x120",
+                "value": round(wl.frames_total * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)" % args.cnn_math,
+                "data": "synthetic",
+                "config": {"workload": "BASELINE configs[3]: %d seeded synthetic clips of 90-540 frames, LPT-sharded by frame "
+                                       "count over the ranks, device batches of <= %d frames, track -> 25-frame segments -> "
+                                       "crop/tile + WR-ResNet-22-4, all_gather of [clip_id, track_id, %d x f32]"
+                                       % (n_clips, args.sub_frames, N_LABELS),
+                           "clips": int(n_clips), "frames_total": wl.frames_total, "frames_per_rank": loads,
+                           "imbalance": round(max(loads) / (sum(loads) / len(loads)), 4),
+                           "device_batches_rank0": len(wl.subs), "records_gathered": int(gathered.shape[0]),
+                           "record_width": int(gathered.shape[1]), "frame_size": args.frame_size,
+                           "cnn_chunk": args.cnn_chunk, "n_labels": N_LABELS}}
+        line.update(cpu)
+        print(json.dumps(line), flush=True)
+    wl.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +448,11 @@ def main():
                          "network of group k (measured: no gain on MI355X, see DESIGN.md section 6; 1 = off)")
     ap.add_argument("--denoise", action="store_true",
                     help="tracking.denoise = true (the reference's default: NLM kernel between normalise and blur)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE configs[3]: --clips (default 10000) seeded clips of 90-540 frames, LPT-sharded over the "
+                         "ranks, processed in device batches, all_gather of [clip_id, track_id, 17 x f32] (strong scaling)")
+    ap.add_argument("--sub-frames", type=int, default=2048 * 270,
+                    help="--config4: frames per device batch (their per-frame outputs must fit HBM beside the clips)")
     args = ap.parse_args()
 
     import numpy as np
@@ -280,6 +461,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.cnn_chunk <= 0:
+        args.cnn_chunk = 2048 if args.frame_size == 32 else 512
+    # ---- CPU baselines first: worker processes are spawned while this process has not touched the GPU yet ----
+    cpu = {}
+    if world == 1 and rank == 0 and args.cpu_clips != 0 and args.stage != "ir":
+        from cpx.ml_tools import wrresnet as wr0
+
+        w0 = wr0.random_weights(N_LABELS, seed=0)
+        e2e0 = args.stage == "e2e"
+        n1 = args.cpu_clips if args.cpu_clips > 0 else (20 if e2e0 else 16)  # ~15 s of single-core work
+        lens = [int(v) for v in config4_lengths(10000)[:n1]] if args.config4 else [args.frames] * n1
+        cpu["cpu_baseline"] = cpu_baseline(args.stage, lens, 1234, w0, args.frame_size, cores=1)
+        host = os.cpu_count() or 1
+        cores = min(host, 64)
+        if cores > 1:
+            many = [lens[i % len(lens)] for i in range(max(2 * cores, n1))]
+            allc = cpu_baseline(args.stage, many, 1234, w0, args.frame_size, cores=cores)
+            allc["host_cores"] = host
+            cpu["cpu_baseline_all_cores"] = allc
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -297,18 +497,18 @@ def main():
     from cpx.engine import TrackEngine
     from cpx.ml_tools import wrresnet as wr
     from cpx.pipeline import BatchPipeline
-    from cpx.sharding import gather_records
+    from cpx.sharding import gather_records, pack_records
 
     if args.stage == "ir":
         return bench_ir(args, torch, np, dist, device, rank, world, local_rank)
+    if args.config4:
+        return bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu)
     e2e = args.stage == "e2e"
     H, W, T = 120, 160, args.frames
     P = H * W
     B = args.clips or 4096
     free, _ = torch.cuda.mem_get_info(device)
     per_clip = T * P * 2 + T * 64 * 32 + T * 80 + 6 * P * 4 + T * P * 4 + (T * 16 * 56 if e2e else T * P * 4)
-    if args.cnn_chunk <= 0:
-        args.cnn_chunk = 2048 if args.frame_size == 32 else 512
     reserve = (args.cnn_chunk * 30e6 * (args.frame_size / 32) ** 2) if e2e else 0
     while B > 64 and B * per_clip + reserve > 0.80 * free:
         B //= 2
@@ -341,12 +541,11 @@ def main():
             state["res"] = res
             state["track_ms"], state["track_n"] = res.track_timing
             if dist is not None:  # every rank enters the collective, also one whose clips produced no track
+                # the record of SURVEY section 8(d) config 4: [clip_id, track_id, n_labels x f32]
                 if res.n_tracks:
-                    rec = torch.cat([res.track_clip[:, :1] + rank * B, res.track_clip[:, 1:], res.best.view(-1, 1),
-                                     (res.scores.max(dim=1).values * 1e6).to(torch.int32).view(-1, 1)], dim=1).contiguous()
-                    state["rec_width"] = rec.shape[1]
+                    rec = pack_records(res.track_clip[:, 0] + rank * B, res.track_clip[:, 1], res.scores)
                 else:
-                    rec = torch.empty((0, state.get("rec_width", 4)), dtype=torch.int32, device=device)
+                    rec = torch.empty((0, 2 + N_LABELS), dtype=torch.int32, device=device)
                 state["gathered"] = gather_records(rec, dist)
             return res.track
         res = eng.track_batch(frames, offs, meta, outputs=outputs)
@@ -421,7 +620,7 @@ def main():
                 "frames_per_clip": T,
                 "camera_model": "lepton3",
                 "denoise": bool(args.denoise),
-                "sharding": "clips across ranks, all_gather of per-track records" if world > 1 else "single GPU",
+                "sharding": "clips across ranks, all_gather of [clip_id, track_id, 17 x f32] records" if world > 1 else "single GPU",
             },
         }
         if e2e:
@@ -483,9 +682,7 @@ def main():
         else:
             line["config"]["outputs"] = "components + label image + filtered image"
             line["roofline"] = track_roof
-        ncpu = args.cpu_clips if args.cpu_clips >= 0 else (20 if e2e else 16)  # ~15 s of single-core work
-        if world == 1 and ncpu > 0:
-            line["cpu_baseline"] = cpu_baseline(args.stage, ncpu, T, 1234, weights, args.frame_size)
+        line.update(cpu)  # measured before the GPU was initialised (top of main)
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

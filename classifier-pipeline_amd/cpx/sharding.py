@@ -64,3 +64,42 @@ def gather_records(records, dist=None, device=None):
         out = gathered[gathered[:, 0] >= 0]
     order = torch.argsort(out[:, 0], stable=True)
     return out[order]
+
+
+def plan_sub_batches(frame_counts, clip_ids, max_frames, max_clips=4096):
+    """Cuts one rank's clips into device batches: clips ordered by length (a batch advances all its clips one frame
+    per kernel launch, so clips of similar length waste the fewest launches), a batch closed when it would exceed
+    `max_frames` frames (what fits HBM next to the per-frame outputs) or `max_clips` clips.
+    -> list of lists of clip ids (every id of `clip_ids` exactly once)."""
+    order = sorted((int(i) for i in clip_ids), key=lambda i: (int(frame_counts[i]), i))
+    out, cur, cur_frames = [], [], 0
+    for i in order:
+        n = int(frame_counts[i])
+        if cur and (cur_frames + n > max_frames or len(cur) >= max_clips):
+            out.append(cur)
+            cur, cur_frames = [], 0
+        cur.append(i)
+        cur_frames += n
+    if cur:
+        out.append(cur)
+    return out
+
+
+def pack_records(clip_ids, track_ids, scores):
+    """Per-track result records for the all-gather: int32 [n, 2 + n_labels] =
+    clip id, track id, the float32 class scores bit for bit."""
+    import torch
+
+    n = int(scores.shape[0])
+    rec = torch.empty((n, 2 + int(scores.shape[1])), dtype=torch.int32, device=scores.device)
+    rec[:, 0] = clip_ids.to(torch.int32)
+    rec[:, 1] = track_ids.to(torch.int32)
+    rec[:, 2:] = scores.contiguous().view(torch.int32)
+    return rec
+
+
+def unpack_records(records):
+    """-> (clip ids int32 [n], track ids int32 [n], scores float32 [n, n_labels]) of pack_records / gather_records."""
+    import torch
+
+    return records[:, 0], records[:, 1], records[:, 2:].contiguous().view(torch.float32)

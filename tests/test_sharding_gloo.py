@@ -74,6 +74,29 @@ WORKER = textwrap.dedent(
     rec2 = rec if rank == 0 else torch.empty((0, 4), dtype=torch.int32)
     out2 = gather_records(rec2, dist)
     assert out2.shape == (len(partition_clips(counts, world)[0]), 4) and (out2[:, 3] == 0).all()
+    # the configs[3] record [clip_id, track_id, 17 x f32] over the LPT shards of variable-length clips (bench.py --config4)
+    from cpx.sharding import pack_records, unpack_records, plan_sub_batches
+    lengths = np.random.default_rng(1234).integers(90, 541, size=61)
+    shards = partition_clips(lengths, world)
+    def table(ids):
+        rows = [(i, t) for i in ids for t in range(1, 1 + i %% 3)]     # clip i has i %% 3 kept tracks
+        sc = np.array([[np.float32(np.sin(i * 17 + t * 3 + l)) for l in range(17)] for i, t in rows], np.float32).reshape(-1, 17)
+        return rows, sc
+    batches = plan_sub_batches(lengths, shards[rank], 2000)
+    assert sorted(i for b in batches for i in b) == shards[rank]
+    assert all(sum(int(lengths[i]) for i in b) <= 2000 for b in batches)
+    recs = []
+    for b in batches:
+        rows, sc = table(b)
+        if rows:
+            recs.append(pack_records(torch.tensor([r[0] for r in rows]), torch.tensor([r[1] for r in rows]), torch.from_numpy(sc)))
+    mine = torch.cat(recs) if recs else torch.empty((0, 19), dtype=torch.int32)
+    allrec = gather_records(mine, dist)
+    rows, sc = table(range(61))
+    cid, tid, got = unpack_records(allrec)
+    assert allrec.shape == (len(rows), 19) and allrec.dtype == torch.int32
+    assert cid.tolist() == [r[0] for r in rows] and tid.tolist() == [r[1] for r in rows]
+    assert np.array_equal(got.numpy(), sc)          # float32 scores cross the collective bit for bit
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ok_%%d" %% rank), "w").write("ok")
