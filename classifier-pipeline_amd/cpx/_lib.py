@@ -58,7 +58,7 @@ FRAME_INFO_DTYPE = np.dtype(
 )
 REGION_REF_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"),
                              ("in_segment", "<i4")])
-TRACK_LIMITS_DTYPE = np.dtype([("filt_min", "<f4"), ("filt_max", "<f4"), ("clip_at_zero", "<i4"), ("reserved", "<i4")])
+TRACK_LIMITS_DTYPE = np.dtype([("filt_min", "<f4"), ("filt_max", "<f4"), ("clip_at_zero", "<i4"), ("flags", "<i4")])
 CROP_REQ_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"),
                            ("track", "<i4"), ("sample", "<i4"), ("tile", "<i4")])
 THUMB_STAT_DTYPE = np.dtype([("contours", "<i4"), ("status", "<i4"), ("median_diff", "<f8")])
@@ -88,7 +88,12 @@ EXPORTS = [
     "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
+    "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
 ]
+
+# flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
+TRACK_KEEP_BACKGROUND, TRACK_FREEZE_ON_FFC, TRACK_FREEZE_BACKGROUND = 1, 2, 4
+LIMITS_POST_PROCESS = 1
 
 _lib = None
 
@@ -165,6 +170,16 @@ def load():
     lib.cpx_cnn_forward.restype = C.c_int
     lib.cpx_track_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.cpx_track_frame.restype = C.c_int
+    lib.cpx_track_batch_ex.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+    lib.cpx_track_batch_ex.restype = C.c_int
+    lib.cpx_track_frame_ex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+    lib.cpx_track_frame_ex.restype = C.c_int
+    lib.cpx_set_background.argtypes = [vp, C.c_int, vp, vp, C.c_double]
+    lib.cpx_set_background.restype = C.c_int
+    lib.cpx_get_background.argtypes = [vp, C.c_int, vp, vp, C.POINTER(C.c_double)]
+    lib.cpx_get_background.restype = C.c_int
+    lib.cpx_track_limits_batch_ex.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int]
+    lib.cpx_track_limits_batch_ex.restype = C.c_int
     lib.cpx_associate_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpx_associate_frame.restype = C.c_int
     lib.cpx_thumb_stats.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]

@@ -1,11 +1,13 @@
 """ClipClassifier -- file-level driver of track + classify
-(reference src/classify/clipclassifier.py:20-383).  The low-memory re-read path
-(post_process_file) and previews are not part of this build."""
+(reference src/classify/clipclassifier.py:20-651), incl. the re-read path post_process_file that classify.py runs
+today (classify/main.py:129).  Previews are not part of this build."""
 
 import json
 import logging
+import math
 import os
 import time
+from datetime import datetime
 from pathlib import Path
 
 import numpy as np
@@ -190,5 +192,117 @@ class ClipClassifier:
         return meta_data
 
     def post_process_file(self, filename, service):
-        raise NotImplementedError("post_process_file (low-memory re-read path) is not part of this build: "
-                                  "use process_file(track=True)")
+        """clipclassifier.py:385-651: tracks come from <clip>.txt when it exists (else from tracking the file), segments
+        are chosen first, then the recording is walked AGAIN with the background model the tracking left behind
+        (a fresh one in the metadata case) -- updated from the 45-frame running mean on every frame that is not
+        FFC-affected -- and only the sampled regions are cropped: thermal - frame median, filtered = thermal -
+        background as it stands at that frame; limits over the sampled crops; the median is subtracted before the
+        resize, thermals are always clipped at zero; predictions in chunks of 5 segments.
+        On the device the second walk is one cpx_track_batch_ex(KEEP_BACKGROUND | FREEZE_ON_FFC) over the resident
+        frames, and the crops are cpx_track_limits_batch_ex(CPX_LIMITS_POST_PROCESS) + cpx_crop_tile."""
+        from .._lib import (CROP_REQ_DTYPE, LIMITS_POST_PROCESS, REGION_REF_DTYPE, TRACK_FREEZE_ON_FFC,
+                            TRACK_KEEP_BACKGROUND)
+
+        filename = Path(filename)
+        meta_file = filename.with_suffix(".txt")
+        has_metadata = meta_file.exists()
+        if not filename.exists():
+            logging.error("File %s not found.", filename)
+            return False
+        if has_metadata:
+            track_extractor = ClipTrackExtractor(self.config.tracking, self.config.use_opt_flow,
+                                                 calculate_filtered=True, verbose=self.config.verbose)
+            clip = Clip(track_extractor.config, filename)
+            meta_data = load_clip_metadata(meta_file)
+            rec_end = datetime.fromisoformat(meta_data["end_time"])
+            clip.load_metadata(meta_data, getattr(getattr(self.config, "build", None), "tag_precedence", None))
+            track_extractor.init_clip(clip)
+            frames = track_extractor._frames
+            eng = track_extractor._engine
+            meta = eng.make_meta(len(frames), [f.time_on for f in frames], [f.last_ffc_time for f in frames],
+                                 [bool(f.background_frame) for f in frames])
+            flags = TRACK_FREEZE_ON_FFC  # init_clip seeded a fresh model from the file's first frame
+        else:
+            clip, track_extractor, meta_data = extract_file(filename, self.config, False, max_frames=45, save_meta=False)
+            rec_end = datetime.fromisoformat(meta_data["end_time"])
+            frames = track_extractor._frames
+            eng = track_extractor._engine
+            meta = track_extractor._meta
+            # the model continues from where tracking left it (the reference re-uses track_extractor.background_alg)
+            eng.set_background(0, *track_extractor._final_state)
+            flags = TRACK_KEEP_BACKGROUND | TRACK_FREEZE_ON_FFC
+        del rec_end  # only the dbus event of the Pi reads it (service.TrackReprocessed)
+
+        logging.info("Just running on first model")
+        start = time.time()
+        model = self.config.classify.models[0]
+        classifier = self.get_classifier(model)
+        predictions = Predictions(classifier.labels, model, classifier.thresholds)
+        predictions.model_load_time = time.time() - start
+        if classifier.params.thermal_diff_norm:
+            logging.error("Thermal min diff is not implemented so will not be used")
+        if not classifier.params.diff_norm or list(classifier.params.channels) != ["thermal", "filtered"]:
+            raise NotImplementedError("only diff_norm=True models with channels (thermal, filtered) are supported")
+
+        track_data = {}
+        for track in clip.tracks:
+            track_data[track.get_id()] = {"pred_frames": classifier.frames_for_prediction(clip, track), "track": track}
+
+        # ---- the second walk over the recording, on the device ----
+        n = len(frames)
+        offs = np.array([0, n], np.int32)
+        frames_dev = track_extractor._frames_dev
+        res = eng.track_batch(frames_dev, offs, meta, want_filtered=True, flags=flags)
+        res.check()
+        proc = [i for i in range(n) if not meta["background_frame"][i]]  # frame number -> index in frames_dev
+
+        sq, fs = classifier.params.square_width, classifier.params.frame_size
+        for i, (track_id, data) in enumerate(track_data.items()):
+            segments = data["pred_frames"]
+            if len(segments) == 0:
+                logging.info("No prediction made for track %s", track_id)
+                continue
+            by_frame = {}
+            for seg in segments:
+                for r in seg.regions:
+                    by_frame[int(r.frame_number)] = r
+            refs = [(proc[fn], r.x, r.y, r.width, r.height, 1) for fn, r in sorted(by_frame.items())]
+            reqs = []
+            for s_i, seg in enumerate(segments):
+                for tile, fn in enumerate(seg.frame_indices):
+                    r = by_frame[int(fn)]
+                    reqs.append((proc[int(fn)], r.x, r.y, r.width, r.height, 0, s_i, tile))
+            x, _ = eng.preprocess_segments(frames_dev, res, np.array(refs, dtype=REGION_REF_DTYPE),
+                                           np.array([0, len(refs)], np.int32), np.array(reqs, dtype=CROP_REQ_DTYPE),
+                                           len(segments), frame_size=fs, square_width=sq,
+                                           limits_flags=LIMITS_POST_PROCESS)
+            preds = []
+            chunk_size = 5
+            for chunk in range(int(math.ceil(len(segments) / chunk_size))):
+                part = x[chunk * chunk_size: chunk * chunk_size + chunk_size]
+                logging.info("Predicting chunk %s (%s #) of %s total preprocessed %s", chunk, len(part),
+                             int(math.ceil(len(segments) / chunk_size)), len(segments))
+                try:
+                    pred = classifier.predict(part)
+                except Exception:
+                    logging.error("Could not classify chunk not trying again ", exc_info=True)
+                    break
+                preds.extend(pred)
+            track_prediction = classifier.track_prediction_from_raw(
+                track_id, [seg.frame_indices for seg in segments], preds, [seg.mass for seg in segments])
+            predictions.prediction_per_track[track_id] = track_prediction
+            logging.info("%s - [%s/%s] prediction: %s", track_id, i + 1, len(clip.tracks), track_prediction.description())
+            if self.tracking_events and service is not None and len(track_prediction.predictions) > 0:
+                # the dbus event of the Pi (clipclassifier.py:612-637); the region it reports is the last one the
+                # reference's re-read loop touched (a leaked loop variable there)
+                last_fn = max(int(r.frame_number) for d in track_data.values() for sg in d["pred_frames"] for r in sg.regions)
+                region = [r for d in track_data.values() for sg in d["pred_frames"] for r in sg.regions
+                          if int(r.frame_number) == last_fn][-1]
+                scores = np.uint8(np.round(track_prediction.class_best_score.copy() * 100)).tolist()
+                service.TrackReprocessed(
+                    meta_data.get("id", 0), track_id, scores, track_prediction.predicted_tag(),
+                    int(round(100 * track_prediction.max_score)), np.uint8(region.to_ltrb()).tolist(),
+                    region.frame_number, int(region.mass), region.blank, True,
+                    data["track"].bounds_history[-1].frame_number, model.id,
+                    datetime.fromisoformat(meta_data["end_time"]).timestamp())
+        return self.save_metadata(meta_data, meta_file, clip, {model.id: predictions}, [model], calculate_thumbnails=False)

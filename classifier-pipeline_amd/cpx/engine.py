@@ -143,9 +143,10 @@ class TrackStream:
     def _p(self, tensor):
         return C.c_void_p(tensor.data_ptr() if tensor is not None else None)
 
-    def append(self, pix, time_on=None, last_ffc=None, init_only=False, associate=True):
+    def append(self, pix, time_on=None, last_ffc=None, init_only=False, associate=True, flags=0):
         """Upload one frame and process it.  init_only: the frame only initialises the background
-        (a CPTV background frame).  Returns the frame's index in the stream's arrays."""
+        (a CPTV background frame).  flags: _lib.TRACK_* (who owns the background, include/cpx.h).
+        Returns the frame's index in the stream's arrays."""
         eng, t = self.engine, self.engine.torch
         if self.n >= self.cap_frames:
             raise CpxError(-1, "stream is full (%d frames): open the extractor with a larger max_frames"
@@ -162,9 +163,9 @@ class TrackStream:
             return f  # consumed together with the first real frame
         t.cuda.current_stream(eng.device).synchronize()
         mp = C.c_void_p(self.meta.ctypes.data)
-        rc = eng.lib.cpx_track_frame(eng.h, self._p(self.frames_dev), mp, self.n_tracked, self.n, self._p(self.comps),
-                                     self._p(self.info), self._p(self.labels), self._p(self.filtered),
-                                     self._p(self.background))
+        rc = eng.lib.cpx_track_frame_ex(eng.h, self._p(self.frames_dev), mp, self.n_tracked, self.n,
+                                        self._p(self.comps), self._p(self.info), self._p(self.labels),
+                                        self._p(self.filtered), self._p(self.background), int(flags))
         if rc != 0:
             raise CpxError(rc, eng._err())
         n_prev = self.n_tracked
@@ -372,9 +373,41 @@ class TrackEngine:
             m["background_frame"] = np.asarray(background, dtype=np.int32)
         return m
 
+    def set_background(self, clip, background, weights=None, average=None):
+        """Stage a WeightedBackground state (host arrays: background [H,W], weights [H-2e,W-2e] or None, average) for
+        clip `clip` of the next track call (cpx_set_background)."""
+        bg = np.ascontiguousarray(background, dtype=np.float32)
+        if bg.shape != (self.height, self.width):
+            raise ValueError("background must be [%d, %d]" % (self.height, self.width))
+        e = self.cfg.edge_pixels
+        w = None
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.float64)
+            if w.shape != (self.height - 2 * e, self.width - 2 * e):
+                raise ValueError("weights must cover the cropped interior")
+        if average is None:
+            average = float(np.average(bg[e:self.height - e, e:self.width - e]))
+        rc = self.lib.cpx_set_background(self.h, int(clip), C.c_void_p(bg.ctypes.data),
+                                         C.c_void_p(w.ctypes.data if w is not None else None), float(average))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+
+    def get_background(self, clip=0):
+        """-> (background float32 [H,W], weights float64 [H-2e,W-2e], average) the last track call left for `clip`."""
+        e = self.cfg.edge_pixels
+        bg = np.empty((self.height, self.width), np.float32)
+        w = np.empty((self.height - 2 * e, self.width - 2 * e), np.float64)
+        avg = C.c_double()
+        rc = self.lib.cpx_get_background(self.h, int(clip), C.c_void_p(bg.ctypes.data), C.c_void_p(w.ctypes.data),
+                                         C.byref(avg))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        return bg, w, float(avg.value)
+
     def track_batch(self, frames_dev, clip_offsets, meta, want_labels=False, want_filtered=False,
-                    want_background=False, outputs=None):
-        """frames_dev: device tensor [total,H,W] of uint16 bits; clip_offsets: int32 [B+1]."""
+                    want_background=False, outputs=None, flags=0):
+        """frames_dev: device tensor [total,H,W] of uint16 bits; clip_offsets: int32 [B+1].
+        flags: _lib.TRACK_* (who owns the background, include/cpx.h)."""
         t = self.torch
         offs = np.ascontiguousarray(clip_offsets, dtype=np.int32)
         B = offs.size - 1
@@ -391,12 +424,12 @@ class TrackEngine:
         else:
             comps, info, labels, filt, bgo = outputs
         t.cuda.current_stream(self.device).synchronize()  # inputs were produced on torch's stream
-        rc = self.lib.cpx_track_batch(
+        rc = self.lib.cpx_track_batch_ex(
             self.h, C.c_void_p(frames_dev.data_ptr()), offs.ctypes.data_as(C.POINTER(C.c_int32)),
             C.c_void_p(meta.ctypes.data), B, C.c_void_p(comps.data_ptr()), C.c_void_p(info.data_ptr()),
             C.c_void_p(labels.data_ptr() if labels is not None else None),
             C.c_void_p(filt.data_ptr() if filt is not None else None),
-            C.c_void_p(bgo.data_ptr() if bgo is not None else None))
+            C.c_void_p(bgo.data_ptr() if bgo is not None else None), int(flags))
         if rc != 0:
             raise CpxError(rc, self._err())
         return TrackBatchResult(self, total, self.cap, comps, info, labels, filt, bgo)
@@ -434,7 +467,7 @@ class TrackEngine:
         return self.torch.from_numpy(a.view(np.int32).reshape(-1).copy()).to(self.device)
 
     def preprocess_segments(self, frames_dev, track_result, refs, track_offsets, reqs, n_samples, frame_size=32,
-                            square_width=5, out=None):
+                            square_width=5, out=None, limits_flags=0):
         """get_limits + clip test per track, then crop / resize / normalise / tile every request.
         refs: REGION_REF_DTYPE [R]; track_offsets: int32 [n_tracks+1]; reqs: CROP_REQ_DTYPE [n].
         -> (device float tensor [n_samples, sq*fs, sq*fs, 2], limits host array)."""
@@ -453,10 +486,10 @@ class TrackEngine:
         if out is None:
             out = t.empty((n_samples, side, side, 2), dtype=t.float32, device=self.device)
         t.cuda.current_stream(self.device).synchronize()
-        rc = self.lib.cpx_track_limits_batch(
+        rc = self.lib.cpx_track_limits_batch_ex(
             self.h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(track_result.filtered_dev.data_ptr()),
             C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(refs_dev.data_ptr()),
-            C.c_void_p(offs_dev.data_ptr()), n_tracks, C.c_void_p(limits_dev.data_ptr()))
+            C.c_void_p(offs_dev.data_ptr()), n_tracks, C.c_void_p(limits_dev.data_ptr()), int(limits_flags))
         if rc != 0:
             raise CpxError(rc, self._err())
         if reqs.size:  # limits only when there is nothing to crop

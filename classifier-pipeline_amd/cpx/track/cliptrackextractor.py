@@ -15,6 +15,7 @@ from datetime import datetime
 
 import numpy as np
 
+from .._lib import TRACK_FREEZE_BACKGROUND
 from ..cptv import CptvReader, decode_clips_on_device
 from ..engine import TrackEngine
 from ..ml_tools.rectangle import Rectangle
@@ -199,8 +200,6 @@ class ClipTrackExtractor(ClipTracker):
                          max_frames=max_frames)
         if use_opt_flow:
             raise NotImplementedError("optical flow is outside the cpx hot path")
-        if not update_background:
-            raise NotImplementedError("update_background=False (Pi live loop) is not supported yet")
         self.version = f"PI-{ClipTrackExtractor.VERSION}" if from_pi else ClipTrackExtractor.VERSION
         self.use_opt_flow = use_opt_flow
         self.high_quality_optical_flow = high_quality_optical_flow
@@ -210,6 +209,10 @@ class ClipTrackExtractor(ClipTracker):
         self.device = device
         self.host_images = True  # parse_clips: copy thermal / filtered / mask images into the frame buffer
         self._stream = None
+        self._external_bg = None   # a caller-owned background model (start_tracking(background_alg=...))
+        self._imported = None      # (background, average) last handed to the device from it
+        self._meta = None          # cpx_frame_meta of the clip parse_clip tracked (post_process_file re-runs it)
+        self._final_state = None   # WeightedBackground state (background, weights, average) after parse_clip
         self._frames = None
         self._frames_dev = None
         self._engine = None
@@ -321,7 +324,8 @@ class ClipTrackExtractor(ClipTracker):
                 clips[i]._background_calculated()
             meta = np.concatenate(metas)
             t0 = time.time()
-            res = eng.track_batch(frames_dev, offs, meta, want_labels=True, want_filtered=True, want_background=True)
+            res = eng.track_batch(frames_dev, offs, meta, want_labels=True, want_filtered=True, want_background=True,
+                                  flags=0 if self.update_background else TRACK_FREEZE_BACKGROUND)
             assoc = None
             if self.do_tracking and not any(clips[i].from_metadata for i in members):
                 c0 = clips[members[0]]
@@ -347,11 +351,13 @@ class ClipTrackExtractor(ClipTracker):
 
     def start_tracking(self, clip, frames, track_frames=True, background_alg=None, **args):
         """Feed `frames` one by one (cliptrackextractor.py:181-193); with track_frames=False they only build the
-        background / frame buffer.  The background model lives on the device: an external background_alg
-        (the Pi motion detector's) cannot be plugged in."""
-        if background_alg is not None:
-            raise NotImplementedError("an external background_alg is not supported: the device keeps the background")
+        frame buffer.  background_alg: a caller-owned background model (the Pi motion detector's WeightedBackground,
+        piclassifier.py:423-431) -- any object with .background ([H, W], integer-valued) and .average; the extractor
+        reads it before every frame and never updates it, exactly as the reference's process_frame does."""
         do_tracking = self.do_tracking
+        self._external_bg = background_alg
+        self._imported = None
+        self.background_alg = background_alg
         self.do_tracking = self.do_tracking and track_frames
         new_tracks = []
         try:
@@ -362,15 +368,29 @@ class ClipTrackExtractor(ClipTracker):
         return new_tracks
 
     def process_frame(self, clip, frame):
-        """One frame through the device: the reference's process_frame (cliptrackextractor.py:195-247) followed by
-        the background update its caller does with the 45-frame mean (cliptrackextractor.py:169-176).  The first
-        call opens the stream: the clip background (clip.update_background, else this frame) seeds the model.
-        Returns the tracks created by this frame."""
+        """One frame through the device: the reference's process_frame (cliptrackextractor.py:195-247).  Who updates
+        the background afterwards depends on who owns it: with a caller-owned model (start_tracking(background_alg=),
+        the Pi loop) or update_background=False nobody here does -- the device reads the model as the owner left it;
+        otherwise the device applies the update _track_clip would (45-frame mean, cliptrackextractor.py:169-176).
+        The first call opens the stream: the clip background (clip.update_background, else this frame) seeds the
+        model.  Returns the tracks created by this frame."""
         st = self._stream
         if st is None or st["clip"] is not clip:
             st = self._open_stream(clip, frame)
         stream = st["stream"]
-        f = stream.append(frame.pix, frame.time_on, frame.last_ffc_time, associate=self.do_tracking)
+        flags = 0
+        ext = self._external_bg
+        if ext is not None:
+            flags = TRACK_FREEZE_BACKGROUND
+            bg = np.asarray(ext.background)
+            avg = float(ext.average)
+            last = self._imported
+            if last is None or last[1] != avg or not np.array_equal(last[0], bg):
+                stream.engine.set_background(0, bg, getattr(ext, "background_weight", None), avg)
+                self._imported = (np.array(bg, copy=True), avg)
+        elif not self.update_background:
+            flags = TRACK_FREEZE_BACKGROUND
+        f = stream.append(frame.pix, frame.time_on, frame.last_ffc_time, associate=self.do_tracking, flags=flags)
         fi = stream.frame_info(f)
         thermal = np.array(frame.pix, dtype=np.uint16, copy=True)
         P = clip.res_x * clip.res_y
@@ -384,7 +404,7 @@ class ClipTrackExtractor(ClipTracker):
         clip.add_frame(thermal, filtered, mask, clip.ffc_affected, stats=stats)
         st["device_state"]._index[clip.current_frame] = f
         clip.device_state = st["device_state"]
-        self.background_alg = StreamBackgroundView(stream, fi, st["weight_add"])
+        self.background_alg = ext if ext is not None else StreamBackgroundView(stream, fi, st["weight_add"])
         if not self.do_tracking:
             return []
         new_tracks = []
@@ -433,15 +453,22 @@ class ClipTrackExtractor(ClipTracker):
         cam35 = clip.camera_model == "lepton3.5"
         weight_add = (1 if cam35 else 0.1) / self.weighting_percent
         capacity = (self.max_frames or 2047) + 1
-        eng = get_engine(clip.res_x, clip.res_y, clip.background_thresh, weight_add, self.config.edge_pixels,
-                         self.device, max_frames=capacity, denoise=bool(self.config.denoise))
+        # a stream's background / window / association state lives in its handle's workspace, so every stream gets a
+        # handle of its own: two extractors (or two live clips) fed in lockstep can never resume on each other's state
+        if self._stream is not None:
+            self._stream["engine"].close()
+            self._stream = None
+        eng = TrackEngine(width=clip.res_x, height=clip.res_y, device=self.device, edge_pixels=self.config.edge_pixels,
+                          background_thresh=clip.background_thresh, weight_add=weight_add, max_components=64,
+                          max_frames=max(capacity, 1024), denoise=bool(self.config.denoise))
         params = make_track_params(
             clip.res_x, clip.res_y, self.config.edge_pixels, self.config.frame_padding, self.min_dimension,
             self.config.cropped_regions_strategy, self.config.filter_regions_pre_match, self.config.aoi_min_mass,
             self.config.aoi_pixel_variance, self.config.params, clip.frames_per_second)
         stream = eng.open_stream(capacity, params, want_labels=True)
+        self._imported = None
         stream.append(clip.background, init_only=True)  # slot 0 seeds the background model, it is not tracked
-        self._stream = dict(clip=clip, stream=stream, tracks={}, weight_add=weight_add,
+        self._stream = dict(clip=clip, stream=stream, tracks={}, weight_add=weight_add, engine=eng,
                             device_state=DeviceClipState(eng, stream.frames_dev, stream.result, []))
         return self._stream
 
@@ -458,8 +485,11 @@ class ClipTrackExtractor(ClipTracker):
         offs = np.array([0, n], np.int32)
         want_images = self.keep_frames
         frames_dev = self._frames_dev
+        # update_background = False: the model stays as init_clip seeded it (cliptrackextractor.py:169)
         res = eng.track_batch(frames_dev, offs, meta, want_labels=want_images, want_filtered=True,
-                              want_background=True)
+                              want_background=True, flags=0 if self.update_background else TRACK_FREEZE_BACKGROUND)
+        self._meta = meta
+        self._final_state = eng.get_background(0)
         assoc = None
         if self.do_tracking and not clip.from_metadata:
             params = make_track_params(
@@ -500,6 +530,8 @@ class ClipTrackExtractor(ClipTracker):
         last = info[proc[-1]] if proc else None
         self.background_alg = WeightedBackgroundView(np.asarray(background, dtype=np.float64),
                                                      None if last is None else last["background_average"], weight_add)
+        if self._final_state is not None and b == 0 and n == len(self._frames or ()):
+            self.background_alg.background_weight = self._final_state[1]
         if assoc is not None:
             assoc.check()
             clip.tracks = [Track.from_device(clip, rec, regs, self.tracker_version, self.config)
@@ -507,6 +539,18 @@ class ClipTrackExtractor(ClipTracker):
             last_frame = clip.current_frame
             clip.active_tracks = set(t for t in clip.tracks if t.end_frame == last_frame and self._still_tracking(t))
             self.apply_track_filtering(clip)
+
+    def close(self):
+        """Release the device handle of an open frame-by-frame stream."""
+        if self._stream is not None:
+            self._stream["engine"].close()
+            self._stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def _still_tracking(track):

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,9 @@ struct cpx_handle {
   int stream_frames = -1;
   int stream_assoc_frames = -1;
   bool stream_filt_state = false;
+  int last_B = 0;  // clips of the last track call: whose state cpx_get_background / CPX_TRACK_KEEP_BACKGROUND refer to
+  struct StagedBackground { std::vector<uint16_t> bg, kcnt; double average; };
+  std::map<int, StagedBackground> staged_bg;  // cpx_set_background: applied by the next track call
   int cnn_math = CPX_CNN_MATH_BF16X3;    // cpx_set_cnn_math / CPX_CNN_MATH
   bool fuse_shortcut = true;             // CPX_CNN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts as launches of their own
   void* bf3_scratch = nullptr;           // split weights of a cpx_conv2d call that brought none
@@ -319,8 +323,10 @@ size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames) {
 static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
                      const cpx_frame_meta* meta, int B, int n_prev, cpx_component* comps_dev,
                      cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
-                     float* background_dev) {
+                     float* background_dev, int flags) {
   CPX_ENTER(h);
+  if (flags & ~(CPX_TRACK_KEEP_BACKGROUND | CPX_TRACK_FREEZE_ON_FFC | CPX_TRACK_FREEZE_BACKGROUND))
+    return fail(h, CPX_ERR_INVALID, "track: unknown flag");
   const cpx_config& c = h->cfg;
   Schedule sc;
   int rc = build_schedule(h, clip_offsets, meta, B, &sc);
@@ -335,7 +341,18 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   const WsLayout l = ws_layout(c, B, need_filt);
   if (resume && (l.total > h->ws_bytes || need_filt != h->stream_filt_state))
     return fail(h, CPX_ERR_INVALID, "cpx_track_frame: the stream's workspace is gone (optional outputs changed?)");
+  const bool keep = !resume && (flags & CPX_TRACK_KEEP_BACKGROUND);
+  if (keep) {
+    // every clip needs a state to continue from: the previous call's (same layout) or a staged one
+    const bool have_prev = h->ws && h->last_B == B && need_filt == h->stream_filt_state && l.total <= h->ws_bytes;
+    for (int b = 0; b < B && !have_prev; ++b)
+      if (!h->staged_bg.count(b))
+        return fail(h, CPX_ERR_INVALID, "CPX_TRACK_KEEP_BACKGROUND: no background state for a clip (previous call had another batch size, and nothing staged)");
+  }
+  for (const auto& kv : h->staged_bg)
+    if (kv.first >= B) return fail(h, CPX_ERR_INVALID, "cpx_set_background: staged clip index outside the batch");
   h->stream_filt_state = need_filt;
+  h->last_B = B;
   if (l.total > h->ws_bytes) {
     if (h->ws) hipFree(h->ws);
     h->ws = nullptr;
@@ -354,6 +371,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.edge = c.edge_pixels;
   a.window = c.window;
   a.cap_out = c.max_components;
+  a.flags = flags;
   a.background_thresh = c.background_thresh;
   a.weight_add = c.weight_add;
   a.frames = frames_dev;
@@ -381,7 +399,25 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   // frames that are never processed (background frames) get frame_number = -1
   const int f_new = resume ? n_prev : 0;
   CPX_HIP(h, hipMemsetAsync(info_dev + f_new, 0xFF, (size_t)(total - f_new) * sizeof(cpx_frame_info), h->stream));
-  if (!resume) cpx::launch_init(a, B, h->stream);
+  if (!resume) cpx::launch_init(a, B, keep ? 1 : 0, h->stream);
+  if (!h->staged_bg.empty()) {
+    // staged states replace the seeding (or, in the middle of a stream, the model an external owner changed): both
+    // ping-pong slots, the weight counters, the average
+    const size_t P = (size_t)c.width * c.height;
+    for (const auto& kv : h->staged_bg) {
+      const int b = kv.first;
+      const auto& sb = kv.second;
+      for (int slot = 0; slot < 2; ++slot)
+        CPX_HIP(h, hipMemcpyAsync(a.bg + ((size_t)b * 2 + slot) * P, sb.bg.data(), P * sizeof(uint16_t),
+                                  hipMemcpyHostToDevice, h->stream));
+      CPX_HIP(h, hipMemcpyAsync(a.kcnt + (size_t)b * P, sb.kcnt.data(), P * sizeof(uint16_t), hipMemcpyHostToDevice,
+                                h->stream));
+      CPX_HIP(h, hipMemcpyAsync(&a.cstate[b].bg_average, &sb.average, sizeof(double), hipMemcpyHostToDevice, h->stream));
+      CPX_HIP(h, hipMemcpyAsync(a.bgavg + b, &sb.average, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    CPX_HIP(h, hipStreamSynchronize(h->stream));  // the staged vectors die here
+    h->staged_bg.clear();
+  }
   CPX_HIP(h, hipEventRecord(h->ev0, h->stream));
   // (with the internal ping-pong of filtered frames the back half of step t would read what the front half of
   // step t+1 overwrites: split only when the caller keeps every filtered frame)
@@ -416,21 +452,28 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   return CPX_OK;
 }
 
-int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
-                    const cpx_frame_meta* meta, int B, cpx_component* comps_dev,
-                    cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
-                    float* background_dev) {
+int cpx_track_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
+                       const cpx_frame_meta* meta, int B, cpx_component* comps_dev, cpx_frame_info* info_dev,
+                       int32_t* labels_dev, float* filtered_dev, float* background_dev, int flags) {
   if (!h) return CPX_ERR_INVALID;
   if (!frames_dev || !clip_offsets || !meta || B <= 0 || !comps_dev || !info_dev)
     return fail(h, CPX_ERR_INVALID, "cpx_track_batch: null argument");
   h->stream_frames = -1;  // the workspace is re-initialised: an open stream ends here
   return track_run(h, frames_dev, clip_offsets, meta, B, -1, comps_dev, info_dev, labels_dev, filtered_dev,
-                   background_dev);
+                   background_dev, flags);
 }
 
-int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_meta* meta, int n_prev, int n_frames,
-                    cpx_component* comps_dev, cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
+                    const cpx_frame_meta* meta, int B, cpx_component* comps_dev,
+                    cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
                     float* background_dev) {
+  return cpx_track_batch_ex(h, frames_dev, clip_offsets, meta, B, comps_dev, info_dev, labels_dev, filtered_dev,
+                            background_dev, 0);
+}
+
+int cpx_track_frame_ex(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_meta* meta, int n_prev, int n_frames,
+                       cpx_component* comps_dev, cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                       float* background_dev, int flags) {
   if (!h) return CPX_ERR_INVALID;
   if (!frames_dev || !meta || !comps_dev || !info_dev || n_prev < 0 || n_frames <= n_prev)
     return fail(h, CPX_ERR_INVALID, "cpx_track_frame: bad argument");
@@ -440,9 +483,103 @@ int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_m
   h->stream_frames = -1;
   if (n_prev == 0) h->stream_assoc_frames = -1;  // a new clip: its association starts fresh
   const int rc = track_run(h, frames_dev, offs, meta, 1, n_prev, comps_dev, info_dev, labels_dev, filtered_dev,
-                           background_dev);
+                           background_dev, flags);
   if (rc == CPX_OK) h->stream_frames = n_frames;
   return rc;
+}
+
+int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_meta* meta, int n_prev, int n_frames,
+                    cpx_component* comps_dev, cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                    float* background_dev) {
+  return cpx_track_frame_ex(h, frames_dev, meta, n_prev, n_frames, comps_dev, info_dev, labels_dev, filtered_dev,
+                            background_dev, 0);
+}
+
+int cpx_set_background(cpx_handle* h, int clip, const float* background, const double* weights, double average) {
+  if (!h) return CPX_ERR_INVALID;
+  if (clip < 0 || !background) return fail(h, CPX_ERR_INVALID, "cpx_set_background: bad argument");
+  const cpx_config& c = h->cfg;
+  const int W = c.width, H = c.height, e = c.edge_pixels;
+  const size_t P = (size_t)W * H;
+  cpx_handle::StagedBackground sb;
+  sb.bg.resize(P);
+  sb.kcnt.assign(P, 0);
+  sb.average = average;
+  for (size_t p = 0; p < P; ++p) {
+    const float v = background[p];
+    if (!(v >= 0.0f && v <= 65535.0f) || v != std::floor(v))
+      return fail(h, CPX_ERR_UNSUPPORTED, "cpx_set_background: the background must be integer-valued in [0, 65535]");
+    sb.bg[p] = (uint16_t)v;
+  }
+  if (weights) {
+    // a weight is the k-fold float64 accumulation of weight_add (motiondetector.py:218-222): find k, exactly
+    std::vector<double> wt(h->wtab_len);
+    double w = 0.0;
+    for (int k = 0; k < h->wtab_len; ++k) {
+      wt[k] = w;
+      w = w + c.weight_add;
+    }
+    const int iw = W - 2 * e, ih = H - 2 * e;
+    for (int y = 0; y < ih; ++y)
+      for (int x = 0; x < iw; ++x) {
+        const double wv = weights[(size_t)y * iw + x];
+        long k = c.weight_add > 0 ? std::lround(wv / c.weight_add) : 0;
+        bool ok = false;
+        for (long kk = std::max(0L, k - 1); kk <= k + 1 && kk < h->wtab_len; ++kk)
+          if (wt[kk] == wv) {
+            k = kk;
+            ok = true;
+            break;
+          }
+        if (!ok) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_set_background: a weight is not an accumulation of weight_add");
+        sb.kcnt[(size_t)(y + e) * W + (x + e)] = (uint16_t)k;
+      }
+  }
+  h->staged_bg[clip] = std::move(sb);
+  return CPX_OK;
+}
+
+int cpx_get_background(cpx_handle* h, int clip, float* background, double* weights, double* average) {
+  if (!h) return CPX_ERR_INVALID;
+  if (clip < 0 || clip >= h->last_B || !h->ws) return fail(h, CPX_ERR_INVALID, "cpx_get_background: no such clip in the last track call");
+  CPX_ENTER(h);
+  const cpx_config& c = h->cfg;
+  const int W = c.width, H = c.height, e = c.edge_pixels;
+  const size_t P = (size_t)W * H;
+  const WsLayout l = ws_layout(c, h->last_B, h->stream_filt_state);
+  char* base = (char*)h->ws;
+  CPX_HIP(h, hipStreamSynchronize(h->stream));
+  cpx::ClipState st;
+  CPX_HIP(h, hipMemcpy(&st, base + l.cstate + (size_t)clip * sizeof(cpx::ClipState), sizeof(st), hipMemcpyDeviceToHost));
+  if (average) *average = st.bg_average;
+  if (background) {
+    std::vector<uint16_t> bg(P);
+    CPX_HIP(h, hipMemcpy(bg.data(), base + l.bg + ((size_t)clip * 2 + (st.n_done & 1)) * P * sizeof(uint16_t),
+                         P * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {  // the interior is authoritative, edges replicate it (motiondetector.py:239-244)
+        const int cy = std::min(std::max(y, e), H - 1 - e), cx = std::min(std::max(x, e), W - 1 - e);
+        background[(size_t)y * W + x] = (float)bg[(size_t)cy * W + cx];
+      }
+  }
+  if (weights) {
+    std::vector<uint16_t> kc(P);
+    CPX_HIP(h, hipMemcpy(kc.data(), base + l.kcnt + (size_t)clip * P * sizeof(uint16_t), P * sizeof(uint16_t),
+                         hipMemcpyDeviceToHost));
+    std::vector<double> wt(h->wtab_len);
+    double w = 0.0;
+    for (int k = 0; k < h->wtab_len; ++k) {
+      wt[k] = w;
+      w = w + c.weight_add;
+    }
+    const int iw = W - 2 * e, ih = H - 2 * e;
+    for (int y = 0; y < ih; ++y)
+      for (int x = 0; x < iw; ++x) {
+        const int k = kc[(size_t)(y + e) * W + (x + e)];
+        weights[(size_t)y * iw + x] = k < h->wtab_len ? wt[k] : (double)k * c.weight_add;
+      }
+  }
+  return CPX_OK;
 }
 
 static int assoc_run(cpx_handle* h, const cpx_track_params* params, const int32_t* clip_offsets,
@@ -563,12 +700,21 @@ static cpx::ClassifyArgs classify_args(const cpx_handle* h) {
 int cpx_track_limits_batch(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
                            const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev,
                            const int32_t* track_offsets_dev, int n_tracks, cpx_track_limits* limits_dev) {
+  return cpx_track_limits_batch_ex(h, frames_dev, filtered_dev, info_dev, refs_dev, track_offsets_dev, n_tracks,
+                                   limits_dev, 0);
+}
+
+int cpx_track_limits_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
+                              const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev,
+                              const int32_t* track_offsets_dev, int n_tracks, cpx_track_limits* limits_dev, int flags) {
   if (!h) return CPX_ERR_INVALID;
-  if (!frames_dev || !filtered_dev || !info_dev || !refs_dev || !track_offsets_dev || !limits_dev || n_tracks < 0)
-    return fail(h, CPX_ERR_INVALID, "cpx_track_limits_batch: null argument");
+  if (!frames_dev || !filtered_dev || !info_dev || !refs_dev || !track_offsets_dev || !limits_dev || n_tracks < 0 ||
+      (flags & ~CPX_LIMITS_POST_PROCESS))
+    return fail(h, CPX_ERR_INVALID, "cpx_track_limits_batch: bad argument");
   if (n_tracks == 0) return CPX_OK;
   CPX_ENTER(h);
   cpx::ClassifyArgs a = classify_args(h);
+  a.limits_flags = flags;
   a.frames = frames_dev;
   a.filtered = filtered_dev;
   a.info = info_dev;

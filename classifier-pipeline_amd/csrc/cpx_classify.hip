@@ -85,11 +85,15 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
   const int r0 = a.track_offsets[t], r1 = a.track_offsets[t + 1];
   const int W = a.W, P = a.W * a.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float mn = INFINITY, mx = 0.0f;  // max_diff starts at 0, min_diff at None (interpreter.py:316-317)
+  // get_limits: max_diff starts at 0, min_diff at None (interpreter.py:316-317).  post_process_file: the first sampled
+  // crop's own min / max start both, and only sampled frames count (clipclassifier.py:484-497)
+  const bool post = (a.limits_flags & CPX_LIMITS_POST_PROCESS) != 0;
+  float mn = INFINITY, mx = post ? -INFINITY : 0.0f;
   int clip0 = 1;
   for (int r = r0 + wave; r < r1; r += LW) {
     const cpx_region_ref ref = a.refs[r];
     if (ref.width <= 0 || ref.height <= 0) continue;
+    if (post && !ref.in_segment) continue;
     const int n = ref.width * ref.height;
     const float* F = a.filtered + (size_t)ref.frame * P;
     for (int k = lane; k < n; k += 64) {
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
       mn = fminf(mn, v);
       mx = fmaxf(mx, v);
     }
-    if (ref.in_segment && clip0) {
+    if (ref.in_segment && clip0 && !post) {
       // np.median(float32(crop) - median) <= 0  <=>  a + b <= M, with a <= b the two middle order statistics of
       // the crop (a == b for an odd count) and M = 2 * median (an integer: the frame median is k/2).  One counting
       // pass decides it: with t = floor(M / 2) and c = #{v <= t},
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
     }
     o.filt_min = fmn;
     o.filt_max = fmx;
-    o.clip_at_zero = c0;
-    o.reserved = 0;
+    o.clip_at_zero = post ? 1 : c0;  // preprocess_frame's default clip_thermals_at_zero = True (preprocess.py:68)
+    o.flags = a.limits_flags;
     a.limits[t] = o;
   }
 }
@@ -208,6 +212,10 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
     pmin = fminf(pmin, (float)T[(q.y + yy) * W + q.x + (k - yy * rw)]);
   }
   pmin = block_min(pmin, sc);
+  // post_process_file hands preprocess_frame a crop that already had the frame median subtracted (float32, exact:
+  // integer pixels, half-integer median), with sub_median = False: the subtraction happens BEFORE the resize
+  const bool pre = (lim.flags & CPX_LIMITS_POST_PROCESS) != 0;
+  if (pre) pmin = __fsub_rn(pmin, median);
   // ---- both channels: bilinear sample (two float32 passes), paste, per-pixel ops ----
   const int n = fs * fs;
   const int ty = q.tile / sq, tx = q.tile - ty * sq;
@@ -226,7 +234,11 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
       lin_coord(ry, dh, rh, &y0, &y1, &ay);
       const float bx = __fsub_rn(1.0f, ax), by = __fsub_rn(1.0f, ay);
       const int r0 = (q.y + y0) * W + q.x, r1 = (q.y + y1) * W + q.x;
-      const float t00 = (float)T[r0 + x0], t01 = (float)T[r0 + x1], t10 = (float)T[r1 + x0], t11 = (float)T[r1 + x1];
+      float t00 = (float)T[r0 + x0], t01 = (float)T[r0 + x1], t10 = (float)T[r1 + x0], t11 = (float)T[r1 + x1];
+      if (pre) {
+        t00 = __fsub_rn(t00, median); t01 = __fsub_rn(t01, median);
+        t10 = __fsub_rn(t10, median); t11 = __fsub_rn(t11, median);
+      }
       const float th0 = __fadd_rn(__fmul_rn(t00, bx), __fmul_rn(t01, ax));
       const float th1 = __fadd_rn(__fmul_rn(t10, bx), __fmul_rn(t11, ax));
       tv = __fadd_rn(__fmul_rn(th0, by), __fmul_rn(th1, ay));
@@ -236,14 +248,20 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
       fv = __fadd_rn(__fmul_rn(fh0, by), __fmul_rn(fh1, ay));
     }
     // thermal: -= median ; clip at 0 (preprocess.py:87-90)
-    tv = __fsub_rn(tv, median);
+    if (!pre) tv = __fsub_rn(tv, median);
     if (lim.clip_at_zero && tv < 0.0f) tv = 0.0f;
     s_t[k] = tv;
     tmn = fminf(tmn, tv);
     tmx = fmaxf(tmx, tv);
     // filtered: normalize(min, max of the track, new_max = 255) (preprocess.py:92-98)
     float fo;
-    if (lim.filt_max == lim.filt_min) fo = (lim.filt_max == 0.0f) ? 0.0f : __fdiv_rn(fv, lim.filt_max);
+    if (pre) {
+      // post_process_file's limits are np.float64 scalars (np.min / np.max of a float64 crop), which promote
+      // new_max * (float32(data) - min) / (max - min) to float64 (imageprocessing.py:168); one rounding at the end
+      const double dmin = (double)lim.filt_min, dmax = (double)lim.filt_max;
+      if (dmax == dmin) fo = (dmax == 0.0) ? 0.0f : (float)((double)fv / dmax);
+      else fo = (float)(255.0 * ((double)fv - dmin) / (dmax - dmin));
+    } else if (lim.filt_max == lim.filt_min) fo = (lim.filt_max == 0.0f) ? 0.0f : __fdiv_rn(fv, lim.filt_max);
     else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, lim.filt_min)), fspan);
     out[((size_t)yy * OW + xx) * 2 + 1] = fo;
   }

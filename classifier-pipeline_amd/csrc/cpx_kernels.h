@@ -34,7 +34,7 @@ struct ClipState {
   double bg_average;  // WeightedBackground.average (float until the first change, then integral)
   int prev_fmin, prev_fmax;  // min / max of the previous frame's filtered image
   int has_prev;
-  int pad;
+  int n_done;  // frames processed since the state was seeded: the final background sits in ping-pong slot n_done & 1
 };
 
 // block-reduced scalars of the streaming pass
@@ -59,6 +59,7 @@ struct FrameCarry {  // front half -> (NLM ->) back half of a split frame step; 
 struct TrackArgs {
   // geometry / config
   int W, H, edge, window, cap_out;
+  int flags;                // CPX_TRACK_* of the call (include/cpx.h)
   double background_thresh;
   double weight_add;
   // inputs
@@ -147,6 +148,7 @@ size_t assoc_score_bytes();
 struct ClassifyArgs {
   int W, H, crop_x, crop_y, crop_w, crop_h;
   int frame_size, square_width;
+  int limits_flags;  // CPX_LIMITS_* (cpx_limits_kernel)
   const uint16_t* frames;
   const float* filtered;
   const FrameInfo* info;
@@ -277,7 +279,7 @@ size_t track_lds_bytes(int W, int H);
 int track_max_pixels();
 int track_lds_components();
 int frame_kernel_attr_setup();
-void launch_init(const TrackArgs& a, int B, hipStream_t s);
+void launch_init(const TrackArgs& a, int B, int keep, hipStream_t s);
 void launch_frame(const TrackArgs& a, int B, int t, int mode, hipStream_t s);
 void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s);
 size_t nlm_lds_bytes(int W, int H);

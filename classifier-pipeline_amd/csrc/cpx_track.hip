@@ -126,13 +126,32 @@ __device__ __forceinline__ void uf_union(u32* parent, u32 a, u32 b) {
 // init: WeightedBackground.__init__ + first process_frame
 // (motiondetector.py:178-211; cliptrackextractor.py:129-139)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a) {
+__global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a, int keep) {
   const int b = blockIdx.x;
   const int W = a.W, H = a.H, P = W * H, e = a.edge;
   const uint16_t* F = a.frames + (size_t)a.clip_first[b] * P;
   uint16_t* bg0 = a.bg + (size_t)b * 2 * P;
   u32* ws = a.wsum + (size_t)b * P;
   uint16_t* kc = a.kcnt + (size_t)b * P;
+  if (keep) {
+    // CPX_TRACK_KEEP_BACKGROUND: background, weights and average continue from where the previous run left them
+    // (its last frame wrote ping-pong slot n_done & 1); only the 45-frame window starts again
+    const ClipState old = a.cstate[b];
+    const int src = old.n_done & 1;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      bg0[(1 - src) * P + p] = bg0[src * P + p];
+      ws[p] = 0;
+    }
+    if (threadIdx.x == 0) {
+      ClipState st = old;
+      st.prev_fmin = st.prev_fmax = 0;
+      st.has_prev = 0;
+      st.n_done = 0;
+      a.cstate[b] = st;
+      if (a.bgavg) a.bgavg[b] = st.bg_average;
+    }
+    return;
+  }
   u64 s = 0;
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     int y = p / W, x = p - y * W;
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a) {
     st.prev_fmin = 0;
     st.prev_fmax = 0;
     st.has_prev = 0;
-    st.pad = 0;
+    st.n_done = 0;
     a.cstate[b] = st;
     if (a.bgavg) a.bgavg[b] = st.bg_average;
   }
@@ -218,6 +237,10 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     filt_prev = a.filt_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
   }
   ClipState cs = a.cstate[b];
+  // who owns the background (include/cpx.h, CPX_TRACK_*): a frozen frame leaves background, weights and average as
+  // they are (post_process_file skips FFC-affected frames, clipclassifier.py:510-511; update_background = False)
+  const bool freeze = (a.flags & CPX_TRACK_FREEZE_BACKGROUND) ||
+                      ((a.flags & CPX_TRACK_FREEZE_ON_FFC) && a.proc_ffc[pbase + t] != 0);
   // split steps: the front half of step t+1 may run while the back half of step t has not yet written the clip
   // state, so the background average travels front -> front (a.bgavg) and front -> back (the carry)
   const int slot = t & 1;
@@ -412,8 +435,9 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
             else if (dd < ap - 1e-5) keep = false;
             else keep = (double)bgv[j] < (double)f - a.wtab[kv[j]];
           }
+          if (freeze) keep = true;
           const int nv = keep ? bgv[j] : f;
-          kv[j] = keep ? kv[j] + 1 : 0;
+          if (!freeze) kv[j] = keep ? kv[j] + 1 : 0;
           r.changed |= (u32)(nv != bgv[j]);
           r.sumbg += (u32)nv;
           nb[j] = nv;
@@ -870,7 +894,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     ns.prev_fmin = R.fmin;
     ns.prev_fmax = R.fmax;
     ns.has_prev = 1;
-    ns.pad = 0;
+    ns.n_done = t + 1;
     fi.background_average = ns.bg_average;
     fi.background_changed = (int)R.changed;
     fi.reserved = 0;
@@ -1077,8 +1101,7 @@ void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
 __global__ __launch_bounds__(256) void cpx_export_background_kernel(TrackArgs a, float* out) {
   const int b = blockIdx.x;
   const int W = a.W, H = a.H, P = W * H, e = a.edge;
-  const int nproc = a.proc_off[b + 1] - a.proc_off[b];
-  const uint16_t* bg = a.bg + ((size_t)b * 2 + (nproc & 1)) * P;
+  const uint16_t* bg = a.bg + ((size_t)b * 2 + (a.cstate[b].n_done & 1)) * P;
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     int y = p / W, x = p - y * W;
     out[(size_t)b * P + p] = (float)bg[clampi(y, e, H - 1 - e) * W + clampi(x, e, W - 1 - e)];
@@ -1090,7 +1113,9 @@ size_t track_lds_bytes(int W, int H) {
   return 3 * P + 2 * (size_t)H * RW * 8 + (size_t)9 * CAP * 4 + (NWAVE + 1) * sizeof(Red1) + NWAVE * 2 * sizeof(int) + 16 + 3 * NWAVE * sizeof(u32) + 16;
 }
 
-void launch_init(const TrackArgs& a, int B, hipStream_t s) { hipLaunchKernelGGL(cpx_init_kernel, dim3(B), dim3(256), 0, s, a); }
+void launch_init(const TrackArgs& a, int B, int keep, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_init_kernel, dim3(B), dim3(256), 0, s, a, keep);
+}
 void launch_frame(const TrackArgs& a, int B, int t, int mode, hipStream_t s) {
   hipLaunchKernelGGL(cpx_frame_kernel, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t, mode);
 }

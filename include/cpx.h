@@ -157,6 +157,39 @@ int cpx_synchronize(cpx_handle* h);
 int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_meta* meta, int n_prev, int n_frames,
                     cpx_component* comps_dev, cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
                     float* background_dev);
+
+/* ---- who owns the background ---------------------------------------------------------------------------
+ * The reference's process_frame never updates the background itself (track/cliptrackextractor.py:198-247): its
+ * callers do -- _track_clip with the 45-frame mean after every frame (:169-176), post_process_file the same but
+ * not on FFC-affected frames and CONTINUING from the state tracking left (classify/clipclassifier.py:418-431,
+ * 460-512), the Pi loop not at all: there the motion detector owns the WeightedBackground and hands it in
+ * (start_tracking(..., background_alg=), update_background=False; piclassifier/piclassifier.py:322-333,423-431).
+ * flags of the _ex calls:
+ *   CPX_TRACK_KEEP_BACKGROUND    do not seed background / weights / average from the clips' first frames: every clip
+ *                                continues from the state the previous track call on this handle left for the clip of
+ *                                the same index (same B), or from what cpx_set_background staged for it; the 45-frame
+ *                                window starts empty as always
+ *   CPX_TRACK_FREEZE_ON_FFC      FFC-affected frames leave background, weights and average untouched
+ *   CPX_TRACK_FREEZE_BACKGROUND  no frame updates them (update_background = False: the caller owns the model)
+ * cpx_track_batch / cpx_track_frame are the _ex calls with flags 0. */
+#define CPX_TRACK_KEEP_BACKGROUND 1
+#define CPX_TRACK_FREEZE_ON_FFC 2
+#define CPX_TRACK_FREEZE_BACKGROUND 4
+int cpx_track_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
+                       const cpx_frame_meta* meta, int B, cpx_component* comps_dev, cpx_frame_info* info_dev,
+                       int32_t* labels_dev, float* filtered_dev, float* background_dev, int flags);
+int cpx_track_frame_ex(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_meta* meta, int n_prev, int n_frames,
+                       cpx_component* comps_dev, cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
+                       float* background_dev, int flags);
+/* The state of a WeightedBackground (piclassifier/motiondetector.py:178-248) as HOST arrays: background float
+ * [H, W] (integer-valued, edges replicated), weights double [H - 2 edge, W - 2 edge] or NULL (all zero), average.
+ * cpx_set_background stages it for clip `clip` of the NEXT track call on the handle (batch, or frame of a stream --
+ * also in the middle of a stream: an externally owned model that changed between two frames); it replaces whatever
+ * seeding that call would do for the clip.  Values the device state cannot hold exactly (a non-integer or > 65535
+ * background, a weight that is not an accumulation of the handle's weight_add) -> CPX_ERR_UNSUPPORTED.
+ * cpx_get_background reads the state the last track call left for clip `clip` (synchronises the handle's stream). */
+int cpx_set_background(cpx_handle* h, int clip, const float* background, const double* weights, double average);
+int cpx_get_background(cpx_handle* h, int clip, float* background, double* weights, double* average);
 int cpx_associate_frame(cpx_handle* h, const cpx_track_params* params, const cpx_frame_meta* meta, int n_prev,
                         int n_frames, const cpx_component* comps_dev, const cpx_frame_info* info_dev,
                         cpx_region* pool_dev, cpx_track_record* tracks_dev, int32_t* n_tracks_dev,
@@ -270,8 +303,15 @@ typedef struct cpx_region_ref { /* one non-blank region of a track */
 typedef struct cpx_track_limits { /* per track */
   float filt_min, filt_max;       /* filtered_norm_limits: min / max over the track's region crops, max >= 0 */
   int32_t clip_at_zero;           /* clip_thermals_at_zero (interpreter.py:372-399) */
-  int32_t reserved;
+  int32_t flags;                  /* CPX_LIMITS_* the limits were computed with: cpx_crop_tile follows them */
 } cpx_track_limits;
+
+/* cpx_track_limits_batch_ex flags.  CPX_LIMITS_POST_PROCESS = ClipClassifier.post_process_file
+ * (classify/clipclassifier.py:472-497,525-538): limits over the frames the segments use only (refs with in_segment,
+ * no floor of 0 on the maximum), thermals always clipped at zero, and the frame median subtracted from the thermal
+ * crop BEFORE it is resized (preprocess_frame(cropped=True, sub_median=False) on a crop that already had it
+ * subtracted) instead of after. */
+#define CPX_LIMITS_POST_PROCESS 1
 
 typedef struct cpx_crop_req { /* one tile = one frame of one segment */
   int32_t frame;
@@ -298,6 +338,9 @@ int cpx_plan_segments(cpx_handle* h, const cpx_filter_params* params, const int3
 int cpx_track_limits_batch(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
                            const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev,
                            const int32_t* track_offsets_dev, int n_tracks, cpx_track_limits* limits_dev);
+int cpx_track_limits_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const float* filtered_dev,
+                              const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev,
+                              const int32_t* track_offsets_dev, int n_tracks, cpx_track_limits* limits_dev, int flags);
 
 /* out_dev: float [n_samples, square_width*frame_size, square_width*frame_size, 2] (NHWC; thermal, filtered).
  * Every tile of every sample must be covered by exactly one request. */
