@@ -77,7 +77,22 @@ class WRResNetParams(C.Structure):  # struct cpx_wrresnet_params
                 ("block", (WRResNetBlock * 8) * 3),
                 ("shortcut_w", C.c_void_p * 3), ("shortcut_b", C.c_void_p * 3),
                 ("final_scale", C.c_void_p), ("final_shift", C.c_void_p),
-                ("dense_w", C.c_void_p), ("dense_b", C.c_void_p)]
+                ("dense_w", C.c_void_p), ("dense_b", C.c_void_p),
+                ("n_hidden", C.c_int32), ("activation", C.c_int32), ("hidden_sizes", C.c_int32 * 4),
+                ("hidden_w", C.c_void_p * 4), ("hidden_b", C.c_void_p * 4)]
+
+
+class HeadDesc(C.Structure):  # struct cpx_head_desc
+    _fields_ = [("N", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("L", C.c_int32),
+                ("n_hidden", C.c_int32), ("activation", C.c_int32), ("hidden_sizes", C.c_int32 * 4),
+                ("in_dev", C.c_void_p), ("bn_scale_dev", C.c_void_p), ("bn_shift_dev", C.c_void_p),
+                ("hidden_w_dev", C.c_void_p * 4), ("hidden_b_dev", C.c_void_p * 4),
+                ("dense_w_dev", C.c_void_p), ("dense_b_dev", C.c_void_p),
+                ("logits_dev", C.c_void_p), ("probs_dev", C.c_void_p)]
+
+
+assert C.sizeof(WRResNetParams) == 1560
+HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1
 
 
 EXPORTS = [
@@ -89,6 +104,7 @@ EXPORTS = [
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
+    "cpx_cnn_head_ex",
 ]
 
 # flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
@@ -138,6 +154,8 @@ def load():
     lib.cpx_conv2d.restype = C.c_int
     lib.cpx_cnn_head.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.cpx_cnn_head.restype = C.c_int
+    lib.cpx_cnn_head_ex.argtypes = [vp, C.POINTER(HeadDesc)]
+    lib.cpx_cnn_head_ex.restype = C.c_int
     lib.cpx_finalize_tracks.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp]
     lib.cpx_finalize_tracks.restype = C.c_int
     lib.cpx_plan_segments.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]

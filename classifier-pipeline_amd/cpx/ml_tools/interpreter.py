@@ -43,8 +43,13 @@ class Interpreter:
         self.mapped_labels = metadata.get("mapped_labels")
         self.label_probabilities = metadata.get("label_probabilities")
         self.thresholds = metadata.get("thresholds")
-        if self.params.model_name not in ("wr-resnet", "efficientnetv2b3"):
-            raise NotImplementedError("only models without an input preprocess_fn (wr-resnet) are supported")
+        # what this build's network covers (ml_tools/kerasmodel.py:259-350): the WR-ResNet base, optional hidden
+        # dense layers, sigmoid or softmax output -- anything else must fail here, not classify with a wrong head
+        if self.params.model_name != "wr-resnet":
+            raise NotImplementedError("model_name %r: only wr-resnet models are supported" % self.params.model_name)
+        if self.params.get("mvm") or self.params.get("mvm_forest") or self.params.get("lstm") or \
+                self.params.get("model_merge"):
+            raise NotImplementedError("models with track-feature (mvm), LSTM or merged heads are not supported")
         self.preprocess_fn = None
 
     def shape(self):
@@ -202,10 +207,22 @@ class WRResNetInterpreter(Interpreter):
     def load_model(self):
         from .wrresnet import load_weights
 
+        from .wrresnet import head_of
+
         self._weights = load_weights(self.model_file.with_suffix(".npz"))
         n = self._weights["prediction/bias"].shape[0]
         if n != len(self.labels):
             raise ValueError("model has %d outputs but %d labels" % (n, len(self.labels)))
+        hidden, act = head_of(self._weights)
+        sizes = [int(self._weights[h + "/bias"].shape[0]) for h in hidden]
+        want_sizes = [int(v) for v in (self.params.dense_sizes or [])]
+        want_act = "sigmoid" if self.params.get("multi_label", True) else "softmax"
+        explicit = "prediction/activation" in self._weights
+        if sizes != want_sizes or (explicit and act != want_act):
+            raise ValueError("weights head (dense %s, %s) does not match the sidecar (dense_sizes %s, multi_label %s)"
+                             % (sizes, act, want_sizes, self.params.get("multi_label", True)))
+        if not explicit:
+            self._weights["prediction/activation"] = want_act  # an archive without the record: the sidecar decides
 
     def _network(self, engine):
         from .wrresnet import WRResNetDevice

@@ -9,7 +9,10 @@ be converted 1:1:
   dense 'prediction/kernel' [C, n_labels], 'prediction/bias'
 Layer names: conv1_1; res{s}b{d}_branch2a|2b, bn{s}b{d}_branch2a|2b for stage s = 2..4, block
 d = 0..2; shortcut{s} (the 1x1 projection of each stage's first block); final_bn; prediction.
-"""
+Head variants of KerasModel.build_model (kerasmodel.py:337-345): hidden Dense(relu) layers
+'dense_{i}/kernel|bias' (hyperparams.dense_sizes, in order), and the output activation in
+'prediction/activation' ("sigmoid", the multi_label default, or "softmax").
+tools/keras_to_npz.py writes this layout from an exported Keras model."""
 
 import ctypes as C
 import json
@@ -45,12 +48,22 @@ def layer_plan(n_labels):
     return plan
 
 
-def random_weights(n_labels=17, seed=0):
+def random_weights(n_labels=17, seed=0, dense_sizes=None, activation="sigmoid"):
     """Seeded Glorot-uniform kernels, small random biases and BatchNorm statistics (no checkpoint
     can be downloaded here): same architecture, same layouts."""
     rng = np.random.default_rng(seed)
     w = {}
-    for name, kind, shape in layer_plan(n_labels):
+    plan = layer_plan(n_labels)
+    if dense_sizes:
+        head = plan.pop()
+        width = head[2][0]
+        for i, size in enumerate(dense_sizes):
+            plan.append(("dense_%d" % i, "dense", (width, int(size))))
+            width = int(size)
+        plan.append(("prediction", "dense", (width, n_labels)))
+    if activation != "sigmoid":
+        w["prediction/activation"] = activation
+    for name, kind, shape in plan:
         if kind == "conv":
             kh, kw, ci, co = shape
             fan_in, fan_out = kh * kw * ci, kh * kw * co // GROUPS
@@ -82,7 +95,18 @@ def save_model(path_base, weights, labels, hyperparams=None, thresholds=None, mo
 
 def load_weights(path):
     z = np.load(str(path))
-    return {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+    return {k: (str(z[k]) if z[k].dtype.kind in "US" else np.asarray(z[k], dtype=np.float32)) for k in z.files}
+
+
+def head_of(weights):
+    """-> (hidden layer names in order, activation) of a weights dict."""
+    hidden = []
+    while "dense_%d/kernel" % len(hidden) in weights:
+        hidden.append("dense_%d" % len(hidden))
+    act = str(weights.get("prediction/activation", "sigmoid"))
+    if act not in ("sigmoid", "softmax"):
+        raise NotImplementedError("output activation %r" % act)
+    return hidden, act
 
 
 def bn_affine(w, name):
@@ -146,6 +170,12 @@ class WRResNetDevice:
         self.p["final/scale"], self.p["final/shift"] = up(fs), up(fh)
         self.p["dense/w"] = up(w["prediction/kernel"])
         self.p["dense/b"] = up(w["prediction/bias"])
+        self.hidden, self.activation = head_of(w)
+        if len(self.hidden) > 4:
+            raise NotImplementedError("more than 4 hidden dense layers")
+        for name in self.hidden:
+            self.p[name + "/w"] = up(w[name + "/kernel"])
+            self.p[name + "/b"] = up(w[name + "/bias"])
         self._bufs = {}
         self._cnn = None
         self._create_native()
@@ -167,6 +197,11 @@ class WRResNetDevice:
             prm.shortcut_w[si], prm.shortcut_b[si] = ptr("sc%d/w" % stage), ptr("sc%d/b" % stage)
         prm.final_scale, prm.final_shift = ptr("final/scale"), ptr("final/shift")
         prm.dense_w, prm.dense_b = ptr("dense/w"), ptr("dense/b")
+        prm.n_hidden = len(self.hidden)
+        prm.activation = 1 if self.activation == "softmax" else 0
+        for k, name in enumerate(self.hidden):
+            prm.hidden_sizes[k] = int(self.p[name + "/b"].shape[0])
+            prm.hidden_w[k], prm.hidden_b[k] = ptr(name + "/w"), ptr(name + "/b")
         out = C.c_void_p()
         rc = self.lib.cpx_cnn_create(self.eng.h, C.byref(prm), C.byref(out))
         if rc != 0:
@@ -265,11 +300,20 @@ class WRResNetDevice:
                 cur, H, W, c_in = nxt, Ho, Wo, f
         logits = t.empty((N, self.n_labels), dtype=t.float32, device=self.eng.device)
         probs = t.empty((N, self.n_labels), dtype=t.float32, device=self.eng.device) if want_probs else None
-        rc = self.lib.cpx_cnn_head(self.eng.h, C.c_void_p(cur.data_ptr()), N, H * W, c_in,
-                                   C.c_void_p(self.p["final/scale"].data_ptr()), C.c_void_p(self.p["final/shift"].data_ptr()),
-                                   C.c_void_p(self.p["dense/w"].data_ptr()), C.c_void_p(self.p["dense/b"].data_ptr()),
-                                   self.n_labels, C.c_void_p(logits.data_ptr()),
-                                   C.c_void_p(probs.data_ptr()) if probs is not None else None)
+        from .._lib import HeadDesc
+
+        hd = HeadDesc()
+        hd.N, hd.HW, hd.C, hd.L = N, H * W, c_in, self.n_labels
+        hd.n_hidden, hd.activation = len(self.hidden), 1 if self.activation == "softmax" else 0
+        for k, name in enumerate(self.hidden):
+            hd.hidden_sizes[k] = int(self.p[name + "/b"].shape[0])
+            hd.hidden_w_dev[k], hd.hidden_b_dev[k] = self.p[name + "/w"].data_ptr(), self.p[name + "/b"].data_ptr()
+        hd.in_dev = cur.data_ptr()
+        hd.bn_scale_dev, hd.bn_shift_dev = self.p["final/scale"].data_ptr(), self.p["final/shift"].data_ptr()
+        hd.dense_w_dev, hd.dense_b_dev = self.p["dense/w"].data_ptr(), self.p["dense/b"].data_ptr()
+        hd.logits_dev = logits.data_ptr()
+        hd.probs_dev = probs.data_ptr() if probs is not None else None
+        rc = self.lib.cpx_cnn_head_ex(self.eng.h, C.byref(hd))
         if rc != 0:
             raise CpxError(rc, self.eng._err())
         self.eng.synchronize()

@@ -855,21 +855,42 @@ int cpx_set_cnn_math(cpx_handle* h, int mode) {
 }
 int cpx_get_cnn_math(const cpx_handle* h) { return h ? h->cnn_math : CPX_ERR_INVALID; }
 
+int cpx_cnn_head_ex(cpx_handle* h, const cpx_head_desc* d) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!d || !d->in_dev || !d->bn_scale_dev || !d->bn_shift_dev || !d->dense_w_dev || !d->dense_b_dev || !d->logits_dev ||
+      d->N < 1 || d->HW < 1 || d->C < 1 || d->L < 1 || d->C > 8192 || d->L > 8192 || d->n_hidden < 0 ||
+      d->n_hidden > CPX_HEAD_MAX_HIDDEN || (d->activation != CPX_HEAD_SIGMOID && d->activation != CPX_HEAD_SOFTMAX))
+    return fail(h, CPX_ERR_INVALID, "cpx_cnn_head: bad argument");
+  CPX_ENTER(h);
+  cpx::HeadArgs a{};
+  a.N = d->N; a.HW = d->HW; a.C = d->C; a.L = d->L;
+  a.n_hidden = d->n_hidden;
+  a.activation = d->activation;
+  for (int k = 0; k < d->n_hidden; ++k) {
+    if (!d->hidden_w_dev[k] || !d->hidden_b_dev[k] || d->hidden_sizes[k] < 1 || d->hidden_sizes[k] > 2048)
+      return fail(h, CPX_ERR_INVALID, "cpx_cnn_head: bad hidden layer");
+    a.hidden_sizes[k] = d->hidden_sizes[k];
+    a.hidden_w[k] = d->hidden_w_dev[k];
+    a.hidden_b[k] = d->hidden_b_dev[k];
+  }
+  a.in = d->in_dev; a.bn_scale = d->bn_scale_dev; a.bn_shift = d->bn_shift_dev;
+  a.dense_w = d->dense_w_dev; a.dense_b = d->dense_b_dev; a.logits = d->logits_dev; a.probs = d->probs_dev;
+  cpx::launch_head(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
                  float* logits_dev, float* probs_dev) {
   if (!h) return CPX_ERR_INVALID;
-  if (!in_dev || !bn_scale_dev || !bn_shift_dev || !dense_w_dev || !dense_b_dev || !logits_dev || N < 1 || HW < 1 ||
-      C < 1 || L < 1 || C > 8192)
-    return fail(h, CPX_ERR_INVALID, "cpx_cnn_head: bad argument");
-  CPX_ENTER(h);
-  cpx::HeadArgs a{};
-  a.N = N; a.HW = HW; a.C = C; a.L = L;
-  a.in = in_dev; a.bn_scale = bn_scale_dev; a.bn_shift = bn_shift_dev;
-  a.dense_w = dense_w_dev; a.dense_b = dense_b_dev; a.logits = logits_dev; a.probs = probs_dev;
-  cpx::launch_head(a, h->stream);
-  CPX_HIP(h, hipGetLastError());
-  return CPX_OK;
+  cpx_head_desc d{};
+  d.N = N; d.HW = HW; d.C = C; d.L = L;
+  d.n_hidden = 0;
+  d.activation = CPX_HEAD_SIGMOID;
+  d.in_dev = in_dev; d.bn_scale_dev = bn_scale_dev; d.bn_shift_dev = bn_shift_dev;
+  d.dense_w_dev = dense_w_dev; d.dense_b_dev = dense_b_dev; d.logits_dev = logits_dev; d.probs_dev = probs_dev;
+  return cpx_cnn_head_ex(h, &d);
 }
 
 static int final_common(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
@@ -1105,7 +1126,7 @@ static void cnn_free(cpx_cnn* c) {
   delete c;
 }
 
-static_assert(sizeof(cpx_wrresnet_block) == 56 && sizeof(cpx_wrresnet_params) == 1472,
+static_assert(sizeof(cpx_wrresnet_block) == 56 && sizeof(cpx_wrresnet_params) == 1560,
               "cpx_wrresnet_params layout is part of the ABI");
 
 int cpx_cnn_create(cpx_handle* h, const cpx_wrresnet_params* params, cpx_cnn** out) {
@@ -1114,8 +1135,13 @@ int cpx_cnn_create(cpx_handle* h, const cpx_wrresnet_params* params, cpx_cnn** o
   *out = nullptr;
   const cpx_wrresnet_params& p = *params;
   if (p.n_labels < 1 || p.blocks_per_stage < 1 || p.blocks_per_stage > CPX_WRRESNET_MAX_BLOCKS || p.groups < 1 ||
-      p.in_channels < 1 || !p.conv1_w || !p.final_scale || !p.final_shift || !p.dense_w || !p.dense_b)
+      p.in_channels < 1 || !p.conv1_w || !p.final_scale || !p.final_shift || !p.dense_w || !p.dense_b ||
+      p.n_hidden < 0 || p.n_hidden > CPX_HEAD_MAX_HIDDEN ||
+      (p.activation != CPX_HEAD_SIGMOID && p.activation != CPX_HEAD_SOFTMAX))
     return fail(h, CPX_ERR_INVALID, "cpx_cnn_create: bad network description");
+  for (int k = 0; k < p.n_hidden; ++k)
+    if (!p.hidden_w[k] || !p.hidden_b[k] || p.hidden_sizes[k] < 1 || p.hidden_sizes[k] > 2048)
+      return fail(h, CPX_ERR_INVALID, "cpx_cnn_create: bad hidden dense layer");
   for (int st = 0; st < 3; ++st) {
     if (!p.shortcut_w[st]) return fail(h, CPX_ERR_INVALID, "cpx_cnn_create: missing shortcut weights");
     for (int d = 0; d < p.blocks_per_stage; ++d) {
@@ -1264,8 +1290,18 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
       c_in = f;
     }
   }
-  return cpx_cnn_head(h, cur, N, hh * ww, c_in, p.final_scale, p.final_shift, p.dense_w, p.dense_b, p.n_labels,
-                      logits_dev, probs_dev);
+  cpx_head_desc hd{};
+  hd.N = N; hd.HW = hh * ww; hd.C = c_in; hd.L = p.n_labels;
+  hd.n_hidden = p.n_hidden;
+  hd.activation = p.activation;
+  for (int k = 0; k < p.n_hidden; ++k) {
+    hd.hidden_sizes[k] = p.hidden_sizes[k];
+    hd.hidden_w_dev[k] = p.hidden_w[k];
+    hd.hidden_b_dev[k] = p.hidden_b[k];
+  }
+  hd.in_dev = cur; hd.bn_scale_dev = p.final_scale; hd.bn_shift_dev = p.final_shift;
+  hd.dense_w_dev = p.dense_w; hd.dense_b_dev = p.dense_b; hd.logits_dev = logits_dev; hd.probs_dev = probs_dev;
+  return cpx_cnn_head_ex(h, &hd);
 }
 
 // ---- IR background model ---------------------------------------------------------------------------------------------

@@ -332,22 +332,54 @@ __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
 }
 
 // final_bn -> ReLU -> GlobalAveragePooling2D -> Dense(n_labels) (+ sigmoid): one workgroup per sample
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_feat[];  // [C]
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a, int vmax) {
+  extern __shared__ __attribute__((aligned(16))) float s_feat[];  // [vmax] x 2: layer input / output, ping-pong
+  __shared__ float s_red[2];
   const int n = blockIdx.x;
   const float* x = a.in + (size_t)n * a.HW * a.C;
+  float* cur = s_feat;
+  float* nxt = s_feat + vmax;
   for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
     const float sc = a.bn_scale[c], sh = a.bn_shift[c];
     float s = 0.0f;
     for (int p = 0; p < a.HW; ++p) s += fmaxf(x[(size_t)p * a.C + c] * sc + sh, 0.0f);
-    s_feat[c] = s / (float)a.HW;
+    cur[c] = s / (float)a.HW;
   }
   __syncthreads();
+  int width = a.C;
+  for (int k = 0; k < a.n_hidden; ++k) {  // Dense(size, relu) layers of hyperparams.dense_sizes (kerasmodel.py:337-339)
+    const int out = a.hidden_sizes[k];
+    const float* w = a.hidden_w[k];
+    for (int j = threadIdx.x; j < out; j += blockDim.x) {
+      float s = a.hidden_b[k][j];
+      for (int c = 0; c < width; ++c) s += cur[c] * w[(size_t)c * out + j];
+      nxt[j] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+    width = out;
+  }
   for (int l = threadIdx.x; l < a.L; l += blockDim.x) {
     float s = a.dense_b[l];
-    for (int c = 0; c < a.C; ++c) s += s_feat[c] * a.dense_w[(size_t)c * a.L + l];
+    for (int c = 0; c < width; ++c) s += cur[c] * a.dense_w[(size_t)c * a.L + l];
     a.logits[(size_t)n * a.L + l] = s;
-    if (a.probs) a.probs[(size_t)n * a.L + l] = 1.0f / (1.0f + expf(-s));
+    nxt[l] = s;
+    if (a.probs && a.activation == CPX_HEAD_SIGMOID) a.probs[(size_t)n * a.L + l] = 1.0f / (1.0f + expf(-s));
+  }
+  if (a.probs && a.activation == CPX_HEAD_SOFTMAX) {  // softmax as Keras evaluates it: exp(x - max) / sum
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = nxt[0];
+      for (int l = 1; l < a.L; ++l) m = fmaxf(m, nxt[l]);
+      float z = 0.0f;
+      for (int l = 0; l < a.L; ++l) z += expf(nxt[l] - m);
+      s_red[0] = m;
+      s_red[1] = z;
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < a.L; l += blockDim.x) a.probs[(size_t)n * a.L + l] = expf(nxt[l] - s_red[0]) / s_red[1];
   }
 }
 
@@ -400,7 +432,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_head(const HeadArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(head_kernel, dim3(a.N), dim3(256), (size_t)a.C * sizeof(float), s, a);
+  int vmax = a.C > a.L ? a.C : a.L;
+  for (int k = 0; k < a.n_hidden; ++k) vmax = a.hidden_sizes[k] > vmax ? a.hidden_sizes[k] : vmax;
+  hipLaunchKernelGGL(head_kernel, dim3(a.N), dim3(256), (size_t)2 * vmax * sizeof(float), s, a, vmax);
 }
 
 }  // namespace cpx

@@ -190,9 +190,13 @@ struct ConvArgs {
 };
 struct HeadArgs {
   int N, HW, C, L;
+  int n_hidden, activation;  // hidden Dense(relu) layers; CPX_HEAD_SIGMOID / CPX_HEAD_SOFTMAX
+  int hidden_sizes[CPX_HEAD_MAX_HIDDEN];
   const float* in;
   const float* bn_scale;
   const float* bn_shift;
+  const float* hidden_w[CPX_HEAD_MAX_HIDDEN];
+  const float* hidden_b[CPX_HEAD_MAX_HIDDEN];
   const float* dense_w;
   const float* dense_b;
   float* logits;

@@ -444,6 +444,27 @@ int cpx_get_cnn_math(const cpx_handle* h);
 int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
                  float* logits_dev, float* probs_dev);
+/* The head as KerasModel.build_model can make it (ml_tools/kerasmodel.py:308-350): after the pooling up to
+ * CPX_HEAD_MAX_HIDDEN Dense(size, relu) layers (hyperparams.dense_sizes), then Dense(n_labels) with sigmoid
+ * (multi_label, the default) or softmax.  hidden weights [in][out] row-major, sizes <= 2048. */
+#define CPX_HEAD_MAX_HIDDEN 4
+#define CPX_HEAD_SIGMOID 0
+#define CPX_HEAD_SOFTMAX 1
+typedef struct cpx_head_desc {
+  int32_t N, HW, C, L;
+  int32_t n_hidden, activation;
+  int32_t hidden_sizes[CPX_HEAD_MAX_HIDDEN];
+  const float* in_dev;        /* [N, HW, C] */
+  const float* bn_scale_dev;  /* final BatchNorm folded to scale / shift, [C] */
+  const float* bn_shift_dev;
+  const float* hidden_w_dev[CPX_HEAD_MAX_HIDDEN];
+  const float* hidden_b_dev[CPX_HEAD_MAX_HIDDEN];
+  const float* dense_w_dev;   /* [last hidden size or C][L] */
+  const float* dense_b_dev;
+  float* logits_dev;          /* [N, L] pre-activation */
+  float* probs_dev;           /* [N, L] or NULL */
+} cpx_head_desc;
+int cpx_cnn_head_ex(cpx_handle* h, const cpx_head_desc* desc);
 
 /* ---- whole-network forward ------------------------------------------------------------------------------
  * KerasModel.predict (ml_tools/kerasmodel.py:856-859) for the WR-ResNet classifier in one call: conv1, three
@@ -474,8 +495,13 @@ typedef struct cpx_wrresnet_params {
   const float* shortcut_b[3];
   const float* final_scale;
   const float* final_shift;
-  const float* dense_w;   /* [filters[3]][n_labels] */
+  const float* dense_w;   /* [filters[3] or the last hidden size][n_labels] */
   const float* dense_b;
+  /* head variants (ml_tools/kerasmodel.py:337-345): hidden Dense(relu) layers, sigmoid or softmax output */
+  int32_t n_hidden, activation; /* CPX_HEAD_SIGMOID / CPX_HEAD_SOFTMAX */
+  int32_t hidden_sizes[CPX_HEAD_MAX_HIDDEN];
+  const float* hidden_w[CPX_HEAD_MAX_HIDDEN];
+  const float* hidden_b[CPX_HEAD_MAX_HIDDEN];
 } cpx_wrresnet_params;
 
 /* A network belongs to the handle it was created on: cpx_destroy(h) frees the networks still alive, after which

@@ -58,8 +58,14 @@ def forward(w, x_nhwc, return_features=False):
                 x = F.relu(y + shortcut)
         x = F.relu(_bn(x, w, "final_bn"))
         feat = x.mean(dim=(2, 3))
-        logits = feat @ torch.from_numpy(w["prediction/kernel"]) + torch.from_numpy(w["prediction/bias"])
-        probs = torch.sigmoid(logits)
+        # head variants (kerasmodel.py:337-345): Dense(relu) layers of dense_sizes, then sigmoid or softmax
+        h, k = feat, 0
+        while "dense_%d/kernel" % k in w:
+            h = F.relu(h @ torch.from_numpy(w["dense_%d/kernel" % k]) + torch.from_numpy(w["dense_%d/bias" % k]))
+            k += 1
+        logits = h @ torch.from_numpy(w["prediction/kernel"]) + torch.from_numpy(w["prediction/bias"])
+        probs = torch.softmax(logits, dim=1) if str(w.get("prediction/activation", "sigmoid")) == "softmax" \
+            else torch.sigmoid(logits)
         if return_features:
             return logits.numpy(), probs.numpy(), feat.numpy()
         return logits.numpy(), probs.numpy()

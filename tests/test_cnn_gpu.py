@@ -209,3 +209,30 @@ def test_fused_shortcut_equals_separate_launch(engine, monkeypatch):
     assert 0.0 < diff <= 1e-5 or diff == 0.0, diff
     want, _ = co.forward(w, x)
     assert float(np.abs(fused.cpu().numpy() - want).max()) <= LOGIT_ATOL
+
+
+@pytest.mark.parametrize("dense_sizes,activation", [((48, 24), "softmax"), ((40,), "sigmoid"), (None, "softmax")])
+def test_head_variants_match_oracle(dense_sizes, activation):
+    """KerasModel.build_model's head variants (kerasmodel.py:337-345): hidden Dense(relu) layers of dense_sizes and
+    a softmax output, through cpx_cnn_forward and the layer-wise cpx_cnn_head_ex."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.engine import TrackEngine
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(21)
+    x = rng.uniform(0, 255, size=(3, 160, 160, 2)).astype(np.float32)
+    w = co.calibrate_bn(wr.random_weights(17, seed=5, dense_sizes=dense_sizes, activation=activation), x[:2])
+    want_logits, want_probs = co.forward(w, x)
+    eng = TrackEngine()
+    net = wr.WRResNetDevice(eng, w, 17)
+    xd = torch.from_numpy(x).to(eng.device)
+    for fwd in (net.forward, net.forward_layerwise):
+        logits, probs = fwd(xd)
+        assert float(np.abs(logits.cpu().numpy() - want_logits).max()) <= 2e-4
+        assert float(np.abs(probs.cpu().numpy() - want_probs).max()) <= 1e-5
+    if activation == "softmax":
+        assert np.allclose(probs.cpu().numpy().sum(axis=1), 1.0, atol=1e-5)
+    net.close()
+    eng.close()
