@@ -170,11 +170,18 @@ def _oracle_warm(_):
 STAGE2_CONV_FLOPS_PER_SAMPLE = 2.0 * 160 * 160 * 64 * 32 * 9
 
 
+PMC_SUMMARY = "profiles/r01_e2e_pmc.json"
+PMC_NOTE = ("NOT measured in this run: bytes per unit from the committed rocprofv3 PMC summary %s (separate FETCH_SIZE / "
+            "WRITE_SIZE passes over `python3 bench.py --clips 1024`, FETCH_SIZE doubled per the gfx950 note of "
+            "MI355X_MICROARCH.md), rescaled to this run's units per launch" % PMC_SUMMARY)
+
+
 def pmc_traffic(section, units_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r01_e2e_pmc.json: separate FETCH_SIZE /
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (PMC_SUMMARY: separate FETCH_SIZE /
     WRITE_SIZE passes over this same bench command, gfx950 correction applied), scaled to this run's launch size.
-    PMC collection needs the profiler, so it cannot be taken live here; None when the summary is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e2e_pmc.json")
+    PMC collection needs the profiler, so it cannot be taken live here; None when the summary is absent.
+    The bench line says so in roofline.traffic_source."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), *PMC_SUMMARY.split("/"))
     try:
         with open(path) as fh:
             sec = json.load(fh)[section]
@@ -448,6 +455,8 @@ def main():
                          "network of group k (measured: no gain on MI355X, see DESIGN.md section 6; 1 = off)")
     ap.add_argument("--denoise", action="store_true",
                     help="tracking.denoise = true (the reference's default: NLM kernel between normalise and blur)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the default_config (denoise on) and fs64 measurements taken after the timed region")
     ap.add_argument("--config4", action="store_true",
                     help="BASELINE configs[3]: --clips (default 10000) seeded clips of 90-540 frames, LPT-sharded over the "
                          "ranks, processed in device batches, all_gather of [clip_id, track_id, 17 x f32] (strong scaling)")
@@ -590,11 +599,21 @@ def main():
         clips_per_launch = B * T * args.steps / max(kernel_launches, 1)
         bytes_per_launch = (ALGO_BYTES_PER_FRAME - (LABEL_BYTES_PER_FRAME if e2e else 0)) * clips_per_launch
         hbm = bytes_per_launch / avg_launch_s / 1e9
+        # what the kernel really moves: the background is kept as uint16 (a floor of a mean of uint16 frames), so its
+        # read + write cost 76,800 B per frame instead of the 153,600 B of SURVEY's int32 count
+        moved_per_launch = bytes_per_launch - 76800 * clips_per_launch
+        hbm_moved = moved_per_launch / avg_launch_s / 1e9
         track_roof = {"kernel": "cpx_frame_kernel", "bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
                       "traffic": pmc_traffic("frame_kernel_e2e" if e2e else "frame_kernel_track", clips_per_launch),
+                      "traffic_source": PMC_NOTE,
                       "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": kernel_launches,
-                      "algorithmic_bytes_per_launch": bytes_per_launch}
+                      "algorithmic_bytes_per_launch": bytes_per_launch,
+                      "moved_bytes_per_launch": moved_per_launch, "achieved_moved": round(hbm_moved, 1),
+                      "frac_moved": round(hbm_moved / HBM_PEAK_GBS, 4),
+                      "frac_moved_of_achievable": round(hbm_moved / 6290.0, 4),
+                      "note": "frac counts SURVEY section 8(d)'s bytes (int32 background); frac_moved the bytes the "
+                              "kernel moves (uint16 background); 6.29 TB/s is the measured float4-copy rate of the guide"}
         line = {
             "metric": "CPTV frames/s end-to-end (track+classify) at 160x120" if e2e else
                       "CPTV frames/s (track stage only: background + region-label HIP kernels) at 160x120",
@@ -661,6 +680,7 @@ def main():
                                     "bound": "mfma", "achieved": round(tf, 2), "peak": peak,
                                     "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                                     "traffic": traffic,
+                                    "traffic_source": PMC_NOTE if traffic is not None else None,
                                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
                                     "algorithmic_flops_per_launch": fl / n,
                                     "algorithmic_bytes_per_launch": algo_bytes,
@@ -683,6 +703,58 @@ def main():
             line["config"]["outputs"] = "components + label image + filtered image"
             line["roofline"] = track_roof
         line.update(cpu)  # measured before the GPU was initialised (top of main)
+        if e2e and world == 1 and not args.no_extras and not args.denoise and args.frame_size == 32:
+            # ---- the same run, after the timed region: the two configurations the headline does not cover ----
+            # (a) the reference's DEFAULT tracking configuration (denoise = true: NLM between normalise and blur,
+            #     SURVEY F7), track stage over a slice of the resident clips
+            # (b) frame size 64 (BASELINE north_star's 64 x 64 crops): end to end over a slice
+            net.close()
+            nb = min(B, 512)
+            o2 = offs[: nb + 1]
+            deng = TrackEngine(width=W, height=H, model="lepton3", device=local_rank, max_components=64,
+                               max_frames=max(T, 45), denoise=True)
+            deng.track_batch(frames, o2, meta[: nb * T], outputs=outputs)       # warm-up
+            deng.synchronize()
+            t1 = time.perf_counter()
+            deng.track_batch(frames, o2, meta[: nb * T], outputs=outputs)
+            deng.synchronize()
+            dt = time.perf_counter() - t1
+            kms, kn = deng.last_kernel_timing()
+            deng.close()
+            # the same slice without denoise: the difference is the NLM kernel
+            eng.track_batch(frames, o2, meta[: nb * T], outputs=outputs)
+            eng.synchronize()
+            t1 = time.perf_counter()
+            eng.track_batch(frames, o2, meta[: nb * T], outputs=outputs)
+            eng.synchronize()
+            dt0 = time.perf_counter() - t1
+            line["default_config"] = {"what": "track stage with tracking.denoise = true (the reference's default, SURVEY F7) "
+                                              "over %d of the resident clips x %d frames, same run" % (nb, T),
+                                      "frames_per_s": round(nb * T / dt, 1),
+                                      "nlm_us_per_frame": round((dt - dt0) / (nb * T) * 1e6, 3),
+                                      "frames_per_s_denoise_off_same_slice": round(nb * T / dt0, 1)}
+            nb64 = min(B, 1024)
+            net64 = wr.WRResNetDevice(eng, weights, N_LABELS)
+            pipe64 = BatchPipeline(eng, net64, n_labels=N_LABELS, fp_index=4, cnn_chunk=512, frame_size=64)
+            o64 = offs[: nb64 + 1]
+            pipe64.run(frames, o64, meta[: nb64 * T], outputs=outputs)          # warm-up (arena for 320 x 320 inputs)
+            eng.conv_timing(True)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            r64 = pipe64.run(frames, o64, meta[: nb64 * T], outputs=outputs)
+            torch.cuda.synchronize(device)
+            dt64 = time.perf_counter() - t1
+            c64 = eng.conv_timing()
+            eng.conv_timing(False)
+            f64 = {"what": "end to end at frame_size 64 (320 x 320 network input) over %d of the resident clips, same run" % nb64,
+                   "frames_per_s": round(nb64 * T / dt64, 1), "classified_segments": int(r64.n_samples)}
+            k2, k3 = 32 * 10000 + 32 * 10 + 1, 64 * 10000 + 64 * 10 + 1
+            if k2 in c64 and k3 in c64 and c64[k2][1] + c64[k3][1] > 0:
+                tf64 = (c64[k2][2] + c64[k3][2]) / ((c64[k2][1] + c64[k3][1]) / 1e3) / 1e12
+                f64["stage2_3_conv_tflops"] = round(tf64, 2)
+                f64["stage2_3_conv_frac"] = round(tf64 / (MFMA_BF16_PEAK_TFLOPS / BF16X3_PRODUCTS), 4)
+            line["fs64"] = f64
+            net64.close()
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

@@ -64,13 +64,13 @@ class ClipClassifier:
             for name in sorted(files):
                 if os.path.splitext(name)[1] == ".cptv":
                     todo.append(os.path.join(folder, name))
+        rank, world, local_rank = rank_world()  # under torchrun: this rank's share of the files, on its own GPU
+        todo = shard_files(todo, rank, world)
         if not track:
             for filename in todo:
                 self.process_file(filename, cache=cache, reuse_frames=reuse_frames, track=False,
-                                  calculate_thumbnails=calculate_thumbnails)
+                                  calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
             return
-        rank, world, local_rank = rank_world()  # under torchrun: this rank's share of the files, on its own GPU
-        todo = shard_files(todo, rank, world)
         for i in range(0, len(todo), self.batch_files):
             self.process_files(todo[i:i + self.batch_files], reuse_frames=reuse_frames,
                                calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
@@ -90,8 +90,9 @@ class ClipClassifier:
                                               calculate_thumbnails=calculate_thumbnails))
         return results
 
-    def process_file(self, filename, cache=None, reuse_frames=None, track=False, calculate_thumbnails=False):
-        """Track (optionally) and classify one recording; writes / returns the metadata (clipclassifier.py:145-250)."""
+    def process_file(self, filename, cache=None, reuse_frames=None, track=False, calculate_thumbnails=False, device=0):
+        """Track (optionally) and classify one recording; writes / returns the metadata (clipclassifier.py:145-250).
+        cache (the reference's HDF5 frame cache) has no meaning here -- frames stay on the device -- and is ignored."""
         filename = str(filename)
         _, ext = os.path.splitext(filename)
         if ext != ".cptv":
@@ -103,8 +104,12 @@ class ClipClassifier:
         meta_file = os.path.splitext(filename)[0] + ".txt"
         meta_data = None
         if track:
-            clip, track_extractor, meta_data = extract_file(filename, self.config, False, to_stdout=False,
-                                                            save_meta=False)
+            if device:
+                clip, track_extractor, meta_data = extract_files([filename], self.config, False, to_stdout=False,
+                                                                 save_meta=False, device=device)[0]
+            else:
+                clip, track_extractor, meta_data = extract_file(filename, self.config, False, to_stdout=False,
+                                                                save_meta=False)
         else:
             if not os.path.exists(meta_file):
                 logging.error("File %s not found.", meta_file)
@@ -112,7 +117,7 @@ class ClipClassifier:
             meta_data = load_clip_metadata(meta_file)
             track_extractor = ClipTrackExtractor(self.config.tracking, self.config.use_opt_flow, False,
                                                  do_tracking=False, calculate_filtered=True,
-                                                 verbose=self.config.verbose)
+                                                 verbose=self.config.verbose, device=device)
             clip = Clip(track_extractor.config, filename)
             clip.load_metadata(meta_data)
             track_extractor.parse_clip(clip)

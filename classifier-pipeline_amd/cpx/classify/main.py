@@ -1,5 +1,6 @@
 """Command line of the classifier (reference src/classify/main.py:14-142):
-    python -m cpx.classify.main [-c CONFIG] [-m MODEL_FILE] [--track] [--reuse-prediction-frames] [-o] source
+    python -m cpx.classify.main [-c CONFIG] [-m MODEL_FILE] [--track] [--reuse-prediction-frames]
+                                [--calculate-thumbnails] [--post-process] [-o] source
 """
 
 import argparse
@@ -19,11 +20,16 @@ def parse_args(argv=None):
     ap.add_argument("-T", "--timestamps", action="store_true", help="Emit log timestamps")
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("--track", action="store_true", help="Track the clip before classifying")
-    ap.add_argument("--calculate-thumbnails", action="store_true", help="(not supported) thumbnails")
+    ap.add_argument("--calculate-thumbnails", action="store_true",
+                    help="Calculate thumbnail regions for each track and save in metadata")
     ap.add_argument("--reuse-prediction-frames", action="count",
                     help="Use the prediction frames saved in the metadata")
     ap.add_argument("-o", "--meta-to-stdout", action="store_true", help="Print metadata to stdout instead of a file")
-    ap.add_argument("--cache", default=None, help="(not supported) cache frames to disk")
+    ap.add_argument("--post-process", action="store_true",
+                    help="run ClipClassifier.post_process_file on the source file (what the reference's classify.py "
+                         "currently calls, classify/main.py:129) instead of process()")
+    ap.add_argument("--cache", default=None,
+                    help="accepted for compatibility: the reference's disk cache of frames; frames stay on the device here")
     return ap.parse_args(argv)
 
 
@@ -41,7 +47,11 @@ def main(argv=None):
     model = None
     if args.model_file:
         model = ModelConfig.load({"id": 1, "model_file": args.model_file, "name": args.model_file})
-    ClipClassifier(config, model).process(args.source, reuse_frames=args.reuse_prediction_frames, track=args.track)
+    if args.post_process:
+        ClipClassifier(config, model).post_process_file(args.source, None)
+        return
+    ClipClassifier(config, model).process(args.source, cache=args.cache, reuse_frames=args.reuse_prediction_frames,
+                                          track=args.track, calculate_thumbnails=args.calculate_thumbnails)
 
 
 if __name__ == "__main__":
