@@ -59,8 +59,9 @@ struct TileDiv {
 };
 __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)n * m) >> 42); }
 
+// (two workgroups per CU is what the LDS footprint allows: the register budget is pinned to match)
 template <int NTN, int S, int NB, int TW, int CT>
-__global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+__global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT / 128, CT / 128))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3;
   constexpr int WSETS = CT / 256;    // sets of four waves
   constexpr int NTM = NB / WSETS;    // bands per wave
@@ -95,29 +96,53 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
   const int nchunks = cin_g / KC;
   // weight image: [g][chunk][3][9][2][cout_g] entries
   const uint4* wg = wimg + (size_t)g * nchunks * 54 * cout_g + (size_t)ns * COGW;
+  // a tile whose patch lies inside the image needs no padding tests (uniform)
+  const bool interior = iy0 >= 0 && iy0 + PH <= a.H && ix0 >= 0 && ix0 + PW <= a.W;
 
+  // The residual goes INTO the accumulators before the first product (possible when the output is not scaled):
+  // its loads are in flight under the whole tile instead of stalling the epilogue, and they cost no registers.
+  // out = (res + sum of products) + bias: the same terms as before in another float32 order.
+  const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;
   f32x16 acc[NTM][NTN];
+  if (res_in_acc) {
+    const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout + (g * cout_g + ns * COGW + (lane & 31));
 #pragma unroll
-  for (int m = 0; m < NTM; ++m)
+    for (int m = 0; m < NTM; ++m)
 #pragma unroll
-    for (int t = 0; t < NTN; ++t)
+      for (int t = 0; t < NTN; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel of the wave tile this register holds
+          const int oy = min(oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, a.Ho - 1), ox = min(ox0 + i % TW, a.Wo - 1);
+          acc[m][t][r] = res_n[(oy * a.Wo + ox) * a.Cout + t * 32];
+        }
+  } else {
+#pragma unroll
+    for (int m = 0; m < NTM; ++m)
+#pragma unroll
+      for (int t = 0; t < NTN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+  }
 
   const int pi = lane & 31, kh = lane >> 5;
   const int prow = WR * wave + pi / TW, pcol = pi % TW;
   const int a_base = kh * NPX + ((prow + wset * TB) * S) * PW + pcol * S;  // band m of this wave: wset + m * WSETS
   const int b_base = kh * COGW + (lane & 31);
 
-  // staging: an item is (patch pixel, k half) = 8 channels = two float4 loads; a thread keeps its k half
-  constexpr int NITEM = NPX * 2;
+  // staging: an item is ONE 16-byte piece (4 channels) of a patch pixel's 16-channel chunk, and the four pieces of a
+  // pixel sit on adjacent lanes, so that a wave's load instruction covers whole contiguous 64-byte runs -- a quarter
+  // of the cache-line requests the (pixel, 8 channels)-per-lane form made, which kept the vector-memory issue busy for
+  // thousands of cycles per chunk (in-kernel s_memtime stamps, scratch/patches/README.md).  BatchNorm + ReLU + split
+  // happen here; a piece fills the low or high 8 bytes of an LDS entry.
+  constexpr int NITEM = NPX * 4;
   constexpr int NP = (NITEM + CT - 1) / CT;
   constexpr int NW = 54 * COGW;               // uint4 entries of a weight chunk
   constexpr int NWI = (NW + CT - 1) / CT;
-  const int my_h = tid & 1;
-  float4 pre_p[NP][2];
+  const int my_q = tid & 3;                   // float32 input: CT is a multiple of 4, so a thread keeps its quarter
+  u32x4 pre_p[NP];
   u32x4 pre_w[NWI];
-  float4 psc[2], psh[2];
+  f32x4 psc, psh;
   for (int cc = -1; cc < nchunks; ++cc) {
     if (cc >= 0) {
       // ---- registers -> LDS: BatchNorm + ReLU prologue, split into bf16 planes ----
@@ -125,30 +150,35 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
       for (int i = 0; i < NP; ++i) {
         const int item = tid + i * CT;
         if (item < NITEM) {
-          const int px = item >> 1;
-          const int py = px / PW, pxx = px - py * PW;
-          const int iy = iy0 + py, ix = ix0 + pxx;
-          float v[8] = {pre_p[i][0].x, pre_p[i][0].y, pre_p[i][0].z, pre_p[i][0].w,
-                        pre_p[i][1].x, pre_p[i][1].y, pre_p[i][1].z, pre_p[i][1].w};
-          // the loads are unconditional (clamped addresses, below): padding pixels are zeroed here, after the
-          // prologue, exactly as TensorFlow pads the activated tensor
-          const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-          if (a.in_scale) {
-            const float sc[8] = {psc[0].x, psc[0].y, psc[0].z, psc[0].w, psc[1].x, psc[1].y, psc[1].z, psc[1].w};
-            const float sh[8] = {psh[0].x, psh[0].y, psh[0].z, psh[0].w, psh[1].x, psh[1].y, psh[1].z, psh[1].w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j], 0.0f);
+          const int px = item >> 2;
+          bool inside = true;
+          if (!interior) {
+            const int py = px / PW, pxx = px - py * PW;
+            const int iy = iy0 + py, ix = ix0 + pxx;
+            // the loads are unconditional (clamped addresses, below): padding pixels are zeroed here, after the
+            // prologue, exactly as TensorFlow pads the activated tensor
+            inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
           }
+          {
+            float v[4];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
-          uint4 p0, p1, p2;
-          split_pair(v[0], v[1], p0.x, p1.x, p2.x);
-          split_pair(v[2], v[3], p0.y, p1.y, p2.y);
-          split_pair(v[4], v[5], p0.z, p1.z, p2.z);
-          split_pair(v[6], v[7], p0.w, p1.w, p2.w);
-          s_patch[(0 * 2 + my_h) * NPX + px] = p0;
-          s_patch[(1 * 2 + my_h) * NPX + px] = p1;
-          s_patch[(2 * 2 + my_h) * NPX + px] = p2;
+            for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);
+            if (a.in_scale) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] * psc[j] + psh[j], 0.0f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
+            unsigned q0[2], q1[2], q2[2];
+            split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
+            split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
+            // channels 4 q .. 4 q + 3 of the chunk: entry of k half q >> 1, its low or high 8 bytes
+            uint2* sp2 = reinterpret_cast<uint2*>(s_patch);
+            const int e2 = ((my_q >> 1) * NPX + px) * 2 + (my_q & 1);
+            sp2[(0 * 2 * NPX) * 2 + e2] = make_uint2(q0[0], q0[1]);
+            sp2[(1 * 2 * NPX) * 2 + e2] = make_uint2(q1[0], q1[1]);
+            sp2[(2 * 2 * NPX) * 2 + e2] = make_uint2(q2[0], q2[1]);
+          }
         }
       }
 #pragma unroll
@@ -161,27 +191,24 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
     if (cc + 1 < nchunks) {
       // ---- global -> registers for the next chunk (in flight during the MFMA loop below) ----
       const int cn = (cc + 1) * KC;
-      {  // without a prologue any readable 32 bytes do (never used): no branch around the loads
-        const int ch = g * cin_g + cn + 8 * my_h;
+      {  // without a prologue any readable 16 bytes do (never used): no branch around the loads
+        const int ch = g * cin_g + cn + 4 * my_q;
         const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);
         const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);
-        psc[0] = *reinterpret_cast<const float4*>(scp);
-        psc[1] = *reinterpret_cast<const float4*>(scp + 4);
-        psh[0] = *reinterpret_cast<const float4*>(shp);
-        psh[1] = *reinterpret_cast<const float4*>(shp + 4);
+        psc = *reinterpret_cast<const f32x4*>(scp);
+        psh = *reinterpret_cast<const f32x4*>(shp);
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int item = min(tid + i * CT, NITEM - 1);
-        const int px = item >> 1;
+        const int px = item >> 2;
         const int py = px / PW, pxx = px - py * PW;
         const int iy = iy0 + py, ix = ix0 + pxx;
         // branch-free: a clamped address is always loaded (conditional loads split the block and make the
         // compiler wait for all outstanding loads at every join); out-of-image pixels are zeroed at commit
         const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-        const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 8 * my_h);  // inside one sample: < 2^31
-        pre_p[i][0] = *reinterpret_cast<const float4*>(src);
-        pre_p[i][1] = *reinterpret_cast<const float4*>(src + 4);
+        const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 4 * my_q);  // inside one sample: < 2^31
+        pre_p[i] = *reinterpret_cast<const u32x4*>(src);
       }
       const uint4* wc = wg + (size_t)(cc + 1) * 54 * cout_g;
 #pragma unroll
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(CT) void conv_bf3_kernel(ConvArgs a, const uint4* _
   // Each wave transposes through its own 4 KB of LDS (the patch / weights are dead after the loop's last barrier),
   // and LDS operations of one wave complete in order, so no workgroup barrier is needed here ----
   float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
-  const float* res_n = a.residual ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+  const float* res_n = (a.residual && !res_in_acc) ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
   float* s_tile = reinterpret_cast<float*>(lds4) + (wset * 4 + wave) * (32 * 32);
   const int ch0 = g * cout_g + ns * COGW;
 #pragma unroll
@@ -322,11 +349,23 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   const int nchunks = cin_g / KC;
   const uint4* wg = wimg + (size_t)g * nchunks * 54 * cout_g + (size_t)ns * COGW;
 
+  const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;  // see conv_bf3_kernel
   f32x16 acc[NTN];
+  if (res_in_acc) {
+    const float* res_n = a.residual + (size_t)n * M * a.Cout + (g * cout_g + ns * COGW + (lane & 31));
 #pragma unroll
-  for (int t = 0; t < NTN; ++t)
+    for (int t = 0; t < NTN; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        acc[t][r] = res_n[(size_t)min(p0 + wave * 32 + i, M - 1) * a.Cout + t * 32];
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  }
 
   const int kh = lane >> 5;
   const int pl = min(p0 + wave * 32 + (lane & 31), M - 1);  // this lane's output position (clamped: never stored)
@@ -449,7 +488,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
 
   // ---- epilogue: as conv_bf3_kernel; the NHWC offset of flattened position p is p * Cout ----
   float* out_n = a.out + (size_t)n * M * a.Cout;
-  const float* res_n = a.residual ? a.residual + (size_t)n * M * a.Cout : nullptr;
+  const float* res_n = (a.residual && !res_in_acc) ? a.residual + (size_t)n * M * a.Cout : nullptr;
   float* s_tile = reinterpret_cast<float*>(lds4) + wave * (32 * 32);
   const int ch0 = g * cout_g + ns * COGW;
 #pragma unroll
