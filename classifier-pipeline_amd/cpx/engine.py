@@ -161,7 +161,7 @@ class TrackStream:
         self.n = f + 1
         if init_only and f == 0:
             return f  # consumed together with the first real frame
-        t.cuda.current_stream(eng.device).synchronize()
+        eng.sync_inputs()
         mp = C.c_void_p(self.meta.ctypes.data)
         rc = eng.lib.cpx_track_frame_ex(eng.h, self._p(self.frames_dev), mp, self.n_tracked, self.n,
                                         self._p(self.comps), self._p(self.info), self._p(self.labels),
@@ -247,6 +247,14 @@ class TrackEngine:
         if rc != 0:
             raise CpxError(rc, self._err())
 
+    def sync_inputs(self):
+        """Order this handle's next kernels behind what torch has enqueued: a host wait on torch's current stream --
+        unless that stream IS the handle's (``with torch.cuda.stream(engine.torch_stream())``), where stream order
+        already does it and nothing blocks the host (cpx.pipeline runs that way)."""
+        cur = self.torch.cuda.current_stream(self.device)
+        if int(cur.cuda_stream) != int(self.lib.cpx_stream(self.h) or 0):
+            cur.synchronize()
+
     def upload_frames(self, frames):
         """uint16 [N,H,W] numpy -> device tensor (stored as int16 bits)."""
         t = self.torch
@@ -265,7 +273,7 @@ class TrackEngine:
         pay = t.from_numpy(np.array(payload, dtype=np.uint8, copy=True)).to(self.device)
         fo_d, bw_d, offs_d = (t.from_numpy(a).to(self.device) for a in (fo, bw, offs))
         out = t.empty((total, self.height, self.width), dtype=t.int16, device=self.device)
-        t.cuda.current_stream(self.device).synchronize()
+        self.sync_inputs()
         rc = self.lib.cpx_cptv_unpack(self.h, C.c_void_p(pay.data_ptr()), C.c_void_p(fo_d.data_ptr()),
                                       C.c_void_p(bw_d.data_ptr()), C.c_void_p(offs_d.data_ptr()), offs.size - 1,
                                       C.c_void_p(out.data_ptr()))
@@ -290,7 +298,7 @@ class TrackEngine:
             return np.zeros(0, THUMB_STAT_DTYPE)
         refs_dev = self._to_dev(np.ascontiguousarray(refs, dtype=REGION_REF_DTYPE))
         out = t.zeros(n * 4, dtype=t.int32, device=self.device)
-        t.cuda.current_stream(self.device).synchronize()
+        self.sync_inputs()
         rc = self.lib.cpx_thumb_stats(self.h, C.c_void_p(frames_dev.data_ptr()),
                                       C.c_void_p(track_result.labels_dev.data_ptr()),
                                       C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(refs_dev.data_ptr()), n,
@@ -329,7 +337,7 @@ class TrackEngine:
         counts = t.zeros(n, dtype=t.int32, device=self.device)
         status = t.zeros(n, dtype=t.int32, device=self.device)
         labels = t.empty((n, H, W), dtype=t.int32, device=self.device) if want_labels else None
-        t.cuda.current_stream(self.device).synchronize()
+        self.sync_inputs()
         rc = self.lib.cpx_ir_detect(self.h, C.c_void_p(images_dev.data_ptr()), n, W, H, int(threshold),
                                     int(max_components), C.c_void_p(comps.data_ptr()), C.c_void_p(counts.data_ptr()),
                                     C.c_void_p(status.data_ptr()),
@@ -351,7 +359,7 @@ class TrackEngine:
         """cpx_trackless_thumb -> (x, y) of the chosen 64x64 window."""
         t = self.torch
         out = t.zeros(2, dtype=t.int32, device=self.device)
-        t.cuda.current_stream(self.device).synchronize()
+        self.sync_inputs()
         rc = self.lib.cpx_trackless_thumb(self.h, C.c_void_p(frames_dev.data_ptr()), int(frame), int(background),
                                           C.c_void_p(out.data_ptr()))
         if rc != 0:
@@ -423,7 +431,7 @@ class TrackEngine:
             bgo = t.empty((B, self.height, self.width), dtype=t.float32, device=self.device) if want_background else None
         else:
             comps, info, labels, filt, bgo = outputs
-        t.cuda.current_stream(self.device).synchronize()  # inputs were produced on torch's stream
+        self.sync_inputs()  # inputs were produced on torch's stream
         rc = self.lib.cpx_track_batch_ex(
             self.h, C.c_void_p(frames_dev.data_ptr()), offs.ctypes.data_as(C.POINTER(C.c_int32)),
             C.c_void_p(meta.ctypes.data), B, C.c_void_p(comps.data_ptr()), C.c_void_p(info.data_ptr()),
@@ -449,7 +457,7 @@ class TrackEngine:
         status = t.zeros(B, dtype=t.int32, device=self.device)
         regions = t.zeros(total * self.cap * 14, dtype=t.int32, device=self.device) if want_regions else None
         rcounts = t.zeros(total, dtype=t.int32, device=self.device) if want_regions else None
-        t.cuda.current_stream(self.device).synchronize()
+        self.sync_inputs()
         rc = self.lib.cpx_associate_batch(
             self.h, C.byref(params), offs.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(meta.ctypes.data), B,
             C.c_void_p(track_result.comps_dev.data_ptr()), C.c_void_p(track_result.info_dev.data_ptr()),
@@ -485,7 +493,7 @@ class TrackEngine:
         side = square_width * frame_size
         if out is None:
             out = t.empty((n_samples, side, side, 2), dtype=t.float32, device=self.device)
-        t.cuda.current_stream(self.device).synchronize()
+        self.sync_inputs()
         rc = self.lib.cpx_track_limits_batch_ex(
             self.h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(track_result.filtered_dev.data_ptr()),
             C.c_void_p(track_result.info_dev.data_ptr()), C.c_void_p(refs_dev.data_ptr()),

@@ -54,53 +54,61 @@ class BatchPipeline:
             raise CpxError(rc, self.eng._err())
 
     def run(self, frames_dev, clip_offsets, meta, outputs=None, classify=True, keep_samples=False, sub_batches=1):
-        """All stages for the clips of one batch.  sub_batches > 1 (and a network living on a second engine, i.e. a
-        second HIP stream): the batch is cut into that many groups of clips and the HBM-bound track stage of group
-        k+1 runs while the MFMA-bound network works on group k."""
+        """All stages for the clips of one batch.  Everything -- the cpx kernels and the few torch ops between them --
+        is enqueued on the handle's HIP stream (torch's current stream is switched to it for the duration), so stream
+        order replaces host synchronisation: the host blocks exactly once, to read the per-clip work counts that size
+        the classification buffers.  sub_batches > 1 (and a network living on a second engine, i.e. a second HIP
+        stream): the batch is cut into that many groups of clips and the HBM-bound track stage of group k+1 runs
+        while the MFMA-bound network works on group k."""
         if sub_batches > 1 and classify and self.net is not None and not keep_samples:
             return self._run_overlapped(frames_dev, clip_offsets, meta, outputs, sub_batches)
+        eng, t = self.eng, self.eng.torch
+        t.cuda.current_stream(eng.device).synchronize()  # the caller's inputs (made on its stream) are complete
+        with t.cuda.stream(eng.torch_stream()):
+            return self._run_on_stream(frames_dev, clip_offsets, meta, outputs, classify, keep_samples)
+
+    def _run_on_stream(self, frames_dev, clip_offsets, meta, outputs, classify, keep_samples):
         eng, t = self.eng, self.eng.torch
         lib, h = eng.lib, eng.h
         dev = eng.device
         out = self._front(frames_dev, clip_offsets, meta, outputs, classify)
         if not classify or out.n_tracks == 0 or out.n_samples == 0:
+            eng.synchronize()
             return out
         n_tracks, n_samples = out.n_tracks, out.n_samples
         reqs, limits, per = out.reqs_dev, out.limits_dev, self.sq * self.sq
         side = self.sq * self.fs
         probs = t.empty((n_samples, self.n_labels), dtype=t.float32, device=dev)
+        logits = t.empty((n_samples, self.n_labels), dtype=t.float32, device=dev)
         chunk = min(self.cnn_chunk, n_samples)
         if keep_samples:
             out.samples_dev = t.empty((n_samples, side, side, 2), dtype=t.float32, device=dev)
         elif self._sample_buf is None or self._sample_buf.shape[0] < chunk or self._sample_buf.shape[1] != side:
             self._sample_buf = t.empty((chunk, side, side, 2), dtype=t.float32, device=dev)
+        sample_bytes = side * side * 2 * 4
         for s0 in range(0, n_samples, chunk):
             s1 = min(s0 + chunk, n_samples)
             buf = out.samples_dev[s0:s1] if keep_samples else self._sample_buf[: s1 - s0]
-            # requests of the chunk address samples relative to s0
-            rq = reqs.view(-1, 8)[s0 * per : s1 * per].clone()
-            rq[:, 6] -= s0
-            t.cuda.current_stream(dev).synchronize()
+            # the chunk's requests carry absolute sample indices: hand the kernel the address sample 0 WOULD have
+            # (it only writes the samples of these requests), instead of rewriting the requests
             self._check(lib.cpx_crop_tile(
                 h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(out.track.filtered_dev.data_ptr()),
-                C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(rq.data_ptr()), (s1 - s0) * per,
-                C.c_void_p(limits.data_ptr()), self.fs, self.sq, C.c_void_p(buf.data_ptr())))
-            eng.synchronize()
+                C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(reqs.data_ptr() + s0 * per * 32), (s1 - s0) * per,
+                C.c_void_p(limits.data_ptr()), self.fs, self.sq, C.c_void_p(buf.data_ptr() - s0 * sample_bytes)))
             if self.net is not None:
-                _, p = self.net.forward(buf)
-                probs[s0:s1] = p
+                self.net.forward_async(buf, logits[s0:s1], probs[s0:s1])
         if self.net is None:
+            eng.synchronize()
             return out
         # ---- 7. per-track aggregation ----
         out.scores = t.empty((n_tracks, self.n_labels), dtype=t.float32, device=dev)
         out.best = t.empty(n_tracks, dtype=t.int32, device=dev)
-        t.cuda.current_stream(dev).synchronize()
         self._check(lib.cpx_aggregate_predictions(
             h, C.c_void_p(probs.data_ptr()), C.c_void_p(out.sample_track_dev.data_ptr()), n_samples,
             C.c_void_p(reqs.data_ptr()), n_tracks, self.n_labels, self.fp_index, self.sq,
             C.c_void_p(out.scores.data_ptr()), C.c_void_p(out.best.data_ptr())))
-        eng.synchronize()
         out.probs = probs
+        eng.synchronize()  # results are complete when run() returns (callers read them from any stream)
         return out
 
     def _front(self, frames_dev, clip_offsets, meta, outputs, classify=True):
@@ -120,17 +128,19 @@ class BatchPipeline:
         summ = t.zeros(B * mt * 30, dtype=t.int32, device=dev)
         counts = t.zeros((B, 4), dtype=t.int32, device=dev)
         offs_p = offs.ctypes.data_as(C.POINTER(C.c_int32))
-        t.cuda.current_stream(dev).synchronize()
+        eng.sync_inputs()
         self._check(lib.cpx_finalize_tracks(
             h, C.byref(self.fp), offs_p, C.c_void_p(meta.ctypes.data), B, C.c_void_p(out.assoc.pool_dev.data_ptr()),
             C.c_void_p(out.assoc.tracks_dev.data_ptr()), C.c_void_p(out.assoc.ntracks_dev.data_ptr()),
             C.c_void_p(summ.data_ptr()), C.c_void_p(counts.data_ptr())))
-        eng.synchronize()
-        out.track_timing = eng.last_kernel_timing()  # (ms, launches) of this group's frame-kernel launches
         out.summaries_dev = summ
+        on_stream = int(t.cuda.current_stream(dev).cuda_stream) == int(lib.cpx_stream(h) or 0)
+        if not on_stream:
+            eng.synchronize()  # torch runs on another stream (the overlapped form): the kernels must have finished
         prefix = (t.cumsum(counts, dim=0) - counts).to(t.int32).contiguous()
-        totals = counts.sum(dim=0).cpu().numpy()
-        out.counts = counts.cpu().numpy()
+        out.counts = counts.cpu().numpy()   # the one host wait of a run: the work counts size what follows
+        totals = out.counts.sum(axis=0)
+        out.track_timing = eng.last_kernel_timing()  # (ms, launches) of this group's frame-kernel launches
         n_tracks, n_refs, n_samples = int(totals[0]), int(totals[1]), int(totals[2])
         out.n_tracks, out.n_samples = n_tracks, n_samples
         if not classify or n_tracks == 0 or n_samples == 0:
@@ -142,18 +152,19 @@ class BatchPipeline:
         reqs = t.zeros(n_samples * per * 8, dtype=t.int32, device=dev)
         sample_track = t.zeros(n_samples, dtype=t.int32, device=dev)
         track_clip = t.zeros((n_tracks, 2), dtype=t.int32, device=dev)
-        t.cuda.current_stream(dev).synchronize()
+        eng.sync_inputs()
         self._check(lib.cpx_plan_segments(
             h, C.byref(self.fp), offs_p, C.c_void_p(meta.ctypes.data), B, C.c_void_p(out.assoc.pool_dev.data_ptr()),
             C.c_void_p(summ.data_ptr()), C.c_void_p(out.assoc.ntracks_dev.data_ptr()), C.c_void_p(prefix.data_ptr()),
             self.sq, C.c_void_p(refs.data_ptr()), C.c_void_p(toffs.data_ptr()), C.c_void_p(reqs.data_ptr()),
             C.c_void_p(sample_track.data_ptr()), C.c_void_p(track_clip.data_ptr())))
-        eng.synchronize()
+        if not on_stream:
+            eng.synchronize()
         toffs[n_tracks] = n_refs
         out.track_clip, out.reqs_dev, out.sample_track_dev = track_clip, reqs, sample_track
         # ---- 5a. per-track limits ----
         limits = t.zeros(n_tracks * 4, dtype=t.int32, device=dev)
-        t.cuda.current_stream(dev).synchronize()
+        eng.sync_inputs()
         self._check(lib.cpx_track_limits_batch(
             h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(out.track.filtered_dev.data_ptr()),
             C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(refs.data_ptr()), C.c_void_p(toffs.data_ptr()),
@@ -197,7 +208,7 @@ class BatchPipeline:
             logits = t.empty((ns, self.n_labels), dtype=t.float32, device=dev)
             part.scores = t.empty((nt, self.n_labels), dtype=t.float32, device=dev)
             part.best = t.empty(nt, dtype=t.int32, device=dev)
-            t.cuda.current_stream(dev).synchronize()
+            eng.sync_inputs()
             self._check(lib.cpx_crop_tile(
                 eng.h, C.c_void_p(fr.data_ptr()), C.c_void_p(part.track.filtered_dev.data_ptr()),
                 C.c_void_p(part.track.info_dev.data_ptr()), C.c_void_p(part.reqs_dev.data_ptr()), ns * per,
