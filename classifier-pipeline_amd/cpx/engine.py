@@ -201,6 +201,61 @@ class TrackStream:
         return self.pool[q * ma * 14:(q + 1) * ma * 14].cpu().numpy().view(REGION_DTYPE)
 
 
+class ComponentStream:
+    """Association of ONE clip frame by frame from component lists the caller supplies (the IR tracker: its
+    components come out of the background subtractor + cpx_ir_detect + the host's fragment merge, not out of
+    cpx_track_frame).  Same device core and outputs as TrackStream: cpx_associate_frame."""
+
+    def __init__(self, engine, capacity, params):
+        t = engine.torch
+        self.engine, self.cap_frames, self.params = engine, int(capacity), params
+        if self.cap_frames > engine.cfg.max_frames:
+            raise ValueError("stream capacity %d exceeds the engine's max_frames %d" % (capacity, engine.cfg.max_frames))
+        dev, cap, n = engine.device, engine.cap, self.cap_frames
+        ma, mt = params.max_active_tracks, params.max_tracks
+        self.comps = t.zeros(n * cap * 8, dtype=t.int32, device=dev)
+        self.info = t.zeros(n * 20, dtype=t.int32, device=dev)
+        self.pool = t.zeros(n * ma * 14, dtype=t.int32, device=dev)
+        self.tracks = t.zeros(mt * 8, dtype=t.int32, device=dev)
+        self.ntracks = t.zeros(1, dtype=t.int32, device=dev)
+        self.status = t.zeros(1, dtype=t.int32, device=dev)
+        self.regions = t.zeros(n * cap * 14, dtype=t.int32, device=dev)
+        self.rcounts = t.zeros(n, dtype=t.int32, device=dev)
+        self.meta = np.zeros(n, dtype=FRAME_META_DTYPE)
+        self.n = 0
+
+    def append(self, components, ffc_affected=False):
+        """components: COMPONENT_DTYPE rows of this frame (label order = region ids).  -> the frame's index."""
+        eng, t = self.engine, self.engine.torch
+        if self.n >= self.cap_frames:
+            raise CpxError(-1, "stream is full (%d frames)" % self.cap_frames)
+        comps = np.ascontiguousarray(components, dtype=COMPONENT_DTYPE)
+        if len(comps) > eng.cap:
+            raise CpxError(-5, "%d components exceed the engine's max_components %d" % (len(comps), eng.cap))
+        f = self.n
+        if len(comps):
+            self.comps[f * eng.cap * 8:(f * eng.cap + len(comps)) * 8] = t.from_numpy(comps.view(np.int32).reshape(-1).copy()).to(eng.device)
+        fi = np.zeros(1, FRAME_INFO_DTYPE)
+        fi["frame_number"], fi["n_components"], fi["ffc_affected"] = f, len(comps), 1 if ffc_affected else 0
+        self.info[f * 20:(f + 1) * 20] = t.from_numpy(fi.view(np.int32).copy()).to(eng.device)
+        if ffc_affected:  # the schedule derives the flag from the times: less than 9 ms apart (SURVEY F5)
+            self.meta[f]["time_on_ms"], self.meta[f]["last_ffc_ms"], self.meta[f]["has_times"] = 100, 100, 1
+        self.n = f + 1
+        eng.sync_inputs()
+        p = lambda x: C.c_void_p(x.data_ptr())
+        rc = eng.lib.cpx_associate_frame(eng.h, C.byref(self.params), C.c_void_p(self.meta.ctypes.data), f, self.n,
+                                         p(self.comps), p(self.info), p(self.pool), p(self.tracks), p(self.ntracks),
+                                         p(self.status), p(self.regions), p(self.rcounts))
+        if rc != 0:
+            raise CpxError(rc, eng._err())
+        eng.synchronize()
+        return f
+
+    frame_regions = TrackStream.frame_regions
+    track_records = TrackStream.track_records
+    pool_row = TrackStream.pool_row
+
+
 class TrackEngine:
     def __init__(self, width=160, height=120, model="lepton3", device=0, edge_pixels=1, window=45,
                  max_components=64, max_frames=4096, background_thresh=None, weight_add=None, denoise=False):
@@ -354,6 +409,24 @@ class TrackEngine:
         used = max(1, int(cnt.max()))  # only the filled part of the table crosses PCIe
         host = comps[:, :used].contiguous().cpu().numpy().view(COMPONENT_DTYPE).reshape(n, used)
         return cnt, host, labels
+
+    def ir_delta_variance(self, cur_dev, prev_dev, rects):
+        """cpx_ir_delta_variance: np.var of the uint8-wrapping frame difference over each [x, y, w, h] box -> float64 [n]."""
+        t = self.torch
+        rects = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
+        n = len(rects)
+        if n == 0:
+            return np.zeros(0, np.float64)
+        H, W = (int(v) for v in cur_dev.shape)
+        r_dev = t.from_numpy(rects).to(self.device)
+        out = t.empty(n, dtype=t.float64, device=self.device)
+        self.sync_inputs()
+        rc = self.lib.cpx_ir_delta_variance(self.h, C.c_void_p(cur_dev.data_ptr()), C.c_void_p(prev_dev.data_ptr()), W, H,
+                                            C.c_void_p(r_dev.data_ptr()), n, C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        self.synchronize()
+        return out.cpu().numpy()
 
     def trackless_thumb(self, frames_dev, frame, background):
         """cpx_trackless_thumb -> (x, y) of the chosen 64x64 window."""

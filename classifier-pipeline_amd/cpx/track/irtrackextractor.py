@@ -1,0 +1,464 @@
+"""IRTrackExtractor -- the 640 x 480 IR tracker around the device detection stage (reference
+src/track/irtrackextractor.py:94-787).
+
+Per frame, on the GPU: MOG2 background model (cpx_mog2_apply, the role of CVBackground / cv2 MOG2,
+track/cliptracker.py:561-613) -> foreground mask -> detect_objects_ir (cpx_ir_detect) -> [host: merge_components,
+a few dozen rectangles] -> per-region variance of the frame-to-frame change (cpx_ir_delta_variance) -> region
+filter + matching + Kalman on the shared association core with the IR TrackingConfig (cpx_associate_frame).  Host
+side, as in the reference: trap geometry (Line, get_trap_lines, filter_components, inside_trap_top / _bottom),
+filter_track, end-of-clip trim.
+
+What the reference itself cannot pin at this snapshot (both are AttributeErrors there, so its IR tracker does not
+run): ``clip.frame_buffer.get_frame_ago`` (irtrackextractor.py:647; FrameBuffer has no such method, only a comment
+at framebuffer.py:101) and ``track.get_stats()`` (irtrackextractor.py:481,528; Track has calculate_stats only).
+Here get_frame_ago(n) is read as "the frame n frames before the current one" and get_stats() as calculate_stats()
+-> stats; everything else follows the reference line by line and its pure functions are pinned by a golden made
+from the reference's own code (tests/golden/make_golden_irtrap.py).  MP4 decoding (cv2.VideoCapture) is third-party
+code that is not part of the build: parse_clip needs cv2, parse_frames takes the gray frames themselves."""
+
+import logging
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+
+from .._lib import COMPONENT_DTYPE
+from ..engine import ComponentStream, TrackEngine
+from ..tracking import make_track_params
+from .cliptrackextractor import ClipTracker
+from .irdetect import MOG2Background, detect_objects_ir, merge_components, rect_distance  # noqa: F401
+from .region import Region
+from .track import Track
+
+
+class Line:
+    """y = m x + c in the trap's coordinates (irtrackextractor.py:40-74)."""
+
+    def __init__(self, m, c):
+        self.m = m
+        self.c = c
+
+    def is_above(self, point):
+        return point[1] > self.y_res(point[0])
+
+    def is_below(self, point):
+        return not self.is_above(point)
+
+    def is_left(self, point):
+        return point[0] < self.x_res(point[1])
+
+    def is_right(self, point):
+        return not self.is_left(point)
+
+    def y_res(self, x):
+        return x * self.m + self.c
+
+    def x_res(self, y):
+        return (y - self.c) / self.m
+
+    def __str__(self):
+        return f"y={self.m}x + {self.c}"
+
+
+def get_trap_lines(trap_size):
+    """irtrackextractor.py:77-91."""
+    if trap_size == "S":
+        lb, rb = Line(1.3, 297.5), Line(-1.4, 1148)
+    else:
+        lb, rb = Line(1.28, 180), Line(-1.2, 979)
+    logging.info("Getting trap lines for trap size %s left bottom %s right bottom %s", trap_size, lb, rb)
+    return lb, rb
+
+
+class Direction:
+    LEFT = 1
+    BOTTOM = 2
+    RIGHT = 4
+    TOP = 8
+    MIDDLE = 16
+
+
+class IRTrackExtractor(ClipTracker):
+    PREVIEW = "preview"
+    VERSION = 10
+    TYPE = "IR"
+    FRAMES_AGO = 10  # get_delta_frame compares with the frame this many frames back (irtrackextractor.py:641)
+
+    @property
+    def type(self):
+        return IRTrackExtractor.TYPE
+
+    @property
+    def tracker_version(self):
+        return self.version
+
+    @property
+    def tracking_time(self):
+        return self._tracking_time
+
+    def __init__(self, config, cache_to_disk=False, keep_frames=True, calc_stats=True, verbose=False, scale=None,
+                 do_tracking=True, on_trapped=None, update_background=True, trap_size="L", tracking_alg="mog2",
+                 check_trapped=False, from_pi=False, device=0, max_frames=4096):
+        super().__init__(config, cache_to_disk, keep_frames, calc_stats, verbose, do_tracking=do_tracking, scale=scale)
+        if scale:
+            raise NotImplementedError("scale (cv2.resize INTER_AREA of the foreground) is not part of this build")
+        if tracking_alg != "mog2":
+            raise NotImplementedError("tracking_alg %r: only the MOG2 background model is built (SuBSENSE is pybgs)"
+                                      % tracking_alg)
+        self.version = f"PI-IR-{IRTrackExtractor.VERSION}" if from_pi else f"IR-{IRTrackExtractor.VERSION}"
+        self.check_trapped = check_trapped
+        self.tracking_alg = tracking_alg
+        self.on_trapped = on_trapped
+        self.saliency = None
+        self.background = None
+        self.res_x = None
+        self.res_y = None
+        self.update_background = update_background
+        self.trap_size = trap_size
+        self.left_bottom, self.right_bottom = get_trap_lines(self.trap_size)
+        self.learning_rate = -1
+        self.device = device
+        self.capacity = int(max_frames)
+        self._engine = None
+        self._stream = None
+        self._ring = []      # the last FRAMES_AGO + 1 frames on the device (number, tensor)
+        self._tracks = {}
+
+    # ---- file / frame-list drivers ------------------------------------------------------------------
+    def parse_clip(self, clip, process_background=False):
+        """irtrackextractor.py:166-231.  Needs cv2.VideoCapture for the MP4 container."""
+        try:
+            import cv2
+        except ImportError:
+            raise NotImplementedError("MP4 decoding is cv2's (not part of this build): decode the recording elsewhere "
+                                      "and call parse_frames(clip, gray_frames)") from None
+        vidcap = cv2.VideoCapture(str(clip.source_file))
+
+        def frames():
+            fail_count = 0
+            while True:
+                success, image = vidcap.read()
+                if not success:
+                    if fail_count < 1:
+                        fail_count += 1
+                        continue
+                    break
+                fail_count = 0
+                grey = bool(np.all(image[:, :, 0] == image[:, :, 1]) and np.all(image[:, :, 1] == image[:, :, 2]))
+                yield cv2.cvtColor(image, cv2.COLOR_BGR2GRAY), grey
+        try:
+            return self._parse(clip, frames())
+        finally:
+            vidcap.release()
+
+    def parse_frames(self, clip, frames, first_is_background=False):
+        """parse_clip for already decoded gray uint8 [H, W] frames.  first_is_background: the first frame is the
+        recorder's tracking background (a grey-scale frame in the MP4: 500 background frames, not tracked)."""
+        return self._parse(clip, ((f, first_is_background and i == 0) for i, f in enumerate(frames)))
+
+    def _parse(self, clip, frames):
+        clip.type = self.type
+        self._tracking_time = None
+        start = time.time()
+        clip.set_frame_buffer(False, self.cache_to_disk, False, self.keep_frames,
+                              max_frames=None if self.keep_frames else 51)
+        background = None
+        for gray, is_background_frame in frames:
+            gray = np.ascontiguousarray(gray, dtype=np.uint8)
+            if background is None:
+                self.res_x, self.res_y = gray.shape[0], gray.shape[1]  # (sic, irtrackextractor.py:199-200)
+                clip.set_res(gray.shape[1], gray.shape[0])
+                if clip.from_metadata:
+                    for track in clip.tracks:
+                        track.crop_regions()
+                background = gray
+                self.start_tracking(clip, background_frame=gray, background_frames=500 if is_background_frame else 1)
+                if is_background_frame:
+                    continue
+            self.process_frame(clip, gray)
+        if not clip.from_metadata and self.do_tracking:
+            self.apply_track_filtering(clip)
+        if self.calc_stats:
+            clip.stats.completed()
+        self._tracking_time = time.time() - start
+        return True
+
+    def start_tracking(self, clip, frames=None, track_frames=-1, background_alg=None, background_frame=None,
+                       background_frames=1, retrack_back=True):
+        """irtrackextractor.py:233-283."""
+        self.res_x, self.res_y = clip.res_x, clip.res_y
+        clip.set_model("IR")
+        clip.set_video_stats(datetime.now())
+        self._open(clip)
+        if background_alg is None:
+            self.background = MOG2Background(self._engine, clip.res_x, clip.res_y, history=1000)
+            if background_frame is not None:
+                self.background.set_background(self._upload(background_frame), background_frames)
+        else:
+            self.background = background_alg
+        if frames is not None:
+            do_tracking, update_background = self.do_tracking, self.update_background
+            remaining = len(frames)
+            for frame in frames:
+                self.do_tracking = do_tracking and ((track_frames == -1) or (remaining <= track_frames))
+                self.learning_rate = 0
+                self.update_background = self.do_tracking and retrack_back
+                self.process_frame(clip, frame)
+                remaining -= 1
+            self.learning_rate = -1
+            self.update_background = update_background
+            self.do_tracking = do_tracking
+
+    def _open(self, clip):
+        if self._engine is not None:
+            self._engine.close()
+        # the IR calls take their geometry per call; the handle only carries the component capacity and the stream
+        self._engine = TrackEngine(width=160, height=120, device=self.device, max_components=256,
+                                   max_frames=max(self.capacity, 1024))
+        cfg = self.config
+        params = make_track_params(clip.res_x, clip.res_y, cfg.edge_pixels, cfg.frame_padding, self.min_dimension,
+                                   cfg.cropped_regions_strategy, cfg.filter_regions_pre_match, cfg.aoi_min_mass,
+                                   cfg.aoi_pixel_variance, cfg.params, clip.frames_per_second)
+        self._stream = ComponentStream(self._engine, self.capacity, params)
+        self._ring = []
+        self._tracks = {}
+
+    def _upload(self, frame):
+        t = self._engine.torch
+        return t.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8)).to(self._engine.device)
+
+    def process_frame(self, clip, frame, ffc_affected=False):
+        """irtrackextractor.py:295-312."""
+        frame = np.asarray(frame)
+        if frame.ndim == 3:
+            raise NotImplementedError("colour frames: convert to gray first (cv2.cvtColor is not part of this build)")
+        if ffc_affected:
+            self.print_if_verbose("{} ffc_affected".format(clip.current_frame))
+        clip.ffc_affected = ffc_affected
+        self._process_frame(clip, frame, ffc_affected)
+
+    def merge_components(self, rectangles):
+        return merge_components(rectangles, self.scale)
+
+    # ---- one frame -----------------------------------------------------------------------------------
+    def _process_frame(self, clip, frame, ffc_affected=False):
+        """irtrackextractor.py:391-492."""
+        if self._stream is None:
+            self._open(clip)
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        frame_dev = self._upload(frame)
+        filtered_dev = None
+        if self.do_tracking:
+            if self.background is None:
+                self.background = MOG2Background(self._engine, clip.res_x, clip.res_y, history=1000)
+            if self.background._background is None:
+                self.background.set_background(frame_dev.clone())
+            if self.update_background:
+                self.background.update_background(frame_dev, learning_rate=self.learning_rate)
+            filtered_dev = self.background.compute_filtered(frame_dev)
+            if not clip.background_calculated:
+                clip.set_background(self.background.background.cpu().numpy())
+        filtered = filtered_dev.cpu().numpy() if (filtered_dev is not None and self.keep_frames) else None
+        clip.add_frame(frame, filtered, None, ffc_affected)
+        q = clip.current_frame
+        self._ring.append((q, frame_dev))
+        del self._ring[: -(self.FRAMES_AGO + 1)]
+        if not self.do_tracking:
+            return
+        _, _, stats = detect_objects_ir(self._engine, filtered_dev, threshold=0, max_components=4096)
+        component_details = self.merge_components(list(stats[1:]))
+        if clip.from_metadata:
+            return  # tracks come from the metadata: nothing is matched (the reference re-reads their frames only)
+        regions = []
+        if ffc_affected:
+            clip.active_tracks = set()
+            self._stream.append(np.zeros(0, COMPONENT_DTYPE), ffc_affected=True)
+        else:
+            regions = self._associate(clip, component_details, q)
+        for track in clip.active_tracks:
+            if getattr(track, "trap_reported", False):
+                continue
+            self.inside_trap_top(track, self.scale)
+            if track.in_trap:
+                if not self.filter_track(clip, track, track.get_stats()):
+                    track.trigger_frame = q
+                    if self.on_trapped is not None:   # fire trapping event
+                        track.trap_reported = True
+                        self.on_trapped(track)
+        clip.region_history.append(regions)
+
+    def get_delta_frame(self, clip):
+        """irtrackextractor.py:638-659 -> (frame number compared with, its device frame) or (None, None)."""
+        cur = clip.current_frame
+        prev_i = cur - 1 if cur < self.FRAMES_AGO else self.FRAMES_AGO
+        want = cur - prev_i          # "prev_i frames before the current one"
+        if prev_i == cur or want == cur:
+            return None, None
+        for q, dev in self._ring:
+            if q == want:
+                return q, dev
+        return None, None
+
+    def _associate(self, clip, component_details, q):
+        """_get_regions_of_interest with the IR branch (track/cliptracker.py:263-365) + _apply_region_matchings, on
+        the device association core; -> the frame's regions."""
+        n = len(component_details)
+        comps = np.zeros(n, COMPONENT_DTYPE)
+        variances = np.zeros(n, np.float64)
+        if n:
+            rects = np.array([[int(c[0]), int(c[1]), int(c[2]), int(c[3])] for c in component_details], np.int32)
+            _, prev_dev = self.get_delta_frame(clip)
+            if prev_dev is not None:
+                variances = self._engine.ir_delta_variance(self._ring[-1][1], prev_dev, rects)
+            for i, c in enumerate(component_details):
+                x, y, w, h, mass = (int(v) for v in c[:5])
+                cx, cy = int(x + w / 2), int(y + h / 2)     # the IR tracker's centroid: the box centre, truncated
+                comps[i] = (x, y, w, h, mass, cx * mass, cy * mass, np.float32(variances[i]))
+        f = self._stream.append(comps, ffc_affected=False)
+        stream = self._stream
+        regions = []
+        for rec in stream.frame_regions(f):
+            r = Region.from_record(rec)
+            r.centroid = [int(r.centroid[0]), int(r.centroid[1])]
+            r.pixel_variance = variances[int(rec["id"])]      # float64, as np.var returns it
+            regions.append(r)
+        records = stream.track_records()
+        row = stream.pool_row(f)
+        active = set()
+        for rec in records:
+            tid = int(rec["id"])
+            if int(rec["start_frame"]) + int(rec["n_frames"]) - 1 != f:
+                continue  # not touched by this frame
+            track = self._tracks.get(tid)
+            if track is None:
+                track = Track(clip.get_id(), id=tid, fps=clip.frames_per_second, tracking_config=self.config,
+                              crop_rectangle=clip.crop_rectangle, tracker_version=self.tracker_version)
+                track.start_frame = int(rec["start_frame"])
+                track.start_s = track.start_frame / float(clip.frames_per_second)
+                track.direction, track.trap_reported = 0, False
+                self._tracks[tid] = track
+                clip.tracks.append(track)
+            track.append_from_device(rec, row[int(rec["slot"])])
+            rt = track.tracker
+            since = rt.frames_since_target_seen
+            if since == 0 or since < min(2 * (rt.frames - since), 18):
+                active.add(track)
+        clip.active_tracks = active
+        return regions
+
+    # ---- trap geometry and filters (host, as in the reference) -----------------------------------------
+    def filter_components(self, component_details):
+        """irtrackextractor.py:564-594."""
+        kept = []
+        for component in component_details:
+            region = Region(component[0], component[1], component[2], component[3])
+            p = (region.right, 480 - region.bottom)
+            flt = self.left_bottom.is_above(p) and self.left_bottom.is_left(p)
+            p = (region.left, 480 - region.bottom)
+            flt = flt or (self.right_bottom.is_above(p) and self.right_bottom.is_right(p))
+            if not flt:
+                kept.append(component)
+            else:
+                logging.info("Filtered components %s", region)
+        return kept
+
+    def filter_track(self, clip, track, stats):
+        """irtrackextractor.py:596-636."""
+        if len(track) < self.config.min_duration_secs * clip.frames_per_second:
+            self.print_if_verbose("Track filtered. Too short, {}".format(len(track)))
+            clip.filtered_tracks.append(("Track filtered.  Too short", track))
+            return True
+        if stats.max_offset < self.config.track_min_offset or stats.frames_moved < self.config.min_moving_frames:
+            self.print_if_verbose("Track filtered.  Didn't move {}".format(stats.max_offset))
+            clip.filtered_tracks.append(("Track filtered.  Didn't move", track))
+            return True
+        return False
+
+    def filter_tracks(self, clip):
+        """The IR tracker's end of clip: trim only (track/cliptracker.py:367-371 as IRTrackExtractor inherits it)."""
+        for track in clip.tracks:
+            track.trim()
+            track.set_end_s(clip.frames_per_second)
+        return False
+
+    def inside_trap_bottom(self, track, scale=None):
+        """irtrackextractor.py:661-697."""
+        region = track.last_bound.copy()
+        if region.width < 60 or region.height < 40:
+            return False
+        if track.direction == 0:
+            if region.left < 100:
+                track.direction |= Direction.LEFT
+            if region.right > (640 - 100):
+                track.direction |= Direction.RIGHT
+            if region.bottom > (480 - 100):
+                track.direction |= Direction.BOTTOM
+            if track.direction == 0:
+                if region.bottom < 300:
+                    track.direction |= Direction.TOP
+                else:
+                    track.direction = Direction.MIDDLE
+        p = (region.left, 480 - region.bottom)
+        inside = self.left_bottom.is_below(p) and self.left_bottom.is_right(p)
+        p = (region.right, 480 - region.bottom)
+        inside = inside and (self.right_bottom.is_below(p) and self.right_bottom.is_left(p))
+        x_diff = p[0] - self.right_bottom.x_res(p[1])
+        inside = inside and abs(x_diff) > 150
+        track.last_bound.in_trap = inside
+        track.update_trapped_state()
+        return inside
+
+    def inside_trap_top(self, track, scale=None):
+        """irtrackextractor.py:699-778."""
+        SIDE_ALLOWANCE, TOP_ALLOWANCE, BOTTOM_ALLOWANCE = 150, 300, 100
+        region = track.last_bound.copy()
+        if region.width < 60 or region.height < 40:
+            return False
+        if track.direction == 0:
+            if region.left < SIDE_ALLOWANCE:
+                track.direction |= Direction.LEFT
+            if region.right > (640 - SIDE_ALLOWANCE):
+                track.direction |= Direction.RIGHT
+            if region.bottom > (480 - BOTTOM_ALLOWANCE):
+                track.direction |= Direction.BOTTOM
+            if track.direction == 0:
+                if region.bottom < TOP_ALLOWANCE:
+                    track.direction |= Direction.TOP
+                else:
+                    track.direction = Direction.MIDDLE
+        p = (region.right, 480 - region.top)
+        inside = self.left_bottom.is_below(p) and self.left_bottom.is_right(p)
+        left_percent = abs(p[0] - self.left_bottom.x_res(p[1])) / region.width
+        p = (region.left, 480 - region.top)
+        inside = inside and self.right_bottom.is_below(p) and self.right_bottom.is_left(p)
+        right_percent = abs(p[0] - self.right_bottom.x_res(p[1])) / region.width
+        if not inside:
+            return False
+        in_trap = False
+        if left_percent < 0.5 and right_percent < 0.5:
+            return False
+        if track.direction & Direction.LEFT and region.left > 40 and left_percent > 0.5:
+            in_trap = True
+        elif track.direction & Direction.RIGHT and region.right < 580 and right_percent > 0.5:
+            in_trap = True
+        if track.direction == Direction.TOP and region.bottom > 300:
+            in_trap = True
+        if track.direction == Direction.BOTTOM and region.bottom < 480 - 50:
+            in_trap = True
+        if track.direction == Direction.MIDDLE and region.left > 40 and region.right < 580:
+            in_trap = True
+        track.last_bound.in_trap = in_trap
+        track.update_trapped_state()
+        return in_trap
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -80,6 +80,8 @@ class Track:
         self.stats = None
         self.in_trap = False
         self.trigger_frame = None
+        self.trap_reported = False
+        self.direction = 0
         self.trap_tag = None
 
     # ---- construction from the device records ---------------------------------------------
@@ -182,6 +184,22 @@ class Track:
     @property
     def last_bound(self):
         return self.bounds_history[-1]
+
+    def update_trapped_state(self):
+        """track.py:951-958: trapped once the last two bounds are inside the trap."""
+        if self.in_trap:
+            return self.in_trap
+        min_frames = 2
+        if len(self.bounds_history) < min_frames:
+            return False
+        self.in_trap = all(r.in_trap for r in self.bounds_history[-min_frames:])
+        return self.in_trap
+
+    def get_stats(self):
+        """IRTrackExtractor asks a live track for its statistics (irtrackextractor.py:481,528); the reference's Track
+        has no such method at this snapshot (an AttributeError there): read as calculate_stats() -> stats."""
+        self.calculate_stats()
+        return self.stats
 
     def crop_regions(self):
         if self.crop_rectangle is not None:

@@ -51,7 +51,11 @@ def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False
         raise Exception("File {} not found.".format(filename))
     logging.info("Tracking %s", filename)
     if filename.suffix != ".cptv":
-        raise NotImplementedError("only thermal .cptv clips are handled (IR path: SURVEY section 8 f4)")
+        raise NotImplementedError(
+            "only thermal .cptv files are handled here: for other containers the reference decodes with "
+            "cv2.VideoCapture and subtracts the background with SuBSENSE (pybgs), trackextractor.py:148-156 -- "
+            "neither is part of this build.  The IR tracker itself is: cpx.track.irtrackextractor.IRTrackExtractor"
+            ".parse_frames(clip, gray_frames) (MOG2, the algorithm the Pi uses)")
     track_extractor = ClipTrackExtractor(config.tracking, config.use_opt_flow, cache_to_disk, verbose=config.verbose,
                                          max_frames=max_frames)
     clip = Clip(track_extractor.config, filename)

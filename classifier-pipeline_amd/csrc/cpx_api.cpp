@@ -1304,6 +1304,21 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
   return cpx_cnn_head_ex(h, &hd);
 }
 
+int cpx_ir_delta_variance(cpx_handle* h, const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height,
+                          const int32_t* rects_dev, int n, double* var_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!cur_dev || !prev_dev || width < 1 || height < 1 || n < 0 || (n > 0 && (!rects_dev || !var_dev)))
+    return fail(h, CPX_ERR_INVALID, "cpx_ir_delta_variance: bad argument");
+  if (n == 0) return CPX_OK;
+  CPX_ENTER(h);
+  cpx::IrVarArgs a{};
+  a.W = width; a.H = height; a.n = n;
+  a.cur = cur_dev; a.prev = prev_dev; a.rects = rects_dev; a.out = var_dev;
+  cpx::launch_ir_delta_variance(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 // ---- IR background model ---------------------------------------------------------------------------------------------
 struct cpx_mog2 {
   cpx_handle* h = nullptr;

@@ -390,6 +390,41 @@ size_t ir_slot_bytes(int W, int H) {
   return ((P / 2 + 64 + 8 * cs) * 4 + 255) & ~(size_t)255;
 }
 
+// np.var(np.abs(frame.thermal - prev.thermal)[region]) of the IR tracker (track/irtrackextractor.py:638-655,
+// track/cliptracker.py:303-312): both frames are uint8, so the difference wraps modulo 256 and np.abs leaves it as
+// it is.  One wavefront per region; the sums are exact integers (n * S2 - S1^2 < 2^63 for a 640 x 480 box), one
+// division at the end -- NumPy's two-pass float64 evaluation agrees to rounding noise.
+__global__ __launch_bounds__(64) void cpx_ir_delta_var_kernel(IrVarArgs a) {
+  const int r = blockIdx.x;
+  const int x0 = a.rects[4 * r], y0 = a.rects[4 * r + 1];
+  const int x1 = min(x0 + a.rects[4 * r + 2], a.W), y1 = min(y0 + a.rects[4 * r + 3], a.H);  // slicing clips
+  const int w = x1 - x0, hgt = y1 - y0;
+  unsigned long long s1 = 0, s2 = 0;
+  if (w > 0 && hgt > 0 && x0 >= 0 && y0 >= 0) {
+    const int n = w * hgt;
+    for (int k = threadIdx.x; k < n; k += 64) {
+      const int yy = k / w, xx = k - yy * w;
+      const int p = (y0 + yy) * a.W + x0 + xx;
+      const unsigned d = ((unsigned)a.cur[p] - (unsigned)a.prev[p]) & 255u;
+      s1 += d;
+      s2 += (unsigned long long)d * d;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (threadIdx.x == 0) {
+    const long long n = (w > 0 && hgt > 0 && x0 >= 0 && y0 >= 0) ? (long long)w * hgt : 0;
+    a.out[r] = n ? (double)((unsigned long long)n * s2 - s1 * s1) / ((double)n * (double)n) : NAN;  // np.var([]) is nan
+  }
+}
+
+void launch_ir_delta_variance(const IrVarArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_ir_delta_var_kernel, dim3(a.n), dim3(64), 0, s, a);
+}
+
 int launch_ir_detect(const IrArgs& a, int n_frames, hipStream_t s) {
   static bool lds_ready[64];
   if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_ir_detect_kernel), lds_ready, 160 * 1024 - 1024)) return -1;

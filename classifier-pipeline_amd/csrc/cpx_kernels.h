@@ -250,6 +250,14 @@ struct IrArgs {
   int n_slots;
 };
 int launch_ir_detect(const IrArgs& a, int n_frames, hipStream_t s);
+struct IrVarArgs {
+  int W, H, n;
+  const unsigned char* cur;   // [H, W]
+  const unsigned char* prev;  // [H, W]
+  const int* rects;           // [n][4] x, y, width, height
+  double* out;                // [n]
+};
+void launch_ir_delta_variance(const IrVarArgs& a, hipStream_t s);
 int ir_supported(int W, int H);
 size_t ir_slot_bytes(int W, int H);
 

@@ -394,6 +394,13 @@ int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int wi
                   int max_components, cpx_component* comps_dev, int32_t* counts_dev, int32_t* status_dev,
                   int32_t* labels_dev);
 
+/* Per-region variance of the frame-to-frame change the IR tracker gates regions with: replaces
+ * np.var(np.abs(frame.thermal - frame_ago.thermal)[region]) (track/irtrackextractor.py:638-655 get_delta_frame,
+ * track/cliptracker.py:303-312).  Both frames are uint8, so the difference wraps modulo 256 as NumPy's does.
+ * rects_dev int32 [n][4] = x, y, width, height (clipped to the image like a NumPy slice); var_dev double [n]. */
+int cpx_ir_delta_variance(cpx_handle* h, const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height,
+                          const int32_t* rects_dev, int n, double* var_dev);
+
 /* ---- IR background model ---------------------------------------------------------------
  * Replaces CVBackground (track/cliptracker.py:561-613): cv2.createBackgroundSubtractorMOG2(history, varThreshold,
  * detectShadows=False) for `n_streams` independent 8-bit single-channel videos of `width` x `height` advancing in

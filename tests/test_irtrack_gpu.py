@@ -1,0 +1,156 @@
+"""The IR tracker end to end on the GPU (BASELINE configs[4]): IRTrackExtractor.parse_frames on a
+seeded synthetic 640 x 480 video against the oracle chain -- MOG2 restatement (C) -> detect_objects_ir / merge_components
+(NumPy, both pinned by the reference-generated ir_detect_golden.json) -> NumPy uint8-wrapping delta variance -> the
+association restatement (pinned by the thermal goldens) with the IR TrackingConfig.  What no reference run can pin
+(its own frame loop raises at this snapshot, see cpx/track/irtrackextractor.py) is stated there.  Plus the mixed
+lepton3.5 + IR batch of configs[4]: both cameras' clips on one GPU, each equal to its own single-camera run."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def ir_video(seed, n=60, blobs=2):
+    rng = np.random.default_rng(seed)
+    H, W = 480, 640
+    yy, xx = np.mgrid[0:H, 0:W]
+    scene = (90 + 40 * np.sin(xx / 37.0) * np.cos(yy / 53.0) + rng.normal(0, 6, (H, W))).clip(0, 255)
+    frames = np.empty((n, H, W), np.uint8)
+    objs = []
+    for _ in range(blobs):
+        objs.append(dict(x=float(rng.uniform(-80, 100)), y=float(rng.uniform(120, 330)), w=int(rng.integers(70, 130)),
+                         h=int(rng.integers(50, 90)), vx=float(rng.uniform(6, 11)), vy=float(rng.uniform(-1.5, 1.5)),
+                         start=int(rng.integers(3, 15)), level=int(rng.integers(200, 250))))
+    for t in range(n):
+        f = scene + rng.normal(0, 2.0, (H, W))
+        for o in objs:
+            if t < o["start"]:
+                continue
+            x0, y0 = int(o["x"] + o["vx"] * (t - o["start"])), int(o["y"] + o["vy"] * (t - o["start"]))
+            xa, xb, ya, yb = max(x0, 0), min(x0 + o["w"], W), max(y0, 0), min(y0 + o["h"], H)
+            if xa < xb and ya < yb:
+                f[ya:yb, xa:xb] = o["level"] + rng.normal(0, 3.0, (yb - ya, xb - xa))
+        frames[t] = f.clip(0, 255).astype(np.uint8)
+    return frames
+
+
+def _ir_oracle_config():
+    import track_oracle as to
+
+    cfg = to.OracleConfig("lepton3")
+    # the reference's IR TrackingConfig (config/trackingconfig.py:179-208)
+    cfg.edge_pixels, cfg.frame_padding, cfg.min_dimension = 0, 10, 10
+    cfg.aoi_min_mass, cfg.aoi_pixel_variance, cfg.filter_regions_pre_match = 0, 0, False
+    cfg.base_distance_change, cfg.min_mass_change, cfg.mass_change_percent = 12000, None, None
+    cfg.max_distance, cfg.velocity_multiplier, cfg.base_velocity, cfg.fps = 30752, 8, 10, 10
+    return cfg
+
+
+def _oracle_ir_track(frames):
+    import ir_oracle as iro
+    import mog2_oracle as mo
+    import track_oracle as to
+
+    cfg = _ir_oracle_config()
+    H, W = frames.shape[1:]
+    crop = (0, 0, W, H)
+    bg = mo.MOG2(W, H, history=1000)
+    bg.apply(frames[0], 1)            # start_tracking: set_background(background_frame), learning rate 1
+    state = dict(cfg=cfg, crop=crop, active=[], tracks=[], next_id=1, filtered=[])
+    history = []
+    for q, frame in enumerate(frames):
+        mask = bg.apply(frame, -1)
+        _, _, stats = iro.detect_objects_ir(mask, threshold=0)
+        merged = iro.merge_components(list(stats[1:]))
+        delta = None
+        prev_i = q - 1 if q < 10 else 10
+        want = q - prev_i
+        if prev_i != q and want != q and 0 <= want < q:
+            delta = np.abs(frame - frames[want])          # uint8 arithmetic wraps, as in the reference
+        st = np.array([[int(v) for v in m[:5]] for m in merged], np.int64).reshape(-1, 5)
+        cents = [[int(m[0] + m[2] / 2), int(m[1] + m[3] / 2)] for m in merged]
+        regions = to.regions_of_interest(st, cents, delta, q, cfg, crop)
+        to.apply_matchings(state, regions)
+        history.append(regions)
+    for t in state["tracks"]:
+        t.trim()
+    return history, state["tracks"]
+
+
+def _rt(r):
+    return (int(r.x), int(r.y), int(r.width), int(r.height), int(r.mass), bool(r.blank))
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_ir_tracker_matches_oracle_chain(seed):
+    from cpx.config import Config
+    from cpx.track.clip import Clip
+    from cpx.track.irtrackextractor import IRTrackExtractor
+
+    frames = ir_video(seed)
+    cfg = Config.get_defaults()
+    ex = IRTrackExtractor(cfg.tracking, max_frames=frames.shape[0] + 4)
+    clip = Clip(ex.config, "synthetic-ir.mp4", type="IR")
+    clip.frames_per_second = 10
+    assert ex.parse_frames(clip, frames)
+    history, tracks = _oracle_ir_track(frames)
+    assert len(clip.region_history) == len(history) == frames.shape[0]
+    n_regions = 0
+    for q, (got, want) in enumerate(zip(clip.region_history, history)):
+        assert [_rt(r) for r in got] == [_rt(r) for r in want], q
+        for a, b in zip(got, want):
+            assert abs(float(a.pixel_variance) - float(b.pixel_variance)) <= 1e-9 * max(1.0, float(b.pixel_variance)), q
+            assert list(a.centroid) == list(b.centroid)
+        n_regions += len(got)
+    assert n_regions >= 40
+    got_tracks = sorted(clip.tracks, key=lambda t: t.get_id())
+    want_tracks = sorted(tracks, key=lambda t: t.id)
+    assert [t.get_id() for t in got_tracks] == [t.id for t in want_tracks] and len(got_tracks) >= 1
+    for a, b in zip(got_tracks, want_tracks):
+        assert a.start_frame == b.start_frame
+        assert [_rt(r) for r in a.bounds_history] == [_rt(r) for r in b.bounds], a.get_id()
+    assert clip.background is not None and clip.background.shape == (480, 640)
+    ex.close()
+
+
+def test_mixed_lepton35_and_ir_batch():
+    """BASELINE configs[4]: lepton3.5 160 x 120 clips and 640 x 480 IR videos handled side by side on one GPU -- the
+    thermal clips as one device batch, the IR videos through the IR tracker -- each result equal to the same clip run
+    alone."""
+    from cpx import synth
+    from cpx.config import Config
+    from cpx.engine import TrackEngine
+    from cpx.track.clip import Clip
+    from cpx.track.irtrackextractor import IRTrackExtractor
+
+    rng = np.random.default_rng(8)
+    T = 50
+    thermal = [synth.make_clip(rng, T, model="lepton3.5", max_blobs=3) for _ in range(4)]
+    ir = [ir_video(21, n=30, blobs=1), ir_video(22, n=30, blobs=2)]
+    cfg = Config.get_defaults()
+    eng = TrackEngine(model="lepton3.5", max_frames=T)
+    offs = (np.arange(5) * T).astype(np.int32)
+    meta = np.concatenate([eng.make_meta(T) for _ in range(4)])
+    dev = eng.upload_frames(np.concatenate(thermal))
+    # interleave: thermal batch enqueued, IR videos tracked meanwhile on their own handles, then the batch is read
+    res = eng.track_batch(dev, offs, meta, want_labels=True, want_filtered=True)
+    ir_clips = []
+    for k, frames in enumerate(ir):
+        ex = IRTrackExtractor(cfg.tracking, max_frames=40)
+        clip = Clip(ex.config, "ir-%d.mp4" % k, type="IR")
+        clip.frames_per_second = 10
+        ex.parse_frames(clip, frames)
+        ir_clips.append((clip, ex))
+    res.check()
+    labels, filt = res.labels(), res.filtered()
+    for b in range(4):   # every thermal clip of the mixed run == the clip alone
+        solo = eng.track_batch(eng.upload_frames(thermal[b]), np.array([0, T], np.int32), eng.make_meta(T),
+                               want_labels=True, want_filtered=True)
+        assert np.array_equal(solo.labels(), labels[b * T:(b + 1) * T])
+        assert np.array_equal(solo.filtered(), filt[b * T:(b + 1) * T])
+    for (clip, ex), frames in zip(ir_clips, ir):   # every IR video == the oracle chain
+        history, tracks = _oracle_ir_track(frames)
+        assert [[_rt(r) for r in g] for g in clip.region_history] == [[_rt(r) for r in w] for w in history]
+        assert sorted(len(t.bounds_history) for t in clip.tracks) == sorted(len(t.bounds) for t in tracks)
+        ex.close()
+    eng.close()
