@@ -57,7 +57,9 @@ extern "C" int final_host_clip(const cpx_filter_params* fp, const cpx_region* po
   FinalScratch sc{d.data(), f.data()};
   finalize_clip(*fp, pool, recs, n_tracks, proc_ffc, 5, out, counts, sc);
   const int prefix[4] = {0, 0, 0, 0};
-  plan_clip(*fp, pool, out, n_tracks, proc_ffc, proc_idx, 5, 0, prefix, refs, track_offsets, reqs, sample_track, track_clip);
+  std::vector<unsigned char> taken((size_t)max_frames + 16);
+  plan_clip(*fp, pool, out, n_tracks, proc_ffc, proc_idx, 5, 0, prefix, refs, track_offsets, reqs, sample_track, track_clip,
+            taken.data());
   track_offsets[counts[0]] = counts[1];
   return 0;
 }
