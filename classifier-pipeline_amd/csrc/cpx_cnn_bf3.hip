@@ -290,27 +290,48 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT / 128, CT
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // two loops, not one with a conditional residual load inside: a load in the loop makes the compiler wait for
+      // vmcnt(0) before every store, i.e. for the PREVIOUS store to complete -- four serialized round trips per tile
+      // (seen in the ISA and as 5-8 k cycles of epilogue in the stamps).  Without loads the four stores go out back
+      // to back.
+      if (res_n) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int f = it * 64 + lane;
-        const int i = f >> 3, c4 = f & 7;
-        const int oy = oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = ox0 + i % TW;
-        if (oy < a.Ho && ox < a.Wo) {
-          float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
-          const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
-          if (res_n) {
+        for (int it = 0; it < 4; ++it) {
+          const int f = it * 64 + lane;
+          const int i = f >> 3, c4 = f & 7;
+          const int oy = oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = ox0 + i % TW;
+          if (oy < a.Ho && ox < a.Wo) {
+            float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
+            const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
             const float4 rv = *reinterpret_cast<const float4*>(res_n + o);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            if (a.relu) {
+              v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            }
+            *reinterpret_cast<float4*>(out_n + o) = v;
           }
-          if (a.relu) {
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int f = it * 64 + lane;
+          const int i = f >> 3, c4 = f & 7;
+          const int oy = oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = ox0 + i % TW;
+          if (oy < a.Ho && ox < a.Wo) {
+            float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
+            const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+            if (a.relu) {
+              v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            }
+            *reinterpret_cast<float4*>(out_n + o) = v;
           }
-          *reinterpret_cast<float4*>(out_n + o) = v;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (m + 1 < NTM || t + 1 < NTN) {  // the wave's LDS tile is reused by the next accumulator tile
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
   }
 }
@@ -504,24 +525,43 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (res_n) {  // (two loops: see conv_bf3_kernel)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int f = it * 64 + lane;
-      const int i = f >> 3, c4 = f & 7;
-      const int p = p0 + wave * 32 + i;
-      if (p < M) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + i * 32 + 4 * c4);
-        const int o = p * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
-        if (res_n) v += *reinterpret_cast<const f32x4*>(res_n + o);
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+      for (int it = 0; it < 4; ++it) {
+        const int f = it * 64 + lane;
+        const int i = f >> 3, c4 = f & 7;
+        const int p = p0 + wave * 32 + i;
+        if (p < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + i * 32 + 4 * c4);
+          const int o = p * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+          v += *reinterpret_cast<const f32x4*>(res_n + o);
+          if (a.relu) {
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(out_n + o) = v;
         }
-        *reinterpret_cast<f32x4*>(out_n + o) = v;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int f = it * 64 + lane;
+        const int i = f >> 3, c4 = f & 7;
+        const int p = p0 + wave * 32 + i;
+        if (p < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + i * 32 + 4 * c4);
+          const int o = p * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+          if (a.relu) {
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(out_n + o) = v;
+        }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t + 1 < NTN) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
 }
 

@@ -1,4 +1,4 @@
-"""Builds profiles/r01_e2e_pmc.json from the rocprofv3 counter CSVs of four passes (run on the GPU box from the repo
+"""Builds profiles/<round>_e2e_pmc.json (round = $CPX_ROUND, default r02) from the rocprofv3 counter CSVs of four passes (run on the GPU box from the repo
 root, after `cd /tmp && export TMPDIR=/tmp && cd -`):
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_e2e_fetch -- python3 bench.py --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
@@ -15,6 +15,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("CPX_ROUND", "r02")
 
 
 def rows(dirname, counter, kernel_sub, phase=None):
@@ -81,7 +82,7 @@ if glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_trk_fetch", "*", "*_counter_c
     out["frame_kernel_track"] = section(
         "cpx_frame_kernel, 1024 clip-frames per launch, label image written (BASELINE configs[1])", "pmc_trk_fetch",
         "pmc_trk_write", "cpx_frame_kernel", None, 1024, "clip-frames", 614400 * 1024, "SURVEY 8(d): 614,400 B per frame")
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_e2e_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", ROUND + "_e2e_pmc.json"), "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict):
         print(k, "traffic/algorithmic = %.3f" % v["traffic_over_algorithmic"])
