@@ -49,6 +49,7 @@ struct cpx_handle {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
   int split_min_clips = 0;  // 0 = never split
+  bool track_per_step = false;  // CPX_TRACK_PER_STEP=1: one launch per frame step (the form before the per-clip walk)
   std::vector<struct cpx_cnn*> cnns;  // networks created on this handle (destroyed with it)
   std::vector<struct cpx_mog2*> mog2s;  // background models created on this handle
   int stream_frames = -1;
@@ -137,7 +138,7 @@ WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
 }
 
 struct Schedule {
-  std::vector<int> clip_first, proc_off, proc_idx, proc_ffc;
+  std::vector<int> clip_first, proc_off, proc_idx, proc_ffc, order;
   int total = 0, max_proc = 0;
 };
 
@@ -165,13 +166,19 @@ int build_schedule(cpx_handle* h, const int32_t* clip_offsets, const cpx_frame_m
     if (np > h->cfg.max_frames) return fail(h, CPX_ERR_INVALID, "clip longer than max_frames");
     sc->max_proc = std::max(sc->max_proc, np);
   }
+  // longest clips first: one workgroup walks a whole clip, and the dispatcher hands out workgroups in index order
+  sc->order.resize(B);
+  for (int b = 0; b < B; ++b) sc->order[b] = b;
+  std::stable_sort(sc->order.begin(), sc->order.end(), [&](int x, int y) {
+    return sc->proc_off[x + 1] - sc->proc_off[x] > sc->proc_off[y + 1] - sc->proc_off[y];
+  });
   return CPX_OK;
 }
 
-// layout in sched_dev: clip_first[B] | proc_off[B+1] | proc_idx[n] | proc_ffc[n]
+// layout in sched_dev: clip_first[B] | proc_off[B+1] | proc_idx[n] | proc_ffc[n] | order[B]
 int upload_schedule(cpx_handle* h, const Schedule& sc, int B) {
   const int n = std::max((int)sc.proc_idx.size(), 1);
-  const size_t ints = (size_t)B + (B + 1) + 2 * (size_t)n;
+  const size_t ints = (size_t)B + (B + 1) + 2 * (size_t)n + (size_t)B;
   if (ints > h->sched_ints) {
     if (h->sched_dev) hipFree(h->sched_dev);
     h->sched_dev = nullptr;
@@ -185,6 +192,7 @@ int upload_schedule(cpx_handle* h, const Schedule& sc, int B) {
   std::copy(sc.proc_off.begin(), sc.proc_off.end(), flat.begin() + B);
   std::copy(sc.proc_idx.begin(), sc.proc_idx.end(), flat.begin() + B + (B + 1));
   std::copy(sc.proc_ffc.begin(), sc.proc_ffc.end(), flat.begin() + B + (B + 1) + n);
+  std::copy(sc.order.begin(), sc.order.end(), flat.begin() + B + (B + 1) + 2 * (size_t)n);
   CPX_HIP(h, hipMemcpyAsync(h->sched_dev, flat.data(), ints * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CPX_HIP(h, hipStreamSynchronize(h->stream));  // `flat` dies with this scope
   return CPX_OK;
@@ -258,6 +266,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     return CPX_ERR_HIP;
   }
   if (const char* env = std::getenv("CPX_TRACK_SPLIT_MIN_CLIPS")) h->split_min_clips = std::atoi(env);
+  if (const char* env = std::getenv("CPX_TRACK_PER_STEP")) h->track_per_step = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_FUSE_SHORTCUT")) h->fuse_shortcut = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_MATH")) {
     if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
@@ -379,6 +388,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.proc_off = h->sched_dev + B;
   a.proc_idx = h->sched_dev + B + (B + 1);
   a.proc_ffc = h->sched_dev + B + (B + 1) + std::max(nproc_total, 1);
+  a.order = h->sched_dev + B + (B + 1) + 2 * (size_t)std::max(nproc_total, 1);
   a.wtab = h->wtab_dev;
   char* base = (char*)h->ws;
   a.bg = (uint16_t*)(base + l.bg);
@@ -418,26 +428,38 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
     CPX_HIP(h, hipStreamSynchronize(h->stream));  // the staged vectors die here
     h->staged_bg.clear();
   }
-  CPX_HIP(h, hipEventRecord(h->ev0, h->stream));
+  // medians of all new frames first (independent of the clips' frame order; the frame kernel copies them into the
+  // records it writes).  Grid y = clip: 65535 clips per launch at most
+  if (B > 65535) return fail(h, CPX_ERR_INVALID, "more than 65535 clips in one batch");
+  cpx::launch_median(a, B, t_begin, max_proc, h->stream);
+  CPX_HIP(h, hipEventRecord(h->ev0, h->stream));  // (ev0 .. ev1 bracket the frame / NLM kernels)
   // (with the internal ping-pong of filtered frames the back half of step t would read what the front half of
   // step t+1 overwrites: split only when the caller keeps every filtered frame)
   const bool split = !c.denoise && !need_filt && h->split_min_clips > 0 && B >= h->split_min_clips &&
                      max_proc - t_begin > 2;
-  for (int t = t_begin; t < max_proc; ++t) {
-    if (split) {
-      // front(t) reuses the hand-over slot that back(t - 2) read
-      if (t - t_begin >= 2) CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_back[t & 1], 0));
-      cpx::launch_frame(a, B, t, 1, h->stream);
-      CPX_HIP(h, hipEventRecord(h->ev_front[t & 1], h->stream));
-      CPX_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_front[t & 1], 0));
-      cpx::launch_frame(a, B, t, 2, h->stream2);
-      CPX_HIP(h, hipEventRecord(h->ev_back[t & 1], h->stream2));
-    } else if (!c.denoise) {
-      cpx::launch_frame(a, B, t, 0, h->stream);
-    } else {  // front (normalise) -> non-local means -> back (blur / threshold / label / statistics)
-      cpx::launch_frame(a, B, t, 1, h->stream);
-      cpx::launch_nlm(a, B, t, h->stream);
-      cpx::launch_frame(a, B, t, 2, h->stream);
+  int launches = 0;
+  if (!split && !c.denoise && !h->track_per_step) {
+    // one workgroup per clip walks its frames: a single launch, no phase lockstep between the clips (cpx_track.hip)
+    cpx::launch_frame(a, B, t_begin, max_proc, 0, h->stream);
+    launches = 1;
+  } else {
+    for (int t = t_begin; t < max_proc; ++t) {
+      if (split) {
+        // front(t) reuses the hand-over slot that back(t - 2) read
+        if (t - t_begin >= 2) CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_back[t & 1], 0));
+        cpx::launch_frame(a, B, t, t + 1, 1, h->stream);
+        CPX_HIP(h, hipEventRecord(h->ev_front[t & 1], h->stream));
+        CPX_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_front[t & 1], 0));
+        cpx::launch_frame(a, B, t, t + 1, 2, h->stream2);
+        CPX_HIP(h, hipEventRecord(h->ev_back[t & 1], h->stream2));
+      } else if (!c.denoise) {
+        cpx::launch_frame(a, B, t, t + 1, 0, h->stream);
+      } else {  // front (normalise) -> non-local means -> back (blur / threshold / label / statistics)
+        cpx::launch_frame(a, B, t, t + 1, 1, h->stream);
+        cpx::launch_nlm(a, B, t, h->stream);
+        cpx::launch_frame(a, B, t, t + 1, 2, h->stream);
+      }
+      ++launches;
     }
   }
   if (split) {  // everything enqueued later on the handle's stream sees the last back halves
@@ -445,7 +467,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
     if (max_proc - t_begin >= 2) CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_back[(max_proc - 2) & 1], 0));
   }
   CPX_HIP(h, hipEventRecord(h->ev1, h->stream));
-  h->last_launches = max_proc - t_begin;
+  h->last_launches = launches;
   h->timing_valid = true;
   if (background_dev) cpx::launch_export_background(a, B, background_dev, h->stream);
   CPX_HIP(h, hipGetLastError());

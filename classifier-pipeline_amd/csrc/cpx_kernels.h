@@ -68,6 +68,7 @@ struct TrackArgs {
   const int* proc_off;      // [B+1] offsets into proc_idx
   const int* proc_idx;      // [total_proc] frame index (into frames) of each processed frame
   const int* proc_ffc;      // [total_proc] is_affected_by_ffc
+  const int* order;         // [B] clips by falling number of processed frames (workgroup index -> clip), or nullptr
   const double* wtab;       // [max_frames+2] k-fold float64 accumulation of weight_add
   // per-clip state
   int nlm_flip;             // 1: a denoiser wrote the hand-over image into the other slot (back half reads that)
@@ -292,8 +293,9 @@ int track_max_pixels();
 int track_lds_components();
 int frame_kernel_attr_setup();
 void launch_init(const TrackArgs& a, int B, int keep, hipStream_t s);
-void launch_frame(const TrackArgs& a, int B, int t, int mode, hipStream_t s);
+void launch_frame(const TrackArgs& a, int B, int t0, int t1, int mode, hipStream_t s);  // processed frames [t0, t1) of every clip
 void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s);
+void launch_median(const TrackArgs& a, int B, int t0, int t1, hipStream_t s);  // thermal medians of processed frames [t0, t1) -> FrameInfo
 size_t nlm_lds_bytes(int W, int H);
 int nlm_supported(int W, int H);
 void launch_export_background(const TrackArgs& a, int B, float* out, hipStream_t s);

@@ -43,6 +43,16 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// uniform base + 32-bit unsigned byte offset: the form the compiler turns into `global_load v, v_off, s[base]`
+// (one offset register per lane instead of a 64-bit address pair per array: the streaming pass touches seven arrays)
+template <typename T>
+__device__ __forceinline__ T* at_off(T* base, unsigned bytes) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + bytes);
+}
+template <typename T>
+__device__ __forceinline__ const T* at_off(const T* base, unsigned bytes) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + bytes);
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -67,6 +77,64 @@ __device__ __forceinline__ T wave_max(T v) {
     v = w > v ? w : v;
   }
   return v;
+}
+
+// 32-bit reductions of a fully active wave on the DPP network (no LDS traffic, unlike the ds_bpermute behind
+// __shfl_xor): butterflies inside quads, mirrors inside rows of 16, then row broadcasts; the total lands in lane 63
+// and comes back as a scalar.  OP(x, x) must be x-neutral for `self` as the fill value (min / max / or), sums fill 0.
+#define CPX_DPP_STEP(OP, X, FILL, CTRL, ROWMASK) X = OP(X, __builtin_amdgcn_update_dpp(FILL, X, CTRL, ROWMASK, 0xF, false))
+#define CPX_DPP_REDUCE(OP, X, FILL)             \
+  CPX_DPP_STEP(OP, X, FILL, 0xB1, 0xF);  /* quad_perm [1,0,3,2] */ \
+  CPX_DPP_STEP(OP, X, FILL, 0x4E, 0xF);  /* quad_perm [2,3,0,1] */ \
+  CPX_DPP_STEP(OP, X, FILL, 0x141, 0xF); /* row_half_mirror */     \
+  CPX_DPP_STEP(OP, X, FILL, 0x140, 0xF); /* row_mirror */          \
+  CPX_DPP_STEP(OP, X, FILL, 0x142, 0xA); /* row_bcast:15 -> rows 1, 3 */ \
+  CPX_DPP_STEP(OP, X, FILL, 0x143, 0xC); /* row_bcast:31 -> rows 2, 3 */
+__device__ __forceinline__ int dpp_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int dpp_imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int dpp_imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int dpp_umin(int a, int b) { return (u32)a < (u32)b ? a : b; }
+__device__ __forceinline__ int dpp_umax(int a, int b) { return (u32)a > (u32)b ? a : b; }
+__device__ __forceinline__ int wave_sum(int v) {
+  CPX_DPP_REDUCE(dpp_add, v, 0)
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) { return (u32)wave_sum((int)v); }
+__device__ __forceinline__ int wave_min(int v) {
+  CPX_DPP_REDUCE(dpp_imin, v, v)
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max(int v) {
+  CPX_DPP_REDUCE(dpp_imax, v, v)
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ u32 wave_min(u32 v) {
+  int x = (int)v;
+  CPX_DPP_REDUCE(dpp_umin, x, x)
+  return (u32)__builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ u32 wave_max(u32 v) {
+  int x = (int)v;
+  CPX_DPP_REDUCE(dpp_umax, x, x)
+  return (u32)__builtin_amdgcn_readlane(x, 63);
+}
+// lanes of a fully active wave for which `pred` holds (a scalar: one compare + s_bcnt1 per call)
+__device__ __forceinline__ u32 wave_count(bool pred) { return (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
+// the same for both 16-bit halves of a packed register against a uniform bound: how many halves of the wave are
+// <= bound.  Written out because the compiler, given ballots, issues every compare of an unrolled loop first and
+// spills the lane masks (v_writelane per mask); here a mask lives in VCC for one instruction, and the halves are
+// selected by the compare itself (SDWA), so the packed registers are never unpacked.
+__device__ __forceinline__ u32 wave_count_le_halves(u32 packed, u32 bound) {
+  u32 c0, c1;
+  asm volatile(
+      "v_cmp_ge_u32_sdwa vcc, %2, %3 src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "s_bcnt1_i32_b64 %0, vcc\n\t"
+      "v_cmp_ge_u32_sdwa vcc, %2, %3 src0_sel:DWORD src1_sel:WORD_1\n\t"
+      "s_bcnt1_i32_b64 %1, vcc"
+      : "=&s"(c0), "=&s"(c1)
+      : "s"(bound), "v"(packed)
+      : "vcc", "scc");
+  return c0 + c1;
 }
 
 // ---- bit-row helpers (rows are RW little-endian 64-bit words, bit x = pixel x) ----
@@ -186,20 +254,41 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a, int keep) {
 // mode 0: whole frame step.  With denoise the step is split around the NLM kernel: mode 1 = front
 // (phases 1-3: streaming pass, normalised uint8 image -> HBM), mode 2 = back (phases 4-8 on the
 // denoised image); the scalars crossing the split travel in FrameCarry.
-__global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_kernel(TrackArgs a, int t, int mode) {
-  const int b = blockIdx.x;
-  const int pbase = a.proc_off[b];
-  const int nproc = a.proc_off[b + 1] - pbase;
-  if (t >= nproc) return;
-
+namespace {
+// one processed frame (number t) of clip b; cs = the clip's state before / after the frame (uniform)
+// values every lane holds alike (read from LDS or through a vector load) -> scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+  const long long q = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(q & 0xFFFFFFFFll)), hi = __builtin_amdgcn_readfirstlane((int)(q >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ ClipState uniform_state(const ClipState& s) {
+  ClipState o;
+  o.bg_average = uni(s.bg_average);
+  o.prev_fmin = uni(s.prev_fmin);
+  o.prev_fmax = uni(s.prev_fmax);
+  o.has_prev = uni(s.has_prev);
+  o.n_done = uni(s.n_done);
+  return o;
+}
+// (the arguments are read through the kernel-argument segment, see the kernel below)
+typedef __attribute__((address_space(4))) const TrackArgs KernArgs;
+__device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int pbase, const int t, const int mode,
+                                           ClipState& cs, unsigned char* smem) {
   const int W = a.W, H = a.H, P = W * H, e = a.edge;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // opaque per frame: otherwise everything that depends only on the thread index (pixel coordinates, clamps, row
+  // tests of every chunk) is hoisted out of the frame loop and kept live across it -- 100 bytes of scratch per lane
+  int tid_ = threadIdx.x;
+#ifndef CPX_EXP_NO_LAUNDER
+  asm volatile("" : "+v"(tid_));
+#endif
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const int SW = W >> 1;  // run-start slots per row
   const int nchunk = P >> 2;
 
   // ---- LDS ---------------------------------------------------------------
   // everything is carved from one dynamic region so that its base stays 16-byte aligned
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [0, P)            u8 image           | later: component id per slot (u16 [H*SW])
   // [P, 3P)           u16 h-blur         | later: union-find parents (u32 [H*SW])
   unsigned char* s_u8 = smem;
@@ -236,7 +325,6 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     filt_cur = a.filt_state + ((size_t)b * 2 + (t & 1)) * P;
     filt_prev = a.filt_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
   }
-  ClipState cs = a.cstate[b];
   // who owns the background (include/cpx.h, CPX_TRACK_*): a frozen frame leaves background, weights and average as
   // they are (post_process_file skips FFC-affected frames, clipclassifier.py:510-511; update_background = False)
   const bool freeze = (a.flags & CPX_TRACK_FREEZE_BACKGROUND) ||
@@ -246,30 +334,32 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   const int slot = t & 1;
   if (mode == 1) cs.bg_average = a.bgavg[b];
 
+#define CPX_STOP(n)                                                                                   \
+  if (CPX_TIMING_STOP_AFTER == (n)) {                                                                 \
+    if (tid == 0) a.info_out[fidx].threshold = thresh + (float)ithr + (float)s_u8[avg_change & 1023] + (float)s_rowE[5] + (float)(mn + mx);  \
+    return;                                                                                           \
+  }
+#ifndef CPX_TIMING_STOP_AFTER
+#define CPX_TIMING_STOP_AFTER 0  // timing experiments only: 1..8 = return after that phase (1 = thermal load + median, 2 = streaming pass)
+#endif
   int avg_change = 0, mn = 0, mx = 0, ithr = 0;
   float thresh = 0.0f;
   if (mode != 2) {
-  // ---- phase 1a: thermal frame -> registers (2 pixels per VGPR), sum / min / max ----------------
-  u32 pk[NCH][2];
+  // ---- phase 1a: thermal frame -> LDS (phase 1b reads it there), sum / min / max ----------------
+  // (np.median(thermal) of ClipStats is not on the dependency chain of the clip's frames: cpx_median_kernel
+  // computes it for all frames at once and the record at the end of the step picks it up)
   {
     u32 sumpix = 0, minpix = 0xFFFFFFFFu, maxpix = 0;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * NT;
       if (c < nchunk) {
-        const uint2 q = *reinterpret_cast<const uint2*>(F + (c << 2));
-        pk[i][0] = q.x;
-        pk[i][1] = q.y;
-        *reinterpret_cast<uint2*>(s_tmp + (c << 2)) = q;  // phase 1b re-reads it from LDS (rolled loop)
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-          const u32 val = (hh & 1) ? (pk[i][hh >> 1] >> 16) : (pk[i][hh >> 1] & 0xFFFFu);
-          sumpix += val;
-          minpix = min(minpix, val);
-          maxpix = max(maxpix, val);
-        }
-      } else {
-        pk[i][0] = pk[i][1] = 0xFFFFFFFFu;  // padding: 65535, never below a bisection candidate
+        const uint2 q = *reinterpret_cast<const uint2*>(at_off(F, (unsigned)c << 3));
+        *reinterpret_cast<uint2*>(s_tmp + (c << 2)) = q;
+        const u32 v0 = q.x & 0xFFFFu, v1 = q.x >> 16, v2 = q.y & 0xFFFFu, v3 = q.y >> 16;
+        sumpix += v0 + v1 + v2 + v3;
+        minpix = min(min(minpix, v0), min(v1, min(v2, v3)));
+        maxpix = max(max(maxpix, v0), max(v1, max(v2, v3)));
       }
     }
     sumpix = wave_sum(sumpix);
@@ -292,73 +382,15 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     minpix = min(minpix, s_red[w].minpix);
     maxpix = max(maxpix, s_red[w].maxpix);
   }
+  // (the same in every lane: keep them in scalar registers)
+  sumpix = (u32)uni((int)sumpix);
+  minpix = (u32)uni((int)minpix);
+  maxpix = (u32)uni((int)maxpix);
   // avg_change = int(round(np.average(thermal) - background.average))  (cliptracker.py:103-105)
   const double mean_thermal = (double)sumpix / (double)P;
   avg_change = (int)rint(mean_thermal - cs.bg_average);
 
-  // ---- np.median(thermal) (clip.py:475): exact selection by bisection on the value range, counting
-  // in registers; median = mean of the two middle order statistics ---------------------------------
-  {
-    float median;
-    u32 lo = minpix, hi = maxpix;
-    const u32 k1 = (u32)((P - 1) >> 1), k2 = (u32)(P >> 1);
-    int par = 0;
-#ifdef CPX_TIMING_NO_MEDIAN  // timing experiments only: wrong medians
-    lo = hi;
-#endif
-    while (lo < hi) {  // uniform: every thread sees the same block totals
-      const u32 mid = (lo + hi) >> 1;
-      u32 cnt = 0;
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        // opaque to the optimiser: otherwise the 20 unpacked halves are hoisted out of the bisection loop and the
-        // extra live registers spill (60 bytes of scratch per lane = +20 % HBM traffic of this HBM-bound kernel)
-        asm volatile("" : "+v"(pk[i][0]), "+v"(pk[i][1]));
-        cnt += ((pk[i][0] & 0xFFFFu) <= mid) + ((pk[i][0] >> 16) <= mid) + ((pk[i][1] & 0xFFFFu) <= mid) +
-               ((pk[i][1] >> 16) <= mid);
-      }
-      cnt = wave_sum(cnt);
-      if (lane == 0) s_cnt[par * NWAVE + wave] = cnt;
-      __syncthreads();
-      u32 tot = 0;
-#pragma unroll
-      for (int w = 0; w < NWAVE; ++w) tot += s_cnt[par * NWAVE + w];
-      par ^= 1;
-      if (tot >= k1 + 1) hi = mid;
-      else lo = mid + 1;
-    }
-    // lo = value of rank k1; rank k2 is the same value unless exactly k1+1 pixels are <= lo
-    u32 cnt = 0, nxt = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-#pragma unroll
-      for (int hh = 0; hh < 4; ++hh) {
-        const u32 val = (hh & 1) ? (pk[i][hh >> 1] >> 16) : (pk[i][hh >> 1] & 0xFFFFu);
-        cnt += (val <= lo);
-        nxt = (val > lo && val < nxt) ? val : nxt;
-      }
-    }
-    cnt = wave_sum(cnt);
-    nxt = wave_min(nxt);
-    if (lane == 0) {
-      s_cnt[par * NWAVE + wave] = cnt;
-      s_cnt[2 * NWAVE + wave] = nxt;
-    }
-    __syncthreads();
-    u32 tot = 0, mnx = 0xFFFFFFFFu;
-#pragma unroll
-    for (int w = 0; w < NWAVE; ++w) {
-      tot += s_cnt[par * NWAVE + w];
-      mnx = min(mnx, s_cnt[2 * NWAVE + w]);
-    }
-    // (padding lanes hold 65535: they only count when lo == 65535, where both ranks are 65535 anyway)
-    const u32 v2 = (tot >= k2 + 1 || lo == 65535u) ? lo : mnx;
-    median = 0.5f * (float)(lo + v2);
-    // park it in LDS now: otherwise the compiler sinks this whole reduction to the kernel's end and
-    // spills the 32 partials it needs for it
-    if (tid == 0) reinterpret_cast<float*>(s_bc)[2] = median;
-  }
-
+  CPX_STOP(1)
   // ---- phase 1b: the streaming pass over the clip state -----------------------------------------------
   // x = max(thermal - background - avg_change, 0) goes to LDS as 17 bits (u16 plane + 1-bit-in-a-byte plane)
   Red1 r;
@@ -370,6 +402,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   r.sumbg = 0;
   r.changed = 0;
   r.sumabs = 0;
+  u32 sabs = 0;  // this lane's share of sum |filtered|: <= 20 pixels x 65535
   mn = 0x7FFFFFFF;
   mx = 0;
   // deliberately NOT unrolled: the body is long, and an unrolled version keeps 30 precomputed 64-bit
@@ -378,6 +411,10 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   for (int c = tid; c < nchunk; c += NT) {
     {
       const int p0 = c << 2;
+      // opaque: otherwise loop strength reduction turns every store stream into its own 64-bit pointer induction
+      // variable (two registers each) instead of base + offset addressing
+      unsigned p0u = (unsigned)p0;
+      asm volatile("" : "+v"(p0u));
       const int y = p0 / W, x0 = p0 - y * W;
       const uint2 pq = *reinterpret_cast<const uint2*>(s_tmp + p0);
       const int pix[4] = {(int)(pq.x & 0xFFFFu), (int)(pq.x >> 16), (int)(pq.y & 0xFFFFu), (int)(pq.y >> 16)};
@@ -385,20 +422,20 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       const int cy = clampi(y, e, H - 1 - e);
       const bool row_in = (cy == y);
       if (row_in && x0 >= e && x0 + 3 <= W - 1 - e) {
-        const ushort4 q = *reinterpret_cast<const ushort4*>(bg_old + p0);
+        const ushort4 q = *reinterpret_cast<const ushort4*>(at_off(bg_old, p0u << 1));
         bgv[0] = q.x; bgv[1] = q.y; bgv[2] = q.z; bgv[3] = q.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bgv[j] = bg_old[cy * W + clampi(x0 + j, e, W - 1 - e)];
+        for (int j = 0; j < 4; ++j) bgv[j] = *at_off(bg_old, (unsigned)(cy * W + clampi(x0 + j, e, W - 1 - e)) << 1);
       }
       int oldp[4] = {0, 0, 0, 0};
       if (O) {
-        const ushort4 q = *reinterpret_cast<const ushort4*>(O + p0);
+        const ushort4 q = *reinterpret_cast<const ushort4*>(at_off(O, p0u << 1));
         oldp[0] = q.x; oldp[1] = q.y; oldp[2] = q.z; oldp[3] = q.w;
       }
-      uint4 wq = *reinterpret_cast<const uint4*>(ws + p0);
+      uint4 wq = *reinterpret_cast<const uint4*>(at_off(ws, p0u << 2));
       u32 wsv[4] = {wq.x, wq.y, wq.z, wq.w};
-      ushort4 kq = *reinterpret_cast<const ushort4*>(kc + p0);
+      ushort4 kq = *reinterpret_cast<const ushort4*>(at_off(kc, p0u << 1));
       int kv[4] = {kq.x, kq.y, kq.z, kq.w};
       int nb[4];
       float fo[4];
@@ -409,7 +446,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
         fo[j] = (float)d;
         r.fmin = min(r.fmin, d);
         r.fmax = max(r.fmax, d);
-        r.sumabs += (u64)(d < 0 ? -d : d);
+        sabs += (u32)(d < 0 ? -d : d);
         int xs = d - avg_change;  // cliptracker.py:109-114
         xs = xs < 0 ? 0 : xs;
         mn = min(mn, xs);
@@ -445,11 +482,11 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       }
       *reinterpret_cast<uint2*>(s_tmp + p0) = make_uint2(xlo[0] | (xlo[1] << 16), xlo[2] | (xlo[3] << 16));
       *reinterpret_cast<u32*>(s_u8 + p0) = xhi[0] | (xhi[1] << 8) | (xhi[2] << 16) | (xhi[3] << 24);
-      *reinterpret_cast<float4*>(filt_cur + p0) = make_float4(fo[0], fo[1], fo[2], fo[3]);
-      *reinterpret_cast<uint4*>(ws + p0) = make_uint4(wsv[0], wsv[1], wsv[2], wsv[3]);
-      *reinterpret_cast<ushort4*>(bg_new + p0) =
+      *reinterpret_cast<float4*>(at_off(filt_cur, p0u << 2)) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+      *reinterpret_cast<uint4*>(at_off(ws, p0u << 2)) = make_uint4(wsv[0], wsv[1], wsv[2], wsv[3]);
+      *reinterpret_cast<ushort4*>(at_off(bg_new, p0u << 1)) =
           make_ushort4((unsigned short)nb[0], (unsigned short)nb[1], (unsigned short)nb[2], (unsigned short)nb[3]);
-      *reinterpret_cast<ushort4*>(kc + p0) =
+      *reinterpret_cast<ushort4*>(at_off(kc, p0u << 1)) =
           make_ushort4((unsigned short)kv[0], (unsigned short)kv[1], (unsigned short)kv[2], (unsigned short)kv[3]);
     }
   }
@@ -457,7 +494,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   r.fmax = wave_max(r.fmax);
   r.sumbg = wave_sum(r.sumbg);
   r.changed = wave_max(r.changed);
-  r.sumabs = wave_sum(r.sumabs);
+  r.sumabs = (u64)wave_sum(sabs);
   mn = wave_min(mn);
   mx = wave_max(mx);
   if (lane == 0) {
@@ -482,7 +519,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     q.fmax = wave_max(q.fmax);
     q.sumbg = wave_sum(q.sumbg);
     q.changed = wave_max(q.changed);
-    q.sumabs = wave_sum(q.sumabs);
+    q.sumabs = (u64)wave_sum((u32)q.sumabs);  // <= 20480 pixels x 65535 < 2^31
     qmn = wave_min(qmn);
     qmx = wave_max(qmx);
     if (lane == 0) {
@@ -495,8 +532,9 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     }
   }
   __syncthreads();
-  mn = s_bc[0];
-  mx = s_bc[1];
+  mn = uni(s_bc[0]);
+  mx = uni(s_bc[1]);
+  CPX_STOP(2)
 
   // ---- phase 3: normalise to 0..255 (float32, imageprocessing.py:151-169) -> uint8 in LDS
   {
@@ -542,7 +580,6 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     thresh = fc.thresh;
     if (tid == 0) {
       *s_R = fc.R;
-      reinterpret_cast<float*>(s_bc)[2] = fc.median;
       *s_ncomp_p = 0;
     }
     const uint4* src = reinterpret_cast<const uint4*>(a.u8_state + ((size_t)b * 2 + (slot ^ a.nlm_flip)) * P);
@@ -562,7 +599,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       fc.mx = mx;
       fc.ithr = ithr;
       fc.thresh = thresh;
-      fc.median = reinterpret_cast<const float*>(s_bc)[2];
+      fc.median = 0.0f;  // (cpx_median_kernel writes the record's median)
       fc.pad = 0;
       fc.bg_avg_in = cs.bg_average;
       a.carry[(size_t)b * 2 + slot] = fc;
@@ -571,14 +608,6 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     }
     return;
   }
-#define CPX_STOP(n)                                                                                   \
-  if (CPX_TIMING_STOP_AFTER == (n)) {                                                                 \
-    if (tid == 0) a.info_out[fidx].threshold = thresh + (float)ithr + (float)s_u8[avg_change & 1023] + (float)s_rowE[5]; \
-    return;                                                                                           \
-  }
-#ifndef CPX_TIMING_STOP_AFTER
-#define CPX_TIMING_STOP_AFTER 0  // timing experiments only: 3..8 = return after that phase
-#endif
   CPX_STOP(3)
 
   // ---- phase 4a: horizontal [1 4 6 4 1], BORDER_REFLECT_101 -----------------------
@@ -706,7 +735,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     }
   }
   __syncthreads();
-  const int ncomp_all = (int)*s_ncomp_p;
+  const int ncomp_all = uni((int)*s_ncomp_p);
   const bool overflow = ncomp_all > CAP || ncomp_all > a.cap_out;
   const int ncomp = overflow ? 0 : ncomp_all;
 
@@ -782,7 +811,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
       } else if (nib) {
         lab[0] = (nib & 1) ? -1 : 0; lab[1] = (nib & 2) ? -1 : 0; lab[2] = (nib & 4) ? -1 : 0; lab[3] = (nib & 8) ? -1 : 0;
       }
-      *reinterpret_cast<int4*>(Lout + p0) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+      *reinterpret_cast<int4*>(at_off(Lout, (unsigned)p0 << 2)) = make_int4(lab[0], lab[1], lab[2], lab[3]);
     }
   }
 
@@ -796,7 +825,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   const double cmin = (double)s_R->fmin, cmax = (double)s_R->fmax;
   const double pmin = (double)cs.prev_fmin, pmax = (double)cs.prev_fmax;
   auto delta_at = [&](int q) -> double {
-    const float cv = filt_cur[q], pv = filt_prev[q];
+    const float cv = *at_off(filt_cur, (unsigned)q << 2), pv = *at_off(filt_prev, (unsigned)q << 2);
     float an, bn;
     if (cmax == cmin) an = (cmax == 0.0) ? 0.0f : (float)((double)cv / cmax);
     else an = (float)((255.0 * ((double)cv - cmin)) / (cmax - cmin));
@@ -870,8 +899,15 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   }
 
   // ---- per-frame record + clip state -------------------------------------------------------------------
+  const Red1 R = *s_R;  // (written two phases ago; every thread keeps the new clip state for the clip's next frame)
+  ClipState ns;
+  // motiondetector.py:224-226: average = int(round(np.average(background))) when any pixel changed
+  ns.bg_average = R.changed ? rint((double)R.sumbg / (double)((W - 2 * e) * (H - 2 * e))) : cs.bg_average;
+  ns.prev_fmin = R.fmin;
+  ns.prev_fmax = R.fmax;
+  ns.has_prev = 1;
+  ns.n_done = t + 1;
   if (tid == 0) {
-    const Red1 R = *s_R;
     FrameInfo fi;
     fi.frame_number = t;
     fi.n_components = overflow ? ncomp_all : ncomp;
@@ -886,23 +922,168 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
     fi.thermal_min = (int)R.minpix;
     fi.thermal_max = (int)R.maxpix;
     fi.thermal_sum = R.sumpix;
-    fi.thermal_median = reinterpret_cast<const float*>(s_bc)[2];
+    fi.thermal_median = a.info_out[fidx].thermal_median;  // cpx_median_kernel put it there before this kernel started
     fi.filtered_abs_sum = R.sumabs;
-    ClipState ns;
-    // motiondetector.py:224-226: average = int(round(np.average(background))) when any pixel changed
-    ns.bg_average = R.changed ? rint((double)R.sumbg / (double)((W - 2 * e) * (H - 2 * e))) : cs.bg_average;
-    ns.prev_fmin = R.fmin;
-    ns.prev_fmax = R.fmax;
-    ns.has_prev = 1;
-    ns.n_done = t + 1;
     fi.background_average = ns.bg_average;
     fi.background_changed = (int)R.changed;
     fi.reserved = 0;
     a.info_out[fidx] = fi;
     a.cstate[b] = ns;
   }
+  cs = uniform_state(ns);
+}
+}  // namespace
+
+// One workgroup per clip walks the clip's processed frames [t0, t1) in order.  Frames of a clip depend on each other
+// (background, window sum, previous filtered frame), clips do not -- so nothing orders workgroups against each
+// other, and after a few frames the streaming pass of one workgroup runs beside the labelling phases of its
+// neighbour on the CU instead of every workgroup of a per-frame launch moving through the same phase at once.
+// a.order (optional) lists the clips by falling length: the dispatcher hands out workgroups in index order.
+// The split forms (mode 1 / 2, around the NLM kernel or on two streams) are launched one step at a time.
+__global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_kernel(TrackArgs a, int t0, int t1, int mode) {
+#ifdef CPX_EXP_NO_ORDER
+  const int b = blockIdx.x;
+#else
+  const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+#endif
+  const int pbase = a.proc_off[b];
+  const int nproc = a.proc_off[b + 1] - pbase;
+  const int tend = t1 < nproc ? t1 : nproc;
+  if (t0 >= tend) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ClipState cs = uniform_state(a.cstate[b]);
+  // The frame step reads its arguments from the kernel-argument segment (TrackArgs is the first parameter) through a
+  // pointer the optimiser cannot see through: otherwise every pointer and constant of TrackArgs is hoisted out of the
+  // frame loop, kept live across it, and the scalar registers spill into vector registers and those into scratch
+  // (208 bytes per lane = +20 % HBM traffic of an HBM-bound pass).  A scalar load per use costs nothing.
+  KernArgs* ap = (KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef CPX_EXP_STAGGER
+  if (tend - t0 > 4 && blockIdx.x < 512) {  // first round of workgroups: spread their phases (units of CPX_EXP_STAGGER x 10 ns)
+    const unsigned units = ((blockIdx.x >> 3) & 7u) ^ (((blockIdx.x >> 8) & 1u) ? 4u : 0u);
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t_start < (unsigned long long)units * CPX_EXP_STAGGER) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
+  for (int t = t0; t < tend; ++t) {
+#ifndef CPX_EXP_DIRECT_ARGS
+    asm volatile("" : "+s"(ap));
+#endif
+    frame_step(*ap, b, pbase, t, mode, cs, smem);
+    if (t + 1 < tend) {
+      // the next frame reads what other threads of this workgroup wrote (clamped background edges, the previous
+      // filtered frame under a bounding box) and reuses the LDS image.  Workgroup scope is all it takes: the waves
+      // of a workgroup share the CU's write-through L1.  (An agent-scope fence here writes back and invalidates the
+      // XCD's whole L2 once per frame and workgroup: measured 4x slower.)
+      __syncthreads();
+    }
+  }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------
+// np.median(thermal) of every processed frame (ClipStats.add_frame, track/clip.py:475).  It feeds the clip statistics
+// only, so it does not have to sit on the frame-after-frame dependency chain of a clip: one 256-thread workgroup per
+// frame, all frames of the batch at once.  Exact selection by bisection on the value range with the frame in
+// registers; a step counts `value <= mid` with one compare + s_bcnt1 per register half (the wave's count is a scalar,
+// no cross-lane reduction); median = mean of the two middle order statistics.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int NT_MED = 256;
+constexpr int NW_MED = NT_MED / 64;
+constexpr int MCH = (4 * NCH * NT / 4 + NT_MED - 1) / NT_MED;  // 4-pixel chunks per thread at the largest frame
+}  // namespace
+__global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0) {
+  const int b = blockIdx.y, t = t0 + (int)blockIdx.x;
+  const int pbase = a.proc_off[b];
+  if (t >= a.proc_off[b + 1] - pbase) return;
+  const int fidx = a.proc_idx[pbase + t];
+  const int P = a.W * a.H, nchunk = P >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* F = a.frames + (size_t)fidx * P;
+  __shared__ u32 s_cnt[3 * NW_MED];
+  __shared__ u32 s_mm[2 * NW_MED];
+  u32 pk[MCH][2];
+  // all loads first, branch-free (clamped address, padding selected afterwards): a conditional load makes the compiler
+  // wait for each one before the next is issued -- twenty serialised trips to HBM
+#pragma unroll
+  for (int i = 0; i < MCH; ++i) {
+    const int c = tid + i * NT_MED;
+    const uint2 q = *reinterpret_cast<const uint2*>(at_off(F, (unsigned)min(c, nchunk - 1) << 3));
+    pk[i][0] = q.x;
+    pk[i][1] = q.y;
+  }
+  u32 minpix = 0xFFFFFFFFu, maxpix = 0;
+#pragma unroll
+  for (int i = 0; i < MCH; ++i) {
+    const bool in = tid + i * NT_MED < nchunk;
+    const u32 v0 = pk[i][0] & 0xFFFFu, v1 = pk[i][0] >> 16, v2 = pk[i][1] & 0xFFFFu, v3 = pk[i][1] >> 16;
+    minpix = in ? min(min(minpix, v0), min(v1, min(v2, v3))) : minpix;
+    maxpix = in ? max(max(maxpix, v0), max(v1, max(v2, v3))) : maxpix;
+    pk[i][0] = in ? pk[i][0] : 0xFFFFFFFFu;  // padding: 65535, never below a bisection candidate
+    pk[i][1] = in ? pk[i][1] : 0xFFFFFFFFu;
+  }
+  minpix = wave_min(minpix);
+  maxpix = wave_max(maxpix);
+  if (lane == 0) {
+    s_mm[wave] = minpix;
+    s_mm[NW_MED + wave] = maxpix;
+  }
+  __syncthreads();
+  u32 lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll
+  for (int w = 0; w < NW_MED; ++w) {
+    lo = min(lo, s_mm[w]);
+    hi = max(hi, s_mm[NW_MED + w]);
+  }
+  lo = (u32)uni((int)lo);
+  hi = (u32)uni((int)hi);
+  const u32 k1 = (u32)((P - 1) >> 1), k2 = (u32)(P >> 1);
+  int par = 0;
+  while (lo < hi) {  // uniform: every thread sees the same block totals
+    const u32 mid = (lo + hi) >> 1;
+    u32 cnt = 0;
+#pragma unroll
+    for (int i = 0; i < MCH; ++i) {
+      cnt += wave_count_le_halves(pk[i][0], mid) + wave_count_le_halves(pk[i][1], mid);
+    }
+    if (lane == 0) s_cnt[par * NW_MED + wave] = cnt;
+    __syncthreads();
+    u32 tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW_MED; ++w) tot += s_cnt[par * NW_MED + w];
+    tot = (u32)uni((int)tot);
+    par ^= 1;
+    if (tot >= k1 + 1) hi = mid;
+    else lo = mid + 1;
+  }
+  // lo = value of rank k1; rank k2 is the same value unless exactly k1+1 pixels are <= lo
+  u32 cnt = 0, nxt = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < MCH; ++i) {
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      const u32 val = (hh & 1) ? (pk[i][hh >> 1] >> 16) : (pk[i][hh >> 1] & 0xFFFFu);
+      nxt = (val > lo && val < nxt) ? val : nxt;
+    }
+    cnt += wave_count_le_halves(pk[i][0], lo) + wave_count_le_halves(pk[i][1], lo);
+  }
+  nxt = wave_min(nxt);
+  if (lane == 0) {
+    s_cnt[par * NW_MED + wave] = cnt;
+    s_cnt[2 * NW_MED + wave] = nxt;
+  }
+  __syncthreads();
+  u32 tot = 0, mnx = 0xFFFFFFFFu;
+#pragma unroll
+  for (int w = 0; w < NW_MED; ++w) {
+    tot += s_cnt[par * NW_MED + w];
+    mnx = min(mnx, s_cnt[2 * NW_MED + w]);
+  }
+  // (padding lanes hold 65535: they only count when lo == 65535, where both ranks are 65535 anyway)
+  const u32 v2 = (tot >= k2 + 1 || lo == 65535u) ? lo : mnx;
+  if (tid == 0) a.info_out[fidx].thermal_median = 0.5f * (float)(lo + v2);
+}
 
 // ---------------------------------------------------------------------------------------------
 // cv2.fastNlMeansDenoising(uint8, None) with the defaults h = 3, template 7, search 21
@@ -914,23 +1095,24 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
 // halves of the frame step.
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int NLM_R = 13;   // border = template radius 3 + search radius 10
+constexpr int NLM_R = 13;      // border = template radius 3 + search radius 10
+constexpr int NT_NLM = 1024;  // threads of an NLM workgroup (independent of the frame kernel's)
 __device__ __forceinline__ int refl101(int v, int n) { return v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v); }
 }  // namespace
 
-// BH = output rows per thread in pass B.  A workgroup owns a band of RB = BH * (NT / W) image rows of one frame
+// BH = output rows per thread in pass B.  A workgroup owns a band of RB = BH * (NT_NLM / W) image rows of one frame
 // (blockIdx.y = band): BH = 20 covers a whole 120-row frame with one workgroup -- the throughput configuration for
 // large batches; smaller BH spread a frame over several CUs, which is what the latency of a single clip (one frame
 // per launch) needs.  Reads slot t & 1 of the hand-over image, writes the other slot (the bands of a frame overlap
 // in what they read, so the result cannot go back in place).
 template <int BH>
-__global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
+__global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   const int b = blockIdx.x;
   const int nproc = a.proc_off[b + 1] - a.proc_off[b];
   if (t >= nproc) return;
   const int W = a.W, H = a.H, P = W * H;
   const int tid = threadIdx.x;
-  const int nsub = NT / W;                 // pass-B sub-bands (one image column each per thread)
+  const int nsub = NT_NLM / W;                 // pass-B sub-bands (one image column each per thread)
   const int RB = BH * nsub;                // rows of this workgroup's band
   const int yb0 = blockIdx.y * RB;         // first image row of the band
   if (yb0 >= H) return;
@@ -946,7 +1128,7 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
   const unsigned char* img = a.u8_state + ((size_t)b * 2 + (t & 1)) * P;
   unsigned char* out = a.u8_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
 
-  for (int i = tid; i < EHb * ES; i += NT) {
+  for (int i = tid; i < EHb * ES; i += NT_NLM) {
     const int ey = i / ES, ex = i - ey * ES;
     unsigned char v = 0;
     if (ex < EW) v = img[refl101(yb0 + ey - NLM_R, H) * W + refl101(ex - NLM_R, W)];
@@ -966,7 +1148,7 @@ __global__ __launch_bounds__(NT) void cpx_nlm_kernel(TrackArgs a, int t) {
   for (int off = 0; off < 441; ++off) {
     const int dy = off / 21 - 10, dx = off - (off / 21) * 21 - 10;
     // ---- pass A: Hs[rr][x] = sum_{v=-3..3} (ext(r, x+v) - ext(r+dy, x+dx+v))^2 for r = yb0 + rr - 3 ----
-    for (int it = tid; it < items; it += NT) {
+    for (int it = tid; it < items; it += NT_NLM) {
       const int rr = it / segs, x0 = (it - rr * segs) << 3;
       // bytes x0-3 .. x0+10 of both rows (14 values); the local row of image row r is r - yb0 + 13 = rr + 10 and
       // the byte of column x is x + 13.  ES is a multiple of 8 and x0 a multiple of 8, so both rows are fetched
@@ -1069,25 +1251,25 @@ template <int BH>
 void launch_nlm_t(const TrackArgs& a, int B, int t, hipStream_t s) {
   static bool lds_ready[64];
   (void)cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_nlm_kernel<BH>), lds_ready, 160 * 1024 - 2048);
-  const int RB = BH * (NT / a.W);
-  hipLaunchKernelGGL(cpx_nlm_kernel<BH>, dim3(B, (a.H + RB - 1) / RB), dim3(NT),
+  const int RB = BH * (NT_NLM / a.W);
+  hipLaunchKernelGGL(cpx_nlm_kernel<BH>, dim3(B, (a.H + RB - 1) / RB), dim3(NT_NLM),
                      nlm_lds_rows(a.W, RB < a.H ? RB : a.H), s, a, t);
 }
 }  // namespace
 
 size_t nlm_lds_bytes(int W, int H) {
-  const int rb = 20 * (NT / W);
+  const int rb = 20 * (NT_NLM / W);
   return nlm_lds_rows(W, rb < H ? rb : H);
 }
 int nlm_supported(int W, int H) {
-  const int nsub = NT / W;
+  const int nsub = NT_NLM / W;
   // any height works (bands), the width must leave at least one pass-B sub-band per workgroup
   return nsub >= 1 && (W % 8) == 0 && H >= 1 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
 }
 void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
   // enough workgroups to fill the chip: whole frames per workgroup for big batches, bands of a frame for small
   // ones (a single clip is one frame per launch)
-  const int nsub = NT / a.W;
+  const int nsub = NT_NLM / a.W;
   const int want = (B >= 384) ? 1 : (512 + B - 1) / B;  // bands per frame that would give ~2 workgroups per CU
   const int rows = (a.H + want - 1) / want;              // rows per band for that
   if (rows > 10 * nsub) launch_nlm_t<20>(a, B, t, s);
@@ -1116,8 +1298,12 @@ size_t track_lds_bytes(int W, int H) {
 void launch_init(const TrackArgs& a, int B, int keep, hipStream_t s) {
   hipLaunchKernelGGL(cpx_init_kernel, dim3(B), dim3(256), 0, s, a, keep);
 }
-void launch_frame(const TrackArgs& a, int B, int t, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(cpx_frame_kernel, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t, mode);
+void launch_frame(const TrackArgs& a, int B, int t0, int t1, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_frame_kernel, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t0, t1, mode);
+}
+void launch_median(const TrackArgs& a, int B, int t0, int t1, hipStream_t s) {
+  if (t1 <= t0) return;
+  hipLaunchKernelGGL(cpx_median_kernel, dim3((unsigned)(t1 - t0), (unsigned)B), dim3(NT_MED), 0, s, a, t0);
 }
 void launch_export_background(const TrackArgs& a, int B, float* out, hipStream_t s) {
   hipLaunchKernelGGL(cpx_export_background_kernel, dim3(B), dim3(256), 0, s, a, out);

@@ -536,7 +536,9 @@ int cpx_conv_timing_report(cpx_handle* h, cpx_conv_timing* out, int cap, int* n_
 size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames);
 
 /* Duration in ms of the frame kernel launches of the last cpx_track_batch
- * (HIP events on the handle's stream; valid after cpx_synchronize) and their count. */
+ * (HIP events on the handle's stream; valid after cpx_synchronize) and their count:
+ * 1 when one workgroup per clip walks all of the clip's frames (the default without
+ * denoise), one (or three, with denoise) per frame step otherwise. */
 int cpx_last_kernel_timing(cpx_handle* h, float* total_ms, int* launches);
 
 #ifdef __cplusplus
