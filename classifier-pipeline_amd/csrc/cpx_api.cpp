@@ -30,6 +30,7 @@ struct cpx_handle {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   double* wtab_dev = nullptr;
+  uint32_t* wthr_dev = nullptr;
   int wtab_len = 0;
   int* nlm_lut_dev = nullptr;
   // small device arrays for the schedule
@@ -259,6 +260,24 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
       return CPX_ERR_HIP;
     }
   }
+  // integer form of `bg < f - w_k` for integer bg, f (cpx_track.hip, streaming pass): keep <=> f - bg >= hi_k,
+  // hi_k = floor(w_k) + 1.  Exact whenever w_k is an integer or at least 1e-6 away from one (f - w_k is then no
+  // integer and its float64 rounding, < 2e-11 for f < 65536, cannot reach one).  Otherwise bit 31 is set and the
+  // kernel decides f - bg == rint(w_k) with the float64 expression; hi_k = rint(w_k) + 1 then.
+  std::vector<uint32_t> thr(h->wtab_len);
+  for (int k = 0; k < h->wtab_len; ++k) {
+    const double wk = wt[k], m = std::nearbyint(wk);
+    const bool exact = (wk == m), near = !exact && std::fabs(wk - m) < 1e-6;
+    double hi = near ? m + 1.0 : std::floor(wk) + 1.0;
+    if (!(hi >= 0.0)) hi = 0.0;                    // (negative weight_add: never reached by a sane config)
+    if (hi > 1073741824.0) hi = 1073741824.0;      // beyond any f - bg: never kept
+    thr[k] = (uint32_t)hi | (near ? 0x80000000u : 0u);
+  }
+  if (hipMalloc((void**)&h->wthr_dev, thr.size() * sizeof(uint32_t)) != hipSuccess ||
+      hipMemcpy(h->wthr_dev, thr.data(), thr.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+    cpx_destroy(h);
+    return CPX_ERR_HIP;
+  }
   if (hipMalloc(&h->wtab_dev, wt.size() * sizeof(double)) != hipSuccess ||
       hipMemcpy(h->wtab_dev, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
       cpx::frame_kernel_attr_setup() != 0) {
@@ -286,6 +305,7 @@ void cpx_destroy(cpx_handle* h) {
   h->mog2s.clear();
   if (h->ws) hipFree(h->ws);
   if (h->wtab_dev) hipFree(h->wtab_dev);
+  if (h->wthr_dev) hipFree(h->wthr_dev);
   if (h->nlm_lut_dev) hipFree(h->nlm_lut_dev);
   if (h->sched_dev) hipFree(h->sched_dev);
   if (h->ws_assoc) hipFree(h->ws_assoc);
@@ -390,6 +410,8 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.proc_ffc = h->sched_dev + B + (B + 1) + std::max(nproc_total, 1);
   a.order = h->sched_dev + B + (B + 1) + 2 * (size_t)std::max(nproc_total, 1);
   a.wtab = h->wtab_dev;
+  a.wtab_len = h->wtab_len;
+  a.wthr = h->wthr_dev;
   char* base = (char*)h->ws;
   a.bg = (uint16_t*)(base + l.bg);
   a.wsum = (uint32_t*)(base + l.wsum);

@@ -256,6 +256,16 @@ __global__ __launch_bounds__(256) void cpx_init_kernel(TrackArgs a, int keep) {
 // denoised image); the scalars crossing the split travel in FrameCarry.
 namespace {
 // one processed frame (number t) of clip b; cs = the clip's state before / after the frame (uniform)
+// entries of the weight tables kept in LDS (two workgroups of 80 KB share a CU): the integer thresholds every pixel
+// looks up (4 bytes each) and the float64 weights behind the rare exact comparison (8 bytes each)
+constexpr int WTHR_LDS = 1024;
+constexpr int WTAB_LDS = 512;
+__host__ __device__ inline size_t wtab_lds_offset(int W, int H) {
+  const size_t P = (size_t)W * H;
+  const size_t used = 3 * P + 2 * (size_t)H * RW * 8 + (size_t)9 * CAP * 4 + (NWAVE + 1) * sizeof(Red1) + NWAVE * 2 * sizeof(int) + 16 +
+                      3 * NWAVE * sizeof(u32) + 16;
+  return (used + 15) & ~(size_t)15;
+}
 // values every lane holds alike (read from LDS or through a vector load) -> scalar registers
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uni(double v) {
@@ -280,9 +290,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   // opaque per frame: otherwise everything that depends only on the thread index (pixel coordinates, clamps, row
   // tests of every chunk) is hoisted out of the frame loop and kept live across it -- 100 bytes of scratch per lane
   int tid_ = threadIdx.x;
-#ifndef CPX_EXP_NO_LAUNDER
   asm volatile("" : "+v"(tid_));
-#endif
   const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const int SW = W >> 1;  // run-start slots per row
   const int nchunk = P >> 2;
@@ -305,11 +313,19 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   Red1* s_R = reinterpret_cast<Red1*>(s_ncomp_p + 2);
   u32* s_cnt = reinterpret_cast<u32*>(s_R + 1);  // [2][NWAVE] counts of the median search + [NWAVE] mins
   int* s_bc = reinterpret_cast<int*>(s_cnt + 3 * NWAVE);  // [0..1] normalisation min / max, [2] median (float)
+  // [WTAB_LDS], filled by the kernel.  Typed as LDS: as a generic pointer the lookup below merges with its fall-back
+  // into ONE flat load of a selected address, which waits for every outstanding vector-memory operation
+  typedef __attribute__((address_space(3))) const double LdsDouble;
+  typedef __attribute__((address_space(3))) const u32 LdsU32;
+  LdsDouble* s_wtab = (LdsDouble*)(smem + wtab_lds_offset(W, H));
+  LdsU32* s_wthr = (LdsU32*)(smem + wtab_lds_offset(W, H) + WTAB_LDS * sizeof(double));
 
   const int fidx = a.proc_idx[pbase + t];
   const int oidx = (t >= a.window) ? a.proc_idx[pbase + t - a.window] : -1;
   const int nwin = (t + 1 < a.window) ? (t + 1) : a.window;
-  const u64 div_magic = ((1ull << 40) + (u64)nwin - 1ull) / (u64)nwin;
+  // window_sum // n for window_sum < 2^22, n <= 64: one v_mul_hi_u32 with M = floor(2^32 / n) + 1 (the error term
+  // x * (M - 2^32 / n) / 2^32 < 2^-10 cannot carry the quotient over an integer: fractions are multiples of 1 / n)
+  const u32 div_magic = (nwin > 1) ? (u32)(0xFFFFFFFFu / (u32)nwin + 1u) : 0u;
   const uint16_t* F = a.frames + (size_t)fidx * P;
   const uint16_t* O = (oidx >= 0) ? a.frames + (size_t)oidx * P : nullptr;
   const uint16_t* bg_old = a.bg + ((size_t)b * 2 + (t & 1)) * P;
@@ -350,13 +366,18 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   // computes it for all frames at once and the record at the end of the step picks it up)
   {
     u32 sumpix = 0, minpix = 0xFFFFFFFFu, maxpix = 0;
+    // all loads first and unconditionally (clamped address): a load inside `if (c < nchunk)` is waited for before
+    // the next one is issued -- five dependent trips to HBM instead of one
+    uint2 q[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      q[i] = *reinterpret_cast<const uint2*>(at_off(F, (unsigned)min(tid + i * NT, nchunk - 1) << 3));
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * NT;
       if (c < nchunk) {
-        const uint2 q = *reinterpret_cast<const uint2*>(at_off(F, (unsigned)c << 3));
-        *reinterpret_cast<uint2*>(s_tmp + (c << 2)) = q;
-        const u32 v0 = q.x & 0xFFFFu, v1 = q.x >> 16, v2 = q.y & 0xFFFFu, v3 = q.y >> 16;
+        *reinterpret_cast<uint2*>(s_tmp + (c << 2)) = q[i];
+        const u32 v0 = q[i].x & 0xFFFFu, v1 = q[i].x >> 16, v2 = q[i].y & 0xFFFFu, v3 = q[i].y >> 16;
         sumpix += v0 + v1 + v2 + v3;
         minpix = min(min(minpix, v0), min(v1, min(v2, v3)));
         maxpix = max(max(maxpix, v0), max(v1, max(v2, v3)));
@@ -405,43 +426,74 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   u32 sabs = 0;  // this lane's share of sum |filtered|: <= 20 pixels x 65535
   mn = 0x7FFFFFFF;
   mx = 0;
-  // deliberately NOT unrolled: the body is long, and an unrolled version keeps 30 precomputed 64-bit
-  // addresses live and spills; 32 waves per CU cover the HBM latency instead
-#pragma unroll CPX_TRACK_P1B_UNROLL
-  for (int c = tid; c < nchunk; c += NT) {
-    {
-      const int p0 = c << 2;
-      // opaque: otherwise loop strength reduction turns every store stream into its own 64-bit pointer induction
-      // variable (two registers each) instead of base + offset addressing
-      unsigned p0u = (unsigned)p0;
-      asm volatile("" : "+v"(p0u));
-      const int y = p0 / W, x0 = p0 - y * W;
-      const uint2 pq = *reinterpret_cast<const uint2*>(s_tmp + p0);
-      const int pix[4] = {(int)(pq.x & 0xFFFFu), (int)(pq.x >> 16), (int)(pq.y & 0xFFFFu), (int)(pq.y >> 16)};
-      int bgv[4];
+  // Two pixels per lane and step (4-byte lanes: a wave instruction still covers 256 contiguous bytes), software
+  // pipelined: the state of step i+1 is requested before step i is computed, so a workgroup pays the trip to HBM once
+  // instead of once per step (a frame's 42 us in isolation were half this pass: five dependent trips).  Everything is
+  // branch-free around the loads -- a conditional load makes the compiler drain all outstanding loads at the join.
+  {
+    const int npair = P >> 1;
+    const bool edge1 = (e == 1);  // the usual border: the clamped background of a border pixel is its neighbour in the pair
+    // without a frame leaving the window any readable address does (the value is discarded)
+    const uint16_t* Osafe = O ? O : F;
+    const u32 omask = O ? 0xFFFFFFFFu : 0u;
+    struct Pair { u32 bg, old, kc; uint2 ws; };
+    // a lane's pair walks the frame in strides of 2 NT pixels: row / column advance by constants (one compare per
+    // round) instead of a division by the run-time width per request and per step
+    struct Coord { int p0, yx; };  // first pixel; row << 8 | column (W < 192)
+    const int dY = (2 * NT) / W, dX = 2 * NT - dY * W;  // uniform
+    auto coord_of = [&](int c) -> Coord {
+      const int p0 = c << 1;
+      const int y = p0 / W;
+      return Coord{p0, (y << 8) | (p0 - y * W)};
+    };
+    auto next = [&](const Coord& q) -> Coord {
+      int x = (q.yx & 0xFF) + dX, y = (q.yx >> 8) + dY;
+      const bool wrap = x >= W;
+      x = wrap ? x - W : x;
+      y = wrap ? y + 1 : y;
+      return Coord{q.p0 + 2 * NT, (y << 8) | x};
+    };
+    auto request = [&](const Coord& q0) -> Pair {
+      unsigned p0u = (unsigned)q0.p0;
+      asm volatile("" : "+v"(p0u));  // opaque: base + offset addressing instead of one pointer induction variable per array
+      const int y = q0.yx >> 8, x0 = q0.yx & 0xFF;
       const int cy = clampi(y, e, H - 1 - e);
-      const bool row_in = (cy == y);
-      if (row_in && x0 >= e && x0 + 3 <= W - 1 - e) {
-        const ushort4 q = *reinterpret_cast<const ushort4*>(at_off(bg_old, p0u << 1));
-        bgv[0] = q.x; bgv[1] = q.y; bgv[2] = q.z; bgv[3] = q.w;
+      Pair q;
+      // aligned pair of the clamped row; the column clamp is resolved on the data (edge1) or by two loads (any other edge)
+      if (edge1) {
+        q.bg = *reinterpret_cast<const u32*>(at_off(bg_old, (unsigned)(cy * W + x0) << 1));
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bgv[j] = *at_off(bg_old, (unsigned)(cy * W + clampi(x0 + j, e, W - 1 - e)) << 1);
+        const u32 b0 = *at_off(bg_old, (unsigned)(cy * W + clampi(x0, e, W - 1 - e)) << 1);
+        const u32 b1 = *at_off(bg_old, (unsigned)(cy * W + clampi(x0 + 1, e, W - 1 - e)) << 1);
+        q.bg = b0 | (b1 << 16);
       }
-      int oldp[4] = {0, 0, 0, 0};
-      if (O) {
-        const ushort4 q = *reinterpret_cast<const ushort4*>(at_off(O, p0u << 1));
-        oldp[0] = q.x; oldp[1] = q.y; oldp[2] = q.z; oldp[3] = q.w;
+      q.old = *reinterpret_cast<const u32*>(at_off(Osafe, p0u << 1));
+      q.ws = *reinterpret_cast<const uint2*>(at_off(ws, p0u << 2));
+      q.kc = *reinterpret_cast<const u32*>(at_off(kc, p0u << 1));
+      return q;
+    };
+    auto step = [&](const Coord& q0, const Pair& cur) {
+      unsigned p0u = (unsigned)q0.p0;
+      asm volatile("" : "+v"(p0u));
+      const int p0 = (int)p0u;
+      const int y = q0.yx >> 8, x0 = q0.yx & 0xFF;
+      const bool row_in = (y >= e && y <= H - 1 - e);
+      const u32 pq = *reinterpret_cast<const u32*>(s_tmp + p0);
+      const int pix[2] = {(int)(pq & 0xFFFFu), (int)(pq >> 16)};
+      int bgv[2] = {(int)(cur.bg & 0xFFFFu), (int)(cur.bg >> 16)};
+      if (edge1) {  // x0 is even, W is even: only pixel 0 can sit on the left border, only pixel 1 on the right one
+        bgv[0] = (x0 == 0) ? bgv[1] : bgv[0];
+        bgv[1] = (x0 == W - 2) ? bgv[0] : bgv[1];
       }
-      uint4 wq = *reinterpret_cast<const uint4*>(at_off(ws, p0u << 2));
-      u32 wsv[4] = {wq.x, wq.y, wq.z, wq.w};
-      ushort4 kq = *reinterpret_cast<const ushort4*>(at_off(kc, p0u << 1));
-      int kv[4] = {kq.x, kq.y, kq.z, kq.w};
-      int nb[4];
-      float fo[4];
-      u32 xlo[4], xhi[4];
+      const u32 oldq = cur.old & omask;
+      const int oldp[2] = {(int)(oldq & 0xFFFFu), (int)(oldq >> 16)};
+      u32 wsv[2] = {cur.ws.x, cur.ws.y};
+      int kv[2] = {(int)(cur.kc & 0xFFFFu), (int)(cur.kc >> 16)};
+      int nb[2];
+      float fo[2];
+      u32 xs2[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const int d = pix[j] - bgv[j];  // filtered = float32(pix) - background (cliptrackextractor.py:212)
         fo[j] = (float)d;
         r.fmin = min(r.fmin, d);
@@ -451,26 +503,33 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
         xs = xs < 0 ? 0 : xs;
         mn = min(mn, xs);
         mx = max(mx, xs);
-        xlo[j] = (u32)xs & 0xFFFFu;
-        xhi[j] = (u32)xs >> 16;
+        xs2[j] = (u32)xs;
         // background feed: np.int32(np.mean(last <=45 frames)) == window_sum // n (cliptrackextractor.py:173-176)
         wsv[j] = wsv[j] + (u32)pix[j] - (u32)oldp[j];
-        const int f = (int)(((u64)wsv[j] * div_magic) >> 40);  // == wsv / nwin exactly (wsv < 2^22, nwin <= window)
+        const int f = (nwin > 1) ? (int)__umulhi(wsv[j], div_magic) : (int)wsv[j];  // == wsv / nwin exactly
         const int x = x0 + j;
         nb[j] = bgv[j];
         if (row_in && x >= e && x <= W - 1 - e) {
           // motiondetector.py:212-223: bg' = bg if bg < f - w else f ; w' = w + add if (same) else 0
-          // keep <=> bg < fl64(f - w_k), w_k = k-fold float64 accumulation of weight_add (table).  The table
-          // is only consulted when f - bg is within 1e-5 of k * weight_add, i.e. where rounding can matter.
-          bool keep;
-          if (kv[j] == 0) {
-            keep = bgv[j] < f;
-          } else {
-            const double ap = (double)kv[j] * a.weight_add;
-            const double dd = (double)(f - bgv[j]);
-            if (dd > ap + 1e-5) keep = true;
-            else if (dd < ap - 1e-5) keep = false;
-            else keep = (double)bgv[j] < (double)f - a.wtab[kv[j]];
+          // keep <=> bg < fl64(f - w_k), w_k = k-fold float64 accumulation of weight_add.  For integers bg, f that is
+          // d = f - bg >= hi_k with hi_k = floor(w_k) + 1 from a table (csrc/cpx_api.cpp:weight_thresholds) -- unless
+          // w_k lies within 1e-6 of an integer m without being one: then d = m is decided by NumPy's float64
+          // expression itself (rounding of f - w_k against bg), d > m keeps, d < m does not.  Both tables' first
+          // entries sit in LDS (copied once per clip): no vector-memory operation on the common path, so nothing
+          // waits for the prefetched loads; longer runs of kept frames go to the tables in memory.
+          const int kk = kv[j];
+          const int d2 = f - bgv[j];
+          const u32 th = s_wthr[min(kk, WTHR_LDS - 1)];
+          const int hi = (int)(th & 0x7FFFFFFFu);
+          bool keep = d2 >= hi;
+          if (kk >= WTHR_LDS || ((th >> 31) && d2 == hi - 1)) {
+            // (the loads are consumed INSIDE the branch: a value merged after it would put the wait for them, and
+            // with it for every prefetched load, on the common path)
+            int far;
+            if (kk < WTAB_LDS) far = (double)bgv[j] < (double)f - s_wtab[kk];
+            else far = (double)bgv[j] < (double)f - a.wtab[kk];
+            asm volatile("" : "+v"(far));
+            keep = far != 0;
           }
           if (freeze) keep = true;
           const int nv = keep ? bgv[j] : f;
@@ -480,14 +539,43 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
           nb[j] = nv;
         }
       }
-      *reinterpret_cast<uint2*>(s_tmp + p0) = make_uint2(xlo[0] | (xlo[1] << 16), xlo[2] | (xlo[3] << 16));
-      *reinterpret_cast<u32*>(s_u8 + p0) = xhi[0] | (xhi[1] << 8) | (xhi[2] << 16) | (xhi[3] << 24);
-      *reinterpret_cast<float4*>(at_off(filt_cur, p0u << 2)) = make_float4(fo[0], fo[1], fo[2], fo[3]);
-      *reinterpret_cast<uint4*>(at_off(ws, p0u << 2)) = make_uint4(wsv[0], wsv[1], wsv[2], wsv[3]);
-      *reinterpret_cast<ushort4*>(at_off(bg_new, p0u << 1)) =
-          make_ushort4((unsigned short)nb[0], (unsigned short)nb[1], (unsigned short)nb[2], (unsigned short)nb[3]);
-      *reinterpret_cast<ushort4*>(at_off(kc, p0u << 1)) =
-          make_ushort4((unsigned short)kv[0], (unsigned short)kv[1], (unsigned short)kv[2], (unsigned short)kv[3]);
+      // x as 17 bits: u16 plane + one byte plane (phase 3 reads them back)
+      *reinterpret_cast<u32*>(s_tmp + p0) = (xs2[0] & 0xFFFFu) | (xs2[1] << 16);
+      *reinterpret_cast<uint16_t*>(s_u8 + p0) = (uint16_t)((xs2[0] >> 16) | ((xs2[1] >> 16) << 8));
+      *reinterpret_cast<float2*>(at_off(filt_cur, p0u << 2)) = make_float2(fo[0], fo[1]);
+      *reinterpret_cast<uint2*>(at_off(ws, p0u << 2)) = make_uint2(wsv[0], wsv[1]);
+      *reinterpret_cast<u32*>(at_off(bg_new, p0u << 1)) = ((u32)nb[0] & 0xFFFFu) | ((u32)nb[1] << 16);
+      *reinterpret_cast<u32*>(at_off(kc, p0u << 1)) = ((u32)kv[0] & 0xFFFFu) | ((u32)kv[1] << 16);
+    };
+    // Full rounds (every lane has a pair) run pipelined and without any predicate around a memory operation, so that
+    // the wait before a step's arithmetic counts exactly: the four loads of the next step and the four stores of the
+    // previous one may still be in flight.  The first round is peeled -- the loop is then entered in the state the
+    // back edge leaves (loads requested, then stores) and the compiler's wait count is not the conservative merge of
+    // two different histories -- and the loop body holds two rounds.  The ragged last round (P / 2 is not a multiple of the workgroup) runs on its own.
+    const int nfull = npair / NT;
+    const Coord c0 = coord_of(tid);
+    if (nfull > 0) {
+      // two register sets take turns (no copies: a copy of a loaded register would wait for the load)
+      Coord cA = c0, cB = nfull > 1 ? next(c0) : c0;
+      Pair A = request(cA);
+      Pair B = request(cB);
+      step(cA, A);
+      int k = 1;
+#pragma unroll 1
+      for (; k + 1 < nfull; k += 2) {
+        cA = next(cB);
+        A = request(cA);
+        step(cB, B);
+        cB = (k + 2 < nfull) ? next(cA) : cA;
+        B = request(cB);
+        step(cA, A);
+      }
+      if (k < nfull) step(cB, B);
+    }
+    if (tid + nfull * NT < npair) {
+      const Coord ct = coord_of(tid + nfull * NT);
+      const Pair last = request(ct);
+      step(ct, last);
     }
   }
   r.fmin = wave_min(r.fmin);
@@ -941,33 +1029,27 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
 // a.order (optional) lists the clips by falling length: the dispatcher hands out workgroups in index order.
 // The split forms (mode 1 / 2, around the NLM kernel or on two streams) are launched one step at a time.
 __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_kernel(TrackArgs a, int t0, int t1, int mode) {
-#ifdef CPX_EXP_NO_ORDER
-  const int b = blockIdx.x;
-#else
   const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-#endif
   const int pbase = a.proc_off[b];
   const int nproc = a.proc_off[b + 1] - pbase;
   const int tend = t1 < nproc ? t1 : nproc;
   if (t0 >= tend) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ClipState cs = uniform_state(a.cstate[b]);
+  {  // weight table -> LDS, once per clip (entries beyond the table's length are never indexed: k <= frames so far)
+    double* wl = reinterpret_cast<double*>(smem + wtab_lds_offset(a.W, a.H));
+    u32* tl = reinterpret_cast<u32*>(wl + WTAB_LDS);
+    for (int i = threadIdx.x; i < WTAB_LDS; i += NT) wl[i] = a.wtab[min(i, a.wtab_len - 1)];
+    for (int i = threadIdx.x; i < WTHR_LDS; i += NT) tl[i] = a.wthr[min(i, a.wtab_len - 1)];
+    __syncthreads();
+  }
   // The frame step reads its arguments from the kernel-argument segment (TrackArgs is the first parameter) through a
   // pointer the optimiser cannot see through: otherwise every pointer and constant of TrackArgs is hoisted out of the
   // frame loop, kept live across it, and the scalar registers spill into vector registers and those into scratch
   // (208 bytes per lane = +20 % HBM traffic of an HBM-bound pass).  A scalar load per use costs nothing.
   KernArgs* ap = (KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-#ifdef CPX_EXP_STAGGER
-  if (tend - t0 > 4 && blockIdx.x < 512) {  // first round of workgroups: spread their phases (units of CPX_EXP_STAGGER x 10 ns)
-    const unsigned units = ((blockIdx.x >> 3) & 7u) ^ (((blockIdx.x >> 8) & 1u) ? 4u : 0u);
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t_start < (unsigned long long)units * CPX_EXP_STAGGER) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
   for (int t = t0; t < tend; ++t) {
-#ifndef CPX_EXP_DIRECT_ARGS
     asm volatile("" : "+s"(ap));
-#endif
     frame_step(*ap, b, pbase, t, mode, cs, smem);
     if (t + 1 < tend) {
       // the next frame reads what other threads of this workgroup wrote (clamped background edges, the previous
@@ -1290,10 +1372,7 @@ __global__ __launch_bounds__(256) void cpx_export_background_kernel(TrackArgs a,
   }
 }
 
-size_t track_lds_bytes(int W, int H) {
-  const size_t P = (size_t)W * H;
-  return 3 * P + 2 * (size_t)H * RW * 8 + (size_t)9 * CAP * 4 + (NWAVE + 1) * sizeof(Red1) + NWAVE * 2 * sizeof(int) + 16 + 3 * NWAVE * sizeof(u32) + 16;
-}
+size_t track_lds_bytes(int W, int H) { return wtab_lds_offset(W, H) + (size_t)WTAB_LDS * sizeof(double) + (size_t)WTHR_LDS * sizeof(u32); }
 
 void launch_init(const TrackArgs& a, int B, int keep, hipStream_t s) {
   hipLaunchKernelGGL(cpx_init_kernel, dim3(B), dim3(256), 0, s, a, keep);
