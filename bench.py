@@ -595,7 +595,8 @@ def main():
     if rank == 0:
         frames_done = world * B * T * args.steps
         avg_launch_s = kernel_ms / 1e3 / max(kernel_launches, 1)
-        # a launch handles one frame of every clip of its group (the whole batch, or one of the sub-batches)
+        # a launch walks every clip of its group (the whole batch, or one of the sub-batches) through all of its frames
+        # (one workgroup per clip; CPX_TRACK_PER_STEP=1: one launch per frame step): clip-frames per launch
         clips_per_launch = B * T * args.steps / max(kernel_launches, 1)
         bytes_per_launch = (ALGO_BYTES_PER_FRAME - (LABEL_BYTES_PER_FRAME if e2e else 0)) * clips_per_launch
         hbm = bytes_per_launch / avg_launch_s / 1e9
