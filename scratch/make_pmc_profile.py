@@ -74,14 +74,16 @@ out["conv_stage3"] = section(
     "conv_bf3_kernel<1,1,2,16,512>, stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
     "pmc_e2e_write", CONV, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
     "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
+# one launch walks 1024 clips through their 270 frames (bench.py defaults): clip-frames per launch
+FRAMES = int(os.environ.get("CPX_BENCH_FRAMES", "270"))
 out["frame_kernel_e2e"] = section(
-    "cpx_frame_kernel, 1024 clip-frames per launch, no label image (end-to-end configuration)", "pmc_e2e_fetch",
-    "pmc_e2e_write", "cpx_frame_kernel", None, 1024, "clip-frames", (614400 - 76800) * 1024,
+    "cpx_frame_kernel, one launch = 1024 clips x %d frames, no label image (end-to-end configuration)" % FRAMES, "pmc_e2e_fetch",
+    "pmc_e2e_write", "cpx_frame_kernel", None, 1024 * FRAMES, "clip-frames", (614400 - 76800) * 1024 * FRAMES,
     "SURVEY 8(d): 614,400 B per frame minus the 76,800 B label image")
 if glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_trk_fetch", "*", "*_counter_collection.csv")):
     out["frame_kernel_track"] = section(
-        "cpx_frame_kernel, 1024 clip-frames per launch, label image written (BASELINE configs[1])", "pmc_trk_fetch",
-        "pmc_trk_write", "cpx_frame_kernel", None, 1024, "clip-frames", 614400 * 1024, "SURVEY 8(d): 614,400 B per frame")
+        "cpx_frame_kernel, one launch = 1024 clips x %d frames, label image written (BASELINE configs[1])" % FRAMES, "pmc_trk_fetch",
+        "pmc_trk_write", "cpx_frame_kernel", None, 1024 * FRAMES, "clip-frames", 614400 * 1024 * FRAMES, "SURVEY 8(d): 614,400 B per frame")
 json.dump(out, open(os.path.join(ROOT, "profiles", ROUND + "_e2e_pmc.json"), "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict):
