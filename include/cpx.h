@@ -321,9 +321,13 @@ typedef struct cpx_crop_req { /* one tile = one frame of one segment */
   int32_t tile;                /* 0 .. square_width^2 - 1, row-major */
 } cpx_crop_req;
 
-/* Plans the classification work of a batch on the device (the reference chooses segments at random,
- * SURVEY F13; this planner is the deterministic member of that family: consecutive runs of
- * square_width^2 usable frames per kept track, a short tail padded by repeating its frames).
+/* Plans the classification work of a batch on the device: get_segments(SegmentType.ALL_RANDOM_MASKED)
+ * (ml_tools/datasetstructures.py:972-1301) as it plans when every random draw is the identity -- np.random.shuffle
+ * leaves the order, choice(replace=False) takes the first k, choice(replace=True) cycles (the reference draws at
+ * random; this is the member of that family a test can pin): usable frames (not blank, not FFC-affected,
+ * mass > 0) in frame order, masked windows of square_width^2 frames at the segment spacing for tracks of >= 40 usable
+ * frames, the short remainder padded both ways as the reference pads, segments whose mass falls below the track's
+ * threshold dropped.  tests/golden/segments_identity_golden.json holds the reference's own output under these draws.
  * Inputs: outputs of cpx_associate_batch / cpx_finalize_tracks and, per clip, exclusive prefix sums
  * (device int32 [B][4]) of counts_dev.  Fills refs / track offsets / crop requests / per-sample track
  * index for cpx_track_limits_batch and cpx_crop_tile; track_clip_dev[t] = (clip, track id). */
