@@ -1182,31 +1182,52 @@ constexpr int NT_NLM = 1024;  // threads of an NLM workgroup (independent of the
 __device__ __forceinline__ int refl101(int v, int n) { return v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v); }
 }  // namespace
 
-// BH = output rows per thread in pass B.  A workgroup owns a band of RB = BH * (NT_NLM / W) image rows of one frame
-// (blockIdx.y = band): BH = 20 covers a whole 120-row frame with one workgroup -- the throughput configuration for
-// large batches; smaller BH spread a frame over several CUs, which is what the latency of a single clip (one frame
-// per launch) needs.  Reads slot t & 1 of the hand-over image, writes the other slot (the bands of a frame overlap
-// in what they read, so the result cannot go back in place).
-template <int BH>
+// Offsets come in pairs: dist(p, p + d) = dist(p + d, p), i.e. the row sums of squared differences of offset -d are
+// those of offset d shifted by d.  Pass A computes them once per pair over the band extended by d (rows -3 - dy ... ,
+// columns -dx ... or ... W - dx), pass B accumulates both directions from the same array: 220 pairs + the zero offset
+// instead of 441 passes.  Row sums are kept as uint16 saturated at 4095: a 7-row sum of them is exact below 4096 and
+// >= 4095 otherwise, and every distance >= 3072 has weight zero (LUT index >= 48), so the weights are those of the
+// exact sums.  Pass A works on packed 16-bit pairs (difference, square, saturating adds), pass B on two adjacent
+// columns per thread with packed sliding sums and a zero-padded weight table (no branch per pixel).
+//
+// BH = output rows per thread in pass B (two adjacent columns each).  A workgroup owns a band of
+// RB = BH * (NT_NLM / (W / 2)) image rows of one frame (blockIdx.y = band): BH = 10 covers a whole 120-row frame with
+// one workgroup -- the throughput configuration for large batches; smaller BH spread a frame over several CUs, which
+// is what the latency of a single clip (one frame per launch) needs.  Reads slot t & 1 of the hand-over image, writes
+// the other slot (the bands of a frame overlap in what they read, so the result cannot go back in place).
+namespace {
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+constexpr int NLM_LUT2 = 49;    // LDS weight table: pairs of the 48 non-zero weights + the zero weight
+__device__ __forceinline__ u16x2 as_pk(u32 v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ u32 as_u32(u16x2 v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ int nlm_hs(int W) { return (W + 10 + 7) & ~7; }  // row stride of the row-sum array (uint16)
+}  // namespace
+
+// WC = the frame width when it is known at compile time (160: row strides fold into instruction offsets and the
+// pass-B row loads pair up as ds_read2_b32), 0 = any supported width.
+template <int BH, int WC>
 __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   const int b = blockIdx.x;
   const int nproc = a.proc_off[b + 1] - a.proc_off[b];
   if (t >= nproc) return;
-  const int W = a.W, H = a.H, P = W * H;
+  const int W = WC > 0 ? WC : a.W, H = a.H, P = W * H;
   const int tid = threadIdx.x;
-  const int nsub = NT_NLM / W;                 // pass-B sub-bands (one image column each per thread)
+  const int npair = W >> 1;                // pass-B column pairs
+  const int nsub = NT_NLM / npair;         // pass-B sub-bands
   const int RB = BH * nsub;                // rows of this workgroup's band
   const int yb0 = blockIdx.y * RB;         // first image row of the band
   if (yb0 >= H) return;
   const int RBc = (H - yb0 < RB) ? (H - yb0) : RB;
   const int EW = W + 2 * NLM_R, EHb = RBc + 2 * NLM_R;
-  const int ES = (EW + 8 + 7) & ~7;  // row stride of the padded image: multiple of 8, 8 bytes of slack for the
-                                     // aligned 24-byte fetch of a shifted row
+  const int ES = (EW + 8 + 7) & ~7;  // row stride of the padded image: multiple of 8, slack for the aligned fetches of a
+                                     // shifted row (the zero padding is read, never used)
+  const int HS = nlm_hs(W);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ext = smem;                                                   // [EHb][ES]: padded rows yb0-13 ...
   const int RBa = RB < H ? RB : H;   // rows the launch sized the LDS for
-  u32* Hs = reinterpret_cast<u32*>(smem + (((size_t)(RBa + 2 * NLM_R) * ES + 15) & ~(size_t)15));  // [(RBa+6)][W]
-  int* s_lut = reinterpret_cast<int*>(Hs + (size_t)(RBa + 6) * W);            // [64]
+  uint16_t* Hh = reinterpret_cast<uint16_t*>(smem + (((size_t)(RBa + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15));  // [RBa+16+BH][HS]
+  // weights of a PAIR of distances in one 8-byte entry: [min(d0 >> 6, 48)][min(d1 >> 6, 48)] (entry 48 = weight 0)
+  int2* s_lut2 = reinterpret_cast<int2*>(Hh + (size_t)(RBa + 16 + BH) * HS);  // [49][49]
   const unsigned char* img = a.u8_state + ((size_t)b * 2 + (t & 1)) * P;
   unsigned char* out = a.u8_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
 
@@ -1216,97 +1237,158 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
     if (ex < EW) v = img[refl101(yb0 + ey - NLM_R, H) * W + refl101(ex - NLM_R, W)];
     ext[i] = v;
   }
-  if (tid < 64) s_lut[tid] = a.nlm_lut[tid];
-  // pass-B role: one image column and a sub-band of BH rows
-  const int bx = tid % W, sub = tid / W;
+  for (int i = tid; i < NLM_LUT2 * NLM_LUT2; i += NT_NLM) {
+    const int i0 = i / NLM_LUT2, i1 = i - i0 * NLM_LUT2;
+    s_lut2[i] = make_int2(i0 < 48 ? a.nlm_lut[i0] : 0, i1 < 48 ? a.nlm_lut[i1] : 0);
+  }
+  // pass-B role: two adjacent image columns and a sub-band of BH rows
+  const int pcol = tid % npair, sub = tid / npair;
+  const int bx = pcol << 1;
   const bool active_b = sub < nsub && sub * BH < RBc;
-  int est[BH], wsum[BH];
-#pragma unroll
-  for (int i = 0; i < BH; ++i) est[i] = wsum[i] = 0;
+  const int l0 = sub * BH;  // first band-local row of this thread
+  int est[2 * BH], wsum[2 * BH];
   __syncthreads();
+  {  // the zero offset: distance 0 everywhere
+    const int w0 = s_lut2[0].x;
+#pragma unroll
+    for (int i = 0; i < BH; ++i) {
+      const int l = (l0 + i < RBc) ? l0 + i : 0;
+      const unsigned char* px = ext + (l + NLM_R) * ES + bx + NLM_R;
+      est[2 * i] = w0 * (int)px[0];
+      est[2 * i + 1] = w0 * (int)px[1];
+      wsum[2 * i] = wsum[2 * i + 1] = w0;
+    }
+  }
 
-  const int segs = W >> 3;              // 8-pixel segments per row
-  const int items = (RBc + 6) * segs;   // pass-A work items
-  for (int off = 0; off < 441; ++off) {
-    const int dy = off / 21 - 10, dx = off - (off / 21) * 21 - 10;
-    // ---- pass A: Hs[rr][x] = sum_{v=-3..3} (ext(r, x+v) - ext(r+dy, x+dx+v))^2 for r = yb0 + rr - 3 ----
-    for (int it = tid; it < items; it += NT_NLM) {
-      const int rr = it / segs, x0 = (it - rr * segs) << 3;
-      // bytes x0-3 .. x0+10 of both rows (14 values); the local row of image row r is r - yb0 + 13 = rr + 10 and
-      // the byte of column x is x + 13.  ES is a multiple of 8 and x0 a multiple of 8, so both rows are fetched
-      // with aligned 8-byte LDS reads (conflict-free at this lane stride) and shifted into place with
-      // wave-uniform shifts.
-      const int abase = (rr + NLM_R - 3) * ES + x0 + 8;            // a-bytes start at abase + 2
-      const uint2 qa0 = *reinterpret_cast<const uint2*>(ext + abase);
-      const uint2 qa1 = *reinterpret_cast<const uint2*>(ext + abase + 8);
-      const u64 a0 = ((u64)qa0.y << 32) | qa0.x, a1 = ((u64)qa1.y << 32) | qa1.x;
-      const u64 alo = (a0 >> 16) | (a1 << 48);                    // bytes 0..7 of the 14
-      const u64 ahi = a1 >> 16;                                   // bytes 8..13
-      const int boff = NLM_R - 3 + dx;                            // 0 .. 20
-      const int bsh = (boff & 7) * 8;
-      const int bbase = (rr + NLM_R - 3 + dy) * ES + x0 + (boff & ~7);
-      const uint2 qb0 = *reinterpret_cast<const uint2*>(ext + bbase);
-      const uint2 qb1 = *reinterpret_cast<const uint2*>(ext + bbase + 8);
-      const uint2 qb2 = *reinterpret_cast<const uint2*>(ext + bbase + 16);
-      const u64 b0 = ((u64)qb0.y << 32) | qb0.x, b1 = ((u64)qb1.y << 32) | qb1.x, b2 = ((u64)qb2.y << 32) | qb2.x;
-      u64 blo, bhi;
-      if (bsh == 0) {
-        blo = b0;
-        bhi = b1;
-      } else {
-        blo = (b0 >> bsh) | (b1 << (64 - bsh));
-        bhi = (b1 >> bsh) | (b2 << (64 - bsh));
-      }
-      int d2[14];
+  for (int q = 0; q < 220; ++q) {
+    // upper half of the search window: (0, 1..10), then (1..10, -10..10)
+    int dy, dx;
+    if (q < 10) {
+      dy = 0;
+      dx = q + 1;
+    } else {
+      dy = (q - 10) / 21 + 1;
+      dx = (q - 10) - (dy - 1) * 21 - 10;
+    }
+    const int adx = dx > 0 ? dx : -dx;
+    const int c0 = dx > 0 ? -dx : 0;           // first column of the extended domain
+    const int nrows = RBc + 6 + dy;            // rows -3 - dy .. RBc + 2 of the band
+    const int nseg = (W + adx + 7) >> 3;       // 8-column segments
+    // ---- pass A: Hh[rr][c - c0] = min(4095, sum_{v=-3..3} (ext(r, c+v) - ext(r+dy, c+dx+v))^2), r = yb0 - 3 - dy + rr ----
+    {
+      const int sa0 = NLM_R - 3 + c0, sb0 = sa0 + dx;   // byte of a row where the 14 values of segment 0 start (>= 0)
+      const int abase = sa0 & ~3, bbase = sb0 & ~3;     // 4-byte aligned starts; the shifts are wave-uniform
+      const u32 asel = 0x03020100u + 0x01010101u * (u32)(sa0 & 3), bsel = 0x03020100u + 0x01010101u * (u32)(sb0 & 3);
+      const int items = nrows * nseg;
+      // (row, segment) of this thread's first item and the step of 1024 items, without a division per item
+      const u32 mg = 65536u / (u32)nseg + 1u;            // floor(i / nseg) = (i * mg) >> 16 for i < 1024, 8 <= nseg <= 32
+      int rr = (int)((__umul24((u32)tid, mg)) >> 16);
+      int sg = tid - rr * nseg;
+      const int drr = NT_NLM / nseg, dsg = NT_NLM - drr * nseg;
+      for (int it = tid; it < items; it += NT_NLM) {
+        const int er = rr + NLM_R - 3 - dy;                // padded row of the a values
+        const u32* pa = reinterpret_cast<const u32*>(ext + er * ES + abase + (sg << 3));
+        const u32* pb = reinterpret_cast<const u32*>(ext + (er + dy) * ES + bbase + (sg << 3));
+        u32 qa[5], qb[5];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int d = (int)((alo >> (8 * k)) & 0xFF) - (int)((blo >> (8 * k)) & 0xFF);
-        d2[k] = d * d;
-      }
+        for (int k = 0; k < 5; ++k) {
+          qa[k] = pa[k];
+          qb[k] = pb[k];
+        }
+        u32 ra[4], rb[4];  // the 14 (16) values of each row, byte-aligned
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int d = (int)((ahi >> (8 * k)) & 0xFF) - (int)((bhi >> (8 * k)) & 0xFF);
-        d2[8 + k] = d * d;
-      }
-      u32 hsum[8];
-      u32 acc = 0;
+        for (int k = 0; k < 4; ++k) {
+          ra[k] = __builtin_amdgcn_perm(qa[k + 1], qa[k], asel);
+          rb[k] = __builtin_amdgcn_perm(qb[k + 1], qb[k], bsel);
+        }
+        // D[i] = (d^2 of value 2i, d^2 of value 2i+1), E[i] = (d^2 of 2i+1, d^2 of 2i+2)
+        u16x2 D[7];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) acc += (u32)d2[k];
-      hsum[0] = acc;
+        for (int i = 0; i < 7; ++i) {
+          const u32 sel = (i & 1) ? 0x0c030c02u : 0x0c010c00u;
+          const u16x2 av = as_pk(__builtin_amdgcn_perm(0u, ra[i >> 1], sel));
+          const u16x2 bv = as_pk(__builtin_amdgcn_perm(0u, rb[i >> 1], sel));
+          const u16x2 d = av - bv;
+          D[i] = d * d;  // <= 255^2: exact in 16 bits
+        }
+        u16x2 E[6];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) {
-        acc += (u32)d2[k + 6] - (u32)d2[k - 1];
-        hsum[k] = acc;
+        for (int i = 0; i < 6; ++i) E[i] = as_pk(__builtin_amdgcn_alignbit(as_u32(D[i + 1]), as_u32(D[i]), 16));
+        // output pair (2m, 2m+1) = sum of the seven pairs P[2m .. 2m+6], P[2i] = D[i], P[2i+1] = E[i]; saturating adds
+        auto sadd = [](u16x2 x, u16x2 y) { return __builtin_elementwise_add_sat(x, y); };
+        const u16x2 Sa = sadd(sadd(sadd(D[1], E[1]), sadd(D[2], E[2])), D[3]);   // P2..P6
+        const u16x2 Sb = sadd(sadd(sadd(D[3], E[3]), sadd(D[4], E[4])), D[5]);   // P6..P10
+        const u16x2 cap = {4095, 4095};
+        const u16x2 o0 = __builtin_elementwise_min(sadd(sadd(D[0], E[0]), Sa), cap);   // P0..P6
+        const u16x2 o1 = __builtin_elementwise_min(sadd(Sa, sadd(E[3], D[4])), cap);   // P2..P8
+        const u16x2 o2 = __builtin_elementwise_min(sadd(sadd(D[2], E[2]), Sb), cap);   // P4..P10
+        const u16x2 o3 = __builtin_elementwise_min(sadd(Sb, sadd(E[5], D[6])), cap);   // P6..P12
+        *reinterpret_cast<uint4*>(Hh + (size_t)rr * HS + (sg << 3)) = make_uint4(as_u32(o0), as_u32(o1), as_u32(o2), as_u32(o3));
+        rr += drr;
+        sg += dsg;
+        if (sg >= nseg) {
+          sg -= nseg;
+          ++rr;
+        }
       }
-      uint4* dst = reinterpret_cast<uint4*>(Hs + (size_t)rr * W + x0);
-      dst[0] = make_uint4(hsum[0], hsum[1], hsum[2], hsum[3]);
-      dst[1] = make_uint4(hsum[4], hsum[5], hsum[6], hsum[7]);
     }
     __syncthreads();
-    // ---- pass B: dist(y, x) = sum_{k=0..6} Hs[y - yb0 + k][x]; weight; accumulate ----
+    // ---- pass B: dist = sum of seven row sums; weight; accumulate -- offset d, then offset -d ----
     if (active_b) {
-      const int l0 = sub * BH;  // first band-local row of this thread
-      // the sub-band's BH + 6 row sums of this column, once, into registers; then a sliding 7-sum
-      u32 hv[BH + 6];
 #pragma unroll
-      for (int k = 0; k < BH + 6; ++k) hv[k] = (l0 + k < RBc + 6) ? Hs[(size_t)(l0 + k) * W + bx] : 0u;
-      u32 V = 0;
+      for (int side = 0; side < 2; ++side) {
+        // offset +d reads rows l + k + dy at column x - c0, offset -d rows l + k at column x - dx - c0
+        const int rbase = l0 + (side == 0 ? dy : 0);
+        const int coff = side == 0 ? (dx > 0 ? dx : 0) : (dx > 0 ? 0 : -dx);   // uniform
+        const int poff = NLM_R + (side == 0 ? dx : -dx);                       // uniform
+        const int cc = bx + coff;
+        u32 hv[BH + 6];
+        const uint16_t* hp = Hh + (cc & ~1);
+        // (rows past the band's last one feed only outputs that are never stored; the array has BH spare rows for them)
+        const uint16_t* hr0 = hp + (size_t)rbase * HS;
+        if (coff & 1) {  // the pair straddles two aligned words (bx is even: the parity is the offset's)
 #pragma unroll
-      for (int k = 0; k < 7; ++k) V += hv[k];
-#pragma unroll
-      for (int i = 0; i < BH; ++i) {
-        const int l = l0 + i;
-        if (l < RBc) {
-          const u32 aidx = V >> 6;
-          if (aidx < 64u) {
-            const int w = s_lut[aidx];
-            if (w) {
-              est[i] += w * (int)ext[(l + NLM_R + dy) * ES + bx + NLM_R + dx];
-              wsum[i] += w;
-            }
+          for (int k = 0; k < BH + 6; ++k) {
+            const uint16_t* hr = hr0 + (size_t)k * HS;
+            const u32 w0 = *reinterpret_cast<const u32*>(hr), w1 = *reinterpret_cast<const u32*>(hr + 2);
+            hv[k] = __builtin_amdgcn_alignbit(w1, w0, 16);
           }
+        } else {
+#pragma unroll
+          for (int k = 0; k < BH + 6; ++k) hv[k] = *reinterpret_cast<const u32*>(hr0 + (size_t)k * HS);
         }
-        if (i + 1 < BH) V += hv[i + 7] - hv[i];
+        u16x2 V = as_pk(hv[0]);
+#pragma unroll
+        for (int k = 1; k < 7; ++k) V = V + as_pk(hv[k]);
+        // the two pixels of a row as ALIGNED 16-bit reads: left to itself the compiler merges px[0], px[1] into one
+        // ds_read_u16, which for odd columns (every other offset) is a misaligned LDS access -- measured 3.3 of
+        // 8.3 us per frame.  Rows past the band's end (last band of a frame only) read whatever follows in LDS and
+        // are never stored: no test per row.
+        const unsigned char* px = ext + (l0 + NLM_R + (side == 0 ? dy : -dy)) * ES + ((bx + poff) & ~1);
+        const bool podd = (poff & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < BH; ++i) {
+          const u16x2 cap48 = {48, 48};
+          const u32 ai = as_u32(__builtin_elementwise_min(V >> 6, cap48));
+          const int2 w01 = s_lut2[__umul24(ai & 0xFFFFu, (u32)NLM_LUT2) + (ai >> 16)];
+          const int w0 = w01.x, w1 = w01.y;
+          u32 p0, p1;
+          if (podd) {
+            p0 = (u32)*reinterpret_cast<const uint16_t*>(px) >> 8;
+            p1 = (u32)*reinterpret_cast<const uint16_t*>(px + 2) & 0xFFu;
+          } else {
+            const u32 pp = *reinterpret_cast<const uint16_t*>(px);
+            p0 = pp & 0xFFu;
+            p1 = pp >> 8;
+          }
+          // weights < 2^15, pixels < 2^8: the 24-bit multiply-add (full rate; a 32-bit one is a quarter of that)
+          est[2 * i] = (int)(__umul24((u32)w0, p0) + (u32)est[2 * i]);
+          est[2 * i + 1] = (int)(__umul24((u32)w1, p1) + (u32)est[2 * i + 1]);
+          wsum[2 * i] += w0;
+          wsum[2 * i + 1] += w1;
+          px += ES;
+          if (i + 1 < BH) V = V + as_pk(hv[i + 7]) - as_pk(hv[i]);
+        }
       }
     }
     __syncthreads();
@@ -1314,49 +1396,57 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   if (active_b) {
 #pragma unroll
     for (int i = 0; i < BH; ++i) {
-      const int l = sub * BH + i;
+      const int l = l0 + i;
       if (l < RBc) {
-        const u32 ws = (u32)wsum[i];
-        u32 v = ((u32)est[i] + ws / 2u) / ws;  // the zero offset always contributes LUT[0] > 0
-        out[(yb0 + l) * W + bx] = (unsigned char)(v > 255u ? 255u : v);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32 ws = (u32)wsum[2 * i + j];
+          u32 v = ((u32)est[2 * i + j] + ws / 2u) / ws;  // the zero offset always contributes LUT[0] > 0
+          out[(yb0 + l) * W + bx + j] = (unsigned char)(v > 255u ? 255u : v);
+        }
       }
     }
   }
 }
 
 namespace {
-size_t nlm_lds_rows(int W, int rows) {
+size_t nlm_lds_rows(int W, int rows, int bh) {
   const size_t ES = ((size_t)W + 2 * NLM_R + 8 + 7) & ~(size_t)7;
-  return ((((size_t)rows + 2 * NLM_R) * ES + 15) & ~(size_t)15) + ((size_t)rows + 6) * W * 4 + 64 * 4;
+  const size_t HS = ((size_t)W + 10 + 7) & ~(size_t)7;
+  return ((((size_t)rows + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15) + ((size_t)rows + 16 + bh) * HS * 2 + NLM_LUT2 * NLM_LUT2 * 8 + 64;
+}
+template <int BH, int WC>
+void launch_nlm_tw(const TrackArgs& a, int B, int t, hipStream_t s) {
+  static bool lds_ready[64];
+  (void)cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_nlm_kernel<BH, WC>), lds_ready, 160 * 1024 - 2048);
+  const int RB = BH * (NT_NLM / (a.W / 2));
+  hipLaunchKernelGGL((cpx_nlm_kernel<BH, WC>), dim3(B, (a.H + RB - 1) / RB), dim3(NT_NLM),
+                     nlm_lds_rows(a.W, RB < a.H ? RB : a.H, BH), s, a, t);
 }
 template <int BH>
 void launch_nlm_t(const TrackArgs& a, int B, int t, hipStream_t s) {
-  static bool lds_ready[64];
-  (void)cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_nlm_kernel<BH>), lds_ready, 160 * 1024 - 2048);
-  const int RB = BH * (NT_NLM / a.W);
-  hipLaunchKernelGGL(cpx_nlm_kernel<BH>, dim3(B, (a.H + RB - 1) / RB), dim3(NT_NLM),
-                     nlm_lds_rows(a.W, RB < a.H ? RB : a.H), s, a, t);
+  if (a.W == 160) launch_nlm_tw<BH, 160>(a, B, t, s);
+  else launch_nlm_tw<BH, 0>(a, B, t, s);
 }
 }  // namespace
 
 size_t nlm_lds_bytes(int W, int H) {
-  const int rb = 20 * (NT_NLM / W);
-  return nlm_lds_rows(W, rb < H ? rb : H);
+  const int rb = 10 * (NT_NLM / (W / 2));
+  return nlm_lds_rows(W, rb < H ? rb : H, 10);
 }
 int nlm_supported(int W, int H) {
-  const int nsub = NT_NLM / W;
-  // any height works (bands), the width must leave at least one pass-B sub-band per workgroup
-  return nsub >= 1 && (W % 8) == 0 && H >= 1 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
+  const int nsub = NT_NLM / (W / 2);
+  // any height works (bands), the width must leave at least one pass-B sub-band per workgroup and 8 .. 32 segments
+  return nsub >= 1 && (W % 8) == 0 && W >= 64 && W + 10 <= 256 && H >= 1 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
 }
 void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
   // enough workgroups to fill the chip: whole frames per workgroup for big batches, bands of a frame for small
   // ones (a single clip is one frame per launch)
-  const int nsub = NT_NLM / a.W;
+  const int nsub = NT_NLM / (a.W / 2);
   const int want = (B >= 384) ? 1 : (512 + B - 1) / B;  // bands per frame that would give ~2 workgroups per CU
   const int rows = (a.H + want - 1) / want;              // rows per band for that
-  if (rows > 10 * nsub) launch_nlm_t<20>(a, B, t, s);
-  else if (rows > 4 * nsub) launch_nlm_t<10>(a, B, t, s);
-  else if (rows > 2 * nsub) launch_nlm_t<4>(a, B, t, s);
+  if (rows > 5 * nsub) launch_nlm_t<10>(a, B, t, s);
+  else if (rows > 2 * nsub) launch_nlm_t<5>(a, B, t, s);
   else if (rows > nsub) launch_nlm_t<2>(a, B, t, s);
   else launch_nlm_t<1>(a, B, t, s);
 }
