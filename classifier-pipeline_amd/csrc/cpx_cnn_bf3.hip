@@ -61,7 +61,7 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
 
 // (two workgroups per CU is what the LDS footprint allows: the register budget is pinned to match)
 template <int NTN, int S, int NB, int TW, int CT>
-__global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT / 128, CT / 128))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+__global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ? 4 : CT / 128, CT >= 1024 ? 4 : CT / 128))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3;
   constexpr int WSETS = CT / 256;    // sets of four waves
   constexpr int NTM = NB / WSETS;    // bands per wave

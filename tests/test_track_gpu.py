@@ -521,10 +521,37 @@ def test_association_busy_scenes(engines):
     assert _PY_SIZED[0] > 0  # the float32 blank-region case was exercised
 
 
+@pytest.mark.parametrize("W,H", [(128, 96), (184, 104)])
+def test_denoise_other_widths_match_oracle(W, H):
+    """The NLM kernel has a compile-time-width form for 160-wide frames and a generic one: the generic form (other
+    strides, other numbers of segments and sub-bands, a last band shorter than the others) against the oracle."""
+    import track_oracle as to
+    from cpx import synth
+    from cpx.engine import TrackEngine
+
+    n_clips, T = 2, 5
+    frames, offs = synth.make_batch(n_clips, T, seed=W + H, h=H, w=W)
+    eng = TrackEngine(width=W, height=H, model="lepton3", max_frames=T, denoise=True)
+    meta = np.concatenate([eng.make_meta(T) for _ in range(n_clips)])
+    res = eng.track_batch(eng.upload_frames(frames), offs, meta, want_labels=True)
+    res.check()
+    labels = res.labels()
+    n = 0
+    for b in range(n_clips):
+        cfg = to.OracleConfig("lepton3")
+        cfg.denoise = True
+        out = to.track_clip(frames[offs[b]:offs[b + 1]], cfg=cfg, keep=True, do_tracking=False)
+        for i, o in enumerate(out["frames"]):
+            assert np.array_equal(labels[int(offs[b]) + i], o["mask"]), (b, i)
+            n += int(o["mask"].max() > 0)
+    assert n > 0
+    eng.close()
+
+
 def test_denoise_band_variants_by_batch_size(engines):
-    """The NLM kernel is instantiated for 20 / 10 / 4 / 2 / 1 rows per pass-B thread and picked by batch size (whole
-    frames per workgroup for big batches, bands of a frame for small ones): every variant must give the oracle's
-    label images.  Two distinct short clips, replicated to the batch sizes that select each variant."""
+    """The NLM kernel is instantiated for 10 / 5 / 2 / 1 rows per pass-B thread (two columns each) and picked by batch
+    size (whole frames per workgroup for big batches, bands of a frame for small ones): every variant must give the
+    oracle's label images.  Two distinct short clips, replicated to the batch sizes that select each variant."""
     import torch
     import track_oracle as to
     from cpx import synth
@@ -541,7 +568,7 @@ def test_denoise_band_variants_by_batch_size(engines):
     want = np.concatenate(want)                       # [2T, H, W]
     eng = engines("lepton3", denoise=True)
     dev_base = eng.upload_frames(np.concatenate(base))
-    for B in (2, 32, 64, 128, 384):                   # -> 1, 2, 4, 10, 20 rows per thread at 160x120
+    for B in (2, 32, 64, 128, 384):                   # -> 1, 1, 2, 5, 10 rows per thread at 160x120
         reps = B // 2
         frames = dev_base.unsqueeze(0).expand(reps, -1, -1, -1).reshape(B * T, 120, 160).contiguous()
         offs = (np.arange(B + 1) * T).astype(np.int32)
