@@ -451,8 +451,8 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
     h->staged_bg.clear();
   }
   // medians of all new frames first (independent of the clips' frame order; the frame kernel copies them into the
-  // records it writes).  Grid y = clip: 65535 clips per launch at most
-  if (B > 65535) return fail(h, CPX_ERR_INVALID, "more than 65535 clips in one batch");
+  // records it writes): one workgroup per (clip, step)
+  if ((long long)B * (max_proc - t_begin) > 2147483647LL) return fail(h, CPX_ERR_INVALID, "batch too large for one launch");
   cpx::launch_median(a, B, t_begin, max_proc, h->stream);
   CPX_HIP(h, hipEventRecord(h->ev0, h->stream));  // (ev0 .. ev1 bracket the frame / NLM kernels)
   // (with the internal ping-pong of filtered frames the back half of step t would read what the front half of

@@ -311,8 +311,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   int* s_red2 = reinterpret_cast<int*>(s_red + NWAVE);    // [NWAVE][2]
   u32* s_ncomp_p = reinterpret_cast<u32*>(s_red2 + 2 * NWAVE);
   Red1* s_R = reinterpret_cast<Red1*>(s_ncomp_p + 2);
-  u32* s_cnt = reinterpret_cast<u32*>(s_R + 1);  // [2][NWAVE] counts of the median search + [NWAVE] mins
-  int* s_bc = reinterpret_cast<int*>(s_cnt + 3 * NWAVE);  // [0..1] normalisation min / max, [2] median (float)
   // [WTAB_LDS], filled by the kernel.  Typed as LDS: as a generic pointer the lookup below merges with its fall-back
   // into ONE flat load of a selected address, which waits for every outstanding vector-memory operation
   typedef __attribute__((address_space(3))) const double LdsDouble;
@@ -424,8 +422,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   r.changed = 0;
   r.sumabs = 0;
   u32 sabs = 0;  // this lane's share of sum |filtered|: <= 20 pixels x 65535
-  mn = 0x7FFFFFFF;
-  mx = 0;
   // Two pixels per lane and step (4-byte lanes: a wave instruction still covers 256 contiguous bytes), software
   // pipelined: the state of step i+1 is requested before step i is computed, so a workgroup pays the trip to HBM once
   // instead of once per step (a frame's 42 us in isolation were half this pass: five dependent trips).  Everything is
@@ -498,11 +494,9 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
         fo[j] = (float)d;
         r.fmin = min(r.fmin, d);
         r.fmax = max(r.fmax, d);
-        sabs += (u32)(d < 0 ? -d : d);
+        sabs = __usad((u32)pix[j], (u32)bgv[j], sabs);  // |pix - bg| + sum in one v_sad_u32
         int xs = d - avg_change;  // cliptracker.py:109-114
         xs = xs < 0 ? 0 : xs;
-        mn = min(mn, xs);
-        mx = max(mx, xs);
         xs2[j] = (u32)xs;
         // background feed: np.int32(np.mean(last <=45 frames)) == window_sum // n (cliptrackextractor.py:173-176)
         wsv[j] = wsv[j] + (u32)pix[j] - (u32)oldp[j];
@@ -534,7 +528,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
           if (freeze) keep = true;
           const int nv = keep ? bgv[j] : f;
           if (!freeze) kv[j] = keep ? kv[j] + 1 : 0;
-          r.changed |= (u32)(nv != bgv[j]);
+          r.changed |= (u32)(nv ^ bgv[j]);  // non-zero <=> some background pixel changed
           r.sumbg += (u32)nv;
           nb[j] = nv;
         }
@@ -583,22 +577,13 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   r.sumbg = wave_sum(r.sumbg);
   r.changed = wave_max(r.changed);
   r.sumabs = (u64)wave_sum(sabs);
-  mn = wave_min(mn);
-  mx = wave_max(mx);
-  if (lane == 0) {
-    s_red[wave] = r;
-    s_red2[2 * wave] = mn;
-    s_red2[2 * wave + 1] = mx;
-  }
+  if (lane == 0) s_red[wave] = r;
   __syncthreads();
   if (wave == 0) {
     // combine the per-wave partials once; the result stays in LDS (s_R) for the later phases
     Red1 q;
-    int qmn = 0x7FFFFFFF, qmx = 0;
     if (lane < NWAVE) {
       q = s_red[lane];
-      qmn = s_red2[2 * lane];
-      qmx = s_red2[2 * lane + 1];
     } else {
       q.sumpix = sumpix; q.minpix = minpix; q.maxpix = maxpix; q.fmin = 0x7FFFFFFF; q.fmax = -0x7FFFFFFF - 1;
       q.sumbg = 0; q.changed = 0; q.sumabs = 0;
@@ -608,20 +593,20 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     q.sumbg = wave_sum(q.sumbg);
     q.changed = wave_max(q.changed);
     q.sumabs = (u64)wave_sum((u32)q.sumabs);  // <= 20480 pixels x 65535 < 2^31
-    qmn = wave_min(qmn);
-    qmx = wave_max(qmx);
     if (lane == 0) {
       q.sumpix = sumpix;
       q.minpix = minpix;
       q.maxpix = maxpix;
+      q.changed = q.changed != 0;
       *s_R = q;
-      s_bc[0] = qmn;
-      s_bc[1] = qmx;
     }
   }
   __syncthreads();
-  mn = uni(s_bc[0]);
-  mx = uni(s_bc[1]);
+  // min / max of x = max(filtered - avg_change, 0) follow from those of filtered (monotone): no reduction of their own
+  mn = uni(s_R->fmin) - avg_change;
+  mx = uni(s_R->fmax) - avg_change;
+  mn = mn < 0 ? 0 : mn;
+  mx = mx < 0 ? 0 : mx;
   CPX_STOP(2)
 
   // ---- phase 3: normalise to 0..255 (float32, imageprocessing.py:151-169) -> uint8 in LDS
@@ -1075,8 +1060,8 @@ constexpr int NT_MED = 256;
 constexpr int NW_MED = NT_MED / 64;
 constexpr int MCH = (4 * NCH * NT / 4 + NT_MED - 1) / NT_MED;  // 4-pixel chunks per thread at the largest frame
 }  // namespace
-__global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0) {
-  const int b = blockIdx.y, t = t0 + (int)blockIdx.x;
+__global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0, int nsteps) {
+  const int b = (int)(blockIdx.x / (unsigned)nsteps), t = t0 + (int)(blockIdx.x - (unsigned)b * (unsigned)nsteps);
   const int pbase = a.proc_off[b];
   if (t >= a.proc_off[b + 1] - pbase) return;
   const int fidx = a.proc_idx[pbase + t];
@@ -1472,7 +1457,7 @@ void launch_frame(const TrackArgs& a, int B, int t0, int t1, int mode, hipStream
 }
 void launch_median(const TrackArgs& a, int B, int t0, int t1, hipStream_t s) {
   if (t1 <= t0) return;
-  hipLaunchKernelGGL(cpx_median_kernel, dim3((unsigned)(t1 - t0), (unsigned)B), dim3(NT_MED), 0, s, a, t0);
+  hipLaunchKernelGGL(cpx_median_kernel, dim3((unsigned)(t1 - t0) * (unsigned)B), dim3(NT_MED), 0, s, a, t0, t1 - t0);
 }
 void launch_export_background(const TrackArgs& a, int B, float* out, hipStream_t s) {
   hipLaunchKernelGGL(cpx_export_background_kernel, dim3(B), dim3(256), 0, s, a, out);
