@@ -375,11 +375,16 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
     // every clip needs a state to continue from: the previous call's (same layout) or a staged one
     const bool have_prev = h->ws && h->last_B == B && need_filt == h->stream_filt_state && l.total <= h->ws_bytes;
     for (int b = 0; b < B && !have_prev; ++b)
-      if (!h->staged_bg.count(b))
-        return fail(h, CPX_ERR_INVALID, "CPX_TRACK_KEEP_BACKGROUND: no background state for a clip (previous call had another batch size, and nothing staged)");
+      if (!h->staged_bg.count(b)) {
+        h->staged_bg.clear();  // staged for THIS call: a refused call does not leave them behind for the one after
+        return fail(h, CPX_ERR_INVALID, "CPX_TRACK_KEEP_BACKGROUND: no background state for a clip (previous call had another batch size, and nothing staged; staged states dropped)");
+      }
   }
   for (const auto& kv : h->staged_bg)
-    if (kv.first >= B) return fail(h, CPX_ERR_INVALID, "cpx_set_background: staged clip index outside the batch");
+    if (kv.first >= B) {
+      h->staged_bg.clear();  // staged for THIS call: a refused call does not leave them behind for the one after
+      return fail(h, CPX_ERR_INVALID, "cpx_set_background: staged clip index outside the batch (staged states dropped)");
+    }
   h->stream_filt_state = need_filt;
   h->last_B = B;
   if (l.total > h->ws_bytes) {

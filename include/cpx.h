@@ -186,7 +186,9 @@ int cpx_track_frame_ex(cpx_handle* h, const uint16_t* frames_dev, const cpx_fram
  * cpx_set_background stages it for clip `clip` of the NEXT track call on the handle (batch, or frame of a stream --
  * also in the middle of a stream: an externally owned model that changed between two frames); it replaces whatever
  * seeding that call would do for the clip.  Values the device state cannot hold exactly (a non-integer or > 65535
- * background, a weight that is not an accumulation of the handle's weight_add) -> CPX_ERR_UNSUPPORTED.
+ * background, a weight that is not an accumulation of the handle's weight_add) -> CPX_ERR_UNSUPPORTED.  A track call
+ * that is refused over the staged states (one staged for a clip index it does not have, or CPX_TRACK_KEEP_BACKGROUND
+ * without a state for every clip) fails with CPX_ERR_INVALID and drops all staged states.
  * cpx_get_background reads the state the last track call left for clip `clip` (synchronises the handle's stream). */
 int cpx_set_background(cpx_handle* h, int clip, const float* background, const double* weights, double average);
 int cpx_get_background(cpx_handle* h, int clip, float* background, double* weights, double* average);

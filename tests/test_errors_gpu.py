@@ -108,3 +108,40 @@ def test_contour_chain_overflow_is_reported():
     got = eng.thumb_stats(dev, res, refs)
     assert got[0]["contours"] == 4 and got[0]["status"] == 0
     eng.close()
+
+
+def test_background_ownership_errors():
+    """cpx_set_background / cpx_get_background / CPX_TRACK_KEEP_BACKGROUND refuse what they cannot honour: a
+    non-integer background, a weight that is no accumulation of weight_add, a clip outside the batch, keeping a
+    background that was never there -- and the handle stays usable."""
+    from cpx import _lib
+    from cpx._lib import CpxError
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3", max_frames=16)
+    frames = eng.upload_frames(np.full((6, 120, 160), 3000, np.uint16))
+    offs = np.array([0, 6], np.int32)
+    meta = eng.make_meta(6)
+    # nothing to keep yet
+    with pytest.raises(CpxError):
+        eng.track_batch(frames, offs, meta, flags=_lib.TRACK_KEEP_BACKGROUND)
+    with pytest.raises(CpxError):
+        eng.get_background(0)
+    bg = np.full((120, 160), 2990.5, np.float32)
+    with pytest.raises(CpxError):
+        eng.set_background(0, bg)                                  # not integer-valued
+    bg[:] = 2990
+    with pytest.raises(CpxError):
+        eng.set_background(0, bg, weights=np.full((118, 158), 0.05))  # 0.05 is no multiple accumulation of 0.1
+    eng.set_background(3, bg)                                      # staged for a clip the next batch does not have
+    with pytest.raises(CpxError):
+        eng.track_batch(frames, offs, meta, flags=_lib.TRACK_KEEP_BACKGROUND)
+    # a proper hand-over: background 2990 under frames of 3000, weights = 3 accumulations
+    w3 = np.full((118, 158), 0.1 + 0.1 + 0.1)
+    eng.set_background(0, bg, weights=w3)
+    res = eng.track_batch(frames, offs, meta, flags=_lib.TRACK_KEEP_BACKGROUND)
+    res.check()
+    got, w, avg = eng.get_background(0)
+    assert got.shape == (120, 160) and w.shape == (118, 158) and np.isfinite(avg)
+    assert (got[1:-1, 1:-1] >= 2990).all() and (got <= 3000).all()
+    eng.close()
