@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 // only): one thread per pixel computes all 16 output channels -- float2 input loads, four 16-byte stores per
 // pixel (64 contiguous bytes), weights through uniform (scalar) loads.  HBM-bound: 8 B read, 64 B written per pixel.
 __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
+  __shared__ float4 s_out[4 * 256];
   const size_t total = (size_t)a.N * a.Ho * a.Wo;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     size_t p = idx;
@@ -303,13 +304,26 @@ __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
     const float* in_n = a.in + (size_t)n * a.H * a.W * 2;
+    // all nine loads first and unconditionally (clamped address, padding zeroed afterwards): a load behind
+    // `if (inside)` is waited for before the next one is issued -- nine dependent trips to memory per pixel
+    float2 tap[9];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int iy = oy - a.pad_top + ky, ix = ox - a.pad_left + kx;
-        if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;
-        const float2 v = *reinterpret_cast<const float2*>(in_n + ((size_t)iy * a.W + ix) * 2);
+        const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+        tap[ky * 3 + kx] = *reinterpret_cast<const float2*>(in_n + ((size_t)cy * a.W + cx) * 2);
+      }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy - a.pad_top + ky, ix = ox - a.pad_left + kx;
+        const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        float2 v = tap[ky * 3 + kx];
+        v.x = inside ? v.x : 0.0f;
+        v.y = inside ? v.y : 0.0f;
         const float* w0 = a.weights + (ky * 3 + kx) * 8;       // group 0: [tap][1][8]
         const float* w1 = a.weights + 72 + (ky * 3 + kx) * 8;  // group 1
 #pragma unroll
@@ -318,7 +332,11 @@ __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
           acc[8 + c] += v.y * w1[c];
         }
       }
-    float* o = a.out + idx * 16;
+    // the 64 bytes of a pixel go through the wave's 4 KB of LDS so that a store instruction writes 1 KB of
+    // consecutive addresses (a lane storing its own pixel's four float4 scatters 16-byte pieces 64 bytes apart:
+    // four partial writes per cache line)
+    float4* tile = s_out + (threadIdx.x >> 6) * 256;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 r;
@@ -326,8 +344,23 @@ __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
       r.y = acc[4 * q + 1] + a.out_shift[4 * q + 1];
       r.z = acc[4 * q + 2] + a.out_shift[4 * q + 2];
       r.w = acc[4 * q + 3] + a.out_shift[4 * q + 3];
-      *reinterpret_cast<float4*>(o + 4 * q) = r;
+      tile[lane * 4 + q] = r;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the wave's pixels are consecutive: idx0 .. idx0 + 63 (the tail of the last wave is cut by `total`)
+    const size_t idx0 = idx - lane;
+    float4* o = reinterpret_cast<float4*>(a.out + idx0 * 16);
+    const size_t left = (total - idx0) * 4;  // float4 slots that exist behind idx0
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = q * 64 + lane;
+      if ((size_t)f < left) o[f] = tile[f];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
