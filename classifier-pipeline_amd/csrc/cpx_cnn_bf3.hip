@@ -60,7 +60,10 @@ struct TileDiv {
 __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)n * m) >> 42); }
 
 // (two workgroups per CU is what the LDS footprint allows: the register budget is pinned to match)
-template <int NTN, int S, int NB, int TW, int CT>
+// C8: the layer with 8 input channels per group (one 16-byte k half per pixel).  A K = 16 step then pairs two TAPS
+// instead of two channel halves: lanes 0-31 (k half 0) read tap 2 s, lanes 32-63 tap 2 s + 1 of the same 8-channel
+// entry array -- five steps for the nine taps (the tenth tap has zero weights) instead of nine half-empty ones.
+template <int NTN, int S, int NB, int TW, int CT, bool C8>
 __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ? 4 : CT / 128, CT >= 1024 ? 4 : CT / 128))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3;
   constexpr int WSETS = CT / 256;    // sets of four waves
@@ -72,9 +75,12 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr int NPX = PH * PW;
   constexpr int COGW = 32 * NTN;  // output channels of this workgroup
+  constexpr int KH = C8 ? 1 : 2;      // 8-channel entries (k halves) stored per patch pixel
+  constexpr int QPP = C8 ? 2 : 4;     // 16-byte pieces of float32 input per patch pixel and chunk
+  constexpr int NSTEP = C8 ? 5 : 9;   // K = 16 steps per chunk
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  uint4* s_patch = lds4;            // [3][2][NPX]
-  uint4* s_w = lds4 + 6 * NPX;      // [3][9][2][COGW]
+  uint4* s_patch = lds4;                // [3][KH][NPX]
+  uint4* s_w = lds4 + 3 * KH * NPX;     // [3][NSTEP][2][COGW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wset = tid >> 8;
   int bid = blockIdx.x;
@@ -93,9 +99,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
   const int oy0 = tyi * TH, ox0 = txi * TW;
   const int iy0 = oy0 * S - a.pad_top, ix0 = ox0 * S - a.pad_left;
   const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
-  const int nchunks = cin_g / KC;
-  // weight image: [g][chunk][3][9][2][cout_g] entries
-  const uint4* wg = wimg + (size_t)g * nchunks * 54 * cout_g + (size_t)ns * COGW;
+  const int nchunks = C8 ? 1 : cin_g / KC;
+  // weight image: [g][chunk][3][NSTEP][2][cout_g] entries
+  const uint4* wg = wimg + (size_t)g * nchunks * (6 * NSTEP) * cout_g + (size_t)ns * COGW;
   // a tile whose patch lies inside the image needs no padding tests (uniform)
   const bool interior = iy0 >= 0 && iy0 + PH <= a.H && ix0 >= 0 && ix0 + PW <= a.W;
 
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
 
   const int pi = lane & 31, kh = lane >> 5;
   const int prow = WR * wave + pi / TW, pcol = pi % TW;
-  const int a_base = kh * NPX + ((prow + wset * TB) * S) * PW + pcol * S;  // band m of this wave: wset + m * WSETS
+  const int a_base = (C8 ? 0 : kh * NPX) + ((prow + wset * TB) * S) * PW + pcol * S;  // band m of this wave: wset + m * WSETS
   const int b_base = kh * COGW + (lane & 31);
 
   // staging: an item is ONE 16-byte piece (4 channels) of a patch pixel's 16-channel chunk, and the four pieces of a
@@ -135,11 +141,11 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
   // of the cache-line requests the (pixel, 8 channels)-per-lane form made, which kept the vector-memory issue busy for
   // thousands of cycles per chunk (in-kernel s_memtime stamps, scratch/patches/README.md).  BatchNorm + ReLU + split
   // happen here; a piece fills the low or high 8 bytes of an LDS entry.
-  constexpr int NITEM = NPX * 4;
+  constexpr int NITEM = NPX * QPP;
   constexpr int NP = (NITEM + CT - 1) / CT;
-  constexpr int NW = 54 * COGW;               // uint4 entries of a weight chunk
+  constexpr int NW = 6 * NSTEP * COGW;        // uint4 entries of a weight chunk
   constexpr int NWI = (NW + CT - 1) / CT;
-  const int my_q = tid & 3;                   // float32 input: CT is a multiple of 4, so a thread keeps its quarter
+  const int my_q = tid & (QPP - 1);           // float32 input: CT is a multiple of 4, so a thread keeps its piece
   u32x4 pre_p[NP];
   u32x4 pre_w[NWI];
   f32x4 psc, psh;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
       for (int i = 0; i < NP; ++i) {
         const int item = tid + i * CT;
         if (item < NITEM) {
-          const int px = item >> 2;
+          const int px = C8 ? item >> 1 : item >> 2;
           bool inside = true;
           if (!interior) {
             const int py = px / PW, pxx = px - py * PW;
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
             // channels 4 q .. 4 q + 3 of the chunk: entry of k half q >> 1, its low or high 8 bytes
             uint2* sp2 = reinterpret_cast<uint2*>(s_patch);
             const int e2 = ((my_q >> 1) * NPX + px) * 2 + (my_q & 1);
-            sp2[(0 * 2 * NPX) * 2 + e2] = make_uint2(q0[0], q0[1]);
-            sp2[(1 * 2 * NPX) * 2 + e2] = make_uint2(q1[0], q1[1]);
-            sp2[(2 * 2 * NPX) * 2 + e2] = make_uint2(q2[0], q2[1]);
+            sp2[(0 * KH * NPX) * 2 + e2] = make_uint2(q0[0], q0[1]);
+            sp2[(1 * KH * NPX) * 2 + e2] = make_uint2(q1[0], q1[1]);
+            sp2[(2 * KH * NPX) * 2 + e2] = make_uint2(q2[0], q2[1]);
           }
         }
       }
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
     }
     if (cc + 1 < nchunks) {
       // ---- global -> registers for the next chunk (in flight during the MFMA loop below) ----
-      const int cn = (cc + 1) * KC;
+      const int cn = C8 ? 0 : (cc + 1) * KC;
       {  // without a prologue any readable 16 bytes do (never used): no branch around the loads
         const int ch = g * cin_g + cn + 4 * my_q;
         const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int item = min(tid + i * CT, NITEM - 1);
-        const int px = item >> 2;
+        const int px = C8 ? item >> 1 : item >> 2;
         const int py = px / PW, pxx = px - py * PW;
         const int iy = iy0 + py, ix = ix0 + pxx;
         // branch-free: a clamped address is always loaded (conditional loads split the block and make the
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
         const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 4 * my_q);  // inside one sample: < 2^31
         pre_p[i] = *reinterpret_cast<const u32x4*>(src);
       }
-      const uint4* wc = wg + (size_t)(cc + 1) * 54 * cout_g;
+      const uint4* wc = wg + (size_t)(cc + 1) * (6 * NSTEP) * cout_g;
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, NW - 1);
@@ -220,17 +226,27 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
     }
     if (cc >= 0) {
 #pragma unroll
-      for (int tap = 0; tap < KS * KS; ++tap) {
-        const int ky = tap / KS, kx = tap - ky * KS;
+      for (int st = 0; st < NSTEP; ++st) {
+        // the patch offset of this step's tap: the same for the whole wave, or (C8) tap 2 st for k half 0 and tap
+        // 2 st + 1 for k half 1 (the tenth tap does not exist: its weights are zero, any address will do)
+        int koff;
+        if (C8) {
+          const int tl = 2 * st + kh, tc = tl > 8 ? 8 : tl;
+          const int ky = (tc * 11) >> 5;  // tc / 3 for tc <= 8
+          koff = ky * PW + (tc - 3 * ky);
+        } else {
+          const int ky = st / KS, kx = st - ky * KS;
+          koff = ky * PW + kx;
+        }
         bf16x8 av[NTM][3], bv[NTN][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
           for (int m = 0; m < NTM; ++m)
-            av[m][p] = __builtin_bit_cast(bf16x8, s_patch[p * 2 * NPX + a_base + m * (WSETS * TB * S * PW) + ky * PW + kx]);
+            av[m][p] = __builtin_bit_cast(bf16x8, s_patch[p * KH * NPX + a_base + m * (WSETS * TB * S * PW) + koff]);
 #pragma unroll
           for (int t = 0; t < NTN; ++t)
-            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * 9 + tap) * 2 * COGW + b_base + t * 32]);
+            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * NSTEP + st) * 2 * COGW + b_base + t * 32]);
         }
 #pragma unroll
         for (int m = 0; m < NTM; ++m)
@@ -595,6 +611,34 @@ static bool flat_pays(const ConvArgs& a, int TW, int TH, int npx_cap) {
 }
 
 // packed float32 weights [g][tap][cin_g][cout_g] -> bf16 plane image [g][chunk][3][9][2][cout_g] of 16-byte entries
+// cin_g == 8: [g][3][5][2][cout_g], the entry of (step s, k half h) = the 8 channels of tap 2 s + h (zeros for tap 9)
+__global__ __launch_bounds__(256) void split_weights8_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
+                                                             int cout_g) {
+  const size_t total = (size_t)groups * 5 * 2 * cout_g;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    const int col = (int)(r % cout_g);
+    r /= cout_g;
+    const int h = (int)(r & 1);
+    r >>= 1;
+    const int st = (int)(r % 5);
+    const int g = (int)(r / 5);
+    const int tap = 2 * st + h;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tap < 9 ? w[(((size_t)g * 9 + tap) * 8 + j) * cout_g + col] : 0.0f;
+    uint4 p0, p1, p2;
+    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+    const size_t base = (size_t)g * 30 * cout_g;
+    out[base + ((size_t)(0 * 5 + st) * 2 + h) * cout_g + col] = p0;
+    out[base + ((size_t)(1 * 5 + st) * 2 + h) * cout_g + col] = p1;
+    out[base + ((size_t)(2 * 5 + st) * 2 + h) * cout_g + col] = p2;
+  }
+}
+
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
                                                             int cin_g, int cout_g) {
   const int nchunks = cin_g / KC;
@@ -625,14 +669,14 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
-template <int NTN, int S, int NB, int TW, int CT>
+template <int NTN, int S, int NB, int TW, int CT, bool C8 = false>
 int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int TB = 128 / TW, TH = TB * NB;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-  size_t lds = ((size_t)6 * PH * PW + (size_t)54 * 32 * NTN) * 16;
+  size_t lds = ((size_t)(C8 ? 3 : 6) * PH * PW + (size_t)(C8 ? 30 : 54) * 32 * NTN) * 16;
   if (lds < (CT / 64) * 32 * 32 * sizeof(float)) lds = (CT / 64) * 32 * 32 * sizeof(float);
   static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT, C8>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Wo + TW - 1) / TW;
   td.tiles_y = (a.Ho + TH - 1) / TH;
@@ -642,7 +686,7 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT, C8>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
   return 0;
 }
 
@@ -684,15 +728,25 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
 #define CPX_BF3_CT_S4 256
 #endif
 
+// (8 input channels per group: the tap-paired form, built for the 32 output channels per group the network has)
+static bool bf3_c8(const ConvArgs& a) { return a.Cin / a.groups == 8 && a.Cout / a.groups == 32; }
 bool conv_bf3_supported(const ConvArgs& a) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  if (a.ksize == 3 && a.stride == 1 && bf3_c8(a)) return true;
   return a.ksize == 3 && a.stride == 1 && cin_g >= KC && (cin_g % KC) == 0 && (cout_g == 32 || cout_g == 64 || cout_g == 128);
 }
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
+  if (bf3_c8(a)) return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16;
   return (size_t)a.groups * (a.Cin / a.groups / KC) * 54 * (a.Cout / a.groups) * 16;
 }
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  if (bf3_c8(a)) {
+    const size_t total8 = (size_t)a.groups * 10 * cout_g;
+    hipLaunchKernelGGL(split_weights8_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg), a.groups, cout_g);
+    return;
+  }
   const size_t total = (size_t)a.groups * (cin_g / KC) * 18 * cout_g;
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
                      reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g);
@@ -700,6 +754,7 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   const int cout_g = a.Cout / a.groups;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
+  if (bf3_c8(a)) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2, true>(a, w, s);
   if (cout_g == 32) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2>(a, w, s);
   if (cout_g == 64) return launch_bf3_t<CPX_BF3_NTN_S3, 1, CPX_BF3_NB_S3, CPX_BF3_TW_S3, CPX_BF3_CT_S3>(a, w, s);
   // 256 staged pixels + two N tiles = 80 KB: two workgroups per CU.  (Wider maps -- 54 x 54 at frame size 64 -- would
