@@ -17,7 +17,7 @@ no data-path collective; the per-track result records are all-gathered once per 
 
 Extra objects on the JSON line:
   roofline      the dominant kernel of the step.  e2e: the stage-2 3x3 grouped convolution
-                (conv_bf3_kernel<1,1,2,16,512> in the rocprof CSV, an instantiation the stage-3 3x3 convolutions share:
+                (conv_bf3_kernel<1,1,2,16,512,false> in the rocprof CSV, an instantiation the stage-3 3x3 convolutions share:
                 the roofline covers both; conv_mfma_kernel<8,1,1,3,2,16>, stage 2 only, with --cnn-math f32):
                 algorithmic FLOPs (2*M*N*K of the float32 convolution) of its launches / their HIP-event time on the
                 handle's stream.  Peak: with the default bf16x3 math every float32 multiply-add is six bf16 MFMA
@@ -657,7 +657,7 @@ def main():
                 # input + output (+ residual in 3 of the 5 launches of a shape per forward), float32 NHWC
                 bytes2 = side * side * 64 * 4 * 2.6
                 if bf3 and key3 in conv:
-                    # stage 2 and stage 3 run the same instantiation (conv_bf3_kernel<1,1,2,16,512>: one row of the
+                    # stage 2 and stage 3 run the same instantiation (conv_bf3_kernel<1,1,2,16,512,false>: one row of the
                     # rocprof CSV), with the same FLOPs per sample: the roofline covers the launches of both
                     n = conv[key][0] + conv[key3][0]
                     ms = conv[key][1] + conv[key3][1]
@@ -667,7 +667,7 @@ def main():
                     t2 = pmc_traffic("conv_stage2", samples_per_launch * area)
                     t3 = pmc_traffic("conv_stage3", samples_per_launch * area)
                     traffic = round((t2 + t3) / 2, 1) if t2 is not None and t3 is not None else None
-                    what = "conv_bf3_kernel<1,1,2,16,512> (stage-2 and stage-3 3x3 convs: 64->64 ch at %dx%d, 128->128 ch at %dx%d, groups 2)" % (
+                    what = "conv_bf3_kernel<1,1,2,16,512,false> (stage-2 and stage-3 3x3 convs: 64->64 ch at %dx%d, 128->128 ch at %dx%d, groups 2)" % (
                         side, side, side // 2, side // 2)
                 else:
                     n, ms, fl = conv[key]
