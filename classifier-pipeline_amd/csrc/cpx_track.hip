@@ -348,14 +348,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   const int slot = t & 1;
   if (mode == 1) cs.bg_average = a.bgavg[b];
 
-#define CPX_STOP(n)                                                                                   \
-  if (CPX_TIMING_STOP_AFTER == (n)) {                                                                 \
-    if (tid == 0) a.info_out[fidx].threshold = thresh + (float)ithr + (float)s_u8[avg_change & 1023] + (float)s_rowE[5] + (float)(mn + mx);  \
-    return;                                                                                           \
-  }
-#ifndef CPX_TIMING_STOP_AFTER
-#define CPX_TIMING_STOP_AFTER 0  // timing experiments only: 1..8 = return after that phase (1 = thermal load + median, 2 = streaming pass)
-#endif
   int avg_change = 0, mn = 0, mx = 0, ithr = 0;
   float thresh = 0.0f;
   if (mode != 2) {
@@ -409,7 +401,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   const double mean_thermal = (double)sumpix / (double)P;
   avg_change = (int)rint(mean_thermal - cs.bg_average);
 
-  CPX_STOP(1)
   // ---- phase 1b: the streaming pass over the clip state -----------------------------------------------
   // x = max(thermal - background - avg_change, 0) goes to LDS as 17 bits (u16 plane + 1-bit-in-a-byte plane)
   Red1 r;
@@ -607,7 +598,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   mx = uni(s_R->fmax) - avg_change;
   mn = mn < 0 ? 0 : mn;
   mx = mx < 0 ? 0 : mx;
-  CPX_STOP(2)
 
   // ---- phase 3: normalise to 0..255 (float32, imageprocessing.py:151-169) -> uint8 in LDS
   {
@@ -681,7 +671,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     }
     return;
   }
-  CPX_STOP(3)
 
   // ---- phase 4a: horizontal [1 4 6 4 1], BORDER_REFLECT_101 -----------------------
   const int ngroup = P >> 3;
@@ -732,7 +721,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     reinterpret_cast<unsigned char*>(s_rowI)[y * (RW * 8) + (x0 >> 3)] = (unsigned char)bits;
   }
   __syncthreads();
-  CPX_STOP(4)
   // ---- phase 5: MORPH_CLOSE with the 1x2 element ----------------------
   for (int i = tid; i < H * RW; i += NT) {
     const int y = i / RW;
@@ -743,7 +731,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   }
   __syncthreads();
 
-  CPX_STOP(5)
   // ---- phase 6: 8-connected labelling on runs --------------------------------------
   // parents live on run-start slots (row * SW + start/2); initialise them
   for (int i = tid; i < H * RW; i += NT) {
@@ -812,7 +799,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   const bool overflow = ncomp_all > CAP || ncomp_all > a.cap_out;
   const int ncomp = overflow ? 0 : ncomp_all;
 
-  CPX_STOP(6)
   // ---- phase 7: statistics per component ------------------------------------------------
   // s_stat rows: 0 area, 1 minx, 2 maxx, 3 miny, 4 maxy, 5 sumx, 6 sumy, 7 key
   for (int i = tid; i < ncomp; i += NT) {
@@ -862,7 +848,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   }
   __syncthreads();
 
-  CPX_STOP(7)
   // ---- phase 8a: label image (Frame.mask) ------------------------------------------------------
   if (a.labels_out) {
     int32_t* Lout = a.labels_out + (size_t)fidx * P;
@@ -888,7 +873,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     }
   }
 
-  CPX_STOP(8)
   // ---- phase 8b: np.var(delta_filtered[bbox]) per component ------------------------------------------
   // delta = |f32(norm255(cur.filtered)) - f32(norm255(prev.filtered))|  (cliptracker.py:249-261);
   // normalize() promotes to float64 for these float64 frames (NumPy >= 2 scalar promotion).
