@@ -21,10 +21,6 @@
 #define CPX_TRACK_MIN_WAVES_PER_SIMD 8  // __launch_bounds__ 2nd argument (waves per SIMD)
 #endif
 
-#ifndef CPX_TRACK_P1B_UNROLL
-#define CPX_TRACK_P1B_UNROLL 1  // unroll factor of the streaming loop (register pressure vs loads in flight)
-#endif
-
 namespace cpx {
 
 typedef cpx_component Component;
