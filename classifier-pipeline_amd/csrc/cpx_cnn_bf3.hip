@@ -36,6 +36,24 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32: round to nearest even
   return __builtin_bit_cast(unsigned, v);
 }
+// uniform base + 32-bit unsigned byte offset: the form the compiler turns into `global_load v, v_off, s[base]` (one
+// offset register per lane instead of 64-bit address arithmetic per access; everything addressed here stays inside
+// one sample or one weight image: < 2^32 bytes)
+template <typename T>
+__device__ __forceinline__ const T* at_off(const T* base, unsigned bytes) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + bytes);
+}
+template <typename T>
+__device__ __forceinline__ T* at_off(T* base, unsigned bytes) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + bytes);
+}
+// element offset of pixel (y, x) in an NHWC sample: both products stay below 2^24 (y * W + x < 2^17 pixels, x C <= 256
+// channels), so the full-rate 24-bit multiply does (a 32-bit v_mul_lo_u32 / v_mad_u64_u32 takes four issue slots)
+__device__ __forceinline__ unsigned pix_off(int y, int x, int W, int C) {
+  return __umul24(__umul24((unsigned)y, (unsigned)W) + (unsigned)x, (unsigned)C);
+}
+// ReLU of a float as an integer maximum: one instruction (fmaxf(x, 0) on a value of unknown origin is canonicalised first)
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 // two float32 -> their three bf16 planes (packed pairs)
@@ -111,7 +129,8 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
   const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;
   f32x16 acc[NTM][NTN];
   if (res_in_acc) {
-    const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout + (g * cout_g + ns * COGW + (lane & 31));
+    const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout + (g * cout_g + ns * COGW);  // (uniform)
+    const int rcol = lane & 31;
 #pragma unroll
     for (int m = 0; m < NTM; ++m)
 #pragma unroll
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
         for (int r = 0; r < 16; ++r) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel of the wave tile this register holds
           const int oy = min(oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, a.Ho - 1), ox = min(ox0 + i % TW, a.Wo - 1);
-          acc[m][t][r] = res_n[(oy * a.Wo + ox) * a.Cout + t * 32];
+          acc[m][t][r] = *at_off(res_n, (pix_off(oy, ox, a.Wo, a.Cout) + (unsigned)(t * 32 + rcol)) << 2);
         }
   } else {
 #pragma unroll
@@ -198,11 +217,13 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
       // ---- global -> registers for the next chunk (in flight during the MFMA loop below) ----
       const int cn = C8 ? 0 : (cc + 1) * KC;
       {  // without a prologue any readable 16 bytes do (never used): no branch around the loads
-        const int ch = g * cin_g + cn + 4 * my_q;
+        const int ch = g * cin_g + cn;  // (uniform; the lane's piece goes into the offset)
         const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);
         const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);
-        psc = *reinterpret_cast<const f32x4*>(scp);
-        psh = *reinterpret_cast<const f32x4*>(shp);
+        unsigned qoff = (unsigned)my_q << 4;
+        asm volatile("" : "+v"(qoff));
+        psc = *reinterpret_cast<const f32x4*>(at_off(scp, qoff));
+        psh = *reinterpret_cast<const f32x4*>(at_off(shp, qoff));
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -213,15 +234,16 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
         // branch-free: a clamped address is always loaded (conditional loads split the block and make the
         // compiler wait for all outstanding loads at every join); out-of-image pixels are zeroed at commit
         const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-        const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 4 * my_q);  // inside one sample: < 2^31
-        pre_p[i] = *reinterpret_cast<const u32x4*>(src);
+        pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, a.Cin) + (unsigned)(cn + 4 * my_q)) << 2));
       }
       const uint4* wc = wg + (size_t)(cc + 1) * (6 * NSTEP) * cout_g;
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, NW - 1);
         const int pth = item / COGW, col = item - pth * COGW;
-        pre_w[i] = reinterpret_cast<const u32x4*>(wc)[(size_t)pth * cout_g + col];
+        unsigned woff = (unsigned)(pth * cout_g + col) << 4;
+        asm volatile("" : "+v"(woff));  // (kept 32-bit: hoisted out of the chunk loop it becomes a 64-bit pair per load)
+        pre_w[i] = *at_off(reinterpret_cast<const u32x4*>(wc), woff);
       }
     }
     if (cc >= 0) {
@@ -318,13 +340,13 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
           const int oy = oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = ox0 + i % TW;
           if (oy < a.Ho && ox < a.Wo) {
             float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
-            const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
-            const float4 rv = *reinterpret_cast<const float4*>(res_n + o);
+            const int o = (int)pix_off(oy, ox, a.Wo, a.Cout) + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+            const float4 rv = *reinterpret_cast<const float4*>(at_off(res_n, (unsigned)o << 2));
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             if (a.relu) {
-              v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+              v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
             }
-            *reinterpret_cast<float4*>(out_n + o) = v;
+            *reinterpret_cast<float4*>(at_off(out_n, (unsigned)o << 2)) = v;
           }
         }
       } else {
@@ -335,11 +357,11 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
           const int oy = oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, ox = ox0 + i % TW;
           if (oy < a.Ho && ox < a.Wo) {
             float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
-            const int o = (oy * a.Wo + ox) * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+            const int o = (int)pix_off(oy, ox, a.Wo, a.Cout) + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
             if (a.relu) {
-              v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+              v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
             }
-            *reinterpret_cast<float4*>(out_n + o) = v;
+            *reinterpret_cast<float4*>(at_off(out_n, (unsigned)o << 2)) = v;
           }
         }
       }
