@@ -59,8 +59,12 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
 // two float32 -> their three bf16 planes (packed pairs)
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
   p0 = pack2(a, b);
+  // (opaque: seeing through the pack, the compiler converts `a` a second time just to shift it -- one vector
+  // instruction more per level and pair; the halves of the packed word are what is wanted)
+  asm volatile("" : "+v"(p0));
   const float ra = a - bf_lo(p0), rb = b - bf_hi(p0);  // exact
   p1 = pack2(ra, rb);
+  asm volatile("" : "+v"(p1));
   const float sa = ra - bf_lo(p1), sb = rb - bf_hi(p1);  // exact
   p2 = pack2(sa, sb);
 }
@@ -190,10 +194,12 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
             for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);
             if (a.in_scale) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] * psc[j] + psh[j], 0.0f);
+              for (int j = 0; j < 4; ++j) v[j] = fmaxf(__fmaf_rn(v[j], psc[j], psh[j]), 0.0f);
             }
+            if (!interior) {  // (uniform: most tiles skip the selects)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
+              for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
+            }
             unsigned q0[2], q1[2], q2[2];
             split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
             split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
