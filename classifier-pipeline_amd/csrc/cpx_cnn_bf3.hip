@@ -417,13 +417,14 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;  // see conv_bf3_kernel
   f32x16 acc[NTN];
   if (res_in_acc) {
-    const float* res_n = a.residual + (size_t)n * M * a.Cout + (g * cout_g + ns * COGW + (lane & 31));
+    const float* res_n = a.residual + (size_t)n * M * a.Cout + (g * cout_g + ns * COGW);  // (uniform)
+    const int rcol = lane & 31;
 #pragma unroll
     for (int t = 0; t < NTN; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        acc[t][r] = res_n[(size_t)min(p0 + wave * 32 + i, M - 1) * a.Cout + t * 32];
+        acc[t][r] = *at_off(res_n, (__umul24((unsigned)min(p0 + wave * 32 + i, M - 1), (unsigned)a.Cout) + (unsigned)(t * 32 + rcol)) << 2);
       }
   } else {
 #pragma unroll
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         for (int j = 0; j < 8; ++j) v[j] = pre_p[i][j >> 2][j & 3];
         if (a.in_scale) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * psc[j >> 2][j & 3] + psh[j >> 2][j & 3], 0.0f);
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(__fmaf_rn(v[j], psc[j >> 2][j & 3], psh[j >> 2][j & 3]), 0.0f);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
@@ -489,27 +490,31 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
       // ---- global -> registers for the next chunk (in flight during the MFMA loop below), branch-free ----
       const int cn = (cc + 1) * KC;
       {
-        const int ch = g * cin_g + cn + 8 * my_h;
+        const int ch = g * cin_g + cn;  // (uniform; the lane's half goes into the offset)
         const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);
         const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);
-        psc[0] = *reinterpret_cast<const f32x4*>(scp);
-        psc[1] = *reinterpret_cast<const f32x4*>(scp + 4);
-        psh[0] = *reinterpret_cast<const f32x4*>(shp);
-        psh[1] = *reinterpret_cast<const f32x4*>(shp + 4);
+        unsigned hoff = (unsigned)my_h << 5;
+        asm volatile("" : "+v"(hoff));
+        psc[0] = *reinterpret_cast<const f32x4*>(at_off(scp, hoff));
+        psc[1] = *reinterpret_cast<const f32x4*>(at_off(scp, hoff + 16));
+        psh[0] = *reinterpret_cast<const f32x4*>(at_off(shp, hoff));
+        psh[1] = *reinterpret_cast<const f32x4*>(at_off(shp, hoff + 16));
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int cy = min(max(iy0 + item_py[i], 0), a.H - 1), cx = min(max(ix0 + item_px[i], 0), a.W - 1);
-        const float* src = in_n + ((cy * a.W + cx) * a.Cin + cn + 8 * my_h);
-        pre_p[i][0] = *reinterpret_cast<const f32x4*>(src);
-        pre_p[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        const unsigned soff = (pix_off(cy, cx, a.W, a.Cin) + (unsigned)(cn + 8 * my_h)) << 2;
+        pre_p[i][0] = *reinterpret_cast<const f32x4*>(at_off(in_n, soff));
+        pre_p[i][1] = *reinterpret_cast<const f32x4*>(at_off(in_n, soff + 16));
       }
       const u32x4* wc = reinterpret_cast<const u32x4*>(wg + (size_t)(cc + 1) * 54 * cout_g);
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, NW - 1);
         const int pth = item / COGW, col = item - pth * COGW;
-        pre_w[i] = wc[pth * cout_g + col];
+        unsigned woff = (unsigned)(pth * cout_g + col) << 4;
+        asm volatile("" : "+v"(woff));  // (see conv_bf3_kernel)
+        pre_w[i] = *at_off(wc, woff);
       }
     }
     if (cc >= 0) {
@@ -577,12 +582,12 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         const int p = p0 + wave * 32 + i;
         if (p < M) {
           f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + i * 32 + 4 * c4);
-          const int o = p * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
-          v += *reinterpret_cast<const f32x4*>(res_n + o);
+          const int o = (int)__umul24((unsigned)p, (unsigned)a.Cout) + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+          v += *reinterpret_cast<const f32x4*>(at_off(res_n, (unsigned)o << 2));
           if (a.relu) {
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
           }
-          *reinterpret_cast<f32x4*>(out_n + o) = v;
+          *reinterpret_cast<f32x4*>(at_off(out_n, (unsigned)o << 2)) = v;
         }
       }
     } else {
@@ -593,11 +598,11 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         const int p = p0 + wave * 32 + i;
         if (p < M) {
           f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + i * 32 + 4 * c4);
-          const int o = p * a.Cout + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
+          const int o = (int)__umul24((unsigned)p, (unsigned)a.Cout) + ch0 + t * 32 + 4 * c4;  // inside one sample: < 2^31
           if (a.relu) {
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
           }
-          *reinterpret_cast<f32x4*>(out_n + o) = v;
+          *reinterpret_cast<f32x4*>(at_off(out_n, (unsigned)o << 2)) = v;
         }
       }
     }
@@ -781,6 +786,8 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
 }
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   const int cout_g = a.Cout / a.groups;
+  // pixel offsets are formed with 24-bit multiplies (pix_off): a sample of 2^24 pixels or more is out of their range
+  if ((long long)a.H * a.W >= (1 << 24) || (long long)a.Ho * a.Wo >= (1 << 24) || a.Cin >= (1 << 24) || a.Cout >= (1 << 24)) return -3;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
   if (bf3_c8(a)) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2, true>(a, w, s);
   if (cout_g == 32) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2>(a, w, s);
