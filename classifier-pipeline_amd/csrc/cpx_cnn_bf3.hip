@@ -126,6 +126,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
   const uint4* wg = wimg + (size_t)g * nchunks * (6 * NSTEP) * cout_g + (size_t)ns * COGW;
   // a tile whose patch lies inside the image needs no padding tests (uniform)
   const bool interior = iy0 >= 0 && iy0 + PH <= a.H && ix0 >= 0 && ix0 + PW <= a.W;
+  // a tile whose OUTPUT lies inside the map needs no clamps / bounds tests in the residual preload and the stores, and
+  // the offsets of a lane's values then differ by wave-uniform amounts: one per-lane base + scalar terms (uniform)
+  const bool full_tile = oy0 + TH <= a.Ho && ox0 + TW <= a.Wo;
 
   // The residual goes INTO the accumulators before the first product (possible when the output is not scaled):
   // its loads are in flight under the whole tile instead of stalling the epilogue, and they cost no registers.
@@ -135,16 +138,33 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
   if (res_in_acc) {
     const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout + (g * cout_g + ns * COGW);  // (uniform)
     const int rcol = lane & 31;
+    if (full_tile) {
 #pragma unroll
-    for (int m = 0; m < NTM; ++m)
+      for (int m = 0; m < NTM; ++m) {
+        // register r holds pixel ic(r) + 4 (lane >> 5) of the wave tile; TW is a multiple of 8, so the lane part never
+        // carries into the row: row / column split into a constant of r and the lane's share
+        const unsigned lb = (pix_off(oy0 + (wset + m * WSETS) * TB + WR * wave, ox0 + 4 * (lane >> 5), a.Wo, a.Cout) + (unsigned)rcol) << 2;
 #pragma unroll
-      for (int t = 0; t < NTN; ++t)
+        for (int t = 0; t < NTN; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel of the wave tile this register holds
-          const int oy = min(oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, a.Ho - 1), ox = min(ox0 + i % TW, a.Wo - 1);
-          acc[m][t][r] = *at_off(res_n, (pix_off(oy, ox, a.Wo, a.Cout) + (unsigned)(t * 32 + rcol)) << 2);
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int ic = (r & 3) + 8 * (r >> 2);
+            const unsigned ub = (unsigned)(((ic / TW) * a.Wo + (ic % TW)) * a.Cout + t * 32) << 2;  // (scalar)
+            acc[m][t][r] = *at_off(res_n, lb + ub);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < NTM; ++m)
+#pragma unroll
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel of the wave tile this register holds
+            const int oy = min(oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, a.Ho - 1), ox = min(ox0 + i % TW, a.Wo - 1);
+            acc[m][t][r] = *at_off(res_n, (pix_off(oy, ox, a.Wo, a.Cout) + (unsigned)(t * 32 + rcol)) << 2);
+          }
+    }
   } else {
 #pragma unroll
     for (int m = 0; m < NTM; ++m)
@@ -354,6 +374,19 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
             }
             *reinterpret_cast<float4*>(at_off(out_n, (unsigned)o << 2)) = v;
           }
+        }
+      } else if (full_tile) {
+        // lane f of store `it` writes pixel 8 it + (lane >> 3), channels 4 (lane & 7) ..: a per-lane base + a scalar
+        const unsigned lb = (pix_off(oy0 + (wset + m * WSETS) * TB + WR * wave, ox0 + (lane >> 3), a.Wo, a.Cout) +
+                             (unsigned)(ch0 + t * 32 + 4 * (lane & 7))) << 2;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          float4 v = *reinterpret_cast<const float4*>(s_tile + (it * 64 + lane) * 4);
+          const unsigned ub = (unsigned)((((it * 8) / TW) * a.Wo + ((it * 8) % TW)) * a.Cout) << 2;  // (scalar)
+          if (a.relu) {
+            v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+          }
+          *reinterpret_cast<float4*>(at_off(out_n, lb + ub)) = v;
         }
       } else {
 #pragma unroll
