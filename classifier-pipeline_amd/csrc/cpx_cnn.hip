@@ -46,6 +46,19 @@ namespace cpx {
 
 namespace {
 
+// uniform base + 32-bit unsigned byte offset: `global_load v, v_off, s[base]` instead of 64-bit address arithmetic per
+// access (everything addressed this way stays inside one sample or one weight block: < 2^32 bytes)
+template <typename T>
+__device__ __forceinline__ const T* at_off(const T* base, unsigned bytes) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + bytes);
+}
+template <typename T>
+__device__ __forceinline__ T* at_off(T* base, unsigned bytes) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + bytes);
+}
+// ReLU of a float as an integer maximum: one instruction (fmaxf(x, 0) on a value of unknown origin is canonicalised first)
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // a native vector, not HIP's float4 struct: struct copies become memcpy calls that keep a staging array in scratch
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -170,13 +183,13 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
         // branch-free: a clamped address is always loaded (conditional loads split the block and make the compiler
         // wait for every outstanding load at each join); out-of-image pixels are zeroed at commit
         const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-        pre_p[i] = *reinterpret_cast<const f32x4*>(in_n + ((cy * a.W + cx) * a.Cin + cn + 4 * my_c4));
+        pre_p[i] = *reinterpret_cast<const f32x4*>(at_off(in_n, (unsigned)((cy * a.W + cx) * a.Cin + cn + 4 * my_c4) << 2));
       }
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, KS * KS * WV - 1);
         const int tap = item / WV, r = item - tap * WV;
-        pre_w[i] = *reinterpret_cast<const f32x4*>(wg + ((tap * cin_g + cn) * COG + 4 * r));
+        pre_w[i] = *reinterpret_cast<const f32x4*>(at_off(wg, (unsigned)((tap * cin_g + cn) * COG + 4 * r) << 2));
       }
     }
     if (cc >= 0) {
@@ -226,22 +239,39 @@ __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // two loops, not one with a conditional residual load inside: a load in the loop makes the compiler wait for
+      // the PREVIOUS store before every store (cpx_cnn_bf3.hip)
+      if (res_n) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int f = it * 64 + lane;         // float4 index inside the tile
-        const int i = f >> 3, c4 = f & 7;
-        const int oy = oy0 + m * TB + WR * wave + i / TW, ox = ox0 + i % TW;
-        if (oy < a.Ho && ox < a.Wo) {
-          float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
-          const size_t o = ((size_t)oy * a.Wo + ox) * a.Cout + g * COG + t * 32 + 4 * c4;
-          if (res_n) {
-            const float4 rv = *reinterpret_cast<const float4*>(res_n + o);
+        for (int it = 0; it < 4; ++it) {
+          const int f = it * 64 + lane;         // float4 index inside the tile
+          const int i = f >> 3, c4 = f & 7;
+          const int oy = oy0 + m * TB + WR * wave + i / TW, ox = ox0 + i % TW;
+          if (oy < a.Ho && ox < a.Wo) {
+            float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
+            const unsigned o = (unsigned)((oy * a.Wo + ox) * a.Cout + g * COG + t * 32 + 4 * c4) << 2;  // inside one sample
+            const float4 rv = *reinterpret_cast<const float4*>(at_off(res_n, o));
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            if (a.relu) {
+              v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+            }
+            *reinterpret_cast<float4*>(at_off(out_n, o)) = v;
           }
-          if (a.relu) {
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int f = it * 64 + lane;
+          const int i = f >> 3, c4 = f & 7;
+          const int oy = oy0 + m * TB + WR * wave + i / TW, ox = ox0 + i % TW;
+          if (oy < a.Ho && ox < a.Wo) {
+            float4 v = *reinterpret_cast<const float4*>(s_tile + i * 32 + 4 * c4);
+            const unsigned o = (unsigned)((oy * a.Wo + ox) * a.Cout + g * COG + t * 32 + 4 * c4) << 2;  // inside one sample
+            if (a.relu) {
+              v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+            }
+            *reinterpret_cast<float4*>(at_off(out_n, o)) = v;
           }
-          *reinterpret_cast<float4*>(out_n + o) = v;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
