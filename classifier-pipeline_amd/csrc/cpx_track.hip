@@ -448,7 +448,9 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       Pair q;
       // aligned pair of the clamped row; the column clamp is resolved on the data (edge1) or by two loads (any other edge)
       if (edge1) {
-        q.bg = *reinterpret_cast<const u32*>(at_off(bg_old, (unsigned)(cy * W + x0) << 1));
+        // the clamped row is the pixel's own, or (top / bottom row) the one next to it: no multiply
+        const int rowadj = (y == 0) ? W : ((y == H - 1) ? -W : 0);
+        q.bg = *reinterpret_cast<const u32*>(at_off(bg_old, (unsigned)((int)p0u + rowadj) << 1));
       } else {
         const u32 b0 = *at_off(bg_old, (unsigned)(cy * W + clampi(x0, e, W - 1 - e)) << 1);
         const u32 b1 = *at_off(bg_old, (unsigned)(cy * W + clampi(x0 + 1, e, W - 1 - e)) << 1);
