@@ -237,8 +237,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
         const int item = tid + i * CT;
         if (item < NW) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
       }
-      __syncthreads();
     }
+    // (the next chunk's loads are issued BEFORE the barrier: their registers are free once the commit above has read
+    // them, and the time a wave waits for the others at the barrier then counts towards hiding the loads' latency)
     if (cc + 1 < nchunks) {
       // ---- global -> registers for the next chunk (in flight during the MFMA loop below) ----
       const int cn = C8 ? 0 : (cc + 1) * KC;
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ?
       }
     }
     if (cc >= 0) {
+      __syncthreads();
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {
         // the patch offset of this step's tap: the same for the whole wave, or (C8) tap 2 st for k half 0 and tap
