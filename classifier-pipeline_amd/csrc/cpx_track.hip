@@ -1252,8 +1252,8 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
       const u32 asel = 0x03020100u + 0x01010101u * (u32)(sa0 & 3), bsel = 0x03020100u + 0x01010101u * (u32)(sb0 & 3);
       const int items = nrows * nseg;
       // (row, segment) of this thread's first item and the step of 1024 items, without a division per item
-      const u32 mg = 65536u / (u32)nseg + 1u;            // floor(i / nseg) = (i * mg) >> 16 for i < 1024, 8 <= nseg <= 32
-      int rr = (int)((__umul24((u32)tid, mg)) >> 16);
+      const u32 mg = (1u << 20) / (u32)nseg + 1u;        // floor(i / nseg) = (i * mg) >> 20 for i < 1024, nseg < 1024
+      int rr = (int)((__umul24((u32)tid, mg)) >> 20);
       int sg = tid - rr * nseg;
       const int drr = NT_NLM / nseg, dsg = NT_NLM - drr * nseg;
       for (int it = tid; it < items; it += NT_NLM) {
@@ -1407,8 +1407,8 @@ size_t nlm_lds_bytes(int W, int H) {
 }
 int nlm_supported(int W, int H) {
   const int nsub = NT_NLM / (W / 2);
-  // any height works (bands), the width must leave at least one pass-B sub-band per workgroup and 8 .. 32 segments
-  return nsub >= 1 && (W % 8) == 0 && W >= 64 && W + 10 <= 256 && H >= 1 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
+  // any height works (bands), the width must leave at least one pass-B sub-band per workgroup
+  return nsub >= 1 && (W % 8) == 0 && W >= 8 && H >= 1 && nlm_lds_bytes(W, H) <= 160 * 1024 - 2048;
 }
 void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
   // enough workgroups to fill the chip: whole frames per workgroup for big batches, bands of a frame for small

@@ -522,7 +522,7 @@ def test_association_busy_scenes(engines):
     assert _PY_SIZED[0] > 0  # the float32 blank-region case was exercised
 
 
-@pytest.mark.parametrize("W,H", [(64, 48), (128, 96), (184, 104)])
+@pytest.mark.parametrize("W,H", [(32, 24), (64, 48), (128, 96), (184, 104)])
 def test_denoise_other_widths_match_oracle(W, H):
     """The NLM kernel has a compile-time-width form for 160-wide frames and a generic one: the generic form (other
     strides, other numbers of segments and sub-bands, a last band shorter than the others) against the oracle."""
