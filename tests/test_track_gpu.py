@@ -373,12 +373,13 @@ def test_denoise_matches_oracle_on_synthetic(engines):
     assert ncomp > 0
 
 
-@pytest.mark.parametrize("W,H", [(32, 24), (64, 40), (80, 60), (128, 96), (184, 104)])
+@pytest.mark.parametrize("W,H", [(32, 24), (64, 40), (80, 60), (128, 96), (184, 104), (160, 128)])
 def test_other_resolutions_match_oracle(W, H):
     """The kernels take the resolution from the handle (the reference reads it from the CPTV header): smaller and
     non-4:3 frames inside the kernel envelope (W % 8 == 0, W < 192, W*H <= 20480) against the oracle, pixel stage and
     association.  The sizes also walk the streaming pass through its forms: no full round of pixel pairs (32 x 24), one
-    (64 x 40), an even and an odd number of them, each with a ragged last round."""
+    (64 x 40), an even and an odd number of them, each with a ragged last round; 160 x 128 is the largest frame the
+    kernel takes (20 pixels per lane, one workgroup per CU by its LDS footprint)."""
     import track_oracle as to
     from cpx import synth
     from cpx.engine import TrackEngine
