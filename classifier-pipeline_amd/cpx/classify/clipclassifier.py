@@ -234,7 +234,7 @@ class ClipClassifier:
             eng = track_extractor._engine
             meta = track_extractor._meta
             # the model continues from where tracking left it (the reference re-uses track_extractor.background_alg)
-            eng.set_background(0, *track_extractor._final_state)
+            eng.set_background(0, *track_extractor.final_state())
             flags = TRACK_KEEP_BACKGROUND | TRACK_FREEZE_ON_FFC
         del rec_end  # only the dbus event of the Pi reads it (service.TrackReprocessed)
 

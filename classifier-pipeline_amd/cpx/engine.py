@@ -162,6 +162,7 @@ class TrackStream:
         if init_only and f == 0:
             return f  # consumed together with the first real frame
         eng.sync_inputs()
+        eng.track_calls = getattr(eng, "track_calls", 0) + 1
         mp = C.c_void_p(self.meta.ctypes.data)
         rc = eng.lib.cpx_track_frame_ex(eng.h, self._p(self.frames_dev), mp, self.n_tracked, self.n,
                                         self._p(self.comps), self._p(self.info), self._p(self.labels),
@@ -505,6 +506,7 @@ class TrackEngine:
         else:
             comps, info, labels, filt, bgo = outputs
         self.sync_inputs()  # inputs were produced on torch's stream
+        self.track_calls = getattr(self, "track_calls", 0) + 1  # whose state cpx_get_background would read
         rc = self.lib.cpx_track_batch_ex(
             self.h, C.c_void_p(frames_dev.data_ptr()), offs.ctypes.data_as(C.POINTER(C.c_int32)),
             C.c_void_p(meta.ctypes.data), B, C.c_void_p(comps.data_ptr()), C.c_void_p(info.data_ptr()),

@@ -86,6 +86,12 @@ class BatchPipeline:
         elif self._sample_buf is None or self._sample_buf.shape[0] < chunk or self._sample_buf.shape[1] != side:
             self._sample_buf = t.empty((chunk, side, side, 2), dtype=t.float32, device=dev)
         sample_bytes = side * side * 2 * 4
+        # a network living on a second engine (= a second HIP stream; the set-up of sub_batches > 1) is ordered
+        # against this engine's stream by events: its forward waits for the crop that fills its input, the next crop
+        # into the shared buffer waits for that forward, and the aggregation waits for the last forward
+        two_streams = self.net is not None and self.net.eng is not eng
+        s_eng = eng.torch_stream()
+        s_net = self.net.eng.torch_stream() if two_streams else None
         for s0 in range(0, n_samples, chunk):
             s1 = min(s0 + chunk, n_samples)
             buf = out.samples_dev[s0:s1] if keep_samples else self._sample_buf[: s1 - s0]
@@ -96,7 +102,15 @@ class BatchPipeline:
                 C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(reqs.data_ptr() + s0 * per * 32), (s1 - s0) * per,
                 C.c_void_p(limits.data_ptr()), self.fs, self.sq, C.c_void_p(buf.data_ptr() - s0 * sample_bytes)))
             if self.net is not None:
+                if two_streams:
+                    ev = t.cuda.Event()
+                    ev.record(s_eng)
+                    s_net.wait_event(ev)
                 self.net.forward_async(buf, logits[s0:s1], probs[s0:s1])
+                if two_streams:
+                    ev = t.cuda.Event()
+                    ev.record(s_net)
+                    s_eng.wait_event(ev)
         if self.net is None:
             eng.synchronize()
             return out
@@ -109,6 +123,8 @@ class BatchPipeline:
             C.c_void_p(out.scores.data_ptr()), C.c_void_p(out.best.data_ptr())))
         out.probs = probs
         eng.synchronize()  # results are complete when run() returns (callers read them from any stream)
+        if two_streams:
+            self.net.eng.synchronize()
         return out
 
     def _front(self, frames_dev, clip_offsets, meta, outputs, classify=True):

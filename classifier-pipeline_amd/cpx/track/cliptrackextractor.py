@@ -82,6 +82,15 @@ class WeightedBackgroundView:
     def get_average(self):
         return self.average
 
+    @property
+    def background_weight(self):
+        """The model's float64 weights after parse_clip (motiondetector.py:218-222): three blocking device-to-host
+        copies, made only when a caller asks (post_process_file hands them on)."""
+        src = getattr(self, "_weights_from", None)
+        if src is None:
+            raise AttributeError("background_weight")
+        return src.final_state()[1]
+
 
 class StreamBackgroundView:
     """extractor.background_alg during incremental tracking: the device's current background, fetched on demand."""
@@ -386,7 +395,10 @@ class ClipTrackExtractor(ClipTracker):
             avg = float(ext.average)
             last = self._imported
             if last is None or last[1] != avg or not np.array_equal(last[0], bg):
-                stream.engine.set_background(0, bg, getattr(ext, "background_weight", None), avg)
+                # the model is frozen (TRACK_FREEZE_BACKGROUND): the device neither reads nor updates the weights, so
+                # only background and average cross -- a detector whose weight_add differs from the extractor's
+                # (or whose weights were adjusted while recording) must not make the frame loop raise
+                stream.engine.set_background(0, bg, None, avg)
                 self._imported = (np.array(bg, copy=True), avg)
         elif not self.update_background:
             flags = TRACK_FREEZE_BACKGROUND
@@ -489,7 +501,9 @@ class ClipTrackExtractor(ClipTracker):
         res = eng.track_batch(frames_dev, offs, meta, want_labels=want_images, want_filtered=True,
                               want_background=True, flags=0 if self.update_background else TRACK_FREEZE_BACKGROUND)
         self._meta = meta
-        self._final_state = eng.get_background(0)
+        self._final_state = None   # read on demand (final_state), after the stream has drained anyway
+        self._final_engine = eng
+        self._final_call = eng.track_calls
         assoc = None
         if self.do_tracking and not clip.from_metadata:
             params = make_track_params(
@@ -530,8 +544,8 @@ class ClipTrackExtractor(ClipTracker):
         last = info[proc[-1]] if proc else None
         self.background_alg = WeightedBackgroundView(np.asarray(background, dtype=np.float64),
                                                      None if last is None else last["background_average"], weight_add)
-        if self._final_state is not None and b == 0 and n == len(self._frames or ()):
-            self.background_alg.background_weight = self._final_state[1]
+        if getattr(self, "_final_engine", None) is eng and b == 0 and n == len(self._frames or ()):
+            self.background_alg._weights_from = self  # background_weight is fetched when somebody reads it
         if assoc is not None:
             assoc.check()
             clip.tracks = [Track.from_device(clip, rec, regs, self.tracker_version, self.config)
@@ -539,6 +553,17 @@ class ClipTrackExtractor(ClipTracker):
             last_frame = clip.current_frame
             clip.active_tracks = set(t for t in clip.tracks if t.end_frame == last_frame and self._still_tracking(t))
             self.apply_track_filtering(clip)
+
+    def final_state(self):
+        """(background, weights, average) the model held after parse_clip's last frame (cpx_get_background)."""
+        if self._final_state is None:
+            if getattr(self, "_final_engine", None) is None:
+                return None
+            if self._final_engine.track_calls != self._final_call:
+                raise RuntimeError("the device engine has tracked another clip since this one: read the background "
+                                   "weights (extractor.final_state()) before tracking the next clip")
+            self._final_state = self._final_engine.get_background(0)
+        return self._final_state
 
     def close(self):
         """Release the device handle of an open frame-by-frame stream."""

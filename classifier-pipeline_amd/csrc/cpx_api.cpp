@@ -32,6 +32,7 @@ struct cpx_handle {
   double* wtab_dev = nullptr;
   uint32_t* wthr_dev = nullptr;
   int wtab_len = 0;
+  std::vector<double> wtab_host;  // w_k, k = 0 .. wtab_len - 1 (the table the device holds)
   int* nlm_lut_dev = nullptr;
   // small device arrays for the schedule
   int* sched_dev = nullptr;
@@ -233,8 +234,11 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   }
   // weight table: w_k = k-fold float64 accumulation of weight_add, exactly as
   // NumPy evaluates background_weight + weight_add (motiondetector.py:218-222)
-  h->wtab_len = cfg->max_frames + 2;
-  std::vector<double> wt(h->wtab_len);
+  // one entry per value the uint16 per-pixel counter can take: CPX_TRACK_KEEP_BACKGROUND chains and long streams
+  // carry a pixel's count past this handle's max_frames (the tables cost 786 KB per handle)
+  h->wtab_len = 65536;
+  h->wtab_host.resize(h->wtab_len);
+  std::vector<double>& wt = h->wtab_host;
   double w = 0.0;
   for (int k = 0; k < h->wtab_len; ++k) {
     wt[k] = w;
@@ -562,12 +566,7 @@ int cpx_set_background(cpx_handle* h, int clip, const float* background, const d
   }
   if (weights) {
     // a weight is the k-fold float64 accumulation of weight_add (motiondetector.py:218-222): find k, exactly
-    std::vector<double> wt(h->wtab_len);
-    double w = 0.0;
-    for (int k = 0; k < h->wtab_len; ++k) {
-      wt[k] = w;
-      w = w + c.weight_add;
-    }
+    const std::vector<double>& wt = h->wtab_host;
     const int iw = W - 2 * e, ih = H - 2 * e;
     for (int y = 0; y < ih; ++y)
       for (int x = 0; x < iw; ++x) {
@@ -615,12 +614,7 @@ int cpx_get_background(cpx_handle* h, int clip, float* background, double* weigh
     std::vector<uint16_t> kc(P);
     CPX_HIP(h, hipMemcpy(kc.data(), base + l.kcnt + (size_t)clip * P * sizeof(uint16_t), P * sizeof(uint16_t),
                          hipMemcpyDeviceToHost));
-    std::vector<double> wt(h->wtab_len);
-    double w = 0.0;
-    for (int k = 0; k < h->wtab_len; ++k) {
-      wt[k] = w;
-      w = w + c.weight_add;
-    }
+    const std::vector<double>& wt = h->wtab_host;
     const int iw = W - 2 * e, ih = H - 2 * e;
     for (int y = 0; y < ih; ++y)
       for (int x = 0; x < iw; ++x) {

@@ -324,8 +324,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
   __shared__ float4 s_out[4 * 256];
   const size_t total = (size_t)a.N * a.Ho * a.Wo;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    size_t p = idx;
+  // the loop condition is wave-uniform (a wave's first pixel): in the last wave of a launch whose pixel count is not a
+  // multiple of 64 the lanes past `total` compute a clamped (discarded) pixel and still take part in the store loop
+  // below, which writes slots of OTHER lanes' pixels
+  const int lane0 = threadIdx.x & 63;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx - lane0 < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t p = idx < total ? idx : total - 1;
     const int ox = (int)(p % a.Wo);
     p /= a.Wo;
     const int oy = (int)(p % a.Ho);

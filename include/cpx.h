@@ -168,7 +168,9 @@ int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_m
  *   CPX_TRACK_KEEP_BACKGROUND    do not seed background / weights / average from the clips' first frames: every clip
  *                                continues from the state the previous track call on this handle left for the clip of
  *                                the same index (same B), or from what cpx_set_background staged for it; the 45-frame
- *                                window starts empty as always
+ *                                window starts empty as always.  The per-pixel count of consecutive kept frames is a
+ *                                uint16 and the weight tables hold all 65,536 values: a pixel kept for more than
+ *                                65,535 frames in a row (two hours at 9 fps) across chained calls wraps to 0
  *   CPX_TRACK_FREEZE_ON_FFC      FFC-affected frames leave background, weights and average untouched
  *   CPX_TRACK_FREEZE_BACKGROUND  no frame updates them (update_background = False: the caller owns the model)
  * cpx_track_batch / cpx_track_frame are the _ex calls with flags 0. */

@@ -24,6 +24,7 @@ def engine():
 CASES = [
     # (Cin, Cout, H, W, ksize, stride, same)  -- every (channels per group, stride, kernel) of WR-ResNet-22-4
     (2, 16, 20, 24, 3, 1, True),      # conv1_1 (direct kernel)
+    (2, 16, 19, 23, 3, 1, True),      # conv1_1 with N*H*W = 874, not a multiple of 64: the last wave's LDS-staged stores
     (16, 64, 17, 21, 3, 1, True),     # res2b0_branch2a
     (16, 64, 17, 21, 1, 1, False),    # shortcut2
     (64, 64, 16, 33, 3, 1, True),     # res2*

@@ -107,7 +107,9 @@ def test_overlapped_sub_batches_equal_single_pass():
     plain = BatchPipeline(eng, wr.WRResNetDevice(eng, w, 17), n_labels=17, fp_index=4, cnn_chunk=7).run(dev, offs, meta)
     assert plain.n_tracks >= 4
     pipe = BatchPipeline(eng, wr.WRResNetDevice(ceng, w, 17), n_labels=17, fp_index=4, cnn_chunk=7)
-    for n_sub in (2, 3, 11):
+    # n_sub = 1 on the two-engine pipeline: the plain (non-overlapped) pass with the network on another stream than the
+    # crop / aggregation kernels -- ordered by events (cnn_chunk = 7: the shared sample buffer is reused per chunk)
+    for n_sub in (1, 2, 3, 11):
         got = pipe.run(dev, offs, meta, sub_batches=n_sub)
         got.track.check()
         got.assoc.check()
