@@ -63,6 +63,23 @@ CROP_REQ_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width
                            ("track", "<i4"), ("sample", "<i4"), ("tile", "<i4")])
 THUMB_STAT_DTYPE = np.dtype([("contours", "<i4"), ("status", "<i4"), ("median_diff", "<f8")])
 CONV_TIMING_DTYPE = np.dtype([("key", "<i4"), ("launches", "<i4"), ("total_ms", "<f8"), ("flops", "<f8")])
+# cpx_cptv_file / cpx_cptv_file_result / cpx_cptv_frame_slot (gzip inflate + section index on the device)
+CPTV_FILE_DTYPE = np.dtype([("in_offset", "<i8"), ("in_bytes", "<i8"), ("out_offset", "<i8"), ("out_capacity", "<i8"),
+                            ("slot_offset", "<i8"), ("slot_capacity", "<i4"), ("reserved", "<i4")])
+CPTV_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_frames", "<i4"), ("out_bytes", "<i8"), ("in_consumed", "<i8"),
+                              ("header_bytes", "<i4"), ("width", "<i4"), ("height", "<i4"), ("reserved", "<i4")])
+CPTV_SLOT_DTYPE = np.dtype([("offset", "<i8"), ("bit_width", "<i4"), ("time_on_ms", "<u4"), ("last_ffc_ms", "<u4"),
+                            ("temp_c", "<f4"), ("last_ffc_temp_c", "<f4"), ("flags", "<u4")])
+CPTV_HEADER_BYTES = 1024
+CPTV_BACKGROUND_FRAME, CPTV_HAS_TIME_ON, CPTV_HAS_LAST_FFC = 1, 2, 4
+CPTV_STATUS = {1: "deflate: reserved block type", 2: "deflate: stored block length", 3: "deflate: block header",
+               4: "deflate: code lengths", 5: "deflate: invalid symbol", 6: "deflate: distance too far back",
+               7: "inflated data larger than the gzip trailer says", 8: "deflate: input exhausted (truncated file)",
+               9: "deflate: no end-of-block code", 10: "not a gzip member", 11: "gzip trailer / further member",
+               20: "not a CPTV file", 21: "unsupported CPTV version", 22: "CPTV header section", 23: "expected frame section",
+               24: "truncated CPTV frame", 25: "malformed CPTV frame section", 26: "more frames than slots",
+               27: "CPTV file has no frames"}
+assert CPTV_FILE_DTYPE.itemsize == 48 and CPTV_RESULT_DTYPE.itemsize == 40 and CPTV_SLOT_DTYPE.itemsize == 32
 assert REGION_REF_DTYPE.itemsize == 24 and TRACK_LIMITS_DTYPE.itemsize == 16 and CROP_REQ_DTYPE.itemsize == 32
 assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FRAME_INFO_DTYPE.itemsize == 80
 
@@ -104,7 +121,7 @@ EXPORTS = [
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
-    "cpx_cnn_head_ex", "cpx_ir_delta_variance",
+    "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index",
 ]
 
 # flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
@@ -208,6 +225,10 @@ def load():
     lib.cpx_trackless_thumb.restype = C.c_int
     lib.cpx_cptv_unpack.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
     lib.cpx_cptv_unpack.restype = C.c_int
+    lib.cpx_cptv_inflate.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.cpx_cptv_inflate.restype = C.c_int
+    lib.cpx_cptv_gather_index.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    lib.cpx_cptv_gather_index.restype = C.c_int
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]

@@ -89,6 +89,40 @@ def _f32(b):
     return struct.unpack("<f", b)[0]
 
 
+def _header_from_fields(fields):
+    h = CptvHeader()
+    if "T" in fields:
+        h.timestamp = struct.unpack("<Q", fields["T"])[0]
+    h.x_resolution = _u32(fields["X"])
+    h.y_resolution = _u32(fields["Y"])
+    h.compression = fields.get("C", b"\0")[0]
+    for code, name in (("D", "device_name"), ("E", "model"), ("B", "brand"),
+                       ("V", "firmware"), ("M", "motion_config")):
+        if code in fields:
+            setattr(h, name, fields[code].decode("utf-8", "replace"))
+    if "Z" in fields:
+        h.fps = fields["Z"][0]
+    if "I" in fields:
+        h.device_id = _u32(fields["I"])
+    if "N" in fields:
+        h.serial = _u32(fields["N"])
+    if "P" in fields:
+        h.preview_secs = fields["P"][0]
+    if "L" in fields:
+        h.latitude = _f32(fields["L"])
+    if "O" in fields:
+        h.longitude = _f32(fields["O"])
+    if "S" in fields:
+        h.loc_timestamp = struct.unpack("<Q", fields["S"])[0]
+    if "A" in fields:
+        h.altitude = _f32(fields["A"])
+    if "U" in fields:
+        h.accuracy = _f32(fields["U"])
+    if "g" in fields:
+        h.has_background_frame = fields["g"][0] != 0
+    return h
+
+
 def _unpack_deltas(payload, n, width):
     """n signed `width`-bit big-endian (MSB first) values from payload -> int64."""
     if width == 8:
@@ -137,36 +171,7 @@ class CptvReader:
         if buf[5:6] != b"H":
             raise ValueError("CPTV header section missing")
         fields, self._pos = _read_fields(buf, 6)
-        h = CptvHeader()
-        if "T" in fields:
-            h.timestamp = struct.unpack("<Q", fields["T"])[0]
-        h.x_resolution = _u32(fields["X"])
-        h.y_resolution = _u32(fields["Y"])
-        h.compression = fields.get("C", b"\0")[0]
-        for code, name in (("D", "device_name"), ("E", "model"), ("B", "brand"),
-                           ("V", "firmware"), ("M", "motion_config")):
-            if code in fields:
-                setattr(h, name, fields[code].decode("utf-8", "replace"))
-        if "Z" in fields:
-            h.fps = fields["Z"][0]
-        if "I" in fields:
-            h.device_id = _u32(fields["I"])
-        if "N" in fields:
-            h.serial = _u32(fields["N"])
-        if "P" in fields:
-            h.preview_secs = fields["P"][0]
-        if "L" in fields:
-            h.latitude = _f32(fields["L"])
-        if "O" in fields:
-            h.longitude = _f32(fields["O"])
-        if "S" in fields:
-            h.loc_timestamp = struct.unpack("<Q", fields["S"])[0]
-        if "A" in fields:
-            h.altitude = _f32(fields["A"])
-        if "U" in fields:
-            h.accuracy = _f32(fields["U"])
-        if "g" in fields:
-            h.has_background_frame = fields["g"][0] != 0
+        h = _header_from_fields(fields)
         self._header = h
         self._w = h.x_resolution
         self._h = h.y_resolution
@@ -291,3 +296,139 @@ def decode_clips_on_device(engine, paths, workers=8):
     frames_dev = engine.cptv_unpack(payload, np.concatenate(offs), np.concatenate(widths),
                                     np.asarray(clip_offsets, np.int32))
     return headers, metas, frames_dev, np.asarray(clip_offsets, np.int32)
+
+
+# ---- whole files on the device: gzip inflate + section index + frame unpack (cpx_cptv_inflate) -------------------
+
+def parse_header_bytes(buf):
+    """CptvHeader from the first bytes of an inflated file (magic, version, section H)."""
+    if buf[:4] != b"CPTV" or buf[4] != 2 or buf[5:6] != b"H":
+        raise ValueError("not a CPTV v2 header")
+    fields, _ = _read_fields(buf, 6)
+    return _header_from_fields(fields)
+
+
+class DeviceFileBatch:
+    """What inflate_files_on_device returns.  ``ok`` lists the indices (into the input list) of the files that
+    decoded; headers / metas / clip_offsets are per those files, in that order; ``errors`` maps the index of every
+    other file to a message."""
+
+    def __init__(self):
+        self.ok = []
+        self.errors = {}
+        self.headers = []
+        self.slots = None         # CPTV_SLOT_DTYPE [total frames] (host)
+        self.clip_offsets = None  # int32 [len(ok) + 1]
+        self.frames_dev = None    # uint16 bits [total, H, W] (torch int16)
+        self.results = None       # CPTV_RESULT_DTYPE per input file
+
+    def frame_metas(self, k):
+        """Metadata-only CptvFrame objects of the k-th decoded file (the reader API's per-frame fields)."""
+        from ._lib import CPTV_BACKGROUND_FRAME, CPTV_HAS_LAST_FFC, CPTV_HAS_TIME_ON
+
+        s = self.slots[self.clip_offsets[k]:self.clip_offsets[k + 1]]
+        fl = s["flags"].tolist()
+        return [CptvFrame(None, t if f & CPTV_HAS_TIME_ON else None, c if f & CPTV_HAS_LAST_FFC else None, a, b,
+                          bool(f & CPTV_BACKGROUND_FRAME))
+                for t, c, a, b, f in zip(s["time_on_ms"].tolist(), s["last_ffc_ms"].tolist(), s["temp_c"].tolist(),
+                                         s["last_ffc_temp_c"].tolist(), fl)]
+
+
+def inflate_files_on_device(engine, blobs, names=None):
+    """The bytes of whole .cptv files -> frames on the device, without the host touching their content: upload,
+    cpx_cptv_inflate (one wavefront per file: gzip + DEFLATE + section walk), cpx_cptv_gather_index,
+    cpx_cptv_unpack.  A file that fails is reported in ``errors`` and leaves the others alone."""
+    import ctypes as C
+
+    from ._lib import (CPTV_FILE_DTYPE, CPTV_HEADER_BYTES, CPTV_RESULT_DTYPE, CPTV_SLOT_DTYPE, CPTV_STATUS, CpxError)
+
+    t = engine.torch
+    dev = engine.device
+    n = len(blobs)
+    out = DeviceFileBatch()
+    if n == 0:
+        return out
+    P = engine.width * engine.height
+    min_frame = 4 + (P - 1 + 7) // 8 + 8      # payload at one bit per delta + the smallest field list
+    files = np.zeros(n, CPTV_FILE_DTYPE)
+    sizes = np.array([len(b) for b in blobs], np.int64)
+    in_off = np.zeros(n + 1, np.int64)
+    np.cumsum((sizes + 15) & ~15, out=in_off[1:])
+    isize = np.zeros(n, np.int64)
+    for i, b in enumerate(blobs):
+        if len(b) >= 18:
+            isize[i] = int.from_bytes(bytes(b[-4:]), "little")
+            # DEFLATE cannot expand by more than 1032 : 1; a trailer beyond that is not one (a truncated file's last
+            # bytes): no capacity -> the file fails with "output" / "input exhausted" instead of reserving gigabytes
+            if isize[i] > 1032 * len(b) + 64:
+                isize[i] = 0
+    files["in_offset"], files["in_bytes"] = in_off[:-1], sizes
+    cap = (isize + 15) & ~15
+    out_off = np.zeros(n + 1, np.int64)
+    np.cumsum(cap + 16, out=out_off[1:])
+    files["out_offset"], files["out_capacity"] = out_off[:-1], isize
+    slot_cap = isize // min_frame + 1
+    slot_off = np.zeros(n + 1, np.int64)
+    np.cumsum(slot_cap, out=slot_off[1:])
+    files["slot_offset"], files["slot_capacity"] = slot_off[:-1], slot_cap
+    stage = t.empty(int(in_off[-1]) + 16, dtype=t.uint8, pin_memory=True)
+    sv = stage.numpy()
+    for i, b in enumerate(blobs):
+        sv[in_off[i]:in_off[i] + sizes[i]] = np.frombuffer(b, np.uint8)
+    in_dev = stage.to(dev, non_blocking=True)
+    files_dev = engine._to_dev(files)
+    out_dev = t.empty(int(out_off[-1]) + 16, dtype=t.uint8, device=dev)
+    slots_dev = t.empty(max(int(slot_off[-1]), 1) * 8, dtype=t.int32, device=dev)
+    header_dev = t.empty((n, CPTV_HEADER_BYTES), dtype=t.uint8, device=dev)
+    results_dev = t.zeros(n * 10, dtype=t.int32, device=dev)
+    engine.sync_inputs()
+    p = lambda x: C.c_void_p(x.data_ptr())
+    rc = engine.lib.cpx_cptv_inflate(engine.h, p(in_dev), p(files_dev), n, p(out_dev), p(slots_dev), p(header_dev),
+                                     p(results_dev))
+    if rc != 0:
+        raise CpxError(rc, engine._err())
+    engine.synchronize()
+    res = results_dev.cpu().numpy().view(CPTV_RESULT_DTYPE).reshape(-1)
+    out.results = res
+    hdr = header_dev.cpu().numpy()
+    for i in range(n):
+        st = int(res["status"][i])
+        name = names[i] if names else "file %d" % i
+        if st != 0:
+            out.errors[i] = "%s: %s" % (name, CPTV_STATUS.get(st, "status %d" % st))
+        elif (int(res["width"][i]), int(res["height"][i])) != (engine.width, engine.height):
+            out.errors[i] = "%s is %dx%d, the engine was created for %dx%d" % (
+                name, res["width"][i], res["height"][i], engine.width, engine.height)
+        elif int(res["header_bytes"][i]) > CPTV_HEADER_BYTES:
+            out.errors[i] = "%s: header section of %d bytes" % (name, res["header_bytes"][i])
+        else:
+            out.ok.append(i)
+    if not out.ok:
+        out.clip_offsets = np.zeros(1, np.int32)
+        return out
+    ok = np.asarray(out.ok)
+    out.headers = [parse_header_bytes(hdr[i].tobytes()) for i in out.ok]
+    offs = np.zeros(len(ok) + 1, np.int32)
+    np.cumsum(res["n_frames"][ok], out=offs[1:])
+    total = int(offs[-1])
+    out.clip_offsets = offs
+    offs_dev = t.from_numpy(offs).to(dev)
+    so_dev = t.from_numpy(np.ascontiguousarray(slot_off[:-1][ok])).to(dev)
+    fo_dev = t.empty(total, dtype=t.int64, device=dev)
+    bw_dev = t.empty(total, dtype=t.int32, device=dev)
+    dense_dev = t.empty(total * 8, dtype=t.int32, device=dev)
+    frames_dev = t.empty((total, engine.height, engine.width), dtype=t.int16, device=dev)
+    engine.sync_inputs()
+    rc = engine.lib.cpx_cptv_gather_index(engine.h, p(slots_dev), p(so_dev), p(offs_dev), len(ok), p(fo_dev), p(bw_dev),
+                                          p(dense_dev))
+    if rc != 0:
+        raise CpxError(rc, engine._err())
+    rc = engine.lib.cpx_cptv_unpack(engine.h, p(out_dev), p(fo_dev), p(bw_dev), p(offs_dev), len(ok), p(frames_dev))
+    if rc != 0:
+        raise CpxError(rc, engine._err())
+    engine.synchronize()
+    out.slots = dense_dev.cpu().numpy().view(CPTV_SLOT_DTYPE).reshape(-1)
+    out.frames_dev = frames_dev
+    out.inflated_dev = out_dev          # kept for tests (the inflated bytes, file i at files["out_offset"][i])
+    out.files = files
+    return out

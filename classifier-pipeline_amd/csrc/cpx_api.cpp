@@ -1106,6 +1106,44 @@ int cpx_cptv_unpack(cpx_handle* h, const uint8_t* payload_dev, const int64_t* fr
   return CPX_OK;
 }
 
+int cpx_cptv_inflate(cpx_handle* h, const uint8_t* in_dev, const cpx_cptv_file* files_dev, int B, uint8_t* out_dev,
+                     cpx_cptv_frame_slot* slots_dev, uint8_t* header_dev, cpx_cptv_file_result* results_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!in_dev || !files_dev || !out_dev || !slots_dev || !results_dev || B < 1)
+    return fail(h, CPX_ERR_INVALID, "cpx_cptv_inflate: bad argument");
+  CPX_ENTER(h);
+  cpx::CptvInflateArgs a{};
+  a.B = B;
+  a.in = in_dev;
+  a.files = files_dev;
+  a.out = out_dev;
+  a.slots = slots_dev;
+  a.header = header_dev;
+  a.results = results_dev;
+  cpx::launch_cptv_inflate(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
+int cpx_cptv_gather_index(cpx_handle* h, const cpx_cptv_frame_slot* slots_dev, const int64_t* slot_offsets_dev,
+                          const int32_t* clip_offsets_dev, int B, int64_t* frame_offsets_dev, int32_t* bit_widths_dev,
+                          cpx_cptv_frame_slot* slots_out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!slots_dev || !slot_offsets_dev || !clip_offsets_dev || !frame_offsets_dev || !bit_widths_dev || B < 1)
+    return fail(h, CPX_ERR_INVALID, "cpx_cptv_gather_index: bad argument");
+  CPX_ENTER(h);
+  cpx::CptvGatherArgs a{};
+  a.slots = slots_dev;
+  a.slot_offsets = (const long long*)slot_offsets_dev;
+  a.clip_offsets = clip_offsets_dev;
+  a.frame_offsets = (long long*)frame_offsets_dev;
+  a.bit_widths = bit_widths_dev;
+  a.slots_out = slots_out_dev;
+  cpx::launch_cptv_gather(a, B, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
                     const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev, int n_refs,
                     cpx_thumb_stat* out_dev) {

@@ -219,6 +219,27 @@ struct CptvArgs {
 };
 int launch_cptv_unpack(const CptvArgs& a, int B, hipStream_t s);
 
+struct CptvInflateArgs {
+  int B;
+  const unsigned char* in;
+  const cpx_cptv_file* files;
+  unsigned char* out;
+  cpx_cptv_frame_slot* slots;
+  unsigned char* header;
+  cpx_cptv_file_result* results;
+};
+int launch_cptv_inflate(const CptvInflateArgs& a, hipStream_t s);
+
+struct CptvGatherArgs {
+  const cpx_cptv_frame_slot* slots;
+  const long long* slot_offsets;
+  const int* clip_offsets;
+  long long* frame_offsets;
+  int* bit_widths;
+  cpx_cptv_frame_slot* slots_out;
+};
+int launch_cptv_gather(const CptvGatherArgs& a, int B, hipStream_t s);
+
 struct ThumbArgs {
   int W, H, chain_cap;
   const uint16_t* frames;

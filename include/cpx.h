@@ -216,6 +216,63 @@ int cpx_cptv_unpack(cpx_handle* h, const uint8_t* payload_dev, const int64_t* fr
                     const int32_t* bit_widths_dev, const int32_t* clip_offsets_dev, int B,
                     uint16_t* frames_out_dev);
 
+/* ---- CPTV v2 container on the GPU: gzip inflate + section index -------------------------
+ * Replaces CptvReader(path) / get_header() / next_frame() of the Rust reader (python-cptv 0.0.8 -> flate2) at the
+ * call sites track/cliptrackextractor.py:108-129,160-162 and classify/clipclassifier.py:460-469, for B WHOLE FILES
+ * per call: the bytes of the .cptv files go to the device as they are on disk.  One wavefront per file parses the
+ * gzip member header (RFC 1952), inflates the DEFLATE stream (RFC 1951: stored, fixed and dynamic blocks; decode
+ * tables in LDS) into out_dev and walks the CPTV sections of what it inflated: header fields, then per frame the
+ * field list and the offset of the payload -- what cpx_cptv_unpack needs.  A file that fails (corrupt stream, output
+ * larger than its capacity, malformed section, more frames than slots) gets a non-zero status in its result record and
+ * does not affect the others; nothing is written outside the file's own output / slot ranges.
+ *
+ * in_dev        the files' bytes, file i at files[i].in_offset (multiple of 4), in_bytes long; the buffer must be
+ *               readable for 8 bytes past the last file
+ * files_dev     [B] where each file's input, output and frame slots live
+ * out_dev       inflated bytes: file i at out_offset (multiple of 16), at most out_capacity bytes (the gzip trailer's
+ *               ISIZE, the last four bytes of a single-member file, is the exact figure)
+ * slots_dev     frame slots: file i's frames at slot_offset .. slot_offset + n_frames (<= slot_capacity)
+ * header_dev    [B][CPX_CPTV_HEADER_BYTES] the first bytes of every inflated file (magic, version, header section) for
+ *               the host to read the camera model, timestamps ... from
+ * results_dev   [B]
+ * Status values: 0 ok; 1-9 DEFLATE errors (block type, stored length, code lengths, table, symbol, distance, output
+ * capacity, input exhausted, no end-of-block code); 10 gzip header; 11 data after the member's trailer / ISIZE mismatch
+ * (a multi-member file: inflate it on the host); 20-27 CPTV section errors (magic, version, header, section tag,
+ * truncated, frame fields, slots, no frames).  Asynchronous on the handle's stream. */
+#define CPX_CPTV_HEADER_BYTES 1024
+#define CPX_CPTV_BACKGROUND_FRAME 1u
+#define CPX_CPTV_HAS_TIME_ON 2u
+#define CPX_CPTV_HAS_LAST_FFC 4u
+typedef struct cpx_cptv_file {
+  int64_t in_offset, in_bytes;
+  int64_t out_offset, out_capacity;
+  int64_t slot_offset;
+  int32_t slot_capacity, reserved;
+} cpx_cptv_file;
+typedef struct cpx_cptv_file_result {
+  int32_t status, n_frames;
+  int64_t out_bytes;        /* inflated size */
+  int64_t in_consumed;      /* bytes of the file up to and including the gzip trailer */
+  int32_t header_bytes;     /* offset of the first frame section in the inflated data */
+  int32_t width, height;    /* header fields X, Y */
+  int32_t reserved;
+} cpx_cptv_file_result;
+typedef struct cpx_cptv_frame_slot {
+  int64_t offset;           /* of the frame's payload inside out_dev */
+  int32_t bit_width;
+  uint32_t time_on_ms, last_ffc_ms;
+  float temp_c, last_ffc_temp_c;
+  uint32_t flags;           /* CPX_CPTV_* */
+} cpx_cptv_frame_slot;
+int cpx_cptv_inflate(cpx_handle* h, const uint8_t* in_dev, const cpx_cptv_file* files_dev, int B, uint8_t* out_dev,
+                     cpx_cptv_frame_slot* slots_dev, uint8_t* header_dev, cpx_cptv_file_result* results_dev);
+/* The slots of the files that decoded (clip b = file file_index[b], n_frames[b] frames) gathered into the dense
+ * per-frame arrays of cpx_cptv_unpack: frame_offsets_dev int64 [total], bit_widths_dev int32 [total], and
+ * slots_out_dev [total] (the same records, dense: times / flags for the host).  clip_offsets_dev int32 [B+1]. */
+int cpx_cptv_gather_index(cpx_handle* h, const cpx_cptv_frame_slot* slots_dev, const int64_t* slot_offsets_dev,
+                          const int32_t* clip_offsets_dev, int B, int64_t* frame_offsets_dev, int32_t* bit_widths_dev,
+                          cpx_cptv_frame_slot* slots_out_dev);
+
 /* ---- track stage: background + filtered + threshold + CC + stats ---------
  * Replaces, for a batch of B independent clips, the per-frame arithmetic of
  *   ClipTrackExtractor.init_clip / _track_clip / process_frame

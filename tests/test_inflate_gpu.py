@@ -1,0 +1,131 @@
+"""Whole .cptv files decoded on the GPU (cpx_cptv_inflate: gzip + DEFLATE + section walk, one wavefront per file;
+cpx_cptv_gather_index; cpx_cptv_unpack) against zlib and the host reader: inflated bytes, section index, frames --
+for the fixture recordings, the same content recompressed into every DEFLATE block type, synthetic recordings of
+other delta widths, and batches with corrupt members, which must fail alone."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, encode_cptv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3")
+    yield eng
+    eng.close()
+
+
+def regzip(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, 31, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def host_view(blob):
+    """(inflated bytes, frames uint16 [n, H, W], per-frame (time_on, last_ffc, temp, ffc temp, background)) by the host reader."""
+    import tempfile
+
+    from cpx.cptv import CptvReader
+
+    with tempfile.NamedTemporaryFile(suffix=".cptv") as fh:
+        fh.write(blob)
+        fh.flush()
+        r = CptvReader(fh.name)
+        fr = r.read_all()
+    return r.inflated, np.stack([f.pix for f in fr]), [(f.time_on, f.last_ffc_time, f.temp_c, f.last_ffc_temp_c,
+                                                         f.background_frame) for f in fr], r.get_header()
+
+
+def check(engine, blobs):
+    from cpx.cptv import inflate_files_on_device
+
+    got = inflate_files_on_device(engine, blobs)
+    assert got.errors == {}, got.errors
+    assert got.ok == list(range(len(blobs)))
+    frames = got.frames_dev.cpu().numpy().view(np.uint16)
+    raw = got.inflated_dev.cpu().numpy()
+    for k, blob in enumerate(blobs):
+        want_bytes, want_frames, want_meta, hdr = host_view(blob)
+        o = int(got.files["out_offset"][k])
+        assert int(got.results["out_bytes"][k]) == len(want_bytes)
+        assert raw[o:o + len(want_bytes)].tobytes() == want_bytes, k
+        f0, f1 = int(got.clip_offsets[k]), int(got.clip_offsets[k + 1])
+        assert f1 - f0 == len(want_frames)
+        assert np.array_equal(frames[f0:f1], want_frames), k
+        metas = got.frame_metas(k)
+        assert [(m.time_on, m.last_ffc_time, m.temp_c, m.last_ffc_temp_c, m.background_frame) for m in metas] == want_meta
+        h = got.headers[k]
+        assert (h.model, h.brand, h.timestamp, h.x_resolution, h.y_resolution, h.fps, h.device_name) == (
+            hdr.model, hdr.brand, hdr.timestamp, hdr.x_resolution, hdr.y_resolution, hdr.fps, hdr.device_name)
+    return got
+
+
+def fixture(name):
+    with open(os.path.join(GOLDEN, name + ".cptv"), "rb") as fh:
+        return fh.read()
+
+
+def test_fixture_recordings(engine):
+    check(engine, [fixture("possum"), fixture("hedgehog")])
+
+
+def test_every_block_type(engine):
+    """The possum recording's content behind stored blocks (level 0), the fixed code, Huffman only, run-length matches
+    and small / large hash tables: every decoding path of RFC 1951."""
+    data = zlib.decompress(fixture("possum"), 47)[:600000]
+    # cut at a frame boundary: keep whole sections only (the section walk rejects a truncated frame)
+    from cpx.cptv import CptvReader
+
+    r = CptvReader(os.path.join(GOLDEN, "possum.cptv"))
+    _, offsets, widths = r.scan()
+    P = 160 * 120
+    ends = [int(o) + 4 + ((P - 1) * int(w) + 7) // 8 for o, w in zip(offsets, widths)]
+    data = r.inflated[:[e for e in ends if e <= 600000][-1]]
+    blobs = [regzip(data, 0), regzip(data, 1), regzip(data, 9), regzip(data, 6, zlib.Z_FIXED),
+             regzip(data, 6, zlib.Z_HUFFMAN_ONLY), regzip(data, 6, zlib.Z_RLE), regzip(data, 9, memlevel=1)]
+    check(engine, blobs)
+
+
+def test_synthetic_widths_and_ragged_batch(engine, tmp_path):
+    from cpx import synth
+
+    rng = np.random.default_rng(5)
+    blobs = []
+    for k, (n, w) in enumerate(((3, 16), (40, 12), (17, 9), (1, 32), (64, 16))):
+        clip = synth.make_clip(rng, n, max_blobs=2)
+        p = tmp_path / ("s%d.cptv" % k)
+        encode_cptv(p, clip, [w] * n, time_on=[1000 + 111 * i for i in range(n)], last_ffc=[7] * n,
+                    background_first=(k % 2 == 0))
+        blobs.append(p.read_bytes())
+    check(engine, blobs)
+
+
+def test_corrupt_members_fail_alone(engine):
+    from cpx.cptv import inflate_files_on_device
+
+    good = fixture("hedgehog")
+    rng = np.random.default_rng(3)
+    flipped = bytearray(good)
+    for _ in range(40):
+        flipped[int(rng.integers(100, len(flipped) - 8))] ^= 0xFF
+    not_cptv = regzip(b"x" * 5000)
+    two_members = good + regzip(b"tail")
+    blobs = [good, good[: len(good) // 2], bytes(flipped), b"not gzip at all....................", not_cptv,
+             two_members, fixture("possum"), b""]
+    got = inflate_files_on_device(engine, blobs, names=["f%d" % i for i in range(len(blobs))])
+    assert got.ok == [0, 6], (got.ok, got.errors)
+    assert set(got.errors) == {1, 2, 3, 4, 5, 7}
+    assert int(got.results["status"][3]) == 10 and int(got.results["status"][4]) == 20
+    # a second gzip member: the trailer at the end of the file belongs to it, so the first member either overflows the
+    # capacity taken from it (7) or ends before the end of the file (11) -- both send the file to the host reader
+    assert int(got.results["status"][5]) in (7, 11)
+    frames = got.frames_dev.cpu().numpy().view(np.uint16)
+    for k, name in enumerate(("hedgehog", "possum")):
+        _, want, _, _ = host_view(fixture(name))
+        assert np.array_equal(frames[got.clip_offsets[k]:got.clip_offsets[k + 1]], want)
