@@ -1,0 +1,635 @@
+"""The file-fed extract path at device speed: what TrackExtractor.extract(directory) runs
+(reference src/track/trackextractor.py:60-120 forks a pool of CPU workers over the files; here the files of a directory
+go through ONE device in large batches and no per-frame or per-region Python object is built on the way).
+
+Per batch of recordings:
+  host     the files' bytes are read into pinned memory by a thread pool (readinto: no copy, no GIL), the next batch
+           while the device works on this one
+  device   cpx_cptv_inflate (gzip + DEFLATE + section walk, one wavefront per file) -> cpx_cptv_gather_index ->
+           cpx_cptv_unpack -> cpx_track_batch -> cpx_associate_batch -> cpx_finalize_tracks (trim, statistics, score
+           order, rejects) -> the kept tracks' regions gathered into one array -> cpx_thumb_stats for all of them
+  host     per file: the thumbnail ranking (a few NumPy operations per track), the metadata JSON with the positions
+           written by cpx_format_regions, one file write
+A recording that fails anywhere (unreadable, corrupt gzip, malformed section, another resolution than its group's
+engine, capacity overflow) is logged and retried alone through extract_file; when that fails too it is skipped -- the
+other recordings of the batch are unaffected.
+
+The metadata equals extract_file's field by field (tests/test_batch_files_gpu.py): the device's end-of-clip statistics
+are bit-identical to the host's (scratch/final_exact_probe.py, 422 tracks), the thumbnail scores are computed by the
+same float64 operations in the same order."""
+
+import ctypes as C
+import json
+import logging
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+from datetime import datetime, timedelta
+
+import numpy as np
+
+from .._lib import (CPTV_BACKGROUND_FRAME, CPTV_FILE_DTYPE, CPTV_HAS_LAST_FFC, CPTV_HAS_TIME_ON, CPTV_HEADER_BYTES,
+                    CPTV_RESULT_DTYPE, CPTV_SLOT_DTYPE, CPTV_STATUS, FRAME_INFO_DTYPE, FRAME_META_DTYPE,
+                    REGION_REF_DTYPE, THUMB_STAT_DTYPE, CpxError)
+from ..ml_tools import tools
+from ..tracking import (REGION_DTYPE, TRACK_SUMMARY_DTYPE, make_filter_params, make_track_params)
+from .clip import Clip
+
+THUMBNAIL_SIZE = 64
+
+
+class StagedFiles:
+    """A batch of files in pinned host memory."""
+
+    def __init__(self, paths, stage, in_off, sizes, isize, errors):
+        self.paths, self.stage, self.in_off, self.sizes, self.isize, self.errors = paths, stage, in_off, sizes, isize, errors
+
+
+class FileStager:
+    """Reads batches of files into (two alternating) pinned buffers with a thread pool; stage(paths) returns a future."""
+
+    def __init__(self, torch, threads=None):
+        self.torch = torch
+        self.threads = threads or min(16, os.cpu_count() or 1)
+        self.pool = ThreadPoolExecutor(max_workers=self.threads)
+        self.driver = ThreadPoolExecutor(max_workers=1)
+        self.buffers = [None, None]
+        self.turn = 0
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        self.driver.shutdown(wait=True)
+
+    def stage(self, paths):
+        slot = self.turn
+        self.turn ^= 1
+        return self.driver.submit(self._stage, list(paths), slot)
+
+    def _stage(self, paths, slot):
+        t = self.torch
+        n = len(paths)
+        sizes = np.zeros(n, np.int64)
+        errors = {}
+        for i, p in enumerate(paths):
+            try:
+                sizes[i] = os.path.getsize(p)
+            except OSError as e:
+                errors[i] = "%s: %s" % (p, e)
+        in_off = np.zeros(n + 1, np.int64)
+        np.cumsum((sizes + 15) & ~15, out=in_off[1:])
+        need = int(in_off[-1]) + 16
+        buf = self.buffers[slot]
+        if buf is None or buf.numel() < need:
+            buf = t.empty(max(need, 1 << 20), dtype=t.uint8, pin_memory=True)
+            self.buffers[slot] = buf
+        view = memoryview(buf.numpy())
+        isize = np.zeros(n, np.int64)
+
+        def read(i):
+            if i in errors or sizes[i] == 0:
+                return
+            try:
+                with open(paths[i], "rb", buffering=0) as fh:
+                    got = fh.readinto(view[in_off[i]:in_off[i] + sizes[i]])
+                if got != sizes[i]:
+                    errors[i] = "%s: short read (%d of %d bytes)" % (paths[i], got, sizes[i])
+                    return
+                if sizes[i] >= 18:
+                    v = int.from_bytes(view[in_off[i] + sizes[i] - 4:in_off[i] + sizes[i]], "little")
+                    # DEFLATE cannot expand by more than 1032 : 1: a larger figure is not a gzip trailer
+                    isize[i] = v if v <= 1032 * sizes[i] + 64 else 0
+            except OSError as e:
+                errors[i] = "%s: %s" % (paths[i], e)
+
+        list(self.pool.map(read, range(n)))
+        return StagedFiles(paths, buf, in_off, sizes, isize, errors)
+
+
+def stage_blobs(torch, blobs):
+    """The same staging for byte strings already in memory (bench.py from_files, tests)."""
+    n = len(blobs)
+    sizes = np.array([len(b) for b in blobs], np.int64)
+    in_off = np.zeros(n + 1, np.int64)
+    np.cumsum((sizes + 15) & ~15, out=in_off[1:])
+    buf = torch.empty(int(in_off[-1]) + 16, dtype=torch.uint8, pin_memory=True)
+    view = buf.numpy()
+    isize = np.zeros(n, np.int64)
+    for i, b in enumerate(blobs):
+        view[in_off[i]:in_off[i] + sizes[i]] = np.frombuffer(b, np.uint8)
+        if sizes[i] >= 18:
+            v = int.from_bytes(bytes(b[-4:]), "little")
+            isize[i] = v if v <= 1032 * sizes[i] + 64 else 0
+    return StagedFiles([None] * n, buf, in_off, sizes, isize, {})
+
+
+class DecodedBatch:
+    """Frames of the files that decoded, grouped by what one engine can track together."""
+
+    def __init__(self):
+        self.errors = {}      # file index -> message
+        self.groups = []      # DecodedGroup
+        self.results = None
+
+
+class DecodedGroup:
+    def __init__(self, key, files, headers, offs, slots, frames_dev):
+        self.key = key                # (width, height, camera model)
+        self.files = files            # indices into the staged batch
+        self.headers = headers        # CptvHeader per file
+        self.offs = offs              # int32 [len(files) + 1] frame ranges inside frames_dev
+        self.slots = slots            # CPTV_SLOT_DTYPE [total]
+        self.frames_dev = frames_dev  # uint16 bits [total, H, W]
+
+
+def decode_staged(eng, staged, min_pixels=160 * 120):
+    """cpx_cptv_inflate over a staged batch, then per (resolution, camera model) group gather + unpack.  `eng`: any
+    engine on the device (the inflate kernel does not depend on its geometry; the unpack of a group runs on an engine
+    of that group's resolution, created on demand)."""
+    from ..cptv import parse_header_bytes
+    from .cliptrackextractor import get_engine
+
+    t, dev = eng.torch, eng.device
+    n = len(staged.sizes)
+    out = DecodedBatch()
+    out.errors.update(staged.errors)
+    min_frame = 4 + (min_pixels - 1 + 7) // 8 + 8
+    files = np.zeros(n, CPTV_FILE_DTYPE)
+    sizes = np.where(np.isin(np.arange(n), list(staged.errors)), 0, staged.sizes)
+    files["in_offset"], files["in_bytes"] = staged.in_off[:-1], sizes
+    isize = np.where(sizes > 0, staged.isize, 0)
+    out_off = np.zeros(n + 1, np.int64)
+    np.cumsum(((isize + 15) & ~15) + 16, out=out_off[1:])
+    files["out_offset"], files["out_capacity"] = out_off[:-1], isize
+    slot_cap = isize // min_frame + 1
+    slot_off = np.zeros(n + 1, np.int64)
+    np.cumsum(slot_cap, out=slot_off[1:])
+    files["slot_offset"], files["slot_capacity"] = slot_off[:-1], slot_cap
+    n_in = int(staged.in_off[-1]) + 16
+    in_dev = staged.stage[:n_in].to(dev, non_blocking=True)
+    files_dev = eng._to_dev(files)
+    out_dev = t.empty(int(out_off[-1]) + 16, dtype=t.uint8, device=dev)
+    slots_dev = t.empty(max(int(slot_off[-1]), 1) * 8, dtype=t.int32, device=dev)
+    header_dev = t.empty((n, CPTV_HEADER_BYTES), dtype=t.uint8, device=dev)
+    results_dev = t.zeros(n * 10, dtype=t.int32, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    eng.sync_inputs()
+    rc = eng.lib.cpx_cptv_inflate(eng.h, p(in_dev), p(files_dev), n, p(out_dev), p(slots_dev), p(header_dev),
+                                  p(results_dev))
+    if rc != 0:
+        raise CpxError(rc, eng._err())
+    eng.synchronize()
+    res = results_dev.cpu().numpy().view(CPTV_RESULT_DTYPE).reshape(-1)
+    out.results = res
+    hdr = header_dev.cpu().numpy()
+    groups = {}
+    headers = {}
+    for i in range(n):
+        if i in out.errors:
+            continue
+        st = int(res["status"][i])
+        if st != 0:
+            out.errors[i] = "%s: %s" % (staged.paths[i], CPTV_STATUS.get(st, "status %d" % st))
+            continue
+        if int(res["header_bytes"][i]) > CPTV_HEADER_BYTES:
+            out.errors[i] = "%s: header section of %d bytes" % (staged.paths[i], res["header_bytes"][i])
+            continue
+        try:
+            h = parse_header_bytes(hdr[i].tobytes())
+        except Exception as e:  # a header the host parser refuses: the file goes the slow way
+            out.errors[i] = "%s: %s" % (staged.paths[i], e)
+            continue
+        headers[i] = h
+        groups.setdefault((int(res["width"][i]), int(res["height"][i]), h.model if h.model else None), []).append(i)
+    for key, members in groups.items():
+        W, H, _ = key
+        ok = np.asarray(members)
+        offs = np.zeros(len(ok) + 1, np.int32)
+        np.cumsum(res["n_frames"][ok], out=offs[1:])
+        total = int(offs[-1])
+        # any engine of this resolution can unpack; the tracking engine is picked by the caller
+        ueng = eng if (eng.width, eng.height) == (W, H) else get_engine(W, H, 20.0, 0.1, device=dev.index or 0)
+        offs_dev = t.from_numpy(offs).to(dev)
+        so_dev = t.from_numpy(np.ascontiguousarray(slot_off[:-1][ok])).to(dev)
+        fo_dev = t.empty(total, dtype=t.int64, device=dev)
+        bw_dev = t.empty(total, dtype=t.int32, device=dev)
+        dense_dev = t.empty(total * 8, dtype=t.int32, device=dev)
+        frames_dev = t.empty((total, H, W), dtype=t.int16, device=dev)
+        ueng.sync_inputs()
+        rc = ueng.lib.cpx_cptv_gather_index(ueng.h, p(slots_dev), p(so_dev), p(offs_dev), len(ok), p(fo_dev), p(bw_dev),
+                                            p(dense_dev))
+        if rc == 0:
+            rc = ueng.lib.cpx_cptv_unpack(ueng.h, p(out_dev), p(fo_dev), p(bw_dev), p(offs_dev), len(ok), p(frames_dev))
+        if rc != 0:
+            raise CpxError(rc, ueng._err())
+        ueng.synchronize()
+        slots = dense_dev.cpu().numpy().view(CPTV_SLOT_DTYPE).reshape(-1)
+        out.groups.append(DecodedGroup(key, members, [headers[i] for i in members], offs, slots, frames_dev))
+    return out
+
+
+def frame_meta_from_slots(slots, process_background=False):
+    """cpx_frame_meta [total] for the track stage from the section index."""
+    m = np.zeros(len(slots), FRAME_META_DTYPE)
+    fl = slots["flags"]
+    has = ((fl & CPTV_HAS_TIME_ON) != 0) & ((fl & CPTV_HAS_LAST_FFC) != 0)
+    m["time_on_ms"] = np.where(has, slots["time_on_ms"], 0)
+    m["last_ffc_ms"] = np.where(has, slots["last_ffc_ms"], 0)
+    m["has_times"] = has
+    if not process_background:
+        m["background_frame"] = (fl & CPTV_BACKGROUND_FRAME) != 0
+    return m
+
+
+class BulkTracker:
+    """Tracks decoded groups and writes the metadata; one instance per TrackExtractor.extract call."""
+
+    def __init__(self, config, device=0):
+        from .cliptrackextractor import ClipTrackExtractor
+
+        self.config = config
+        self.device = device
+        # a real extractor supplies version / config exactly as the one-file path reports them
+        self.extractor = ClipTrackExtractor(config.tracking, config.use_opt_flow, False, verbose=config.verbose,
+                                            device=device)
+        self.tcfg = self.extractor.config
+        self.lib = None
+        self._algorithm_text = {}
+        self.timings = {"decode_s": 0.0, "device_s": 0.0, "host_s": 0.0, "write_s": 0.0, "files": 0, "frames": 0}
+
+    # ---- device ----------------------------------------------------------------------------------------------
+    def track_group(self, group, clips):
+        """-> dict of host arrays for the group's clips (clips[k]: the Clip object of group.files[k])."""
+        from .cliptrackextractor import get_engine
+
+        cfg = self.tcfg
+        c0 = clips[0]
+        W, H, _ = group.key
+        weight_add = (1 if c0.camera_model == "lepton3.5" else 0.1) / self.extractor.weighting_percent
+        longest = int(np.diff(group.offs).max())
+        eng = get_engine(W, H, c0.background_thresh, weight_add, cfg.edge_pixels, self.device, max_frames=longest,
+                         denoise=bool(cfg.denoise))
+        t, dev = eng.torch, eng.device
+        self.lib = eng.lib
+        offs = group.offs
+        B = len(offs) - 1
+        total = int(offs[-1])
+        meta = frame_meta_from_slots(group.slots)
+        res = eng.track_batch(group.frames_dev, offs, meta, want_labels=True, want_filtered=False)
+        tp = make_track_params(c0.res_x, c0.res_y, cfg.edge_pixels, cfg.frame_padding, self.extractor.min_dimension,
+                               cfg.cropped_regions_strategy, cfg.filter_regions_pre_match, cfg.aoi_min_mass,
+                               cfg.aoi_pixel_variance, cfg.params, c0.frames_per_second)
+        assoc = eng.associate_batch(res, offs, meta, params=tp, want_regions=True)
+        fp = make_filter_params(cfg.min_duration_secs, cfg.track_min_offset, cfg.track_min_mass, c0.track_min_delta,
+                                c0.track_max_delta, cfg.min_moving_frames, cfg.max_blank_percent, cfg.max_jitter,
+                                c0.frames_per_second, cfg.max_tracks, tp.max_active_tracks, tp.max_tracks)
+        mt, ma = tp.max_tracks, tp.max_active_tracks
+        summ_dev = t.zeros(B * mt * 30, dtype=t.int32, device=dev)
+        counts_dev = t.zeros((B, 4), dtype=t.int32, device=dev)
+        p = lambda x: C.c_void_p(x.data_ptr())
+        eng.sync_inputs()
+        rc = eng.lib.cpx_finalize_tracks(eng.h, C.byref(fp), offs.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         C.c_void_p(meta.ctypes.data), B, p(assoc.pool_dev), p(assoc.tracks_dev),
+                                         p(assoc.ntracks_dev), p(summ_dev), p(counts_dev))
+        if rc != 0:
+            raise CpxError(rc, eng._err())
+        eng.synchronize()
+        info = res.info_dev.cpu().numpy().view(FRAME_INFO_DTYPE).reshape(-1)
+        bad = np.nonzero((info["frame_number"] >= 0) & (info["status"] != 0))[0]
+        ntr = assoc.ntracks_dev.cpu().numpy()
+        astatus = assoc.status_dev.cpu().numpy()
+        summ = summ_dev.cpu().numpy().view(TRACK_SUMMARY_DTYPE).reshape(B, mt)
+        # clips whose capacities overflowed (components per frame, tracks per clip) go the slow way
+        failed = {}
+        clip_of_frame = np.repeat(np.arange(B), np.diff(offs))
+        for f in bad:
+            failed[int(clip_of_frame[f])] = "frame %d: more than %d components" % (int(f - offs[clip_of_frame[f]]), eng.cap)
+        for b in np.nonzero(astatus != 0)[0]:
+            failed[int(b)] = "track capacity exceeded"
+        # ---- kept tracks in score order; their regions gathered on the device ----
+        proc_mask = info["frame_number"] >= 0
+        kept = []       # (clip, summary row) in output order
+        for b in range(B):
+            if b in failed:
+                continue
+            s = summ[b, : int(ntr[b])]
+            k = np.nonzero(s["reject"] == 0)[0]
+            if len(k):
+                k = k[np.argsort(s["rank"][k], kind="stable")]
+                kept.extend((b, int(j)) for j in k)
+        rows = []
+        tr_off = [0]
+        for b, j in kept:
+            s = summ[b, j]
+            n = int(s["n_frames"])
+            rows.append((int(offs[b]) + int(s["start_frame"]) + np.arange(n, dtype=np.int64)) * ma + int(s["slot"]))
+            tr_off.append(tr_off[-1] + n)
+        regions = np.zeros(0, REGION_DTYPE)
+        if rows:
+            idx = t.from_numpy(np.concatenate(rows)).to(dev)
+            pool = assoc.pool_dev.view(-1, 14)
+            regions = pool[idx].cpu().numpy().view(REGION_DTYPE).reshape(-1)
+        # ---- processed-frame index per clip: frame number q -> index in the batch ----
+        proc_idx = [np.nonzero(proc_mask[offs[b]:offs[b + 1]])[0] + int(offs[b]) for b in range(B)]
+        # ---- thumbnails of the kept tracks: one cpx_thumb_stats over every usable region ----
+        tr_off = np.asarray(tr_off, np.int64)
+        stats = np.zeros(0, THUMB_STAT_DTYPE)
+        usable = np.zeros(0, np.int64)
+        if len(regions):
+            clip_of_reg = np.repeat(np.array([b for b, _ in kept], np.int64), np.diff(tr_off))
+            usable = np.nonzero(((regions["flags"] & 1) == 0) & (regions["mass"] != 0))[0]
+            if len(usable):
+                refs = np.zeros(len(usable), REGION_REF_DTYPE)
+                r = regions[usable]
+                fidx = np.empty(len(usable), np.int64)
+                cb = clip_of_reg[usable]
+                for b in np.unique(cb):
+                    sel = cb == b
+                    fidx[sel] = proc_idx[b][r["frame_number"][sel]]
+                refs["frame"], refs["x"], refs["y"], refs["width"], refs["height"] = fidx, r["x"], r["y"], r["width"], r["height"]
+                stats = eng.thumb_stats(group.frames_dev, res, refs)
+        # ---- clips without a kept track: the heaviest region ever seen, else the window search ----
+        kept_clips = set(b for b, _ in kept)
+        trackless = [b for b in range(B) if b not in kept_clips and b not in failed]
+        best_region = {}
+        if trackless:
+            best_region = self._trackless(eng, group, res, assoc, info, offs, trackless, proc_idx)
+        return dict(info=info, summ=summ, ntr=ntr, kept=kept, tr_off=tr_off, regions=regions, usable=usable,
+                    stats=stats, failed=failed, best_region=best_region, proc_idx=proc_idx, engine=eng, result=res,
+                    assoc=assoc)
+
+    def _trackless(self, eng, group, res, assoc, info, offs, clips, proc_idx):
+        """best_trackless_thumb (classify/thumbnail.py:13-64) for the clips `clips`: the first region of maximal mass
+        in (frame, region) order over the clip's region history, else the 64 x 64 window search on the frame of
+        maximal mean."""
+        t, dev = eng.torch, eng.device
+        cap = eng.cap
+        out = {}
+        regs = assoc.regions_dev.view(-1, cap, 14)
+        rc_dev = assoc.rcounts_dev
+        ffc = res.info_dev.view(-1, 20)[:, 3]
+        valid = (t.arange(cap, device=dev)[None, :] < rc_dev[:, None]) & (ffc[:, None] == 0)
+        mass = t.where(valid, regs[:, :, 4], t.full((), -1, dtype=t.int32, device=dev))
+        fmax, farg = mass.max(dim=1)   # per frame: heaviest region (first of equals)
+        tmax = int(max(offs[b + 1] - offs[b] for b in clips))
+        pad_idx = np.full((len(clips), tmax), -1, np.int64)
+        for k, b in enumerate(clips):
+            pad_idx[k, : offs[b + 1] - offs[b]] = np.arange(offs[b], offs[b + 1])
+        pi = t.from_numpy(pad_idx).to(dev)
+        m = t.where(pi >= 0, fmax[pi.clamp(min=0)], t.full((), -1, dtype=fmax.dtype, device=dev))
+        best_f = m.argmax(dim=1)       # first frame of maximal mass
+        best_m = m.gather(1, best_f[:, None])[:, 0]
+        frame_abs = pi.gather(1, best_f[:, None])[:, 0]
+        rsel = regs[frame_abs, farg[frame_abs]]
+        best_m_h = best_m.cpu().numpy()
+        rsel_h = rsel.cpu().numpy().view(REGION_DTYPE).reshape(-1)
+        search = []
+        for k, b in enumerate(clips):
+            if best_m_h[k] >= 0:
+                out[b] = ("region", rsel_h[k])
+            else:
+                search.append(b)
+        if search:
+            xy = t.zeros((len(search), 2), dtype=t.int32, device=dev)
+            eng.sync_inputs()
+            P = eng.width * eng.height
+            for k, b in enumerate(search):
+                pf = proc_idx[b]
+                if len(pf) == 0:
+                    out[b] = ("none", None)
+                    continue
+                means = info["thermal_sum"][pf] / P
+                q = int(np.argmax(means))
+                rc = eng.lib.cpx_trackless_thumb(eng.h, C.c_void_p(group.frames_dev.data_ptr()), int(pf[q]), int(offs[b]),
+                                                 C.c_void_p(xy[k].data_ptr()))
+                if rc != 0:
+                    raise CpxError(rc, eng._err())
+                out[b] = ("window", q)
+            eng.synchronize()
+            xy_h = xy.cpu().numpy()
+            for k, b in enumerate(search):
+                if out[b][0] == "window":
+                    out[b] = ("window", (out[b][1], int(xy_h[k, 0]), int(xy_h[k, 1])))
+        return out
+
+    # ---- host: metadata ---------------------------------------------------------------------------------------
+    def _fmt_regions(self, regs, indent, depth, as_list=True):
+        n = len(regs)
+        cap = 512 + 420 * max(n, 1)
+        buf = C.create_string_buffer(cap)
+        got = self.lib.cpx_format_regions(C.c_void_p(regs.ctypes.data), n, REGION_DTYPE.itemsize, indent, depth,
+                                          1 if as_list else 0, buf, cap)
+        if got < 0:
+            buf = C.create_string_buffer(-got + 16)
+            got = self.lib.cpx_format_regions(C.c_void_p(regs.ctypes.data), n, REGION_DTYPE.itemsize, indent, depth,
+                                              1 if as_list else 0, buf, -got + 16)
+        return buf.raw[:got].decode("ascii")
+
+    def thumbnail_of(self, regs, use, st):
+        """get_thumbnail_info (classify/thumbnail.py:137-197) for one track: regs = its regions, use = indices of the
+        usable ones, st = their cpx_thumb_stat.  -> (region record, contours, median_diff, score) or None."""
+        if len(regs) == 0:
+            return None
+        if len(use):
+            keep = st["contours"] != 0
+            use, st = use[keep], st[keep]
+        if len(use) == 0:
+            return regs[0], 0, 0, 0
+        r = regs[use]
+        mass = r["mass"].astype(np.int64)
+        contours = st["contours"].astype(np.int64)
+        md = st["median_diff"]
+        max_mass = max(0, int(mass.max()))
+        max_contour = max(0, int(contours.max()))
+        max_md = max(0.0, float(md.max()))
+        min_md = min(0.0, float(md.min()))
+        mass_percent = mass / max_mass * 40
+        pts = contours / max_contour * 50
+        mid_x = r["x"] + r["width"] / 2
+        mid_y = r["y"] + r["height"] / 2
+        dx, dy = r["cx"] - mid_x, r["cy"] - mid_y
+        centroid_mid = np.power(dx * dx + dy * dy, 0.5) * 2
+        if max_md == 0:
+            diff = np.zeros(len(r))
+            if min_md != 0:
+                diff = (md + abs(min_md)) / abs(min_md) * 40
+        else:
+            diff = md / max_md * 40
+        total = mass_percent + pts + diff - centroid_mid
+        border = (r["x"] <= 1) | (r["y"] <= 1) | (r["y"] + r["height"] >= 119) | (r["x"] + r["width"] >= 159)
+        total = np.where(border, total - 1000, total)
+        k = int(np.argmax(total))   # sorted(..., reverse=True)[0]: the first of equal scores
+        return r[k], int(contours[k]), float(md[k]), float(total[k])
+
+    def algorithm_text(self, indent):
+        """The "algorithm" entry is the same for every file of a run: encoded once."""
+        if indent not in self._algorithm_text:
+            d = {"tracker_version": self.extractor.tracker_version, "tracker_config": self.tcfg.as_dict()}
+            self._algorithm_text[indent] = json.dumps(d, indent=indent or None, cls=tools.CustomJSONEncoder)
+        return self._algorithm_text[indent]
+
+    def metadata_text(self, clip, n_frames, tracks, trackless, source, tracking_time, existing, indent):
+        """The JSON extract_file writes for this clip (trackextractor.get_metadata), as text.
+        tracks: list of dict(summary, regions, thumb)."""
+        head = {}
+        if clip.camera_model:
+            head["camera_model"] = clip.camera_model
+        head["background_thresh"] = clip.background_thresh
+        start = clip.video_start_time
+        end = start + timedelta(seconds=n_frames / clip.frames_per_second)
+        head["id"] = clip._id
+        head["start_time"] = start.isoformat()
+        head["end_time"] = end.isoformat()
+        fps = clip.frames_per_second
+        tlist = []
+        subs = {}
+        for k, tr in enumerate(tracks):
+            s, regs = tr["summary"], tr["regions"]
+            start_frame = int(s["start_frame"])
+            end_frame = int(regs["frame_number"][-1])
+            info = {"id": int(s["id"]), "tracker_version": self.extractor.tracker_version,
+                    "start_s": round(start_frame / float(fps), 2), "end_s": round((end_frame + 1) / fps, 2),
+                    "num_frames": len(regs), "frame_start": start_frame, "frame_end": end_frame,
+                    "positions": "@@cpx-positions-%d@@" % k, "tracking_score": float(s["score"]), "predictions": []}
+            subs['"@@cpx-positions-%d@@"' % k] = self._fmt_regions(regs, indent, 4 if indent else 1)
+            th = tr["thumb"]
+            if th is None:
+                info["thumbnail"] = None
+            else:
+                reg, contours, md, score = th
+                info["thumbnail"] = {"region": "@@cpx-thumb-%d@@" % k, "contours": contours, "median_diff": md,
+                                     "score": round(score)}
+                subs['"@@cpx-thumb-%d@@"' % k] = self._fmt_regions(reg.reshape(1), indent, 5 if indent else 1, as_list=False)
+            tlist.append(info)
+        head["tracks"] = tlist
+        if not tracks:
+            head["thumbnail_region"] = trackless
+        head["source"] = str(source)
+        head["tracking_time"] = round(tracking_time, 1)
+        head["algorithm"] = "@@cpx-algorithm@@"
+        if existing is not None:
+            existing.pop("tracks", None)
+            existing.pop("Tracks", None)
+            existing.update(head)
+            head = existing
+        text = json.dumps(head, indent=indent or None, cls=tools.CustomJSONEncoder)
+        alg = self.algorithm_text(indent)
+        if indent:  # nested one level deep: every line but the first moves right
+            alg = alg.replace("\n", "\n" + " " * indent)
+        subs['"@@cpx-algorithm@@"'] = alg
+        for key, val in subs.items():
+            text = text.replace(key, val, 1)
+        return text
+
+
+def _trackless_region(kind, payload):
+    """What best_trackless_thumb returns, as the metadata dictionary of that Region."""
+    from .region import Region
+
+    if kind == "region":
+        return Region.from_record(payload).meta_dictionary()
+    if kind == "window":
+        q, x, y = payload
+        return Region(x, y, THUMBNAIL_SIZE, THUMBNAIL_SIZE, frame_number=q,
+                      centroid=(x + THUMBNAIL_SIZE // 2, y + THUMBNAIL_SIZE // 2)).meta_dictionary()
+    return None
+
+
+def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024,
+                       want_text=False, stager=None, tracker=None):
+    """extract_file for many recordings at device speed.  Writes <file>.txt (or prints with to_stdout) and returns
+    {filename: metadata text (want_text) or True, or an error message string for a skipped file} plus the tracker
+    (timings).  Files that cannot take the batched path are retried through extract_file."""
+    import torch
+
+    from .cliptrackextractor import default_engine
+    from .trackextractor import extract_file
+
+    filenames = [str(f) for f in filenames]
+    own_stager = stager is None
+    stager = stager or FileStager(torch)
+    tracker = tracker or BulkTracker(config, device)
+    eng0 = default_engine(device)
+    indent = None if to_stdout else 4
+    out = {}
+    batches = [filenames[i:i + batch_files] for i in range(0, len(filenames), batch_files)]
+    pending = stager.stage(batches[0]) if batches else None
+    for bi, paths in enumerate(batches):
+        t0 = time.time()
+        staged = pending.result()
+        pending = stager.stage(batches[bi + 1]) if bi + 1 < len(batches) else None
+        decoded = decode_staged(eng0, staged)
+        t1 = time.time()
+        tracker.timings["decode_s"] += t1 - t0
+        retry = dict(decoded.errors)
+        texts = {}
+        n_ok = sum(len(g.files) for g in decoded.groups)
+        for group in decoded.groups:
+            td = time.time()
+            clips, existing = [], []
+            for k, i in enumerate(group.files):
+                clip = Clip(tracker.tcfg, paths[i])
+                clip.frames_per_second = 9
+                h = group.headers[k]
+                clip.set_res(h.x_resolution, h.y_resolution)
+                clip.set_model(h.model if h.model else None)
+                clip.set_video_stats(datetime.fromtimestamp(h.timestamp / 1000000).astimezone(Clip.local_tz))
+                clips.append(clip)
+                mf = os.path.splitext(paths[i])[0] + ".txt"
+                existing.append(tools.load_clip_metadata(mf) if os.path.exists(mf) else None)
+            # (lepton3 and "no model" files share thresholds but not the metadata's camera_model: grouped by model)
+            try:
+                r = tracker.track_group(group, clips)
+            except CpxError as e:  # the whole group failed on the device: every member goes the slow way
+                for i in group.files:
+                    retry[i] = "%s: %s" % (paths[i], e)
+                continue
+            th = time.time()
+            tracker.timings["device_s"] += th - td
+            info, offs = r["info"], group.offs
+            per_clip = {}
+            for ti, (b, j) in enumerate(r["kept"]):
+                per_clip.setdefault(b, []).append(ti)
+            # usable-region index ranges per kept track
+            upos = np.searchsorted(r["usable"], r["tr_off"])
+            tracking_time = (time.time() - t0) / max(n_ok, 1)
+            for b, i in enumerate(group.files):
+                if b in r["failed"]:
+                    retry[i] = "%s: %s" % (paths[i], r["failed"][b])
+                    continue
+                n_proc = len(r["proc_idx"][b])
+                tracks = []
+                for ti in per_clip.get(b, ()):
+                    _, j = r["kept"][ti]
+                    regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
+                    use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
+                    st = r["stats"][upos[ti]:upos[ti + 1]]
+                    tracks.append(dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st)))
+                trackless = None
+                if not tracks:
+                    kind, payload = r["best_region"].get(b, ("none", None))
+                    trackless = _trackless_region(kind, payload)
+                texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[i], tracking_time,
+                                                 existing[b], indent)
+                tracker.timings["frames"] += int(offs[b + 1] - offs[b])
+            tracker.timings["host_s"] += time.time() - th
+        tw = time.time()
+        for i, text in texts.items():
+            if to_stdout:
+                print(text)
+            elif save_meta:
+                with open(os.path.splitext(paths[i])[0] + ".txt", "w") as fh:
+                    fh.write(text)
+            out[paths[i]] = text if want_text else True
+            tracker.timings["files"] += 1
+        tracker.timings["write_s"] += time.time() - tw
+        for i, why in sorted(retry.items()):
+            logging.warning("batched extract: %s -- retrying the file on its own", why)
+            try:
+                res = extract_file(paths[i], config, False, False, to_stdout, save_meta=save_meta)
+                out[paths[i]] = (json.dumps(res[2], indent=indent, cls=tools.CustomJSONEncoder) if want_text else True)
+            except Exception as e:  # noqa: BLE001 -- fault isolation: one bad recording must not stop the directory
+                logging.error("could not extract %s: %s", paths[i], e)
+                out[paths[i]] = "error: %s" % (e,)
+    if own_stager:
+        stager.close()
+    return out, tracker

@@ -19,7 +19,8 @@ class TrackExtractor:
         self.worker_threads = max(1, config.worker_threads)
         self.retrack = retrack
         self.cache_to_disk = config.classify.cache_to_disk if cache_to_disk is None else cache_to_disk
-        self.batch_files = 64  # files per device batch of extract(directory)
+        self.batch_files = 1024  # files per device batch of extract(directory)
+        self.last_run = None     # timings of the last extract(directory) (cpx.track.bulk.BulkTracker.timings)
 
     def extract(self, base, to_stdout=False):
         base = Path(base)
@@ -40,9 +41,20 @@ class TrackExtractor:
         # metadata is written by the rank that tracked it, no collective is needed
         rank, world, local_rank = rank_world()
         todo = shard_files(todo, rank, world)
-        for i in range(0, len(todo), self.batch_files):
-            extract_files(todo[i:i + self.batch_files], self.config, self.cache_to_disk, self.retrack, to_stdout,
-                          device=local_rank if world > 1 else 0)
+        device = local_rank if world > 1 else 0
+        if self.retrack:  # existing tracks are re-used per file: no batch form
+            for i in range(0, len(todo), self.batch_files):
+                extract_files(todo[i:i + self.batch_files], self.config, self.cache_to_disk, self.retrack, to_stdout,
+                              device=device)
+            return
+        # the file-fed path at device speed (cpx/track/bulk.py): gzip inflate, section index, decode, tracking,
+        # end-of-clip statistics and thumbnails on the device for `batch_files` recordings at a time, the next batch
+        # read from disk meanwhile; a recording that fails is logged, retried on its own and otherwise skipped
+        from .bulk import extract_files_bulk
+
+        _, tracker = extract_files_bulk(todo, self.config, to_stdout=to_stdout, device=device,
+                                        batch_files=self.batch_files)
+        self.last_run = tracker.timings
 
 
 def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True):

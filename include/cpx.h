@@ -273,6 +273,15 @@ int cpx_cptv_gather_index(cpx_handle* h, const cpx_cptv_frame_slot* slots_dev, c
                           const int32_t* clip_offsets_dev, int B, int64_t* frame_offsets_dev, int32_t* bit_widths_dev,
                           cpx_cptv_frame_slot* slots_out_dev);
 
+/* ---- metadata text (host only; no device work) ---------------------------------------------------------------------
+ * The JSON of `n` regions as json.dump(..., indent=indent, cls=CustomJSONEncoder) writes Region.meta_dictionary()
+ * entries (reference src/track/track.py:1001-1031 "positions", src/ml_tools/rectangle.py:164-177): as a list whose items
+ * sit at nesting `depth` (as_list = 1), or one dict whose keys sit at nesting `depth` (as_list = 0, n = 1); indent = 0
+ * writes json.dumps' one-line form.  regs: records stride_bytes apart (a track's rows of the association pool).
+ * Returns the bytes written, or minus the bytes needed when `cap` is too small. */
+long cpx_format_regions(const cpx_region* regs, int n, long stride_bytes, int indent, int depth, int as_list, char* out,
+                        long cap);
+
 /* ---- track stage: background + filtered + threshold + CC + stats ---------
  * Replaces, for a batch of B independent clips, the per-frame arithmetic of
  *   ClipTrackExtractor.init_clip / _track_clip / process_frame

@@ -89,3 +89,67 @@ def test_directory_drivers_write_the_same_files(golden_dir, tmp_path):
             m.pop("source", None)
             m.pop("id", None)
         assert ma == mb, p.name
+
+
+def test_directory_driver_isolates_bad_recordings(golden_dir, tmp_path, caplog):
+    """A truncated recording, a corrupt one, a file that is not gzip and an empty file in the directory: each is logged
+    and skipped; every other recording gets the metadata it gets on its own."""
+    import logging
+
+    from cpx.config import Config
+    from cpx.track.trackextractor import TrackExtractor, extract_file
+
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    good = _files(golden_dir, a)
+    for p in good:
+        shutil.copy(p, b / p.name)
+    raw = (a / "possum.cptv").read_bytes()
+    (b / "bad_truncated.cptv").write_bytes(raw[: len(raw) // 3])
+    flipped = bytearray(raw)
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        flipped[int(rng.integers(200, len(flipped) - 8))] ^= 0x5A
+    (b / "bad_flipped.cptv").write_bytes(bytes(flipped))
+    (b / "bad_text.cptv").write_bytes(b"this is not a recording\n" * 10)
+    (b / "bad_empty.cptv").write_bytes(b"")
+    for p in sorted(a.glob("*.cptv")):
+        extract_file(p, cfg, False)
+    ex = TrackExtractor(cfg)
+    with caplog.at_level(logging.WARNING):
+        ex.extract(b)
+    for name in ("bad_truncated", "bad_text", "bad_empty"):
+        assert not (b / (name + ".txt")).exists(), name
+        assert any(name in r.getMessage() for r in caplog.records), name
+    for p in sorted(a.glob("*.txt")):
+        with open(p) as fa, open(b / p.name) as fb:
+            ma, mb = json.load(fa), json.load(fb)
+        for m in (ma, mb):
+            m.pop("tracking_time", None)
+            m.pop("source", None)
+            m.pop("id", None)
+        assert ma == mb, p.name
+    assert ex.last_run["files"] == len(good)
+
+
+def test_bulk_metadata_text_is_json_dump_text(golden_dir, tmp_path):
+    """The text the batched path writes (positions by cpx_format_regions, the rest by json) is, character for
+    character, what json.dump(indent=4) writes for the same metadata -- and the one-line form with to_stdout."""
+    from cpx.config import Config
+    from cpx.ml_tools.tools import CustomJSONEncoder
+    from cpx.track.bulk import extract_files_bulk
+
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    paths = _files(golden_dir, tmp_path)
+    out, _ = extract_files_bulk(paths, cfg, save_meta=False, want_text=True)
+    n_pos = 0
+    for p in paths:
+        text = out[str(p)]
+        meta = json.loads(text)
+        assert json.dumps(meta, indent=4, cls=CustomJSONEncoder) == text, p
+        n_pos += sum(len(t["positions"]) for t in meta["tracks"])
+    assert n_pos > 100
