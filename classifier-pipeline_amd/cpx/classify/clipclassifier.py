@@ -28,7 +28,8 @@ class ClipClassifier:
     def __init__(self, config, model=None, keep_original_predictions=False, tracking_events=False,
                  model_by_country=True):
         self.keep_original_predictions = keep_original_predictions
-        self.batch_files = 64  # recordings per device batch of process(directory, track=True)
+        self.batch_files = 1024  # recordings per device batch of process(directory, track=True)
+        self.last_run = None
         self.config = config
         self.model = model
         self.model_by_country = model_by_country
@@ -71,9 +72,19 @@ class ClipClassifier:
                 self.process_file(filename, cache=cache, reuse_frames=reuse_frames, track=False,
                                   calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
             return
-        for i in range(0, len(todo), self.batch_files):
-            self.process_files(todo[i:i + self.batch_files], reuse_frames=reuse_frames,
-                               calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
+        if reuse_frames:  # the frames saved in each file's metadata decide the segments: per file
+            for i in range(0, len(todo), 64):
+                self.process_files(todo[i:i + 64], reuse_frames=reuse_frames,
+                                   calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
+            return
+        # the file-fed path at device speed (cpx/track/bulk.py): the recordings of a device batch are decoded, tracked,
+        # cut into segments (the reference's get_segments with every random draw the identity: cpx_plan_segments),
+        # cropped, classified and written without per-frame Python objects; a recording that fails is retried on its own
+        from ..track.bulk import run_files_bulk
+
+        _, tracker = run_files_bulk(todo, self.config, device=local_rank if world > 1 else 0,
+                                    batch_files=self.batch_files, clip_classifier=self)
+        self.last_run = tracker.timings
 
     def process_files(self, filenames, reuse_frames=None, calculate_thumbnails=False, device=0):
         """process_file(track=True) for a list of recordings whose decode / tracking / association run as one device

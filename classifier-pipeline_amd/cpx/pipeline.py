@@ -37,7 +37,8 @@ class BatchResult:
 
 class BatchPipeline:
     def __init__(self, engine, network=None, n_labels=17, fp_index=-1, frame_size=32, square_width=5,
-                 track_params=None, filter_params=None, cnn_chunk=512):
+                 track_params=None, filter_params=None, cnn_chunk=512, want_regions=False):
+        self.want_regions = want_regions  # per-frame region lists from the association (the trackless thumbnail)
         self.eng = engine
         self.net = network
         self.n_labels = n_labels
@@ -75,6 +76,14 @@ class BatchPipeline:
         if not classify or out.n_tracks == 0 or out.n_samples == 0:
             eng.synchronize()
             return out
+        return self.classify_front(out, frames_dev, keep_samples)
+
+    def classify_front(self, out, frames_dev, keep_samples=False):
+        """Stages 5b-7 for a _front result: crop / tile, network, aggregation (on the current stream = the handle's).
+        Callable again on the same `out` from a pipeline with another network / frame size (one per model)."""
+        eng, t = self.eng, self.eng.torch
+        lib, h = eng.lib, eng.h
+        dev = eng.device
         n_tracks, n_samples = out.n_tracks, out.n_samples
         reqs, limits, per = out.reqs_dev, out.limits_dev, self.sq * self.sq
         side = self.sq * self.fs
@@ -138,7 +147,7 @@ class BatchPipeline:
         out = BatchResult()
         # ---- 1. track stage (one launch per time step), 2. association ----
         out.track = eng.track_batch(frames_dev, offs, meta, want_filtered=True, outputs=outputs)
-        out.assoc = eng.associate_batch(out.track, offs, meta, params=self.tp, want_regions=False)
+        out.assoc = eng.associate_batch(out.track, offs, meta, params=self.tp, want_regions=self.want_regions)
         # ---- 3. end of clip: trim / stats / rejects / plan sizes ----
         mt = self.tp.max_tracks
         summ = t.zeros(B * mt * 30, dtype=t.int32, device=dev)

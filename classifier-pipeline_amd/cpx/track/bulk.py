@@ -253,12 +253,16 @@ class BulkTracker:
                                             device=device)
         self.tcfg = self.extractor.config
         self.lib = None
+        self.cnn_chunk = 2048
         self._algorithm_text = {}
         self.timings = {"decode_s": 0.0, "device_s": 0.0, "host_s": 0.0, "write_s": 0.0, "files": 0, "frames": 0}
 
     # ---- device ----------------------------------------------------------------------------------------------
-    def track_group(self, group, clips):
-        """-> dict of host arrays for the group's clips (clips[k]: the Clip object of group.files[k])."""
+    def track_group(self, group, clips, classifiers=()):
+        """-> dict of host arrays for the group's clips (clips[k]: the Clip object of group.files[k]).
+        classifiers: [(model config, interpreter)] -- every kept track's segments (cpx_plan_segments: the reference's
+        get_segments under identity draws) are cropped, tiled and run through each model's network."""
+        from ..pipeline import BatchPipeline
         from .cliptrackextractor import get_engine
 
         cfg = self.tcfg
@@ -274,30 +278,44 @@ class BulkTracker:
         B = len(offs) - 1
         total = int(offs[-1])
         meta = frame_meta_from_slots(group.slots)
-        res = eng.track_batch(group.frames_dev, offs, meta, want_labels=True, want_filtered=False)
         tp = make_track_params(c0.res_x, c0.res_y, cfg.edge_pixels, cfg.frame_padding, self.extractor.min_dimension,
                                cfg.cropped_regions_strategy, cfg.filter_regions_pre_match, cfg.aoi_min_mass,
                                cfg.aoi_pixel_variance, cfg.params, c0.frames_per_second)
-        assoc = eng.associate_batch(res, offs, meta, params=tp, want_regions=True)
         fp = make_filter_params(cfg.min_duration_secs, cfg.track_min_offset, cfg.track_min_mass, c0.track_min_delta,
                                 c0.track_max_delta, cfg.min_moving_frames, cfg.max_blank_percent, cfg.max_jitter,
                                 c0.frames_per_second, cfg.max_tracks, tp.max_active_tracks, tp.max_tracks)
         mt, ma = tp.max_tracks, tp.max_active_tracks
-        summ_dev = t.zeros(B * mt * 30, dtype=t.int32, device=dev)
-        counts_dev = t.zeros((B, 4), dtype=t.int32, device=dev)
-        p = lambda x: C.c_void_p(x.data_ptr())
-        eng.sync_inputs()
-        rc = eng.lib.cpx_finalize_tracks(eng.h, C.byref(fp), offs.ctypes.data_as(C.POINTER(C.c_int32)),
-                                         C.c_void_p(meta.ctypes.data), B, p(assoc.pool_dev), p(assoc.tracks_dev),
-                                         p(assoc.ntracks_dev), p(summ_dev), p(counts_dev))
-        if rc != 0:
-            raise CpxError(rc, eng._err())
-        eng.synchronize()
-        info = res.info_dev.cpu().numpy().view(FRAME_INFO_DTYPE).reshape(-1)
+        sq = classifiers[0][1].params.square_width if classifiers else 5
+        comps = t.empty(total * eng.cap * 8, dtype=t.int32, device=dev)
+        info_dev = t.empty(total * 20, dtype=t.int32, device=dev)
+        labels = t.empty((total, H, W), dtype=t.int32, device=dev)
+        filt = t.empty((total, H, W), dtype=t.float32, device=dev) if classifiers else None
+        pipe = BatchPipeline(eng, None, square_width=sq, track_params=tp, filter_params=fp, want_regions=True)
+        model_out = []
+        t.cuda.current_stream(dev).synchronize()
+        with t.cuda.stream(eng.torch_stream()):
+            front = pipe._front(group.frames_dev, offs, meta, (comps, info_dev, labels, filt, None),
+                                classify=bool(classifiers))
+            for model, interp in classifiers:
+                if interp.params.square_width != sq:
+                    raise NotImplementedError("models with different square_width in one run")
+                fpi = interp.labels.index("false-positive") if "false-positive" in interp.labels else -1
+                mp = BatchPipeline(eng, interp._network(eng), n_labels=len(interp.labels), fp_index=fpi,
+                                   frame_size=interp.params.frame_size, square_width=sq, track_params=tp,
+                                   filter_params=fp, cnn_chunk=self.cnn_chunk)
+                t0 = time.time()
+                probs = None
+                if front.n_tracks and front.n_samples:
+                    mp.classify_front(front, group.frames_dev)
+                    probs = front.probs.cpu().numpy()
+                model_out.append(dict(model=model, interp=interp, probs=probs, seconds=time.time() - t0))
+            eng.synchronize()
+        res, assoc = front.track, front.assoc
+        info = info_dev.cpu().numpy().view(FRAME_INFO_DTYPE).reshape(-1)
         bad = np.nonzero((info["frame_number"] >= 0) & (info["status"] != 0))[0]
         ntr = assoc.ntracks_dev.cpu().numpy()
         astatus = assoc.status_dev.cpu().numpy()
-        summ = summ_dev.cpu().numpy().view(TRACK_SUMMARY_DTYPE).reshape(B, mt)
+        summ = front.summaries(mt)
         # clips whose capacities overflowed (components per frame, tracks per clip) go the slow way
         failed = {}
         clip_of_frame = np.repeat(np.arange(B), np.diff(offs))
@@ -307,15 +325,16 @@ class BulkTracker:
             failed[int(b)] = "track capacity exceeded"
         # ---- kept tracks in score order; their regions gathered on the device ----
         proc_mask = info["frame_number"] >= 0
-        kept = []       # (clip, summary row) in output order
+        kept = []       # (clip, summary row) in output order = the order of the segment plan
+        kept_pipe = []  # index of the track in the pipeline's arrays (clips that failed keep their slots there)
+        prefix = np.concatenate([[0], np.cumsum(front.counts[:, 0])])
         for b in range(B):
-            if b in failed:
-                continue
             s = summ[b, : int(ntr[b])]
             k = np.nonzero(s["reject"] == 0)[0]
-            if len(k):
+            if len(k) and b not in failed:
                 k = k[np.argsort(s["rank"][k], kind="stable")]
                 kept.extend((b, int(j)) for j in k)
+                kept_pipe.extend(int(prefix[b]) + q for q in range(len(k)))
         rows = []
         tr_off = [0]
         for b, j in kept:
@@ -353,9 +372,17 @@ class BulkTracker:
         best_region = {}
         if trackless:
             best_region = self._trackless(eng, group, res, assoc, info, offs, trackless, proc_idx)
-        return dict(info=info, summ=summ, ntr=ntr, kept=kept, tr_off=tr_off, regions=regions, usable=usable,
-                    stats=stats, failed=failed, best_region=best_region, proc_idx=proc_idx, engine=eng, result=res,
-                    assoc=assoc)
+        # ---- classification: the samples of every kept track (frame numbers per segment, for the metadata) ----
+        samples = None
+        if classifiers and front.n_samples:
+            from .._lib import CROP_REQ_DTYPE
+
+            per = sq * sq
+            reqs = front.reqs_dev.cpu().numpy().view(CROP_REQ_DTYPE).reshape(-1, per)
+            samples = dict(sample_track=front.sample_track_dev.cpu().numpy(), frames=reqs["frame"])
+        return dict(info=info, summ=summ, ntr=ntr, kept=kept, kept_pipe=kept_pipe, tr_off=tr_off, regions=regions,
+                    usable=usable, stats=stats, failed=failed, best_region=best_region, proc_idx=proc_idx, engine=eng,
+                    result=res, assoc=assoc, model_out=model_out, samples=samples)
 
     def _trackless(self, eng, group, res, assoc, info, offs, clips, proc_idx):
         """best_trackless_thumb (classify/thumbnail.py:13-64) for the clips `clips`: the first region of maximal mass
@@ -467,7 +494,7 @@ class BulkTracker:
             self._algorithm_text[indent] = json.dumps(d, indent=indent or None, cls=tools.CustomJSONEncoder)
         return self._algorithm_text[indent]
 
-    def metadata_text(self, clip, n_frames, tracks, trackless, source, tracking_time, existing, indent):
+    def metadata_text(self, clip, n_frames, tracks, trackless, source, tracking_time, existing, indent, models=None):
         """The JSON extract_file writes for this clip (trackextractor.get_metadata), as text.
         tracks: list of dict(summary, regions, thumb)."""
         head = {}
@@ -489,7 +516,8 @@ class BulkTracker:
             info = {"id": int(s["id"]), "tracker_version": self.extractor.tracker_version,
                     "start_s": round(start_frame / float(fps), 2), "end_s": round((end_frame + 1) / fps, 2),
                     "num_frames": len(regs), "frame_start": start_frame, "frame_end": end_frame,
-                    "positions": "@@cpx-positions-%d@@" % k, "tracking_score": float(s["score"]), "predictions": []}
+                    "positions": "@@cpx-positions-%d@@" % k, "tracking_score": float(s["score"]),
+                    "predictions": tr.get("predictions", [])}
             subs['"@@cpx-positions-%d@@"' % k] = self._fmt_regions(regs, indent, 4 if indent else 1)
             th = tr["thumb"]
             if th is None:
@@ -511,6 +539,11 @@ class BulkTracker:
             existing.pop("Tracks", None)
             existing.update(head)
             head = existing
+        if models is not None:  # ClipClassifier.save_metadata: one entry per model, with its classify time
+            by_id = {m["id"]: m for m in head.get("models", [])}
+            for d in models:
+                by_id[d["id"]] = d
+            head["models"] = list(by_id.values())
         text = json.dumps(head, indent=indent or None, cls=tools.CustomJSONEncoder)
         alg = self.algorithm_text(indent)
         if indent:  # nested one level deep: every line but the first moves right
@@ -534,29 +567,89 @@ def _trackless_region(kind, payload):
     return None
 
 
-def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024,
-                       want_text=False, stager=None, tracker=None):
-    """extract_file for many recordings at device speed.  Writes <file>.txt (or prints with to_stdout) and returns
-    {filename: metadata text (want_text) or True, or an error message string for a skipped file} plus the tracker
-    (timings).  Files that cannot take the batched path are retried through extract_file."""
+def track_predictions(r, ti, b, model_out, classify_seconds):
+    """The "predictions" entry of kept track `ti` (ClipClassifier.save_metadata / TrackPrediction.get_metadata,
+    reference src/classify/clipclassifier.py:305-383, src/classify/trackprediction.py:465-501) from the batch's
+    network outputs: per model the sum / normalisation / low-evidence cap of Interpreter.track_prediction_from_raw
+    (src/ml_tools/interpreter.py:151-168) over the track's segments."""
+    from ..classify.trackprediction import TrackPrediction
+
+    out = []
+    smp = r["samples"]
+    if smp is None:
+        return out
+    tp = r["kept_pipe"][ti]
+    s0, s1 = np.searchsorted(smp["sample_track"], [tp, tp + 1])
+    if s1 <= s0:
+        return out  # no segment ("Skipping track"): no prediction entry
+    regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
+    first = int(regs["frame_number"][0])
+    mass16 = regs["mass"].astype(np.uint16)
+    frames = np.searchsorted(r["proc_idx"][b], smp["frames"][s0:s1])   # device frame index -> frame number
+    masses = []
+    for fr in frames:
+        # SegmentHeader.mass: the uint16 sum over the segment after its first padding (distinct frames + the first
+        # min(missing, have) of them once more), ml_tools/datasetstructures.py:1236-1249
+        d = np.unique(fr)
+        extra = min(len(fr) - len(d), len(d))
+        masses.append(np.uint16(np.sum(mass16[d - first]) + np.sum(mass16[d[:extra] - first])))
+    for mo in model_out:
+        if mo["probs"] is None:
+            continue
+        interp = mo["interp"]
+        pred = TrackPrediction(int(r["summ"][b, r["kept"][ti][1]]["id"]), interp.labels,
+                               smooth_preds=interp.params.smooth_predictions)
+        pred.classified_track(mo["probs"][s0:s1], [f for f in frames], masses)
+        if len(frames) == 1 and len(set(frames[0].tolist())) < interp.params.square_width ** 2 / 4:
+            if pred.predicted_tag() != "false-positive":
+                pred.cap_confidences(0.5)
+        pred.classify_time = classify_seconds
+        pm = pred.get_metadata(interp.thresholds)
+        pm["model_id"] = mo["model"].id
+        out.append(pm)
+    return out
+
+
+def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024, want_text=False,
+                   stager=None, tracker=None, clip_classifier=None, blobs=None):
+    """extract_file -- or, with a ClipClassifier, process_file(track=True) -- for many recordings at device speed.
+    Writes <file>.txt (or prints with to_stdout) and returns ({filename: metadata text (want_text) or True, or an
+    "error: ..." string for a skipped file}, tracker with timings).  Files that cannot take the batched path are
+    retried through the one-file path.  blobs: the recordings as byte strings already in memory (names in
+    `filenames`; nothing is read from disk and a failing one is skipped, there being no file to retry)."""
     import torch
 
     from .cliptrackextractor import default_engine
     from .trackextractor import extract_file
 
     filenames = [str(f) for f in filenames]
-    own_stager = stager is None
-    stager = stager or FileStager(torch)
+    own_stager = stager is None and blobs is None
+    if blobs is None:
+        stager = stager or FileStager(torch)
     tracker = tracker or BulkTracker(config, device)
     eng0 = default_engine(device)
-    indent = None if to_stdout else 4
+    indent = None if (to_stdout or (clip_classifier is not None and config.classify.meta_to_stdout)) else 4
+    classifiers, models = [], []
+    if clip_classifier is not None:
+        models = [clip_classifier.model] if clip_classifier.model else (config.classify.models or [])
+        t0 = time.time()
+        classifiers = [(m, clip_classifier.get_classifier(m)) for m in models]
+        tracker.timings["model_load_s"] = time.time() - t0
     out = {}
-    batches = [filenames[i:i + batch_files] for i in range(0, len(filenames), batch_files)]
-    pending = stager.stage(batches[0]) if batches else None
+    order = list(range(0, len(filenames), batch_files))
+    batches = [filenames[i:i + batch_files] for i in order]
+    pending = None
+    if blobs is None and batches:
+        pending = stager.stage(batches[0])
     for bi, paths in enumerate(batches):
         t0 = time.time()
-        staged = pending.result()
-        pending = stager.stage(batches[bi + 1]) if bi + 1 < len(batches) else None
+        if blobs is None:
+            staged = pending.result()
+            pending = stager.stage(batches[bi + 1]) if bi + 1 < len(batches) else None
+        else:
+            staged = stage_blobs(torch, blobs[order[bi]:order[bi] + batch_files])
+            staged.paths = paths
+        tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + time.time() - t0
         decoded = decode_staged(eng0, staged)
         t1 = time.time()
         tracker.timings["decode_s"] += t1 - t0
@@ -575,10 +668,10 @@ def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, devic
                 clip.set_video_stats(datetime.fromtimestamp(h.timestamp / 1000000).astimezone(Clip.local_tz))
                 clips.append(clip)
                 mf = os.path.splitext(paths[i])[0] + ".txt"
-                existing.append(tools.load_clip_metadata(mf) if os.path.exists(mf) else None)
+                existing.append(tools.load_clip_metadata(mf) if blobs is None and os.path.exists(mf) else None)
             # (lepton3 and "no model" files share thresholds but not the metadata's camera_model: grouped by model)
             try:
-                r = tracker.track_group(group, clips)
+                r = tracker.track_group(group, clips, classifiers)
             except CpxError as e:  # the whole group failed on the device: every member goes the slow way
                 for i in group.files:
                     retry[i] = "%s: %s" % (paths[i], e)
@@ -592,6 +685,14 @@ def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, devic
             # usable-region index ranges per kept track
             upos = np.searchsorted(r["usable"], r["tr_off"])
             tracking_time = (time.time() - t0) / max(n_ok, 1)
+            n_kept = max(len(r["kept"]), 1)
+            model_meta = None
+            if classifiers:
+                model_meta = []
+                for mo in r["model_out"]:
+                    d = mo["model"].as_dict()
+                    d["classify_time"] = float(round(mo["seconds"] / max(len(group.files), 1), 1))
+                    model_meta.append(d)
             for b, i in enumerate(group.files):
                 if b in r["failed"]:
                     retry[i] = "%s: %s" % (paths[i], r["failed"][b])
@@ -603,18 +704,22 @@ def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, devic
                     regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
                     use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
                     st = r["stats"][upos[ti]:upos[ti + 1]]
-                    tracks.append(dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st)))
+                    tr = dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st))
+                    if classifiers:
+                        secs = sum(mo["seconds"] for mo in r["model_out"]) / n_kept
+                        tr["predictions"] = track_predictions(r, ti, b, r["model_out"], secs)
+                    tracks.append(tr)
                 trackless = None
                 if not tracks:
                     kind, payload = r["best_region"].get(b, ("none", None))
                     trackless = _trackless_region(kind, payload)
                 texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[i], tracking_time,
-                                                 existing[b], indent)
+                                                 existing[b], indent, models=model_meta)
                 tracker.timings["frames"] += int(offs[b + 1] - offs[b])
             tracker.timings["host_s"] += time.time() - th
         tw = time.time()
         for i, text in texts.items():
-            if to_stdout:
+            if indent is None and (to_stdout or clip_classifier is not None):
                 print(text)
             elif save_meta:
                 with open(os.path.splitext(paths[i])[0] + ".txt", "w") as fh:
@@ -623,13 +728,28 @@ def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, devic
             tracker.timings["files"] += 1
         tracker.timings["write_s"] += time.time() - tw
         for i, why in sorted(retry.items()):
+            if blobs is not None:
+                logging.error("batched extract: %s -- skipped", why)
+                out[paths[i]] = "error: %s" % (why,)
+                continue
             logging.warning("batched extract: %s -- retrying the file on its own", why)
             try:
-                res = extract_file(paths[i], config, False, False, to_stdout, save_meta=save_meta)
-                out[paths[i]] = (json.dumps(res[2], indent=indent, cls=tools.CustomJSONEncoder) if want_text else True)
+                if clip_classifier is not None:
+                    res = clip_classifier.process_file(paths[i], track=True, calculate_thumbnails=True, device=device)
+                    if not res:
+                        raise RuntimeError("process_file refused the file")
+                else:
+                    res = extract_file(paths[i], config, False, False, to_stdout, save_meta=save_meta)[2]
+                out[paths[i]] = (json.dumps(res, indent=indent, cls=tools.CustomJSONEncoder) if want_text else True)
             except Exception as e:  # noqa: BLE001 -- fault isolation: one bad recording must not stop the directory
-                logging.error("could not extract %s: %s", paths[i], e)
+                logging.error("could not process %s: %s", paths[i], e)
                 out[paths[i]] = "error: %s" % (e,)
     if own_stager:
         stager.close()
     return out, tracker
+
+
+def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024,
+                       want_text=False, stager=None, tracker=None):
+    """run_files_bulk without classification: what TrackExtractor.extract(directory) runs."""
+    return run_files_bulk(filenames, config, to_stdout, save_meta, device, batch_files, want_text, stager, tracker)

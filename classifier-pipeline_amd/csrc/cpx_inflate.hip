@@ -48,33 +48,33 @@ struct WaveIO {
   // ---- input: the file as dwords (the buffer is readable past the file's end; bits past it read as zero) ----
   const uint32_t* words;  // dword-aligned start of the file
   long n_words;           // dwords holding file bytes
-  long bits_total;        // bits of the file from the start of the DEFLATE data
-  long bits_used;         // bits dropped so far
-  long next_chunk;        // index (in 64-dword chunks) of what `nxt` holds
-  int cur, nxt;           // per lane: dword `lane` of the current / following chunk
-  int widx;               // next dword of `cur`
+  long file_bits;         // bits of the file
+  long data_bits;         // bit position of the start of the DEFLATE data
+  long wabs;              // index of the next dword the bit buffer takes
+  int cur;                // per lane: dword `lane` of the current 64-dword chunk
+  int widx;               // next dword of `cur` (= wabs & 63, or 64 when the chunk is used up)
   uint64_t buf;
   int cnt;
   int lane;
   // ---- output ----
   uint8_t* out;
-  long cap, n_out;        // n_out counts the pending literals too
+  long cap;
   long lim;               // = cap, or 0 once the input is exhausted
-  int lit, nlit;
+  long n_flushed;         // bytes stored
+  int lit, nlit;          // pending literals: lane k of `lit` holds literal k of the run as byte << 4 (a table entry)
   WaveLds* lds;
+  const uint8_t* file_bytes;
 
+  __device__ __forceinline__ long pos_bits() const { return wabs * 32 - cnt; }  // absolute position of the next bit
   __device__ __forceinline__ int load_chunk(long chunk) const {
     const long w = chunk * 64 + lane;
     return w < n_words ? (int)words[w] : 0;
   }
-  // position the reader at bit `bit` of the file (a multiple of 8)
   __device__ __forceinline__ void seek_byte(long byte) {
-    const long w = byte >> 2;
-    const long chunk = w >> 6;
+    wabs = byte >> 2;
+    const long chunk = wabs >> 6;
     cur = load_chunk(chunk);
-    nxt = load_chunk(chunk + 1);
-    next_chunk = chunk + 1;
-    widx = (int)(w & 63);
+    widx = (int)(wabs & 63);
     buf = 0;
     cnt = 0;
     const int skip = (int)(byte & 3) * 8;
@@ -87,15 +87,17 @@ struct WaveIO {
   __device__ __forceinline__ uint32_t next_word() {
     // a stream that runs past its input decodes the zero padding -- possibly as literals, for as long as the output
     // has room: checked here, once per 32 input bits (the literal path itself only tests the output limit)
-    if (bits_used > bits_total) lim = 0;
+    if (wabs * 32 - cnt > file_bits) lim = 0;
     if (widx == 64) {
-      cur = nxt;
-      next_chunk += 1;
-      nxt = load_chunk(next_chunk);
+      // (loaded when it is needed: a register with a load in flight that lives across the decoder's control flow makes
+      // the compiler wait for ALL outstanding memory operations -- the acknowledgements of recent stores included --
+      // at every copy of it; one exposed load per 256 bytes of input is cheaper)
+      cur = load_chunk(wabs >> 6);
       widx = 0;
     }
     const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(cur, rfl(widx));
     widx += 1;
+    wabs += 1;
     return v;
   }
   __device__ __forceinline__ uint32_t bits() {
@@ -108,37 +110,55 @@ struct WaveIO {
   __device__ __forceinline__ void drop(int n) {  // n <= 32 bits of what the preceding bits() returned
     buf >>= n;
     cnt -= n;
-    bits_used += n;
   }
-  __device__ __forceinline__ bool overrun() const { return bits_used > bits_total; }
+  __device__ __forceinline__ bool overrun() const { return pos_bits() > file_bits; }
   __device__ __forceinline__ void align_byte() {
-    const int n = (int)((8 - (bits_used & 7)) & 7);
+    const int n = (int)((8 - (pos_bits() & 7)) & 7);
     if (n) {
       if (cnt < n) (void)bits();
       drop(n);
     }
   }
-  __device__ __forceinline__ void flush() {
+  __device__ __forceinline__ long n_out() const { return n_flushed + nlit; }
+  // pending literals -> memory; false when they do not fit
+  __device__ __forceinline__ bool flush() {
     if (nlit > 0) {
-      if (lane < nlit) out[n_out - nlit + lane] = (uint8_t)lit;
+      if (n_flushed + nlit > lim) return false;
+      if (lane < nlit) out[n_flushed + lane] = (uint8_t)(lit >> 4);  // `lit` holds table entries: byte = entry >> 4
+      n_flushed += nlit;
       nlit = 0;
     }
+    return true;
   }
   __device__ __forceinline__ bool literal(uint32_t b) {
-    if (n_out >= lim) return false;
     // lane nlit of `lit` = b (the lane select goes through M0: one other scalar operand per vector instruction)
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(lit) : "s"(rfl((int)b)), "s"(rfl(nlit)) : "m0");
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(lit) : "s"(rfl((int)(b << 4))), "s"(rfl(nlit)) : "m0");
     nlit += 1;
-    n_out += 1;
-    if (nlit == 64) flush();
+    if (nlit == 64) return flush();
     return true;
   }
   __device__ __forceinline__ int match(int len, int dist) {
-    if (dist > n_out) return infl::ERR_DISTANCE;
-    if (n_out + len > cap) return infl::ERR_OUTPUT;
-    flush();
-    uint8_t* const dst = out + n_out;
+    const long at = n_flushed + nlit;  // where the match goes
+    if (dist > at) return infl::ERR_DISTANCE;
+    if (at + len > lim) return infl::ERR_OUTPUT;
+    uint8_t* const dst = out + at;
     const uint8_t* const src = dst - dist;
+    if (dist >= len + nlit && len <= 64) {
+      // the common shape: its source lies before the pending literals, so the load is issued FIRST and the literal
+      // store rides in its shadow; the wait before the match's own store then counts past that younger store
+      // (vmcnt is in order) instead of waiting for its acknowledgement
+      int v = 0;
+      if (lane < len) v = src[lane];
+      if (nlit > 0) {
+        if (lane < nlit) out[n_flushed + lane] = (uint8_t)(lit >> 4);
+        n_flushed += nlit;
+        nlit = 0;
+      }
+      if (lane < len) dst[lane] = (uint8_t)v;
+      n_flushed += len;
+      return infl::OK;
+    }
+    if (!flush()) return infl::ERR_OUTPUT;
     if (dist >= len) {
       for (int k = 0; k < len; k += 64) {
         const int j = k + lane;
@@ -151,27 +171,22 @@ struct WaveIO {
         if (j < len) dst[j] = src[j % dist];
       }
     }
-    n_out += len;
+    n_flushed += len;
     return infl::OK;
   }
-  __device__ __forceinline__ int stored(int len, const uint8_t* file_bytes, long data_start) {
-    flush();
-    const long byte = data_start + (bits_used >> 3);
-    if ((bits_used >> 3) + len > (bits_total >> 3)) return infl::ERR_INPUT;
-    if (n_out + len > cap) return infl::ERR_OUTPUT;
+  __device__ __forceinline__ int stored(int len) {
+    if (!flush()) return infl::ERR_OUTPUT;
+    const long byte = pos_bits() >> 3;
+    if (byte + len > (file_bits >> 3)) return infl::ERR_INPUT;
+    if (n_flushed + len > lim) return infl::ERR_OUTPUT;
     for (int k = 0; k < len; k += 64) {
       const int j = k + lane;
-      if (j < len) out[n_out + j] = file_bytes[byte + j];
+      if (j < len) out[n_flushed + j] = file_bytes[byte + j];
     }
-    n_out += len;
-    bits_used += (long)len * 8;
+    n_flushed += len;
     seek_byte(byte + len);
     return infl::OK;
   }
-  // the core's policy interface
-  const uint8_t* file_bytes;
-  long data_start;
-  __device__ __forceinline__ int stored(int len) { return stored(len, file_bytes, data_start); }
   __device__ __forceinline__ uint16_t* ll_table() { return lds->ll; }
   __device__ __forceinline__ uint16_t* d_table() { return lds->dt; }
   __device__ __forceinline__ uint8_t* lens() { return lds->lens; }
@@ -179,6 +194,81 @@ struct WaveIO {
   __device__ __forceinline__ uint16_t* small() { return lds->small; }
   static __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return (uint32_t)rfl((int)*p); }
   static __device__ __forceinline__ int uni(int v) { return rfl(v); }
+
+  // The symbols of a block.  Root-table literals -- four of five symbols of a recording -- run in a hand-written
+  // loop of 20 scalar instructions (the compiler's form of the same loop is about sixty, and a lone wave issues one
+  // instruction per four to five cycles): look the low ten bits up, leave when the entry is not a literal, when
+  // fewer than 32 bits are buffered or when 64 literals are pending; otherwise shift the buffer and put the byte into
+  // lane `nlit` of the literal register.  (The bit buffer is pinned to s[90:91] for the block: the loop reads its low
+  // half by name.)
+  __device__ __forceinline__ int decode_symbols(const uint16_t* ll, const uint16_t* dt) {
+    // The root table of the literal / length code lives in REGISTERS for the block: 1024 entries = 16 vector
+    // registers x 64 lanes (entry i in lane i & 63 of register i >> 6).  A look-up is then a register-indexed move
+    // (s_set_gpr_idx_on) + v_readlane into a scalar register: no LDS round trip (about 150 cycles of the 260 a
+    // literal took with the table in LDS) on the decoder's dependency chain.  Second-level tables stay in LDS.
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    v16i tab;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tab[k] = (int)ll[k * 64 + lane];
+    for (;;) {
+      uint32_t e = 0xFFFF;
+      int t0, t1, vt;
+      // (values the compiler may hold in vector registers although every lane agrees: moved to scalar ones here)
+      uint64_t sbuf = (uint64_t)rfl64((long)buf);
+      int scnt = rfl(cnt), snlit = rfl(nlit);
+      // One literal: entry = tab[low ten bits]; leave when it is no literal, else shift the buffer and put the ENTRY
+      // into lane nlit of `lit` (the byte is entry >> 4: taken when the run is stored).  Three literals per round:
+      // 32 buffered bits cover three root-table codes.  The bit buffer is pinned to s[90:91] and the table to
+      // v[40:55]: the loop names their parts.
+#define CPX_INFL_LITERAL                                  \
+  "s_and_b32 %[t0], s90, 0x3ff\n\t"                       \
+  "s_lshr_b32 %[t1], %[t0], 6\n\t"                        \
+  "s_set_gpr_idx_on %[t1], 0x1\n\t"                       \
+  "s_nop 0\n\t"                                           \
+  "v_mov_b32 %[vt], v40\n\t"                              \
+  "s_set_gpr_idx_off\n\t"                                 \
+  "s_nop 0\n\t"                                           \
+  "v_readlane_b32 %[e], %[vt], %[t0]\n\t"                 \
+  "s_cmp_ge_u32 %[e], 0x1000\n\t"                         \
+  "s_cbranch_scc1 2f\n\t"                                 \
+  "s_and_b32 %[t0], %[e], 15\n\t"                         \
+  "s_mov_b32 m0, %[nlit]\n\t"                             \
+  "s_lshr_b64 s[90:91], s[90:91], %[t0]\n\t"              \
+  "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
+  "v_writelane_b32 %[lit], %[e], m0\n\t"                  \
+  "s_add_u32 %[nlit], %[nlit], 1\n\t"
+      asm volatile(
+          "1:\n\t"
+          "s_cmp_lt_i32 %[cnt], 32\n\t"
+          "s_cbranch_scc1 3f\n\t"
+          "s_cmp_gt_u32 %[nlit], 61\n\t"
+          "s_cbranch_scc1 3f\n\t"
+          CPX_INFL_LITERAL CPX_INFL_LITERAL CPX_INFL_LITERAL
+          "s_branch 1b\n\t"
+          "3:\n\t"
+          "s_mov_b32 %[e], 0xffff\n\t"
+          "2:\n\t"
+          : "+{s[90:91]}"(sbuf), [cnt] "+s"(scnt), [nlit] "+s"(snlit), [lit] "+v"(lit), [e] "+s"(e), [t0] "=&s"(t0),
+            [t1] "=&s"(t1), [vt] "=&v"(vt)
+          : "{v[40:55]}"(tab)
+          : "m0", "scc", "memory");
+#undef CPX_INFL_LITERAL
+      buf = sbuf;
+      cnt = scnt;
+      nlit = snlit;
+      if (e == 0xFFFF) {  // left for a refill or a store of the pending literals, not for a symbol
+        if (cnt < 32) (void)bits();
+        if (nlit > 61 && !flush()) return infl::ERR_OUTPUT;
+        continue;
+      }
+      // e: the root entry of a symbol that is not a root-table literal (selected by the ten low bits, which were
+      // valid; the second or third literal of a round may have left fewer than the 32 bits the slow path reads)
+      if (cnt < 32) (void)bits();
+      const int rc = infl::slow_symbol(*this, ll, dt, (uint32_t)buf, e);
+      if (rc == 1000) return infl::OK;
+      if (rc != infl::OK) return rc;
+    }
+  }
 };
 
 struct GlobalBytes {
@@ -239,26 +329,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void cpx_cptv_inflate_kernel(Cpt
     WaveIO io;
     io.words = reinterpret_cast<const uint32_t*>(file);
     io.n_words = (fi.in_bytes + 3) >> 2;
-    io.bits_total = (fi.in_bytes - start) * 8;
-    io.bits_used = 0;
+    io.file_bits = fi.in_bytes * 8;
+    io.data_bits = start * 8;
     io.lane = lane;
     io.out = out;
     io.cap = fi.out_capacity;
     io.lim = fi.out_capacity;
-    io.n_out = 0;
+    io.n_flushed = 0;
     io.lit = 0;
     io.nlit = 0;
-    io.lds = &s_lds[threadIdx.x >> 6];
+    io.lds = &s_lds[rfl((int)(threadIdx.x >> 6))];
     io.file_bytes = file;
-    io.data_start = start;
     io.seek_byte(start);
     status = infl::inflate(io);
+    if (!io.flush() && status == 0) status = infl::ERR_OUTPUT;
     if (status == infl::ERR_OUTPUT && io.overrun()) status = infl::ERR_INPUT;
-    io.flush();
-    n_out = io.n_out;
+    n_out = io.n_flushed;
     if (status == 0) {
       // trailer: crc32, isize; what follows must be the end of the file (a further member goes to the host path)
-      const long used = start + ((io.bits_used + 7) >> 3);
+      const long used = (io.pos_bits() + 7) >> 3;
       res.in_consumed = used + 8;
       if (used + 8 != fi.in_bytes) {
         status = ERR_GZIP_TRAILER;

@@ -18,6 +18,8 @@
 //   int      stored(int len)                   copy len bytes input -> output (input is byte aligned): OK / ERR_*
 //   uint16_t* ll_table() / d_table()           LL_ENOUGH / D_ENOUGH entries
 //   uint8_t* lens()  [LENS_SCRATCH]   uint16_t* work() [WORK_SCRATCH]   uint16_t* small() [32]    scratch
+//   int      decode_symbols(ll, dt)            the symbols of a block: decode_symbols_generic(*this, ll, dt) or an
+//                                              equivalent
 //   static uint32_t ld16(const uint16_t*)      table entry read
 //   static int uni(int)                        identity (on the device: moves a value every lane holds into a scalar
 //                                              register, so that what depends on it stays scalar)
@@ -65,10 +67,18 @@ enum Status {
   ERR_NO_EOB = 9,         // litlen code without end-of-block symbol
 };
 
-// table entry (uint16): leaf    bit 15 = 0, [3:0] bits to drop (0 = no such code), [12:4] symbol
-//                       pointer bit 15 = 1, [14:11] index bits of the second-level table, [10:0] its offset
-CPX_HD inline uint16_t leaf(int nbits, int sym) { return (uint16_t)(nbits | (sym << 4)); }
+// table entry (uint16): literal leaf  [15:12] = 0, [11:4] the byte, [3:0] bits to drop (1..15): entry < 0x1000 is the
+//                                     whole test of the decoder's fast path
+//                       other leaf    bit 14 = 1, [8:4] symbol - 256 (end of block, lengths), [3:0] bits to drop;
+//                                     INVALID (0x4000, zero bits to drop) marks bit patterns no code maps to
+//                       pointer       bit 15 = 1, [14:11] index bits of the second-level table, [10:0] its offset
+// (the distance and code-length codes have fewer than 256 symbols: their leaves are all of the first kind)
+constexpr uint16_t INVALID = 0x4000;
+CPX_HD inline uint16_t leaf(int nbits, int sym) {
+  return sym < 256 ? (uint16_t)(nbits | (sym << 4)) : (uint16_t)(0x4000 | nbits | ((sym - 256) << 4));
+}
 CPX_HD inline uint16_t pointer(int sub_bits, int offset) { return (uint16_t)(0x8000 | (sub_bits << 11) | offset); }
+CPX_HD inline int entry_symbol(uint32_t e) { return (e & 0x4000) ? 256 + (int)((e >> 4) & 31) : (int)((e >> 4) & 255); }
 
 // Decode table for `n` symbols with code lengths lens[0..n) (0 = unused), root table of 2^root entries followed
 // by the second-level tables.  `single_ok`: an incomplete code is accepted when it consists of exactly one
@@ -85,7 +95,7 @@ CPX_HD CPX_INFL_NOINLINE inline int build_table(const uint8_t* lens, int n, int 
   while (max >= 1 && count[max] == 0) --max;
   const int root_size = 1 << root;
   if (max == 0) {  // no codes at all: every pattern is invalid (a block of literals only has such a distance code)
-    for (int i = 0; i < root_size; ++i) table[i] = 0;
+    for (int i = 0; i < root_size; ++i) table[i] = INVALID;
     return OK;
   }
   int min = 1;
@@ -102,7 +112,7 @@ CPX_HD CPX_INFL_NOINLINE inline int build_table(const uint8_t* lens, int n, int 
   for (int len = 1; len < 15; ++len) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
   for (int s = 0; s < n; ++s)
     if (lens[s] != 0) work[offs[lens[s]]++] = (uint16_t)s;
-  for (int i = 0; i < root_size; ++i) table[i] = 0;
+  for (int i = 0; i < root_size; ++i) table[i] = INVALID;
   unsigned huff = 0;  // the current code, bit-reversed
   int sym = 0, len = min, curr = root, drop = 0, used = root_size;
   int next = 0;       // offset of the table being filled
@@ -143,7 +153,7 @@ CPX_HD CPX_INFL_NOINLINE inline int build_table(const uint8_t* lens, int n, int 
       }
       used += 1 << curr;
       if (used > enough) return ERR_TABLE;
-      for (int i = 0; i < (1 << curr); ++i) table[next + i] = 0;
+      for (int i = 0; i < (1 << curr); ++i) table[next + i] = INVALID;
       low = huff & mask;
       table[low] = pointer(curr, next);
     }
@@ -164,7 +174,7 @@ CPX_HD CPX_INFL_INLINE int decode_sym(const uint16_t* table, int root, uint32_t 
   }
   const int n = e & 15;
   *nbits = n == 0 ? 0 : used + n;
-  return (e >> 4) & 0x1FF;
+  return entry_symbol(e);
 }
 
 CPX_HD inline int length_base(int s) {  // s = litlen symbol - 257, 0..28
@@ -184,6 +194,59 @@ CPX_HD inline void fixed_lengths(uint8_t* lens) {
   for (; s < 280; ++s) lens[s] = 7;
   for (; s < 288; ++s) lens[s] = 8;
   for (; s < 320; ++s) lens[s] = 5;  // 288..319: the 32 distance symbols (30 and 31 never occur in valid data)
+}
+
+// One symbol that is not a root-table literal: `b` = the unread bits, `e` = the root entry they select.
+// Returns OK (symbol consumed), 1000 (end of block) or an error.
+template <class IO>
+CPX_HD CPX_INFL_INLINE int slow_symbol(IO& io, const uint16_t* ll, const uint16_t* dt, uint32_t b, uint32_t e) {
+  int used = 0;
+  if (e & 0x8000) {
+    const int sb = (e >> 11) & 15;
+    used = LL_ROOT;
+    e = IO::ld16(ll + (e & 0x7FF) + ((b >> LL_ROOT) & ((1u << sb) - 1u)));
+  }
+  if ((e & 15) == 0) return ERR_SYMBOL;
+  int nb = used + (int)(e & 15);
+  const int s = entry_symbol(e);
+  if (s < 256) {  // a literal with a code longer than the root table's index
+    io.drop(nb);
+    return io.literal((uint32_t)s) ? OK : ERR_OUTPUT;
+  }
+  if (s == 256) {
+    io.drop(nb);
+    return 1000;
+  }
+  const int ls = s - 257;
+  if (ls > 28) return ERR_SYMBOL;
+  const int le = length_extra(ls);
+  const int len = length_base(ls) + (int)((b >> nb) & ((1u << le) - 1u));
+  io.drop(nb + le);
+  b = io.bits();
+  const int ds = decode_sym<IO>(dt, D_ROOT, b, &nb);
+  if (nb == 0 || ds > 29) return ERR_SYMBOL;
+  const int de = dist_extra(ds);
+  const int dist = dist_base(ds) + (int)((b >> nb) & ((1u << de) - 1u));
+  io.drop(nb + de);
+  if (io.overrun()) return ERR_INPUT;
+  return io.match(len, dist);
+}
+
+// The symbols of one block up to its end-of-block code (the portable form; the device has its own literal loop).
+template <class IO>
+CPX_HD CPX_INFL_INLINE int decode_symbols_generic(IO& io, const uint16_t* ll, const uint16_t* dt) {
+  for (;;) {
+    const uint32_t b = io.bits();
+    const uint32_t e = IO::ld16(ll + (b & ((1u << LL_ROOT) - 1u)));
+    if (e < 0x1000) {
+      io.drop((int)(e & 15));
+      if (!io.literal(e >> 4)) return ERR_OUTPUT;
+      continue;
+    }
+    const int rc = slow_symbol(io, ll, dt, b, e);
+    if (rc == 1000) return OK;
+    if (rc != OK) return rc;
+  }
 }
 
 // Inflate one DEFLATE stream (all blocks up to and including the final one).
@@ -271,35 +334,8 @@ CPX_HD CPX_INFL_INLINE int inflate(IO& io) {
         if (rc != OK) return rc;
       }
       // ---- the block's symbols ----
-      for (;;) {
-        b = io.bits();
-        int nb;
-        const int s = decode_sym<IO>(ll, LL_ROOT, b, &nb);
-        if (nb == 0) return ERR_SYMBOL;
-        if (s < 256) {
-          io.drop(nb);
-          if (!io.literal((uint32_t)s)) return ERR_OUTPUT;
-          continue;
-        }
-        if (s == 256) {
-          io.drop(nb);
-          break;
-        }
-        const int ls = s - 257;
-        if (ls > 28) return ERR_SYMBOL;
-        const int le = length_extra(ls);
-        const int len = length_base(ls) + (int)((b >> nb) & ((1u << le) - 1u));
-        io.drop(nb + le);
-        b = io.bits();
-        const int ds = decode_sym<IO>(dt, D_ROOT, b, &nb);
-        if (nb == 0 || ds > 29) return ERR_SYMBOL;
-        const int de = dist_extra(ds);
-        const int dist = dist_base(ds) + (int)((b >> nb) & ((1u << de) - 1u));
-        io.drop(nb + de);
-        if (io.overrun()) return ERR_INPUT;
-        const int rc = io.match(len, dist);
-        if (rc != OK) return rc;
-      }
+      const int rc = io.decode_symbols(ll, dt);
+      if (rc != OK) return rc;
       if (io.overrun()) return ERR_INPUT;
     }
     if (final_block) return OK;

@@ -23,6 +23,7 @@ struct HostIO {
   uint16_t small_[32];
   static uint32_t ld16(const uint16_t* p) { return *p; }
   static int uni(int v) { return v; }
+  int decode_symbols(const uint16_t* l, const uint16_t* d) { return cpx::infl::decode_symbols_generic(*this, l, d); }
   uint16_t* small() { return small_; }
 
   uint32_t bits() {

@@ -96,27 +96,29 @@ def test_classify_track_inputs_equal_reference(tmp_path, model_dir):
     assert [list(p.frames) for p in pred.predictions] == [list(s) for s in z["t0_segments"]]
 
 
-def test_process_files_equals_process_file(tmp_path, model_dir, monkeypatch):
+def test_process_files_equals_process_file(tmp_path, model_dir):
     """ClipClassifier.process(directory, track=True): the recordings of a device batch get the metadata files the
-    one-file-at-a-time path writes (segment choice is random as in the reference: the generator is pinned here)."""
+    one-file-at-a-time path writes.  Segment choice is random in the reference; the batched path plans the
+    member of that family in which every draw is the identity (cpx_plan_segments, pinned by
+    tests/golden/segments_identity_golden.json), so the one-file path runs under the same draws here.  Also the
+    explicit list form, ClipClassifier.process_files."""
     from cpx.classify.clipclassifier import ClipClassifier
-    from cpx.ml_tools import datasetstructures as ds
-
-    real_rng = np.random.default_rng
-    monkeypatch.setattr(ds.np.random, "default_rng", lambda seed=None: real_rng(1234 if seed is None else seed))
+    from helpers import IdentityDraws
 
     mdir, w = model_dir
     cfg = _config(mdir)
-    a, b = tmp_path / "a", tmp_path / "b"
-    for d in (a, b):
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    for d in (a, b, c):
         d.mkdir()
         for name in ("possum", "hedgehog"):
             shutil.copy(os.path.join(GOLDEN, name + ".cptv"), d / (name + ".cptv"))
-    np.random.seed(5)
-    for p in sorted(a.glob("*.cptv")):
-        ClipClassifier(cfg).process_file(str(p), track=True, calculate_thumbnails=True)
-    np.random.seed(5)
-    ClipClassifier(cfg).process(str(b), track=True, calculate_thumbnails=True)
+    with IdentityDraws():
+        for p in sorted(a.glob("*.cptv")):
+            ClipClassifier(cfg).process_file(str(p), track=True, calculate_thumbnails=True)
+        ClipClassifier(cfg).process_files(sorted(str(p) for p in c.glob("*.cptv")), calculate_thumbnails=True)
+    cc = ClipClassifier(cfg)
+    cc.process(str(b), track=True, calculate_thumbnails=True)
+    assert cc.last_run["files"] == 2
 
     def load(p):
         with open(p) as fh:
@@ -133,11 +135,16 @@ def test_process_files_equals_process_file(tmp_path, model_dir, monkeypatch):
         return m
 
     for name in ("possum", "hedgehog"):
-        ma, mb = load(a / (name + ".txt")), load(b / (name + ".txt"))
+        ma = load(a / (name + ".txt"))
         assert len(ma["tracks"]) > 0 and ma["tracks"][0]["predictions"] and ma["tracks"][0]["thumbnail"]
-        for ta, tb in zip(ma["tracks"], mb["tracks"]):
-            for k in ta:
-                assert ta[k] == tb[k], (name, ta["id"], k)
+        for other in (b, c):
+            mb = load(other / (name + ".txt"))
+            assert len(ma["tracks"]) == len(mb["tracks"]) and list(ma) == list(mb)
+            for ta, tb in zip(ma["tracks"], mb["tracks"]):
+                assert list(ta) == list(tb)
+                for k in ta:
+                    assert ta[k] == tb[k], (name, other.name, ta["id"], k)
+            assert ma["models"] == mb["models"]
         assert ma == mb, name
 
 
