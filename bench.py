@@ -26,8 +26,19 @@ Extra objects on the JSON line:
   roofline_track  (e2e) the same HBM accounting for cpx_frame_kernel inside the same run.
   cpu_baseline  the oracle chain ("port": NumPy tracker + NumPy crop/tile + PyTorch-CPU forward, 1 core)
                 timed on a bounded sample of the same workload on this host (rank 0, N = 1 only);
-  cpu_baseline_all_cores  the same chain on min(os.cpu_count(), 64) worker processes (single
-                thread AND all cores).  Both run before this process initialises the GPU.
+  cpu_baseline_all_cores  the same chain on one worker process per CPU this process may use (the scheduler affinity,
+                capped by the cgroup's CPU quota: 16 on the GPU boxes of this pool although 256 are visible).  Both run
+                before this process initialises the GPU.
+
+--gpus N > 1 without WORLD_SIZE in the environment: bench.py starts the N ranks itself (a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`, before anything touches the GPU) and
+relays rank 0's line; WORLD_SIZE set and != N is an error.  For N > 1 the line also carries "config4": the strong-scaling
+workload below at a reduced size, in the same processes.
+
+  from_files    (default run, N = 1) the file-fed form of the same path: synthetic CPTV byte strings in host memory ->
+                upload -> gzip inflate + section index + frame decode on the device -> track -> segments -> crop/tile +
+                network -> thumbnails -> metadata JSON text per recording (cpx.track.bulk.run_files_bulk); frames/s and
+                the split of the wall time.
 
 --config4: BASELINE configs[3] -- 10,000 seeded clips of 90-540 frames, sharded over the
 ranks by greedy longest-processing-time on the frame counts, processed in device batches, one all_gather per step of
@@ -51,6 +62,74 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA
 BF16X3_PRODUCTS = 6            # bf16 MFMA products per float32 multiply-add (csrc/cpx_cnn_bf3.hip)
 N_LABELS = 17
+
+
+def usable_cpus():
+    """CPUs this process can actually run on: the scheduler affinity, capped by the cgroup v2 / v1 CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                per = int(fh.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def spawn_ranks(n, argv):
+    """--gpus n without a launcher: start the n ranks as a child torch.distributed.run (never exec: this process may
+    not be replaced), relay the child's output, return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_launch(args):
+    """--dry-launch: the ranks rendezvous over gloo, report themselves and leave -- the launch path of --gpus N checked
+    without a GPU (tests/test_bench_launch_cpu.py)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    seen = [rank]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.zeros(world, dtype=torch.int64)
+        t[rank] = rank + 1
+        dist.all_reduce(t)
+        seen = [int(v) - 1 for v in t]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "CPTV frames/s end-to-end (track+classify) at 160x120", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_launch": True,
+                          "ranks": seen}), flush=True)
 
 
 def synth_on_device(torch, device, n_clips, n_frames, seed, h=120, w=160, chunk=64):
@@ -291,6 +370,87 @@ def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+def bench_from_files(args, torch, np, local_rank, weights, T):
+    """The file-fed form of the headline path: `--from-files` synthetic recordings as CPTV byte
+    strings in host memory (16 distinct clips of T frames, gzip level 1, replicated) -> cpx.track.bulk.run_files_bulk
+    with a ClipClassifier: upload, gzip inflate + section index + frame decode on the device, track, segments,
+    crop/tile + network, thumbnails, metadata JSON text per recording.  One warm-up pass, then a timed one."""
+    import tempfile
+
+    from cpx import synth
+    from cpx.classify.clipclassifier import ClipClassifier
+    from cpx.config import Config
+    from cpx.config.config import ModelConfig
+    from cpx.cptv import encode_cptv
+    from cpx.ml_tools import wrresnet as wr
+    from cpx.track.bulk import run_files_bulk
+
+    labels = ["bird", "cat", "deer", "dog", "false-positive", "hedgehog", "human", "kiwi", "leporidae", "mustelid",
+              "penguin", "possum", "rodent", "sheep", "vehicle", "wallaby", "land-bird"]
+    tmp = tempfile.mkdtemp(prefix="cpx_bench_model_")
+    wr.save_model(os.path.join(tmp, "wr"), weights, labels, hyperparams={"frame_size": 32})
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    cfg.classify.models = [ModelConfig.load({"id": 1, "name": "wr-bench", "model_file": os.path.join(tmp, "wr.npz")})]
+    cfg.classify.meta_to_stdout = False
+    t0 = time.perf_counter()
+    rng = np.random.default_rng(4321)
+    t_on, ffc = synth.frame_times(T)
+    # gzip level 6 = zlib's default, what the fixture recordings' headers say their writer used (XFL 0); level 1 finds
+    # three times as many (short) matches in sensor noise, and a match is the decoder's expensive symbol
+    distinct = [encode_cptv(synth.make_clip(rng, T), t_on, ffc, level=6) for _ in range(16)]
+    encode_s = time.perf_counter() - t0
+    n = args.from_files
+    batch = 2048   # recordings per decode launch (tracked in groups of 1024)
+    cc = ClipClassifier(cfg)
+
+    def measure(blobs, names):
+        run_files_bulk(names[:batch], cfg, save_meta=False, want_text=True, device=local_rank, batch_files=batch,
+                       clip_classifier=cc, blobs=blobs[:batch])                   # warm-up: engines, arena, model
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, tracker = run_files_bulk(names, cfg, save_meta=False, want_text=True, device=local_rank,
+                                      batch_files=batch, clip_classifier=cc, blobs=blobs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        bad = [k for k, v in out.items() if v.startswith("error")]
+        assert not bad, bad[:3]
+        return out, tracker.timings, dt
+
+    # the same path over real recordings: copies of the two fixture clips (reference tests/clips), when they are here
+    fixtures = None
+    gold = os.path.join(REPO, "tests", "golden")
+    if all(os.path.exists(os.path.join(gold, f + ".cptv")) for f in ("possum", "hedgehog")):
+        real = [open(os.path.join(gold, f + ".cptv"), "rb").read() for f in ("possum", "hedgehog")]
+        nr = min(n, 2048)
+        outr, tmr, dtr = measure([real[i % 2] for i in range(nr)], ["fixture_%05d.cptv" % i for i in range(nr)])
+        fixtures = {"what": "%d copies of the reference's two fixture recordings (tests/clips/possum.cptv, hedgehog.cptv: "
+                            "161 / 120 frames, 1.1 MB each) through the same call" % nr,
+                    "files": nr, "frames": int(tmr["frames"]), "seconds": round(dtr, 3),
+                    "frames_per_s": round(tmr["frames"] / dtr, 1), "files_per_s": round(nr / dtr, 1)}
+    blobs = [distinct[i % len(distinct)] for i in range(n)]
+    names = ["synthetic_%05d.cptv" % i for i in range(n)]
+    out, tm, dt = measure(blobs, names)
+    n_tracks = sum(text.count('"tracking_score"') for text in out.values())
+    n_pred = sum(text.count('"all_class_confidences"') for text in out.values())
+    return {"what": "%d synthetic recordings (%d frames each, 16 distinct, gzip level 6, %.2f MB per file) as byte strings "
+                    "in host memory -> upload -> inflate + index + decode on the device -> track -> segments -> "
+                    "crop/tile + WR-ResNet -> thumbnails -> metadata JSON text per recording; decode launches of %d recordings, tracking groups of 1024"
+                    % (n, T, len(distinct[0]) / 1e6, batch),
+            "fixture_recordings": fixtures,
+            "files": n, "frames": int(tm["frames"]), "seconds": round(dt, 3),
+            "frames_per_s": round(tm["frames"] / dt, 1), "files_per_s": round(n / dt, 1),
+            "tracks_in_metadata": n_tracks, "tracks_with_predictions": n_pred,
+            "metadata_bytes": int(sum(len(v) for v in out.values())),
+            "split_s": {"note": "the first two run in a worker thread beside the others (a HIP stream of its own)",
+                        "stage_pinned_copy": round(tm.get("stage_s", 0.0), 3),
+                        "upload_inflate_index_unpack": round(tm["decode_s"], 3),
+                        "main_thread_waiting_for_decode": round(tm.get("wait_decode_s", 0.0), 3),
+                        "track_classify_thumbnails_device": round(tm["device_s"], 3),
+                        "metadata_host": round(tm["host_s"], 3), "collect": round(tm["write_s"], 3)},
+            "encode_synthetic_files_s": round(encode_s, 2), "denoise": False}
+
+
 def config4_lengths(n_clips, seed=1234, lo=90, hi=540):
     """Frames per clip of the configs[3] workload: seeded, uniform in [lo, hi] (10 s - 60 s at 9 fps)."""
     import numpy as np
@@ -369,17 +529,25 @@ class Config4Workload:
                 recs.append(pack_records(ids_dev[res.track_clip[:, 0].long()], res.track_clip[:, 1], res.scores))
         rec = t.cat(recs) if recs else t.empty((0, 2 + self.n_labels), dtype=t.int32, device=self.device)
         self.last = results
-        return gather_records(rec, dist)
+        t.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        out = gather_records(rec, dist)
+        t.cuda.synchronize(self.device)
+        self.last_gather_s = time.perf_counter() - t0
+        return out
 
     def close(self):
         self.net.close()
         self.eng.close()
 
 
-def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu):
+def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu, as_sub_object=False, n_clips=None,
+                  steps=None):
     """--config4: see Config4Workload.  value = frames of ALL clips x steps / max-over-ranks time (strong scaling: the
-    clip set is fixed, ranks share it)."""
-    n_clips = args.clips or 10000
+    clip set is fixed, ranks share it).  as_sub_object: return the line (rank 0; None elsewhere) instead of printing it
+    and keep the process group -- the "config4" entry of a multi-GPU default run."""
+    n_clips = n_clips or args.clips or 10000
+    steps = steps or args.steps
     # every rank needs its shard resident: shrink the clip set when one GPU cannot hold its share
     free, _ = torch.cuda.mem_get_info(device)
     budget = 0.42 * free
@@ -398,8 +566,10 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu):
         wl.step(dist)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    gather_s = 0.0
+    for _ in range(steps):
         gathered = wl.step(dist)
+        gather_s += wl.last_gather_s
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -409,11 +579,12 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu):
     for r in wl.last:
         r.track.check()
         r.assoc.check()
+    line = None
     if rank == 0:
         loads = [int(wl.lengths[s].sum()) for s in wl.shards]
         line = {"metric": "CPTV frames/s end-to-end (track+classify) at 160x120",
-                "value": round(wl.frames_total * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "value": round(wl.frames_total * steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+                "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)" % args.cnn_math,
                 "data": "synthetic",
@@ -425,10 +596,14 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu):
                            "imbalance": round(max(loads) / (sum(loads) / len(loads)), 4),
                            "device_batches_rank0": len(wl.subs), "records_gathered": int(gathered.shape[0]),
                            "record_width": int(gathered.shape[1]), "frame_size": args.frame_size,
-                           "cnn_chunk": args.cnn_chunk, "n_labels": N_LABELS}}
+                           "cnn_chunk": args.cnn_chunk, "n_labels": N_LABELS,
+                           "gather_ms_per_step_rank0": round(gather_s / steps * 1e3, 3)}}
         line.update(cpu)
-        print(json.dumps(line), flush=True)
+        if not as_sub_object:
+            print(json.dumps(line), flush=True)
     wl.close()
+    if as_sub_object:
+        return line
     if dist is not None:
         dist.destroy_process_group()
 
@@ -462,7 +637,22 @@ def main():
                          "ranks, processed in device batches, all_gather of [clip_id, track_id, 17 x f32] (strong scaling)")
     ap.add_argument("--sub-frames", type=int, default=2048 * 270,
                     help="--config4: frames per device batch (their per-frame outputs must fit HBM beside the clips)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="only launch the ranks (gloo rendezvous, no GPU work): checks the --gpus N path on a CPU host")
+    ap.add_argument("--from-files", type=int, default=4096,
+                    help="recordings of the from_files measurement of the default run (0 = skip)")
     args = ap.parse_args()
+
+    # ---- --gpus N: this process becomes the launcher of N ranks unless a launcher already started us ----
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %s ranks (WORLD_SIZE)\n"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
+        raise SystemExit(2)
+    if args.dry_launch:
+        return dry_launch(args)
 
     import numpy as np
     import torch
@@ -483,11 +673,12 @@ def main():
         lens = [int(v) for v in config4_lengths(10000)[:n1]] if args.config4 else [args.frames] * n1
         cpu["cpu_baseline"] = cpu_baseline(args.stage, lens, 1234, w0, args.frame_size, cores=1)
         host = os.cpu_count() or 1
-        cores = min(host, 64)
+        cores = usable_cpus()  # affinity and cgroup quota: the CPUs this process really has
         if cores > 1:
             many = [lens[i % len(lens)] for i in range(max(2 * cores, n1))]
             allc = cpu_baseline(args.stage, many, 1234, w0, args.frame_size, cores=cores)
-            allc["host_cores"] = host
+            allc["host_cores_visible"] = host
+            allc["note"] = "one worker per usable CPU (scheduler affinity capped by the cgroup CPU quota)"
             cpu["cpu_baseline_all_cores"] = allc
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -756,8 +947,40 @@ def main():
                 f64["stage2_3_conv_frac"] = round(tf64 / (MFMA_BF16_PEAK_TFLOPS / BF16X3_PRODUCTS), 4)
             line["fs64"] = f64
             net64.close()
+    # ---- after the timed region, in the same process(es): what the headline does not cover ----
+    extras = e2e and not args.no_extras and not args.denoise and args.frame_size == 32
+    if extras and (world > 1 or args.from_files > 0):
+        # the resident workload makes room first
+        if net is not None:
+            try:
+                net.close()
+            except Exception:  # (already closed by the fs64 measurement)
+                pass
+        pipe = None
+        state.clear()
+        del frames, comps, info, filt, labels, outputs, res
+        eng.close()
+        if overlap:
+            ceng.close()
+        torch.cuda.empty_cache()
+    if extras and world > 1:
+        # the weak-scaling value above is trivially N-fold (identical clips per rank): next to it the strong-scaling,
+        # imbalanced workload of configs[3] -- 10,000 clips of 90-540 frames LPT-sharded over the ranks
+        sub = bench_config4(args, torch, np, dist, device, rank, world, local_rank, {}, as_sub_object=True,
+                            n_clips=10000, steps=max(1, min(args.steps, 3)))
+        if rank == 0:
+            cfg4 = sub["config"]
+            line["config4"] = {"what": cfg4["workload"], "scaling": "strong", "value": sub["value"], "unit": "frames/s",
+                               "ms_per_step": sub["ms_per_step"], "steps": sub["steps"], "clips": cfg4["clips"],
+                               "frames_total": cfg4["frames_total"], "frames_per_rank": cfg4["frames_per_rank"],
+                               "imbalance": cfg4["imbalance"], "records_gathered": cfg4["records_gathered"],
+                               "gather_ms_per_step_rank0": cfg4["gather_ms_per_step_rank0"]}
+    if extras and world == 1 and args.from_files > 0 and rank == 0:
+        line["from_files"] = bench_from_files(args, torch, np, local_rank, weights, T)
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    eng.close()
+    if not (extras and (world > 1 or args.from_files > 0)):
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -121,7 +121,7 @@ EXPORTS = [
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
-    "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index", "cpx_format_regions",
+    "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index", "cpx_format_regions", "cpx_json_indent",
 ]
 
 # flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
@@ -231,6 +231,8 @@ def load():
     lib.cpx_cptv_gather_index.restype = C.c_int
     lib.cpx_format_regions.argtypes = [vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, vp, C.c_long]
     lib.cpx_format_regions.restype = C.c_long
+    lib.cpx_json_indent.argtypes = [C.c_char_p, C.c_long, C.c_int, C.c_int, vp, C.c_long]
+    lib.cpx_json_indent.restype = C.c_long
     lib.cpx_track_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]

@@ -44,10 +44,13 @@ class Prediction:
         self.predicted_time = time.time()
 
     def get_metadata(self):
-        meta = {"prediction": np.uint8(np.round(100 * self.prediction)),
+        # (plain lists / ints: the same JSON as the NumPy arrays the reference puts here, without a trip through the
+        # encoder's default() hook per element)
+        frames = self.frames.tolist() if isinstance(self.frames, np.ndarray) else [int(f) for f in self.frames]
+        meta = {"prediction": np.uint8(np.round(100 * self.prediction)).tolist(),
                 "smoothed_prediction": None if self.smoothed_prediction is None
-                else np.uint32(np.round(self.smoothed_prediction)),
-                "frames": self.frames, "predicted_at_frame": self.predicted_at_frame, "mass": self.mass,
+                else np.uint32(np.round(self.smoothed_prediction)).tolist(),
+                "frames": frames, "predicted_at_frame": int(self.predicted_at_frame), "mass": int(self.mass),
                 "predicted_time": self.predicted_time}
         return meta
 
@@ -166,6 +169,6 @@ class TrackPrediction:
         meta["all_class_confidences"] = {}
         meta["predictions"] = [p.get_metadata() for p in self.predictions]
         if self.class_best_score is not None:
-            for i, value in enumerate(self.class_best_score):
-                meta["all_class_confidences"][self.labels[i]] = round(value, 3)
+            # round(numpy float64, 3) per label is NumPy's rounding: done on the whole vector at once
+            meta["all_class_confidences"] = dict(zip(self.labels, np.round(np.asarray(self.class_best_score), 3).tolist()))
         return meta

@@ -256,6 +256,53 @@ class CptvReader:
             frames.append(f)
 
 
+def encode_cptv(frames, time_on=None, last_ffc=None, model=b"lepton3", background_first=False, timestamp=1600000000000000,
+                level=1, device_name=b"synthetic"):
+    """A CPTV v2 file (bytes) of `frames` uint16 [N, H, W]: the inverse of CptvReader, for synthetic recordings (bench.py
+    from_files, tests).  Every frame is packed at the narrowest of 8 / 16 / 32 bits per delta that holds it (the
+    byte-aligned widths: packing is then one astype per frame); gzip level 1 by default."""
+    import gzip
+    import io
+
+    frames = np.ascontiguousarray(frames, dtype=np.uint16)
+    N, H, W = frames.shape
+
+    def field(code, data):
+        return bytes([len(data)]) + code + data
+
+    hdr = [field(b"T", struct.pack("<Q", int(timestamp))), field(b"X", struct.pack("<I", W)),
+           field(b"Y", struct.pack("<I", H)), field(b"C", b"\x01"), field(b"D", device_name), field(b"Z", b"\x09")]
+    if model:
+        hdr.append(field(b"E", model if isinstance(model, bytes) else str(model).encode()))
+    if background_first:
+        hdr.append(field(b"g", b"\x01"))
+    out = [b"CPTV\x02H", bytes([len(hdr)]), b"".join(hdr)]
+    snake = frames.astype(np.int32)
+    snake[:, 1::2] = snake[:, 1::2, ::-1]
+    snake = snake.reshape(N, H * W)
+    diff = np.diff(snake, axis=0, prepend=np.zeros((1, H * W), np.int32))   # inter-frame difference, scan order
+    deltas = np.diff(diff, axis=1, prepend=np.zeros((N, 1), np.int32))      # its running differences
+    lo, hi = deltas[:, 1:].min(axis=1), deltas[:, 1:].max(axis=1)
+    for i in range(N):
+        if lo[i] >= -128 and hi[i] <= 127:
+            w, packed = 8, deltas[i, 1:].astype(np.int8).tobytes()
+        elif lo[i] >= -32768 and hi[i] <= 32767:
+            w, packed = 16, deltas[i, 1:].astype(">i2").tobytes()
+        else:
+            w, packed = 32, deltas[i, 1:].astype(">i4").tobytes()
+        payload = struct.pack("<i", int(deltas[i, 0])) + packed
+        fl = [field(b"w", bytes([w])), field(b"f", struct.pack("<I", len(payload)))]
+        if time_on is not None:
+            fl += [field(b"t", struct.pack("<I", int(time_on[i]))), field(b"c", struct.pack("<I", int(last_ffc[i])))]
+        if background_first and i == 0:
+            fl.append(field(b"g", b"\x01"))
+        out += [b"F", bytes([len(fl)]), b"".join(fl), payload]
+    buf = io.BytesIO()
+    with gzip.GzipFile(fileobj=buf, mode="wb", compresslevel=level, mtime=0) as fh:
+        fh.write(b"".join(out))
+    return buf.getvalue()
+
+
 def decode_clips_on_device(engine, paths, workers=8):
     """Decode whole CPTV files with ``cpx_cptv_unpack`` (include/cpx.h): the host
     inflates the gzip stream and indexes the sections, the GPU unpacks the

@@ -114,11 +114,19 @@ def stage_blobs(torch, blobs):
     buf = torch.empty(int(in_off[-1]) + 16, dtype=torch.uint8, pin_memory=True)
     view = buf.numpy()
     isize = np.zeros(n, np.int64)
-    for i, b in enumerate(blobs):
-        view[in_off[i]:in_off[i] + sizes[i]] = np.frombuffer(b, np.uint8)
+    def copy(i):
+        b = blobs[i]
+        view[in_off[i]:in_off[i] + sizes[i]] = np.frombuffer(b, np.uint8)   # (NumPy releases the GIL for the copy)
         if sizes[i] >= 18:
             v = int.from_bytes(bytes(b[-4:]), "little")
             isize[i] = v if v <= 1032 * sizes[i] + 64 else 0
+
+    if n >= 64:
+        with ThreadPoolExecutor(max_workers=8) as pool:
+            list(pool.map(copy, range(n)))
+    else:
+        for i in range(n):
+            copy(i)
     return StagedFiles([None] * n, buf, in_off, sizes, isize, {})
 
 
@@ -139,6 +147,20 @@ class DecodedGroup:
         self.offs = offs              # int32 [len(files) + 1] frame ranges inside frames_dev
         self.slots = slots            # CPTV_SLOT_DTYPE [total]
         self.frames_dev = frames_dev  # uint16 bits [total, H, W]
+
+    def split(self, max_clips):
+        """The group in runs of at most max_clips recordings (views of the same device frames): the decode stage likes
+        thousands of files per launch (one wavefront each: its time hardly grows until the chip is full), the tracking
+        stage is sized by the memory its per-frame outputs take."""
+        n = len(self.files)
+        if n <= max_clips:
+            yield self
+            return
+        for b0 in range(0, n, max_clips):
+            b1 = min(n, b0 + max_clips)
+            f0, f1 = int(self.offs[b0]), int(self.offs[b1])
+            yield DecodedGroup(self.key, self.files[b0:b1], self.headers[b0:b1], (self.offs[b0:b1 + 1] - f0).astype(np.int32),
+                               self.slots[f0:f1], self.frames_dev[f0:f1])
 
 
 def decode_staged(eng, staged, min_pixels=160 * 120):
@@ -253,6 +275,7 @@ class BulkTracker:
                                             device=device)
         self.tcfg = self.extractor.config
         self.lib = None
+        self.decode_engine = None   # a handle (= HIP stream) of its own for the decode stage of run_files_bulk
         self.cnn_chunk = 2048
         self._algorithm_text = {}
         self.timings = {"decode_s": 0.0, "device_s": 0.0, "host_s": 0.0, "write_s": 0.0, "files": 0, "frames": 0}
@@ -292,10 +315,23 @@ class BulkTracker:
         filt = t.empty((total, H, W), dtype=t.float32, device=dev) if classifiers else None
         pipe = BatchPipeline(eng, None, square_width=sq, track_params=tp, filter_params=fp, want_regions=True)
         model_out = []
+        prof = self.timings.setdefault("device_split_s", {}) if os.environ.get("CPX_BULK_PROFILE") else None
+        tick = [time.time()]
+
+        def lap(name):  # CPX_BULK_PROFILE=1: wall time per stage, with a device synchronisation at every boundary
+            if prof is not None:
+                eng.synchronize()
+                t.cuda.synchronize(dev)
+                now = time.time()
+                prof[name] = prof.get(name, 0.0) + now - tick[0]
+                tick[0] = now
+
         t.cuda.current_stream(dev).synchronize()
+        lap("alloc")
         with t.cuda.stream(eng.torch_stream()):
             front = pipe._front(group.frames_dev, offs, meta, (comps, info_dev, labels, filt, None),
                                 classify=bool(classifiers))
+            lap("track_assoc_finalize_plan")
             for model, interp in classifiers:
                 if interp.params.square_width != sq:
                     raise NotImplementedError("models with different square_width in one run")
@@ -310,6 +346,7 @@ class BulkTracker:
                     probs = front.probs.cpu().numpy()
                 model_out.append(dict(model=model, interp=interp, probs=probs, seconds=time.time() - t0))
             eng.synchronize()
+        lap("crop_network")
         res, assoc = front.track, front.assoc
         info = info_dev.cpu().numpy().view(FRAME_INFO_DTYPE).reshape(-1)
         bad = np.nonzero((info["frame_number"] >= 0) & (info["status"] != 0))[0]
@@ -347,6 +384,7 @@ class BulkTracker:
             idx = t.from_numpy(np.concatenate(rows)).to(dev)
             pool = assoc.pool_dev.view(-1, 14)
             regions = pool[idx].cpu().numpy().view(REGION_DTYPE).reshape(-1)
+        lap("summaries_and_region_gather")
         # ---- processed-frame index per clip: frame number q -> index in the batch ----
         proc_idx = [np.nonzero(proc_mask[offs[b]:offs[b + 1]])[0] + int(offs[b]) for b in range(B)]
         # ---- thumbnails of the kept tracks: one cpx_thumb_stats over every usable region ----
@@ -366,12 +404,14 @@ class BulkTracker:
                     fidx[sel] = proc_idx[b][r["frame_number"][sel]]
                 refs["frame"], refs["x"], refs["y"], refs["width"], refs["height"] = fidx, r["x"], r["y"], r["width"], r["height"]
                 stats = eng.thumb_stats(group.frames_dev, res, refs)
+        lap("thumbnail_kernel")
         # ---- clips without a kept track: the heaviest region ever seen, else the window search ----
         kept_clips = set(b for b, _ in kept)
         trackless = [b for b in range(B) if b not in kept_clips and b not in failed]
         best_region = {}
         if trackless:
             best_region = self._trackless(eng, group, res, assoc, info, offs, trackless, proc_idx)
+        lap("trackless")
         # ---- classification: the samples of every kept track (frame numbers per segment, for the metadata) ----
         samples = None
         if classifiers and front.n_samples:
@@ -380,9 +420,11 @@ class BulkTracker:
             per = sq * sq
             reqs = front.reqs_dev.cpu().numpy().view(CROP_REQ_DTYPE).reshape(-1, per)
             samples = dict(sample_track=front.sample_track_dev.cpu().numpy(), frames=reqs["frame"])
+        # (no device buffer leaves this function: label / filtered images of a thousand recordings are tens of GB, and
+        # the next group's are allocated while the host still formats this one's metadata)
         return dict(info=info, summ=summ, ntr=ntr, kept=kept, kept_pipe=kept_pipe, tr_off=tr_off, regions=regions,
-                    usable=usable, stats=stats, failed=failed, best_region=best_region, proc_idx=proc_idx, engine=eng,
-                    result=res, assoc=assoc, model_out=model_out, samples=samples)
+                    usable=usable, stats=stats, failed=failed, best_region=best_region, proc_idx=proc_idx,
+                    model_out=model_out, samples=samples)
 
     def _trackless(self, eng, group, res, assoc, info, offs, clips, proc_idx):
         """best_trackless_thumb (classify/thumbnail.py:13-64) for the clips `clips`: the first region of maximal mass
@@ -487,6 +529,22 @@ class BulkTracker:
         k = int(np.argmax(total))   # sorted(..., reverse=True)[0]: the first of equal scores
         return r[k], int(contours[k]), float(md[k]), float(total[k])
 
+    def _dumps(self, obj, indent):
+        """json.dumps(obj, indent=indent, cls=CustomJSONEncoder), character for character: CPython's C encoder (which
+        only runs without an indent) + cpx_json_indent for the layout -- the indented form otherwise goes through the
+        pure-Python encoder at about a microsecond per token (1.5 s per thousand recordings with predictions)."""
+        text = json.dumps(obj, cls=tools.CustomJSONEncoder)
+        if not indent:
+            return text
+        raw = text.encode("utf-8")
+        cap = 4 * len(raw) + 256
+        buf = C.create_string_buffer(cap)
+        got = self.lib.cpx_json_indent(raw, len(raw), indent, 0, buf, cap)
+        if got < 0:
+            buf = C.create_string_buffer(-got + 16)
+            got = self.lib.cpx_json_indent(raw, len(raw), indent, 0, buf, -got + 16)
+        return buf.raw[:got].decode("utf-8")
+
     def algorithm_text(self, indent):
         """The "algorithm" entry is the same for every file of a run: encoded once."""
         if indent not in self._algorithm_text:
@@ -544,7 +602,7 @@ class BulkTracker:
             for d in models:
                 by_id[d["id"]] = d
             head["models"] = list(by_id.values())
-        text = json.dumps(head, indent=indent or None, cls=tools.CustomJSONEncoder)
+        text = self._dumps(head, indent)
         alg = self.algorithm_text(indent)
         if indent:  # nested one level deep: every line but the first moves right
             alg = alg.replace("\n", "\n" + " " * indent)
@@ -611,12 +669,13 @@ def track_predictions(r, ti, b, model_out, classify_seconds):
 
 
 def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024, want_text=False,
-                   stager=None, tracker=None, clip_classifier=None, blobs=None):
+                   stager=None, tracker=None, clip_classifier=None, blobs=None, track_files=1024):
     """extract_file -- or, with a ClipClassifier, process_file(track=True) -- for many recordings at device speed.
     Writes <file>.txt (or prints with to_stdout) and returns ({filename: metadata text (want_text) or True, or an
     "error: ..." string for a skipped file}, tracker with timings).  Files that cannot take the batched path are
     retried through the one-file path.  blobs: the recordings as byte strings already in memory (names in
-    `filenames`; nothing is read from disk and a failing one is skipped, there being no file to retry)."""
+    `filenames`; nothing is read from disk and a failing one is skipped, there being no file to retry).
+    batch_files: recordings per decode launch (and per read-ahead batch); track_files: recordings per tracking group."""
     import torch
 
     from .cliptrackextractor import default_engine
@@ -638,25 +697,40 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     out = {}
     order = list(range(0, len(filenames), batch_files))
     batches = [filenames[i:i + batch_files] for i in order]
-    pending = None
-    if blobs is None and batches:
-        pending = stager.stage(batches[0])
-    for bi, paths in enumerate(batches):
+    # Two stages in flight: a worker thread stages batch k+1 (file reads / copies into pinned memory) and decodes it on
+    # a handle of its own (its own HIP stream: upload, inflate + section index, unpack) while this thread tracks,
+    # classifies and writes batch k.  The inflate kernel is bound by scalar issue and latency, the network by the matrix
+    # pipe: the two share the chip well.
+    from ..engine import TrackEngine
+
+    deng = tracker.decode_engine
+    if deng is None:
+        deng = tracker.decode_engine = TrackEngine(width=eng0.width, height=eng0.height, device=device, max_frames=45)
+
+    def produce(bi):
         t0 = time.time()
         if blobs is None:
-            staged = pending.result()
-            pending = stager.stage(batches[bi + 1]) if bi + 1 < len(batches) else None
+            staged = stager.stage(batches[bi]).result()
         else:
             staged = stage_blobs(torch, blobs[order[bi]:order[bi] + batch_files])
-            staged.paths = paths
-        tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + time.time() - t0
-        decoded = decode_staged(eng0, staged)
+            staged.paths = batches[bi]
         t1 = time.time()
-        tracker.timings["decode_s"] += t1 - t0
+        decoded = decode_staged(deng, staged)
+        return staged, decoded, t1 - t0, time.time() - t1
+
+    worker = ThreadPoolExecutor(max_workers=1)
+    fut = worker.submit(produce, 0) if batches else None
+    for bi, paths in enumerate(batches):
+        t0 = time.time()
+        staged, decoded, stage_s, decode_s = fut.result()
+        fut = worker.submit(produce, bi + 1) if bi + 1 < len(batches) else None
+        tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + stage_s
+        tracker.timings["decode_s"] += decode_s
+        tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + time.time() - t0
         retry = dict(decoded.errors)
         texts = {}
         n_ok = sum(len(g.files) for g in decoded.groups)
-        for group in decoded.groups:
+        for group in (sub for g in decoded.groups for sub in g.split(track_files)):
             td = time.time()
             clips, existing = [], []
             for k, i in enumerate(group.files):
@@ -744,6 +818,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             except Exception as e:  # noqa: BLE001 -- fault isolation: one bad recording must not stop the directory
                 logging.error("could not process %s: %s", paths[i], e)
                 out[paths[i]] = "error: %s" % (e,)
+    worker.shutdown(wait=True)
     if own_stager:
         stager.close()
     return out, tracker

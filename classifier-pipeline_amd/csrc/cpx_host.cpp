@@ -128,3 +128,54 @@ extern "C" long cpx_format_regions(const cpx_region* regs, int n, long stride_by
   }
   return w.n <= cap ? w.n : -w.n;
 }
+
+// json.dumps(obj) [separators ", " and ": "] -> the text json.dumps(obj, indent=indent) writes: the C encoder of CPython
+// only runs without an indent (the indented form goes through the pure-Python encoder, ~1 us per token), so the
+// file-fed path encodes compactly and lays the text out here.  Containers open a level, "," ends a line, empty
+// containers stay "[]" / "{}"; string contents are copied untouched.
+extern "C" long cpx_json_indent(const char* in, long n, int indent, int depth0, char* out, long cap) {
+  if (!in || n < 0 || !out || cap < 0 || indent < 1) return -1;
+  Writer w{out, cap, 0};
+  int depth = depth0;
+  bool in_string = false;
+  for (long i = 0; i < n; ++i) {
+    const char c = in[i];
+    if (in_string) {
+      w.put(&c, 1);
+      if (c == '\\' && i + 1 < n) {
+        ++i;
+        w.put(in + i, 1);
+      } else if (c == '"') {
+        in_string = false;
+      }
+      continue;
+    }
+    if (c == '"') {
+      in_string = true;
+      w.put(&c, 1);
+    } else if (c == '{' || c == '[') {
+      if (i + 1 < n && in[i + 1] == (c == '{' ? '}' : ']')) {
+        w.put(in + i, 2);
+        ++i;
+      } else {
+        w.put(&c, 1);
+        ++depth;
+        w.lit("\n");
+        w.spaces(indent * depth);
+      }
+    } else if (c == '}' || c == ']') {
+      --depth;
+      w.lit("\n");
+      w.spaces(indent * depth);
+      w.put(&c, 1);
+    } else if (c == ',') {
+      w.put(&c, 1);
+      w.lit("\n");
+      w.spaces(indent * depth);
+      if (i + 1 < n && in[i + 1] == ' ') ++i;
+    } else {
+      w.put(&c, 1);
+    }
+  }
+  return w.n <= cap ? w.n : -w.n;
+}

@@ -49,10 +49,9 @@ struct WaveIO {
   const uint32_t* words;  // dword-aligned start of the file
   long n_words;           // dwords holding file bytes
   long file_bits;         // bits of the file
-  long data_bits;         // bit position of the start of the DEFLATE data
-  long wabs;              // index of the next dword the bit buffer takes
+  long wbase;             // index (in the file) of dword 0 of `cur`; the next dword the bit buffer takes is wbase + widx
   int cur;                // per lane: dword `lane` of the current 64-dword chunk
-  int widx;               // next dword of `cur` (= wabs & 63, or 64 when the chunk is used up)
+  int widx;               // next dword of `cur`, 64 when the chunk is used up
   uint64_t buf;
   int cnt;
   int lane;
@@ -65,16 +64,16 @@ struct WaveIO {
   WaveLds* lds;
   const uint8_t* file_bytes;
 
-  __device__ __forceinline__ long pos_bits() const { return wabs * 32 - cnt; }  // absolute position of the next bit
+  __device__ __forceinline__ long pos_bits() const { return (wbase + widx) * 32 - cnt; }  // position of the next bit
   __device__ __forceinline__ int load_chunk(long chunk) const {
     const long w = chunk * 64 + lane;
     return w < n_words ? (int)words[w] : 0;
   }
   __device__ __forceinline__ void seek_byte(long byte) {
-    wabs = byte >> 2;
-    const long chunk = wabs >> 6;
-    cur = load_chunk(chunk);
-    widx = (int)(wabs & 63);
+    const long w = byte >> 2;
+    wbase = w & ~63l;
+    cur = load_chunk(wbase >> 6);
+    widx = (int)(w & 63);
     buf = 0;
     cnt = 0;
     const int skip = (int)(byte & 3) * 8;
@@ -84,20 +83,22 @@ struct WaveIO {
       cnt -= skip;
     }
   }
+  // the next 64 dwords of the file (when the current ones are used up).  A stream that runs past its input decodes
+  // the zero padding -- possibly as literals, for as long as the output has room: checked here, once per 256 bytes
+  // of input (the literal path itself only tests the output limit)
+  __device__ __forceinline__ void next_chunk() {
+    // (loaded when it is needed: a register with a load in flight that lives across the decoder's control flow makes
+    // the compiler wait for ALL outstanding memory operations -- the acknowledgements of recent stores included --
+    // at every copy of it; one exposed load per 256 bytes of input is cheaper)
+    wbase += 64;
+    if (wbase * 32 > file_bits) lim = 0;
+    cur = load_chunk(wbase >> 6);
+    widx = 0;
+  }
   __device__ __forceinline__ uint32_t next_word() {
-    // a stream that runs past its input decodes the zero padding -- possibly as literals, for as long as the output
-    // has room: checked here, once per 32 input bits (the literal path itself only tests the output limit)
-    if (wabs * 32 - cnt > file_bits) lim = 0;
-    if (widx == 64) {
-      // (loaded when it is needed: a register with a load in flight that lives across the decoder's control flow makes
-      // the compiler wait for ALL outstanding memory operations -- the acknowledgements of recent stores included --
-      // at every copy of it; one exposed load per 256 bytes of input is cheaper)
-      cur = load_chunk(wabs >> 6);
-      widx = 0;
-    }
+    if (widx == 64) next_chunk();
     const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(cur, rfl(widx));
     widx += 1;
-    wabs += 1;
     return v;
   }
   __device__ __forceinline__ uint32_t bits() {
@@ -224,10 +225,8 @@ struct WaveIO {
   "s_and_b32 %[t0], s90, 0x3ff\n\t"                       \
   "s_lshr_b32 %[t1], %[t0], 6\n\t"                        \
   "s_set_gpr_idx_on %[t1], 0x1\n\t"                       \
-  "s_nop 0\n\t"                                           \
   "v_mov_b32 %[vt], v40\n\t"                              \
   "s_set_gpr_idx_off\n\t"                                 \
-  "s_nop 0\n\t"                                           \
   "v_readlane_b32 %[e], %[vt], %[t0]\n\t"                 \
   "s_cmp_ge_u32 %[e], 0x1000\n\t"                         \
   "s_cbranch_scc1 2f\n\t"                                 \
@@ -237,10 +236,21 @@ struct WaveIO {
   "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
   "v_writelane_b32 %[lit], %[e], m0\n\t"                  \
   "s_add_u32 %[nlit], %[nlit], 1\n\t"
+      int swidx = rfl(widx);
       asm volatile(
           "1:\n\t"
-          "s_cmp_lt_i32 %[cnt], 32\n\t"
+          "s_cmp_gt_i32 %[cnt], 31\n\t"
+          "s_cbranch_scc1 4f\n\t"
+          // refill: the next dword of the chunk (lane widx of `cur`) goes above the cnt buffered bits
+          "s_cmp_eq_u32 %[widx], 64\n\t"
           "s_cbranch_scc1 3f\n\t"
+          "v_readlane_b32 s92, %[cur], %[widx]\n\t"
+          "s_mov_b32 s93, 0\n\t"
+          "s_add_u32 %[widx], %[widx], 1\n\t"
+          "s_lshl_b64 s[92:93], s[92:93], %[cnt]\n\t"
+          "s_add_u32 %[cnt], %[cnt], 32\n\t"
+          "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
+          "4:\n\t"
           "s_cmp_gt_u32 %[nlit], 61\n\t"
           "s_cbranch_scc1 3f\n\t"
           CPX_INFL_LITERAL CPX_INFL_LITERAL CPX_INFL_LITERAL
@@ -249,14 +259,15 @@ struct WaveIO {
           "s_mov_b32 %[e], 0xffff\n\t"
           "2:\n\t"
           : "+{s[90:91]}"(sbuf), [cnt] "+s"(scnt), [nlit] "+s"(snlit), [lit] "+v"(lit), [e] "+s"(e), [t0] "=&s"(t0),
-            [t1] "=&s"(t1), [vt] "=&v"(vt)
-          : "{v[40:55]}"(tab)
-          : "m0", "scc", "memory");
+            [t1] "=&s"(t1), [vt] "=&v"(vt), [widx] "+s"(swidx)
+          : "{v[40:55]}"(tab), [cur] "v"(cur)
+          : "m0", "scc", "memory", "s92", "s93");
 #undef CPX_INFL_LITERAL
       buf = sbuf;
       cnt = scnt;
       nlit = snlit;
-      if (e == 0xFFFF) {  // left for a refill or a store of the pending literals, not for a symbol
+      widx = swidx;
+      if (e == 0xFFFF) {  // left for the next chunk of input or a store of the pending literals, not for a symbol
         if (cnt < 32) (void)bits();
         if (nlit > 61 && !flush()) return infl::ERR_OUTPUT;
         continue;
@@ -280,6 +291,9 @@ struct GlobalBytes {
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void cpx_cptv_inflate_kernel(CptvInflateArgs a) {
   __shared__ WaveLds s_lds[WAVES_PER_WG];
+#ifdef CPX_INFLATE_CLOCK_PROBE
+  const unsigned long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x & 63;
   const int f = rfl((int)(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6)));
   if (f >= a.B) return;
@@ -330,7 +344,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void cpx_cptv_inflate_kernel(Cpt
     io.words = reinterpret_cast<const uint32_t*>(file);
     io.n_words = (fi.in_bytes + 3) >> 2;
     io.file_bits = fi.in_bytes * 8;
-    io.data_bits = start * 8;
     io.lane = lane;
     io.out = out;
     io.cap = fi.out_capacity;
@@ -376,6 +389,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void cpx_cptv_inflate_kernel(Cpt
     }
   }
   res.status = status;
+#ifdef CPX_INFLATE_CLOCK_PROBE
+  {  // diagnostic build only: the shader clock this wave ran at, in MHz (s_memrealtime ticks at 100 MHz)
+    const unsigned long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    res.reserved = (int)((c1 - probe_c0) * 100 / (r1 - probe_r0 + 1));
+  }
+#endif
   if (lane == 0) a.results[f] = res;
 }
 

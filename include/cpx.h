@@ -281,6 +281,10 @@ int cpx_cptv_gather_index(cpx_handle* h, const cpx_cptv_frame_slot* slots_dev, c
  * Returns the bytes written, or minus the bytes needed when `cap` is too small. */
 long cpx_format_regions(const cpx_region* regs, int n, long stride_bytes, int indent, int depth, int as_list, char* out,
                         long cap);
+/* The text json.dumps(obj, indent=indent) writes, from the text json.dumps(obj) wrote (separators ", " and ": "): CPython
+ * encodes in C only without an indent, so the file-fed path encodes compactly and lays the text out here.  depth0: the
+ * nesting level the text starts at (0 for a whole document).  Returns the bytes written or minus the bytes needed. */
+long cpx_json_indent(const char* in, long n, int indent, int depth0, char* out, long cap);
 
 /* ---- track stage: background + filtered + threshold + CC + stats ---------
  * Replaces, for a batch of B independent clips, the per-frame arithmetic of

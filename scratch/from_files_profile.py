@@ -1,0 +1,34 @@
+"""cProfile of the file-fed path (run_files_bulk with a classifier over in-memory synthetic recordings)."""
+import cProfile, io, os, pstats, sys, tempfile, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "classifier-pipeline_amd"))
+import numpy as np, torch
+from cpx import synth
+from cpx.classify.clipclassifier import ClipClassifier
+from cpx.config import Config
+from cpx.config.config import ModelConfig
+from cpx.cptv import encode_cptv
+from cpx.ml_tools import wrresnet as wr
+from cpx.track.bulk import run_files_bulk
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 270
+classify = "--no-classify" not in sys.argv
+labels = ["bird", "cat", "deer", "dog", "false-positive", "hedgehog", "human", "kiwi", "leporidae", "mustelid", "penguin", "possum", "rodent", "sheep", "vehicle", "wallaby", "land-bird"]
+tmp = tempfile.mkdtemp()
+wr.save_model(os.path.join(tmp, "wr"), wr.random_weights(17, seed=0), labels, hyperparams={"frame_size": 32})
+cfg = Config.get_defaults(); cfg.tracking["thermal"].denoise = False
+cfg.classify.models = [ModelConfig.load({"id": 1, "name": "wr-bench", "model_file": os.path.join(tmp, "wr.npz")})]
+rng = np.random.default_rng(4321)
+t_on, ffc = synth.frame_times(T)
+distinct = [encode_cptv(synth.make_clip(rng, T), t_on, ffc) for _ in range(8)]
+blobs = [distinct[i % 8] for i in range(N)]
+names = ["s%05d.cptv" % i for i in range(N)]
+cc = ClipClassifier(cfg) if classify else None
+run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=N, clip_classifier=cc, blobs=blobs)
+pr = cProfile.Profile()
+t0 = time.time()
+pr.enable()
+out, tr = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=N, clip_classifier=cc, blobs=blobs)
+pr.disable()
+print("seconds", round(time.time() - t0, 3), {k: round(v, 3) if isinstance(v, float) else v for k, v in tr.timings.items()})
+st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(28); print(st.getvalue()[:6000])

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     from cpx import _lib
 
     hdr = open(os.path.join(REPO, "include", "cpx.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|size_t|const char\*|void\*)\s+(cpx_[a-z_0-9]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^\s*(?:int|long|void|size_t|const char\*|void\*)\s+(cpx_[a-z_0-9]+)\s*\(", hdr, re.M))
     assert declared, "no prototypes found in cpx.h"
     lib = _lib.load()
     for name in declared:

@@ -65,3 +65,27 @@ def test_reader_rejects_truncated(tmp_path):
     assert r.next_frame() is not None
     with pytest.raises(ValueError):
         r.next_frame()
+
+
+def test_encode_cptv_round_trip(tmp_path):
+    """cpx.cptv.encode_cptv (the writer behind the synthetic recordings of bench.py from_files) against the reader:
+    frames, times, background flag, model; 8-bit and 16-bit frames in one file."""
+    from cpx import synth
+    from cpx.cptv import CptvReader, encode_cptv
+
+    rng = np.random.default_rng(4)
+    clip = synth.make_clip(rng, 12, max_blobs=2)
+    clip[5, :, ::2] += 3000           # stripes: this frame and the next need 16 bits per delta
+    t_on = [1000 + 111 * i for i in range(12)]
+    blob = encode_cptv(clip, t_on, [7] * 12, model=b"lepton3.5", background_first=True)
+    p = tmp_path / "x.cptv"
+    p.write_bytes(blob)
+    r = CptvReader(str(p))
+    h = r.get_header()
+    assert (h.model, h.x_resolution, h.y_resolution, h.has_background_frame) == ("lepton3.5", 160, 120, True)
+    _, _, widths = CptvReader(str(p)).scan()
+    assert set(widths.tolist()) == {8, 16}
+    fr = r.read_all()
+    assert len(fr) == 12 and fr[0].background_frame and not fr[1].background_frame
+    assert [f.time_on for f in fr] == t_on and all(f.last_ffc_time == 7 for f in fr)
+    assert np.array_equal(np.stack([f.pix for f in fr]), clip)
