@@ -67,9 +67,10 @@ def gather_records(records, dist=None, device=None):
 
 
 def plan_sub_batches(frame_counts, clip_ids, max_frames, max_clips=4096):
-    """Cuts one rank's clips into device batches: clips ordered by length (a batch advances all its clips one frame
-    per kernel launch, so clips of similar length waste the fewest launches), a batch closed when it would exceed
-    `max_frames` frames (what fits HBM next to the per-frame outputs) or `max_clips` clips.
+    """Cuts one rank's clips into device batches: clips ordered by length (one workgroup walks one clip through all of
+    its frames in a single launch of the track kernel and the longest clips are handed out first, so clips of similar
+    length leave the shortest tail), a batch closed when it would exceed `max_frames` frames (what fits HBM next to the
+    per-frame outputs) or `max_clips` clips.
     -> list of lists of clip ids (every id of `clip_ids` exactly once)."""
     order = sorted((int(i) for i in clip_ids), key=lambda i: (int(frame_counts[i]), i))
     out, cur, cur_frames = [], [], 0

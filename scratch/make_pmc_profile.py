@@ -15,7 +15,34 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("CPX_ROUND", "r02")
+ROUND = os.environ.get("CPX_ROUND", "r03")
+
+
+def rocprof_check():
+    """--rocprof-check: fail when the committed PMC summary is older than the last commit that touched the kernels
+    (classifier-pipeline_amd/csrc): bench.py quotes `roofline.traffic` from that file, so it must not go stale."""
+    import subprocess
+
+    summary = os.path.join("profiles", "%s_e2e_pmc.json" % ROUND)
+
+    def last_commit_time(path):
+        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--", path], capture_output=True, text=True)
+        return int(out.stdout.strip() or 0)
+
+    t_src, t_sum = last_commit_time("classifier-pipeline_amd/csrc"), last_commit_time(summary)
+    if not os.path.exists(os.path.join(ROOT, summary)) or t_sum == 0:
+        print("rocprof-check: %s is not committed" % summary)
+        return 1
+    if t_sum < t_src:
+        print("rocprof-check: %s (commit time %d) is older than the last csrc commit (%d): re-run scratch/refresh_pmc.sh "
+              "on the GPU box" % (summary, t_sum, t_src))
+        return 1
+    print("rocprof-check: %s is newer than the last csrc commit" % summary)
+    return 0
+
+
+if "--rocprof-check" in sys.argv:
+    sys.exit(rocprof_check())
 
 
 def rows(dirname, counter, kernel_sub, phase=None):
