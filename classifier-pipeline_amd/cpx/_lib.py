@@ -58,7 +58,8 @@ FRAME_INFO_DTYPE = np.dtype(
 )
 REGION_REF_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"),
                              ("in_segment", "<i4")])
-TRACK_LIMITS_DTYPE = np.dtype([("filt_min", "<f4"), ("filt_max", "<f4"), ("clip_at_zero", "<i4"), ("flags", "<i4")])
+TRACK_LIMITS_DTYPE = np.dtype([("filt_min", "<f4"), ("filt_max", "<f4"), ("clip_at_zero", "<i4"), ("flags", "<i4"),
+                               ("therm_min", "<f4"), ("therm_max", "<f4"), ("reserved", "<i4", (2,))])
 CROP_REQ_DTYPE = np.dtype([("frame", "<i4"), ("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"),
                            ("track", "<i4"), ("sample", "<i4"), ("tile", "<i4")])
 THUMB_STAT_DTYPE = np.dtype([("contours", "<i4"), ("status", "<i4"), ("median_diff", "<f8")])
@@ -80,7 +81,7 @@ CPTV_STATUS = {1: "deflate: reserved block type", 2: "deflate: stored block leng
                24: "truncated CPTV frame", 25: "malformed CPTV frame section", 26: "more frames than slots",
                27: "CPTV file has no frames"}
 assert CPTV_FILE_DTYPE.itemsize == 48 and CPTV_RESULT_DTYPE.itemsize == 40 and CPTV_SLOT_DTYPE.itemsize == 32
-assert REGION_REF_DTYPE.itemsize == 24 and TRACK_LIMITS_DTYPE.itemsize == 16 and CROP_REQ_DTYPE.itemsize == 32
+assert REGION_REF_DTYPE.itemsize == 24 and TRACK_LIMITS_DTYPE.itemsize == 32 and CROP_REQ_DTYPE.itemsize == 32
 assert FRAME_META_DTYPE.itemsize == 24 and COMPONENT_DTYPE.itemsize == 32 and FRAME_INFO_DTYPE.itemsize == 80
 
 class WRResNetBlock(C.Structure):  # struct cpx_wrresnet_block
@@ -126,7 +127,7 @@ EXPORTS = [
 
 # flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
 TRACK_KEEP_BACKGROUND, TRACK_FREEZE_ON_FFC, TRACK_FREEZE_BACKGROUND = 1, 2, 4
-LIMITS_POST_PROCESS = 1
+LIMITS_POST_PROCESS, LIMITS_THERMAL_DIFF_NORM, LIMITS_NO_DIFF_NORM, LIMITS_ALWAYS_CLIP, LIMITS_SWAP_CHANNELS = 1, 2, 4, 8, 16
 
 _lib = None
 

@@ -22,6 +22,25 @@ from .thumbnail import best_trackless_thumb, get_thumbnail_info
 from .trackprediction import Predictions
 
 
+# config/buildconfig.py:48-55 COUNTRY_LOCATIONS = Rectangle.from_ltrb(left, top, right, bottom) in degrees
+COUNTRY_LOCATIONS = {
+    "AU": (113.338953078, -10.6681857235, 153.569469029, -43.6345972634),
+    "NZ": (166.509144322, -34.4506617165, 178.517093541, -46.641235447),
+}
+
+
+def country_by_location(lat, lng):
+    """clipclassifier.py:654-660: the first country whose box contains the point -- Rectangle.contains(lng, lat)
+    (ml_tools/rectangle.py:148-150) on a rectangle built by from_ltrb, i.e. right = left + (right - left) and
+    bottom = top + (bottom - top) in floating point, as the reference evaluates them."""
+    for country, (left, top, right, bottom) in COUNTRY_LOCATIONS.items():
+        r = left + (right - left)
+        b = top + (bottom - top)
+        if left <= lng and r >= lng and top >= lat and b <= lat:
+            return country
+    return None
+
+
 class ClipClassifier:
     FRAME_SKIP = 1
 
@@ -43,10 +62,26 @@ class ClipClassifier:
         self.tracking_events = tracking_events
 
     def get_classifier(self, model, location=None):
-        """Classifier cached per model id in this process (clipclassifier.py:60-83)."""
+        """Classifier cached per model id in this process (clipclassifier.py:60-83).  With a recording location the
+        reference looks for a country-specific model next to the configured one -- <models>/<country>/<file name>,
+        the country decided by the bounding boxes of config/buildconfig.py (COUNTRY_LOCATIONS) -- and, like the
+        reference, the first model loaded for an id is the one the process keeps.  model_by_country = False
+        (ClipClassifier's constructor argument) keeps the configured file."""
         if model.id in self.models:
             return self.models[model.id]
         start = time.time()
+        if location is not None and self.model_by_country:
+            coordinates = location.get("coordinates") if isinstance(location, dict) else None
+            if coordinates is not None:
+                country = country_by_location(coordinates[1], coordinates[0])
+                if country is not None:
+                    model_file = Path(model.model_file)
+                    country_model = model_file.parent.parent / country
+                    logging.info("Checking if country model exists %s", country_model)
+                    if country_model.exists():
+                        model.model_file = str(country_model / model_file.name)
+                        logging.info("Setting to country model %s", model.model_file)
+        logging.info("classifier loading %s", model.model_file)
         classifier = get_interpreter(model, model.run_over_network)
         logging.info("classifier loaded (%s)", time.time() - start)
         self.models[model.id] = classifier
@@ -72,7 +107,11 @@ class ClipClassifier:
                 self.process_file(filename, cache=cache, reuse_frames=reuse_frames, track=False,
                                   calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
             return
-        if reuse_frames:  # the frames saved in each file's metadata decide the segments: per file
+        models = [self.model] if self.model else (self.config.classify.models or [])
+        classifiers = [self.get_classifier(m) for m in models]
+        per_file = bool(reuse_frames) or any(c.params.square_width == 1 for c in classifiers) \
+            or len(set(c.limits_flags() for c in classifiers)) > 1
+        if per_file:  # saved frames decide the segments / single-frame models / mixed normalisation variants
             for i in range(0, len(todo), 64):
                 self.process_files(todo[i:i + 64], reuse_frames=reuse_frames,
                                    calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
@@ -257,8 +296,11 @@ class ClipClassifier:
         predictions.model_load_time = time.time() - start
         if classifier.params.thermal_diff_norm:
             logging.error("Thermal min diff is not implemented so will not be used")
-        if not classifier.params.diff_norm or list(classifier.params.channels) != ["thermal", "filtered"]:
-            raise NotImplementedError("only diff_norm=True models with channels (thermal, filtered) are supported")
+        # the model's normalisation variant: post_process_file computes limits only for diff_norm models
+        # (clipclassifier.py:488) and never thermal ones (:465); without limits preprocess_frame normalises per tile
+        from .._lib import LIMITS_THERMAL_DIFF_NORM
+
+        post_flags = LIMITS_POST_PROCESS | (classifier.limits_flags() & ~LIMITS_THERMAL_DIFF_NORM)
 
         track_data = {}
         for track in clip.tracks:
@@ -291,7 +333,7 @@ class ClipClassifier:
             x, _ = eng.preprocess_segments(frames_dev, res, np.array(refs, dtype=REGION_REF_DTYPE),
                                            np.array([0, len(refs)], np.int32), np.array(reqs, dtype=CROP_REQ_DTYPE),
                                            len(segments), frame_size=fs, square_width=sq,
-                                           limits_flags=LIMITS_POST_PROCESS)
+                                           limits_flags=post_flags)
             preds = []
             chunk_size = 5
             for chunk in range(int(math.ceil(len(segments) / chunk_size))):

@@ -46,7 +46,10 @@ class Prediction:
     def get_metadata(self):
         # (plain lists / ints: the same JSON as the NumPy arrays the reference puts here, without a trip through the
         # encoder's default() hook per element)
-        frames = self.frames.tolist() if isinstance(self.frames, np.ndarray) else [int(f) for f in self.frames]
+        if np.ndim(self.frames) == 0:  # single-frame models: one frame number per prediction
+            frames = int(self.frames)
+        else:
+            frames = self.frames.tolist() if isinstance(self.frames, np.ndarray) else [int(f) for f in self.frames]
         meta = {"prediction": np.uint8(np.round(100 * self.prediction)).tolist(),
                 "smoothed_prediction": None if self.smoothed_prediction is None
                 else np.uint32(np.round(self.smoothed_prediction)).tolist(),

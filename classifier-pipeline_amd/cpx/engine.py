@@ -564,7 +564,7 @@ class TrackEngine:
         refs_dev = self._to_dev(refs) if refs.size else t.zeros(6, dtype=t.int32, device=self.device)
         offs_dev = t.from_numpy(offs).to(self.device)
         reqs_dev = self._to_dev(reqs) if reqs.size else t.zeros(8, dtype=t.int32, device=self.device)
-        limits_dev = t.zeros(max(n_tracks, 1) * 4, dtype=t.int32, device=self.device)
+        limits_dev = t.zeros(max(n_tracks, 1) * 8, dtype=t.int32, device=self.device)
         side = square_width * frame_size
         if out is None:
             out = t.empty((n_samples, side, side, 2), dtype=t.float32, device=self.device)

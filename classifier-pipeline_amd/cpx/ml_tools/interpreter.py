@@ -75,6 +75,8 @@ class Interpreter:
         frames, output, masses = self.predict_track(clip, track, segment_frames=segment_frames,
                                                     frames_per_classify=self.params.square_width**2,
                                                     min_segments=min_segments)
+        if output is not None and self.params.square_width == 1 and not isinstance(frames, list):
+            frames = list(frames)
         if output is None:
             logging.info("Skipping track %s", track.get_id())
             return None
@@ -86,27 +88,43 @@ class Interpreter:
         pred = TrackPrediction(track_id, self.labels, smooth_preds=self.params.smooth_predictions)
         pred.classified_track(output, prediction_frames, masses)
         # a single segment built from very few distinct frames: only 'false-positive' may be confident
-        if len(prediction_frames) == 1 and len(set(prediction_frames[0])) < self.params.square_width**2 / 4:
+        # (single-frame models hand frame NUMBERS here, not frame lists: one number counts as one distinct frame)
+        if len(prediction_frames) == 1 and len(set(np.atleast_1d(prediction_frames[0]).tolist())) < self.params.square_width**2 / 4:
             if pred.predicted_tag() != "false-positive":
                 pred.cap_confidences(0.5)
         return pred
 
+    def preprocess(self, clip, track, samples, **args):
+        """interpreter.py:110-130: segments for frames_per_classify > 1, single frames otherwise.  (The reference's own
+        single-frame branch calls preprocess_frames(clip, track) without the samples at this snapshot and raises
+        TypeError; the functions behind it are what tests/golden/classify_variants_golden.json was taken from.)"""
+        if args.get("frames_per_classify", 25) > 1:
+            return self.preprocess_segments(clip, track, samples, predict_from_last=args.get("predict_from_last"))
+        return self.preprocess_frames(clip, track, samples)
+
     def predict_track(self, clip, track, **args):
         samples = self.frames_for_prediction(clip, track, **args)
-        frames, preprocessed, masses = self.preprocess_segments(clip, track, samples)
+        frames, preprocessed, masses = self.preprocess(clip, track, samples, **args)
         if preprocessed is None or len(preprocessed) == 0:
             return None, None, None
         return frames, self.predict(preprocessed), masses
 
     def predict_recent_frames(self, clip, track, **args):
         samples = self.frames_for_prediction(clip, track, **args)
-        frames, preprocessed, mass = self.preprocess_segments(clip, track, samples)
+        frames, preprocessed, mass = self.preprocess(clip, track, samples, **args)
         if preprocessed is None or len(preprocessed) == 0:
             return None
         return self.predict(preprocessed), frames, mass
 
     def frames_for_prediction(self, clip, track, **args):
-        """interpreter.py:178-253 for frames_per_classify > 1."""
+        """interpreter.py:178-253: segments for frames_per_classify > 1, else the track's usable regions (the last
+        num_predictions of them)."""
+        if args.get("frames_per_classify", 25) <= 1:
+            frames = [r for r in track.bounds_history if not r.blank and r.width > 0 and r.height > 0]
+            max_frames = args.get("num_predictions")
+            if max_frames is not None and len(frames) >= max_frames:
+                frames = frames[-max_frames:]
+            return frames
         segment_frames = args.get("segment_frames")
         dont_filter = args.get("dont_filter", False)
         predict_from_last = args.get("predict_from_last")
@@ -148,6 +166,8 @@ class Interpreter:
     def preprocess_segments(self, clip, track, segments, predict_from_last=None):
         if not segments:
             return [], None, []
+        if self.params.mvm:
+            raise NotImplementedError("mvm models (RandomForest track features beside the images) are not part of this build")
         sq = self.params.square_width
         n_tiles = sq * sq
         for seg in segments:
@@ -156,14 +176,47 @@ class Interpreter:
         x, _ = self._device_preprocess(clip, track, segments)
         return [s.frame_indices for s in segments], x, [s.mass for s in segments]
 
-    def _device_preprocess(self, clip, track, segments):
+    def preprocess_frames(self, clip, track, samples):
+        """Single-frame models (interpreter.py:255-313, ml_tools/preprocess.py:119-144): every usable region is one
+        sample [frame_size, frame_size, channels]: the crop / resize / normalise of preprocess_frame with its default
+        clip_thermals_at_zero = True, no tiling.  -> (frame numbers, device tensor [n, fs, fs, 2], [mass of the LAST
+        region]) -- the reference returns that one mass (sic)."""
+        samples = list(samples)
+        if not samples:
+            return [], None, []
+
+        class _One:  # a one-frame "segment"
+            def __init__(self, region):
+                self.frame_indices = [region.frame_number]
+                self.mass = region.mass
+
+        x, _ = self._device_preprocess(clip, track, [_One(r) for r in samples], single=True)
+        return [r.frame_number for r in samples], x, [samples[-1].mass]
+
+    def limits_flags(self, single=False):
+        """_lib.LIMITS_* of this model's hyper-parameters (include/cpx.h)."""
+        from .._lib import LIMITS_ALWAYS_CLIP, LIMITS_NO_DIFF_NORM, LIMITS_SWAP_CHANNELS, LIMITS_THERMAL_DIFF_NORM
+
+        channels = [str(getattr(c, "name", c)) for c in self.params.channels]
+        if channels not in (["thermal", "filtered"], ["filtered", "thermal"]):
+            raise NotImplementedError("channels %s: the network kernels take the two channels thermal and filtered "
+                                      "(in either order)" % (channels,))
+        flags = 0
+        if self.params.thermal_diff_norm:
+            flags |= LIMITS_THERMAL_DIFF_NORM
+        if not self.params.diff_norm:
+            flags |= LIMITS_NO_DIFF_NORM
+        if single:
+            flags |= LIMITS_ALWAYS_CLIP
+        if channels[0] == "filtered":
+            flags |= LIMITS_SWAP_CHANNELS
+        return flags
+
+    def _device_preprocess(self, clip, track, segments, single=False):
         state = getattr(clip, "device_state", None)
         if state is None:
             raise RuntimeError("clip was not tracked by cpx.ClipTrackExtractor: no device-resident frames")
-        if self.params.thermal_diff_norm or not self.params.diff_norm:
-            raise NotImplementedError("only diff_norm=True, thermal_diff_norm=False models are supported")
-        if list(self.params.channels) != ["thermal", "filtered"]:
-            raise NotImplementedError("only channels (thermal, filtered) are supported")
+        flags = self.limits_flags(single)
         used = set(int(f) for s in segments for f in s.frame_indices)
         by_frame = {}
         refs = []
@@ -187,7 +240,8 @@ class Interpreter:
         x, limits = state.engine.preprocess_segments(
             state.frames_dev, state.track_result, np.array(refs, dtype=REGION_REF_DTYPE),
             np.array([0, len(refs)], np.int32), np.array(reqs, dtype=CROP_REQ_DTYPE), len(segments),
-            frame_size=self.params.frame_size, square_width=self.params.square_width)
+            frame_size=self.params.frame_size, square_width=1 if single else self.params.square_width,
+            limits_flags=flags)
         return x, limits
 
 

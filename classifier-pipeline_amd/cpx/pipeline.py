@@ -37,8 +37,9 @@ class BatchResult:
 
 class BatchPipeline:
     def __init__(self, engine, network=None, n_labels=17, fp_index=-1, frame_size=32, square_width=5,
-                 track_params=None, filter_params=None, cnn_chunk=512, want_regions=False):
+                 track_params=None, filter_params=None, cnn_chunk=512, want_regions=False, limits_flags=0):
         self.want_regions = want_regions  # per-frame region lists from the association (the trackless thumbnail)
+        self.limits_flags = limits_flags  # _lib.LIMITS_*: the model's normalisation variant (cpx_track_limits_batch_ex)
         self.eng = engine
         self.net = network
         self.n_labels = n_labels
@@ -188,12 +189,12 @@ class BatchPipeline:
         toffs[n_tracks] = n_refs
         out.track_clip, out.reqs_dev, out.sample_track_dev = track_clip, reqs, sample_track
         # ---- 5a. per-track limits ----
-        limits = t.zeros(n_tracks * 4, dtype=t.int32, device=dev)
+        limits = t.zeros(n_tracks * 8, dtype=t.int32, device=dev)
         eng.sync_inputs()
-        self._check(lib.cpx_track_limits_batch(
+        self._check(lib.cpx_track_limits_batch_ex(
             h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(out.track.filtered_dev.data_ptr()),
             C.c_void_p(out.track.info_dev.data_ptr()), C.c_void_p(refs.data_ptr()), C.c_void_p(toffs.data_ptr()),
-            n_tracks, C.c_void_p(limits.data_ptr())))
+            n_tracks, C.c_void_p(limits.data_ptr()), int(self.limits_flags)))
         out.limits_dev = limits
         out._keep = (refs, toffs, prefix)
         return out

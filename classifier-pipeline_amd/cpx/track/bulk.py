@@ -313,7 +313,14 @@ class BulkTracker:
         info_dev = t.empty(total * 20, dtype=t.int32, device=dev)
         labels = t.empty((total, H, W), dtype=t.int32, device=dev)
         filt = t.empty((total, H, W), dtype=t.float32, device=dev) if classifiers else None
-        pipe = BatchPipeline(eng, None, square_width=sq, track_params=tp, filter_params=fp, want_regions=True)
+        lflags = classifiers[0][1].limits_flags() if classifiers else 0
+        for _, interp in classifiers:
+            if interp.params.square_width == 1:
+                raise NotImplementedError("single-frame models go through ClipClassifier.process_files")
+            if interp.limits_flags() != lflags:
+                raise NotImplementedError("models with different normalisation variants in one run")
+        pipe = BatchPipeline(eng, None, square_width=sq, track_params=tp, filter_params=fp, want_regions=True,
+                             limits_flags=lflags)
         model_out = []
         prof = self.timings.setdefault("device_split_s", {}) if os.environ.get("CPX_BULK_PROFILE") else None
         tick = [time.time()]

@@ -73,7 +73,7 @@ static_assert(sizeof(cpx_component) == 32, "cpx_component layout is part of the 
 static_assert(sizeof(cpx_frame_info) == 80, "cpx_frame_info layout is part of the ABI");
 static_assert(sizeof(cpx_frame_meta) == 24, "cpx_frame_meta layout is part of the ABI");
 static_assert(sizeof(cpx_config) == 48, "cpx_config layout is part of the ABI");
-static_assert(sizeof(cpx_region_ref) == 24 && sizeof(cpx_track_limits) == 16 && sizeof(cpx_crop_req) == 32,
+static_assert(sizeof(cpx_region_ref) == 24 && sizeof(cpx_track_limits) == 32 && sizeof(cpx_crop_req) == 32,
               "classification request layouts are part of the ABI");
 static_assert(sizeof(cpx_filter_params) == 72 && sizeof(cpx_track_summary) == 120,
               "end-of-clip layouts are part of the ABI");
@@ -752,7 +752,8 @@ int cpx_track_limits_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const f
                               const int32_t* track_offsets_dev, int n_tracks, cpx_track_limits* limits_dev, int flags) {
   if (!h) return CPX_ERR_INVALID;
   if (!frames_dev || !filtered_dev || !info_dev || !refs_dev || !track_offsets_dev || !limits_dev || n_tracks < 0 ||
-      (flags & ~CPX_LIMITS_POST_PROCESS))
+      (flags & ~(CPX_LIMITS_POST_PROCESS | CPX_LIMITS_THERMAL_DIFF_NORM | CPX_LIMITS_NO_DIFF_NORM | CPX_LIMITS_ALWAYS_CLIP |
+                 CPX_LIMITS_SWAP_CHANNELS)))
     return fail(h, CPX_ERR_INVALID, "cpx_track_limits_batch: bad argument");
   if (n_tracks == 0) return CPX_OK;
   CPX_ENTER(h);

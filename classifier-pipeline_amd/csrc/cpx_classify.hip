@@ -79,7 +79,7 @@ __device__ __forceinline__ u32 block_sum_u32(u32 v, u32* sc) {
 __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
   // the track's regions are dealt to the workgroup's waves; a wave handles a region with shuffles only (no
   // workgroup barrier inside the per-region median bisection), the waves meet once at the end
-  __shared__ float s_mn[LW], s_mx[LW];
+  __shared__ float s_mn[LW], s_mx[LW], s_tmn[LW], s_tmx[LW];
   __shared__ int s_clip[LW];
   const int t = blockIdx.x;
   const int r0 = a.track_offsets[t], r1 = a.track_offsets[t + 1];
@@ -89,11 +89,18 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
   // crop's own min / max start both, and only sampled frames count (clipclassifier.py:484-497)
   const bool post = (a.limits_flags & CPX_LIMITS_POST_PROCESS) != 0;
   float mn = INFINITY, mx = post ? -INFINITY : 0.0f;
+  float tmn = INFINITY, tmx = -INFINITY;  // thermal_norm_limits: thermal - median over the whole frame (get_limits)
   int clip0 = 1;
   for (int r = r0 + wave; r < r1; r += LW) {
     const cpx_region_ref ref = a.refs[r];
     if (ref.width <= 0 || ref.height <= 0) continue;
     if (post && !ref.in_segment) continue;
+    {
+      // float32(thermal) - np.median(float32 frame): integers minus a half-integer, exact in float32
+      const FrameInfo fi = a.info[ref.frame];
+      tmn = fminf(tmn, __fsub_rn((float)fi.thermal_min, fi.thermal_median));
+      tmx = fmaxf(tmx, __fsub_rn((float)fi.thermal_max, fi.thermal_median));
+    }
     const int n = ref.width * ref.height;
     const float* F = a.filtered + (size_t)ref.frame * P;
     for (int k = lane; k < n; k += 64) {
@@ -139,6 +146,8 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
   if (lane == 0) {
     s_mn[wave] = mn;
     s_mx[wave] = mx;
+    s_tmn[wave] = tmn;   // (uniform across the wave: every lane read the same frame records)
+    s_tmx[wave] = tmx;
     s_clip[wave] = clip0;
   }
   __syncthreads();
@@ -151,10 +160,20 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
       fmx = fmaxf(fmx, s_mx[w]);
       c0 &= s_clip[w];
     }
+    float ftmn = s_tmn[0], ftmx = s_tmx[0];
+    for (int w = 1; w < LW; ++w) {
+      ftmn = fminf(ftmn, s_tmn[w]);
+      ftmx = fmaxf(ftmx, s_tmx[w]);
+    }
     o.filt_min = fmn;
     o.filt_max = fmx;
-    o.clip_at_zero = post ? 1 : c0;  // preprocess_frame's default clip_thermals_at_zero = True (preprocess.py:68)
+    // preprocess_frame's default clip_thermals_at_zero = True (preprocess.py:68): post_process_file and the
+    // single-frame path (preprocess_frames, interpreter.py:297-306) do not pass the tested value
+    o.clip_at_zero = (post || (a.limits_flags & CPX_LIMITS_ALWAYS_CLIP)) ? 1 : c0;
     o.flags = a.limits_flags;
+    o.therm_min = ftmn;
+    o.therm_max = ftmx;
+    o.reserved[0] = o.reserved[1] = 0;
     a.limits[t] = o;
   }
 }
@@ -184,6 +203,7 @@ __device__ __forceinline__ void lin_coord(int d, int dn, int sn, int* i0, int* i
 __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_t = reinterpret_cast<float*>(smem);  // [fs*fs] thermal tile
+  float* s_f = s_t + a.frame_size * a.frame_size;  // [fs*fs] filtered tile (diff_norm = False: normalised per tile)
   __shared__ float sc[LW];
   const cpx_crop_req q = a.reqs[blockIdx.x];
   const int fs = a.frame_size, sq = a.square_width;
@@ -215,13 +235,16 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
   // post_process_file hands preprocess_frame a crop that already had the frame median subtracted (float32, exact:
   // integer pixels, half-integer median), with sub_median = False: the subtraction happens BEFORE the resize
   const bool pre = (lim.flags & CPX_LIMITS_POST_PROCESS) != 0;
+  const bool tdn = (lim.flags & CPX_LIMITS_THERMAL_DIFF_NORM) != 0;   // thermal_norm_limits given: no clip at zero
+  const bool own = (lim.flags & CPX_LIMITS_NO_DIFF_NORM) != 0;        // Frame.normalize(): both channels per tile
+  const int cth = (lim.flags & CPX_LIMITS_SWAP_CHANNELS) ? 1 : 0, cfi = cth ^ 1;
   if (pre) pmin = __fsub_rn(pmin, median);
   // ---- both channels: bilinear sample (two float32 passes), paste, per-pixel ops ----
   const int n = fs * fs;
   const int ty = q.tile / sq, tx = q.tile - ty * sq;
   const int OW = sq * fs;
   float* out = a.out + ((size_t)q.sample * OW + (size_t)ty * fs) * OW * 2 + (size_t)tx * fs * 2;
-  float tmn = INFINITY, tmx = -INFINITY;
+  float tmn = INFINITY, tmx = -INFINITY, fmn = INFINITY, fmx = -INFINITY;
   const float fspan = __fsub_rn(lim.filt_max, lim.filt_min);
   for (int k = threadIdx.x; k < n; k += LT) {
     const int yy = k / fs, xx = k - yy * fs;
@@ -249,10 +272,16 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
     }
     // thermal: -= median ; clip at 0 (preprocess.py:87-90)
     if (!pre) tv = __fsub_rn(tv, median);
-    if (lim.clip_at_zero && tv < 0.0f) tv = 0.0f;
+    if (lim.clip_at_zero && !tdn && tv < 0.0f) tv = 0.0f;
     s_t[k] = tv;
     tmn = fminf(tmn, tv);
     tmx = fmaxf(tmx, tv);
+    if (own) {
+      s_f[k] = fv;
+      fmn = fminf(fmn, fv);
+      fmx = fmaxf(fmx, fv);
+      continue;
+    }
     // filtered: normalize(min, max of the track, new_max = 255) (preprocess.py:92-98)
     float fo;
     if (pre) {
@@ -263,19 +292,37 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
       else fo = (float)(255.0 * ((double)fv - dmin) / (dmax - dmin));
     } else if (lim.filt_max == lim.filt_min) fo = (lim.filt_max == 0.0f) ? 0.0f : __fdiv_rn(fv, lim.filt_max);
     else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, lim.filt_min)), fspan);
-    out[((size_t)yy * OW + xx) * 2 + 1] = fo;
+    out[((size_t)yy * OW + xx) * 2 + cfi] = fo;
   }
   tmn = block_min(tmn, sc);
   tmx = block_max(tmx, sc);
-  // thermal: normalize over the tile itself (preprocess.py:99-106)
+  // thermal: normalize over the tile itself (preprocess.py:99-106), or with the track's thermal limits
+  // (thermal_diff_norm: normalize(thermal, min, max, 255) with the np.float32 limits of get_limits) -- unless
+  // diff_norm is off, where Frame.normalize() ignores them
+  if (tdn && !own) {
+    tmn = lim.therm_min;
+    tmx = lim.therm_max;
+  }
   const float tspan = __fsub_rn(tmx, tmn);
+  if (own) {
+    fmn = block_min(fmn, sc);
+    fmx = block_max(fmx, sc);
+  }
+  const float ospan = __fsub_rn(fmx, fmn);
   for (int k = threadIdx.x; k < n; k += LT) {
     const int yy = k / fs, xx = k - yy * fs;
     const float tv = s_t[k];
     float to;
     if (tmx == tmn) to = (tmx == 0.0f) ? 0.0f : __fdiv_rn(tv, tmx);
     else to = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(tv, tmn)), tspan);
-    out[((size_t)yy * OW + xx) * 2] = to;
+    out[((size_t)yy * OW + xx) * 2 + cth] = to;
+    if (own) {
+      const float fv = s_f[k];
+      float fo;
+      if (fmx == fmn) fo = (fmx == 0.0f) ? 0.0f : __fdiv_rn(fv, fmx);
+      else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, fmn)), ospan);
+      out[((size_t)yy * OW + xx) * 2 + cfi] = fo;
+    }
   }
 }
 
@@ -349,7 +396,7 @@ void launch_limits(const ClassifyArgs& a, int n_tracks, hipStream_t s) {
   hipLaunchKernelGGL(cpx_limits_kernel, dim3(n_tracks), dim3(LT), 0, s, a);
 }
 void launch_crop(const ClassifyArgs& a, int n_reqs, hipStream_t s) {
-  hipLaunchKernelGGL(cpx_crop_kernel, dim3(n_reqs), dim3(LT), (size_t)a.frame_size * a.frame_size * sizeof(float), s, a);
+  hipLaunchKernelGGL(cpx_crop_kernel, dim3(n_reqs), dim3(LT), (size_t)2 * a.frame_size * a.frame_size * sizeof(float), s, a);
 }
 
 }  // namespace cpx

@@ -378,6 +378,9 @@ typedef struct cpx_track_limits { /* per track */
   float filt_min, filt_max;       /* filtered_norm_limits: min / max over the track's region crops, max >= 0 */
   int32_t clip_at_zero;           /* clip_thermals_at_zero (interpreter.py:372-399) */
   int32_t flags;                  /* CPX_LIMITS_* the limits were computed with: cpx_crop_tile follows them */
+  float therm_min, therm_max;     /* thermal_norm_limits (CPX_LIMITS_THERMAL_DIFF_NORM): min / max of thermal - median
+                                     over the whole frames of the track's regions (interpreter.py:339-346) */
+  int32_t reserved[2];
 } cpx_track_limits;
 
 /* cpx_track_limits_batch_ex flags.  CPX_LIMITS_POST_PROCESS = ClipClassifier.post_process_file
@@ -386,6 +389,16 @@ typedef struct cpx_track_limits { /* per track */
  * crop BEFORE it is resized (preprocess_frame(cropped=True, sub_median=False) on a crop that already had it
  * subtracted) instead of after. */
 #define CPX_LIMITS_POST_PROCESS 1
+/* The normalisation variants of preprocess_frame (ml_tools/preprocess.py:56-113) a model's hyper-parameters select
+ * (ml_tools/hyperparams.py): thermal_diff_norm -> the thermal tile is NOT clipped at zero and is normalised with the
+ * track's thermal limits; diff_norm = False -> no limits are applied, both channels are normalised per tile
+ * (Frame.normalize, ml_tools/frame.py:187-191; the thermal limits are then ignored too, as in the reference);
+ * ALWAYS_CLIP -> clip_thermals_at_zero = True without the median test: what preprocess_frames passes for
+ * single-frame models (interpreter.py:255-313); SWAP_CHANNELS -> channels = (filtered, thermal). */
+#define CPX_LIMITS_THERMAL_DIFF_NORM 2
+#define CPX_LIMITS_NO_DIFF_NORM 4
+#define CPX_LIMITS_ALWAYS_CLIP 8
+#define CPX_LIMITS_SWAP_CHANNELS 16
 
 typedef struct cpx_crop_req { /* one tile = one frame of one segment */
   int32_t frame;
