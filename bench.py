@@ -916,6 +916,16 @@ def main():
             deng.synchronize()
             dt = time.perf_counter() - t1
             kms, kn = deng.last_kernel_timing()
+            # the WHOLE path with the reference's default configuration: track (NLM inside) + classify, same slice
+            net_dn = wr.WRResNetDevice(deng, weights, N_LABELS)
+            pipe_dn = BatchPipeline(deng, net_dn, n_labels=N_LABELS, fp_index=4, cnn_chunk=args.cnn_chunk, frame_size=32)
+            pipe_dn.run(frames, o2, meta[: nb * T], outputs=outputs)            # warm-up
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            r_dn = pipe_dn.run(frames, o2, meta[: nb * T], outputs=outputs)
+            torch.cuda.synchronize(device)
+            dt_e2e = time.perf_counter() - t1
+            net_dn.close()
             deng.close()
             # the same slice without denoise: the difference is the NLM kernel
             eng.track_batch(frames, o2, meta[: nb * T], outputs=outputs)
@@ -924,11 +934,41 @@ def main():
             eng.track_batch(frames, o2, meta[: nb * T], outputs=outputs)
             eng.synchronize()
             dt0 = time.perf_counter() - t1
-            line["default_config"] = {"what": "track stage with tracking.denoise = true (the reference's default, SURVEY F7) "
-                                              "over %d of the resident clips x %d frames, same run" % (nb, T),
-                                      "frames_per_s": round(nb * T / dt, 1),
-                                      "nlm_us_per_frame": round((dt - dt0) / (nb * T) * 1e6, 3),
-                                      "frames_per_s_denoise_off_same_slice": round(nb * T / dt0, 1)}
+            nlm_s = dt - dt0
+            # Operation-count model of cpx_nlm_kernel<10,160> (instructions counted in the gfx950 ISA of the shipped
+            # build, csrc/cpx_track.hip): per (pixel, offset) of the 21 x 21 search window -- pass A (row sums of squared
+            # differences, one pass per offset PAIR, 8 columns per item: 80 vector + 7 LDS instructions) 5.0 vector +
+            # 0.44 LDS lane-operations; pass B (seven-row sliding sum, weight look-up, accumulate, two columns per
+            # thread) ~7.1 vector + 1.8 LDS.  A CU issues at most 128 vector lane-operations per cycle (4 SIMD-32) and
+            # serves 64 LDS lanes per 2 cycles.
+            px_off = H * W * 441.0
+            valu_ops, lds_ops = 12.1 * px_off, 2.24 * px_off
+            clock = 2.4e9
+            t_valu = valu_ops / 128.0 / clock / 256.0      # seconds per frame, chip-wide, if vector issue were the bound
+            t_lds = lds_ops / 32.0 / clock / 256.0          # ... if the LDS instruction rate were
+            nlm_per_frame = nlm_s / (nb * T)
+            line["default_config"] = {
+                "what": "the reference's DEFAULT configuration (tracking.denoise = true, SURVEY F7) over %d of the resident "
+                        "clips x %d frames, same run: end to end (track with the NLM kernel + classify), and the track "
+                        "stage alone" % (nb, T),
+                "frames_per_s": round(nb * T / dt_e2e, 1), "ms_per_step": round(dt_e2e * 1e3, 2),
+                "classified_segments": int(r_dn.n_samples),
+                "track_stage_frames_per_s": round(nb * T / dt, 1),
+                "nlm_us_per_frame": round(nlm_per_frame * 1e6, 3),
+                "nlm_share_of_step": round(nlm_s / dt_e2e, 3),
+                "frames_per_s_denoise_off_same_slice": round(nb * T / dt0, 1)}
+            line["roofline_nlm"] = {
+                "kernel": "cpx_nlm_kernel<10,160>", "bound": "vector + LDS instruction issue (no HBM or matrix roof applies: "
+                          "19 KB in, 19 KB out per frame, integer arithmetic on an LDS-resident frame)",
+                "model": {"pixel_offsets_per_frame": px_off, "vector_lane_ops_per_pixel_offset": 12.1,
+                          "lds_lane_ops_per_pixel_offset": 2.24, "vector_lane_ops_per_cycle_per_cu": 128,
+                          "lds_lanes_per_cycle_per_cu": 32, "clock_hz": clock, "cus": 256},
+                "achieved_us_per_frame": round(nlm_per_frame * 1e6, 3),
+                "vector_issue_bound_us_per_frame": round(t_valu * 1e6, 3),
+                "lds_issue_bound_us_per_frame": round(t_lds * 1e6, 3),
+                "frac": round(max(t_valu, t_lds) / nlm_per_frame, 4), "unit": "fraction of the nearer issue bound",
+                "note": "frames in flight: one 1024-thread workgroup (a whole frame) per CU, 16 waves; the two issue "
+                        "bounds are of the same size, so the kernel needs both pipes busy at once to approach either"}
             nb64 = min(B, 1024)
             net64 = wr.WRResNetDevice(eng, weights, N_LABELS)
             pipe64 = BatchPipeline(eng, net64, n_labels=N_LABELS, fp_index=4, cnn_chunk=512, frame_size=64)

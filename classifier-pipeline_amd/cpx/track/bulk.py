@@ -726,78 +726,83 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         return staged, decoded, t1 - t0, time.time() - t1
 
     worker = ThreadPoolExecutor(max_workers=1)
+    dev_worker = ThreadPoolExecutor(max_workers=1)
     fut = worker.submit(produce, 0) if batches else None
-    for bi, paths in enumerate(batches):
-        t0 = time.time()
-        staged, decoded, stage_s, decode_s = fut.result()
-        fut = worker.submit(produce, bi + 1) if bi + 1 < len(batches) else None
-        tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + stage_s
-        tracker.timings["decode_s"] += decode_s
-        tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + time.time() - t0
-        retry = dict(decoded.errors)
-        texts = {}
-        n_ok = sum(len(g.files) for g in decoded.groups)
-        for group in (sub for g in decoded.groups for sub in g.split(track_files)):
-            td = time.time()
-            clips, existing = [], []
-            for k, i in enumerate(group.files):
-                clip = Clip(tracker.tcfg, paths[i])
-                clip.frames_per_second = 9
-                h = group.headers[k]
-                clip.set_res(h.x_resolution, h.y_resolution)
-                clip.set_model(h.model if h.model else None)
-                clip.set_video_stats(datetime.fromtimestamp(h.timestamp / 1000000).astimezone(Clip.local_tz))
-                clips.append(clip)
-                mf = os.path.splitext(paths[i])[0] + ".txt"
-                existing.append(tools.load_clip_metadata(mf) if blobs is None and os.path.exists(mf) else None)
-            # (lepton3 and "no model" files share thresholds but not the metadata's camera_model: grouped by model)
-            try:
-                r = tracker.track_group(group, clips, classifiers)
-            except CpxError as e:  # the whole group failed on the device: every member goes the slow way
-                for i in group.files:
-                    retry[i] = "%s: %s" % (paths[i], e)
+
+    # Three stages in flight: the decode of batch k+1 (worker above), the device phase of group g+1 (dev_worker: track,
+    # classify, thumbnails -- mostly waiting on the device with the GIL released) and the metadata of group g (this
+    # thread).
+    def device_phase(paths, group):
+        td = time.time()
+        clips, existing = [], []
+        for k, i in enumerate(group.files):
+            clip = Clip(tracker.tcfg, paths[i])
+            clip.frames_per_second = 9
+            h = group.headers[k]
+            clip.set_res(h.x_resolution, h.y_resolution)
+            clip.set_model(h.model if h.model else None)
+            clip.set_video_stats(datetime.fromtimestamp(h.timestamp / 1000000).astimezone(Clip.local_tz))
+            clips.append(clip)
+            mf = os.path.splitext(paths[i])[0] + ".txt"
+            existing.append(tools.load_clip_metadata(mf) if blobs is None and os.path.exists(mf) else None)
+        # (lepton3 and "no model" files share thresholds but not the metadata's camera_model: grouped by model)
+        try:
+            r = tracker.track_group(group, clips, classifiers)
+        except CpxError as e:  # the whole group failed on the device: every member goes the slow way
+            r = e
+        return clips, existing, r, time.time() - td
+
+    def host_phase(ctx, group, result):
+        paths, texts, retry = ctx["paths"], ctx["texts"], ctx["retry"]
+        clips, existing, r, dev_s = result
+        tracker.timings["device_s"] += dev_s
+        if isinstance(r, Exception):
+            for i in group.files:
+                retry[i] = "%s: %s" % (paths[i], r)
+            return
+        th = time.time()
+        offs = group.offs
+        per_clip = {}
+        for ti, (b, j) in enumerate(r["kept"]):
+            per_clip.setdefault(b, []).append(ti)
+        # usable-region index ranges per kept track
+        upos = np.searchsorted(r["usable"], r["tr_off"])
+        tracking_time = (time.time() - ctx["t0"]) / max(ctx["n_ok"], 1)
+        n_kept = max(len(r["kept"]), 1)
+        model_meta = None
+        if classifiers:
+            model_meta = []
+            for mo in r["model_out"]:
+                d = mo["model"].as_dict()
+                d["classify_time"] = float(round(mo["seconds"] / max(len(group.files), 1), 1))
+                model_meta.append(d)
+        for b, i in enumerate(group.files):
+            if b in r["failed"]:
+                retry[i] = "%s: %s" % (paths[i], r["failed"][b])
                 continue
-            th = time.time()
-            tracker.timings["device_s"] += th - td
-            info, offs = r["info"], group.offs
-            per_clip = {}
-            for ti, (b, j) in enumerate(r["kept"]):
-                per_clip.setdefault(b, []).append(ti)
-            # usable-region index ranges per kept track
-            upos = np.searchsorted(r["usable"], r["tr_off"])
-            tracking_time = (time.time() - t0) / max(n_ok, 1)
-            n_kept = max(len(r["kept"]), 1)
-            model_meta = None
-            if classifiers:
-                model_meta = []
-                for mo in r["model_out"]:
-                    d = mo["model"].as_dict()
-                    d["classify_time"] = float(round(mo["seconds"] / max(len(group.files), 1), 1))
-                    model_meta.append(d)
-            for b, i in enumerate(group.files):
-                if b in r["failed"]:
-                    retry[i] = "%s: %s" % (paths[i], r["failed"][b])
-                    continue
-                n_proc = len(r["proc_idx"][b])
-                tracks = []
-                for ti in per_clip.get(b, ()):
-                    _, j = r["kept"][ti]
-                    regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
-                    use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
-                    st = r["stats"][upos[ti]:upos[ti + 1]]
-                    tr = dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st))
-                    if classifiers:
-                        secs = sum(mo["seconds"] for mo in r["model_out"]) / n_kept
-                        tr["predictions"] = track_predictions(r, ti, b, r["model_out"], secs)
-                    tracks.append(tr)
-                trackless = None
-                if not tracks:
-                    kind, payload = r["best_region"].get(b, ("none", None))
-                    trackless = _trackless_region(kind, payload)
-                texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[i], tracking_time,
-                                                 existing[b], indent, models=model_meta)
-                tracker.timings["frames"] += int(offs[b + 1] - offs[b])
-            tracker.timings["host_s"] += time.time() - th
+            n_proc = len(r["proc_idx"][b])
+            tracks = []
+            for ti in per_clip.get(b, ()):
+                _, j = r["kept"][ti]
+                regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
+                use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
+                st = r["stats"][upos[ti]:upos[ti + 1]]
+                tr = dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st))
+                if classifiers:
+                    secs = sum(mo["seconds"] for mo in r["model_out"]) / n_kept
+                    tr["predictions"] = track_predictions(r, ti, b, r["model_out"], secs)
+                tracks.append(tr)
+            trackless = None
+            if not tracks:
+                kind, payload = r["best_region"].get(b, ("none", None))
+                trackless = _trackless_region(kind, payload)
+            texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[i], tracking_time,
+                                             existing[b], indent, models=model_meta)
+            tracker.timings["frames"] += int(offs[b + 1] - offs[b])
+        tracker.timings["host_s"] += time.time() - th
+
+    def close_batch(ctx):
+        paths, texts, retry = ctx["paths"], ctx["texts"], ctx["retry"]
         tw = time.time()
         for i, text in texts.items():
             if indent is None and (to_stdout or clip_classifier is not None):
@@ -825,6 +830,39 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             except Exception as e:  # noqa: BLE001 -- fault isolation: one bad recording must not stop the directory
                 logging.error("could not process %s: %s", paths[i], e)
                 out[paths[i]] = "error: %s" % (e,)
+
+    pending = None   # (ctx, group, future of its device phase)
+
+    def drain():
+        nonlocal pending
+        if pending is not None:
+            ctx, group, f = pending
+            pending = None
+            host_phase(ctx, group, f.result())
+            ctx["open"] -= 1
+            if ctx["open"] == 0 and ctx["submitted"]:
+                close_batch(ctx)
+
+    for bi, paths in enumerate(batches):
+        t0 = time.time()
+        staged, decoded, stage_s, decode_s = fut.result()
+        fut = worker.submit(produce, bi + 1) if bi + 1 < len(batches) else None
+        tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + stage_s
+        tracker.timings["decode_s"] += decode_s
+        tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + time.time() - t0
+        groups = [sub for g in decoded.groups for sub in g.split(track_files)]
+        ctx = dict(paths=paths, texts={}, retry=dict(decoded.errors), t0=t0, open=len(groups), submitted=False,
+                   n_ok=sum(len(g.files) for g in decoded.groups))
+        for gi, group in enumerate(groups):
+            f = dev_worker.submit(device_phase, paths, group)
+            ctx["submitted"] = gi + 1 == len(groups)
+            drain()                      # the previous group's metadata, while this one is on the device
+            pending = (ctx, group, f)
+        if not groups:
+            close_batch(ctx)
+        del staged, decoded
+    drain()
+    dev_worker.shutdown(wait=True)
     worker.shutdown(wait=True)
     if own_stager:
         stager.close()

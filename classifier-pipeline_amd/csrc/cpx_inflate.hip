@@ -63,6 +63,9 @@ struct WaveIO {
   int lit, nlit;          // pending literals: lane k of `lit` holds literal k of the run as byte << 4 (a table entry)
   WaveLds* lds;
   const uint8_t* file_bytes;
+  // lane-indexed constant tables (RFC 1951 3.2.5): lane s of len_tab = base | extra bits << 16 of length symbol
+  // 257 + s, of dist_tab the same for distance symbol s -- one v_readlane instead of a branchy computation
+  int len_tab, dist_tab;
 
   __device__ __forceinline__ long pos_bits() const { return (wbase + widx) * 32 - cnt; }  // position of the next bit
   __device__ __forceinline__ int load_chunk(long chunk) const {
@@ -211,6 +214,7 @@ struct WaveIO {
     v16i tab;
 #pragma unroll
     for (int k = 0; k < 16; ++k) tab[k] = (int)ll[k * 64 + lane];
+    const int dtab0 = (int)dt[lane], dtab1 = (int)dt[64 + lane], dtab2 = (int)dt[128 + lane], dtab3 = (int)dt[192 + lane];
     for (;;) {
       uint32_t e = 0xFFFF;
       int t0, t1, vt;
@@ -275,6 +279,51 @@ struct WaveIO {
       // e: the root entry of a symbol that is not a root-table literal (selected by the ten low bits, which were
       // valid; the second or third literal of a round may have left fewer than the 32 bits the slow path reads)
       if (cnt < 32) (void)bits();
+      if ((e & 0xC000) == 0x4000 && (e & 15) != 0) {
+        // ---- the common non-literal: a root-table length code (or the end of the block) ----
+        const int nb = (int)(e & 15);
+        const int ls = (int)((e >> 4) & 31) - 1;   // symbol - 257
+        if (ls < 0) {                              // 256: end of block
+          drop(nb);
+          return infl::OK;
+        }
+        if (ls <= 28) {
+          uint32_t b = (uint32_t)buf;
+          const uint32_t lt = (uint32_t)__builtin_amdgcn_readlane(len_tab, ls);
+          const int le = (int)(lt >> 16);
+          const int len = (int)(lt & 0xFFFFu) + (int)((b >> nb) & ((1u << le) - 1u));
+          drop(nb + le);
+          b = bits();
+          // distance: root table (256 entries) in four registers, entry i in lane i & 63 of register i >> 6
+          const int di = (int)(b & 255u);
+          const int dk = di >> 6;
+          const int dsel = dk == 0 ? dtab0 : (dk == 1 ? dtab1 : (dk == 2 ? dtab2 : dtab3));
+          const uint32_t de_ = (uint32_t)__builtin_amdgcn_readlane(dsel, di & 63);
+          if (!(de_ & 0x8000u) && (de_ & 15u) != 0) {
+            const int nbd = (int)(de_ & 15u);
+            const int ds = (int)((de_ >> 4) & 255u);
+            if (ds > 29) return infl::ERR_SYMBOL;
+            const uint32_t dtv = (uint32_t)__builtin_amdgcn_readlane(dist_tab, ds);
+            const int de = (int)(dtv >> 16);
+            const int dist = (int)(dtv & 0xFFFFu) + (int)((b >> nbd) & ((1u << de) - 1u));
+            drop(nbd + de);
+            const int rcm = match(len, dist);
+            if (rcm != infl::OK) return rcm;
+            continue;
+          }
+          // a distance code longer than the root index (or an invalid one): the generic decoder finishes the symbol
+          int nbd;
+          const int ds = infl::decode_sym<WaveIO>(dt, infl::D_ROOT, b, &nbd);
+          if (nbd == 0 || ds > 29) return infl::ERR_SYMBOL;
+          const int de = infl::dist_extra(ds);
+          const int dist = infl::dist_base(ds) + (int)((b >> nbd) & ((1u << de) - 1u));
+          drop(nbd + de);
+          if (overrun()) return infl::ERR_INPUT;
+          const int rcm = match(len, dist);
+          if (rcm != infl::OK) return rcm;
+          continue;
+        }
+      }
       const int rc = infl::slow_symbol(*this, ll, dt, (uint32_t)buf, e);
       if (rc == 1000) return infl::OK;
       if (rc != infl::OK) return rc;
@@ -289,7 +338,7 @@ struct GlobalBytes {
 
 }  // namespace
 
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void cpx_cptv_inflate_kernel(CptvInflateArgs a) {
+__global__ __launch_bounds__(64 * WAVES_PER_WG, 6) void cpx_cptv_inflate_kernel(CptvInflateArgs a) {
   __shared__ WaveLds s_lds[WAVES_PER_WG];
 #ifdef CPX_INFLATE_CLOCK_PROBE
   const unsigned long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
@@ -352,6 +401,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void cpx_cptv_inflate_kernel(Cpt
     io.lit = 0;
     io.nlit = 0;
     io.lds = &s_lds[rfl((int)(threadIdx.x >> 6))];
+    io.len_tab = lane < 29 ? (infl::length_base(lane) | (infl::length_extra(lane) << 16)) : 0;
+    io.dist_tab = lane < 30 ? (infl::dist_base(lane) | (infl::dist_extra(lane) << 16)) : 0;
     io.file_bytes = file;
     io.seek_byte(start);
     status = infl::inflate(io);

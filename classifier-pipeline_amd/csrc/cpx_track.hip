@@ -1414,7 +1414,11 @@ void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s) {
   // enough workgroups to fill the chip: whole frames per workgroup for big batches, bands of a frame for small
   // ones (a single clip is one frame per launch)
   const int nsub = NT_NLM / (a.W / 2);
+#ifdef CPX_NLM_BANDS   // experiment switch: bands per frame for big batches (scratch/build_variant.sh)
+  const int want = (B >= 384) ? CPX_NLM_BANDS : (512 + B - 1) / B;
+#else
   const int want = (B >= 384) ? 1 : (512 + B - 1) / B;  // bands per frame that would give ~2 workgroups per CU
+#endif
   const int rows = (a.H + want - 1) / want;              // rows per band for that
   if (rows > 5 * nsub) launch_nlm_t<10>(a, B, t, s);
   else if (rows > 2 * nsub) launch_nlm_t<5>(a, B, t, s);
