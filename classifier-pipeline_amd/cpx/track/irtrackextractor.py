@@ -184,6 +184,203 @@ class IRTrackExtractor(ClipTracker):
         self._tracking_time = time.time() - start
         return True
 
+    def parse_frames_batch(self, clips, videos, calc_stats=None):
+        """parse_frames for V videos as ONE device batch: the videos advance in lockstep through
+        the MOG2 model (cpx_mog2_apply, V streams), detect_objects_ir (cpx_ir_detect), the fragment merge and the
+        per-region variance of the frame difference (cpx_ir_merge) -- four launches per frame step for all videos, no
+        host synchronisation inside the walk -- and ONE association call (cpx_associate_batch with the IR tracking
+        parameters) follows the last step.  Host work afterwards, per clip: the Track / Region objects, the trap
+        geometry replayed over every track's history, the end-of-clip trim.
+        videos: uint8 arrays [T_v, H, W], or one uint8 device tensor [T, V, H, W] (all the same H x W; lengths may differ: a shorter video idles on its last
+        frame and those steps are not recorded).  Same tracks as parse_frames clip by clip
+        (tests/test_irtrack_gpu.py), with the region variances in float32 (the device's component record) instead of
+        float64."""
+        import ctypes as C
+
+        from .._lib import FRAME_INFO_DTYPE, CpxError
+        from ..engine import AssocBatchResult
+
+        start = time.time()
+        if len(videos) == 0:
+            return True
+        resident = hasattr(videos, "data_ptr")   # a uint8 device tensor [T, V, H, W]: frames already in HBM
+        if resident:
+            T, V, H, W = (int(x) for x in videos.shape)
+            lens = [T] * V
+        else:
+            V = len(videos)
+            H, W = (int(v) for v in np.asarray(videos[0]).shape[1:])
+            lens = [int(len(v)) for v in videos]
+            T = max(lens)
+        if len(clips) != V:
+            raise ValueError("one clip per video")
+        calc_stats = self.calc_stats if calc_stats is None else calc_stats
+        if self._engine is not None:
+            self._engine.close()
+        eng = self._engine = TrackEngine(width=160, height=120, device=self.device, max_components=256,
+                                         max_frames=max(T, 1024))
+        t, dev, lib, h = eng.torch, eng.device, eng.lib, eng.h
+        for clip in clips:
+            clip.type = self.type
+            clip.set_frame_buffer(False, self.cache_to_disk, False, False, max_frames=51)
+            clip.set_res(W, H)
+            clip.set_model("IR")
+            clip.set_video_stats(datetime.now())
+        self.res_x, self.res_y = H, W   # (sic, irtrackextractor.py:199-200)
+        if resident:
+            video = videos.contiguous()
+        else:
+            # frames resident as [T, V, H, W]: step t reads one contiguous [V, H, W] slab
+            host = np.zeros((T, V, H, W), np.uint8)
+            for v, vid in enumerate(videos):
+                a = np.ascontiguousarray(vid, dtype=np.uint8)
+                host[: lens[v], v] = a
+                host[lens[v]:, v] = a[-1]
+            video = t.from_numpy(host).to(dev)
+            del host
+        bg = MOG2Background(eng, W, H, n_streams=V, history=1000)
+        cap_det, cap = 4096, eng.cap
+        mask = t.empty((V, H, W), dtype=t.uint8, device=dev)
+        det = t.empty((V, cap_det, 8), dtype=t.int32, device=dev)
+        counts = t.zeros((T, V), dtype=t.int32, device=dev)
+        dstatus = t.zeros((T, V), dtype=t.int32, device=dev)
+        mstatus = t.zeros((T, V), dtype=t.int32, device=dev)
+        comps = t.zeros((V * T, cap, 8), dtype=t.int32, device=dev)
+        info = t.zeros((V * T, 20), dtype=t.int32, device=dev)
+        stats = None
+        if calc_stats:
+            stats = dict(mn=t.empty((T, V), dtype=t.uint8, device=dev), mx=t.empty((T, V), dtype=t.uint8, device=dev),
+                         sm=t.empty((T, V), dtype=t.int64, device=dev), md=t.empty((T, V), dtype=t.float64, device=dev),
+                         fs=t.empty((T, V), dtype=t.int64, device=dev))
+        p = lambda x: C.c_void_p(x.data_ptr())
+
+        def check(rc):
+            if rc != 0:
+                raise CpxError(rc, eng._err())
+
+        t.cuda.current_stream(dev).synchronize()
+        with t.cuda.stream(eng.torch_stream()):
+            check(lib.cpx_mog2_apply(bg._m, p(video[0]), 1.0, p(mask)))   # start_tracking: the first frame seeds the model
+            for q in range(T):
+                cur = video[q]
+                check(lib.cpx_mog2_apply(bg._m, p(cur), float(self.learning_rate), p(mask)))
+                if q == 0:   # clip.background is the model's image after the first frame (irtrackextractor.py:415-416)
+                    first_background = bg.background.clone()
+                check(lib.cpx_ir_detect(h, p(mask), V, W, H, 0, cap_det, p(det), p(counts[q]), p(dstatus[q]), None))
+                # get_delta_frame (irtrackextractor.py:638-659): the frame FRAMES_AGO back, frame 1 before that
+                prev_i = q - 1 if q < self.FRAMES_AGO else self.FRAMES_AGO
+                want = q - prev_i
+                prev = video[want] if (prev_i != q and want != q and 0 <= want < q and q - want <= self.FRAMES_AGO) else None
+                check(lib.cpx_ir_merge(h, p(det), p(counts[q]), V, cap_det, cap, p(cur), p(prev) if prev is not None else None,
+                                       W, H, q, T, p(comps), p(info), p(mstatus[q])))
+                if stats is not None:
+                    flat = cur.reshape(V, -1)
+                    stats["mn"][q], stats["mx"][q] = flat.min(dim=1).values, flat.max(dim=1).values
+                    stats["sm"][q] = flat.sum(dim=1, dtype=t.int64)
+                    # np.median of a uint8 frame: the mean of the two middle order statistics, from the histogram
+                    hist = t.zeros(V * 256, dtype=t.int64, device=dev)
+                    idx = (flat.to(t.int64) + (t.arange(V, device=dev, dtype=t.int64) * 256)[:, None]).reshape(-1)
+                    hist.scatter_add_(0, idx, t.ones_like(idx))
+                    cum = hist.view(V, 256).cumsum(dim=1)
+                    n_px = H * W
+                    lo = (cum < (n_px + 1) // 2).sum(dim=1)       # value of order statistic (n - 1) // 2
+                    hi = (cum < n_px // 2 + 1).sum(dim=1)         # ... of order statistic n // 2
+                    stats["md"][q] = (lo + hi).to(t.float64) / 2.0
+                    stats["fs"][q] = mask.reshape(V, -1).sum(dim=1, dtype=t.int64)
+            eng.synchronize()
+        bad = t.nonzero((dstatus != 0) | (mstatus != 0))
+        if bad.numel():
+            q, v = (int(x) for x in bad[0])
+            raise CpxError(-5, "video %d, frame %d: more components than the detection / merge capacity" % (v, q))
+        cfg = self.config
+        c0 = clips[0]
+        params = make_track_params(c0.res_x, c0.res_y, cfg.edge_pixels, cfg.frame_padding, self.min_dimension,
+                                   cfg.cropped_regions_strategy, cfg.filter_regions_pre_match, cfg.aoi_min_mass,
+                                   cfg.aoi_pixel_variance, cfg.params, c0.frames_per_second)
+        offs = (np.arange(V + 1, dtype=np.int64) * T).astype(np.int32)
+        meta = eng.make_meta(V * T)
+        for v in range(V):   # the steps a shorter video idled through are not frames of it
+            meta["background_frame"][v * T + lens[v]:(v + 1) * T] = 1
+
+        class _Res:  # what associate_batch reads of a track result
+            comps_dev, info_dev = comps.view(-1), info.view(-1)
+
+        assoc = eng.associate_batch(_Res, offs, meta, params=params, want_regions=True)
+        assoc.check()
+        if stats is not None:
+            st = {k: v.cpu().numpy() for k, v in stats.items()}
+        background = first_background.cpu().numpy()
+        P = H * W
+        for v, clip in enumerate(clips):
+            clip.set_background(background[v] if V > 1 else background)
+            for q in range(lens[v]):
+                sv = None
+                if stats is not None:
+                    sv = (st["mn"][q, v], st["mx"][q, v], np.float64(st["md"][q, v]), st["sm"][q, v] / P, int(st["fs"][q, v]))
+                clip.ffc_affected = False
+                clip.add_frame(None, None, None, False, stats=sv)
+            f0 = v * T
+            regions_per_frame = []
+            for q in range(lens[v]):
+                regs = []
+                for rec in assoc.frame_regions(f0 + q):
+                    r = Region.from_record(rec)
+                    r.centroid = [int(r.centroid[0]), int(r.centroid[1])]
+                    regs.append(r)
+                regions_per_frame.append(regs)
+            clip.region_history = regions_per_frame
+            tracks = []
+            for rec, regs in assoc.clip_tracks(v):
+                track = Track.from_device(clip, rec, regs, self.tracker_version, self.config)
+                for r in track.bounds_history:
+                    r.centroid = [int(r.centroid[0]), int(r.centroid[1])]
+                track._velocities_from_history()
+                track.direction, track.trap_reported = 0, False
+                tracks.append(track)
+            clip.tracks = tracks
+            self._replay_trap(clip)
+            last = clip.current_frame
+            clip.active_tracks = set(tr for tr in clip.tracks if tr.end_frame == last and self._active(tr.tracker.frames,
+                                                                                                   tr.frames_since_target_seen))
+            if not clip.from_metadata and self.do_tracking:
+                self.apply_track_filtering(clip)
+            if calc_stats:
+                clip.stats.completed()
+        bg.close()
+        self._tracking_time = (time.time() - start) / V
+        return True
+
+    @staticmethod
+    def _active(frames, since):
+        return since == 0 or since < min(2 * (frames - since), 18)
+
+    def _replay_trap(self, clip):
+        """The per-frame trap test of _process_frame (irtrackextractor.py:470-490) replayed over finished tracks: at
+        every frame a track was active, inside_trap_top on its bound of that frame and -- once the last two bounds are
+        inside -- filter_track on its statistics so far; the first frame that passes is the trigger frame."""
+        for track in clip.tracks:
+            full, vx, vy = track.bounds_history, track.vel_x, track.vel_y
+            rt = track.tracker
+            saved = (rt.frames, rt._blank_frames, rt._frames_since_target_seen, rt._last_bound)
+            since = blanks = 0
+            try:
+                for i, region in enumerate(full):
+                    since = since + 1 if region.blank else 0
+                    blanks += 1 if region.blank else 0
+                    if not self._active(i + 1, since) or track.trap_reported:
+                        continue
+                    track.bounds_history, track.vel_x, track.vel_y = full[: i + 1], vx[: i + 1], vy[: i + 1]
+                    rt.frames, rt._blank_frames, rt._frames_since_target_seen, rt._last_bound = i + 1, blanks, since, region
+                    self.inside_trap_top(track, self.scale)
+                    if track.in_trap and not self.filter_track(clip, track, track.get_stats()):
+                        track.trigger_frame = region.frame_number
+                        if self.on_trapped is not None:
+                            track.trap_reported = True
+                            self.on_trapped(track)
+            finally:
+                track.bounds_history, track.vel_x, track.vel_y = full, vx, vy
+                rt.frames, rt._blank_frames, rt._frames_since_target_seen, rt._last_bound = saved
+
     def start_tracking(self, clip, frames=None, track_frames=-1, background_alg=None, background_frame=None,
                        background_frames=1, retrack_back=True):
         """irtrackextractor.py:233-283."""

@@ -1401,6 +1401,25 @@ int cpx_ir_delta_variance(cpx_handle* h, const uint8_t* cur_dev, const uint8_t* 
   return CPX_OK;
 }
 
+int cpx_ir_merge(cpx_handle* h, const cpx_component* comps_dev, const int32_t* counts_dev, int n, int cap_in, int cap_out,
+                 const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height, int frame_number, int out_stride,
+                 cpx_component* out_comps_dev, cpx_frame_info* out_info_dev, int32_t* status_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!comps_dev || !counts_dev || !cur_dev || !out_comps_dev || !status_dev || n < 0 || cap_in < 1 || cap_out < 1 ||
+      cap_out > 1024 || width < 1 || height < 1 || frame_number < 0 || out_stride < 1 || frame_number >= out_stride)
+    return fail(h, CPX_ERR_INVALID, "cpx_ir_merge: bad argument");
+  if (n == 0) return CPX_OK;
+  CPX_ENTER(h);
+  cpx::IrMergeArgs a{};
+  a.W = width; a.H = height; a.n = n; a.cap_in = cap_in; a.cap_out = cap_out;
+  a.frame_number = frame_number; a.out_stride = out_stride;
+  a.comps = comps_dev; a.counts = counts_dev; a.cur = cur_dev; a.prev = prev_dev;
+  a.out_comps = out_comps_dev; a.out_info = out_info_dev; a.status = status_dev;
+  cpx::launch_ir_merge(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 // ---- IR background model ---------------------------------------------------------------------------------------------
 struct cpx_mog2 {
   cpx_handle* h = nullptr;

@@ -76,6 +76,7 @@ struct WaveIO {
     const long w = byte >> 2;
     wbase = w & ~63l;
     cur = load_chunk(wbase >> 6);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     widx = (int)(w & 63);
     buf = 0;
     cnt = 0;
@@ -96,6 +97,9 @@ struct WaveIO {
     wbase += 64;
     if (wbase * 32 > file_bits) lim = 0;
     cur = load_chunk(wbase >> 6);
+    // waited for HERE (vmcnt(0), expcnt / lgkmcnt untouched): the compiler then knows the register holds its value and
+    // does not put a wait -- for every outstanding store's acknowledgement -- in front of each later copy of it
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     widx = 0;
   }
   __device__ __forceinline__ uint32_t next_word() {

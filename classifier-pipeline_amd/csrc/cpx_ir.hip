@@ -421,6 +421,155 @@ __global__ __launch_bounds__(64) void cpx_ir_delta_var_kernel(IrVarArgs a) {
   }
 }
 
+// merge_components of the IR tracker (track/irtrackextractor.py:324-389) for one frame per workgroup, then the
+// variance of the frame difference over every merged box (the kernel above, per box) -- the two host steps between
+// cpx_ir_detect and the association when a batch of videos advances in lockstep.
+//   rows with area > 40 or (width > 16 and height > 16) survive, largest area first (stable);
+//   a row absorbs every other row whose ORIGINAL box is closer than 40 pixels to its original box (gap measured per
+//   axis, 0 where the extents overlap: dx^2 + dy^2 < 1600 -- the reference compares the square root with 40) or
+//   overlaps it on both axes -- except rows with the same x (the reference's self test also skips those); the merged
+//   box takes the union, its height measured from the already-updated top (as the reference computes it); the scan
+//   restarts from the first row after any merge.
+// Thread 0 does the merge (a few dozen rows: scalar work, kept off the host so that no synchronisation separates the
+// steps of a frame); every wave then takes boxes for the variance.
+__global__ __launch_bounds__(256) void cpx_ir_merge_kernel(IrMergeArgs a) {
+  extern __shared__ int s_rows[];          // [cap_out][5] original boxes | [cap_out][5] merged boxes
+  __shared__ int s_n, s_status;
+  const int v = blockIdx.x;
+  const int cap = a.cap_out;
+  int* anchor = s_rows;
+  int* box = s_rows + cap * 5;
+  const size_t row = (size_t)v * a.out_stride + a.frame_number;
+  if (threadIdx.x == 0) {
+    const cpx_component* in = a.comps + (size_t)v * a.cap_in;
+    const int nin = min(a.counts[v], a.cap_in);
+    int n = 0, status = 0;
+    for (int i = 0; i < nin; ++i) {
+      const cpx_component c = in[i];
+      if (!(c.area > 40 || (c.width > 16 && c.height > 16))) continue;
+      if (n >= cap) {
+        status = CPX_ERR_OVERFLOW;
+        break;
+      }
+      // insertion by area, descending, stable (sorted(..., key=area, reverse=True) keeps equal areas in input order)
+      int k = n;
+      while (k > 0 && anchor[(k - 1) * 5 + 4] < c.area) {
+        for (int j = 0; j < 5; ++j) anchor[k * 5 + j] = anchor[(k - 1) * 5 + j];
+        --k;
+      }
+      anchor[k * 5 + 0] = c.x;
+      anchor[k * 5 + 1] = c.y;
+      anchor[k * 5 + 2] = c.width;
+      anchor[k * 5 + 3] = c.height;
+      anchor[k * 5 + 4] = c.area;
+      ++n;
+    }
+    for (int i = 0; i < n * 5; ++i) box[i] = anchor[i];
+    int i = 0;
+    while (i < n) {
+      const int ax = anchor[i * 5], ay = anchor[i * 5 + 1], aw = anchor[i * 5 + 2], ah = anchor[i * 5 + 3];
+      bool absorbed = false;
+      int j = 0;
+      while (j < n) {
+        const int ox = anchor[j * 5], oy = anchor[j * 5 + 1], ow = anchor[j * 5 + 2], oh = anchor[j * 5 + 3];
+        if (ox == ax) {
+          ++j;
+          continue;
+        }
+        const bool over_x = ow + aw > max(ox + ow, ax + aw) - min(ox, ax);
+        const bool over_y = oh + ah > max(oy + oh, ay + ah) - min(oy, ay);
+        int dx = 0, dy = 0;
+        if (!over_x) dx = ax < ox ? (ax + aw) - ox : (ox + ow) - ax;
+        if (!over_y) dy = ay < oy ? (ay + ah) - oy : (oy + oh) - ay;
+        if (!((over_x && over_y) || dx * dx + dy * dy < 1600)) {
+          ++j;
+          continue;
+        }
+        int* b = box + i * 5;
+        const int right = b[0] + b[2];
+        b[0] = min(b[0], ox);
+        b[1] = min(b[1], oy);
+        const int bottom = max(b[1] + b[3], oy + oh);   // (with the top already updated, as the reference does)
+        b[2] = max(right, ox + ow) - b[0];
+        b[3] = bottom - b[1];
+        b[4] += anchor[j * 5 + 4];
+        absorbed = true;
+        for (int k = j; k + 1 < n; ++k)
+          for (int q = 0; q < 5; ++q) {
+            anchor[k * 5 + q] = anchor[(k + 1) * 5 + q];
+            box[k * 5 + q] = box[(k + 1) * 5 + q];
+          }
+        --n;
+        if (j < i) --i;   // the anchor moved down with the list
+      }
+      i = absorbed ? 0 : i + 1;
+    }
+    s_n = n;
+    s_status = status;
+  }
+  __syncthreads();
+  const int n = s_n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  cpx_component* out = a.out_comps + row * cap;
+  const unsigned char* cur = a.cur + (size_t)v * a.W * a.H;
+  const unsigned char* prev = a.prev ? a.prev + (size_t)v * a.W * a.H : nullptr;
+  for (int r = wave; r < n; r += 4) {
+    const int x0 = box[r * 5], y0 = box[r * 5 + 1], bw = box[r * 5 + 2], bh = box[r * 5 + 3], mass = box[r * 5 + 4];
+    double var = 0.0;
+    if (prev) {
+      const int x1 = min(x0 + bw, a.W), y1 = min(y0 + bh, a.H);
+      const int w = x1 - x0, hgt = y1 - y0;
+      unsigned long long s1 = 0, s2 = 0;
+      const bool ok = w > 0 && hgt > 0 && x0 >= 0 && y0 >= 0;
+      if (ok) {
+        const int cnt = w * hgt;
+        for (int k = lane; k < cnt; k += 64) {
+          const int yy = k / w, xx = k - yy * w;
+          const int p = (y0 + yy) * a.W + x0 + xx;
+          const unsigned d = ((unsigned)cur[p] - (unsigned)prev[p]) & 255u;
+          s1 += d;
+          s2 += (unsigned long long)d * d;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+      }
+      const long long cnt = ok ? (long long)w * hgt : 0;
+      var = cnt ? (double)((unsigned long long)cnt * s2 - s1 * s1) / ((double)cnt * (double)cnt) : NAN;
+    }
+    if (lane == 0) {
+      cpx_component c;
+      c.x = x0;
+      c.y = y0;
+      c.width = bw;
+      c.height = bh;
+      c.area = mass;
+      const int cx = (int)(x0 + bw / 2.0), cy = (int)(y0 + bh / 2.0);   // the IR tracker's centroid: box centre, truncated
+      c.sum_x = cx * mass;
+      c.sum_y = cy * mass;
+      c.pixel_variance = (float)var;
+      out[r] = c;
+    }
+  }
+  if (threadIdx.x == 0) {
+    a.status[v] = s_status;
+    if (a.out_info) {
+      cpx_frame_info fi;
+      memset(&fi, 0, sizeof(fi));
+      fi.frame_number = a.frame_number;
+      fi.n_components = n;
+      fi.status = s_status;
+      a.out_info[row] = fi;
+    }
+  }
+}
+
+void launch_ir_merge(const IrMergeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_ir_merge_kernel, dim3(a.n), dim3(256), (size_t)a.cap_out * 10 * sizeof(int), s, a);
+}
+
 void launch_ir_delta_variance(const IrVarArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(cpx_ir_delta_var_kernel, dim3(a.n), dim3(64), 0, s, a);
 }

@@ -278,6 +278,18 @@ struct IrVarArgs {
   double* out;                // [n]
 };
 void launch_ir_delta_variance(const IrVarArgs& a, hipStream_t s);
+struct IrMergeArgs {
+  int W, H, n, cap_in, cap_out;
+  int frame_number, out_stride;   // stream v's outputs go to row v * out_stride + frame_number
+  const cpx_component* comps;     // [n][cap_in] of cpx_ir_detect
+  const int* counts;              // [n]
+  const unsigned char* cur;       // [n][H][W]
+  const unsigned char* prev;      // [n][H][W] or null
+  cpx_component* out_comps;       // rows of cap_out
+  cpx_frame_info* out_info;       // rows (optional)
+  int* status;                    // [n]
+};
+void launch_ir_merge(const IrMergeArgs& a, hipStream_t s);
 int ir_supported(int W, int H);
 size_t ir_slot_bytes(int W, int H);
 

@@ -489,6 +489,21 @@ int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int wi
  * np.var(np.abs(frame.thermal - frame_ago.thermal)[region]) (track/irtrackextractor.py:638-655 get_delta_frame,
  * track/cliptracker.py:303-312).  Both frames are uint8, so the difference wraps modulo 256 as NumPy's does.
  * rects_dev int32 [n][4] = x, y, width, height (clipped to the image like a NumPy slice); var_dev double [n]. */
+/* The two steps between cpx_ir_detect and the association, on the device, for n videos advancing in lockstep:
+ * merge_components (track/irtrackextractor.py:324-389: fragments of one object merged into one box -- rows with area
+ * > 40 or both sides > 16 survive, largest first; a row absorbs rows closer than 40 pixels to, or overlapping, its
+ * original box; the scan restarts after a merge) and the variance of the frame difference over every merged box
+ * (cpx_ir_delta_variance).  comps_dev [n][cap_in] / counts_dev [n]: what cpx_ir_detect wrote for the n frames;
+ * cur_dev / prev_dev uint8 [n][height][width]: the frames and the frames they are compared with (prev_dev NULL: no
+ * comparison yet, variance 0).  Stream v's result goes to row v * out_stride + frame_number of out_comps_dev (rows of
+ * cap_out components: x, y, width, height, area = merged box and mass, sum_x / sum_y = the truncated box centre times
+ * the mass -- the IR tracker's centroid --, pixel_variance) and of out_info_dev (frame_number, n_components; optional):
+ * the clip-major layout cpx_associate_batch reads, so that one association call follows the last step.  status_dev [n]:
+ * CPX_ERR_OVERFLOW when more than cap_out rows survive the small-fragment filter. */
+int cpx_ir_merge(cpx_handle* h, const cpx_component* comps_dev, const int32_t* counts_dev, int n, int cap_in, int cap_out,
+                 const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height, int frame_number, int out_stride,
+                 cpx_component* out_comps_dev, cpx_frame_info* out_info_dev, int32_t* status_dev);
+
 int cpx_ir_delta_variance(cpx_handle* h, const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height,
                           const int32_t* rects_dev, int n, double* var_dev);
 

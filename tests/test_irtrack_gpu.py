@@ -154,3 +154,92 @@ def test_mixed_lepton35_and_ir_batch():
         assert sorted(len(t.bounds_history) for t in clip.tracks) == sorted(len(t.bounds) for t in tracks)
         ex.close()
     eng.close()
+
+
+def _ir_batch(videos, **kw):
+    from cpx.config import Config
+    from cpx.track.clip import Clip
+    from cpx.track.irtrackextractor import IRTrackExtractor
+
+    cfg = Config.get_defaults()
+    ex = IRTrackExtractor(cfg.tracking, **kw)
+    clips = []
+    for k in range(len(videos)):
+        clip = Clip(ex.config, "ir-%d.mp4" % k, type="IR")
+        clip.frames_per_second = 10
+        clips.append(clip)
+    assert ex.parse_frames_batch(clips, videos)
+    return ex, clips
+
+
+def test_ir_device_batch_matches_oracle_and_one_by_one():
+    """IRTrackExtractor.parse_frames_batch: V videos of different lengths in lockstep on the device (MOG2, detection,
+    cpx_ir_merge, one cpx_associate_batch) -- every clip's regions and tracks equal the oracle chain's and the
+    one-video-at-a-time path's, statistics included."""
+    from cpx.config import Config
+    from cpx.track.clip import Clip
+    from cpx.track.irtrackextractor import IRTrackExtractor
+
+    videos = [ir_video(3), ir_video(11, n=45), ir_video(21, n=30, blobs=1), ir_video(5, n=52, blobs=3)]
+    ex, clips = _ir_batch(videos)
+    cfg = Config.get_defaults()
+    for frames, clip in zip(videos, clips):
+        history, tracks = _oracle_ir_track(frames)
+        assert len(clip.region_history) == len(history) == frames.shape[0] == clip.current_frame + 1
+        for q, (got, want) in enumerate(zip(clip.region_history, history)):
+            assert [_rt(r) for r in got] == [_rt(r) for r in want], q
+            for a, b in zip(got, want):
+                # the device record carries the variance as float32
+                assert abs(float(a.pixel_variance) - float(b.pixel_variance)) <= 1e-6 * max(1.0, float(b.pixel_variance)), q
+                assert list(a.centroid) == list(b.centroid)
+        got_tracks = sorted(clip.tracks, key=lambda t: t.get_id())
+        want_tracks = sorted(tracks, key=lambda t: t.id)
+        assert [t.get_id() for t in got_tracks] == [t.id for t in want_tracks] and len(got_tracks) >= 1
+        for a, b in zip(got_tracks, want_tracks):
+            assert a.start_frame == b.start_frame
+            assert [_rt(r) for r in a.bounds_history] == [_rt(r) for r in b.bounds], a.get_id()
+        # against the per-video path: trap state and clip statistics too
+        solo_ex = IRTrackExtractor(cfg.tracking, max_frames=frames.shape[0] + 4)
+        solo = Clip(solo_ex.config, "solo.mp4", type="IR")
+        solo.frames_per_second = 10
+        solo_ex.parse_frames(solo, frames)
+        st = sorted(solo.tracks, key=lambda t: t.get_id())
+        assert [(t.get_id(), t.in_trap, t.trigger_frame, t.direction) for t in got_tracks] == \
+               [(t.get_id(), t.in_trap, t.trigger_frame, t.direction) for t in st]
+        assert [[r.in_trap for r in t.bounds_history] for t in got_tracks] == [[r.in_trap for r in t.bounds_history] for t in st]
+        assert np.array_equal(clip.background, solo.background)
+        for k in ("frame_stats_min", "frame_stats_max", "frame_stats_median", "frame_stats_mean"):
+            assert [float(v) for v in getattr(clip.stats, k)] == [float(v) for v in getattr(solo.stats, k)], k
+        assert float(clip.stats.filtered_sum) == float(solo.stats.filtered_sum)
+        assert clip.stats.mean_temp == solo.stats.mean_temp
+        solo_ex.close()
+    ex.close()
+
+
+def test_mixed_lepton35_and_ir_device_batches():
+    """BASELINE configs[4] with BOTH cameras as device batches: four lepton3.5 clips through cpx_track_batch and two IR
+    videos through parse_frames_batch on the same GPU, each result equal to its own single-camera run."""
+    from cpx import synth
+    from cpx.engine import TrackEngine
+
+    rng = np.random.default_rng(8)
+    T = 50
+    thermal = [synth.make_clip(rng, T, model="lepton3.5", max_blobs=3) for _ in range(4)]
+    ir = [ir_video(21, n=30, blobs=1), ir_video(22, n=30, blobs=2)]
+    eng = TrackEngine(model="lepton3.5", max_frames=T)
+    offs = (np.arange(5) * T).astype(np.int32)
+    meta = np.concatenate([eng.make_meta(T) for _ in range(4)])
+    dev = eng.upload_frames(np.concatenate(thermal))
+    res = eng.track_batch(dev, offs, meta, want_labels=True, want_filtered=True)   # enqueued; the IR batch runs meanwhile
+    ex, clips = _ir_batch(ir)
+    res.check()
+    labels = res.labels()
+    for b in range(4):
+        solo = eng.track_batch(eng.upload_frames(thermal[b]), np.array([0, T], np.int32), eng.make_meta(T), want_labels=True)
+        assert np.array_equal(solo.labels(), labels[b * T:(b + 1) * T])
+    for clip, frames in zip(clips, ir):
+        history, tracks = _oracle_ir_track(frames)
+        assert [[_rt(r) for r in g] for g in clip.region_history] == [[_rt(r) for r in w] for w in history]
+        assert sorted(len(t.bounds_history) for t in clip.tracks) == sorted(len(t.bounds) for t in tracks)
+    ex.close()
+    eng.close()
