@@ -123,7 +123,12 @@ EXPORTS = [
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
     "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index", "cpx_format_regions", "cpx_json_indent", "cpx_ir_merge",
+    "cpx_ir_frame_statistics",
 ]
+
+IR_FRAME_STATS_DTYPE = np.dtype([("min", "<i4"), ("max", "<i4"), ("sum", "<i8"), ("median_x2", "<i4"), ("reserved", "<i4"),
+                                 ("filtered_sum", "<i8")])
+assert IR_FRAME_STATS_DTYPE.itemsize == 32
 
 # flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
 TRACK_KEEP_BACKGROUND, TRACK_FREEZE_ON_FFC, TRACK_FREEZE_BACKGROUND = 1, 2, 4
@@ -202,6 +207,8 @@ def load():
     lib.cpx_ir_delta_variance.restype = C.c_int
     lib.cpx_ir_merge.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.cpx_ir_merge.restype = C.c_int
+    lib.cpx_ir_frame_statistics.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.cpx_ir_frame_statistics.restype = C.c_int
     lib.cpx_cnn_create.argtypes = [vp, C.POINTER(WRResNetParams), C.POINTER(vp)]
     lib.cpx_cnn_create.restype = C.c_int
     lib.cpx_cnn_destroy.argtypes = [vp]

@@ -197,7 +197,7 @@ class IRTrackExtractor(ClipTracker):
         float64."""
         import ctypes as C
 
-        from .._lib import FRAME_INFO_DTYPE, CpxError
+        from .._lib import IR_FRAME_STATS_DTYPE, CpxError
         from ..engine import AssocBatchResult
 
         start = time.time()
@@ -226,6 +226,7 @@ class IRTrackExtractor(ClipTracker):
             clip.set_res(W, H)
             clip.set_model("IR")
             clip.set_video_stats(datetime.now())
+            clip.calc_stats = bool(calc_stats)
         self.res_x, self.res_y = H, W   # (sic, irtrackextractor.py:199-200)
         if resident:
             video = videos.contiguous()
@@ -247,11 +248,10 @@ class IRTrackExtractor(ClipTracker):
         mstatus = t.zeros((T, V), dtype=t.int32, device=dev)
         comps = t.zeros((V * T, cap, 8), dtype=t.int32, device=dev)
         info = t.zeros((V * T, 20), dtype=t.int32, device=dev)
-        stats = None
-        if calc_stats:
-            stats = dict(mn=t.empty((T, V), dtype=t.uint8, device=dev), mx=t.empty((T, V), dtype=t.uint8, device=dev),
-                         sm=t.empty((T, V), dtype=t.int64, device=dev), md=t.empty((T, V), dtype=t.float64, device=dev),
-                         fs=t.empty((T, V), dtype=t.int64, device=dev))
+        stats = hist = None
+        if calc_stats:   # one 32-byte cpx_ir_frame_stats record per (step, video)
+            stats = t.empty((T, V, 32), dtype=t.uint8, device=dev)
+            hist = t.empty((V, 256), dtype=t.int32, device=dev)
         p = lambda x: C.c_void_p(x.data_ptr())
 
         def check(rc):
@@ -274,19 +274,7 @@ class IRTrackExtractor(ClipTracker):
                 check(lib.cpx_ir_merge(h, p(det), p(counts[q]), V, cap_det, cap, p(cur), p(prev) if prev is not None else None,
                                        W, H, q, T, p(comps), p(info), p(mstatus[q])))
                 if stats is not None:
-                    flat = cur.reshape(V, -1)
-                    stats["mn"][q], stats["mx"][q] = flat.min(dim=1).values, flat.max(dim=1).values
-                    stats["sm"][q] = flat.sum(dim=1, dtype=t.int64)
-                    # np.median of a uint8 frame: the mean of the two middle order statistics, from the histogram
-                    hist = t.zeros(V * 256, dtype=t.int64, device=dev)
-                    idx = (flat.to(t.int64) + (t.arange(V, device=dev, dtype=t.int64) * 256)[:, None]).reshape(-1)
-                    hist.scatter_add_(0, idx, t.ones_like(idx))
-                    cum = hist.view(V, 256).cumsum(dim=1)
-                    n_px = H * W
-                    lo = (cum < (n_px + 1) // 2).sum(dim=1)       # value of order statistic (n - 1) // 2
-                    hi = (cum < n_px // 2 + 1).sum(dim=1)         # ... of order statistic n // 2
-                    stats["md"][q] = (lo + hi).to(t.float64) / 2.0
-                    stats["fs"][q] = mask.reshape(V, -1).sum(dim=1, dtype=t.int64)
+                    check(lib.cpx_ir_frame_statistics(h, p(cur), p(mask), V, H * W, p(hist), p(stats[q])))
             eng.synchronize()
         bad = t.nonzero((dstatus != 0) | (mstatus != 0))
         if bad.numel():
@@ -308,7 +296,7 @@ class IRTrackExtractor(ClipTracker):
         assoc = eng.associate_batch(_Res, offs, meta, params=params, want_regions=True)
         assoc.check()
         if stats is not None:
-            st = {k: v.cpu().numpy() for k, v in stats.items()}
+            st = stats.cpu().numpy().view(IR_FRAME_STATS_DTYPE).reshape(T, V)
         background = first_background.cpu().numpy()
         P = H * W
         for v, clip in enumerate(clips):
@@ -316,7 +304,9 @@ class IRTrackExtractor(ClipTracker):
             for q in range(lens[v]):
                 sv = None
                 if stats is not None:
-                    sv = (st["mn"][q, v], st["mx"][q, v], np.float64(st["md"][q, v]), st["sm"][q, v] / P, int(st["fs"][q, v]))
+                    rec = st[q, v]
+                    sv = (np.uint8(rec["min"]), np.uint8(rec["max"]), np.float64(rec["median_x2"]) / 2.0, rec["sum"] / P,
+                          int(rec["filtered_sum"]))
                 clip.ffc_affected = False
                 clip.add_frame(None, None, None, False, stats=sv)
             f0 = v * T

@@ -1420,6 +1420,25 @@ int cpx_ir_merge(cpx_handle* h, const cpx_component* comps_dev, const int32_t* c
   return CPX_OK;
 }
 
+int cpx_ir_frame_statistics(cpx_handle* h, const uint8_t* frames_dev, const uint8_t* masks_dev, int n, int pixels,
+                            uint32_t* hist_dev, cpx_ir_frame_stats* out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !hist_dev || !out_dev || n < 0 || pixels < 1)
+    return fail(h, CPX_ERR_INVALID, "cpx_ir_frame_statistics: bad argument");
+  if (n == 0) return CPX_OK;
+  CPX_ENTER(h);
+  CPX_HIP(h, hipMemsetAsync(hist_dev, 0, (size_t)n * 256 * sizeof(uint32_t), h->stream));
+  CPX_HIP(h, hipMemsetAsync(out_dev, 0, (size_t)n * sizeof(cpx_ir_frame_stats), h->stream));
+  cpx::IrStatsArgs a{};
+  a.n = n; a.pixels = pixels;
+  a.vec16 = pixels % 16 == 0 && reinterpret_cast<uintptr_t>(frames_dev) % 16 == 0 &&
+            (!masks_dev || reinterpret_cast<uintptr_t>(masks_dev) % 16 == 0);
+  a.frames = frames_dev; a.masks = masks_dev; a.hist = hist_dev; a.out = out_dev;
+  cpx::launch_ir_frame_stats(a, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 // ---- IR background model ---------------------------------------------------------------------------------------------
 struct cpx_mog2 {
   cpx_handle* h = nullptr;

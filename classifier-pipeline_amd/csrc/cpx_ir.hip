@@ -570,6 +570,94 @@ void launch_ir_merge(const IrMergeArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(cpx_ir_merge_kernel, dim3(a.n), dim3(256), (size_t)a.cap_out * 10 * sizeof(int), s, a);
 }
 
+
+// ---- per-frame statistics of the IR clip (Clip.add_frame's min / max / median / mean of the frame and the sum of the
+// foreground image, track/clip.py:330-347) ------------------------------------------------------------------------------
+// Pass 1: blockIdx = (slice, frame); a block histograms its slice of the frame in LDS (one 256-bin table per wave) and
+// adds it to the frame's global histogram; the foreground bytes of the slice are summed on the way.
+constexpr int STAT_SPLIT = 16;
+__global__ __launch_bounds__(256) void cpx_ir_hist_kernel(IrStatsArgs a) {
+  __shared__ unsigned int hist[4][256];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  for (int i = tid; i < 4 * 256; i += 256) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  const int f = blockIdx.y;
+  const size_t P = (size_t)a.pixels;
+  const unsigned char* fr = a.frames + (size_t)f * P;
+  const unsigned char* mk = a.masks ? a.masks + (size_t)f * P : nullptr;
+  unsigned long long msum = 0;
+  if (a.vec16) {
+    const size_t nv = P / 16, per = (nv + STAT_SPLIT - 1) / STAT_SPLIT;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < nv ? lo + per : nv;
+    const uint4* fv = reinterpret_cast<const uint4*>(fr);
+    const uint4* mv = reinterpret_cast<const uint4*>(mk);
+    for (size_t i = lo + tid; i < hi; i += 256) {
+      const uint4 q = fv[i];
+      const unsigned int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(&hist[wave][w[k] & 255u], 1u);
+        atomicAdd(&hist[wave][(w[k] >> 8) & 255u], 1u);
+        atomicAdd(&hist[wave][(w[k] >> 16) & 255u], 1u);
+        atomicAdd(&hist[wave][w[k] >> 24], 1u);
+      }
+      if (mk) {
+        const uint4 m = mv[i];
+        const unsigned int u[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) msum += (u[k] & 255u) + ((u[k] >> 8) & 255u) + ((u[k] >> 16) & 255u) + (u[k] >> 24);
+      }
+    }
+  } else {
+    const size_t per = (P + STAT_SPLIT - 1) / STAT_SPLIT;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < P ? lo + per : P;
+    for (size_t i = lo + tid; i < hi; i += 256) {
+      atomicAdd(&hist[wave][fr[i]], 1u);
+      if (mk) msum += mk[i];
+    }
+  }
+  __syncthreads();
+  const unsigned int c = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
+  if (c) atomicAdd(&a.hist[(size_t)f * 256 + tid], c);
+  if (mk) {
+    for (int off = 32; off > 0; off >>= 1) msum += __shfl_down(msum, off, 64);
+    if ((tid & 63) == 0 && msum) atomicAdd(reinterpret_cast<unsigned long long*>(&a.out[f].filtered_sum), msum);
+  }
+}
+
+// Pass 2: one block per frame reads the 256 bins: minimum / maximum = the first / last occupied bin, sum = sum of
+// bin * count, median (np.median of an even or odd count) = the mean of order statistics (P - 1) / 2 and P / 2.
+__global__ __launch_bounds__(256) void cpx_ir_stats_kernel(IrStatsArgs a) {
+  __shared__ unsigned int cum[256];
+  __shared__ int mn, mx, below_lo, below_hi;
+  __shared__ unsigned long long total;
+  const int tid = threadIdx.x, f = blockIdx.x;
+  const unsigned int c = a.hist[(size_t)f * 256 + tid];
+  if (tid == 0) { mn = 255; mx = 0; below_lo = 0; below_hi = 0; total = 0; }
+  cum[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {   // inclusive scan
+    const unsigned int add = tid >= off ? cum[tid - off] : 0u;
+    __syncthreads();
+    cum[tid] += add;
+    __syncthreads();
+  }
+  const unsigned long long P = (unsigned long long)a.pixels;
+  if (c) { atomicMin(&mn, tid); atomicMax(&mx, tid); atomicAdd(&total, (unsigned long long)c * (unsigned)tid); }
+  if ((unsigned long long)cum[tid] < (P + 1) / 2) atomicAdd(&below_lo, 1);
+  if ((unsigned long long)cum[tid] < P / 2 + 1) atomicAdd(&below_hi, 1);
+  __syncthreads();
+  if (tid == 0) {
+    cpx_ir_frame_stats& o = a.out[f];
+    o.min = mn; o.max = mx; o.sum = (long long)total; o.median_x2 = below_lo + below_hi; o.reserved = 0;
+  }
+}
+
+void launch_ir_frame_stats(const IrStatsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_ir_hist_kernel, dim3(STAT_SPLIT, a.n), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(cpx_ir_stats_kernel, dim3(a.n), dim3(256), 0, s, a);
+}
+
 void launch_ir_delta_variance(const IrVarArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(cpx_ir_delta_var_kernel, dim3(a.n), dim3(64), 0, s, a);
 }

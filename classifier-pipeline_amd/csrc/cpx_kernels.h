@@ -290,6 +290,14 @@ struct IrMergeArgs {
   int* status;                    // [n]
 };
 void launch_ir_merge(const IrMergeArgs& a, hipStream_t s);
+struct IrStatsArgs {
+  int n, pixels, vec16;
+  const unsigned char* frames;   // [n][pixels]
+  const unsigned char* masks;    // [n][pixels] or null
+  unsigned int* hist;            // [n][256], zero on entry
+  cpx_ir_frame_stats* out;       // [n], filtered_sum zero on entry
+};
+void launch_ir_frame_stats(const IrStatsArgs& a, hipStream_t s);
 int ir_supported(int W, int H);
 size_t ir_slot_bytes(int W, int H);
 

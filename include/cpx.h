@@ -485,10 +485,6 @@ int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int wi
                   int max_components, cpx_component* comps_dev, int32_t* counts_dev, int32_t* status_dev,
                   int32_t* labels_dev);
 
-/* Per-region variance of the frame-to-frame change the IR tracker gates regions with: replaces
- * np.var(np.abs(frame.thermal - frame_ago.thermal)[region]) (track/irtrackextractor.py:638-655 get_delta_frame,
- * track/cliptracker.py:303-312).  Both frames are uint8, so the difference wraps modulo 256 as NumPy's does.
- * rects_dev int32 [n][4] = x, y, width, height (clipped to the image like a NumPy slice); var_dev double [n]. */
 /* The two steps between cpx_ir_detect and the association, on the device, for n videos advancing in lockstep:
  * merge_components (track/irtrackextractor.py:324-389: fragments of one object merged into one box -- rows with area
  * > 40 or both sides > 16 survive, largest first; a row absorbs rows closer than 40 pixels to, or overlapping, its
@@ -504,8 +500,26 @@ int cpx_ir_merge(cpx_handle* h, const cpx_component* comps_dev, const int32_t* c
                  const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height, int frame_number, int out_stride,
                  cpx_component* out_comps_dev, cpx_frame_info* out_info_dev, int32_t* status_dev);
 
+/* Per-region variance of the frame-to-frame change the IR tracker gates regions with: replaces
+ * np.var(np.abs(frame.thermal - frame_ago.thermal)[region]) (track/irtrackextractor.py:638-655 get_delta_frame,
+ * track/cliptracker.py:303-312).  Both frames are uint8, so the difference wraps modulo 256 as NumPy's does.
+ * rects_dev int32 [n][4] = x, y, width, height (clipped to the image like a NumPy slice); var_dev double [n]. */
 int cpx_ir_delta_variance(cpx_handle* h, const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height,
                           const int32_t* rects_dev, int n, double* var_dev);
+
+/* Per-frame statistics of an IR clip, for n uint8 frames of `pixels` pixels resident in HBM: what Clip.add_frame
+ * (track/clip.py:330-347: np.min / np.max / np.median / np.nanmean of the frame, np.sum(np.abs(filtered))) computes on
+ * the host.  median_x2 = twice np.median (the mean of the two middle order statistics of an even count);
+ * mean = sum / pixels on the caller's side; filtered_sum = the sum of masks_dev's bytes (0 when masks_dev is NULL).
+ * hist_dev: uint32 scratch [n][256] (the 256-bin histograms the statistics come from; zeroed by the call). */
+typedef struct cpx_ir_frame_stats {
+  int32_t min, max;
+  int64_t sum;
+  int32_t median_x2, reserved;
+  int64_t filtered_sum;
+} cpx_ir_frame_stats; /* 32 bytes */
+int cpx_ir_frame_statistics(cpx_handle* h, const uint8_t* frames_dev, const uint8_t* masks_dev, int n, int pixels,
+                            uint32_t* hist_dev, cpx_ir_frame_stats* out_dev);
 
 /* ---- IR background model ---------------------------------------------------------------
  * Replaces CVBackground (track/cliptracker.py:561-613): cv2.createBackgroundSubtractorMOG2(history, varThreshold,

@@ -196,3 +196,38 @@ def test_mog2_streams_and_detection_chain(engine):
         merged = irdetect.merge_components(res[s][2][1:].copy())
         assert [[int(v) for v in r] for r in merged] == [[int(v) for v in r] for r in iro.merge_components(stats_o[1:].copy())]
     dev.close()
+
+
+@pytest.mark.parametrize("shape,with_mask", [((5, 480, 640), True), ((3, 37, 53), True), ((4, 120, 160), False), ((2, 1, 1), True)])
+def test_ir_frame_statistics_match_numpy(engine, shape, with_mask):
+    """cpx_ir_frame_statistics == np.min / np.max / np.median / np.nanmean of every frame and np.sum(|filtered|)
+    (Clip.add_frame, track/clip.py:330-347): bit-exact, odd and even pixel counts, vector and byte paths."""
+    import ctypes as C
+
+    import torch
+
+    from cpx._lib import IR_FRAME_STATS_DTYPE
+
+    rng = np.random.default_rng(sum(shape))
+    n = shape[0]
+    frames = rng.integers(0, 256, shape, dtype=np.uint8)
+    frames[0] = rng.integers(90, 93, shape[1:], dtype=np.uint8)        # a narrow histogram: the median sits between bins
+    if n > 1:
+        frames[1] = 255
+    masks = (rng.random(shape) < 0.1).astype(np.uint8) * 255
+    fd, md = torch.from_numpy(frames).to(engine.device), torch.from_numpy(masks).to(engine.device)
+    hist = torch.empty((n, 256), dtype=torch.int32, device=engine.device)
+    out = torch.full((n, 32), 7, dtype=torch.uint8, device=engine.device)
+    torch.cuda.synchronize()
+    rc = engine.lib.cpx_ir_frame_statistics(engine.h, C.c_void_p(fd.data_ptr()), C.c_void_p(md.data_ptr()) if with_mask else None,
+                                            n, int(np.prod(shape[1:])), C.c_void_p(hist.data_ptr()), C.c_void_p(out.data_ptr()))
+    assert rc == 0, engine._err()
+    engine.synchronize()
+    got = out.cpu().numpy().view(IR_FRAME_STATS_DTYPE).reshape(n)
+    for i in range(n):
+        assert got["min"][i] == frames[i].min() and got["max"][i] == frames[i].max()
+        assert got["sum"][i] == int(frames[i].sum(dtype=np.int64))
+        assert got["median_x2"][i] / 2.0 == float(np.median(frames[i]))
+        assert got["sum"][i] / frames[i].size == np.nanmean(frames[i])
+        assert got["filtered_sum"][i] == (int(masks[i].sum(dtype=np.int64)) if with_mask else 0)
+    assert np.array_equal(hist.cpu().numpy(), np.stack([np.bincount(f.ravel(), minlength=256) for f in frames]))
