@@ -400,7 +400,7 @@ def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
 
 def bench_from_files(args, torch, np, local_rank, weights, T):
     """The file-fed form of the headline path: `--from-files` synthetic recordings as CPTV byte
-    strings in host memory (16 distinct clips of T frames, gzip level 1, replicated) -> cpx.track.bulk.run_files_bulk
+    strings in host memory (32 distinct clips of the headline's generator, T frames, gzip level 6, replicated) -> cpx.track.bulk.run_files_bulk
     with a ClipClassifier: upload, gzip inflate + section index + frame decode on the device, track, segments,
     crop/tile + network, thumbnails, metadata JSON text per recording.  One warm-up pass, then a timed one."""
     import tempfile
@@ -422,11 +422,16 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
     cfg.classify.models = [ModelConfig.load({"id": 1, "name": "wr-bench", "model_file": os.path.join(tmp, "wr.npz")})]
     cfg.classify.meta_to_stdout = False
     t0 = time.perf_counter()
-    rng = np.random.default_rng(4321)
     t_on, ffc = synth.frame_times(T)
     # gzip level 6 = zlib's default, what the fixture recordings' headers say their writer used (XFL 0); level 1 finds
     # three times as many (short) matches in sensor noise, and a match is the decoder's expensive symbol
-    distinct = [encode_cptv(synth.make_clip(rng, T), t_on, ffc, level=6) for _ in range(16)]
+    # the headline's own clips (synth_on_device: the same generator, so the same tracks and segments per frame as
+    # `value` above), written out as recordings
+    n_distinct = 32
+    device = torch.device("cuda", local_rank)
+    clips_host = synth_on_device(torch, device, n_distinct, T, seed=4321).cpu().numpy().view(np.uint16).reshape(n_distinct, T, 120, 160)
+    distinct = [encode_cptv(clips_host[i], t_on, ffc, level=6) for i in range(n_distinct)]
+    del clips_host
     encode_s = time.perf_counter() - t0
     n = args.from_files
     batch = 2048   # recordings per decode launch (tracked in groups of 1024)
@@ -461,10 +466,10 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
     out, tm, dt = measure(blobs, names)
     n_tracks = sum(text.count('"tracking_score"') for text in out.values())
     n_pred = sum(text.count('"all_class_confidences"') for text in out.values())
-    return {"what": "%d synthetic recordings (%d frames each, 16 distinct, gzip level 6, %.2f MB per file) as byte strings "
+    return {"what": "%d synthetic recordings (%d frames each: %d distinct clips of the headline's generator, gzip level 6, %.2f MB per file) as byte strings "
                     "in host memory -> upload -> inflate + index + decode on the device -> track -> segments -> "
                     "crop/tile + WR-ResNet -> thumbnails -> metadata JSON text per recording; decode launches of %d recordings, tracking groups of 1024"
-                    % (n, T, len(distinct[0]) / 1e6, batch),
+                    % (n, T, n_distinct, len(distinct[0]) / 1e6, batch),
             "fixture_recordings": fixtures,
             "files": n, "frames": int(tm["frames"]), "seconds": round(dt, 3),
             "frames_per_s": round(tm["frames"] / dt, 1), "files_per_s": round(n / dt, 1),
@@ -476,7 +481,8 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
                         "main_thread_waiting_for_decode": round(tm.get("wait_decode_s", 0.0), 3),
                         "track_classify_thumbnails_device": round(tm["device_s"], 3),
                         "metadata_host": round(tm["host_s"], 3), "collect": round(tm["write_s"], 3)},
-            "encode_synthetic_files_s": round(encode_s, 2), "denoise": False}
+            "encode_synthetic_files_s": round(encode_s, 2), "denoise": False,
+            **({"device_split_s": {k: round(v, 3) for k, v in tm["device_split_s"].items()}} if "device_split_s" in tm else {})}
 
 
 def config4_lengths(n_clips, seed=1234, lo=90, hi=540):

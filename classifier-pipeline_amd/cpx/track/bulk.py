@@ -465,26 +465,28 @@ class BulkTracker:
             else:
                 search.append(b)
         if search:
-            xy = t.zeros((len(search), 2), dtype=t.int32, device=dev)
-            eng.sync_inputs()
             P = eng.width * eng.height
-            for k, b in enumerate(search):
+            pairs, rows = [], []
+            for b in search:
                 pf = proc_idx[b]
                 if len(pf) == 0:
                     out[b] = ("none", None)
                     continue
-                means = info["thermal_sum"][pf] / P
-                q = int(np.argmax(means))
-                rc = eng.lib.cpx_trackless_thumb(eng.h, C.c_void_p(group.frames_dev.data_ptr()), int(pf[q]), int(offs[b]),
-                                                 C.c_void_p(xy[k].data_ptr()))
+                q = int(np.argmax(info["thermal_sum"][pf] / P))
+                pairs.append((int(pf[q]), int(offs[b])))
+                rows.append((b, q))
+            if pairs:   # one launch: a workgroup per recording
+                pairs_dev = t.from_numpy(np.asarray(pairs, np.int32)).to(dev)
+                xy = t.zeros((len(pairs), 2), dtype=t.int32, device=dev)
+                eng.sync_inputs()
+                rc = eng.lib.cpx_trackless_thumb_batch(eng.h, C.c_void_p(group.frames_dev.data_ptr()),
+                                                       C.c_void_p(pairs_dev.data_ptr()), len(pairs), C.c_void_p(xy.data_ptr()))
                 if rc != 0:
                     raise CpxError(rc, eng._err())
-                out[b] = ("window", q)
-            eng.synchronize()
-            xy_h = xy.cpu().numpy()
-            for k, b in enumerate(search):
-                if out[b][0] == "window":
-                    out[b] = ("window", (out[b][1], int(xy_h[k, 0]), int(xy_h[k, 1])))
+                eng.synchronize()
+                xy_h = xy.cpu().numpy()
+                for k, (b, q) in enumerate(rows):
+                    out[b] = ("window", (q, int(xy_h[k, 0]), int(xy_h[k, 1])))
         return out
 
     # ---- host: metadata ---------------------------------------------------------------------------------------

@@ -1188,6 +1188,26 @@ int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, in
   return CPX_OK;
 }
 
+int cpx_trackless_thumb_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* pairs_dev, int n, int32_t* out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!frames_dev || !pairs_dev || !out_dev || n < 0)
+    return fail(h, CPX_ERR_INVALID, "cpx_trackless_thumb_batch: bad argument");
+  if (n == 0) return CPX_OK;
+  CPX_ENTER(h);
+  cpx::TracklessArgs a{};
+  a.W = h->cfg.width;
+  a.H = h->cfg.height;
+  a.frames = frames_dev;
+  a.out = out_dev;
+  a.pairs = pairs_dev;
+  a.n = n;
+  const int rc = cpx::launch_trackless(a, h->stream);
+  if (rc == -2) return fail(h, CPX_ERR_UNSUPPORTED, "cpx_trackless_thumb_batch: resolution outside the kernel's envelope");
+  if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_trackless_thumb_batch: kernel configuration failed");
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 // ---- whole-network forward ------------------------------------------------------------------------------------------
 struct cpx_cnn {
   cpx_handle* h = nullptr;

@@ -218,7 +218,11 @@ struct WaveIO {
     v16i tab;
 #pragma unroll
     for (int k = 0; k < 16; ++k) tab[k] = (int)ll[k * 64 + lane];
-    const int dtab0 = (int)dt[lane], dtab1 = (int)dt[64 + lane], dtab2 = (int)dt[128 + lane], dtab3 = (int)dt[192 + lane];
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i dtab;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dtab[k] = (int)dt[k * 64 + lane];
+    const int dtab0 = dtab[0], dtab1 = dtab[1], dtab2 = dtab[2], dtab3 = dtab[3];
     for (;;) {
       uint32_t e = 0xFFFF;
       int t0, t1, vt;
@@ -245,6 +249,18 @@ struct WaveIO {
   "v_writelane_b32 %[lit], %[e], m0\n\t"                  \
   "s_add_u32 %[nlit], %[nlit], 1\n\t"
       int swidx = rfl(widx);
+      // the output position / limit as 32-bit scalars for the loop (a file whose output could pass 2 GiB gets lim32 = 0:
+      // every store and match of the loop then declines and the C++ path below does them)
+      int snf = rfl((int)(uint32_t)n_flushed);
+      const int lim32 = rfl(lim < 0x7FFFFFFFl ? (int)lim : 0);
+      const int out_lo = rfl((int)(uint32_t)(uintptr_t)out), out_hi = rfl((int)(uint32_t)((uintptr_t)out >> 32));
+      int t2, t3, vb;
+      // A match whose length AND distance codes are root-table leaves, of at most 64 bytes, with its source before the
+      // pending literals (dist >= len + nlit) stays in the loop as well -- about 60 scalar instructions against some 180
+      // through the compiler's form of match() and the loop's exit / re-entry: the length code is decoded on a COPY of
+      // the bit state (saved in s[96:97], s98, s99) so that any other shape restores it and leaves with the entry, as
+      // before.  The copy: source load first, the pending literals' store in its shadow, then the match's store
+      // (vmcnt counts in order).  A run of 62+ pending literals is stored here too.
       asm volatile(
           "1:\n\t"
           "s_cmp_gt_i32 %[cnt], 31\n\t"
@@ -260,16 +276,154 @@ struct WaveIO {
           "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
           "4:\n\t"
           "s_cmp_gt_u32 %[nlit], 61\n\t"
-          "s_cbranch_scc1 3f\n\t"
+          "s_cbranch_scc1 5f\n\t"
+          "6:\n\t"
           CPX_INFL_LITERAL CPX_INFL_LITERAL CPX_INFL_LITERAL
           "s_branch 1b\n\t"
+          // ---- 62+ literals pending: store the run ----
+          "5:\n\t"
+          "s_add_u32 %[t0], %[nf], %[nlit]\n\t"
+          "s_cmp_gt_u32 %[t0], %[lim]\n\t"
+          "s_cbranch_scc1 3f\n\t"
+          "s_add_u32 s92, %[outlo], %[nf]\n\t"
+          "s_addc_u32 s93, %[outhi], 0\n\t"
+          "v_cmp_gt_u32 vcc, %[nlit], %[vlane]\n\t"
+          "s_and_saveexec_b64 s[94:95], vcc\n\t"
+          "v_lshrrev_b32 %[vt], 4, %[lit]\n\t"
+          "global_store_byte %[vlane], %[vt], s[92:93]\n\t"
+          "s_mov_b64 exec, s[94:95]\n\t"
+          "s_mov_b32 %[nf], %[t0]\n\t"
+          "s_mov_b32 %[nlit], 0\n\t"
+          "s_branch 6b\n\t"
+          // ---- e = a root entry that is no literal ----
+          "2:\n\t"
+          "s_cmp_gt_i32 %[cnt], 31\n\t"
+          "s_cbranch_scc1 7f\n\t"
+          "s_cmp_eq_u32 %[widx], 64\n\t"
+          "s_cbranch_scc1 9f\n\t"
+          "v_readlane_b32 s92, %[cur], %[widx]\n\t"
+          "s_mov_b32 s93, 0\n\t"
+          "s_add_u32 %[widx], %[widx], 1\n\t"
+          "s_lshl_b64 s[92:93], s[92:93], %[cnt]\n\t"
+          "s_add_u32 %[cnt], %[cnt], 32\n\t"
+          "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
+          "7:\n\t"
+          "s_and_b32 %[t0], %[e], 0xc000\n\t"
+          "s_cmp_lg_u32 %[t0], 0x4000\n\t"
+          "s_cbranch_scc1 9f\n\t"                       // a pointer to a second-level table
+          "s_bfe_u32 %[t1], %[e], 0x50004\n\t"          // symbol - 256
+          "s_sub_u32 %[t1], %[t1], 1\n\t"               // length symbol - 257 (end of block, invalid: wraps)
+          "s_cmp_gt_u32 %[t1], 28\n\t"
+          "s_cbranch_scc1 9f\n\t"
+          "s_cmp_eq_u32 %[widx], 64\n\t"                // the distance may need one more dword
+          "s_cbranch_scc1 9f\n\t"
+          "s_mov_b64 s[96:97], s[90:91]\n\t"
+          "s_mov_b32 s98, %[cnt]\n\t"
+          "s_mov_b32 s99, %[widx]\n\t"
+          "s_and_b32 %[t0], %[e], 15\n\t"
+          "v_readlane_b32 %[t2], %[lentab], %[t1]\n\t"  // base | extra bits << 16
+          "s_lshr_b64 s[90:91], s[90:91], %[t0]\n\t"
+          "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"
+          "s_lshr_b32 %[t0], %[t2], 16\n\t"
+          "s_and_b32 %[t2], %[t2], 0xffff\n\t"
+          "s_bfm_b32 %[t3], %[t0], 0\n\t"
+          "s_and_b32 %[t3], %[t3], s90\n\t"
+          "s_add_u32 %[t2], %[t2], %[t3]\n\t"           // t2 = length
+          "s_lshr_b64 s[90:91], s[90:91], %[t0]\n\t"
+          "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"
+          "s_cmp_gt_i32 %[cnt], 31\n\t"
+          "s_cbranch_scc1 10f\n\t"
+          "v_readlane_b32 s92, %[cur], %[widx]\n\t"
+          "s_mov_b32 s93, 0\n\t"
+          "s_add_u32 %[widx], %[widx], 1\n\t"
+          "s_lshl_b64 s[92:93], s[92:93], %[cnt]\n\t"
+          "s_add_u32 %[cnt], %[cnt], 32\n\t"
+          "s_or_b64 s[90:91], s[90:91], s[92:93]\n\t"
+          "10:\n\t"
+          "s_and_b32 %[t0], s90, 0xff\n\t"              // distance: root table (256 entries) in v[56:59]
+          "s_lshr_b32 %[t1], %[t0], 6\n\t"
+          "s_set_gpr_idx_on %[t1], 0x1\n\t"
+          "v_mov_b32 %[vt], v56\n\t"
+          "s_set_gpr_idx_off\n\t"
+          "v_readlane_b32 %[t3], %[vt], %[t0]\n\t"
+          "s_bitcmp1_b32 %[t3], 15\n\t"
+          "s_cbranch_scc1 8f\n\t"                       // second-level distance code
+          "s_and_b32 %[t0], %[t3], 15\n\t"
+          "s_cmp_eq_u32 %[t0], 0\n\t"
+          "s_cbranch_scc1 8f\n\t"                       // invalid code
+          "s_bfe_u32 %[t1], %[t3], 0x80004\n\t"         // distance symbol
+          "s_cmp_gt_u32 %[t1], 29\n\t"
+          "s_cbranch_scc1 8f\n\t"
+          "v_readlane_b32 %[t3], %[disttab], %[t1]\n\t"
+          "s_lshr_b64 s[90:91], s[90:91], %[t0]\n\t"
+          "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"
+          "s_lshr_b32 %[t0], %[t3], 16\n\t"
+          "s_and_b32 %[t3], %[t3], 0xffff\n\t"
+          "s_bfm_b32 %[t1], %[t0], 0\n\t"
+          "s_and_b32 %[t1], %[t1], s90\n\t"
+          "s_add_u32 %[t3], %[t3], %[t1]\n\t"           // t3 = distance
+          "s_lshr_b64 s[90:91], s[90:91], %[t0]\n\t"
+          "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"
+          // the copy's shape: len <= 64, dist <= at, dist >= len + nlit, at + len <= limit
+          "s_cmp_gt_u32 %[t2], 64\n\t"
+          "s_cbranch_scc1 8f\n\t"
+          "s_add_u32 %[t0], %[nf], %[nlit]\n\t"         // t0 = at
+          "s_cmp_gt_u32 %[t3], %[t0]\n\t"
+          "s_cbranch_scc1 8f\n\t"
+          "s_add_u32 %[t1], %[t2], %[nlit]\n\t"
+          "s_cmp_lt_u32 %[t3], %[t1]\n\t"
+          "s_cbranch_scc1 8f\n\t"
+          "s_add_u32 %[t1], %[t0], %[t2]\n\t"           // t1 = at + len
+          "s_cmp_gt_u32 %[t1], %[lim]\n\t"
+          "s_cbranch_scc1 8f\n\t"
+          "s_sub_u32 %[t3], %[t0], %[t3]\n\t"
+          "s_add_u32 s92, %[outlo], %[t3]\n\t"
+          "s_addc_u32 s93, %[outhi], 0\n\t"
+          "v_cmp_gt_u32 vcc, %[t2], %[vlane]\n\t"
+          "s_and_saveexec_b64 s[94:95], vcc\n\t"
+          "global_load_ubyte %[vb], %[vlane], s[92:93]\n\t"
+          "s_mov_b64 exec, s[94:95]\n\t"
+          "s_add_u32 s96, %[outlo], %[t0]\n\t"
+          "s_addc_u32 s97, %[outhi], 0\n\t"
+          "s_cmp_eq_u32 %[nlit], 0\n\t"
+          "s_cbranch_scc1 11f\n\t"
+          "s_add_u32 s92, %[outlo], %[nf]\n\t"
+          "s_addc_u32 s93, %[outhi], 0\n\t"
+          "v_cmp_gt_u32 vcc, %[nlit], %[vlane]\n\t"
+          "s_and_saveexec_b64 s[94:95], vcc\n\t"
+          "v_lshrrev_b32 %[vt], 4, %[lit]\n\t"
+          "global_store_byte %[vlane], %[vt], s[92:93]\n\t"
+          "s_mov_b64 exec, s[94:95]\n\t"
+          "v_cmp_gt_u32 vcc, %[t2], %[vlane]\n\t"
+          "s_and_saveexec_b64 s[94:95], vcc\n\t"
+          "s_waitcnt vmcnt(1)\n\t"
+          "s_branch 12f\n\t"
+          "11:\n\t"
+          "v_cmp_gt_u32 vcc, %[t2], %[vlane]\n\t"
+          "s_and_saveexec_b64 s[94:95], vcc\n\t"
+          "s_waitcnt vmcnt(0)\n\t"
+          "12:\n\t"
+          "global_store_byte %[vlane], %[vb], s[96:97]\n\t"
+          "s_mov_b64 exec, s[94:95]\n\t"
+          "s_mov_b32 %[nf], %[t1]\n\t"
+          "s_mov_b32 %[nlit], 0\n\t"
+          "s_branch 1b\n\t"
+          // any other shape: the bit state as it was before the length code, the entry to the C++ path
+          "8:\n\t"
+          "s_mov_b64 s[90:91], s[96:97]\n\t"
+          "s_mov_b32 %[cnt], s98\n\t"
+          "s_mov_b32 %[widx], s99\n\t"
+          "s_branch 9f\n\t"
           "3:\n\t"
           "s_mov_b32 %[e], 0xffff\n\t"
-          "2:\n\t"
+          "9:\n\t"
           : "+{s[90:91]}"(sbuf), [cnt] "+s"(scnt), [nlit] "+s"(snlit), [lit] "+v"(lit), [e] "+s"(e), [t0] "=&s"(t0),
-            [t1] "=&s"(t1), [vt] "=&v"(vt), [widx] "+s"(swidx)
-          : "{v[40:55]}"(tab), [cur] "v"(cur)
-          : "m0", "scc", "memory", "s92", "s93");
+            [t1] "=&s"(t1), [vt] "=&v"(vt), [widx] "+s"(swidx), [nf] "+s"(snf), [t2] "=&s"(t2), [t3] "=&s"(t3),
+            [vb] "=&v"(vb)
+          : "{v[40:55]}"(tab), [cur] "v"(cur), "{v[56:59]}"(dtab), [lentab] "v"(len_tab), [disttab] "v"(dist_tab),
+            [vlane] "v"(lane), [outlo] "s"(out_lo), [outhi] "s"(out_hi), [lim] "s"(lim32)
+          : "m0", "scc", "vcc", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+      n_flushed = (long)(((unsigned long)n_flushed & ~0xFFFFFFFFul) | (uint32_t)snf);
 #undef CPX_INFL_LITERAL
       buf = sbuf;
       cnt = scnt;

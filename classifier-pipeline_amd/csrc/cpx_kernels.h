@@ -253,7 +253,9 @@ int launch_thumb(const ThumbArgs& a, int n_refs, hipStream_t s);
 struct TracklessArgs {
   int W, H, frame, background;
   const uint16_t* frames;
-  int32_t* out;
+  int32_t* out;           // [n][2]
+  const int32_t* pairs;   // [n][2] = frame, background (null: the one pair above)
+  int n;
 };
 int launch_trackless(const TracklessArgs& a, hipStream_t s);
 

@@ -337,8 +337,12 @@ __global__ __launch_bounds__(TT) void cpx_trackless_kernel(TracklessArgs a) {
   u32* hs = (u32*)s_raw;                 // [H][NX]
   u32* box_t = hs + H * NX;              // [BY][BX] thermal
   u32* box_f = box_t + BY * BX;          // [BY][BX] filtered
-  const uint16_t* fr = a.frames + (size_t)a.frame * P;
-  const uint16_t* bg = a.frames + (size_t)a.background * P;
+  // one workgroup per (frame, background) pair: the single pair of the arguments, or row blockIdx.x of a.pairs
+  const int frame = a.pairs ? a.pairs[2 * blockIdx.x] : a.frame;
+  const int background = a.pairs ? a.pairs[2 * blockIdx.x + 1] : a.background;
+  int32_t* out = a.out + 2 * (size_t)blockIdx.x;
+  const uint16_t* fr = a.frames + (size_t)frame * P;
+  const uint16_t* bg = a.frames + (size_t)background * P;
   for (int plane = 0; plane < 2; ++plane) {
     __syncthreads();
     for (int i = threadIdx.x; i < H * NX; i += TT) {
@@ -377,8 +381,8 @@ __global__ __launch_bounds__(TT) void cpx_trackless_kernel(TracklessArgs a) {
           bx = x; by = y; v1 = ts; v2 = fs;
         }
       }
-    a.out[0] = have ? bx : -1;
-    a.out[1] = have ? by : -1;
+    out[0] = have ? bx : -1;
+    out[1] = have ? by : -1;
   }
 }
 
@@ -388,7 +392,7 @@ int launch_trackless(const TracklessArgs& a, hipStream_t s) {
   if (lds > 160 * 1024 - 1024) return -2;
   static bool lds_ready[64];
   if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_trackless_kernel), lds_ready, 160 * 1024 - 1024)) return -1;
-  hipLaunchKernelGGL(cpx_trackless_kernel, dim3(1), dim3(TT), lds, s, a);
+  hipLaunchKernelGGL(cpx_trackless_kernel, dim3(a.pairs ? a.n : 1), dim3(TT), lds, s, a);
   return 0;
 }
 

@@ -470,6 +470,9 @@ int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* la
  * range(H-64) x range(W-64), mean of the frame and of the uint16-wrapping difference frame - background,
  * walked in raster order with the reference's update rule.  out_dev int32[2] = x, y of the chosen window. */
 int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, int background, int32_t* out_dev);
+/* The same search for n recordings in one launch (one workgroup each): pairs_dev int32 [n][2] = frame, background
+ * indices into frames_dev; out_dev int32 [n][2]. */
+int cpx_trackless_thumb_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* pairs_dev, int n, int32_t* out_dev);
 
 /* ---- IR detection stage (partial) ------------------------------------------------------
  * Replaces detect_objects_ir (ml_tools/imageprocessing.py:185-199) for n frames of `width` x `height` uint8 pixels (the

@@ -18,17 +18,22 @@ tmp = tempfile.mkdtemp()
 wr.save_model(os.path.join(tmp, "wr"), wr.random_weights(17, seed=0), labels, hyperparams={"frame_size": 32})
 cfg = Config.get_defaults(); cfg.tracking["thermal"].denoise = False
 cfg.classify.models = [ModelConfig.load({"id": 1, "name": "wr-bench", "model_file": os.path.join(tmp, "wr.npz")})]
-rng = np.random.default_rng(4321)
+sys.path.insert(0, REPO)
+import bench
 t_on, ffc = synth.frame_times(T)
-distinct = [encode_cptv(synth.make_clip(rng, T), t_on, ffc) for _ in range(8)]
-blobs = [distinct[i % 8] for i in range(N)]
+ND = 32
+host = bench.synth_on_device(torch, torch.device("cuda", 0), ND, T, seed=4321).cpu().numpy().view(np.uint16).reshape(ND, T, 120, 160)
+distinct = [encode_cptv(host[i], t_on, ffc, level=6) for i in range(ND)]
+blobs = [distinct[i % ND] for i in range(N)]
 names = ["s%05d.cptv" % i for i in range(N)]
 cc = ClipClassifier(cfg) if classify else None
-run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=N, clip_classifier=cc, blobs=blobs)
+run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, 2048), clip_classifier=cc, blobs=blobs)
 pr = cProfile.Profile()
+torch.cuda.synchronize()
 t0 = time.time()
-pr.enable()
-out, tr = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=N, clip_classifier=cc, blobs=blobs)
+if "--cprofile" in sys.argv:
+    pr.enable()
+out, tr = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, 2048), clip_classifier=cc, blobs=blobs)
 pr.disable()
 print("seconds", round(time.time() - t0, 3), {k: round(v, 3) if isinstance(v, float) else v for k, v in tr.timings.items()})
 st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(28); print(st.getvalue()[:6000])
