@@ -402,7 +402,7 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
     """The file-fed form of the headline path: `--from-files` synthetic recordings as CPTV byte
     strings in host memory (32 distinct clips of the headline's generator, T frames, gzip level 6, replicated) -> cpx.track.bulk.run_files_bulk
     with a ClipClassifier: upload, gzip inflate + section index + frame decode on the device, track, segments,
-    crop/tile + network, thumbnails, metadata JSON text per recording.  One warm-up pass, then a timed one."""
+    crop/tile + network, thumbnails, metadata JSON text per recording.  One warm-up pass over the same recordings, then a timed one."""
     import tempfile
 
     from cpx import synth
@@ -438,8 +438,11 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
     cc = ClipClassifier(cfg)
 
     def measure(blobs, names):
-        run_files_bulk(names[:batch], cfg, save_meta=False, want_text=True, device=local_rank, batch_files=batch,
-                       clip_classifier=cc, blobs=blobs[:batch])                   # warm-up: engines, arena, model
+        torch.cuda.empty_cache()   # (the previous workload's cached blocks have other sizes: start from a clean pool)
+        # warm-up = the same pass once: engines, model, and the pinned / device allocators grown to the pipeline's
+        # working set (three batches in flight), as in a service that has been running
+        run_files_bulk(names, cfg, save_meta=False, want_text=True, device=local_rank, batch_files=batch,
+                       clip_classifier=cc, blobs=blobs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out, tracker = run_files_bulk(names, cfg, save_meta=False, want_text=True, device=local_rank,
@@ -450,20 +453,20 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
         assert not bad, bad[:3]
         return out, tracker.timings, dt
 
+    blobs = [distinct[i % len(distinct)] for i in range(n)]
+    names = ["synthetic_%05d.cptv" % i for i in range(n)]
+    out, tm, dt = measure(blobs, names)
     # the same path over real recordings: copies of the two fixture clips (reference tests/clips), when they are here
     fixtures = None
     gold = os.path.join(REPO, "tests", "golden")
     if all(os.path.exists(os.path.join(gold, f + ".cptv")) for f in ("possum", "hedgehog")):
         real = [open(os.path.join(gold, f + ".cptv"), "rb").read() for f in ("possum", "hedgehog")]
-        nr = min(n, 2048)
+        nr = min(n, 4096)
         outr, tmr, dtr = measure([real[i % 2] for i in range(nr)], ["fixture_%05d.cptv" % i for i in range(nr)])
         fixtures = {"what": "%d copies of the reference's two fixture recordings (tests/clips/possum.cptv, hedgehog.cptv: "
                             "161 / 120 frames, 1.1 MB each) through the same call" % nr,
                     "files": nr, "frames": int(tmr["frames"]), "seconds": round(dtr, 3),
                     "frames_per_s": round(tmr["frames"] / dtr, 1), "files_per_s": round(nr / dtr, 1)}
-    blobs = [distinct[i % len(distinct)] for i in range(n)]
-    names = ["synthetic_%05d.cptv" % i for i in range(n)]
-    out, tm, dt = measure(blobs, names)
     n_tracks = sum(text.count('"tracking_score"') for text in out.values())
     n_pred = sum(text.count('"all_class_confidences"') for text in out.values())
     return {"what": "%d synthetic recordings (%d frames each: %d distinct clips of the headline's generator, gzip level 6, %.2f MB per file) as byte strings "
@@ -673,7 +676,7 @@ def main():
                     help="--config4: frames per device batch (their per-frame outputs must fit HBM beside the clips)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only launch the ranks (gloo rendezvous, no GPU work): checks the --gpus N path on a CPU host")
-    ap.add_argument("--from-files", type=int, default=4096,
+    ap.add_argument("--from-files", type=int, default=8192,
                     help="recordings of the from_files measurement of the default run (0 = skip)")
     args = ap.parse_args()
 

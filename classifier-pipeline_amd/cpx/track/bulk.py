@@ -187,7 +187,11 @@ def decode_staged(eng, staged, min_pixels=160 * 120):
     np.cumsum(slot_cap, out=slot_off[1:])
     files["slot_offset"], files["slot_capacity"] = slot_off[:-1], slot_cap
     n_in = int(staged.in_off[-1]) + 16
-    in_dev = staged.stage[:n_in].to(dev, non_blocking=True)
+    in_dev = getattr(staged, "in_dev", None)
+    if in_dev is not None:     # uploaded ahead (run_files_bulk's staging thread, a stream of its own)
+        staged.in_event.synchronize()
+    else:
+        in_dev = staged.stage[:n_in].to(dev, non_blocking=True)
     files_dev = eng._to_dev(files)
     out_dev = t.empty(int(out_off[-1]) + 16, dtype=t.uint8, device=dev)
     slots_dev = t.empty(max(int(slot_off[-1]), 1) * 8, dtype=t.int32, device=dev)
@@ -716,16 +720,34 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     if deng is None:
         deng = tracker.decode_engine = TrackEngine(width=eng0.width, height=eng0.height, device=device, max_frames=45)
 
-    def produce(bi):
+    # (the staging of batch k+1 -- file reads / copies into pinned memory, host work -- runs beside the decode of batch k)
+    stage_worker = ThreadPoolExecutor(max_workers=1)
+    stage_futs = {}
+    upload_stream = torch.cuda.Stream(device=deng.device)
+
+    def stage(bi):
         t0 = time.time()
         if blobs is None:
             staged = stager.stage(batches[bi]).result()
         else:
             staged = stage_blobs(torch, blobs[order[bi]:order[bi] + batch_files])
             staged.paths = batches[bi]
+        # ... and so does its upload (a copy stream of its own: the DMA engine, beside the previous batch's inflate)
+        with torch.cuda.stream(upload_stream):
+            staged.in_dev = staged.stage[: int(staged.in_off[-1]) + 16].to(deng.device, non_blocking=True)
+            staged.in_event = torch.cuda.Event()
+            staged.in_event.record(upload_stream)
+        return staged, time.time() - t0
+
+    def produce(bi):
+        if bi not in stage_futs:
+            stage_futs[bi] = stage_worker.submit(stage, bi)
+        staged, stage_s = stage_futs.pop(bi).result()
+        if bi + 1 < len(batches):
+            stage_futs[bi + 1] = stage_worker.submit(stage, bi + 1)
         t1 = time.time()
         decoded = decode_staged(deng, staged)
-        return staged, decoded, t1 - t0, time.time() - t1
+        return staged, decoded, stage_s, time.time() - t1
 
     worker = ThreadPoolExecutor(max_workers=1)
     dev_worker = ThreadPoolExecutor(max_workers=1)
@@ -866,6 +888,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     drain()
     dev_worker.shutdown(wait=True)
     worker.shutdown(wait=True)
+    stage_worker.shutdown(wait=True)
     if own_stager:
         stager.close()
     return out, tracker
