@@ -450,6 +450,8 @@ def inflate_files_on_device(engine, blobs, names=None):
             out.errors[i] = "%s: header section of %d bytes" % (name, res["header_bytes"][i])
         else:
             out.ok.append(i)
+    out.inflated_dev = out_dev          # kept for tests (the inflated bytes, file i at files["out_offset"][i])
+    out.files = files
     if not out.ok:
         out.clip_offsets = np.zeros(1, np.int32)
         return out
@@ -476,6 +478,4 @@ def inflate_files_on_device(engine, blobs, names=None):
     engine.synchronize()
     out.slots = dense_dev.cpu().numpy().view(CPTV_SLOT_DTYPE).reshape(-1)
     out.frames_dev = frames_dev
-    out.inflated_dev = out_dev          # kept for tests (the inflated bytes, file i at files["out_offset"][i])
-    out.files = files
     return out

@@ -25,6 +25,9 @@ ND = 32
 host = bench.synth_on_device(torch, torch.device("cuda", 0), ND, T, seed=4321).cpu().numpy().view(np.uint16).reshape(ND, T, 120, 160)
 distinct = [encode_cptv(host[i], t_on, ffc, level=6) for i in range(ND)]
 blobs = [distinct[i % ND] for i in range(N)]
+if "--fixtures" in sys.argv:
+    real = [open(os.path.join(REPO, "tests", "golden", f + ".cptv"), "rb").read() for f in ("possum", "hedgehog")]
+    blobs = [real[i % 2] for i in range(N)]
 names = ["s%05d.cptv" % i for i in range(N)]
 cc = ClipClassifier(cfg) if classify else None
 run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, 2048), clip_classifier=cc, blobs=blobs)

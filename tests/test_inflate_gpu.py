@@ -129,3 +129,35 @@ def test_corrupt_members_fail_alone(engine):
     for k, name in enumerate(("hedgehog", "possum")):
         _, want, _, _ = host_view(fixture(name))
         assert np.array_equal(frames[got.clip_offsets[k]:got.clip_offsets[k + 1]], want)
+
+
+def test_match_shapes_against_zlib(engine):
+    """The decoder's match paths one by one (the in-loop copy takes root-table codes of <= 64 bytes whose source lies
+    before the pending literals; everything else leaves the loop): short matches in low-entropy noise, run-length
+    chains (distance 1 and 3, length 258), a source that overlaps the literals still pending, distances up to the
+    32 KiB window, matches that end exactly at the output capacity -- every DEFLATE level and the fixed code.  The
+    payloads are not recordings: the inflate must succeed bit for bit and the section walk then refuse them (20)."""
+    from cpx.cptv import inflate_files_on_device
+
+    rng = np.random.default_rng(11)
+    noise4 = rng.integers(0, 4, 300000, dtype=np.uint8).tobytes()            # dense short matches, all distances
+    noise16 = rng.integers(0, 16, 200000, dtype=np.uint8).tobytes()
+    chunk = rng.integers(0, 256, 300, dtype=np.uint8).tobytes()
+    far = b"".join(chunk + rng.integers(0, 256, 32768 - 300, dtype=np.uint8).tobytes() for _ in range(4)) + chunk
+    runs = b"a" * 5000 + b"abc" * 3000 + bytes(range(256)) * 40 + b"\0" * 70000
+    echo = b"".join(rng.integers(0, 256, 5, dtype=np.uint8).tobytes() * 3 for _ in range(20000))   # literals, then their echo
+    mixed = noise4[:50000] + runs + far + echo[:60000] + noise16[:50000]
+    payloads = [noise4, noise16, far, runs, echo, mixed]
+    blobs, want = [], []
+    for data in payloads:
+        for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FIXED), (6, zlib.Z_RLE)):
+            blobs.append(regzip(data, level, strategy))
+            want.append(data)
+    got = inflate_files_on_device(engine, blobs, names=["m%d" % i for i in range(len(blobs))])
+    raw = got.inflated_dev.cpu().numpy()
+    for k, data in enumerate(want):
+        assert int(got.results["status"][k]) == 20, (k, int(got.results["status"][k]))    # inflated; not a recording
+        assert int(got.results["out_bytes"][k]) == len(data), k
+        o = int(got.files["out_offset"][k])
+        assert raw[o:o + len(data)].tobytes() == data, k
