@@ -248,20 +248,33 @@ struct WaveIO {
   "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
   "v_writelane_b32 %[lit], %[e], m0\n\t"                  \
   "s_add_u32 %[nlit], %[nlit], 1\n\t"
+      // the deferred store of the previous in-loop match: %[pl] bytes (0 = none) from %[vb] to s[100:101]
+#define CPX_INFL_RETIRE(L)                                \
+  "s_cmp_eq_u32 %[pl], 0\n\t"                             \
+  "s_cbranch_scc1 " #L "f\n\t"                            \
+  "v_cmp_gt_u32 vcc, %[pl], %[vlane]\n\t"                 \
+  "s_and_saveexec_b64 s[94:95], vcc\n\t"                  \
+  "s_waitcnt vmcnt(0)\n\t"                                \
+  "global_store_byte %[vlane], %[vb], s[100:101]\n\t"     \
+  "s_mov_b64 exec, s[94:95]\n\t"                          \
+  "s_mov_b32 %[pl], 0\n\t"                                \
+  #L ":\n\t"
       int swidx = rfl(widx);
       // the output position / limit as 32-bit scalars for the loop (a file whose output could pass 2 GiB gets lim32 = 0:
       // every store and match of the loop then declines and the C++ path below does them)
       int snf = rfl((int)(uint32_t)n_flushed);
       const int lim32 = rfl(lim < 0x7FFFFFFFl ? (int)lim : 0);
       const int out_lo = rfl((int)(uint32_t)(uintptr_t)out), out_hi = rfl((int)(uint32_t)((uintptr_t)out >> 32));
-      int t2, t3, vb;
+      int t2, t3, vb, pl;
       // A match whose length AND distance codes are root-table leaves, of at most 64 bytes, with its source before the
       // pending literals (dist >= len + nlit) stays in the loop as well -- about 60 scalar instructions against some 180
       // through the compiler's form of match() and the loop's exit / re-entry: the length code is decoded on a COPY of
       // the bit state (saved in s[96:97], s98, s99) so that any other shape restores it and leaves with the entry, as
-      // before.  The copy: source load first, the pending literals' store in its shadow, then the match's store
-      // (vmcnt counts in order).  A run of 62+ pending literals is stored here too.
+      // before.  The copy: source load first, the pending literals' store in its shadow; the match's own store waits
+      // until the NEXT in-loop match (or the loop's exit) needs it, so the load's latency -- 0.5 us, three literals'
+      // worth -- overlaps the decoding that follows.  A run of 62+ pending literals is stored here too.
       asm volatile(
+          "s_mov_b32 %[pl], 0\n\t"
           "1:\n\t"
           "s_cmp_gt_i32 %[cnt], 31\n\t"
           "s_cbranch_scc1 4f\n\t"
@@ -376,6 +389,9 @@ struct WaveIO {
           "s_add_u32 %[t1], %[t0], %[t2]\n\t"           // t1 = at + len
           "s_cmp_gt_u32 %[t1], %[lim]\n\t"
           "s_cbranch_scc1 8f\n\t"
+          // the previous match's bytes have arrived by now, or are waited for here: stored before this match's load
+          // (which may read them) is issued
+          CPX_INFL_RETIRE(13)
           "s_sub_u32 %[t3], %[t0], %[t3]\n\t"
           "s_add_u32 s92, %[outlo], %[t3]\n\t"
           "s_addc_u32 s93, %[outhi], 0\n\t"
@@ -383,8 +399,6 @@ struct WaveIO {
           "s_and_saveexec_b64 s[94:95], vcc\n\t"
           "global_load_ubyte %[vb], %[vlane], s[92:93]\n\t"
           "s_mov_b64 exec, s[94:95]\n\t"
-          "s_add_u32 s96, %[outlo], %[t0]\n\t"
-          "s_addc_u32 s97, %[outhi], 0\n\t"
           "s_cmp_eq_u32 %[nlit], 0\n\t"
           "s_cbranch_scc1 11f\n\t"
           "s_add_u32 s92, %[outlo], %[nf]\n\t"
@@ -394,17 +408,11 @@ struct WaveIO {
           "v_lshrrev_b32 %[vt], 4, %[lit]\n\t"
           "global_store_byte %[vlane], %[vt], s[92:93]\n\t"
           "s_mov_b64 exec, s[94:95]\n\t"
-          "v_cmp_gt_u32 vcc, %[t2], %[vlane]\n\t"
-          "s_and_saveexec_b64 s[94:95], vcc\n\t"
-          "s_waitcnt vmcnt(1)\n\t"
-          "s_branch 12f\n\t"
           "11:\n\t"
-          "v_cmp_gt_u32 vcc, %[t2], %[vlane]\n\t"
-          "s_and_saveexec_b64 s[94:95], vcc\n\t"
-          "s_waitcnt vmcnt(0)\n\t"
-          "12:\n\t"
-          "global_store_byte %[vlane], %[vb], s[96:97]\n\t"
-          "s_mov_b64 exec, s[94:95]\n\t"
+          // the match's own store is DEFERRED: decoding goes on while its bytes are in flight
+          "s_add_u32 s100, %[outlo], %[t0]\n\t"
+          "s_addc_u32 s101, %[outhi], 0\n\t"
+          "s_mov_b32 %[pl], %[t2]\n\t"
           "s_mov_b32 %[nf], %[t1]\n\t"
           "s_mov_b32 %[nlit], 0\n\t"
           "s_branch 1b\n\t"
@@ -417,14 +425,16 @@ struct WaveIO {
           "3:\n\t"
           "s_mov_b32 %[e], 0xffff\n\t"
           "9:\n\t"
+          CPX_INFL_RETIRE(14)
           : "+{s[90:91]}"(sbuf), [cnt] "+s"(scnt), [nlit] "+s"(snlit), [lit] "+v"(lit), [e] "+s"(e), [t0] "=&s"(t0),
             [t1] "=&s"(t1), [vt] "=&v"(vt), [widx] "+s"(swidx), [nf] "+s"(snf), [t2] "=&s"(t2), [t3] "=&s"(t3),
-            [vb] "=&v"(vb)
+            [vb] "=&v"(vb), [pl] "=&s"(pl)
           : "{v[40:55]}"(tab), [cur] "v"(cur), "{v[56:59]}"(dtab), [lentab] "v"(len_tab), [disttab] "v"(dist_tab),
             [vlane] "v"(lane), [outlo] "s"(out_lo), [outhi] "s"(out_hi), [lim] "s"(lim32)
-          : "m0", "scc", "vcc", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+          : "m0", "scc", "vcc", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101");
       n_flushed = (long)(((unsigned long)n_flushed & ~0xFFFFFFFFul) | (uint32_t)snf);
 #undef CPX_INFL_LITERAL
+#undef CPX_INFL_RETIRE
       buf = sbuf;
       cnt = scnt;
       nlit = snlit;
