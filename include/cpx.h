@@ -482,8 +482,8 @@ int cpx_trackless_thumb_batch(cpx_handle* h, const uint16_t* frames_dev, const i
  * entry i; centroid = sum / area), counts_dev [n], status_dev [n] = 0 or CPX_ERR_OVERFLOW (the frame has more than
  * max_components components; counts_dev then holds the true count and nothing else of the frame is written);
  * labels_dev optional int32 [n, height, width].  Frames with up to 8192 pixel runs and 1024 components are labelled
- * entirely in LDS; busier ones use scratch the handle allocates (up to 256 slots of ~3 MB at 640 x 480).  The IR background model (cv2 MOG2) and the merge of fragments
- * (irtrackextractor.py:324-389, host side in cpx/track/irdetect.py) are not part of this call. */
+ * entirely in LDS; busier ones use scratch the handle allocates (up to 256 slots of ~3 MB at 640 x 480).  The IR background model (cpx_mog2_*) and the merge of fragments
+ * (cpx_ir_merge; host form in cpx/track/irdetect.py) are calls of their own. */
 int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int width, int height, int threshold,
                   int max_components, cpx_component* comps_dev, int32_t* counts_dev, int32_t* status_dev,
                   int32_t* labels_dev);

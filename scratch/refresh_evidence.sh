@@ -11,7 +11,12 @@ python3 bench.py --cnn-math f32 --cpu-clips 0 --no-extras 2>/dev/null | grep '^{
 python3 bench.py --stage track 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_track.json
 python3 bench.py --config4 --steps 1 --warmup 1 --cpu-clips 8 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_config4.json
 python3 bench.py --stage ir 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_ir.json
+python3 scratch/dir_bench_bulk.py 4096 1024 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_directory_bulk.json
+python3 scratch/dir_bench_bulk.py 64 1024 --denoise 2>/dev/null | grep '^{' >> gpurun_out/ev/${R}_directory_bulk.json
+python3 scratch/dir_bench_bulk.py 1024 1024 --denoise 2>/dev/null | grep '^{' >> gpurun_out/ev/${R}_directory_bulk.json
 cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_ff -- python3 $ROOT/scratch/from_files_profile.py 8192 270 > $ROOT/gpurun_out/ev/prof_from_files.log 2>&1
+f=$(ls -t $ROOT/gpurun_out/prof_ff/*/*kernel_stats.csv | head -1); cp "$f" $ROOT/gpurun_out/ev/${R}_from_files_kernel_stats.csv; rm -rf $ROOT/gpurun_out/prof_ff
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_e2e -- python3 $ROOT/bench.py --cpu-clips 0 --no-extras > $ROOT/gpurun_out/ev/prof_e2e.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr A-Z a-z | sed 's/_size//')
