@@ -151,6 +151,8 @@ struct WaveIO {
     if (at + len > lim) return infl::ERR_OUTPUT;
     uint8_t* const dst = out + at;
     const uint8_t* const src = dst - dist;
+    // stores of the hand-written loop may still be in flight: complete before a load that may read their bytes
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (dist >= len + nlit && len <= 64) {
       // the common shape: its source lies before the pending literals, so the load is issued FIRST and the literal
       // store rides in its shadow; the wait before the match's own store then counts past that younger store
@@ -248,33 +250,20 @@ struct WaveIO {
   "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
   "v_writelane_b32 %[lit], %[e], m0\n\t"                  \
   "s_add_u32 %[nlit], %[nlit], 1\n\t"
-      // the deferred store of the previous in-loop match: %[pl] bytes (0 = none) from %[vb] to s[100:101]
-#define CPX_INFL_RETIRE(L)                                \
-  "s_cmp_eq_u32 %[pl], 0\n\t"                             \
-  "s_cbranch_scc1 " #L "f\n\t"                            \
-  "v_cmp_gt_u32 vcc, %[pl], %[vlane]\n\t"                 \
-  "s_and_saveexec_b64 s[94:95], vcc\n\t"                  \
-  "s_waitcnt vmcnt(0)\n\t"                                \
-  "global_store_byte %[vlane], %[vb], s[100:101]\n\t"     \
-  "s_mov_b64 exec, s[94:95]\n\t"                          \
-  "s_mov_b32 %[pl], 0\n\t"                                \
-  #L ":\n\t"
       int swidx = rfl(widx);
       // the output position / limit as 32-bit scalars for the loop (a file whose output could pass 2 GiB gets lim32 = 0:
       // every store and match of the loop then declines and the C++ path below does them)
       int snf = rfl((int)(uint32_t)n_flushed);
       const int lim32 = rfl(lim < 0x7FFFFFFFl ? (int)lim : 0);
       const int out_lo = rfl((int)(uint32_t)(uintptr_t)out), out_hi = rfl((int)(uint32_t)((uintptr_t)out >> 32));
-      int t2, t3, vb, pl;
+      int t2, t3, vb;
       // A match whose length AND distance codes are root-table leaves, of at most 64 bytes, with its source before the
       // pending literals (dist >= len + nlit) stays in the loop as well -- about 60 scalar instructions against some 180
       // through the compiler's form of match() and the loop's exit / re-entry: the length code is decoded on a COPY of
       // the bit state (saved in s[96:97], s98, s99) so that any other shape restores it and leaves with the entry, as
-      // before.  The copy: source load first, the pending literals' store in its shadow; the match's own store waits
-      // until the NEXT in-loop match (or the loop's exit) needs it, so the load's latency -- 0.5 us, three literals'
-      // worth -- overlaps the decoding that follows.  A run of 62+ pending literals is stored here too.
+      // before.  The copy: source load first, the pending literals' store in its shadow, then the match's store.
+      // A run of 62+ pending literals is stored here too.
       asm volatile(
-          "s_mov_b32 %[pl], 0\n\t"
           "1:\n\t"
           "s_cmp_gt_i32 %[cnt], 31\n\t"
           "s_cbranch_scc1 4f\n\t"
@@ -391,7 +380,11 @@ struct WaveIO {
           "s_cbranch_scc1 8f\n\t"
           // the previous match's bytes have arrived by now, or are waited for here: stored before this match's load
           // (which may read them) is issued
-          CPX_INFL_RETIRE(13)
+          // every earlier store of this wave complete before the source load: a byte store and a load of the same
+          // bytes a few instructions later are not ordered by the memory pipeline under load (measured: with the
+          // match's store deferred past the next literals, a few recordings in 10^5 decoded wrongly while other
+          // kernels shared the chip; none in 1.5 x 10^5 with the store in place and this wait)
+          "s_waitcnt vmcnt(0)\n\t"
           "s_sub_u32 %[t3], %[t0], %[t3]\n\t"
           "s_add_u32 s92, %[outlo], %[t3]\n\t"
           "s_addc_u32 s93, %[outhi], 0\n\t"
@@ -399,6 +392,8 @@ struct WaveIO {
           "s_and_saveexec_b64 s[94:95], vcc\n\t"
           "global_load_ubyte %[vb], %[vlane], s[92:93]\n\t"
           "s_mov_b64 exec, s[94:95]\n\t"
+          "s_add_u32 s96, %[outlo], %[t0]\n\t"
+          "s_addc_u32 s97, %[outhi], 0\n\t"
           "s_cmp_eq_u32 %[nlit], 0\n\t"
           "s_cbranch_scc1 11f\n\t"
           "s_add_u32 s92, %[outlo], %[nf]\n\t"
@@ -409,10 +404,11 @@ struct WaveIO {
           "global_store_byte %[vlane], %[vt], s[92:93]\n\t"
           "s_mov_b64 exec, s[94:95]\n\t"
           "11:\n\t"
-          // the match's own store is DEFERRED: decoding goes on while its bytes are in flight
-          "s_add_u32 s100, %[outlo], %[t0]\n\t"
-          "s_addc_u32 s101, %[outhi], 0\n\t"
-          "s_mov_b32 %[pl], %[t2]\n\t"
+          "v_cmp_gt_u32 vcc, %[t2], %[vlane]\n\t"
+          "s_and_saveexec_b64 s[94:95], vcc\n\t"
+          "s_waitcnt vmcnt(0)\n\t"
+          "global_store_byte %[vlane], %[vb], s[96:97]\n\t"
+          "s_mov_b64 exec, s[94:95]\n\t"
           "s_mov_b32 %[nf], %[t1]\n\t"
           "s_mov_b32 %[nlit], 0\n\t"
           "s_branch 1b\n\t"
@@ -425,16 +421,14 @@ struct WaveIO {
           "3:\n\t"
           "s_mov_b32 %[e], 0xffff\n\t"
           "9:\n\t"
-          CPX_INFL_RETIRE(14)
           : "+{s[90:91]}"(sbuf), [cnt] "+s"(scnt), [nlit] "+s"(snlit), [lit] "+v"(lit), [e] "+s"(e), [t0] "=&s"(t0),
             [t1] "=&s"(t1), [vt] "=&v"(vt), [widx] "+s"(swidx), [nf] "+s"(snf), [t2] "=&s"(t2), [t3] "=&s"(t3),
-            [vb] "=&v"(vb), [pl] "=&s"(pl)
+            [vb] "=&v"(vb)
           : "{v[40:55]}"(tab), [cur] "v"(cur), "{v[56:59]}"(dtab), [lentab] "v"(len_tab), [disttab] "v"(dist_tab),
             [vlane] "v"(lane), [outlo] "s"(out_lo), [outhi] "s"(out_hi), [lim] "s"(lim32)
-          : "m0", "scc", "vcc", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101");
+          : "m0", "scc", "vcc", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
       n_flushed = (long)(((unsigned long)n_flushed & ~0xFFFFFFFFul) | (uint32_t)snf);
 #undef CPX_INFL_LITERAL
-#undef CPX_INFL_RETIRE
       buf = sbuf;
       cnt = scnt;
       nlit = snlit;
@@ -577,6 +571,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 6) void cpx_cptv_inflate_kernel(
     if (!io.flush() && status == 0) status = infl::ERR_OUTPUT;
     if (status == infl::ERR_OUTPUT && io.overrun()) status = infl::ERR_INPUT;
     n_out = io.n_flushed;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // every store of the stream complete before the section walk reads it back
     if (status == 0) {
       // trailer: crc32, isize; what follows must be the end of the file (a further member goes to the host path)
       const long used = (io.pos_bits() + 7) >> 3;

@@ -153,3 +153,46 @@ def test_bulk_metadata_text_is_json_dump_text(golden_dir, tmp_path):
         assert json.dumps(meta, indent=4, cls=CustomJSONEncoder) == text, p
         n_pos += sum(len(t["positions"]) for t in meta["tracks"])
     assert n_pos > 100
+
+
+def test_bulk_pipeline_is_deterministic_under_load(tmp_path):
+    """3,072 recordings (copies of 16 synthetic clips, sensor noise: half a million DEFLATE matches each) through
+    run_files_bulk with a classifier -- inflate of batch k+1 on its own stream beside the tracking and the network of
+    batch k: no file may be skipped and the metadata text of every copy of a clip must be the same, character for
+    character (file name, clip id and timings aside).  Guards the inflate kernel's store -> load ordering (a match
+    reads bytes the wave stored a moment ago) and the buffer hand-over between the pipeline's threads."""
+    import re
+
+    from cpx import synth
+    from cpx.classify.clipclassifier import ClipClassifier
+    from cpx.config import Config
+    from cpx.config.config import ModelConfig
+    from cpx.cptv import encode_cptv as encode_recording
+    from cpx.ml_tools import wrresnet as wr
+    from cpx.track.bulk import run_files_bulk
+
+    labels = ["bird", "cat", "false-positive", "possum", "rodent"]
+    wr.save_model(str(tmp_path / "wr"), wr.random_weights(len(labels), seed=3), labels, hyperparams={"frame_size": 32})
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    cfg.classify.models = [ModelConfig.load({"id": 1, "name": "wr", "model_file": str(tmp_path / "wr.npz")})]
+    cfg.classify.meta_to_stdout = False
+    rng = np.random.default_rng(77)
+    T, ND, N = 120, 16, 3072
+    t_on, ffc = synth.frame_times(T)
+    distinct = [encode_recording(synth.make_clip(rng, T), t_on, ffc, level=6) for _ in range(ND)]
+    blobs = [distinct[i % ND] for i in range(N)]
+    names = ["d%05d.cptv" % i for i in range(N)]
+    out, _ = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=1024, track_files=512,
+                            clip_classifier=ClipClassifier(cfg), blobs=blobs)
+
+    def norm(text):
+        text = re.sub(r'"(tracking_time|classify_time|predicted_time)": [^,\n]*', '"t": 0', text)
+        text = re.sub(r'^    "id": \d+,', '    "id": 0,', text, flags=re.M)
+        return re.sub(r"d\d{5}\.cptv", "F", text)
+
+    assert not [k for k, v in out.items() if v.startswith("error")]
+    ref = [norm(out[names[j]]) for j in range(ND)]
+    assert sum('"tracking_score"' in r for r in ref) >= ND // 2      # the clips do carry tracks
+    differ = [names[i] for i in range(N) if norm(out[names[i]]) != ref[i % ND]]
+    assert differ == [], differ[:5]

@@ -49,3 +49,42 @@ def test_integration_stub_runs_as_documented():
         n_seen += n
     assert n_seen > 0
     eng.close()
+
+
+def test_whole_file_stub_runs_as_documented():
+    """The second stub of section 2 (whole .cptv files inflated and indexed on the device), executed after the first
+    one in the same scope with `paths` = the two fixture recordings: every file decodes, frame counts and sizes equal
+    the host reader's."""
+    import zlib
+
+    from cpx import _lib
+    from cpx.engine import TrackEngine
+    from helpers import GOLDEN, load_clip
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. Bind the C-ABI directly"):]
+    blocks = re.findall(r"```python\n(.*?)```", sec, re.S)
+    assert len(blocks) >= 2 and "cpx_cptv_inflate" in blocks[1]
+    first = blocks[0].replace('C.CDLL("libcpx_hip.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    frames = load_clip("possum")[0][:4]
+    eng = TrackEngine(model="lepton3", max_frames=64)
+    paths = [os.path.join(GOLDEN, n + ".cptv") for n in ("possum", "hedgehog")]
+    scope = {
+        "clip": types.SimpleNamespace(background_thresh=eng.cfg.background_thresh),
+        "config": types.SimpleNamespace(denoise=False),
+        "cptv_frames": [types.SimpleNamespace(pix=f) for f in frames],
+        "paths": paths,
+    }
+    exec(compile(first, "INTEGRATION.md#2a", "exec"), scope)
+    exec(compile(blocks[1], "INTEGRATION.md#2b", "exec"), scope)
+    assert scope["rc"] == 0
+    res = scope["res"]
+    raw = scope["out_dev"].cpu().numpy()
+    for k, p in enumerate(paths):
+        want = zlib.decompress(open(p, "rb").read(), 47)
+        assert int(res["status"][k]) == 0 and int(res["out_bytes"][k]) == len(want)
+        o = int(scope["files"]["out_offset"][k])
+        assert raw[o:o + len(want)].tobytes() == want
+        assert int(res["n_frames"][k]) == len(load_clip(("possum", "hedgehog")[k])[0])
+        assert (int(res["width"][k]), int(res["height"][k])) == (160, 120)
+    eng.close()
