@@ -708,8 +708,13 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         classifiers = [(m, clip_classifier.get_classifier(m)) for m in models]
         tracker.timings["model_load_s"] = time.time() - t0
     out = {}
-    order = list(range(0, len(filenames), batch_files))
-    batches = [filenames[i:i + batch_files] for i in order]
+    # decode launches of batch_files recordings; the FIRST one half as large when there are several: nothing runs beside
+    # it, and a launch's time hardly falls below a lone wave's (the pipeline fills sooner than it would lose in occupancy)
+    n_all = len(filenames)
+    first = batch_files // 2 if (n_all > 2 * batch_files and batch_files >= 512) else batch_files
+    order = ([0] + list(range(first, n_all, batch_files)) if n_all > first else [0]) if n_all else []
+    bounds = order[1:] + [n_all]
+    batches = [filenames[a:b] for a, b in zip(order, bounds)]
     # Two stages in flight: a worker thread stages batch k+1 (file reads / copies into pinned memory) and decodes it on
     # a handle of its own (its own HIP stream: upload, inflate + section index, unpack) while this thread tracks,
     # classifies and writes batch k.  The inflate kernel is bound by scalar issue and latency, the network by the matrix
@@ -730,7 +735,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         if blobs is None:
             staged = stager.stage(batches[bi]).result()
         else:
-            staged = stage_blobs(torch, blobs[order[bi]:order[bi] + batch_files])
+            staged = stage_blobs(torch, blobs[order[bi]:bounds[bi]])
             staged.paths = batches[bi]
         # ... and so does its upload (a copy stream of its own: the DMA engine, beside the previous batch's inflate)
         with torch.cuda.stream(upload_stream):
