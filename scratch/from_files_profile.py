@@ -13,6 +13,7 @@ from cpx.track.bulk import run_files_bulk
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 270
 classify = "--no-classify" not in sys.argv
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 2048
 labels = ["bird", "cat", "deer", "dog", "false-positive", "hedgehog", "human", "kiwi", "leporidae", "mustelid", "penguin", "possum", "rodent", "sheep", "vehicle", "wallaby", "land-bird"]
 tmp = tempfile.mkdtemp()
 wr.save_model(os.path.join(tmp, "wr"), wr.random_weights(17, seed=0), labels, hyperparams={"frame_size": 32})
@@ -30,13 +31,13 @@ if "--fixtures" in sys.argv:
     blobs = [real[i % 2] for i in range(N)]
 names = ["s%05d.cptv" % i for i in range(N)]
 cc = ClipClassifier(cfg) if classify else None
-run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, 2048), clip_classifier=cc, blobs=blobs)
+run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, BATCH), clip_classifier=cc, blobs=blobs)
 pr = cProfile.Profile()
 torch.cuda.synchronize()
 t0 = time.time()
 if "--cprofile" in sys.argv:
     pr.enable()
-out, tr = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, 2048), clip_classifier=cc, blobs=blobs)
+out, tr = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, BATCH), clip_classifier=cc, blobs=blobs)
 pr.disable()
 print("seconds", round(time.time() - t0, 3), {k: round(v, 3) if isinstance(v, float) else v for k, v in tr.timings.items()})
 st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(28); print(st.getvalue()[:6000])
