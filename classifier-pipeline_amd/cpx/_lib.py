@@ -119,7 +119,7 @@ EXPORTS = [
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
     "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
-    "cpx_trackless_thumb_batch",
+    "cpx_trackless_thumb_batch", "cpx_thumb_stats_ex",
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
@@ -232,6 +232,8 @@ def load():
     lib.cpx_associate_frame.restype = C.c_int
     lib.cpx_thumb_stats.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
     lib.cpx_thumb_stats.restype = C.c_int
+    lib.cpx_thumb_stats_ex.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    lib.cpx_thumb_stats_ex.restype = C.c_int
     lib.cpx_trackless_thumb.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.cpx_trackless_thumb.restype = C.c_int
     lib.cpx_trackless_thumb_batch.argtypes = [vp, vp, vp, C.c_int, vp]

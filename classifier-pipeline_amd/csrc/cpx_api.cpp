@@ -1145,18 +1145,21 @@ int cpx_cptv_gather_index(cpx_handle* h, const cpx_cptv_frame_slot* slots_dev, c
   return CPX_OK;
 }
 
-int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
-                    const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev, int n_refs,
-                    cpx_thumb_stat* out_dev) {
+int cpx_thumb_stats_ex(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
+                       const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev, int n_refs,
+                       cpx_thumb_stat* out_dev, int max_width, int max_height, int chain_capacity) {
   if (!h) return CPX_ERR_INVALID;
-  if (!frames_dev || !labels_dev || !info_dev || !refs_dev || !out_dev || n_refs < 0)
+  if (!frames_dev || !labels_dev || !info_dev || !refs_dev || !out_dev || n_refs < 0 || max_width < 1 || max_height < 1 ||
+      chain_capacity < 16 || chain_capacity > 32000)
     return fail(h, CPX_ERR_INVALID, "cpx_thumb_stats: bad argument");
   if (n_refs == 0) return CPX_OK;
   CPX_ENTER(h);
   cpx::ThumbArgs a{};
   a.W = h->cfg.width;
   a.H = h->cfg.height;
-  a.chain_cap = 8192;
+  a.chain_cap = chain_capacity;
+  a.max_w = max_width < a.W ? max_width : a.W;
+  a.max_h = max_height < a.H ? max_height : a.H;
   a.frames = frames_dev;
   a.labels = labels_dev;
   a.info = info_dev;
@@ -1167,6 +1170,14 @@ int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* la
   if (rc != 0) return fail(h, CPX_ERR_HIP, "cpx_thumb_stats: kernel configuration failed");
   CPX_HIP(h, hipGetLastError());
   return CPX_OK;
+}
+
+int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
+                    const cpx_frame_info* info_dev, const cpx_region_ref* refs_dev, int n_refs,
+                    cpx_thumb_stat* out_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  return cpx_thumb_stats_ex(h, frames_dev, labels_dev, info_dev, refs_dev, n_refs, out_dev, h->cfg.width, h->cfg.height,
+                            8192);
 }
 
 int cpx_trackless_thumb(cpx_handle* h, const uint16_t* frames_dev, int frame, int background, int32_t* out_dev) {

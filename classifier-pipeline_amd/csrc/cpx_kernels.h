@@ -242,6 +242,7 @@ int launch_cptv_gather(const CptvGatherArgs& a, int B, hipStream_t s);
 
 struct ThumbArgs {
   int W, H, chain_cap;
+  int max_w, max_h;   // the launch's LDS holds regions up to this size; a larger one reports CPX_ERR_OVERFLOW
   const uint16_t* frames;
   const int32_t* labels;
   const cpx_frame_info* info;

@@ -198,6 +198,11 @@ __global__ __launch_bounds__(64) void cpx_thumb_kernel(ThumbArgs a) {
     if (lane == 0) a.out[r] = out;
     return;
   }
+  if (w > a.max_w || h > a.max_h) {   // this launch's LDS was sized for smaller regions: the caller runs it again
+    out.status = CPX_ERR_OVERFLOW;
+    if (lane == 0) a.out[r] = out;
+    return;
+  }
   const int PW = w + 2, PH = h + 2;
   signed char* img = (signed char*)s_raw;                       // [PH][PW], zero border
   const int img_bytes = (PH * PW + 15) & ~15;
@@ -314,7 +319,7 @@ size_t thumb_lds_bytes(int W, int H, int cap) {
 }
 
 int launch_thumb(const ThumbArgs& a, int n_refs, hipStream_t s) {
-  const size_t lds = thumb_lds_bytes(a.W, a.H, a.chain_cap);
+  const size_t lds = thumb_lds_bytes(a.max_w, a.max_h, a.chain_cap);
   if (lds > 160 * 1024) return -2;
   static bool lds_ready[64];
   if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(cpx_thumb_kernel), lds_ready, 160 * 1024 - 1024)) return -1;

@@ -464,6 +464,15 @@ typedef struct cpx_thumb_stat {
 int cpx_thumb_stats(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
                     const cpx_frame_info* info_dev, const struct cpx_region_ref* refs_dev, int n_refs,
                     cpx_thumb_stat* out_dev);
+/* The same with the kernel's per-region scratch sized by the caller: one wavefront per region keeps the region's mask
+ * ((max_width + 2) x (max_height + 2) bytes) and the border chain (8 bytes per step, chain_capacity steps) in LDS, and
+ * the number of regions a CU works on at once is what fits its 160 KB -- cpx_thumb_stats sizes for a whole frame and
+ * 8192 steps (one region per CU); 46 x 46 and 2304 steps (cpx/engine.py) runs seven.  A region larger than
+ * max_width x max_height, or a border longer than chain_capacity, reports CPX_ERR_OVERFLOW in its status (nothing
+ * else of it is written): run it again through the wider form. */
+int cpx_thumb_stats_ex(cpx_handle* h, const uint16_t* frames_dev, const int32_t* labels_dev,
+                       const cpx_frame_info* info_dev, const struct cpx_region_ref* refs_dev, int n_refs,
+                       cpx_thumb_stat* out_dev, int max_width, int max_height, int chain_capacity);
 
 /* best_trackless_thumb's window search (thumbnail.py:26-64) on frame `frame` with the clip background
  * frames_dev[background] (the clip's first frame, clip.py:152-158): every 64x64 window position of
