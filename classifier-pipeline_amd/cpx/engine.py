@@ -358,41 +358,46 @@ class TrackEngine:
         self.sync_inputs()
         args = (C.c_void_p(frames_dev.data_ptr()), C.c_void_p(track_result.labels_dev.data_ptr()),
                 C.c_void_p(track_result.info_dev.data_ptr()))
-        # Two tiers: the kernel keeps a region's mask and border chain in LDS, one wavefront per region, and a CU
-        # works on as many regions as fit its LDS -- sized for ordinary regions (<= 46 x 46, the animals of the path)
-        # seven run per CU instead of one; the few larger ones (and any border longer than the small chain) go
-        # through the whole-frame form afterwards.
-        small = (refs["width"] <= self.THUMB_SMALL) & (refs["height"] <= self.THUMB_SMALL)
-        if small.all():
-            rc = self.lib.cpx_thumb_stats_ex(self.h, *args, C.c_void_p(refs_dev.data_ptr()), n, C.c_void_p(out.data_ptr()),
-                                             self.THUMB_SMALL, self.THUMB_SMALL, self.THUMB_SMALL_CHAIN)
-        elif not small.any():
-            rc = self.lib.cpx_thumb_stats(self.h, *args, C.c_void_p(refs_dev.data_ptr()), n, C.c_void_p(out.data_ptr()))
-        else:   # both launches over all refs: the small form marks what it cannot hold, the wide form redoes those below
-            rc = self.lib.cpx_thumb_stats_ex(self.h, *args, C.c_void_p(refs_dev.data_ptr()), n, C.c_void_p(out.data_ptr()),
-                                             self.THUMB_SMALL, self.THUMB_SMALL, self.THUMB_SMALL_CHAIN)
-        if rc != 0:
-            raise CpxError(rc, self._err())
-        self.synchronize()
-        got = out.cpu().numpy().view(THUMB_STAT_DTYPE).copy()
-        redo = np.nonzero(got["status"] != 0)[0]
-        if redo.size and small.any():
-            sub_dev = self._to_dev(np.ascontiguousarray(refs[redo]))
-            sub_out = t.zeros(len(redo) * 4, dtype=t.int32, device=self.device)
+        # Tiers: the kernel keeps a region's mask and border chain in LDS, one wavefront per region, and a CU works on
+        # as many regions as fit its LDS -- sized for ordinary regions (<= 46 x 46, the animals of the path) seven run
+        # per CU, at 80 x 80 three, in the whole-frame form one.  A region goes to the first tier that holds it; one
+        # whose border outgrows a tier's chain is marked by the kernel and moves on to the next.
+        got = np.zeros(n, THUMB_STAT_DTYPE)
+        pending = np.arange(n)
+        for side, chain in self.THUMB_TIERS + ((None, None),):
+            if pending.size == 0:
+                break
+            if side is None:
+                take = pending
+            else:
+                fits = (refs["width"][pending] <= side) & (refs["height"][pending] <= side)
+                take = pending[fits]
+            if take.size == 0:
+                continue
+            whole = take.size == n
+            sub_dev = refs_dev if whole else self._to_dev(np.ascontiguousarray(refs[take]))
+            sub_out = out if whole else t.zeros(take.size * 4, dtype=t.int32, device=self.device)
             self.sync_inputs()
-            rc = self.lib.cpx_thumb_stats(self.h, *args, C.c_void_p(sub_dev.data_ptr()), len(redo),
-                                          C.c_void_p(sub_out.data_ptr()))
+            if side is None:
+                rc = self.lib.cpx_thumb_stats(self.h, *args, C.c_void_p(sub_dev.data_ptr()), int(take.size),
+                                              C.c_void_p(sub_out.data_ptr()))
+            else:
+                rc = self.lib.cpx_thumb_stats_ex(self.h, *args, C.c_void_p(sub_dev.data_ptr()), int(take.size),
+                                                 C.c_void_p(sub_out.data_ptr()), side, side, chain)
             if rc != 0:
                 raise CpxError(rc, self._err())
             self.synchronize()
-            got[redo] = sub_out.cpu().numpy().view(THUMB_STAT_DTYPE)
+            res = sub_out.cpu().numpy().view(THUMB_STAT_DTYPE)
+            got[take] = res
+            done = take[res["status"] == 0] if side is not None else take
+            pending = np.setdiff1d(pending, done, assume_unique=True)
         bad = np.nonzero(got["status"] != 0)[0]
         if bad.size:
             raise CpxError(int(got["status"][bad[0]]), "region %d: contour longer than the kernel's chain capacity"
                            % int(bad[0]))
         return got
 
-    THUMB_SMALL, THUMB_SMALL_CHAIN = 46, 2304
+    THUMB_TIERS = ((46, 2304), (80, 4608))
 
     CNN_MATH = {"f32": 0, "bf16x3": 1}
 
