@@ -972,16 +972,18 @@ def main():
             eng.synchronize()
             dt0 = time.perf_counter() - t1
             nlm_s = dt - dt0
-            # Operation-count model of cpx_nlm_kernel<10,160> (instructions counted in the gfx950 ISA of the shipped
-            # build, csrc/cpx_track.hip): per (pixel, offset) of the 21 x 21 search window -- pass A (row sums of squared
-            # differences, one pass per offset PAIR, 8 columns per item: 80 vector + 7 LDS instructions) 5.0 vector +
-            # 0.44 LDS lane-operations; pass B (seven-row sliding sum, weight look-up, accumulate, two columns per
-            # thread) ~7.1 vector + 1.8 LDS.  A CU issues at most 128 vector lane-operations per cycle (4 SIMD-32) and
-            # serves 64 LDS lanes per 2 cycles.
+            # Operation-count model of cpx_nlm_kernel<10,160>, calibrated by its SQ counters
+            # (profiles/r03_nlm_sq_counters.json, scratch/pmc_nlm.sh: SQ_INSTS_VALU 2.0 M wave-instructions per frame =
+            # 15.1 vector lane-operations per (pixel, offset) of the 21 x 21 window, SQ_INSTS_LDS 0.31 M = 2.3;
+            # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0 cycles per wave-instruction -- the kernel's packed 16-bit,
+            # byte-permute and 24-bit multiply instructions issue 16 lanes per cycle and SIMD, half the fp32 rate --
+            # so a CU retires 64 of these lane-operations per cycle; the vector pipes are busy 76 % of the kernel's
+            # time (4 waves per SIMD x ACTIVE_INST_VALU / WAVE_CYCLES), waves parked on LDS data 45 % of theirs).
             px_off = H * W * 441.0
-            valu_ops, lds_ops = 12.1 * px_off, 2.24 * px_off
+            valu_per, lds_per, valu_rate = 15.1, 2.3, 64.0
+            valu_ops, lds_ops = valu_per * px_off, lds_per * px_off
             clock = 2.4e9
-            t_valu = valu_ops / 128.0 / clock / 256.0      # seconds per frame, chip-wide, if vector issue were the bound
+            t_valu = valu_ops / valu_rate / clock / 256.0   # seconds per frame, chip-wide, if vector issue were the bound
             t_lds = lds_ops / 32.0 / clock / 256.0          # ... if the LDS instruction rate were
             nlm_per_frame = nlm_s / (nb * T)
             line["default_config"] = {
@@ -997,15 +999,20 @@ def main():
             line["roofline_nlm"] = {
                 "kernel": "cpx_nlm_kernel<10,160>", "bound": "vector + LDS instruction issue (no HBM or matrix roof applies: "
                           "19 KB in, 19 KB out per frame, integer arithmetic on an LDS-resident frame)",
-                "model": {"pixel_offsets_per_frame": px_off, "vector_lane_ops_per_pixel_offset": 12.1,
-                          "lds_lane_ops_per_pixel_offset": 2.24, "vector_lane_ops_per_cycle_per_cu": 128,
-                          "lds_lanes_per_cycle_per_cu": 32, "clock_hz": clock, "cus": 256},
+                "model": {"pixel_offsets_per_frame": px_off, "vector_lane_ops_per_pixel_offset": valu_per,
+                          "lds_lane_ops_per_pixel_offset": lds_per, "vector_lane_ops_per_cycle_per_cu": valu_rate,
+                          "lds_lanes_per_cycle_per_cu": 32, "clock_hz": clock, "cus": 256,
+                          "calibration": "profiles/r03_nlm_sq_counters.json (rocprofv3 --pmc, separate passes)"},
+                "measured_sq": {"valu_cycles_per_wave_instruction": 4.0, "valu_pipe_busy": 0.76,
+                                "wave_time_parked_on_waitcnt_or_barrier": 0.45, "wave_time_issue_stalled": 0.26,
+                                "lds_bank_conflict_share_of_lds_cycles": 0.36},
                 "achieved_us_per_frame": round(nlm_per_frame * 1e6, 3),
                 "vector_issue_bound_us_per_frame": round(t_valu * 1e6, 3),
                 "lds_issue_bound_us_per_frame": round(t_lds * 1e6, 3),
                 "frac": round(max(t_valu, t_lds) / nlm_per_frame, 4), "unit": "fraction of the nearer issue bound",
-                "note": "frames in flight: one 1024-thread workgroup (a whole frame) per CU, 16 waves; the two issue "
-                        "bounds are of the same size, so the kernel needs both pipes busy at once to approach either"}
+                "note": "frames in flight: one 1024-thread workgroup (a whole frame) per CU, 16 waves; the vector pipes "
+                        "are 76 % busy: what is left is instruction count, not stalls (double-buffering the row sums to "
+                        "halve the barriers: 4.53 vs 4.56 us; two workgroups per CU: 5.40 vs 4.51)"}
             nb64 = min(B, 1024)
             net64 = wr.WRResNetDevice(eng, weights, N_LABELS)
             pipe64 = BatchPipeline(eng, net64, n_labels=N_LABELS, fp_index=4, cnn_chunk=512, frame_size=64)

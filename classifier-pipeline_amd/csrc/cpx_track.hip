@@ -1198,7 +1198,14 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   const int RBa = RB < H ? RB : H;   // rows the launch sized the LDS for
   uint16_t* Hh = reinterpret_cast<uint16_t*>(smem + (((size_t)(RBa + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15));  // [RBa+16+BH][HS]
   // weights of a PAIR of distances in one 8-byte entry: [min(d0 >> 6, 48)][min(d1 >> 6, 48)] (entry 48 = weight 0)
+#ifdef CPX_NLM_DB
+  // double-buffered row sums: the row pass of pair q + 1 and the column pass of pair q run between the same two
+  // barriers (one barrier per pair, and waves drift between an LDS-heavy and a VALU-heavy phase)
+  uint16_t* const Hh1 = Hh + (size_t)(RBa + 16 + BH) * HS;
+  int2* s_lut2 = reinterpret_cast<int2*>(Hh1 + (size_t)(RBa + 16 + BH) * HS);  // [49][49]
+#else
   int2* s_lut2 = reinterpret_cast<int2*>(Hh + (size_t)(RBa + 16 + BH) * HS);  // [49][49]
+#endif
   const unsigned char* img = a.u8_state + ((size_t)b * 2 + (t & 1)) * P;
   unsigned char* out = a.u8_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
 
@@ -1231,8 +1238,8 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
     }
   }
 
-  for (int q = 0; q < 220; ++q) {
-    // upper half of the search window: (0, 1..10), then (1..10, -10..10)
+  // offset pair q: upper half of the search window: (0, 1..10), then (1..10, -10..10)
+  auto pass_a = [&](const int q, uint16_t* const Hh) __attribute__((always_inline)) {
     int dy, dx;
     if (q < 10) {
       dy = 0;
@@ -1303,7 +1310,16 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
         }
       }
     }
-    __syncthreads();
+  };
+  auto pass_b = [&](const int q, const uint16_t* const Hh) __attribute__((always_inline)) {
+    int dy, dx;
+    if (q < 10) {
+      dy = 0;
+      dx = q + 1;
+    } else {
+      dy = (q - 10) / 21 + 1;
+      dx = (q - 10) - (dy - 1) * 21 - 10;
+    }
     // ---- pass B: dist = sum of seven row sums; weight; accumulate -- offset d, then offset -d ----
     if (active_b) {
 #pragma unroll
@@ -1362,8 +1378,23 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
         }
       }
     }
+  };
+#ifdef CPX_NLM_DB
+  pass_a(0, Hh);
+  __syncthreads();
+  for (int q = 0; q < 220; ++q) {
+    if (q + 1 < 220) pass_a(q + 1, ((q + 1) & 1) ? Hh1 : Hh);
+    pass_b(q, (q & 1) ? Hh1 : Hh);
     __syncthreads();
   }
+#else
+  for (int q = 0; q < 220; ++q) {
+    pass_a(q, Hh);
+    __syncthreads();
+    pass_b(q, Hh);
+    __syncthreads();
+  }
+#endif
   if (active_b) {
 #pragma unroll
     for (int i = 0; i < BH; ++i) {
@@ -1384,7 +1415,12 @@ namespace {
 size_t nlm_lds_rows(int W, int rows, int bh) {
   const size_t ES = ((size_t)W + 2 * NLM_R + 8 + 7) & ~(size_t)7;
   const size_t HS = ((size_t)W + 10 + 7) & ~(size_t)7;
-  return ((((size_t)rows + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15) + ((size_t)rows + 16 + bh) * HS * 2 + NLM_LUT2 * NLM_LUT2 * 8 + 64;
+#ifdef CPX_NLM_DB
+  const size_t nbuf = 2;
+#else
+  const size_t nbuf = 1;
+#endif
+  return ((((size_t)rows + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15) + nbuf * ((size_t)rows + 16 + bh) * HS * 2 + NLM_LUT2 * NLM_LUT2 * 8 + 64;
 }
 template <int BH, int WC>
 void launch_nlm_tw(const TrackArgs& a, int B, int t, hipStream_t s) {
