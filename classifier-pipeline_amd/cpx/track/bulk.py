@@ -148,19 +148,48 @@ class DecodedGroup:
         self.slots = slots            # CPTV_SLOT_DTYPE [total]
         self.frames_dev = frames_dev  # uint16 bits [total, H, W]
 
-    def split(self, max_clips):
-        """The group in runs of at most max_clips recordings (views of the same device frames): the decode stage likes
+    def split(self, max_clips, max_frames=None):
+        """The group in runs of at most max_clips recordings and (when given) max_frames frames -- a single recording
+        longer than that still forms a run of its own -- as views of the same device frames: the decode stage likes
         thousands of files per launch (one wavefront each: its time hardly grows until the chip is full), the tracking
-        stage is sized by the memory its per-frame outputs take."""
+        stage is sized by the memory its per-frame outputs take (label + filtered image + components: ~190 KB per
+        160 x 120 frame)."""
         n = len(self.files)
-        if n <= max_clips:
+        total = int(self.offs[-1])
+        if n <= max_clips and (max_frames is None or total <= max_frames):
             yield self
             return
-        for b0 in range(0, n, max_clips):
+        b0 = 0
+        while b0 < n:
             b1 = min(n, b0 + max_clips)
+            if max_frames is not None:
+                # the longest prefix within the frame budget (at least one recording)
+                fit = int(np.searchsorted(self.offs[b0 + 1:b1 + 1], int(self.offs[b0]) + max_frames, side="right"))
+                b1 = b0 + max(fit, 1)
             f0, f1 = int(self.offs[b0]), int(self.offs[b1])
             yield DecodedGroup(self.key, self.files[b0:b1], self.headers[b0:b1], (self.offs[b0:b1 + 1] - f0).astype(np.int32),
                                self.slots[f0:f1], self.frames_dev[f0:f1])
+            b0 = b1
+
+
+def plan_decode_batches(sizes, batch_files, max_bytes):
+    """[(first, end)] runs of recordings for the decode launches: at most batch_files recordings and max_bytes of
+    compressed data each (a larger single recording forms a run of its own); the FIRST run half as large when there
+    are several -- nothing runs beside it, and a launch's time hardly falls below a lone wave's, so the pipeline fills
+    sooner than the launch loses in occupancy."""
+    n = len(sizes)
+    runs = []
+    a = 0
+    first = batch_files // 2 if (n > 2 * batch_files and batch_files >= 512) else batch_files
+    cum = np.concatenate([[0], np.cumsum(np.asarray(sizes, np.int64))])
+    while a < n:
+        cap = first if not runs else batch_files
+        b = min(n, a + cap)
+        fit = int(np.searchsorted(cum[a + 1:b + 1], cum[a] + max_bytes, side="right"))
+        b = a + max(fit, 1)
+        runs.append((a, b))
+        a = b
+    return runs
 
 
 def decode_staged(eng, staged, min_pixels=160 * 120, unpack_engine=None):
@@ -704,7 +733,8 @@ def track_predictions(r, ti, b, model_out, classify_seconds):
 
 
 def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024, want_text=False,
-                   stager=None, tracker=None, clip_classifier=None, blobs=None, track_files=1024):
+                   stager=None, tracker=None, clip_classifier=None, blobs=None, track_files=1024,
+                   decode_bytes=8 << 30, track_frames=400000):
     """extract_file -- or, with a ClipClassifier, process_file(track=True) -- for many recordings at device speed.
     Writes <file>.txt (or prints with to_stdout) and returns ({filename: metadata text (want_text) or True, or an
     "error: ..." string for a skipped file}, tracker with timings).  Files that cannot take the batched path are
@@ -730,13 +760,23 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         classifiers = [(m, clip_classifier.get_classifier(m)) for m in models]
         tracker.timings["model_load_s"] = time.time() - t0
     out = {}
-    # decode launches of batch_files recordings; the FIRST one half as large when there are several: nothing runs beside
-    # it, and a launch's time hardly falls below a lone wave's (the pipeline fills sooner than it would lose in occupancy)
+    # decode launches: at most batch_files recordings and decode_bytes of compressed data (inflated bytes + frames are
+    # 4-6 x that on the device, and three batches are alive at once); tracking groups: at most track_files recordings
+    # and track_frames frames -- ten-minute recordings do not take the device's memory with them
     n_all = len(filenames)
-    first = batch_files // 2 if (n_all > 2 * batch_files and batch_files >= 512) else batch_files
-    order = ([0] + list(range(first, n_all, batch_files)) if n_all > first else [0]) if n_all else []
-    bounds = order[1:] + [n_all]
-    batches = [filenames[a:b] for a, b in zip(order, bounds)]
+    if blobs is not None:
+        sizes = [len(b) for b in blobs]
+    else:
+        sizes = []
+        for f in filenames:
+            try:
+                sizes.append(os.path.getsize(f))
+            except OSError:
+                sizes.append(0)
+    runs = plan_decode_batches(sizes, batch_files, decode_bytes)
+    order = [a for a, _ in runs]
+    bounds = [b for _, b in runs]
+    batches = [filenames[a:b] for a, b in runs]
     # Two stages in flight: a worker thread stages batch k+1 (file reads / copies into pinned memory) and decodes it on
     # a handle of its own (its own HIP stream: upload, inflate + section index, unpack) while this thread tracks,
     # classifies and writes batch k.  The inflate kernel is bound by scalar issue and latency, the network by the matrix
@@ -905,7 +945,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + stage_s
         tracker.timings["decode_s"] += decode_s
         tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + time.time() - t0
-        groups = [sub for g in decoded.groups for sub in g.split(track_files)]
+        groups = [sub for g in decoded.groups for sub in g.split(track_files, track_frames)]
         ctx = dict(paths=paths, texts={}, retry=dict(decoded.errors), t0=t0, open=len(groups), submitted=False,
                    n_ok=sum(len(g.files) for g in decoded.groups))
         for gi, group in enumerate(groups):

@@ -196,3 +196,26 @@ def test_bulk_pipeline_is_deterministic_under_load(tmp_path):
     assert sum('"tracking_score"' in r for r in ref) >= ND // 2      # the clips do carry tracks
     differ = [names[i] for i in range(N) if norm(out[names[i]]) != ref[i % ND]]
     assert differ == [], differ[:5]
+
+
+def test_memory_budgets_split_batches_without_changing_results(golden_dir, tmp_path):
+    """Decode launches bounded by compressed bytes and tracking groups bounded by frames (directories of long
+    recordings must not take the device's memory with them): with budgets that force one recording per launch and per
+    group the metadata text of every file is what the unconstrained run writes."""
+    import re
+
+    from cpx.config import Config
+    from cpx.track.bulk import run_files_bulk
+
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    paths = [str(p) for p in _files(golden_dir, tmp_path)]
+    ref, _ = run_files_bulk(paths, cfg, save_meta=False, want_text=True)
+    tight, tr = run_files_bulk(paths, cfg, save_meta=False, want_text=True, decode_bytes=1 << 20, track_frames=100)
+    mid, _ = run_files_bulk(paths, cfg, save_meta=False, want_text=True, batch_files=3, track_files=2, track_frames=300)
+    # (the clip id is a counter of Clip objects in the process: it differs from run to run)
+    norm = lambda t: re.sub(r'^    "id": \d+,', '    "id": 0,', re.sub(r'"tracking_time": [^,\n]*', '"tracking_time": 0', t), flags=re.M)
+    for p in paths:
+        assert not ref[p].startswith("error")
+        assert norm(tight[p]) == norm(ref[p]) == norm(mid[p]), p
+    assert tr.timings["files"] == len(paths)
