@@ -845,6 +845,10 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             r = tracker.track_group(group, clips, classifiers)
         except CpxError as e:  # the whole group failed on the device: every member goes the slow way
             r = e
+        except torch.cuda.OutOfMemoryError as e:   # (budgets too generous for this device: same way out, memory released)
+            r = RuntimeError("device out of memory for a group of %d recordings / %d frames: %s"
+                             % (len(group.files), int(group.offs[-1]), str(e).splitlines()[0]))
+            torch.cuda.empty_cache()
         return clips, existing, r, time.time() - td
 
     def host_phase(ctx, group, result):
