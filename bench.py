@@ -1064,7 +1064,10 @@ def main():
                                "imbalance": cfg4["imbalance"], "records_gathered": cfg4["records_gathered"],
                                "gather_ms_per_step_rank0": cfg4["gather_ms_per_step_rank0"]}
     if extras and world == 1 and args.from_files > 0 and rank == 0:
-        line["from_files"] = bench_from_files(args, torch, np, local_rank, weights, T)
+        try:
+            line["from_files"] = bench_from_files(args, torch, np, local_rank, weights, T)
+        except Exception as e:  # noqa: BLE001 -- the headline line above is complete: report, do not lose it
+            line["from_files"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if not (extras and (world > 1 or args.from_files > 0)):
