@@ -79,6 +79,41 @@ class Direction:
     MIDDLE = 16
 
 
+class _LazyRegionHistory:
+    """clip.region_history of a batch-tracked clip: per frame the list of Region objects, built from the association's
+    region records on first access (a sequence like the list the one-video path fills)."""
+
+    def __init__(self, assoc, first, n):
+        self._assoc, self._first, self._n = assoc, first, n
+        self._made = {}
+
+    def __len__(self):
+        return self._n
+
+    def _frame(self, q):
+        regs = self._made.get(q)
+        if regs is None:
+            regs = []
+            for rec in self._assoc.frame_regions(self._first + q):
+                r = Region.from_record(rec)
+                r.centroid = [int(r.centroid[0]), int(r.centroid[1])]
+                regs.append(r)
+            self._made[q] = regs
+        return regs
+
+    def __getitem__(self, q):
+        if isinstance(q, slice):
+            return [self._frame(i) for i in range(*q.indices(self._n))]
+        if q < 0:
+            q += self._n
+        if not 0 <= q < self._n:
+            raise IndexError(q)
+        return self._frame(q)
+
+    def __iter__(self):
+        return (self._frame(q) for q in range(self._n))
+
+
 class IRTrackExtractor(ClipTracker):
     PREVIEW = "preview"
     VERSION = 10
@@ -309,16 +344,9 @@ class IRTrackExtractor(ClipTracker):
                           int(rec["filtered_sum"]))
                 clip.ffc_affected = False
                 clip.add_frame(None, None, None, False, stats=sv)
-            f0 = v * T
-            regions_per_frame = []
-            for q in range(lens[v]):
-                regs = []
-                for rec in assoc.frame_regions(f0 + q):
-                    r = Region.from_record(rec)
-                    r.centroid = [int(r.centroid[0]), int(r.centroid[1])]
-                    regs.append(r)
-                regions_per_frame.append(regs)
-            clip.region_history = regions_per_frame
+            # (Region objects of the per-frame region lists are made when somebody reads them: thousands per clip,
+            # and most callers only want the tracks)
+            clip.region_history = _LazyRegionHistory(assoc, v * T, lens[v])
             tracks = []
             for rec, regs in assoc.clip_tracks(v):
                 track = Track.from_device(clip, rec, regs, self.tracker_version, self.config)
