@@ -231,3 +231,86 @@ def test_ir_frame_statistics_match_numpy(engine, shape, with_mask):
         assert got["sum"][i] / frames[i].size == np.nanmean(frames[i])
         assert got["filtered_sum"][i] == (int(masks[i].sum(dtype=np.int64)) if with_mask else 0)
     assert np.array_equal(hist.cpu().numpy(), np.stack([np.bincount(f.ravel(), minlength=256) for f in frames]))
+
+
+def test_ir_merge_kernel_matches_oracle_on_fragment_soups(engine):
+    """cpx_ir_merge through the C ABI against oracle/ir_oracle.merge_components (pinned by the reference-run golden
+    above) + np.var of the uint8-wrapping frame difference: hundreds of fragments per frame -- chains of merges,
+    restarts, rows sharing the anchor's x (never merged), equal areas (stable order), everything filtered, nothing
+    filtered -- for several streams in one launch, with and without a previous frame."""
+    import ctypes as C
+
+    import torch
+
+    import ir_oracle as iro
+    from cpx._lib import COMPONENT_DTYPE, FRAME_INFO_DTYPE
+
+    W, H, cap_in, cap_out, T = 640, 480, 512, 512, 5
+    rng = np.random.default_rng(21)
+    sets = []
+    for kind in range(8):
+        n = [0, 1, 40, 200, 400, 60, 120, 300][kind]
+        rows = []
+        for _ in range(n):
+            w, h = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+            if kind == 5:
+                w = h = int(rng.integers(1, 6))                       # nothing survives the small-fragment filter
+            x, y = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+            if kind == 6:
+                x = 8 * int(rng.integers(0, 10))                      # many rows share an x: the reference never merges those
+            area = int(rng.integers(1, w * h + 1)) if kind != 7 else 50   # kind 7: equal areas (stable sort)
+            rows.append([x, y, w, h, area])
+        sets.append(rows)
+    V = len(sets)
+    comps = np.zeros((V, cap_in), COMPONENT_DTYPE)
+    counts = np.zeros(V, np.int32)
+    for v, rows in enumerate(sets):
+        counts[v] = len(rows)
+        for k, r in enumerate(rows):
+            comps[v, k] = (r[0], r[1], r[2], r[3], r[4], 0, 0, 0.0)
+    cur = rng.integers(0, 256, (V, H, W), dtype=np.uint8)
+    prev = rng.integers(0, 256, (V, H, W), dtype=np.uint8)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(engine.device)
+    comps_d, counts_d, cur_d, prev_d = to(comps), to(counts), to(cur), to(prev)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    for use_prev, q in ((True, 3), (False, 0)):
+        out_c = torch.zeros(V * T * cap_out * 32, dtype=torch.uint8, device=engine.device)
+        out_i = torch.zeros(V * T * 80, dtype=torch.uint8, device=engine.device)
+        status = torch.full((V,), 7, dtype=torch.int32, device=engine.device)
+        torch.cuda.synchronize()
+        rc = engine.lib.cpx_ir_merge(engine.h, p(comps_d), p(counts_d), V, cap_in, cap_out, p(cur_d),
+                                     p(prev_d) if use_prev else None, W, H, q, T, p(out_c), p(out_i), p(status))
+        assert rc == 0, engine._err()
+        engine.synchronize()
+        assert status.cpu().numpy().tolist() == [0] * V
+        got_c = out_c.cpu().numpy().view(COMPONENT_DTYPE).reshape(V * T, cap_out)
+        got_i = out_i.cpu().numpy().view(FRAME_INFO_DTYPE).reshape(V * T)
+        for v, rows in enumerate(sets):
+            want = iro.merge_components([np.array(r) for r in rows])
+            row = v * T + q
+            assert int(got_i["n_components"][row]) == len(want) and int(got_i["frame_number"][row]) == q, (v, len(want))
+            g = got_c[row, :len(want)]
+            for k, m in enumerate(want):
+                x, y, w, h, area = (int(t) for t in m[:5])
+                assert (int(g["x"][k]), int(g["y"][k]), int(g["width"][k]), int(g["height"][k]), int(g["area"][k])) == (x, y, w, h, area), (v, k)
+                # the tracker's centroid: the truncated box centre (sum_x / area on the device record)
+                assert int(g["sum_x"][k]) == int(x + w / 2) * area and int(g["sum_y"][k]) == int(y + h / 2) * area
+                var = 0.0
+                if use_prev:
+                    x1, y1 = min(x + w, W), min(y + h, H)
+                    d = (cur[v, y:y1, x:x1] - prev[v, y:y1, x:x1]).astype(np.float64)   # uint8 arithmetic wraps first
+                    var = float(np.var(d)) if d.size else 0.0
+                assert abs(float(g["pixel_variance"][k]) - var) <= 1e-5 * max(1.0, var), (v, k)
+    # more rows surviving the small-fragment filter than the output capacity (the kernel's working set): reported for
+    # that stream alone, never truncated
+    survivors = [sum(1 for r in rows if r[4] > 40 or (r[2] > 16 and r[3] > 16)) for rows in sets]
+    small_cap = 128
+    assert any(n > small_cap for n in survivors) and any(0 < n <= small_cap for n in survivors)
+    st = torch.zeros(V, dtype=torch.int32, device=engine.device)
+    oc = torch.zeros(V * T * small_cap * 32, dtype=torch.uint8, device=engine.device)
+    torch.cuda.synchronize()
+    rc = engine.lib.cpx_ir_merge(engine.h, p(comps_d), p(counts_d), V, cap_in, small_cap, p(cur_d), None, W, H, 0, T,
+                                 p(oc), None, p(st))
+    assert rc == 0, engine._err()
+    engine.synchronize()
+    assert st.cpu().numpy().tolist() == [-5 if n > small_cap else 0 for n in survivors]
