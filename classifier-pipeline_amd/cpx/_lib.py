@@ -76,7 +76,7 @@ CPTV_BACKGROUND_FRAME, CPTV_HAS_TIME_ON, CPTV_HAS_LAST_FFC = 1, 2, 4
 CPTV_STATUS = {1: "deflate: reserved block type", 2: "deflate: stored block length", 3: "deflate: block header",
                4: "deflate: code lengths", 5: "deflate: invalid symbol", 6: "deflate: distance too far back",
                7: "inflated data larger than the gzip trailer says", 8: "deflate: input exhausted (truncated file)",
-               9: "deflate: no end-of-block code", 10: "not a gzip member", 11: "gzip trailer / further member",
+               9: "deflate: no end-of-block code", 10: "not a gzip member", 11: "gzip trailer / further member", 12: "gzip CRC-32 mismatch",
                20: "not a CPTV file", 21: "unsupported CPTV version", 22: "CPTV header section", 23: "expected frame section",
                24: "truncated CPTV frame", 25: "malformed CPTV frame section", 26: "more frames than slots",
                27: "CPTV file has no frames"}

@@ -28,6 +28,7 @@ namespace {
 constexpr int WAVES_PER_WG = 1;
 constexpr int ERR_GZIP_HEADER = 10;
 constexpr int ERR_GZIP_TRAILER = 11;
+constexpr int ERR_GZIP_CRC = 12;
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -37,6 +38,7 @@ __device__ __forceinline__ long rfl64(long v) {
 }
 
 struct WaveLds {
+  uint32_t crc_tab[256];   // CRC-32 byte table (built by the wave after the last block)
   uint16_t ll[infl::LL_ENOUGH];
   uint16_t dt[infl::D_ENOUGH];
   uint16_t work[infl::WORK_SCRATCH];
@@ -493,6 +495,74 @@ struct WaveIO {
   }
 };
 
+// ---- CRC-32 of the inflated bytes (RFC 1952: IEEE polynomial, reflected) by the file's own wave ----
+// Lane k runs the byte-table recurrence over chunk k of the output (64 chunks of L bytes, L a multiple of 4); the 64
+// partial states are folded in order with the operator "advance the state through L zero bytes" -- a 32 x 32 matrix over
+// GF(2) kept one column per lane (lanes 32-63 mirror 0-31), built by squaring like zlib's crc32_combine.
+__device__ __forceinline__ uint32_t xor_reduce32(uint32_t v) {   // over each half's 32 lanes -> every lane
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v ^= (uint32_t)__shfl_xor((int)v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t gf2_times(uint32_t col, uint32_t vec, int lane) {   // matrix (columns on lanes) x vec
+  return xor_reduce32(((vec >> (lane & 31)) & 1u) ? col : 0u);
+}
+__device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b, int lane) {          // a x b: column i = a x (column i of b)
+  uint32_t out = 0;
+  for (int i = 0; i < 32; ++i) {
+    const uint32_t r = gf2_times(a, (uint32_t)__builtin_amdgcn_readlane((int)b, i), lane);
+    if ((lane & 31) == i) out = r;
+  }
+  return out;
+}
+__device__ __forceinline__ uint32_t gf2_zero_bytes(long n, int lane) {   // the operator for n zero bytes
+  const int c = lane & 31;
+  uint32_t base = c == 0 ? 0xEDB88320u : (1u << (c - 1));   // one zero BIT
+  base = gf2_mul(base, base, lane);                         // 2 bits
+  base = gf2_mul(base, base, lane);                         // 4
+  base = gf2_mul(base, base, lane);                         // 8 = one byte
+  uint32_t res = 1u << c;                                   // identity
+  while (n > 0) {                                           // (uniform)
+    if (n & 1) res = gf2_mul(base, res, lane);
+    n >>= 1;
+    if (n > 0) base = gf2_mul(base, base, lane);
+  }
+  return res;
+}
+__device__ uint32_t wave_crc32(const uint8_t* data, long n, uint32_t* tab, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t c = (uint32_t)(lane * 4 + k);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    tab[lane * 4 + k] = c;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the table is this wave's own
+  const long L = (((n + 63) >> 6) + 3) & ~3l;               // chunk length (the same for every lane but the last used)
+  const long lo = (long)lane * L;
+  const long len = lo >= n ? 0 : (n - lo < L ? n - lo : L);
+  uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(data + lo);
+  const long nw = len >> 2;
+  for (long j = 0; j < nw; ++j) {
+    const uint32_t v = w[j];
+    c = tab[(c ^ v) & 0xFFu] ^ (c >> 8);
+    c = tab[(c ^ (v >> 8)) & 0xFFu] ^ (c >> 8);
+    c = tab[(c ^ (v >> 16)) & 0xFFu] ^ (c >> 8);
+    c = tab[(c ^ (v >> 24)) & 0xFFu] ^ (c >> 8);
+  }
+  for (long j = nw << 2; j < len; ++j) c = tab[(c ^ data[lo + j]) & 0xFFu] ^ (c >> 8);
+  // fold: state = U_len(k)(state) ^ partial(k), k = 1 .. last used chunk
+  const int used = (int)rfl((int)((n + L - 1) / (L > 0 ? L : 1)));       // chunks that hold bytes (n > 0 here)
+  const long last_len = n - (long)(used - 1) * L;
+  const uint32_t op_full = gf2_zero_bytes(L, lane);
+  const uint32_t op_last = last_len == L ? op_full : gf2_zero_bytes(last_len, lane);
+  uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
+  for (int k = 1; k < used; ++k)
+    acc = gf2_times(k == used - 1 ? op_last : op_full, acc, lane) ^ (uint32_t)__builtin_amdgcn_readlane((int)c, k);
+  return acc ^ 0xFFFFFFFFu;
+}
+
 struct GlobalBytes {
   const uint8_t* p;
   __device__ __forceinline__ uint32_t u8(long i) const { return (uint32_t)rfl((int)p[i]); }  // every lane reads the same byte
@@ -582,6 +652,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 6) void cpx_cptv_inflate_kernel(
         GlobalBytes gb{file};
         const uint32_t isize = gb.u8(used + 4) | (gb.u8(used + 5) << 8) | (gb.u8(used + 6) << 16) | (gb.u8(used + 7) << 24);
         if (isize != (uint32_t)n_out) status = ERR_GZIP_TRAILER;
+        else if (n_out > 0) {
+          const uint32_t want = gb.u8(used) | (gb.u8(used + 1) << 8) | (gb.u8(used + 2) << 16) | (gb.u8(used + 3) << 24);
+          __builtin_amdgcn_s_waitcnt(0);
+          if (wave_crc32(out, n_out, io.lds->crc_tab, lane) != want) status = ERR_GZIP_CRC;
+        }
       }
     }
   }

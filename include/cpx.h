@@ -237,7 +237,9 @@ int cpx_cptv_unpack(cpx_handle* h, const uint8_t* payload_dev, const int64_t* fr
  * results_dev   [B]
  * Status values: 0 ok; 1-9 DEFLATE errors (block type, stored length, code lengths, table, symbol, distance, output
  * capacity, input exhausted, no end-of-block code); 10 gzip header; 11 data after the member's trailer / ISIZE mismatch
- * (a multi-member file: inflate it on the host); 20-27 CPTV section errors (magic, version, header, section tag,
+ * (a multi-member file: inflate it on the host); 12 the CRC-32 of the inflated bytes differs from the trailer's (computed
+ * by the file's own wave: byte-table recurrence per lane over 64 chunks, folded with the zero-bytes operator of
+ * crc32_combine); 20-27 CPTV section errors (magic, version, header, section tag,
  * truncated, frame fields, slots, no frames).  Asynchronous on the handle's stream. */
 #define CPX_CPTV_HEADER_BYTES 1024
 #define CPX_CPTV_BACKGROUND_FRAME 1u

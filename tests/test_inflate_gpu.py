@@ -161,3 +161,25 @@ def test_match_shapes_against_zlib(engine):
         assert int(got.results["out_bytes"][k]) == len(data), k
         o = int(got.files["out_offset"][k])
         assert raw[o:o + len(data)].tobytes() == data, k
+
+
+def test_gzip_crc_is_checked_on_the_device(engine):
+    """A stream that inflates cleanly and matches ISIZE but carries other bytes than its CRC-32 says (a flipped bit inside
+    a stored block, or a wrong CRC field) is refused with status 12 -- what zlib / the reference's gzip reader do --
+    while its neighbours decode; sizes around the 64-chunk split (1 ... 300 bytes, odd lengths) are covered."""
+    from cpx.cptv import inflate_files_on_device
+
+    good = fixture("hedgehog")
+    data = zlib.decompress(good, 47)
+    stored = regzip(data, level=0)                       # stored blocks: payload bytes sit in the file as they are
+    flipped = bytearray(stored)
+    flipped[len(stored) // 2] ^= 0x10                    # a payload byte (block headers are 5 bytes every 64 KiB)
+    bad_field = bytearray(good)
+    bad_field[-8] ^= 0x01                                # the CRC field itself
+    small = [regzip(bytes((7 * i + 3) & 0xFF for i in range(n))) for n in (1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 300)]
+    blobs = [good, bytes(flipped), bytes(bad_field), stored] + small
+    got = inflate_files_on_device(engine, blobs, names=["c%d" % i for i in range(len(blobs))])
+    st = [int(x) for x in got.results["status"]]
+    assert st[0] == 0 and st[3] == 0 and got.ok == [0, 3]
+    assert st[1] == 12 and st[2] == 12, st[:4]
+    assert st[4:] == [20] * len(small), st[4:]           # CRC fine (else 12); not recordings
