@@ -92,7 +92,8 @@ def test_directory_drivers_write_the_same_files(golden_dir, tmp_path):
 
 
 def test_directory_driver_isolates_bad_recordings(golden_dir, tmp_path, caplog):
-    """A truncated recording, a corrupt one, a file that is not gzip and an empty file in the directory: each is logged
+    """A truncated recording, a corrupt one, one whose only defect is the gzip CRC, a file that is not gzip and an empty
+    file in the directory: each is logged
     and skipped; every other recording gets the metadata it gets on its own."""
     import logging
 
@@ -114,6 +115,13 @@ def test_directory_driver_isolates_bad_recordings(golden_dir, tmp_path, caplog):
     for _ in range(60):
         flipped[int(rng.integers(200, len(flipped) - 8))] ^= 0x5A
     (b / "bad_flipped.cptv").write_bytes(bytes(flipped))
+    # decodes cleanly, sizes agree -- only the gzip CRC-32 tells that a payload bit flipped (stored blocks)
+    import zlib
+
+    comp = zlib.compressobj(0, zlib.DEFLATED, 31)
+    stored = bytearray(comp.compress(zlib.decompress(raw, 47)) + comp.flush())
+    stored[len(stored) // 2] ^= 0x04
+    (b / "bad_crc.cptv").write_bytes(bytes(stored))
     (b / "bad_text.cptv").write_bytes(b"this is not a recording\n" * 10)
     (b / "bad_empty.cptv").write_bytes(b"")
     for p in sorted(a.glob("*.cptv")):
@@ -121,7 +129,7 @@ def test_directory_driver_isolates_bad_recordings(golden_dir, tmp_path, caplog):
     ex = TrackExtractor(cfg)
     with caplog.at_level(logging.WARNING):
         ex.extract(b)
-    for name in ("bad_truncated", "bad_text", "bad_empty"):
+    for name in ("bad_truncated", "bad_flipped", "bad_crc", "bad_text", "bad_empty"):
         assert not (b / (name + ".txt")).exists(), name
         assert any(name in r.getMessage() for r in caplog.records), name
     for p in sorted(a.glob("*.txt")):
