@@ -78,6 +78,7 @@ constexpr int KC = 16;  // channels per K step of the bf16 MFMA = per staged chu
 struct TileDiv {
   unsigned long long m_nsplit, m_tx, m_ty;
   int nsplit, tiles_x, tiles_y;
+  int run;  // conv_bf3w_kernel: tiles per workgroup along x (tiles_x then counts runs)
 };
 __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)n * m) >> 42); }
 
@@ -86,7 +87,8 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
 // instead of two channel halves: lanes 0-31 (k half 0) read tap 2 s, lanes 32-63 tap 2 s + 1 of the same 8-channel
 // entry array -- five steps for the nine taps (the tenth tap has zero weights) instead of nine half-empty ones.
 template <int NTN, int S, int NB, int TW, int CT, bool C8>
-__global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT >= 1024 ? 4 : CT / 128, CT >= 1024 ? 4 : CT / 128))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+// (the strided forms fill the LDS with one workgroup: their waves may use the registers of the absent second one)
+__global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128), S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128)))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3;
   constexpr int WSETS = CT / 256;    // sets of four waves
   constexpr int NTM = NB / WSETS;    // bands per wave
@@ -649,6 +651,303 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_bf3w_kernel: the stride-1 3x3 layers with 32 / 64 channels per group on v_mfma_f32_16x16x32_bf16.
+//
+// Why a second MFMA shape: the split-operand loop is bound by the clock the chip holds under it, not by issue slots
+// (profiles/r01_conv_power_probe.md), and the chip holds a higher clock on the 16x16x32 form: scratch/mfma_shape_probe.hip
+// (this kernel's inner loop alone, operands re-read from LDS, random planes) runs 284 TFLOP/s at 1.70 GHz with
+// 32x32x16 and 327 TFLOP/s at 1.97 GHz with 16x16x32, at equal cycles (profiles/r04_mfma_shape_probe.txt).
+//
+// K = 32 per instruction = the 32 channels of one tap, so the staged chunk is 32 channels: the patch (18 x 18 pixels of a
+// 16 x 16 tile) is committed once per 32 channels, the weights in sub-chunks of one kernel ROW (3 taps x 32 channels x
+// 32 columns x 3 planes = 18 KB) so that patch + weights stay at 79 KB and two workgroups share a CU.
+//   patch   LDS [plane][quarter pair][pixel][2] of 16-byte entries (8 channels): the 32 bytes of a pixel's quarter
+//           pair are adjacent, which makes ds_read_b128 conflict-free in its lane groups ({0-3,12-15,20-27}, ...: one
+//           k quarter's pixels 0-3 / 12-15 and the next quarter's 4-11 tile a 256-byte bank period exactly)
+//   weights LDS [plane][kx][quarter][column]; device image [g][chunk][ky][plane][kx][quarter][cout_g]
+// The roles of the operands are swapped (A = weights: M = output channels; B = pixels: N = pixels), so a lane's four
+// accumulator values are four CONSECUTIVE channels of one pixel: the residual preload, the affine and the store are
+// one 16-byte access per accumulator tile straight from the registers -- no transpose through LDS, no epilogue barrier.
+// A wave owns two tile rows (2 x 16 pixels) x 32 columns = 2 x 2 accumulator tiles; 12 ds_read_b128 feed 24 MFMAs.
+constexpr int KW = 32;
+#ifndef CPX_BF3W_RUN
+#define CPX_BF3W_RUN 1  // tiles a workgroup walks along x (launch_bf3w)
+#endif
+#ifndef CPX_BF3W_LDSBN
+#define CPX_BF3W_LDSBN 0
+#endif
+constexpr int W_TW = 16, W_TH = 16, W_PW = 18, W_NPX = 18 * 18;
+constexpr int W_NPXP = 326;  // pixels per (plane, quarter pair) region: 326 * 32 B = 64 mod 128, the two regions' ds_write_b64 lanes then use different banks
+constexpr int W_PATCH = 3 * 2 * W_NPXP * 2;  // entries
+constexpr int W_WSUB = 3 * 3 * 4 * 32;       // entries of a weight sub-chunk (one kernel row)
+// WALK: the workgroup walks a run of td.run tiles along x (else exactly one tile: the loop and the per-use
+// laundering of the staging bases fold away); LDSBN: BatchNorm scale / shift read back from LDS at each patch commit
+// instead of living in eight registers
+template <bool WALK, bool LDSBN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf3w_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+  constexpr int CT = 512;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  uint4* s_patch = lds4;
+  uint4* s_w = lds4 + W_PATCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-contiguous tiles (cpx_cnn.hip)
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  int qd = div_magic(bid, td.m_nsplit);
+  const int ns = bid - qd * td.nsplit;
+  bid = qd;
+  qd = div_magic(bid, td.m_tx);
+  const int txr = bid - qd * td.tiles_x;  // run of td.run consecutive tiles of one tile row (td.tiles_x counts runs)
+  bid = qd;
+  qd = div_magic(bid, td.m_ty);
+  const int tyi = bid - qd * td.tiles_y;
+  const int n = qd;
+  const int g = blockIdx.y;
+  const int oy0 = tyi * W_TH;
+  const int iy0 = oy0 - a.pad_top;
+  const int run = WALK ? td.run : 1;
+  const int tx_end = WALK ? min((txr + 1) * run, (a.Wo + W_TW - 1) / W_TW) : txr + 1;
+  const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
+  const int nch = cin_g / KW;
+  const uint4* wg = wimg + (size_t)g * nch * (3 * 36) * cout_g + (size_t)ns * 32;
+  const int a_base = ((q >> 1) * W_NPXP + (2 * wave) * W_PW + i16) * 2 + (q & 1);
+  const int b_base = q * 32 + i16;
+  // Staging items: ONE 16-byte piece (4 channels) of a patch pixel's 32-channel chunk, the eight pieces of a pixel on
+  // adjacent lanes (a wave's load instruction covers whole 128-byte pixel runs): item tid + 512 i = pixel
+  // (tid >> 3) + 64 i, piece tid & 7.  2592 items = 5 per thread and a sixth for threads 0..31: an even share of the
+  // BatchNorm / split work per SIMD (a row-aligned mapping that spares the division was measured 10 % slower:
+  // three SIMDs then carry six items per wave and one carries three).
+  constexpr int NITEM = W_NPX * 8;
+  constexpr int NP = (NITEM + CT - 1) / CT;
+  constexpr int NWI = (W_WSUB + CT - 1) / CT;
+  const int my_q8 = tid & 7;
+  const int st_e2 = ((my_q8 >> 2) * W_NPXP + (tid >> 3)) * 4 + (my_q8 & 3);  // uint2 slot of item 0, plane 0; an item further = 64 pixels
+  u32x4 pre_p[NP];
+  u32x4 pre_w[NWI];
+  // BatchNorm scale / shift of the group's input channels: staged once per workgroup (read back at each patch commit
+  // instead of living in eight registers across the phases)
+  f32x4* s_bn = reinterpret_cast<f32x4*>(lds4 + W_PATCH + W_WSUB);
+  f32x4 psc_r, psh_r;  // (!LDSBN)
+  if (LDSBN && a.in_scale) {
+    if (tid < cin_g) {
+      reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g * cin_g + tid];
+      reinterpret_cast<float*>(s_bn)[cin_g + tid] = a.in_shift[g * cin_g + tid];
+    }
+    __syncthreads();
+  }
+  // (the per-thread bases are laundered at every use: left visible, the compiler keeps one address register per
+  // staged item alive -- and stepping -- across all phases, and the prefetched pieces themselves go to scratch)
+#define BF3W_ISSUE_W(C_, R_)                                                                              \
+  {                                                                                                       \
+    const uint4* wc = wg + (size_t)(((C_) * 3 + (R_)) * 36) * cout_g;                                     \
+    unsigned woff = (unsigned)((tid >> 5) * cout_g + (tid & 31)) << 4;                                    \
+    if (WALK) asm volatile("" : "+v"(woff));                                                              \
+    _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                     \
+      /* item tid + 512 i = 16 i rows further down; the last slice (rows 32..35) exists for tid < 128 only */ \
+      const unsigned wo = (i == NWI - 1 && (W_WSUB % CT) != 0) ? (tid < (W_WSUB % CT) ? woff + ((unsigned)(16 * i * cout_g) << 4) : woff) : woff + ((unsigned)(16 * i * cout_g) << 4); \
+      pre_w[i] = *at_off(reinterpret_cast<const u32x4*>(wc), wo);                                         \
+    }                                                                                                     \
+  }
+  // (branch-free, clamped addresses: see conv_bf3_kernel; out-of-image pixels are zeroed at commit)
+#define BF3W_ISSUE_P(C_, IX0_)                                                                            \
+  {                                                                                                       \
+    int t8 = tid >> 3;                                                                                    \
+    if (WALK) asm volatile("" : "+v"(t8));                                                                \
+    if (!LDSBN) {                                                                                         \
+      const int ch = g * cin_g + (C_) * KW;                                                               \
+      const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);             \
+      const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);             \
+      unsigned qoff = (unsigned)my_q8 << 4;                                                               \
+      asm volatile("" : "+v"(qoff));                                                                      \
+      psc_r = *reinterpret_cast<const f32x4*>(at_off(scp, qoff));                                         \
+      psh_r = *reinterpret_cast<const f32x4*>(at_off(shp, qoff));                                         \
+    }                                                                                                     \
+    const unsigned coff = (unsigned)((C_) * KW + 4 * my_q8);                                              \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                      \
+      const int px = min(t8 + 64 * i, W_NPX - 1);                                                         \
+      const int py = (px * 3641) >> 16, pxx = px - py * W_PW; /* px / 18 for px < 324 */                  \
+      const int cy = min(max(iy0 + py, 0), a.H - 1), cx = min(max((IX0_) + pxx, 0), a.W - 1);             \
+      pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, a.Cin) + coff) << 2)); \
+    }                                                                                                     \
+  }
+  BF3W_ISSUE_W(0, 0)
+  BF3W_ISSUE_P(0, txr * run * W_TW - a.pad_left)
+  // The workgroup walks a run of tiles along x: the next tile's patch and first weights are in flight under the
+  // current tile's products exactly as the next chunk's are, so only the first tile of a run waits for its loads
+  // with nothing else to do (the other workgroup of the CU aside).
+  for (int txi = txr * run; txi < tx_end; ++txi) {
+  const int ox0 = txi * W_TW, ix0 = ox0 - a.pad_left;
+  const bool interior = iy0 >= 0 && iy0 + 18 <= a.H && ix0 >= 0 && ix0 + 18 <= a.W;
+  const bool full_tile = oy0 + W_TH <= a.Ho && ox0 + W_TW <= a.Wo;
+
+  // this lane's two pixels (tile rows 2 wave, 2 wave + 1; column i16) and its channel quad inside a 16-column tile
+  const int ch_l = g * cout_g + ns * 32 + 4 * q;
+  unsigned opix[2];  // element offsets of the (clamped) pixels in the output map
+  bool ovalid[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int oy = oy0 + 2 * wave + pt, ox = ox0 + i16;
+    ovalid[pt] = full_tile || (oy < a.Ho && ox < a.Wo);
+    opix[pt] = pix_off(min(oy, a.Ho - 1), min(ox, a.Wo - 1), a.Wo, a.Cout) + (unsigned)ch_l;
+  }
+  const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;  // see conv_bf3_kernel
+  f32x4 acc[2][2];
+  if (res_in_acc) {
+    const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 16u * ct) << 2));
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+
+  for (int c = 0; c < nch; ++c) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if (c > 0 || r > 0 || txi > txr * run) __syncthreads();  // every wave has read the previous phase's fragments
+      // ---- registers -> LDS: the kernel row's weights (a straight copy) ----
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        const int item = tid + i * CT;
+        if (item < W_WSUB) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
+      }
+      if (r == 0) {
+        // ---- the chunk's patch: BatchNorm + ReLU prologue, padding zeroed, split into bf16 planes ----
+        {
+          f32x4 psc = psc_r, psh = psh_r;
+          if (LDSBN && a.in_scale) {
+            psc = s_bn[c * 8 + my_q8];
+            psh = s_bn[(cin_g >> 2) + c * 8 + my_q8];
+          }
+          int t8 = tid >> 3;
+          if (WALK) asm volatile("" : "+v"(t8));
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            if (i * CT + CT <= NITEM || tid < NITEM - i * CT) {
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);
+              if (a.in_scale) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(__fmaf_rn(v[j], psc[j], psh[j]), 0.0f);
+              }
+              if (!interior) {  // (uniform: most tiles skip the selects)
+                const int px = t8 + 64 * i;
+                const int py = (px * 3641) >> 16, pxx = px - py * W_PW;
+                const bool inside = (unsigned)(iy0 + py) < (unsigned)a.H && (unsigned)(ix0 + pxx) < (unsigned)a.W;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
+              }
+              unsigned q0[2], q1[2], q2[2];
+              split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
+              split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
+              // channels 4 q8 .. 4 q8 + 3 of the chunk: quarter pair q8 >> 2, 8-byte slot q8 & 3 of the pixel's 32 bytes
+              uint2* sp2 = reinterpret_cast<uint2*>(s_patch) + st_e2 + i * (64 * 4);
+              sp2[(0 * 2 * W_NPXP) * 4] = make_uint2(q0[0], q0[1]);
+              sp2[(1 * 2 * W_NPXP) * 4] = make_uint2(q1[0], q1[1]);
+              sp2[(2 * 2 * W_NPXP) * 4] = make_uint2(q2[0], q2[1]);
+            }
+          }
+        }
+      }
+      // ---- global -> registers for what comes next (in flight under this phase's products) ----
+      if (r < 2) {
+        BF3W_ISSUE_W(c, r + 1)
+      } else if (c + 1 < nch) {
+        BF3W_ISSUE_W(c + 1, 0)
+      } else if (txi + 1 < tx_end) {
+        BF3W_ISSUE_W(0, 0)
+      }
+      if (r == 0) {
+        if (c + 1 < nch) {
+          BF3W_ISSUE_P(c + 1, ix0)
+        } else if (txi + 1 < tx_end) {
+          BF3W_ISSUE_P(0, ix0 + W_TW)
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        bf16x8 xv[2][3], wv[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+            xv[pt][p] = __builtin_bit_cast(bf16x8, s_patch[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(bf16x8, s_w[(p * 3 + kx) * 128 + b_base + 16 * ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            // smallest terms first, as conv_bf3_kernel (x = activation planes, w = weight planes)
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][1], acc[ct][pt], 0, 0, 0);
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][2], xv[pt][0], acc[ct][pt], 0, 0, 0);
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][2], acc[ct][pt], 0, 0, 0);
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][0], acc[ct][pt], 0, 0, 0);
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][1], acc[ct][pt], 0, 0, 0);
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][0], acc[ct][pt], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // ---- fused 1x1 shortcut (see conv_bf3_kernel), on v_mfma_f32_16x16x4_f32: A = weights [column][k], B = pixels ----
+  if (a.sc_in) {
+    const int sc_cg = a.sc_cin / a.groups;
+    const float* wsc = a.sc_w + ((size_t)g * sc_cg + q) * cout_g + ns * 32 + i16;
+    const float* pin[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int oy = min(oy0 + 2 * wave + pt, a.Ho - 1), ox = min(ox0 + i16, a.Wo - 1);
+      pin[pt] = a.sc_in + (((size_t)n * a.sc_H + oy * a.sc_stride) * a.sc_W + ox * a.sc_stride) * a.sc_cin + g * sc_cg + q;
+    }
+    for (int k4 = 0; k4 < sc_cg; k4 += 4) {
+      float xs[2], ws[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) xs[pt] = pin[pt][k4];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) ws[ct] = wsc[(size_t)k4 * cout_g + 16 * ct];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[ct], xs[pt], acc[ct][pt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: affine, residual, ReLU and one 16-byte store per accumulator tile, straight from the registers ----
+  float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
+  const float* res_n = (a.residual && !res_in_acc) ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int ch = ch_l + 16 * ct;
+    f32x4 os = {1.0f, 1.0f, 1.0f, 1.0f}, ob = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.out_scale) os = *reinterpret_cast<const f32x4*>(a.out_scale + ch);
+    if (a.out_shift) ob = *reinterpret_cast<const f32x4*>(a.out_shift + ch);
+    if (a.sc_in && a.sc_bias) ob += *reinterpret_cast<const f32x4*>(a.sc_bias + ch);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      f32x4 v = acc[ct][pt] * os + ob;
+      const unsigned o = (opix[pt] + 16u * ct) << 2;
+      if (res_n) v += *reinterpret_cast<const f32x4*>(at_off(res_n, o));
+      if (a.relu) {
+        v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+      }
+      if (ovalid[pt]) *reinterpret_cast<f32x4*>(at_off(out_n, o)) = v;
+    }
+  }
+  }  // tiles of the run
+}
+#undef BF3W_ISSUE_W
+#undef BF3W_ISSUE_P
+
 template <int NTN, int NPXC>
 int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = ((size_t)6 * NPXC + (size_t)54 * 32 * NTN) * 16;
@@ -737,6 +1036,65 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
+// packed float32 weights [g][tap][cin_g][cout_g] -> [g][chunk of 32][ky][plane][kx][quarter][cout_g] of 16-byte entries
+// (conv_bf3w_kernel: a (chunk, ky) sub-chunk is 36 rows of cout_g entries)
+__global__ __launch_bounds__(256) void split_weights32_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
+                                                              int cin_g, int cout_g) {
+  const int nch = cin_g / KW;
+  const size_t total = (size_t)groups * nch * 9 * 4 * cout_g;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    const int col = (int)(r % cout_g);
+    r /= cout_g;
+    const int qq = (int)(r & 3);
+    r >>= 2;
+    const int kx = (int)(r % 3);
+    r /= 3;
+    const int ky = (int)(r % 3);
+    r /= 3;
+    const int chunk = (int)(r % nch);
+    const int g = (int)(r / nch);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = w[(((size_t)g * 9 + ky * 3 + kx) * cin_g + chunk * KW + 8 * qq + j) * cout_g + col];
+    uint4 p0, p1, p2;
+    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+    const size_t base = (((size_t)g * nch + chunk) * 3 + ky) * 36 * cout_g;
+    out[base + ((size_t)(0 * 3 + kx) * 4 + qq) * cout_g + col] = p0;
+    out[base + ((size_t)(1 * 3 + kx) * 4 + qq) * cout_g + col] = p1;
+    out[base + ((size_t)(2 * 3 + kx) * 4 + qq) * cout_g + col] = p2;
+  }
+}
+
+static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
+  const size_t lds = (size_t)(W_PATCH + W_WSUB) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
+  static bool lds_ready[64];
+  constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN>), lds_ready, 160 * 1024 - 1024)) return -1;
+  TileDiv td;
+  const int tx = (a.Wo + W_TW - 1) / W_TW;
+  // tiles per workgroup: the largest of CPX_BF3W_RUN .. 2 that divides the tiles of a row, else the whole row if it is short
+  int run = 1;
+  for (int r = CPX_BF3W_RUN; r >= 2; --r)  // (never entered at CPX_BF3W_RUN = 1)
+    if (tx % r == 0) { run = r; break; }
+  if (run == 1 && tx <= CPX_BF3W_RUN) run = tx;
+  td.run = run;
+  td.tiles_x = (tx + run - 1) / run;
+  td.tiles_y = (a.Ho + W_TH - 1) / W_TH;
+  td.nsplit = (a.Cout / a.groups) / 32;
+  const long long blocks = (long long)td.tiles_x * td.tiles_y * a.N * td.nsplit;
+  if (blocks >= (1 << 22) || td.tiles_x >= 4096 || td.tiles_y >= 4096) return -3;
+  td.m_nsplit = (1ull << 42) / td.nsplit + 1;
+  td.m_tx = (1ull << 42) / td.tiles_x + 1;
+  td.m_ty = (1ull << 42) / td.tiles_y + 1;
+  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN>), dim3((unsigned)blocks, a.groups), dim3(512), lds, s, a, wimg, td);
+  return 0;
+}
+
 template <int NTN, int S, int NB, int TW, int CT, bool C8 = false>
 int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int TB = 128 / TW, TH = TB * NB;
@@ -777,6 +1135,9 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
 #ifndef CPX_BF3_NTN_S4
 #define CPX_BF3_NTN_S4 2
 #endif
+#ifndef CPX_BF3_NTN_ST3
+#define CPX_BF3_NTN_ST3 1
+#endif
 #ifndef CPX_BF3_NB_S2
 #define CPX_BF3_NB_S2 2
 #endif
@@ -798,9 +1159,35 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
 
 // (8 input channels per group: the tap-paired form, built for the 32 output channels per group the network has)
 static bool bf3_c8(const ConvArgs& a) { return a.Cin / a.groups == 8 && a.Cout / a.groups == 32; }
+// the strided first convolution of a stage (wr_resnet.py:27-30: stride = stage index): the same kernel with a strided
+// patch -- the MFMA loop is unchanged, only the A-fragment addresses carry the stride.  S = 2 (res3b0_branch2a): 33 x 33
+// staged pixels for 16 x 16 outputs and both 32-column tiles of a group in one workgroup (160 KB, one workgroup per CU):
+// 123 TFLOP/s against 95 on the float32 MFMA.  S = 3 (res4b0_branch2a, -DCPX_BF3_STRIDED=3): 24 x 48 staged pixels for
+// 8 x 16 outputs, 138 KB, four waves per CU and the patch split once per 32-column slice: 40 TFLOP/s against 78 on the
+// float32 MFMA (windows of a stride-3 3 x 3 kernel do not overlap: nothing is reused) -- measured, not shipped.
+#ifndef CPX_BF3_STRIDED
+#define CPX_BF3_STRIDED 1
+#endif
+static bool bf3_strided(const ConvArgs& a) {
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  if (!CPX_BF3_STRIDED || a.ksize != 3 || cin_g < KC || (cin_g % KC) != 0) return false;
+  return (a.stride == 2 && cout_g == 64) || (CPX_BF3_STRIDED >= 3 && a.stride == 3 && cout_g == 128);
+}
+// stride-1 layers with 32 or 64 channels per group (stages 2 and 3): the 16x16x32 form (conv_bf3w_kernel) and its
+// weight image; a property of the layer shape alone, so that the image built at cpx_cnn_create is the one every
+// launch of the layer reads (with or without a fused shortcut)
+#ifndef CPX_BF3W
+#define CPX_BF3W 1
+#endif
+
+static bool bf3w_layer(const ConvArgs& a) {
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  return CPX_BF3W && a.ksize == 3 && a.stride == 1 && cin_g >= KW && (cin_g % KW) == 0 && (cout_g == 32 || cout_g == 64) && cin_g <= 64;
+}
 bool conv_bf3_supported(const ConvArgs& a) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   if (a.ksize == 3 && a.stride == 1 && bf3_c8(a)) return true;
+  if (bf3_strided(a)) return true;
   return a.ksize == 3 && a.stride == 1 && cin_g >= KC && (cin_g % KC) == 0 && (cout_g == 32 || cout_g == 64 || cout_g == 128);
 }
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
@@ -815,6 +1202,12 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
                        reinterpret_cast<uint4*>(wimg), a.groups, cout_g);
     return;
   }
+  if (bf3w_layer(a)) {
+    const size_t total32 = (size_t)a.groups * (cin_g / KW) * 36 * cout_g;
+    hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g);
+    return;
+  }
   const size_t total = (size_t)a.groups * (cin_g / KC) * 18 * cout_g;
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
                      reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g);
@@ -825,6 +1218,13 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   if ((long long)a.H * a.W >= (1 << 24) || (long long)a.Ho * a.Wo >= (1 << 24) || a.Cin >= (1 << 24) || a.Cout >= (1 << 24)) return -3;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
   if (bf3_c8(a)) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2, true>(a, w, s);
+  if (a.stride == 2) return bf3_strided(a) ? launch_bf3_t<2, 2, 2, 16, 512>(a, w, s) : -2;
+  if (a.stride == 3) return bf3_strided(a) ? launch_bf3_t<CPX_BF3_NTN_ST3, 3, 1, 16, 256>(a, w, s) : -2;
+  if (a.stride != 1) return -2;
+  if (bf3w_layer(a)) {
+    if (a.sc_in && ((a.sc_cin / a.groups) & 3)) return -2;  // the fused shortcut walks K in fours
+    return launch_bf3w(a, w, s);
+  }
   if (cout_g == 32) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2>(a, w, s);
   if (cout_g == 64) return launch_bf3_t<CPX_BF3_NTN_S3, 1, CPX_BF3_NB_S3, CPX_BF3_TW_S3, CPX_BF3_CT_S3>(a, w, s);
   // 256 staged pixels + two N tiles = 80 KB: two workgroups per CU.  (Wider maps -- 54 x 54 at frame size 64 -- would
