@@ -703,7 +703,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   bid = qd;
   qd = div_magic(bid, td.m_ty);
   const int tyi = bid - qd * td.tiles_y;
+#ifdef CPX_BF3W_ALIAS_N  // experiment (scratch/patches/README.md): every sample reads and writes the first CPX_BF3W_ALIAS_N ones -- same work, no HBM traffic
+  const int n = qd & (CPX_BF3W_ALIAS_N - 1);
+#else
   const int n = qd;
+#endif
   const int g = blockIdx.y;
   const int oy0 = tyi * W_TH;
   const int iy0 = oy0 - a.pad_top;
