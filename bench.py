@@ -647,7 +647,8 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu, a
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node (default: WORLD_SIZE when a launcher started this process, else 1)")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default 4096, reduced if HBM is short)")
@@ -681,10 +682,17 @@ def main():
     args = ap.parse_args()
 
     # ---- --gpus N: this process becomes the launcher of N ranks unless a launcher already started us ----
-    if "WORLD_SIZE" not in os.environ:
+    # A launcher (torch.distributed.run) exports RANK and WORLD_SIZE together; a stray WORLD_SIZE alone is not one.
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not launched:
+        os.environ.pop("WORLD_SIZE", None)
+        if args.gpus is None:
+            args.gpus = 1
         if args.gpus > 1:
             raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
-    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+    elif args.gpus is None:
+        args.gpus = int(os.environ["WORLD_SIZE"])  # `torchrun --nproc-per-node 8 bench.py`: the launcher's world is the answer
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:  # only an explicit, contradicting --gpus is an error
         sys.stderr.write("bench.py: --gpus %d but the launcher started %s ranks (WORLD_SIZE)\n"
                          % (args.gpus, os.environ["WORLD_SIZE"]))
         raise SystemExit(2)

@@ -108,7 +108,10 @@ class ClipClassifier:
                                   calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)
             return
         models = [self.model] if self.model else (self.config.classify.models or [])
-        classifiers = [self.get_classifier(m) for m in models]
+        # as in the reference the FIRST recording's location decides the (country) model the process keeps
+        # (clipclassifier.py:60-83,254-256): it comes from the recording's existing metadata file
+        location = self.first_location(todo)
+        classifiers = [self.get_classifier(m, location) for m in models]
         per_file = bool(reuse_frames) or any(c.params.square_width == 1 for c in classifiers) \
             or len(set(c.limits_flags() for c in classifiers)) > 1
         if per_file:  # saved frames decide the segments / single-frame models / mixed normalisation variants
@@ -125,6 +128,18 @@ class ClipClassifier:
                                     batch_files=self.batch_files, clip_classifier=self)
         self.last_run = tracker.timings
 
+    @staticmethod
+    def first_location(filenames):
+        """`location` of the first recording's existing <file>.txt (None without one or when it cannot be read)."""
+        for filename in filenames[:1]:
+            meta_file = os.path.splitext(str(filename))[0] + ".txt"
+            if os.path.exists(meta_file):
+                try:
+                    return load_clip_metadata(meta_file).get("location")
+                except Exception as e:  # noqa: BLE001 -- the file itself is reported when its turn comes
+                    logging.warning("could not read %s for the recording location: %s", meta_file, e)
+        return None
+
     def process_files(self, filenames, reuse_frames=None, calculate_thumbnails=False, device=0):
         """process_file(track=True) for a list of recordings whose decode / tracking / association run as one device
         batch (trackextractor.extract_files); classification and metadata per file as in process_file."""
@@ -140,20 +155,25 @@ class ClipClassifier:
                                               calculate_thumbnails=calculate_thumbnails))
         return results
 
-    def process_file(self, filename, cache=None, reuse_frames=None, track=False, calculate_thumbnails=False, device=0):
+    def process_file(self, filename, cache=None, reuse_frames=None, track=False, calculate_thumbnails=False, device=0,
+                     blob=None):
         """Track (optionally) and classify one recording; writes / returns the metadata (clipclassifier.py:145-250).
-        cache (the reference's HDF5 frame cache) has no meaning here -- frames stay on the device -- and is ignored."""
+        cache (the reference's HDF5 frame cache) has no meaning here -- frames stay on the device -- and is ignored.
+        blob (with track=True): the recording's bytes, `filename` naming it (extract_file(blob=...))."""
         filename = str(filename)
         _, ext = os.path.splitext(filename)
         if ext != ".cptv":
             logging.error("Unknown extention %s", ext)
             return False
-        if not os.path.exists(filename):
+        if blob is None and not os.path.exists(filename):
             logging.error("File %s not found.", filename)
             return False
         meta_file = os.path.splitext(filename)[0] + ".txt"
         meta_data = None
-        if track:
+        if track and blob is not None:
+            clip, track_extractor, meta_data = extract_file(filename, self.config, False, to_stdout=False,
+                                                            save_meta=False, blob=blob)
+        elif track:
             if device:
                 clip, track_extractor, meta_data = extract_files([filename], self.config, False, to_stdout=False,
                                                                  save_meta=False, device=device)[0]

@@ -53,7 +53,10 @@ class Prediction:
         meta = {"prediction": np.uint8(np.round(100 * self.prediction)).tolist(),
                 "smoothed_prediction": None if self.smoothed_prediction is None
                 else np.uint32(np.round(self.smoothed_prediction)).tolist(),
-                "frames": frames, "predicted_at_frame": int(self.predicted_at_frame), "mass": int(self.mass),
+                "frames": frames, "predicted_at_frame": int(self.predicted_at_frame),
+                # smoothed models carry the mass as a 1-element array (classified_track: masses[:, None]) and the
+                # reference serialises it as a list (trackprediction.py:56, CustomJSONEncoder)
+                "mass": self.mass.tolist() if isinstance(self.mass, np.ndarray) and self.mass.ndim > 0 else int(self.mass),
                 "predicted_time": self.predicted_time}
         return meta
 

@@ -144,8 +144,14 @@ class CptvReader:
     """Sequential CPTV v2 reader with the ``cptv_rs_python_bindings`` surface."""
 
     def __init__(self, path):
-        with open(str(path), "rb") as f:
-            raw = f.read()
+        """path: a file name, or the recording itself as bytes (run_files_bulk(blobs=...) retries of in-memory
+        recordings the device decoder refused)."""
+        if isinstance(path, (bytes, bytearray, memoryview)):
+            raw = bytes(path)
+            path = "<%d bytes in memory>" % len(raw)
+        else:
+            with open(str(path), "rb") as f:
+                raw = f.read()
         if raw[:2] == b"\x1f\x8b":
             # whole-buffer inflate (zlib releases the GIL: decode_clips_on_device runs readers in threads);
             # concatenated gzip members are followed like gzip.open does

@@ -192,6 +192,9 @@ def plan_decode_batches(sizes, batch_files, max_bytes):
     return runs
 
 
+MAX_INFLATED = 1 << 30  # bytes one recording may inflate to on the batched path (a ten-minute 160 x 120 clip is ~0.2 GB)
+
+
 def decode_staged(eng, staged, min_pixels=160 * 120, unpack_engine=None):
     """cpx_cptv_inflate over a staged batch, then per (resolution, camera model) group gather + unpack.  `eng`: any
     engine on the device (the inflate kernel does not depend on its geometry; the unpack of a group runs on an engine
@@ -210,6 +213,15 @@ def inflate_launch(eng, staged, min_pixels=160 * 120):
     sizes = np.where(np.isin(np.arange(n), list(staged.errors)), 0, staged.sizes)
     files["in_offset"], files["in_bytes"] = staged.in_off[:-1], sizes
     isize = np.where(sizes > 0, staged.isize, 0)
+    # ISIZE is the last four bytes of an untrusted file: a claim beyond MAX_INFLATED (or beyond what DEFLATE can expand
+    # the file to, 1032 x) does not size device buffers -- that recording goes to the one-file reader, which needs no
+    # size up front
+    absurd = (isize > MAX_INFLATED) | (isize > 1032 * np.maximum(sizes, 1) + 64)
+    for i in np.nonzero(absurd)[0]:
+        staged.errors.setdefault(int(i), "%s: gzip trailer claims %d inflated bytes" % (staged.paths[i], int(isize[i])))
+    sizes = np.where(absurd, 0, sizes)
+    isize = np.where(absurd, 0, isize)
+    files["in_bytes"] = sizes
     out_off = np.zeros(n + 1, np.int64)
     np.cumsum(((isize + 15) & ~15) + 16, out=out_off[1:])
     files["out_offset"], files["out_capacity"] = out_off[:-1], isize
@@ -245,7 +257,6 @@ def inflate_finish(eng, staged, ctx, unpack_engine=None):
     model) and run gather + unpack per group -- on `unpack_engine`'s stream when given (run_files_bulk: the NEXT batch's
     inflate is already running on `eng`'s)."""
     from ..cptv import parse_header_bytes
-    from .cliptrackextractor import get_engine
 
     t, dev = eng.torch, eng.device
     n, slot_off = ctx["n"], ctx["slot_off"]
@@ -277,31 +288,47 @@ def inflate_finish(eng, staged, ctx, unpack_engine=None):
         headers[i] = h
         groups.setdefault((int(res["width"][i]), int(res["height"][i]), h.model if h.model else None), []).append(i)
     for key, members in groups.items():
-        W, H, _ = key
-        ok = np.asarray(members)
-        offs = np.zeros(len(ok) + 1, np.int32)
-        np.cumsum(res["n_frames"][ok], out=offs[1:])
-        total = int(offs[-1])
-        # any engine of this resolution can unpack; the tracking engine is picked by the caller
-        base = unpack_engine or eng
-        ueng = base if (base.width, base.height) == (W, H) else get_engine(W, H, 20.0, 0.1, device=dev.index or 0)
-        offs_dev = t.from_numpy(offs).to(dev)
-        so_dev = t.from_numpy(np.ascontiguousarray(slot_off[:-1][ok])).to(dev)
-        fo_dev = t.empty(total, dtype=t.int64, device=dev)
-        bw_dev = t.empty(total, dtype=t.int32, device=dev)
-        dense_dev = t.empty(total * 8, dtype=t.int32, device=dev)
-        frames_dev = t.empty((total, H, W), dtype=t.int16, device=dev)
-        ueng.sync_inputs()
-        rc = ueng.lib.cpx_cptv_gather_index(ueng.h, p(slots_dev), p(so_dev), p(offs_dev), len(ok), p(fo_dev), p(bw_dev),
-                                            p(dense_dev))
-        if rc == 0:
-            rc = ueng.lib.cpx_cptv_unpack(ueng.h, p(out_dev), p(fo_dev), p(bw_dev), p(offs_dev), len(ok), p(frames_dev))
-        if rc != 0:
-            raise CpxError(rc, ueng._err())
-        ueng.synchronize()
-        slots = dense_dev.cpu().numpy().view(CPTV_SLOT_DTYPE).reshape(-1)
-        out.groups.append(DecodedGroup(key, members, [headers[i] for i in members], offs, slots, frames_dev))
+        # a group that cannot be unpacked (a resolution no engine takes, a kernel refusal, no memory for its frames)
+        # sends ITS members to the one-file path; the other groups of the batch carry on
+        try:
+            out.groups.append(_unpack_group(eng, unpack_engine, key, members, headers, res, slot_off, slots_dev, out_dev))
+        except Exception as e:  # noqa: BLE001 -- fault isolation
+            if isinstance(e, t.cuda.OutOfMemoryError):
+                t.cuda.empty_cache()
+            for i in members:
+                out.errors[i] = "%s: %s: %s" % (staged.paths[i], type(e).__name__, str(e).splitlines()[0] if str(e) else "")
     return out
+
+
+def _unpack_group(eng, unpack_engine, key, members, headers, res, slot_off, slots_dev, out_dev):
+    from .cliptrackextractor import get_engine
+
+    t, dev = eng.torch, eng.device
+    p = lambda x: C.c_void_p(x.data_ptr())
+    W, H, _ = key
+    ok = np.asarray(members)
+    offs = np.zeros(len(ok) + 1, np.int32)
+    np.cumsum(res["n_frames"][ok], out=offs[1:])
+    total = int(offs[-1])
+    # any engine of this resolution can unpack; the tracking engine is picked by the caller
+    base = unpack_engine or eng
+    ueng = base if (base.width, base.height) == (W, H) else get_engine(W, H, 20.0, 0.1, device=dev.index or 0)
+    offs_dev = t.from_numpy(offs).to(dev)
+    so_dev = t.from_numpy(np.ascontiguousarray(slot_off[:-1][ok])).to(dev)
+    fo_dev = t.empty(total, dtype=t.int64, device=dev)
+    bw_dev = t.empty(total, dtype=t.int32, device=dev)
+    dense_dev = t.empty(total * 8, dtype=t.int32, device=dev)
+    frames_dev = t.empty((total, H, W), dtype=t.int16, device=dev)
+    ueng.sync_inputs()
+    rc = ueng.lib.cpx_cptv_gather_index(ueng.h, p(slots_dev), p(so_dev), p(offs_dev), len(ok), p(fo_dev), p(bw_dev),
+                                        p(dense_dev))
+    if rc == 0:
+        rc = ueng.lib.cpx_cptv_unpack(ueng.h, p(out_dev), p(fo_dev), p(bw_dev), p(offs_dev), len(ok), p(frames_dev))
+    if rc != 0:
+        raise CpxError(rc, ueng._err())
+    ueng.synchronize()
+    slots = dense_dev.cpu().numpy().view(CPTV_SLOT_DTYPE).reshape(-1)
+    return DecodedGroup(key, members, [headers[i] for i in members], offs, slots, frames_dev)
 
 
 def frame_meta_from_slots(slots, process_background=False):
@@ -739,7 +766,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     Writes <file>.txt (or prints with to_stdout) and returns ({filename: metadata text (want_text) or True, or an
     "error: ..." string for a skipped file}, tracker with timings).  Files that cannot take the batched path are
     retried through the one-file path.  blobs: the recordings as byte strings already in memory (names in
-    `filenames`; nothing is read from disk and a failing one is skipped, there being no file to retry).
+    `filenames`; nothing is read from disk; one the batch refuses is retried from its bytes by the host reader).
     batch_files: recordings per decode launch (and per read-ahead batch); track_files: recordings per tracking group."""
     import torch
 
@@ -757,7 +784,8 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     if clip_classifier is not None:
         models = [clip_classifier.model] if clip_classifier.model else (config.classify.models or [])
         t0 = time.time()
-        classifiers = [(m, clip_classifier.get_classifier(m)) for m in models]
+        location = clip_classifier.first_location(filenames) if blobs is None else None
+        classifiers = [(m, clip_classifier.get_classifier(m, location)) for m in models]
         tracker.timings["model_load_s"] = time.time() - t0
     out = {}
     # decode launches: at most batch_files recordings and decode_bytes of compressed data (inflated bytes + frames are
@@ -817,7 +845,17 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         if bi + 1 < len(batches):
             stage_futs[bi + 1] = stage_worker.submit(stage, bi + 1)
         t1 = time.time()
-        decoded = decode_staged(deng, staged)
+        try:
+            decoded = decode_staged(deng, staged)
+        except Exception as e:  # noqa: BLE001 -- (device memory for the batch's buffers, a refused launch): every member
+            # is retried on its own instead of the run unwinding with the open batches' metadata unwritten
+            if isinstance(e, torch.cuda.OutOfMemoryError):
+                torch.cuda.empty_cache()
+            decoded = DecodedBatch()
+            decoded.errors.update(staged.errors)
+            why = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            for i in range(len(staged.paths)):
+                decoded.errors.setdefault(i, "%s: decode stage failed (%s)" % (staged.paths[i], why))
         return staged, decoded, stage_s, time.time() - t1
 
     worker = ThreadPoolExecutor(max_workers=1)
@@ -829,26 +867,39 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     # thread).
     def device_phase(paths, group):
         td = time.time()
-        clips, existing = [], []
+        clips, existing, pre_failed = [], [], {}
         for k, i in enumerate(group.files):
+            # per-file work stays inside a try: a header without a timestamp, an absurd one, or a corrupt existing
+            # .txt fails THAT recording (it goes the one-file way, which reports it) and nothing else
             clip = Clip(tracker.tcfg, paths[i])
             clip.frames_per_second = 9
-            h = group.headers[k]
-            clip.set_res(h.x_resolution, h.y_resolution)
-            clip.set_model(h.model if h.model else None)
-            clip.set_video_stats(datetime.fromtimestamp(h.timestamp / 1000000).astimezone(Clip.local_tz))
+            meta = None
+            try:
+                h = group.headers[k]
+                clip.set_res(h.x_resolution, h.y_resolution)
+                clip.set_model(h.model if h.model else None)
+                clip.set_video_stats(datetime.fromtimestamp(h.timestamp / 1000000).astimezone(Clip.local_tz))
+                mf = os.path.splitext(paths[i])[0] + ".txt"
+                if blobs is None and os.path.exists(mf):
+                    meta = tools.load_clip_metadata(mf)
+            except Exception as e:  # noqa: BLE001 -- fault isolation
+                pre_failed[k] = "%s: %s" % (type(e).__name__, e)
+                clip.set_res(group.key[0], group.key[1])
+                clip.set_model(group.key[2])
             clips.append(clip)
-            mf = os.path.splitext(paths[i])[0] + ".txt"
-            existing.append(tools.load_clip_metadata(mf) if blobs is None and os.path.exists(mf) else None)
+            existing.append(meta)
         # (lepton3 and "no model" files share thresholds but not the metadata's camera_model: grouped by model)
         try:
             r = tracker.track_group(group, clips, classifiers)
-        except CpxError as e:  # the whole group failed on the device: every member goes the slow way
-            r = e
-        except torch.cuda.OutOfMemoryError as e:   # (budgets too generous for this device: same way out, memory released)
+        except torch.cuda.OutOfMemoryError as e:   # (budgets too generous for this device: memory released, members retried)
             r = RuntimeError("device out of memory for a group of %d recordings / %d frames: %s"
                              % (len(group.files), int(group.offs[-1]), str(e).splitlines()[0]))
             torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 -- the whole group failed (CpxError or anything else): every member goes the slow way
+            r = e
+        if not isinstance(r, Exception):
+            for k, why in pre_failed.items():
+                r["failed"].setdefault(k, why)
         return clips, existing, r, time.time() - td
 
     def host_phase(ctx, group, result):
@@ -879,25 +930,29 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             if b in r["failed"]:
                 retry[i] = "%s: %s" % (paths[i], r["failed"][b])
                 continue
-            n_proc = len(r["proc_idx"][b])
-            tracks = []
-            for ti in per_clip.get(b, ()):
-                _, j = r["kept"][ti]
-                regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
-                use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
-                st = r["stats"][upos[ti]:upos[ti + 1]]
-                tr = dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st))
-                if classifiers:
-                    secs = sum(mo["seconds"] for mo in r["model_out"]) / n_kept
-                    tr["predictions"] = track_predictions(r, ti, b, r["model_out"], secs)
-                tracks.append(tr)
-            trackless = None
-            if not tracks:
-                kind, payload = r["best_region"].get(b, ("none", None))
-                trackless = _trackless_region(kind, payload)
-            texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[i], tracking_time,
-                                             existing[b], indent, models=model_meta)
-            tracker.timings["frames"] += int(offs[b + 1] - offs[b])
+            try:  # (fault isolation: a recording whose results do not serialise is retried on its own)
+                n_proc = len(r["proc_idx"][b])
+                tracks = []
+                for ti in per_clip.get(b, ()):
+                    _, j = r["kept"][ti]
+                    regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
+                    use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
+                    st = r["stats"][upos[ti]:upos[ti + 1]]
+                    tr = dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st))
+                    if classifiers:
+                        secs = sum(mo["seconds"] for mo in r["model_out"]) / n_kept
+                        tr["predictions"] = track_predictions(r, ti, b, r["model_out"], secs)
+                    tracks.append(tr)
+                trackless = None
+                if not tracks:
+                    kind, payload = r["best_region"].get(b, ("none", None))
+                    trackless = _trackless_region(kind, payload)
+                texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[i], tracking_time,
+                                                 existing[b], indent, models=model_meta)
+                tracker.timings["frames"] += int(offs[b + 1] - offs[b])
+            except Exception as e:  # noqa: BLE001
+                texts.pop(i, None)
+                retry[i] = "%s: %s: %s" % (paths[i], type(e).__name__, e)
         tracker.timings["host_s"] += time.time() - th
 
     def close_batch(ctx):
@@ -913,18 +968,19 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             tracker.timings["files"] += 1
         tracker.timings["write_s"] += time.time() - tw
         for i, why in sorted(retry.items()):
-            if blobs is not None:
-                logging.error("batched extract: %s -- skipped", why)
-                out[paths[i]] = "error: %s" % (why,)
-                continue
-            logging.warning("batched extract: %s -- retrying the file on its own", why)
+            # a recording the batch refused goes through the one-file path: the host reader (zlib + section walk) is
+            # the reference's one reader (cliptrackextractor.py:108-129) and never loses a valid file; an in-memory
+            # recording is handed to it as bytes
+            blob = blobs[ctx["base"] + i] if blobs is not None else None
+            logging.warning("batched extract: %s -- retrying the recording on its own", why)
             try:
                 if clip_classifier is not None:
-                    res = clip_classifier.process_file(paths[i], track=True, calculate_thumbnails=True, device=device)
+                    res = clip_classifier.process_file(paths[i], track=True, calculate_thumbnails=True, device=device,
+                                                       blob=blob)
                     if not res:
                         raise RuntimeError("process_file refused the file")
                 else:
-                    res = extract_file(paths[i], config, False, False, to_stdout, save_meta=save_meta)[2]
+                    res = extract_file(paths[i], config, False, False, to_stdout, save_meta=save_meta, blob=blob)[2]
                 out[paths[i]] = (json.dumps(res, indent=indent, cls=tools.CustomJSONEncoder) if want_text else True)
             except Exception as e:  # noqa: BLE001 -- fault isolation: one bad recording must not stop the directory
                 logging.error("could not process %s: %s", paths[i], e)
@@ -942,28 +998,30 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             if ctx["open"] == 0 and ctx["submitted"]:
                 close_batch(ctx)
 
-    for bi, paths in enumerate(batches):
-        t0 = time.time()
-        staged, decoded, stage_s, decode_s = fut.result()
-        fut = worker.submit(produce, bi + 1) if bi + 1 < len(batches) else None
-        tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + stage_s
-        tracker.timings["decode_s"] += decode_s
-        tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + time.time() - t0
-        groups = [sub for g in decoded.groups for sub in g.split(track_files, track_frames)]
-        ctx = dict(paths=paths, texts={}, retry=dict(decoded.errors), t0=t0, open=len(groups), submitted=False,
-                   n_ok=sum(len(g.files) for g in decoded.groups))
-        for gi, group in enumerate(groups):
-            f = dev_worker.submit(device_phase, paths, group)
-            ctx["submitted"] = gi + 1 == len(groups)
-            drain()                      # the previous group's metadata, while this one is on the device
-            pending = (ctx, group, f)
-        if not groups:
-            close_batch(ctx)
-        del staged, decoded
-    drain()
-    dev_worker.shutdown(wait=True)
-    worker.shutdown(wait=True)
-    stage_worker.shutdown(wait=True)
+    try:
+        for bi, paths in enumerate(batches):
+            t0 = time.time()
+            staged, decoded, stage_s, decode_s = fut.result()
+            fut = worker.submit(produce, bi + 1) if bi + 1 < len(batches) else None
+            tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + stage_s
+            tracker.timings["decode_s"] += decode_s
+            tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + time.time() - t0
+            groups = [sub for g in decoded.groups for sub in g.split(track_files, track_frames)]
+            ctx = dict(paths=paths, base=order[bi], texts={}, retry=dict(decoded.errors), t0=t0, open=len(groups), submitted=False,
+                       n_ok=sum(len(g.files) for g in decoded.groups))
+            for gi, group in enumerate(groups):
+                f = dev_worker.submit(device_phase, paths, group)
+                ctx["submitted"] = gi + 1 == len(groups)
+                drain()                      # the previous group's metadata, while this one is on the device
+                pending = (ctx, group, f)
+            if not groups:
+                close_batch(ctx)
+            del staged, decoded
+        drain()
+    finally:  # (an exception that does escape must not leave three executors running)
+        dev_worker.shutdown(wait=True)
+        worker.shutdown(wait=True)
+        stage_worker.shutdown(wait=True)
     if own_stager:
         stager.close()
     return out, tracker

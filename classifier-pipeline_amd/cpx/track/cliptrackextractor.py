@@ -236,7 +236,8 @@ class ClipTrackExtractor(ClipTracker):
         clip.set_frame_buffer(self.high_quality_optical_flow, self.cache_to_disk, self.use_opt_flow,
                               self.keep_frames, self.max_frames)
         clip.type = self.type
-        reader = CptvReader(str(clip.source_file))
+        blob = getattr(clip, "source_bytes", None)  # an in-memory recording (trackextractor.extract_file(blob=...))
+        reader = CptvReader(blob if blob is not None else str(clip.source_file))
         header = reader.get_header()
         clip.set_res(header.x_resolution, header.y_resolution)
         if clip.from_metadata:

@@ -57,9 +57,12 @@ class TrackExtractor:
         self.last_run = tracker.timings
 
 
-def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True):
+def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False, max_frames=None, save_meta=True,
+                 blob=None):
+    """trackextractor.py:122-202.  blob: the recording's bytes when it lives in memory (`filename` then only names
+    it in the metadata): the host reader (zlib + section walk) decodes it, as it does a file."""
     filename = Path(filename)
-    if not filename.is_file():
+    if blob is None and not filename.is_file():
         raise Exception("File {} not found.".format(filename))
     logging.info("Tracking %s", filename)
     if filename.suffix != ".cptv":
@@ -72,9 +75,11 @@ def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False
                                          max_frames=max_frames)
     clip = Clip(track_extractor.config, filename)
     clip.frames_per_second = 9
+    if blob is not None:
+        clip.source_bytes = blob
     existing = None
     meta_filename = filename.with_suffix(".txt")
-    if meta_filename.exists():
+    if blob is None and meta_filename.exists():
         existing = tools.load_clip_metadata(meta_filename)
     if retrack:
         clip.load_metadata(existing)
