@@ -26,6 +26,7 @@
 //   phase 7  per-run statistics -> components, 2x2-block raster ordering
 //   phase 8  label image (optional), one wave per component delta-variance
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "cpx_kernels.h"
@@ -1197,14 +1198,14 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   unsigned char* ext = smem;                                                   // [EHb][ES]: padded rows yb0-13 ...
   const int RBa = RB < H ? RB : H;   // rows the launch sized the LDS for
   uint16_t* Hh = reinterpret_cast<uint16_t*>(smem + (((size_t)(RBa + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15));  // [RBa+16+BH][HS]
-  // weights of a PAIR of distances in one 8-byte entry: [min(d0 >> 6, 48)][min(d1 >> 6, 48)] (entry 48 = weight 0)
+  // weights of a PAIR of distances in one 4-byte entry (two uint16): [min(d0 >> 6, 48)][min(d1 >> 6, 48)] (entry 48 = weight 0)
 #ifdef CPX_NLM_DB
   // double-buffered row sums: the row pass of pair q + 1 and the column pass of pair q run between the same two
   // barriers (one barrier per pair, and waves drift between an LDS-heavy and a VALU-heavy phase)
   uint16_t* const Hh1 = Hh + (size_t)(RBa + 16 + BH) * HS;
-  int2* s_lut2 = reinterpret_cast<int2*>(Hh1 + (size_t)(RBa + 16 + BH) * HS);  // [49][49]
+  u32* s_lut2 = reinterpret_cast<u32*>(Hh1 + (size_t)(RBa + 16 + BH) * HS);  // [49][49]
 #else
-  int2* s_lut2 = reinterpret_cast<int2*>(Hh + (size_t)(RBa + 16 + BH) * HS);  // [49][49]
+  u32* s_lut2 = reinterpret_cast<u32*>(Hh + (size_t)(RBa + 16 + BH) * HS);  // [49][49]
 #endif
   const unsigned char* img = a.u8_state + ((size_t)b * 2 + (t & 1)) * P;
   unsigned char* out = a.u8_state + ((size_t)b * 2 + ((t + 1) & 1)) * P;
@@ -1217,7 +1218,7 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   }
   for (int i = tid; i < NLM_LUT2 * NLM_LUT2; i += NT_NLM) {
     const int i0 = i / NLM_LUT2, i1 = i - i0 * NLM_LUT2;
-    s_lut2[i] = make_int2(i0 < 48 ? a.nlm_lut[i0] : 0, i1 < 48 ? a.nlm_lut[i1] : 0);
+    s_lut2[i] = (u32)(i0 < 48 ? a.nlm_lut[i0] : 0) | ((u32)(i1 < 48 ? a.nlm_lut[i1] : 0) << 16);
   }
   // pass-B role: two adjacent image columns and a sub-band of BH rows
   const int pcol = tid % npair, sub = tid / npair;
@@ -1225,9 +1226,10 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   const bool active_b = sub < nsub && sub * BH < RBc;
   const int l0 = sub * BH;  // first band-local row of this thread
   int est[2 * BH], wsum[2 * BH];
+  const u32 lut_off = (u32)(reinterpret_cast<const unsigned char*>(s_lut2) - smem);  // byte offset of the table in the workgroup's LDS
   __syncthreads();
   {  // the zero offset: distance 0 everywhere
-    const int w0 = s_lut2[0].x;
+    const int w0 = (int)(s_lut2[0] & 0xFFFFu);
 #pragma unroll
     for (int i = 0; i < BH; ++i) {
       const int l = (l0 + i < RBc) ? l0 + i : 0;
@@ -1239,8 +1241,18 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
   }
 
   // offset pair q: upper half of the search window: (0, 1..10), then (1..10, -10..10)
-  auto pass_a = [&](const int q, uint16_t* const Hh) __attribute__((always_inline)) {
-    int dy, dx;
+  //
+  // Instruction census (round 4): every vector instruction of this kernel issues at the same
+  // rate on gfx950 (scratch/valu_cost_probe.hip: v_perm, v_pk_*, v_dot2_u32_u16, v_mul_lo_u32, SDWA forms alike), so
+  // the count is the cost.  What the two passes were trimmed by:
+  //   pass A  the byte differences come straight out of the packed rows by SDWA byte operands (two v_sub_u16_sdwa per
+  //           16-bit pair instead of two unpacking v_perm + one v_pk_sub), the a-row starts on a dword (the domain is
+  //           extended to the left by 0..3 columns instead: four alignment v_perm and one LDS read fewer per item)
+  //   pass B  both directions of a pair run together; the table index is ONE v_dot2_u32_u16 (i0 * 196 + i1 * 4 + base)
+  //           instead of and / mul / shift / add; weights and pixels of the two directions are packed per PIXEL by one
+  //           v_perm each, and a pixel's two estimate terms (and its two weights) are accumulated by one
+  //           v_dot2_u32_u16 each instead of two multiply-adds (two adds)
+  auto pair_offset = [](const int q, int& dy, int& dx) {
     if (q < 10) {
       dy = 0;
       dx = q + 1;
@@ -1248,15 +1260,21 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
       dy = (q - 10) / 21 + 1;
       dx = (q - 10) - (dy - 1) * 21 - 10;
     }
+  };
+  auto pass_a = [&](const int q, uint16_t* const Hh) __attribute__((always_inline)) {
+    int dy, dx;
+    pair_offset(q, dy, dx);
     const int adx = dx > 0 ? dx : -dx;
-    const int c0 = dx > 0 ? -dx : 0;           // first column of the extended domain
+    const int c00 = dx > 0 ? -dx : 0;
+    const int ash = (NLM_R - 3 + c00) & 3;     // columns the domain is extended to the left by: the a values start on a dword
+    const int c0 = c00 - ash;                  // first column of the extended domain
     const int nrows = RBc + 6 + dy;            // rows -3 - dy .. RBc + 2 of the band
-    const int nseg = (W + adx + 7) >> 3;       // 8-column segments
+    const int nseg = (W + adx + ash + 7) >> 3; // 8-column segments
     // ---- pass A: Hh[rr][c - c0] = min(4095, sum_{v=-3..3} (ext(r, c+v) - ext(r+dy, c+dx+v))^2), r = yb0 - 3 - dy + rr ----
     {
-      const int sa0 = NLM_R - 3 + c0, sb0 = sa0 + dx;   // byte of a row where the 14 values of segment 0 start (>= 0)
-      const int abase = sa0 & ~3, bbase = sb0 & ~3;     // 4-byte aligned starts; the shifts are wave-uniform
-      const u32 asel = 0x03020100u + 0x01010101u * (u32)(sa0 & 3), bsel = 0x03020100u + 0x01010101u * (u32)(sb0 & 3);
+      const int sa0 = NLM_R - 3 + c0, sb0 = sa0 + dx;   // byte of a row where the 14 values of segment 0 start (>= 0; sa0 = 0 mod 4)
+      const int bbase = sb0 & ~3;                       // 4-byte aligned start of the b values; the shift is wave-uniform
+      const u32 bsel = 0x03020100u + 0x01010101u * (u32)(sb0 & 3);
       const int items = nrows * nseg;
       // (row, segment) of this thread's first item and the step of 1024 items, without a division per item
       const u32 mg = (1u << 20) / (u32)nseg + 1u;        // floor(i / nseg) = (i * mg) >> 20 for i < 1024, nseg < 1024
@@ -1265,29 +1283,32 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
       const int drr = NT_NLM / nseg, dsg = NT_NLM - drr * nseg;
       for (int it = tid; it < items; it += NT_NLM) {
         const int er = rr + NLM_R - 3 - dy;                // padded row of the a values
-        const u32* pa = reinterpret_cast<const u32*>(ext + er * ES + abase + (sg << 3));
-        const u32* pb = reinterpret_cast<const u32*>(ext + (er + dy) * ES + bbase + (sg << 3));
-        u32 qa[5], qb[5];
+        const u32* pa = reinterpret_cast<const u32*>(ext + __umul24((u32)er, (u32)ES) + sa0 + (sg << 3));
+        const u32* pb = reinterpret_cast<const u32*>(ext + __umul24((u32)(er + dy), (u32)ES) + bbase + (sg << 3));
+        u32 ra[4], qb[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          qa[k] = pa[k];
-          qb[k] = pb[k];
-        }
-        u32 ra[4], rb[4];  // the 14 (16) values of each row, byte-aligned
+        for (int k = 0; k < 4; ++k) ra[k] = pa[k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ra[k] = __builtin_amdgcn_perm(qa[k + 1], qa[k], asel);
-          rb[k] = __builtin_amdgcn_perm(qb[k + 1], qb[k], bsel);
-        }
-        // D[i] = (d^2 of value 2i, d^2 of value 2i+1), E[i] = (d^2 of 2i+1, d^2 of 2i+2)
+        for (int k = 0; k < 5; ++k) qb[k] = pb[k];
+        u32 rb[4];  // the 14 (16) b values, byte-aligned with the a values
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rb[k] = __builtin_amdgcn_perm(qb[k + 1], qb[k], bsel);
+        // D[i] = (d^2 of value 2i, d^2 of value 2i+1), E[i] = (d^2 of 2i+1, d^2 of 2i+2); the differences wrap in 16
+        // bits and their squares are exact there (<= 255^2)
         u16x2 D[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-          const u32 sel = (i & 1) ? 0x0c030c02u : 0x0c010c00u;
-          const u16x2 av = as_pk(__builtin_amdgcn_perm(0u, ra[i >> 1], sel));
-          const u16x2 bv = as_pk(__builtin_amdgcn_perm(0u, rb[i >> 1], sel));
-          const u16x2 d = av - bv;
-          D[i] = d * d;  // <= 255^2: exact in 16 bits
+          u32 d;
+          if (i & 1)
+            asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
+                "v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3"
+                : "=&v"(d) : "v"(ra[i >> 1]), "v"(rb[i >> 1]));
+          else
+            asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                "v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1"
+                : "=&v"(d) : "v"(ra[i >> 1]), "v"(rb[i >> 1]));
+          const u16x2 dd = as_pk(d);
+          D[i] = dd * dd;
         }
         u16x2 E[6];
 #pragma unroll
@@ -1301,7 +1322,7 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
         const u16x2 o1 = __builtin_elementwise_min(sadd(Sa, sadd(E[3], D[4])), cap);   // P2..P8
         const u16x2 o2 = __builtin_elementwise_min(sadd(sadd(D[2], E[2]), Sb), cap);   // P4..P10
         const u16x2 o3 = __builtin_elementwise_min(sadd(Sb, sadd(E[5], D[6])), cap);   // P6..P12
-        *reinterpret_cast<uint4*>(Hh + (size_t)rr * HS + (sg << 3)) = make_uint4(as_u32(o0), as_u32(o1), as_u32(o2), as_u32(o3));
+        *reinterpret_cast<uint4*>(Hh + __umul24((u32)rr, (u32)HS) + (sg << 3)) = make_uint4(as_u32(o0), as_u32(o1), as_u32(o2), as_u32(o3));
         rr += drr;
         sg += dsg;
         if (sg >= nseg) {
@@ -1311,72 +1332,83 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
       }
     }
   };
+  // row sums of one direction: the seven-row window of every output row of this thread, as packed column pairs
+  auto load_hv = [&](const uint16_t* const Hh, const int rbase, const int coff, u32* hv) __attribute__((always_inline)) {
+    const int cc = bx + coff;
+    // (rows past the band's last one feed only outputs that are never stored; the array has BH spare rows for them)
+    const uint16_t* hr0 = Hh + (cc & ~1) + __umul24((u32)rbase, (u32)HS);
+    if (coff & 1) {  // the pair straddles two aligned words (bx is even: the parity is the offset's)
+#pragma unroll
+      for (int k = 0; k < BH + 6; ++k) {
+        const uint16_t* hr = hr0 + (size_t)k * HS;
+        const u32 w0 = *reinterpret_cast<const u32*>(hr), w1 = *reinterpret_cast<const u32*>(hr + 2);
+        hv[k] = __builtin_amdgcn_alignbit(w1, w0, 16);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < BH + 6; ++k) hv[k] = *reinterpret_cast<const u32*>(hr0 + (size_t)k * HS);
+    }
+  };
   auto pass_b = [&](const int q, const uint16_t* const Hh) __attribute__((always_inline)) {
     int dy, dx;
-    if (q < 10) {
-      dy = 0;
-      dx = q + 1;
-    } else {
-      dy = (q - 10) / 21 + 1;
-      dx = (q - 10) - (dy - 1) * 21 - 10;
-    }
-    // ---- pass B: dist = sum of seven row sums; weight; accumulate -- offset d, then offset -d ----
+    pair_offset(q, dy, dx);
+    // ---- pass B: dist = sum of seven row sums; weight; accumulate -- offset +d and offset -d together ----
     if (active_b) {
+      const int ash = (NLM_R - 3 + (dx > 0 ? -dx : 0)) & 3;   // pass A's left extension
+      // offset +d reads rows l + k + dy at column x - c0, offset -d rows l + k at column x - dx - c0
+      const int coff0 = (dx > 0 ? dx : 0) + ash, coff1 = (dx > 0 ? 0 : -dx) + ash;   // uniform
+      u32 hv0[BH + 6], hv1[BH + 6];
+      load_hv(Hh, l0 + dy, coff0, hv0);
+      load_hv(Hh, l0, coff1, hv1);
+      u16x2 V0 = as_pk(hv0[0]), V1 = as_pk(hv1[0]);
 #pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        // offset +d reads rows l + k + dy at column x - c0, offset -d rows l + k at column x - dx - c0
-        const int rbase = l0 + (side == 0 ? dy : 0);
-        const int coff = side == 0 ? (dx > 0 ? dx : 0) : (dx > 0 ? 0 : -dx);   // uniform
-        const int poff = NLM_R + (side == 0 ? dx : -dx);                       // uniform
-        const int cc = bx + coff;
-        u32 hv[BH + 6];
-        const uint16_t* hp = Hh + (cc & ~1);
-        // (rows past the band's last one feed only outputs that are never stored; the array has BH spare rows for them)
-        const uint16_t* hr0 = hp + (size_t)rbase * HS;
-        if (coff & 1) {  // the pair straddles two aligned words (bx is even: the parity is the offset's)
-#pragma unroll
-          for (int k = 0; k < BH + 6; ++k) {
-            const uint16_t* hr = hr0 + (size_t)k * HS;
-            const u32 w0 = *reinterpret_cast<const u32*>(hr), w1 = *reinterpret_cast<const u32*>(hr + 2);
-            hv[k] = __builtin_amdgcn_alignbit(w1, w0, 16);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < BH + 6; ++k) hv[k] = *reinterpret_cast<const u32*>(hr0 + (size_t)k * HS);
-        }
-        u16x2 V = as_pk(hv[0]);
-#pragma unroll
-        for (int k = 1; k < 7; ++k) V = V + as_pk(hv[k]);
-        // the two pixels of a row as ALIGNED 16-bit reads: left to itself the compiler merges px[0], px[1] into one
-        // ds_read_u16, which for odd columns (every other offset) is a misaligned LDS access -- measured 3.3 of
-        // 8.3 us per frame.  Rows past the band's end (last band of a frame only) read whatever follows in LDS and
-        // are never stored: no test per row.
-        const unsigned char* px = ext + (l0 + NLM_R + (side == 0 ? dy : -dy)) * ES + ((bx + poff) & ~1);
-        const bool podd = (poff & 1) != 0;
+      for (int k = 1; k < 7; ++k) {
+        V0 = V0 + as_pk(hv0[k]);
+        V1 = V1 + as_pk(hv1[k]);
+      }
+      // the two pixels of a row as ALIGNED 16-bit reads (a merged ds_read_u16 at an odd column is a misaligned LDS
+      // access: measured 3.3 of 8.3 us per frame in round 2).  Rows past the band's end (last band of a frame only)
+      // read whatever follows in LDS and are never stored: no test per row.  +d and -d shift the column by the same
+      // parity, so one flag serves both directions.
+      const unsigned char* px0 = ext + __umul24((u32)(l0 + NLM_R + dy), (u32)ES) + ((bx + NLM_R + dx) & ~1);
+      const unsigned char* px1 = ext + __umul24((u32)(l0 + NLM_R - dy), (u32)ES) + ((bx + NLM_R - dx) & ~1);
+      const bool podd = ((NLM_R + dx) & 1) != 0;
+      const u16x2 lut_k = {NLM_LUT2 * 4, 4};   // bytes per step of the first / second table index
+      const u16x2 ones = {1, 1};
+      auto rows = [&](auto podd_c) __attribute__((always_inline)) {
+        constexpr bool PODD = decltype(podd_c)::value;
 #pragma unroll
         for (int i = 0; i < BH; ++i) {
           const u16x2 cap48 = {48, 48};
-          const u32 ai = as_u32(__builtin_elementwise_min(V >> 6, cap48));
-          const int2 w01 = s_lut2[__umul24(ai & 0xFFFFu, (u32)NLM_LUT2) + (ai >> 16)];
-          const int w0 = w01.x, w1 = w01.y;
-          u32 p0, p1;
-          if (podd) {
-            p0 = (u32)*reinterpret_cast<const uint16_t*>(px) >> 8;
-            p1 = (u32)*reinterpret_cast<const uint16_t*>(px + 2) & 0xFFu;
+          const u16x2 i0 = __builtin_elementwise_min(V0 >> 6, cap48), i1 = __builtin_elementwise_min(V1 >> 6, cap48);
+          // entry = (weight of the left pixel, weight of the right pixel) as two uint16 (weights < 2^15)
+          const u32 W0 = *reinterpret_cast<const u32*>(smem + __builtin_amdgcn_udot2(i0, lut_k, lut_off, false));
+          const u32 W1 = *reinterpret_cast<const u32*>(smem + __builtin_amdgcn_udot2(i1, lut_k, lut_off, false));
+          // per pixel: (weight towards +d, weight towards -d) and (pixel at +d, pixel at -d)
+          const u32 WA = __builtin_amdgcn_perm(W1, W0, 0x05040100u), WB = __builtin_amdgcn_perm(W1, W0, 0x07060302u);
+          u32 PA, PB;
+          if (PODD) {  // left pixel = high byte of the first aligned pair, right pixel = low byte of the next
+            const u32 a0 = *reinterpret_cast<const uint16_t*>(px0 + i * ES), a1 = *reinterpret_cast<const uint16_t*>(px0 + i * ES + 2);
+            const u32 b0 = *reinterpret_cast<const uint16_t*>(px1 + i * ES), b1 = *reinterpret_cast<const uint16_t*>(px1 + i * ES + 2);
+            PA = __builtin_amdgcn_perm(b0, a0, 0x0c050c01u);
+            PB = __builtin_amdgcn_perm(b1, a1, 0x0c040c00u);
           } else {
-            const u32 pp = *reinterpret_cast<const uint16_t*>(px);
-            p0 = pp & 0xFFu;
-            p1 = pp >> 8;
+            const u32 a0 = *reinterpret_cast<const uint16_t*>(px0 + i * ES), b0 = *reinterpret_cast<const uint16_t*>(px1 + i * ES);
+            PA = __builtin_amdgcn_perm(b0, a0, 0x0c040c00u);
+            PB = __builtin_amdgcn_perm(b0, a0, 0x0c050c01u);
           }
-          // weights < 2^15, pixels < 2^8: the 24-bit multiply-add (full rate; a 32-bit one is a quarter of that)
-          est[2 * i] = (int)(__umul24((u32)w0, p0) + (u32)est[2 * i]);
-          est[2 * i + 1] = (int)(__umul24((u32)w1, p1) + (u32)est[2 * i + 1]);
-          wsum[2 * i] += w0;
-          wsum[2 * i + 1] += w1;
-          px += ES;
-          if (i + 1 < BH) V = V + as_pk(hv[i + 7]) - as_pk(hv[i]);
+          est[2 * i] = (int)__builtin_amdgcn_udot2(as_pk(WA), as_pk(PA), (u32)est[2 * i], false);
+          est[2 * i + 1] = (int)__builtin_amdgcn_udot2(as_pk(WB), as_pk(PB), (u32)est[2 * i + 1], false);
+          wsum[2 * i] = (int)__builtin_amdgcn_udot2(as_pk(WA), ones, (u32)wsum[2 * i], false);
+          wsum[2 * i + 1] = (int)__builtin_amdgcn_udot2(as_pk(WB), ones, (u32)wsum[2 * i + 1], false);
+          if (i + 1 < BH) {
+            V0 = V0 + as_pk(hv0[i + 7]) - as_pk(hv0[i]);
+            V1 = V1 + as_pk(hv1[i + 7]) - as_pk(hv1[i]);
+          }
         }
-      }
+      };
+      if (podd) rows(std::true_type{});
+      else rows(std::false_type{});
     }
   };
 #ifdef CPX_NLM_DB
@@ -1420,7 +1452,7 @@ size_t nlm_lds_rows(int W, int rows, int bh) {
 #else
   const size_t nbuf = 1;
 #endif
-  return ((((size_t)rows + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15) + nbuf * ((size_t)rows + 16 + bh) * HS * 2 + NLM_LUT2 * NLM_LUT2 * 8 + 64;
+  return ((((size_t)rows + 2 * NLM_R) * ES + 32 + 15) & ~(size_t)15) + nbuf * ((size_t)rows + 16 + bh) * HS * 2 + NLM_LUT2 * NLM_LUT2 * 4 + 64;
 }
 template <int BH, int WC>
 void launch_nlm_tw(const TrackArgs& a, int B, int t, hipStream_t s) {
