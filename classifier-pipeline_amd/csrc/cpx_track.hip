@@ -1149,6 +1149,15 @@ __global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0,
 // halves of the frame step.
 // ---------------------------------------------------------------------------------------------
 namespace {
+// double-buffered row sums (one barrier per offset pair, the row pass of pair q + 1 beside the column pass of pair q):
+// 4.53 vs 4.56 us per frame in round 3, 3.80 vs 4.04 after the round-4 instruction trims (-DCPX_NLM_SINGLE: one buffer)
+#if !defined(CPX_NLM_SINGLE) && !defined(CPX_NLM_DB)
+#define CPX_NLM_DB 1
+#endif
+#ifndef CPX_NLM_ASM   // experiment switch: 0 = compiler-scheduled LDS reads, 1 = row sums by hand, 2 = the row loop too
+#define CPX_NLM_ASM 1
+#endif
+constexpr bool NLM_ASM_HV = (CPX_NLM_ASM & 1) != 0, NLM_ASM_ROWS = (CPX_NLM_ASM & 2) != 0;
 constexpr int NLM_R = 13;      // border = template radius 3 + search radius 10
 constexpr int NT_NLM = 1024;  // threads of an NLM workgroup (independent of the frame kernel's)
 __device__ __forceinline__ int refl101(int v, int n) { return v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v); }
@@ -1172,7 +1181,41 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 constexpr int NLM_LUT2 = 49;    // LDS weight table: pairs of the 48 non-zero weights + the zero weight
 __device__ __forceinline__ u16x2 as_pk(u32 v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ u32 as_u32(u16x2 v) { return __builtin_bit_cast(u32, v); }
-__device__ __forceinline__ int nlm_hs(int W) { return (W + 10 + 7) & ~7; }  // row stride of the row-sum array (uint16)
+__device__ __forceinline__ int nlm_hs(int W) { return (W + 24 + 7) & ~7; }  // row stride of the row-sum array (uint16): W + 13 columns in segments of 12
+
+// ---- LDS reads with the offsets in the instruction (cpx_nlm_kernel<.., 160>): the compiler pairs neighbouring rows into
+// ds_read2_b32, whose 8-bit offsets reach three rows, and spends a v_add per pair on the base; written out, sixteen
+// rows hang off ONE address register.  The loads of a block are all in flight before the single wait that follows
+// (lds_wait ties the loaded registers to the wait, so no consumer can be scheduled ahead of it).
+template <int STRIDE, int BASE>
+__device__ __forceinline__ void lds_read8_b32(u32 addr, u32* v) {
+  asm volatile("ds_read_b32 %0, %8 offset:%9\n\tds_read_b32 %1, %8 offset:%10\n\tds_read_b32 %2, %8 offset:%11\n\t"
+               "ds_read_b32 %3, %8 offset:%12\n\tds_read_b32 %4, %8 offset:%13\n\tds_read_b32 %5, %8 offset:%14\n\t"
+               "ds_read_b32 %6, %8 offset:%15\n\tds_read_b32 %7, %8 offset:%16"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+               : "v"(addr), "n"(BASE), "n"(BASE + STRIDE), "n"(BASE + 2 * STRIDE), "n"(BASE + 3 * STRIDE), "n"(BASE + 4 * STRIDE),
+                 "n"(BASE + 5 * STRIDE), "n"(BASE + 6 * STRIDE), "n"(BASE + 7 * STRIDE));
+}
+template <int STRIDE, int BASE>
+__device__ __forceinline__ void lds_read5_u16(u32 addr, u32* v) {
+  asm volatile("ds_read_u16 %0, %5 offset:%6\n\tds_read_u16 %1, %5 offset:%7\n\tds_read_u16 %2, %5 offset:%8\n\t"
+               "ds_read_u16 %3, %5 offset:%9\n\tds_read_u16 %4, %5 offset:%10"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+               : "v"(addr), "n"(BASE), "n"(BASE + STRIDE), "n"(BASE + 2 * STRIDE), "n"(BASE + 3 * STRIDE), "n"(BASE + 4 * STRIDE));
+}
+__device__ __forceinline__ void lds_gather5_b32(const u32* addr, u32* v) {
+  asm volatile("ds_read_b32 %0, %5\n\tds_read_b32 %1, %6\n\tds_read_b32 %2, %7\n\tds_read_b32 %3, %8\n\tds_read_b32 %4, %9"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+               : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]));
+}
+__device__ __forceinline__ void lds_wait8(u32* v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ void lds_wait5(u32* v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+}
+// the LDS byte address of a pointer into the workgroup's shared memory
+__device__ __forceinline__ u32 lds_addr(const void* p) { return (u32)reinterpret_cast<size_t>(p); }
 }  // namespace
 
 // WC = the frame width when it is known at compile time (160: row strides fold into instruction offsets and the
@@ -1269,10 +1312,12 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
     const int ash = (NLM_R - 3 + c00) & 3;     // columns the domain is extended to the left by: the a values start on a dword
     const int c0 = c00 - ash;                  // first column of the extended domain
     const int nrows = RBc + 6 + dy;            // rows -3 - dy .. RBc + 2 of the band
-    const int nseg = (W + adx + ash + 7) >> 3; // 8-column segments
+    const int nseg = (W + adx + ash + 11) / 12; // 12-column segments
     // ---- pass A: Hh[rr][c - c0] = min(4095, sum_{v=-3..3} (ext(r, c+v) - ext(r+dy, c+dx+v))^2), r = yb0 - 3 - dy + rr ----
+    // An item is a segment of 12 columns (18 values of each row: five dwords of a, six of b): the per-item index
+    // arithmetic is paid once per 12 columns and a band of 120 rows is at most two items per thread.
     {
-      const int sa0 = NLM_R - 3 + c0, sb0 = sa0 + dx;   // byte of a row where the 14 values of segment 0 start (>= 0; sa0 = 0 mod 4)
+      const int sa0 = NLM_R - 3 + c0, sb0 = sa0 + dx;   // byte of a row where the 18 values of segment 0 start (>= 0; sa0 = 0 mod 4)
       const int bbase = sb0 & ~3;                       // 4-byte aligned start of the b values; the shift is wave-uniform
       const u32 bsel = 0x03020100u + 0x01010101u * (u32)(sb0 & 3);
       const int items = nrows * nseg;
@@ -1283,21 +1328,22 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
       const int drr = NT_NLM / nseg, dsg = NT_NLM - drr * nseg;
       for (int it = tid; it < items; it += NT_NLM) {
         const int er = rr + NLM_R - 3 - dy;                // padded row of the a values
-        const u32* pa = reinterpret_cast<const u32*>(ext + __umul24((u32)er, (u32)ES) + sa0 + (sg << 3));
-        const u32* pb = reinterpret_cast<const u32*>(ext + __umul24((u32)(er + dy), (u32)ES) + bbase + (sg << 3));
-        u32 ra[4], qb[5];
+        const int so = __umul24((u32)sg, 12u);
+        const u32* pa = reinterpret_cast<const u32*>(ext + __umul24((u32)er, (u32)ES) + sa0 + so);
+        const u32* pb = reinterpret_cast<const u32*>(ext + __umul24((u32)(er + dy), (u32)ES) + bbase + so);
+        u32 ra[5], qb[6];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ra[k] = pa[k];
+        for (int k = 0; k < 5; ++k) ra[k] = pa[k];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) qb[k] = pb[k];
-        u32 rb[4];  // the 14 (16) b values, byte-aligned with the a values
+        for (int k = 0; k < 6; ++k) qb[k] = pb[k];
+        u32 rb[5];  // the 18 (20) b values, byte-aligned with the a values
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rb[k] = __builtin_amdgcn_perm(qb[k + 1], qb[k], bsel);
+        for (int k = 0; k < 5; ++k) rb[k] = __builtin_amdgcn_perm(qb[k + 1], qb[k], bsel);
         // D[i] = (d^2 of value 2i, d^2 of value 2i+1), E[i] = (d^2 of 2i+1, d^2 of 2i+2); the differences wrap in 16
         // bits and their squares are exact there (<= 255^2)
-        u16x2 D[7];
+        u16x2 D[9];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < 9; ++i) {
           u32 d;
           if (i & 1)
             asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"
@@ -1310,19 +1356,20 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
           const u16x2 dd = as_pk(d);
           D[i] = dd * dd;
         }
-        u16x2 E[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) E[i] = as_pk(__builtin_amdgcn_alignbit(as_u32(D[i + 1]), as_u32(D[i]), 16));
-        // output pair (2m, 2m+1) = sum of the seven pairs P[2m .. 2m+6], P[2i] = D[i], P[2i+1] = E[i]; saturating adds
+        // output pair (2m, 2m+1) = sum of the seven pairs P[2m .. 2m+6], P[2i] = D[i], P[2i+1] = E[i]
+        //                        = G[m] + G[m+1] + G[m+2] + D[m+3] with G[i] = D[i] + E[i]; saturating adds
         auto sadd = [](u16x2 x, u16x2 y) { return __builtin_elementwise_add_sat(x, y); };
-        const u16x2 Sa = sadd(sadd(sadd(D[1], E[1]), sadd(D[2], E[2])), D[3]);   // P2..P6
-        const u16x2 Sb = sadd(sadd(sadd(D[3], E[3]), sadd(D[4], E[4])), D[5]);   // P6..P10
+        u16x2 G[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) G[i] = sadd(D[i], as_pk(__builtin_amdgcn_alignbit(as_u32(D[i + 1]), as_u32(D[i]), 16)));
         const u16x2 cap = {4095, 4095};
-        const u16x2 o0 = __builtin_elementwise_min(sadd(sadd(D[0], E[0]), Sa), cap);   // P0..P6
-        const u16x2 o1 = __builtin_elementwise_min(sadd(Sa, sadd(E[3], D[4])), cap);   // P2..P8
-        const u16x2 o2 = __builtin_elementwise_min(sadd(sadd(D[2], E[2]), Sb), cap);   // P4..P10
-        const u16x2 o3 = __builtin_elementwise_min(sadd(Sb, sadd(E[5], D[6])), cap);   // P6..P12
-        *reinterpret_cast<uint4*>(Hh + __umul24((u32)rr, (u32)HS) + (sg << 3)) = make_uint4(as_u32(o0), as_u32(o1), as_u32(o2), as_u32(o3));
+        u32 o[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) o[m] = as_u32(__builtin_elementwise_min(sadd(sadd(G[m], sadd(G[m + 1], G[m + 2])), D[m + 3]), cap));
+        uint2* hp = reinterpret_cast<uint2*>(Hh + __umul24((u32)rr, (u32)HS) + so);   // 24 bytes, 8-byte aligned
+        hp[0] = make_uint2(o[0], o[1]);
+        hp[1] = make_uint2(o[2], o[3]);
+        hp[2] = make_uint2(o[4], o[5]);
         rr += drr;
         sg += dsg;
         if (sg >= nseg) {
@@ -1337,6 +1384,25 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
     const int cc = bx + coff;
     // (rows past the band's last one feed only outputs that are never stored; the array has BH spare rows for them)
     const uint16_t* hr0 = Hh + (cc & ~1) + __umul24((u32)rbase, (u32)HS);
+    if constexpr (WC == 160 && BH == 10 && NLM_ASM_HV) {  // sixteen rows off one address register (row stride 352 bytes)
+      constexpr int RS = 2 * ((160 + 24 + 7) & ~7);
+      const u32 ad = lds_addr(hr0);
+      if (coff & 1) {  // the pair straddles two aligned words (bx is even: the parity is the offset's)
+        u32 lo[16], hi[16];
+        lds_read8_b32<RS, 0>(ad, lo);
+        lds_read8_b32<RS, 4>(ad, hi);
+        lds_read8_b32<RS, 8 * RS>(ad, lo + 8);
+        lds_read8_b32<RS, 8 * RS + 4>(ad, hi + 8);
+        lds_wait8(lo); lds_wait8(hi); lds_wait8(lo + 8); lds_wait8(hi + 8);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hv[k] = __builtin_amdgcn_alignbit(hi[k], lo[k], 16);
+      } else {
+        lds_read8_b32<RS, 0>(ad, hv);
+        lds_read8_b32<RS, 8 * RS>(ad, hv + 8);
+        lds_wait8(hv); lds_wait8(hv + 8);
+      }
+      return;
+    }
     if (coff & 1) {  // the pair straddles two aligned words (bx is even: the parity is the offset's)
 #pragma unroll
       for (int k = 0; k < BH + 6; ++k) {
@@ -1377,6 +1443,53 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
       const u16x2 ones = {1, 1};
       auto rows = [&](auto podd_c) __attribute__((always_inline)) {
         constexpr bool PODD = decltype(podd_c)::value;
+        if constexpr (WC == 160 && BH == 10 && NLM_ASM_ROWS) {
+          // three phases instead of ten dependent chains: all table addresses (the sliding sums are cheap), then all
+          // LDS reads in flight at once, then the accumulation
+          constexpr int ESC = (160 + 2 * NLM_R + 8 + 7) & ~7;   // row stride of the padded image (bytes)
+          const u32 lut_ad = lds_addr(s_lut2);
+          u32 T0[BH], T1[BH];
+#pragma unroll
+          for (int i = 0; i < BH; ++i) {
+            const u16x2 cap48 = {48, 48};
+            T0[i] = __builtin_amdgcn_udot2(__builtin_elementwise_min(V0 >> 6, cap48), lut_k, lut_ad, false);
+            T1[i] = __builtin_amdgcn_udot2(__builtin_elementwise_min(V1 >> 6, cap48), lut_k, lut_ad, false);
+            if (i + 1 < BH) {
+              V0 = V0 + as_pk(hv0[i + 7]) - as_pk(hv0[i]);
+              V1 = V1 + as_pk(hv1[i + 7]) - as_pk(hv1[i]);
+            }
+          }
+          u32 W0[BH], W1[BH], A0[BH], B0[BH], A1[BH], B1[BH];
+          const u32 pa0 = lds_addr(px0), pa1 = lds_addr(px1);
+          lds_gather5_b32(T0, W0); lds_gather5_b32(T0 + 5, W0 + 5);
+          lds_gather5_b32(T1, W1); lds_gather5_b32(T1 + 5, W1 + 5);
+          lds_read5_u16<ESC, 0>(pa0, A0); lds_read5_u16<ESC, 5 * ESC>(pa0, A0 + 5);
+          lds_read5_u16<ESC, 0>(pa1, B0); lds_read5_u16<ESC, 5 * ESC>(pa1, B0 + 5);
+          if (PODD) {
+            lds_read5_u16<ESC, 2>(pa0, A1); lds_read5_u16<ESC, 5 * ESC + 2>(pa0, A1 + 5);
+            lds_read5_u16<ESC, 2>(pa1, B1); lds_read5_u16<ESC, 5 * ESC + 2>(pa1, B1 + 5);
+            lds_wait5(A1); lds_wait5(A1 + 5); lds_wait5(B1); lds_wait5(B1 + 5);
+          }
+          lds_wait5(W0); lds_wait5(W0 + 5); lds_wait5(W1); lds_wait5(W1 + 5);
+          lds_wait5(A0); lds_wait5(A0 + 5); lds_wait5(B0); lds_wait5(B0 + 5);
+#pragma unroll
+          for (int i = 0; i < BH; ++i) {
+            const u32 WA = __builtin_amdgcn_perm(W1[i], W0[i], 0x05040100u), WB = __builtin_amdgcn_perm(W1[i], W0[i], 0x07060302u);
+            u32 PA, PB;
+            if (PODD) {
+              PA = __builtin_amdgcn_perm(B0[i], A0[i], 0x0c050c01u);
+              PB = __builtin_amdgcn_perm(B1[i], A1[i], 0x0c040c00u);
+            } else {
+              PA = __builtin_amdgcn_perm(B0[i], A0[i], 0x0c040c00u);
+              PB = __builtin_amdgcn_perm(B0[i], A0[i], 0x0c050c01u);
+            }
+            est[2 * i] = (int)__builtin_amdgcn_udot2(as_pk(WA), as_pk(PA), (u32)est[2 * i], false);
+            est[2 * i + 1] = (int)__builtin_amdgcn_udot2(as_pk(WB), as_pk(PB), (u32)est[2 * i + 1], false);
+            wsum[2 * i] = (int)__builtin_amdgcn_udot2(as_pk(WA), ones, (u32)wsum[2 * i], false);
+            wsum[2 * i + 1] = (int)__builtin_amdgcn_udot2(as_pk(WB), ones, (u32)wsum[2 * i + 1], false);
+          }
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < BH; ++i) {
           const u16x2 cap48 = {48, 48};
@@ -1446,7 +1559,7 @@ __global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
 namespace {
 size_t nlm_lds_rows(int W, int rows, int bh) {
   const size_t ES = ((size_t)W + 2 * NLM_R + 8 + 7) & ~(size_t)7;
-  const size_t HS = ((size_t)W + 10 + 7) & ~(size_t)7;
+  const size_t HS = ((size_t)W + 24 + 7) & ~(size_t)7;
 #ifdef CPX_NLM_DB
   const size_t nbuf = 2;
 #else
