@@ -602,7 +602,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 6) void cpx_cptv_inflate_kernel(
     const long n = fi.in_bytes;
     if (n >= 18 && gb.u8(0) == 0x1f && gb.u8(1) == 0x8b && gb.u8(2) == 8) {
       const int flg = (int)gb.u8(3);
-      long pos = 10;
+      // FHCRC (a CRC-16 of the header, which zlib verifies) and the reserved flag bits (which zlib refuses) are left to
+      // the host reader: the member is reported as "not a gzip member" here, never silently accepted
+      long pos = (flg & 0xE2) ? n : 10;
       if (flg & 4) pos += 2 + (long)(gb.u8(10) | (gb.u8(11) << 8));
       if (flg & 8) {
         while (pos < n && gb.u8(pos) != 0) ++pos;
