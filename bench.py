@@ -398,7 +398,7 @@ def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
         dist.destroy_process_group()
 
 
-def bench_from_files(args, torch, np, local_rank, weights, T):
+def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with_fixtures=True):
     """The file-fed form of the headline path: `--from-files` synthetic recordings as CPTV byte
     strings in host memory (32 distinct clips of the headline's generator, T frames, gzip level 6, replicated) -> cpx.track.bulk.run_files_bulk
     with a ClipClassifier: upload, gzip inflate + section index + frame decode on the device, track, segments,
@@ -433,7 +433,7 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
     distinct = [encode_cptv(clips_host[i], t_on, ffc, level=6) for i in range(n_distinct)]
     del clips_host
     encode_s = time.perf_counter() - t0
-    n = args.from_files
+    n = n_files or args.from_files
     batch = 2048   # recordings per decode launch (tracked in groups of 1024)
     cc = ClipClassifier(cfg)
 
@@ -459,7 +459,7 @@ def bench_from_files(args, torch, np, local_rank, weights, T):
     # the same path over real recordings: copies of the two fixture clips (reference tests/clips), when they are here
     fixtures = None
     gold = os.path.join(REPO, "tests", "golden")
-    if all(os.path.exists(os.path.join(gold, f + ".cptv")) for f in ("possum", "hedgehog")):
+    if with_fixtures and all(os.path.exists(os.path.join(gold, f + ".cptv")) for f in ("possum", "hedgehog")):
         real = [open(os.path.join(gold, f + ".cptv"), "rb").read() for f in ("possum", "hedgehog")]
         nr = min(n, 4096)
         outr, tmr, dtr = measure([real[i % 2] for i in range(nr)], ["fixture_%05d.cptv" % i for i in range(nr)])
@@ -897,7 +897,7 @@ def main():
                 # input + output (+ residual in 3 of the 5 launches of a shape per forward), float32 NHWC
                 bytes2 = side * side * 64 * 4 * 2.6
                 if bf3 and key3 in conv:
-                    # stage 2 and stage 3 run the same instantiation (conv_bf3_kernel<1,1,2,16,512,false>: one row of the
+                    # stage 2 and stage 3 run the same instantiation (conv_bf3w_kernel<false,false>: one row of the
                     # rocprof CSV), with the same FLOPs per sample: the roofline covers the launches of both
                     n = conv[key][0] + conv[key3][0]
                     ms = conv[key][1] + conv[key3][1]
@@ -907,8 +907,8 @@ def main():
                     t2 = pmc_traffic("conv_stage2", samples_per_launch * area)
                     t3 = pmc_traffic("conv_stage3", samples_per_launch * area)
                     traffic = round((t2 + t3) / 2, 1) if t2 is not None and t3 is not None else None
-                    what = "conv_bf3_kernel<1,1,2,16,512,false> (stage-2 and stage-3 3x3 convs: 64->64 ch at %dx%d, 128->128 ch at %dx%d, groups 2)" % (
-                        side, side, side // 2, side // 2)
+                    what = ("conv_bf3w_kernel<false,false> (the 16x16x32 bf16 MFMA form of the split-operand kernel: stage-2 and "
+                            "stage-3 3x3 convs, 64->64 ch at %dx%d, 128->128 ch at %dx%d, groups 2)" % (side, side, side // 2, side // 2))
                 else:
                     n, ms, fl = conv[key]
                     samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
@@ -932,7 +932,9 @@ def main():
                                     "stage2_tflops": round(conv[key][2] / (conv[key][1] / 1e3) / 1e12, 2)}
                 tot_ms = sum(v[1] for v in conv.values())
                 tot_fl = sum(v[2] for v in conv.values())
-                line["cnn"] = {"conv_time_ms_per_step": round(tot_ms / args.steps, 2),
+                line["cnn"] = {"samples_per_s": round(int(r.n_samples) / max(tot_ms / args.steps / 1e3, 1e-9), 1),
+                               "samples_per_s_note": "classified segments of a step / the step's convolution time (SURVEY config 3)",
+                               "conv_time_ms_per_step": round(tot_ms / args.steps, 2),
                                "conv_tflops_all_layers": round(tot_fl / (tot_ms / 1e3) / 1e12, 2),
                                "track_kernel_ms_per_step": round(kernel_ms / args.steps, 2),
                                "math": args.cnn_math,
@@ -980,19 +982,20 @@ def main():
             eng.synchronize()
             dt0 = time.perf_counter() - t1
             nlm_s = dt - dt0
-            # Operation-count model of cpx_nlm_kernel<10,160>, calibrated by its SQ counters
-            # (profiles/r03_nlm_sq_counters.json, scratch/pmc_nlm.sh: SQ_INSTS_VALU 2.0 M wave-instructions per frame =
-            # 15.1 vector lane-operations per (pixel, offset) of the 21 x 21 window, SQ_INSTS_LDS 0.31 M = 2.3;
-            # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0 cycles per wave-instruction -- the kernel's packed 16-bit,
-            # byte-permute and 24-bit multiply instructions issue 16 lanes per cycle and SIMD, half the fp32 rate --
-            # so a CU retires 64 of these lane-operations per cycle; the vector pipes are busy 76 % of the kernel's
-            # time (4 waves per SIMD x ACTIVE_INST_VALU / WAVE_CYCLES), waves parked on LDS data 45 % of theirs).
+            # Instruction census of cpx_nlm_kernel<10,160> (profiles/r04_nlm_sq_counters.json):
+            # the bound is the MINIMAL packed instruction count of this algorithm form -- paired offsets, 16-bit pairs,
+            # row sums through LDS, sliding column sums -- at the vector pipes' nominal rate; `frac` = bound / achieved,
+            # so it says how far the shipped kernel is from that count (it was the kernel's own count until round 3).
+            #   row pass, per 12 columns and offset PAIR: 18 byte differences (SDWA) + 9 squares + 8 shifted copies +
+            #   26 window adds + 6 caps + 5 alignments of the b row = 72 -> 3.0 per (pixel, offset)
+            #   column pass, per 2 pixels and offset PAIR: 2 shifts + 2 caps + 2 table addresses (dot2) + 4 transposes +
+            #   4 accumulations (dot2) + 4 sliding updates = 18 -> 4.5, + window set-up 0.3
             px_off = H * W * 441.0
-            valu_per, lds_per, valu_rate = 15.1, 2.3, 64.0
-            valu_ops, lds_ops = valu_per * px_off, lds_per * px_off
-            clock = 2.4e9
-            t_valu = valu_ops / valu_rate / clock / 256.0   # seconds per frame, chip-wide, if vector issue were the bound
-            t_lds = lds_ops / 32.0 / clock / 256.0          # ... if the LDS instruction rate were
+            valu_min, valu_shipped, lds_shipped = 7.8, 12.2, 2.65
+            clock, cus = 2.4e9, 256.0
+            t_min = valu_min * px_off / 128.0 / clock / cus        # 4 SIMD-32 per CU: 128 lane-operations per cycle
+            t_shipped = valu_shipped * px_off / 128.0 / clock / cus
+            t_lds = lds_shipped * px_off / 32.0 / clock / cus       # ds_read_b32 / u16: 32 lanes per cycle and CU
             nlm_per_frame = nlm_s / (nb * T)
             line["default_config"] = {
                 "what": "the reference's DEFAULT configuration (tracking.denoise = true, SURVEY F7) over %d of the resident "
@@ -1005,22 +1008,26 @@ def main():
                 "nlm_share_of_step": round(nlm_s / dt_e2e, 3),
                 "frames_per_s_denoise_off_same_slice": round(nb * T / dt0, 1)}
             line["roofline_nlm"] = {
-                "kernel": "cpx_nlm_kernel<10,160>", "bound": "vector + LDS instruction issue (no HBM or matrix roof applies: "
-                          "19 KB in, 19 KB out per frame, integer arithmetic on an LDS-resident frame)",
-                "model": {"pixel_offsets_per_frame": px_off, "vector_lane_ops_per_pixel_offset": valu_per,
-                          "lds_lane_ops_per_pixel_offset": lds_per, "vector_lane_ops_per_cycle_per_cu": valu_rate,
-                          "lds_lanes_per_cycle_per_cu": 32, "clock_hz": clock, "cus": 256,
-                          "calibration": "profiles/r03_nlm_sq_counters.json (rocprofv3 --pmc, separate passes)"},
-                "measured_sq": {"valu_cycles_per_wave_instruction": 4.0, "valu_pipe_busy": 0.76,
-                                "wave_time_parked_on_waitcnt_or_barrier": 0.45, "wave_time_issue_stalled": 0.26,
-                                "lds_bank_conflict_share_of_lds_cycles": 0.36},
+                "kernel": "cpx_nlm_kernel<10,160>", "bound": "vector instruction issue at the MINIMAL instruction count of the "
+                          "paired sliding-sum form (no HBM or matrix roof applies: 19 KB in, 19 KB out per frame, integer "
+                          "arithmetic on an LDS-resident frame)",
+                "model": {"pixel_offsets_per_frame": px_off, "minimal_vector_lane_ops_per_pixel_offset": valu_min,
+                          "shipped_vector_lane_ops_per_pixel_offset": valu_shipped,
+                          "shipped_lds_lane_ops_per_pixel_offset": lds_shipped,
+                          "vector_lane_ops_per_cycle_per_cu": 128.0, "lds_lanes_per_cycle_per_cu": 32, "clock_hz": clock,
+                          "cus": cus, "census": "DESIGN.md section 5; SQ_INSTS_VALU / SQ_INSTS_LDS of "
+                                                "profiles/r04_nlm_sq_counters.json (rocprofv3 --pmc, separate passes); "
+                                                "round 3 shipped 15.1 / 2.3"},
                 "achieved_us_per_frame": round(nlm_per_frame * 1e6, 3),
-                "vector_issue_bound_us_per_frame": round(t_valu * 1e6, 3),
-                "lds_issue_bound_us_per_frame": round(t_lds * 1e6, 3),
-                "frac": round(max(t_valu, t_lds) / nlm_per_frame, 4), "unit": "fraction of the nearer issue bound",
-                "note": "frames in flight: one 1024-thread workgroup (a whole frame) per CU, 16 waves; the vector pipes "
-                        "are 76 % busy: what is left is instruction count, not stalls (double-buffering the row sums to "
-                        "halve the barriers: 4.53 vs 4.56 us; two workgroups per CU: 5.40 vs 4.51)"}
+                "minimal_count_bound_us_per_frame": round(t_min * 1e6, 3),
+                "shipped_count_at_nominal_rate_us_per_frame": round(t_shipped * 1e6, 3),
+                "lds_issue_us_per_frame": round(t_lds * 1e6, 3),
+                "frac": round(t_min / nlm_per_frame, 4), "unit": "minimal-count vector issue time / achieved time",
+                "shipped_over_minimal_count": round(valu_shipped / valu_min, 2),
+                "note": "one 1024-thread workgroup (a whole frame) per CU, 16 waves; measured issue cost of every "
+                        "instruction of the kernel: 2.74 cycles per wave-instruction and SIMD at 4 waves per SIMD "
+                        "(scratch/valu_cost_probe.hip), i.e. 0.73 of the nominal rate; LDS busy 56 % (a third of it bank "
+                        "conflicts of the weight-table gather)"}
             nb64 = min(B, 1024)
             net64 = wr.WRResNetDevice(eng, weights, N_LABELS)
             pipe64 = BatchPipeline(eng, net64, n_labels=N_LABELS, fp_index=4, cnn_chunk=512, frame_size=64)
@@ -1071,11 +1078,34 @@ def main():
                                "frames_total": cfg4["frames_total"], "frames_per_rank": cfg4["frames_per_rank"],
                                "imbalance": cfg4["imbalance"], "records_gathered": cfg4["records_gathered"],
                                "gather_ms_per_step_rank0": cfg4["gather_ms_per_step_rank0"]}
-    if extras and world == 1 and args.from_files > 0 and rank == 0:
+    if extras and args.from_files > 0:
+        # N > 1: every rank runs the file-fed path over ITS share of the recordings (shard_files' partition: recordings
+        # are independent), with its host stages beside the other ranks' on the node's CPUs -- the scaling risk of this
+        # path is the host (staging, metadata text), not a collective, so the per-rank split is what is reported
+        share = args.from_files if world == 1 else max(512, args.from_files // world)
         try:
-            line["from_files"] = bench_from_files(args, torch, np, local_rank, weights, T)
+            ff = bench_from_files(args, torch, np, local_rank, weights, T, n_files=share, with_fixtures=world == 1)
         except Exception as e:  # noqa: BLE001 -- the headline line above is complete: report, do not lose it
-            line["from_files"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+            ff = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        if world == 1:
+            line["from_files"] = ff
+        else:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, ff)
+            if rank == 0:
+                ok = [r for r in per_rank if r and "error" not in r]
+                agg = {"what": "every rank: %d synthetic recordings (its share) through run_files_bulk on its own GPU, host "
+                               "stages of all ranks on the node's CPUs at the same time" % share,
+                       "ranks": world, "host_cpus_usable": usable_cpus(),
+                       "per_rank": [{"rank": i, **({k: r[k] for k in ("files", "frames", "seconds", "frames_per_s", "split_s")}
+                                                    if r and "error" not in r else {"error": (r or {}).get("error")})}
+                                    for i, r in enumerate(per_rank)]}
+                if ok:
+                    slowest = max(r["seconds"] for r in ok)
+                    agg["frames"] = int(sum(r["frames"] for r in ok))
+                    agg["seconds_slowest_rank"] = round(slowest, 3)
+                    agg["frames_per_s"] = round(agg["frames"] / slowest, 1)
+                line["from_files"] = agg
     if rank == 0:
         print(json.dumps(line), flush=True)
     if not (extras and (world > 1 or args.from_files > 0)):

@@ -50,7 +50,9 @@ class FileStager:
 
     def __init__(self, torch, threads=None):
         self.torch = torch
-        self.threads = threads or min(16, os.cpu_count() or 1)
+        from ..sharding import host_threads_per_rank
+
+        self.threads = threads or host_threads_per_rank(16)   # the node's CPU quota shared among its ranks
         self.pool = ThreadPoolExecutor(max_workers=self.threads)
         self.driver = ThreadPoolExecutor(max_workers=1)
         self.buffers = [None, None]
