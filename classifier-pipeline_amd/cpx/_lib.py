@@ -117,7 +117,7 @@ EXPORTS = [
     "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
-    "cpx_finalize_tracks", "cpx_plan_segments", "cpx_aggregate_predictions",
+    "cpx_finalize_tracks", "cpx_counts_prefix", "cpx_plan_segments", "cpx_aggregate_predictions",
     "cpx_conv_timing_enable", "cpx_conv_timing_report", "cpx_cptv_unpack", "cpx_thumb_stats", "cpx_trackless_thumb",
     "cpx_trackless_thumb_batch", "cpx_thumb_stats_ex",
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
@@ -184,6 +184,8 @@ def load():
     lib.cpx_finalize_tracks.restype = C.c_int
     lib.cpx_plan_segments.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
     lib.cpx_plan_segments.restype = C.c_int
+    lib.cpx_counts_prefix.argtypes = [vp, vp, C.c_int, vp]
+    lib.cpx_counts_prefix.restype = C.c_int
     lib.cpx_aggregate_predictions.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.cpx_aggregate_predictions.restype = C.c_int
     lib.cpx_conv_timing_enable.argtypes = [vp, C.c_int]

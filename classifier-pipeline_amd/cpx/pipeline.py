@@ -163,7 +163,11 @@ class BatchPipeline:
         on_stream = int(t.cuda.current_stream(dev).cuda_stream) == int(lib.cpx_stream(h) or 0)
         if not on_stream:
             eng.synchronize()  # torch runs on another stream (the overlapped form): the kernels must have finished
-        prefix = (t.cumsum(counts, dim=0) - counts).to(t.int32).contiguous()
+        # exclusive prefix sums of the counts on the handle's stream (cpx_counts_prefix: the step launches no torch kernel)
+        prefix = t.empty((B + 1, 4), dtype=t.int32, device=dev)
+        self._check(lib.cpx_counts_prefix(h, C.c_void_p(counts.data_ptr()), B, C.c_void_p(prefix.data_ptr())))
+        if not on_stream:
+            eng.synchronize()
         out.counts = counts.cpu().numpy()   # the one host wait of a run: the work counts size what follows
         totals = out.counts.sum(axis=0)
         out.track_timing = eng.last_kernel_timing()  # (ms, launches) of this group's frame-kernel launches
@@ -173,11 +177,12 @@ class BatchPipeline:
             return out
         # ---- 4. segment plan ----
         per = self.sq * self.sq
-        refs = t.zeros(max(n_refs, 1) * 6, dtype=t.int32, device=dev)
-        toffs = t.zeros(n_tracks + 1, dtype=t.int32, device=dev)
-        reqs = t.zeros(n_samples * per * 8, dtype=t.int32, device=dev)
-        sample_track = t.zeros(n_samples, dtype=t.int32, device=dev)
-        track_clip = t.zeros((n_tracks, 2), dtype=t.int32, device=dev)
+        # (every entry is written by the plan pass, the closing track offset included: no fills)
+        refs = t.empty(max(n_refs, 1) * 6, dtype=t.int32, device=dev)
+        toffs = t.empty(n_tracks + 1, dtype=t.int32, device=dev)
+        reqs = t.empty(n_samples * per * 8, dtype=t.int32, device=dev)
+        sample_track = t.empty(n_samples, dtype=t.int32, device=dev)
+        track_clip = t.empty((n_tracks, 2), dtype=t.int32, device=dev)
         eng.sync_inputs()
         self._check(lib.cpx_plan_segments(
             h, C.byref(self.fp), offs_p, C.c_void_p(meta.ctypes.data), B, C.c_void_p(out.assoc.pool_dev.data_ptr()),
@@ -186,7 +191,6 @@ class BatchPipeline:
             C.c_void_p(sample_track.data_ptr()), C.c_void_p(track_clip.data_ptr())))
         if not on_stream:
             eng.synchronize()
-        toffs[n_tracks] = n_refs
         out.track_clip, out.reqs_dev, out.sample_track_dev = track_clip, reqs, sample_track
         # ---- 5a. per-track limits ----
         limits = t.zeros(n_tracks * 8, dtype=t.int32, device=dev)

@@ -1030,6 +1030,15 @@ int cpx_plan_segments(cpx_handle* h, const cpx_filter_params* params, const int3
   return CPX_OK;
 }
 
+int cpx_counts_prefix(cpx_handle* h, const int32_t* counts_dev, int B, int32_t* prefix_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!counts_dev || !prefix_dev || B <= 0) return fail(h, CPX_ERR_INVALID, "cpx_counts_prefix: bad argument");
+  CPX_ENTER(h);
+  cpx::launch_counts_prefix(counts_dev, B, prefix_dev, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 int cpx_aggregate_predictions(cpx_handle* h, const float* probs_dev, const int32_t* sample_track_dev,
                               int n_samples, const cpx_crop_req* reqs_dev, int n_tracks, int n_labels,
                               int false_positive_index, int square_width, float* scores_dev, int32_t* best_dev) {

@@ -79,6 +79,47 @@ __global__ __launch_bounds__(64) void cpx_finalize_kernel(FinalArgs a) {
                 a.square_width, a.summaries + (size_t)b * mt, a.counts + 4 * b, sc);
 }
 
+// exclusive prefix sums of the per-clip work counts [B][4] (kept tracks, region refs, samples, spare) -> [B + 1][4],
+// row B = the totals: one workgroup, a wave scan per 1024 clips with the carry handed on -- what sizes and addresses
+// the plan pass, on the handle's stream (it was a torch cumsum + subtract + cast: three at::native launches per step)
+__global__ __launch_bounds__(1024) void cpx_counts_prefix_kernel(const int* __restrict__ counts, int B, int* __restrict__ prefix) {
+  __shared__ int s_wave[16][4];
+  __shared__ int s_carry[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 4) s_carry[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int b = base + tid;
+    int v[4], inc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = b < B ? counts[4 * b + k] : 0;
+      inc[k] = v[k];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc[k], d, 64);
+        if (lane >= d) inc[k] += o;
+      }
+      if (lane == 63) s_wave[wave][k] = inc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int before = s_carry[k];
+      for (int w = 0; w < wave; ++w) before += s_wave[w][k];
+      if (b < B) prefix[4 * b + k] = before + inc[k] - v[k];
+    }
+    __syncthreads();
+    if (tid < 4) {
+      int tot = s_carry[tid];
+      for (int w = 0; w < 16; ++w) tot += s_wave[w][tid];
+      s_carry[tid] = tot;
+    }
+    __syncthreads();
+  }
+  if (tid < 4) prefix[4 * B + tid] = s_carry[tid];
+}
+
 __global__ __launch_bounds__(64) void cpx_plan_kernel(FinalArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
@@ -87,7 +128,7 @@ __global__ __launch_bounds__(64) void cpx_plan_kernel(FinalArgs a) {
   const int ma = a.params.max_active_tracks, mt = a.params.max_tracks_per_clip;
   plan_clip(a.params, a.pool + (size_t)first * ma, a.summaries + (size_t)b * mt, a.n_tracks[b], a.proc_ffc + pbase,
             a.proc_idx + pbase, a.square_width, b, a.prefix + 4 * b, a.refs, a.track_offsets, a.reqs, a.sample_track,
-            a.track_clip, reinterpret_cast<unsigned char*>(a.scratch_d + (size_t)b * 2 * a.max_frames));
+            a.track_clip, reinterpret_cast<unsigned char*>(a.scratch_d + (size_t)b * 2 * a.max_frames), b == a.B - 1);
 }
 
 // One lane walks one clip, and the clips of a wave take different paths: a wave costs the union of its lanes' paths,
@@ -102,6 +143,9 @@ static inline int lanes_per_wave(int B) {
 void launch_finalize(const FinalArgs& a, hipStream_t s) {
   const int l = lanes_per_wave(a.B);
   hipLaunchKernelGGL(cpx_finalize_kernel, dim3((a.B + l - 1) / l), dim3(l), 0, s, a);
+}
+void launch_counts_prefix(const int* counts, int B, int* prefix, hipStream_t s) {
+  hipLaunchKernelGGL(cpx_counts_prefix_kernel, dim3(1), dim3(1024), 0, s, counts, B, prefix);
 }
 void launch_plan(const FinalArgs& a, hipStream_t s) {
   const int l = lanes_per_wave(a.B);

@@ -373,7 +373,7 @@ CPX_HD inline void finalize_clip(const cpx_filter_params& fp, const RegionRec* p
 CPX_HD inline void plan_clip(const cpx_filter_params& fp, const RegionRec* pool, const cpx_track_summary* sums,
                              int n_tracks, const int* proc_ffc, const int* proc_idx, int square_width, int clip,
                              const int* prefix, cpx_region_ref* refs, int* track_offsets, cpx_crop_req* reqs,
-                             int* sample_track, int* track_clip, unsigned char* taken) {
+                             int* sample_track, int* track_clip, unsigned char* taken, bool last_clip = false) {
   int ti = prefix[0], ri = prefix[1], si = prefix[2];
   const int per = square_width * square_width;
   // kept tracks in score order
@@ -412,6 +412,8 @@ CPX_HD inline void plan_clip(const cpx_filter_params& fp, const RegionRec* pool,
     }
     ti += 1;
   }
+  // track_offsets has one entry more than there are kept tracks: the end of the last track's refs
+  if (last_clip) track_offsets[ti] = ri;
 }
 
 }  // namespace cpx

@@ -141,6 +141,7 @@ struct FinalArgs {
 };
 void launch_finalize(const FinalArgs& a, hipStream_t s);
 void launch_plan(const FinalArgs& a, hipStream_t s);
+void launch_counts_prefix(const int* counts, int B, int* prefix, hipStream_t s);
 size_t assoc_active_bytes();
 size_t assoc_score_bytes();
 

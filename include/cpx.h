@@ -410,6 +410,12 @@ typedef struct cpx_crop_req { /* one tile = one frame of one segment */
   int32_t tile;                /* 0 .. square_width^2 - 1, row-major */
 } cpx_crop_req;
 
+/* Exclusive prefix sums of cpx_finalize_tracks' per-clip work counts (counts_dev int32 [B][4]: kept tracks, region
+ * refs, samples, spare) -> prefix_dev int32 [B + 1][4], row B = the totals: the addresses cpx_plan_segments writes a
+ * clip's tracks / refs / samples to (the reference appends them to Python lists in clip order, interpreter.py:178-253,
+ * clipclassifier.py:252-303).  One small launch on the handle's stream. */
+int cpx_counts_prefix(cpx_handle* h, const int32_t* counts_dev, int B, int32_t* prefix_dev);
+
 /* Plans the classification work of a batch on the device: get_segments(SegmentType.ALL_RANDOM_MASKED)
  * (ml_tools/datasetstructures.py:972-1301) as it plans when every random draw is the identity -- np.random.shuffle
  * leaves the order, choice(replace=False) takes the first k, choice(replace=True) cycles (the reference draws at
@@ -418,8 +424,9 @@ typedef struct cpx_crop_req { /* one tile = one frame of one segment */
  * frames, the short remainder padded both ways as the reference pads, segments whose mass falls below the track's
  * threshold dropped.  tests/golden/segments_identity_golden.json holds the reference's own output under these draws.
  * Inputs: outputs of cpx_associate_batch / cpx_finalize_tracks and, per clip, exclusive prefix sums
- * (device int32 [B][4]) of counts_dev.  Fills refs / track offsets / crop requests / per-sample track
- * index for cpx_track_limits_batch and cpx_crop_tile; track_clip_dev[t] = (clip, track id). */
+ * (device int32 [B][4]: cpx_counts_prefix) of counts_dev.  Fills refs / track offsets (one entry more than kept tracks:
+ * the last one closes the last track's refs) / crop requests / per-sample track index for cpx_track_limits_batch and
+ * cpx_crop_tile; track_clip_dev[t] = (clip, track id). */
 int cpx_plan_segments(cpx_handle* h, const cpx_filter_params* params, const int32_t* clip_offsets,
                       const cpx_frame_meta* meta, int B, const cpx_region* pool_dev,
                       const cpx_track_summary* summaries_dev, const int32_t* n_tracks_dev,

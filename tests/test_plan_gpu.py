@@ -75,9 +75,17 @@ def test_plan_segments_equals_reference_under_identity_draws():
     if rc != 0:
         raise CpxError(rc, eng._err())
     eng.synchronize()
+    # the offsets the pipeline feeds the planner: cpx_counts_prefix of the counts = NumPy's exclusive prefix sums + totals
+    counts_d = t.from_numpy(np.ascontiguousarray(counts, np.int32)).to(dev)
+    pre_d = t.full((B + 1, 4), -1, dtype=t.int32, device=dev)
+    assert eng.lib.cpx_counts_prefix(eng.h, C.c_void_p(counts_d.data_ptr()), B, C.c_void_p(pre_d.data_ptr())) == 0
+    eng.synchronize()
+    pre = pre_d.cpu().numpy()
+    assert np.array_equal(pre[:B], prefix) and np.array_equal(pre[B], counts.sum(axis=0))
     reqs = reqs_d.cpu().numpy().view(CROP_REQ_DTYPE).reshape(n_samples, per)
     refs = refs_d.cpu().numpy().view(REGION_REF_DTYPE)
     st, tc, toffs = st_d.cpu().numpy(), tc_d.cpu().numpy(), toffs_d.cpu().numpy()
+    assert int(toffs[n_tracks]) == n_refs          # the closing offset is the planner's (it was a torch index write)
     assert (reqs["frame"] >= 0).all() and (st >= 0).all(), "the planner produced fewer segments than the reference"
     n_checked = 0
     for b, c in enumerate(cases):
