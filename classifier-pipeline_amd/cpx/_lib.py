@@ -123,7 +123,7 @@ EXPORTS = [
     "cpx_track_frame", "cpx_associate_frame", "cpx_cnn_create", "cpx_cnn_destroy", "cpx_cnn_forward", "cpx_ir_detect", "cpx_set_cnn_math", "cpx_get_cnn_math",
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
-    "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index", "cpx_format_regions", "cpx_json_indent", "cpx_ir_merge",
+    "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index", "cpx_format_regions", "cpx_json_indent", "cpx_ir_merge", "cpx_ir_resize_area",
     "cpx_ir_frame_statistics",
 ]
 
@@ -210,6 +210,8 @@ def load():
     lib.cpx_ir_delta_variance.restype = C.c_int
     lib.cpx_ir_merge.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.cpx_ir_merge.restype = C.c_int
+    lib.cpx_ir_resize_area.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.cpx_ir_resize_area.restype = C.c_int
     lib.cpx_ir_frame_statistics.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
     lib.cpx_ir_frame_statistics.restype = C.c_int
     lib.cpx_cnn_create.argtypes = [vp, C.POINTER(WRResNetParams), C.POINTER(vp)]

@@ -441,6 +441,28 @@ class TrackEngine:
         host = comps[:, :used].contiguous().cpu().numpy().view(COMPONENT_DTYPE).reshape(n, used)
         return cnt, host, labels
 
+    def ir_resize_area(self, images_dev, factor, pad_width_to=1):
+        """cpx_ir_resize_area: cv2.resize(..., interpolation=cv2.INTER_AREA) by an integer factor, uint8 [n, H, W] (or
+        [H, W]) on the device -> uint8 [n, H / factor, W / factor]; pad_width_to = 64: zero columns on the right up
+        to a multiple of 64 (what cpx_ir_detect's bit rows want).  Everything runs on the handle's stream."""
+        t = self.torch
+        single = images_dev.dim() == 2
+        src = (images_dev[None] if single else images_dev).contiguous()
+        n, H, W = (int(v) for v in src.shape)
+        out = t.empty((n, H // factor, W // factor), dtype=t.uint8, device=self.device)
+        self.sync_inputs()
+        rc = self.lib.cpx_ir_resize_area(self.h, C.c_void_p(src.data_ptr()), n, W, H, int(factor), C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        wo = W // factor
+        if pad_width_to > 1 and wo % pad_width_to:
+            with t.cuda.stream(self.torch_stream()):
+                wide = t.zeros((n, H // factor, (wo + pad_width_to - 1) // pad_width_to * pad_width_to), dtype=t.uint8,
+                               device=self.device)
+                wide[:, :, :wo] = out
+            out = wide
+        return out[0] if single else out
+
     def ir_delta_variance(self, cur_dev, prev_dev, rects):
         """cpx_ir_delta_variance: np.var of the uint8-wrapping frame difference over each [x, y, w, h] box -> float64 [n]."""
         t = self.torch

@@ -136,8 +136,15 @@ class IRTrackExtractor(ClipTracker):
                  do_tracking=True, on_trapped=None, update_background=True, trap_size="L", tracking_alg="mog2",
                  check_trapped=False, from_pi=False, device=0, max_frames=4096):
         super().__init__(config, cache_to_disk, keep_frames, calc_stats, verbose, do_tracking=do_tracking, scale=scale)
+        self._factor = None
         if scale:
-            raise NotImplementedError("scale (cv2.resize INTER_AREA of the foreground) is not part of this build")
+            # the foreground is detected on cv2.resize(filtered, (int(res_x * scale), int(res_y * scale)), INTER_AREA)
+            # (irtrackextractor.py:445-451): built for the integer ratios (the reference's only caller passes 0.25,
+            # piclassifier.py:225), where INTER_AREA is the block mean (cpx_ir_resize_area)
+            f = 1.0 / float(scale)
+            if abs(f - round(f)) > 1e-9 or round(f) < 1 or round(f) > 16:
+                raise NotImplementedError("scale %r: only 1 / integer (0.5, 0.25, ...) is built" % (scale,))
+            self._factor = int(round(f))
         if tracking_alg != "mog2":
             raise NotImplementedError("tracking_alg %r: only the MOG2 background model is built (SuBSENSE is pybgs)"
                                       % tracking_alg)
@@ -238,6 +245,10 @@ class IRTrackExtractor(ClipTracker):
         start = time.time()
         if len(videos) == 0:
             return True
+        if self.scale:   # (the lockstep batch merges on the device at full resolution: a scaled tracker walks its videos one by one)
+            if hasattr(videos, "data_ptr"):
+                videos = [videos[:, v].cpu().numpy() for v in range(int(videos.shape[1]))]
+            return all(self.parse_frames(clip, np.asarray(video)) for clip, video in zip(clips, videos))
         resident = hasattr(videos, "data_ptr")   # a uint8 device tensor [T, V, H, W]: frames already in HBM
         if resident:
             T, V, H, W = (int(x) for x in videos.shape)
@@ -481,8 +492,15 @@ class IRTrackExtractor(ClipTracker):
         del self._ring[: -(self.FRAMES_AGO + 1)]
         if not self.do_tracking:
             return
-        _, _, stats = detect_objects_ir(self._engine, filtered_dev, threshold=0, max_components=4096)
-        component_details = self.merge_components(list(stats[1:]))
+        re_f = filtered_dev
+        if self.scale and self._factor > 1:
+            if clip.res_x % self._factor or clip.res_y % self._factor:
+                raise NotImplementedError("scale %r does not divide a %d x %d frame" % (self.scale, clip.res_x, clip.res_y))
+            # cpx_ir_detect packs 64 pixels per word: zero columns on the right up to a multiple of 64 change nothing
+            # (the open's element is vertical -- the (15, 15) tuple quirk, SURVEY F3 -- and zeros join no component)
+            re_f = self._engine.ir_resize_area(filtered_dev, self._factor, pad_width_to=64)
+        _, _, stats = detect_objects_ir(self._engine, re_f, threshold=0, max_components=4096)
+        component_details = self.merge_components(list(stats[1:]))   # (thresholds scaled: irdetect.merge_components)
         if clip.from_metadata:
             return  # tracks come from the metadata: nothing is matched (the reference re-reads their frames only)
         regions = []
@@ -522,13 +540,21 @@ class IRTrackExtractor(ClipTracker):
         comps = np.zeros(n, COMPONENT_DTYPE)
         variances = np.zeros(n, np.float64)
         if n:
+            # with a scale the components are in the down-scaled image: Region.rescale(1 / scale) (region.py:44-50,
+            # cliptracker.py:297-298) truncates x, y, width, height times the factor and multiplies the mass by its
+            # square; the centroid was taken from the box BEFORE that and is left where it was (as in the reference)
+            f = float(1 / self.scale) if self.scale else 1.0
+            cents = [(int(c[0] + c[2] / 2), int(c[1] + c[3] / 2)) for c in component_details]
+            if self.scale:
+                component_details = [[int(c[0] * f), int(c[1] * f), int(c[2] * f), int(c[3] * f), int(c[4] * f * f)]
+                                     for c in component_details]
             rects = np.array([[int(c[0]), int(c[1]), int(c[2]), int(c[3])] for c in component_details], np.int32)
             _, prev_dev = self.get_delta_frame(clip)
             if prev_dev is not None:
                 variances = self._engine.ir_delta_variance(self._ring[-1][1], prev_dev, rects)
             for i, c in enumerate(component_details):
                 x, y, w, h, mass = (int(v) for v in c[:5])
-                cx, cy = int(x + w / 2), int(y + h / 2)     # the IR tracker's centroid: the box centre, truncated
+                cx, cy = cents[i]     # the IR tracker's centroid: the box centre, truncated
                 comps[i] = (x, y, w, h, mass, cx * mass, cy * mass, np.float32(variances[i]))
         f = self._stream.append(comps, ffc_affected=False)
         stream = self._stream

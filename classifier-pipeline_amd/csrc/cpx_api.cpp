@@ -1441,6 +1441,19 @@ int cpx_ir_delta_variance(cpx_handle* h, const uint8_t* cur_dev, const uint8_t* 
   return CPX_OK;
 }
 
+int cpx_ir_resize_area(cpx_handle* h, const uint8_t* src_dev, int n, int width, int height, int factor, uint8_t* dst_dev) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!src_dev || !dst_dev || n < 0 || width < 1 || height < 1 || factor < 1)
+    return fail(h, CPX_ERR_INVALID, "cpx_ir_resize_area: bad argument");
+  if (factor > 16 || width % factor || height % factor)
+    return fail(h, CPX_ERR_UNSUPPORTED, "cpx_ir_resize_area: the factor must divide both sides (integer-ratio INTER_AREA only)");
+  if (n == 0) return CPX_OK;
+  CPX_ENTER(h);
+  cpx::launch_ir_resize_area(src_dev, dst_dev, n, width, height, factor, h->stream);
+  CPX_HIP(h, hipGetLastError());
+  return CPX_OK;
+}
+
 int cpx_ir_merge(cpx_handle* h, const cpx_component* comps_dev, const int32_t* counts_dev, int n, int cap_in, int cap_out,
                  const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height, int frame_number, int out_stride,
                  cpx_component* out_comps_dev, cpx_frame_info* out_info_dev, int32_t* status_dev) {

@@ -669,4 +669,36 @@ int launch_ir_detect(const IrArgs& a, int n_frames, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// cv2.resize(uint8, (W / f, H / f), interpolation=cv2.INTER_AREA) for an integer factor f: what the IR tracker does to
+// its foreground image when it is given a `scale` (track/irtrackextractor.py:445-451; the Pi runs scale = 0.25).  With
+// an integer ratio OpenCV averages the f x f block: factor 2 as (sum + 2) >> 2 (its SIMD path), any other factor as
+// the sum times the float32 1 / f^2, rounded to nearest-even (saturate_cast<uchar>).  One thread per output pixel;
+// lanes of a wave read adjacent f-byte runs of the same source rows.
+__global__ __launch_bounds__(256) void cpx_ir_resize_area_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                                 int n, int W, int H, int f) {
+  const int Wo = W / f, Ho = H / f;
+  const long long total = (long long)n * Wo * Ho;
+  const float inv = 1.0f / (float)(f * f);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wo);
+    const long long r = i / Wo;
+    const int y = (int)(r % Ho);
+    const int k = (int)(r / Ho);
+    const unsigned char* p = src + ((size_t)k * H + (size_t)y * f) * W + (size_t)x * f;
+    unsigned sum = 0;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) sum += p[(size_t)dy * W + dx];
+    unsigned v;
+    if (f == 2) v = (sum + 2u) >> 2;
+    else v = (unsigned)__float2int_rn((float)sum * inv);
+    dst[i] = (unsigned char)(v > 255u ? 255u : v);
+  }
+}
+void launch_ir_resize_area(const unsigned char* src, unsigned char* dst, int n, int W, int H, int f, hipStream_t s) {
+  const long long total = (long long)n * (W / f) * (H / f);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+  hipLaunchKernelGGL(cpx_ir_resize_area_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, dst, n, W, H, f);
+}
+
 }  // namespace cpx

@@ -294,6 +294,7 @@ struct IrMergeArgs {
   int* status;                    // [n]
 };
 void launch_ir_merge(const IrMergeArgs& a, hipStream_t s);
+void launch_ir_resize_area(const unsigned char* src, unsigned char* dst, int n, int W, int H, int f, hipStream_t s);
 struct IrStatsArgs {
   int n, pixels, vec16;
   const unsigned char* frames;   // [n][pixels]

@@ -506,6 +506,14 @@ int cpx_ir_detect(cpx_handle* h, const uint8_t* images_dev, int n_frames, int wi
                   int max_components, cpx_component* comps_dev, int32_t* counts_dev, int32_t* status_dev,
                   int32_t* labels_dev);
 
+/* cv2.resize(src, (width / factor, height / factor), interpolation=cv2.INTER_AREA) of n uint8 images for an integer
+ * factor that divides both sides: the down-scaled foreground the IR tracker detects objects in when it is created with
+ * a `scale` (track/irtrackextractor.py:445-451, scale = 1 / factor; piclassifier.py:225 runs 0.25).  OpenCV's
+ * integer-ratio area filter: the block mean, (sum + 2) >> 2 at factor 2, round-half-even of sum / factor^2 in float32
+ * otherwise (restated from OpenCV, which is not in this container: parity with cv2 unpinned, as for cpx_mog2_*).
+ * dst_dev uint8 [n][height / factor][width / factor].  Other ratios: CPX_ERR_UNSUPPORTED. */
+int cpx_ir_resize_area(cpx_handle* h, const uint8_t* src_dev, int n, int width, int height, int factor, uint8_t* dst_dev);
+
 /* The two steps between cpx_ir_detect and the association, on the device, for n videos advancing in lockstep:
  * merge_components (track/irtrackextractor.py:324-389: fragments of one object merged into one box -- rows with area
  * > 40 or both sides > 16 survive, largest first; a row absorbs rows closer than 40 pixels to, or overlapping, its

@@ -234,8 +234,19 @@ def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
         xs = np.minimum(np.floor(np.arange(dw) * (sw / dw)).astype(np.int64), sw - 1)
         ys = np.minimum(np.floor(np.arange(dh) * (sh / dh)).astype(np.int64), sh - 1)
         return src[np.ix_(ys, xs)].copy()
+    if interpolation == INTER_AREA:
+        # integer-ratio area filter (resizeAreaFast_ in OpenCV's resize.cpp): the f x f block mean; 8-bit at f = 2 is
+        # (sum + 2) >> 2 (ResizeAreaFastVec_SIMD_8u), otherwise saturate_cast<uchar>(sum * (1.f / (f * f))): round to
+        # nearest, ties to even.  Used by the IR tracker's `scale` (irtrackextractor.py:445-451).  Not pinned (no cv2 here).
+        if src.dtype != np.uint8 or sw % dw or sh % dh or sw // dw != sh // dh:
+            raise NotImplementedError("shim: INTER_AREA for uint8 and one integer ratio on both axes only")
+        f = sw // dw
+        s = src.reshape(dh, f, dw, f).astype(np.int64).sum(axis=(1, 3))
+        if f == 2:
+            return ((s + 2) >> 2).astype(np.uint8)
+        return np.clip(np.rint(s.astype(np.float32) * np.float32(1.0 / (f * f))), 0, 255).astype(np.uint8)
     if interpolation != INTER_LINEAR:
-        raise NotImplementedError("shim: resize INTER_LINEAR / INTER_NEAREST only")
+        raise NotImplementedError("shim: resize INTER_LINEAR / INTER_NEAREST / INTER_AREA (integer ratio) only")
     s32 = src.astype(np.float32)
 
     def coords(dn, sn):

@@ -46,7 +46,8 @@ def _ir_oracle_config():
     return cfg
 
 
-def _oracle_ir_track(frames):
+def _oracle_ir_track(frames, scale=None):
+    import cv2_shim
     import ir_oracle as iro
     import mog2_oracle as mo
     import track_oracle as to
@@ -60,15 +61,20 @@ def _oracle_ir_track(frames):
     history = []
     for q, frame in enumerate(frames):
         mask = bg.apply(frame, -1)
+        if scale:   # irtrackextractor.py:445-451: the foreground is detected at int(res * scale), INTER_AREA
+            mask = cv2_shim.resize(mask, (int(W * scale), int(H * scale)), interpolation=cv2_shim.INTER_AREA)
         _, _, stats = iro.detect_objects_ir(mask, threshold=0)
-        merged = iro.merge_components(list(stats[1:]))
+        merged = iro.merge_components(list(stats[1:]), scale)
         delta = None
         prev_i = q - 1 if q < 10 else 10
         want = q - prev_i
         if prev_i != q and want != q and 0 <= want < q:
             delta = np.abs(frame - frames[want])          # uint8 arithmetic wraps, as in the reference
-        st = np.array([[int(v) for v in m[:5]] for m in merged], np.int64).reshape(-1, 5)
         cents = [[int(m[0] + m[2] / 2), int(m[1] + m[3] / 2)] for m in merged]
+        if scale:   # Region.rescale(1 / scale) (region.py:44-50) before anything else looks at the region; the centroid stays
+            f = 1 / scale
+            merged = [[int(m[0] * f), int(m[1] * f), int(m[2] * f), int(m[3] * f), m[4] * f ** 2] for m in merged]
+        st = np.array([[int(v) for v in m[:5]] for m in merged], np.int64).reshape(-1, 5)
         regions = to.regions_of_interest(st, cents, delta, q, cfg, crop)
         to.apply_matchings(state, regions)
         history.append(regions)
@@ -111,6 +117,66 @@ def test_ir_tracker_matches_oracle_chain(seed):
         assert [_rt(r) for r in a.bounds_history] == [_rt(r) for r in b.bounds], a.get_id()
     assert clip.background is not None and clip.background.shape == (480, 640)
     ex.close()
+
+
+@pytest.mark.parametrize("scale", [0.25, 0.5])
+def test_ir_tracker_with_scale_matches_oracle_chain(scale):
+    """IRTrackExtractor(scale=...) (the Pi's configuration, piclassifier.py:219-226): foreground down-scaled by
+    INTER_AREA on the device (cpx_ir_resize_area), detection and the fragment merge at that size with the scaled
+    thresholds, regions scaled back -- against the same steps in the oracle chain (cv2_shim.resize INTER_AREA)."""
+    from cpx.config import Config
+    from cpx.track.clip import Clip
+    from cpx.track.irtrackextractor import IRTrackExtractor
+
+    frames = ir_video(5, n=50)
+    cfg = Config.get_defaults()
+    ex = IRTrackExtractor(cfg.tracking, max_frames=frames.shape[0] + 4, scale=scale)
+    clip = Clip(ex.config, "synthetic-ir.mp4", type="IR")
+    clip.frames_per_second = 10
+    assert ex.parse_frames(clip, frames)
+    history, tracks = _oracle_ir_track(frames, scale=scale)
+    n_regions = 0
+    for q, (got, want) in enumerate(zip(clip.region_history, history)):
+        assert [_rt(r) for r in got] == [_rt(r) for r in want], q
+        for a, b in zip(got, want):
+            assert list(a.centroid) == list(b.centroid)
+            assert abs(float(a.pixel_variance) - float(b.pixel_variance)) <= 1e-9 * max(1.0, float(b.pixel_variance)), q
+        n_regions += len(got)
+    assert n_regions >= 30
+    got_tracks = sorted(clip.tracks, key=lambda t: t.get_id())
+    want_tracks = sorted(tracks, key=lambda t: t.id)
+    assert [t.get_id() for t in got_tracks] == [t.id for t in want_tracks] and len(got_tracks) >= 1
+    for a, b in zip(got_tracks, want_tracks):
+        assert [_rt(r) for r in a.bounds_history] == [_rt(r) for r in b.bounds], a.get_id()
+    with pytest.raises(NotImplementedError):
+        IRTrackExtractor(cfg.tracking, scale=0.3)
+    ex.close()
+
+
+def test_ir_resize_area_matches_the_shim():
+    import cv2_shim
+    import torch
+
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3")
+    rng = np.random.default_rng(4)
+    for f in (2, 4, 5, 8):
+        img = rng.integers(0, 256, (3, 480, 640), dtype=np.uint8)
+        img[1] = (rng.random((480, 640)) < 0.3).astype(np.uint8) * 255      # a foreground mask
+        got = eng.ir_resize_area(torch.from_numpy(img).to(eng.device), f)
+        eng.synchronize()
+        got = got.cpu().numpy()
+        for k in range(3):
+            want = cv2_shim.resize(img[k], (640 // f, 480 // f), interpolation=cv2_shim.INTER_AREA)
+            assert np.array_equal(got[k], want), (f, k)
+    import ctypes as C
+
+    src = torch.zeros((480, 640), dtype=torch.uint8, device=eng.device)
+    dst = torch.zeros((480, 640), dtype=torch.uint8, device=eng.device)
+    rc = eng.lib.cpx_ir_resize_area(eng.h, C.c_void_p(src.data_ptr()), 1, 640, 480, 7, C.c_void_p(dst.data_ptr()))
+    assert rc != 0      # 7 divides neither side: refused, not approximated
+    eng.close()
 
 
 def test_mixed_lepton35_and_ir_batch():
