@@ -27,8 +27,18 @@ def _device_state(clip):
     return st
 
 
+def _ir_clip(clip):
+    """IR clips are tracked from uint8 frames by IRTrackExtractor and keep no label masks (the reference hands
+    Clip.add_frame its saliency map, which is None with DO_SALIENCY = False: its own loop raises there at this
+    snapshot, irtrackextractor.py:432).  The contour / median ranking is not built for them: a track's thumbnail is
+    what get_thumbnail_info returns when no region yields statistics -- its first bound, score 0."""
+    return getattr(clip, "type", None) == "IR" and getattr(clip, "device_state", None) is None
+
+
 def get_track_thumb_stats(clip, track):
     """thumbnail.py:70-135 -> (stats, max_mass, max_median_diff, min_median_diff, max_contour)."""
+    if _ir_clip(clip):
+        return [], 0, 0, 0, 0
     usable = []
     st = None
     for region in track.bounds_history:
@@ -105,6 +115,8 @@ def best_trackless_thumb(clip):
                 best_region = region
     if best_region is not None:
         return best_region
+    if _ir_clip(clip):
+        return None
     st = getattr(clip, "device_state", None)
     if st is None:
         raise RuntimeError("best_trackless_thumb needs a clip tracked by ClipTrackExtractor")

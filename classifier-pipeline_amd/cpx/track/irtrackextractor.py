@@ -452,7 +452,7 @@ class IRTrackExtractor(ClipTracker):
 
     def _upload(self, frame):
         t = self._engine.torch
-        return t.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8)).to(self._engine.device)
+        return t.from_numpy(np.array(frame, dtype=np.uint8, order="C")).to(self._engine.device)   # (a copy: memory-mapped .npy frames are read-only)
 
     def process_frame(self, clip, frame, ffc_affected=False):
         """irtrackextractor.py:295-312."""

@@ -66,11 +66,7 @@ def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False
         raise Exception("File {} not found.".format(filename))
     logging.info("Tracking %s", filename)
     if filename.suffix != ".cptv":
-        raise NotImplementedError(
-            "only thermal .cptv files are handled here: for other containers the reference decodes with "
-            "cv2.VideoCapture and subtracts the background with SuBSENSE (pybgs), trackextractor.py:148-156 -- "
-            "neither is part of this build.  The IR tracker itself is: cpx.track.irtrackextractor.IRTrackExtractor"
-            ".parse_frames(clip, gray_frames) (MOG2, the algorithm the Pi uses)")
+        return extract_ir_file(filename, config, cache_to_disk, retrack, to_stdout, save_meta)
     track_extractor = ClipTrackExtractor(config.tracking, config.use_opt_flow, cache_to_disk, verbose=config.verbose,
                                          max_frames=max_frames)
     clip = Clip(track_extractor.config, filename)
@@ -84,6 +80,42 @@ def extract_file(filename, config, cache_to_disk, retrack=False, to_stdout=False
     if retrack:
         clip.load_metadata(existing)
     if not track_extractor.parse_clip(clip):
+        logging.error("Could not parse %s", filename)
+        return
+    if retrack:
+        for track in clip.tracks:
+            track.trim()
+            track.set_end_s(clip.frames_per_second)
+    metadata = get_metadata(existing, filename, meta_filename, clip, track_extractor, to_stdout, save_meta)
+    return clip, track_extractor, metadata
+
+
+def extract_ir_file(filename, config, cache_to_disk, retrack=False, to_stdout=False, save_meta=True):
+    """The other branch of extract_file (trackextractor.py:148-156): every recording that is not a .cptv goes to the
+    IR tracker at 10 frames per second.  The reference decodes the container with cv2.VideoCapture and subtracts the
+    background with SuBSENSE (pybgs); here the containers are the raw-gray ones of cpx/track/grayvideo.py (.npy, .y4m;
+    an MP4 goes through IRTrackExtractor.parse_clip where cv2 exists) and the background model is MOG2 -- the one the
+    reference's Pi runs and the one built on the device (include/cpx.h: cpx_mog2_*; cv2 parity unpinned)."""
+    from .grayvideo import GRAY_SUFFIXES, read_gray_frames
+    from .irtrackextractor import IRTrackExtractor
+
+    track_extractor = IRTrackExtractor(config.tracking, cache_to_disk, verbose=config.verbose, keep_frames=True,
+                                       tracking_alg="mog2")
+    clip = Clip(track_extractor.config, filename)
+    clip.frames_per_second = 10
+    existing = None
+    meta_filename = filename.with_suffix(".txt")
+    if meta_filename.exists():
+        existing = tools.load_clip_metadata(meta_filename)
+    if retrack:
+        clip.load_metadata(existing)
+    if filename.suffix in GRAY_SUFFIXES:
+        frames, _ = read_gray_frames(filename)
+        track_extractor.capacity = max(track_extractor.capacity, int(len(frames)) + 4)
+        ok = track_extractor.parse_frames(clip, frames)
+    else:
+        ok = track_extractor.parse_clip(clip)   # cv2.VideoCapture (NotImplementedError without OpenCV)
+    if not ok:
         logging.error("Could not parse %s", filename)
         return
     if retrack:

@@ -153,6 +153,44 @@ def test_ir_tracker_with_scale_matches_oracle_chain(scale):
     ex.close()
 
 
+def test_extract_file_routes_raw_gray_recordings_to_the_ir_tracker(tmp_path):
+    """extract_file on a recording that is not a .cptv (trackextractor.py:148-156): the IR tracker at 10 frames per
+    second, metadata written next to the file -- here for the two raw-gray containers (cpx/track/grayvideo.py); same
+    tracks as IRTrackExtractor.parse_frames on the frames themselves."""
+    import json
+
+    from test_grayvideo_cpu import write_y4m
+
+    from cpx.config import Config
+    from cpx.track.clip import Clip
+    from cpx.track.irtrackextractor import IRTrackExtractor
+    from cpx.track.trackextractor import extract_file
+
+    frames = ir_video(3, n=40)
+    cfg = Config.get_defaults()
+    ex = IRTrackExtractor(cfg.tracking, max_frames=frames.shape[0] + 4)
+    ref = Clip(ex.config, "direct.npy", type="IR")
+    ref.frames_per_second = 10
+    assert ex.parse_frames(ref, frames)
+    want = [[(r.x, r.y, r.width, r.height, r.mass) for r in t.bounds_history] for t in sorted(ref.tracks, key=lambda t: t.get_id())]
+    ex.close()
+    assert want and sum(len(w) for w in want) > 20
+    np.save(tmp_path / "a.npy", frames)
+    write_y4m(tmp_path / "b.y4m", frames, "420jpeg")
+    for name in ("a.npy", "b.y4m"):
+        clip, extractor, meta = extract_file(tmp_path / name, cfg, False)
+        assert clip.frames_per_second == 10 and clip.type == "IR"
+        got = [[(r.x, r.y, r.width, r.height, r.mass) for r in t.bounds_history] for t in sorted(clip.tracks, key=lambda t: t.get_id())]
+        assert got == want, name
+        with open((tmp_path / name).with_suffix(".txt")) as fh:
+            saved = json.load(fh)
+        assert len(saved["tracks"]) == len(want) and saved["algorithm"]["tracker_version"].startswith("IR-")
+        assert [len(t["positions"]) for t in saved["tracks"]] == [len(w) for w in want]
+    with pytest.raises((NotImplementedError, ValueError)):
+        (tmp_path / "c.mp4").write_bytes(b"not a video")
+        extract_file(tmp_path / "c.mp4", cfg, False)
+
+
 def test_ir_resize_area_matches_the_shim():
     import cv2_shim
     import torch
