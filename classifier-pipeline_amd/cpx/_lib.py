@@ -134,6 +134,7 @@ assert IR_FRAME_STATS_DTYPE.itemsize == 32
 # flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
 TRACK_KEEP_BACKGROUND, TRACK_FREEZE_ON_FFC, TRACK_FREEZE_BACKGROUND = 1, 2, 4
 LIMITS_POST_PROCESS, LIMITS_THERMAL_DIFF_NORM, LIMITS_NO_DIFF_NORM, LIMITS_ALWAYS_CLIP, LIMITS_SWAP_CHANNELS = 1, 2, 4, 8, 16
+LIMITS_TF_SCALING = 32
 
 _lib = None
 

@@ -45,12 +45,32 @@ class Interpreter:
         self.thresholds = metadata.get("thresholds")
         # what this build's network covers (ml_tools/kerasmodel.py:259-350): the WR-ResNet base, optional hidden
         # dense layers, sigmoid or softmax output -- anything else must fail here, not classify with a wrong head
-        if self.params.model_name != "wr-resnet":
-            raise NotImplementedError("model_name %r: only wr-resnet models are supported" % self.params.model_name)
         if self.params.get("mvm") or self.params.get("mvm_forest") or self.params.get("lstm") or \
                 self.params.get("model_merge"):
             raise NotImplementedError("models with track-feature (mvm), LSTM or merged heads are not supported")
-        self.preprocess_fn = None
+        self.preprocess_fn = self.get_preprocess_fn()
+
+    # model families whose Keras preprocess_input runs in 'tf' mode (x / 127.5 - 1), and inceptionv3's own copy of it
+    TF_SCALED_MODELS = ("inceptionv3", "nasnet", "resnetv2", "mobilenet", "inceptionresnetv2")
+    # 'caffe' / 'torch' modes: per-channel means of THREE colour channels (and a BGR swap) -- nothing the two-channel
+    # thermal samples of this path can take
+    CHANNEL_MEAN_MODELS = ("resnet", "resnet152", "vgg16", "vgg19", "densenet121")
+
+    def get_preprocess_fn(self):
+        """interpreter.py:64-98: the input scaling of the model family.  None for wr-resnet / efficientnetv2b3; the
+        'tf'-mode families (and inceptionv3, interpreter.py:563-566) scale the finished sample x / 127.5 - 1 -- done by
+        the crop kernel (CPX_LIMITS_TF_SCALING), the returned function is its host statement for callers that hold a
+        sample; unknown names get None with the reference's warning."""
+        name = self.params.model_name
+        if name in ("wr-resnet", "efficientnetv2b3"):
+            return None
+        if name in self.TF_SCALED_MODELS:
+            return inc3_preprocess
+        if name in self.CHANNEL_MEAN_MODELS:
+            raise NotImplementedError("model_name %r: tf.keras.applications' 'caffe' / 'torch' preprocess_input subtracts "
+                                      "the means of three colour channels; not built for the thermal samples" % name)
+        logging.warning("pretrained model %s has no preprocessing function", name)
+        return None
 
     def shape(self):
         raise NotImplementedError
@@ -195,7 +215,8 @@ class Interpreter:
 
     def limits_flags(self, single=False):
         """_lib.LIMITS_* of this model's hyper-parameters (include/cpx.h)."""
-        from .._lib import LIMITS_ALWAYS_CLIP, LIMITS_NO_DIFF_NORM, LIMITS_SWAP_CHANNELS, LIMITS_THERMAL_DIFF_NORM
+        from .._lib import (LIMITS_ALWAYS_CLIP, LIMITS_NO_DIFF_NORM, LIMITS_SWAP_CHANNELS, LIMITS_TF_SCALING,
+                            LIMITS_THERMAL_DIFF_NORM)
 
         channels = [str(getattr(c, "name", c)) for c in self.params.channels]
         if channels not in (["thermal", "filtered"], ["filtered", "thermal"]):
@@ -210,6 +231,8 @@ class Interpreter:
             flags |= LIMITS_ALWAYS_CLIP
         if channels[0] == "filtered":
             flags |= LIMITS_SWAP_CHANNELS
+        if self.preprocess_fn is not None:
+            flags |= LIMITS_TF_SCALING
         return flags
 
     def _device_preprocess(self, clip, track, segments, single=False):
@@ -255,6 +278,14 @@ class WRResNetInterpreter(Interpreter):
         self._engine = engine
         self._net = None
         self._weights = None
+        if self.params.model_name != "wr-resnet":
+            # the samples of the other families are prepared here (crop / resize / normalise / tile / input scaling);
+            # their NETWORKS are not built: they classify through a model server (run_over_network: POST /predict,
+            # interpreter.py:53-62), as the reference's Pi does with its TFLite / Keras models
+            if not self.run_over_network:
+                raise NotImplementedError("model_name %r: only the wr-resnet network runs on the device; other families "
+                                          "need run_over_network (a model server)" % self.params.model_name)
+            return
         if load_model:
             self.load_model()
 
@@ -305,6 +336,13 @@ class WRResNetInterpreter(Interpreter):
             x = torch.from_numpy(np.array(frames, dtype=np.float32, copy=True)).to(engine.device)
         _, probs = self._network(engine).forward(x.contiguous())
         return probs.cpu().numpy()
+
+
+def inc3_preprocess(x):
+    """interpreter.py:563-566 (= tf.keras.applications' 'tf' mode), in place on a float32 array."""
+    x /= 127.5
+    x -= 1.0
+    return x
 
 
 def get_interpreter(model, run_over_network=False, load_model=True, seed=None):

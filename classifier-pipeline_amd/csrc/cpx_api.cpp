@@ -753,7 +753,7 @@ int cpx_track_limits_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const f
   if (!h) return CPX_ERR_INVALID;
   if (!frames_dev || !filtered_dev || !info_dev || !refs_dev || !track_offsets_dev || !limits_dev || n_tracks < 0 ||
       (flags & ~(CPX_LIMITS_POST_PROCESS | CPX_LIMITS_THERMAL_DIFF_NORM | CPX_LIMITS_NO_DIFF_NORM | CPX_LIMITS_ALWAYS_CLIP |
-                 CPX_LIMITS_SWAP_CHANNELS)))
+                 CPX_LIMITS_SWAP_CHANNELS | CPX_LIMITS_TF_SCALING)))
     return fail(h, CPX_ERR_INVALID, "cpx_track_limits_batch: bad argument");
   if (n_tracks == 0) return CPX_OK;
   CPX_ENTER(h);

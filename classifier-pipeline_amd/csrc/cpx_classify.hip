@@ -238,6 +238,17 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
   const bool tdn = (lim.flags & CPX_LIMITS_THERMAL_DIFF_NORM) != 0;   // thermal_norm_limits given: no clip at zero
   const bool own = (lim.flags & CPX_LIMITS_NO_DIFF_NORM) != 0;        // Frame.normalize(): both channels per tile
   const int cth = (lim.flags & CPX_LIMITS_SWAP_CHANNELS) ? 1 : 0, cfi = cth ^ 1;
+  // the input scaling of the Keras 'tf'-mode families and inceptionv3 (interpreter.py:64-98,563-566: x /= 127.5; x -= 1.0
+  // in float32, applied to the finished sample, preprocess.py:142-143,200-201)
+  // A tiled sample is a float64 array at that point (square_clip pastes the float32 tiles into np.zeros,
+  // imageprocessing.py:85-104) and is cast to float32 after the scaling; a single frame (square_width 1) is the
+  // float32 stack of its channels and is scaled in float32.
+  const bool tfs = (lim.flags & CPX_LIMITS_TF_SCALING) != 0;
+  const bool tiled = sq > 1;
+  auto fin = [tfs, tiled](float v) {
+    if (!tfs) return v;
+    return tiled ? (float)((double)v / 127.5 - 1.0) : __fsub_rn(__fdiv_rn(v, 127.5f), 1.0f);
+  };
   if (pre) pmin = __fsub_rn(pmin, median);
   // ---- both channels: bilinear sample (two float32 passes), paste, per-pixel ops ----
   const int n = fs * fs;
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
       else fo = (float)(255.0 * ((double)fv - dmin) / (dmax - dmin));
     } else if (lim.filt_max == lim.filt_min) fo = (lim.filt_max == 0.0f) ? 0.0f : __fdiv_rn(fv, lim.filt_max);
     else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, lim.filt_min)), fspan);
-    out[((size_t)yy * OW + xx) * 2 + cfi] = fo;
+    out[((size_t)yy * OW + xx) * 2 + cfi] = fin(fo);
   }
   tmn = block_min(tmn, sc);
   tmx = block_max(tmx, sc);
@@ -315,13 +326,13 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
     float to;
     if (tmx == tmn) to = (tmx == 0.0f) ? 0.0f : __fdiv_rn(tv, tmx);
     else to = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(tv, tmn)), tspan);
-    out[((size_t)yy * OW + xx) * 2 + cth] = to;
+    out[((size_t)yy * OW + xx) * 2 + cth] = fin(to);
     if (own) {
       const float fv = s_f[k];
       float fo;
       if (fmx == fmn) fo = (fmx == 0.0f) ? 0.0f : __fdiv_rn(fv, fmx);
       else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, fmn)), ospan);
-      out[((size_t)yy * OW + xx) * 2 + cfi] = fo;
+      out[((size_t)yy * OW + xx) * 2 + cfi] = fin(fo);
     }
   }
 }

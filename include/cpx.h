@@ -401,6 +401,10 @@ typedef struct cpx_track_limits { /* per track */
 #define CPX_LIMITS_NO_DIFF_NORM 4
 #define CPX_LIMITS_ALWAYS_CLIP 8
 #define CPX_LIMITS_SWAP_CHANNELS 16
+/* the finished sample is scaled x / 127.5 - 1 (float32): the preprocess_fn of inceptionv3 and of the Keras families whose
+ * preprocess_input runs in 'tf' mode -- nasnet, resnetv2, mobilenet, inceptionresnetv2 (ml_tools/interpreter.py:64-98,
+ * 563-566; applied by preprocess_movement / preprocess_single_frame, ml_tools/preprocess.py:142-143,200-201) */
+#define CPX_LIMITS_TF_SCALING 32
 
 typedef struct cpx_crop_req { /* one tile = one frame of one segment */
   int32_t frame;

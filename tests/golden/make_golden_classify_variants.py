@@ -30,6 +30,10 @@ VARIANTS = {
     "channels_swapped": {"channels": ["filtered", "thermal"]},
     "single_frame": {"square_width": 1},
     "single_frame_thermal_diff_norm": {"square_width": 1, "thermal_diff_norm": True},
+    # the input scaling of the other model families (interpreter.py:64-98: get_preprocess_fn; inceptionv3 and the
+    # Keras 'tf'-mode families get x / 127.5 - 1 applied to the tiled sample, preprocess.py:200-201)
+    "inceptionv3_scaling": {"model_name": "inceptionv3"},
+    "inceptionv3_scaling_single_frame": {"model_name": "inceptionv3", "square_width": 1},
 }
 
 

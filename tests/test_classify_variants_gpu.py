@@ -43,7 +43,7 @@ def clips(tmp_path_factory):
 
 
 VARIANTS = ["thermal_diff_norm", "no_diff_norm", "thermal_diff_norm_no_diff_norm", "channels_swapped", "single_frame",
-            "single_frame_thermal_diff_norm"]
+            "single_frame_thermal_diff_norm", "inceptionv3_scaling", "inceptionv3_scaling_single_frame"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -54,7 +54,12 @@ def test_variant_inputs_equal_reference(tmp_path, golden, clips, name, variant):
     g = golden["variants"][variant]
     with open(tmp_path / "m.json", "w") as fh:
         json.dump({"labels": golden["labels"], "hyperparams": g["hyperparams"], "type": "thermal", "version": "test"}, fh)
-    interp = WRResNetInterpreter(tmp_path / "m.npz", load_model=False)
+    # (the families other than wr-resnet classify through a model server: run_over_network; predict is replaced below)
+    other = g["hyperparams"].get("model_name", "wr-resnet") != "wr-resnet"
+    if other:
+        with pytest.raises(NotImplementedError):
+            WRResNetInterpreter(tmp_path / "m.npz", load_model=False)
+    interp = WRResNetInterpreter(tmp_path / "m.npz", run_over_network=other, load_model=False)
     seen = {}
 
     def predict(x):
@@ -85,6 +90,28 @@ def test_variant_inputs_equal_reference(tmp_path, golden, clips, name, variant):
         m = pred.get_metadata(None)
         assert m["tag"] == want["meta"]["tag"] and m["all_class_confidences"] == want["meta"]["all_class_confidences"]
         assert len(m["predictions"]) == len(want["meta"]["predictions"])
+
+
+def test_preprocess_fn_families(tmp_path):
+    """interpreter.py:64-98: which model names scale their input, which cannot be prepared here, which get the warning."""
+    from cpx.ml_tools.interpreter import WRResNetInterpreter, inc3_preprocess
+
+    def make(name):
+        with open(tmp_path / "m.json", "w") as fh:
+            json.dump({"labels": ["a", "b"], "hyperparams": {"model_name": name}, "type": "thermal"}, fh)
+        return WRResNetInterpreter(tmp_path / "m.npz", run_over_network=True, load_model=False)
+
+    for name in ("inceptionv3", "nasnet", "resnetv2", "mobilenet", "inceptionresnetv2"):
+        it = make(name)
+        assert it.preprocess_fn is inc3_preprocess and it.limits_flags() & 32
+    for name in ("wr-resnet", "efficientnetv2b3", "something-new"):
+        it = make(name)
+        assert it.preprocess_fn is None and not it.limits_flags() & 32
+    for name in ("resnet", "vgg16", "densenet121"):
+        with pytest.raises(NotImplementedError):
+            make(name)
+    x = np.array([0.0, 127.5, 255.0], np.float32)
+    assert inc3_preprocess(x).tolist() == [-1.0, 0.0, 1.0]
 
 
 def test_model_by_country_picks_the_country_directory(tmp_path):
