@@ -34,4 +34,4 @@ def test_dump_tool_and_parity_tests_agree_on_the_fixture_format(tmp_path):
     env = dict(os.environ, CPX_CV2_FIXTURE=str(out))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_cv2_parity_cpu.py"), "-q", "-x"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
-    assert r.returncode == 0 and "7 passed" in r.stdout, r.stdout[-1500:]
+    assert r.returncode == 0 and "8 passed" in r.stdout, r.stdout[-1500:]

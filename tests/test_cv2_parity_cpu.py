@@ -81,6 +81,23 @@ def test_nlm(z):
         assert np.array_equal(cv2.fastNlMeansDenoising(a, None), want)
 
 
+def test_resize_area_uint8(z):
+    """cv2.resize(uint8, INTER_AREA) at integer ratios (the IR tracker's `scale`) -> cv2_shim.resize, what
+    cpx_ir_resize_area is checked against (tests/test_irtrack_gpu.py)."""
+    import cv2_shim
+
+    k = 0
+    while "area_%d_in" % k in z.files:
+        f = int(z["area_%d_factor" % k])
+        for tag in ("", "gray_"):
+            src = z["area_%d_%sin" % (k, tag)]
+            got = cv2_shim.resize(src, (src.shape[1] // f, src.shape[0] // f), interpolation=cv2_shim.INTER_AREA)
+            assert np.array_equal(got, z["area_%d_%sout" % (k, tag)]), (k, tag)
+        k += 1
+    if k == 0:
+        pytest.skip("the fixture predates the INTER_AREA entries: re-run tools/cv2_dump.py")
+
+
 def test_resize_float32(z):
     import cv2_shim as cv2
 

@@ -10,7 +10,8 @@ Imports only cv2 and numpy.  Calls and arguments are the reference's own (paths 
 GaussianBlur / threshold / morphologyEx(MORPH_CLOSE, tuple kernel) / connectedComponentsWithStats
 (ml_tools/imageprocessing.py:240-248), morphologyEx(MORPH_OPEN) + threshold + components (detect_objects_ir,
 :185-199), fastNlMeansDenoising (track/cliptracker.py:116-117), resize float32 linear / nearest
-(ml_tools/imageprocessing.py:77-82), KalmanFilter(4, 2) (track/kalman.py:5-26), findContours(RETR_EXTERNAL,
+(ml_tools/imageprocessing.py:77-82), resize uint8 INTER_AREA at integer ratios (track/irtrackextractor.py:445-451),
+KalmanFilter(4, 2) (track/kalman.py:5-26), findContours(RETR_EXTERNAL,
 CHAIN_APPROX_TC89_L1) (classify/thumbnail.py:91-96), createBackgroundSubtractorMOG2(history=1000,
 detectShadows=False).apply (track/cliptracker.py:573-575)."""
 import argparse
@@ -97,6 +98,16 @@ def main():
         out["resize_%d_linear" % k] = cv2.resize(src, (dw, dh), interpolation=cv2.INTER_LINEAR)
         out["resize_%d_nearest" % k] = cv2.resize(src, (dw, dh), interpolation=cv2.INTER_NEAREST)
         k += 1
+    # ---- resize, uint8 INTER_AREA at integer ratios (the IR tracker's `scale`, track/irtrackextractor.py:445-451) ----
+    for k, f in enumerate((2, 4, 5)):
+        src = masks(rng, 480, 640, "ellipses" if k else "blocks")
+        src[rng.random(src.shape) < 0.05] = 255
+        out["area_%d_in" % k] = src
+        out["area_%d_factor" % k] = np.array(f)
+        out["area_%d_out" % k] = cv2.resize(src, (640 // f, 480 // f), interpolation=cv2.INTER_AREA)
+        gray = rng.integers(0, 256, size=(120, 160), dtype=np.uint8)
+        out["area_%d_gray_in" % k] = gray
+        out["area_%d_gray_out" % k] = cv2.resize(gray, (160 // f, 120 // f), interpolation=cv2.INTER_AREA)
     # ---- Kalman (track/kalman.py): correct then predict per seen frame, predict alone per blank ----
     for i in range(3):
         kf = cv2.KalmanFilter(4, 2)
