@@ -269,6 +269,34 @@ def pmc_traffic(section, units_per_launch):
         return None
 
 
+INFLATE_COUNTERS = "profiles/r04_inflate_sq_counters.json"
+
+
+def inflate_roofline():
+    """The decode kernel's place against the roof that applies to it: one wavefront per recording
+    walks a serial DEFLATE symbol chain out of scalar instructions, and a CU issues at most one scalar instruction per
+    cycle -- no HBM or matrix roof comes near (34 GB/s of output).  From the committed rocprofv3 SQ counters (PMC needs
+    the profiler: not taken live): scalar instructions per output byte x bytes / (256 CUs x cycles of the launch)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), *INFLATE_COUNTERS.split("/"))
+    try:
+        with open(path) as fh:
+            prof = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    out = {"kernel": "cpx_cptv_inflate_kernel (one wavefront per recording, 16 per CU)",
+           "bound": "scalar instruction issue: one SALU instruction per cycle and CU",
+           "source": "NOT measured in this run: %s (scratch/pmc_inflate.sh, 4096 recordings per launch)" % INFLATE_COUNTERS}
+    for key in ("fixture_recordings", "synthetic_level6_270_frames"):
+        d = prof.get(key, {}).get("derived")
+        if d:
+            out[key] = {"frac": d["scalar_issue_frac"], "scalar_instructions_per_output_byte": d["salu_per_output_byte"],
+                        "vector_instructions_per_output_byte": d["valu_per_output_byte"], "output_GBps": d["GBps_out"],
+                        "kernel_ms_per_4096_recordings": d["kernel_ms"], "clock_GHz": d["clock_GHz"],
+                        "wave_time_parked_on_waitcnt": d["wave_time_parked"]}
+    out["frac"] = out.get("fixture_recordings", {}).get("frac")
+    return out
+
+
 def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
     """--stage ir: S synthetic 640x480 uint8 videos per GPU through the WHOLE IR tracker as one device batch
     (IRTrackExtractor.parse_frames_batch: cpx_mog2_apply, cpx_ir_detect, cpx_ir_merge per frame step in lockstep, one
@@ -474,6 +502,7 @@ def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with
                     "crop/tile + WR-ResNet -> thumbnails -> metadata JSON text per recording; decode launches of %d recordings, tracking groups of 1024"
                     % (n, T, n_distinct, len(distinct[0]) / 1e6, batch),
             "fixture_recordings": fixtures,
+            "roofline_inflate": inflate_roofline(),
             "files": n, "frames": int(tm["frames"]), "seconds": round(dt, 3),
             "frames_per_s": round(tm["frames"] / dt, 1), "files_per_s": round(n / dt, 1),
             "tracks_in_metadata": n_tracks, "tracks_with_predictions": n_pred,
