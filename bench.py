@@ -249,7 +249,7 @@ def _oracle_warm(_):
 STAGE2_CONV_FLOPS_PER_SAMPLE = 2.0 * 160 * 160 * 64 * 32 * 9
 
 
-PMC_SUMMARY = "profiles/r03_e2e_pmc.json"
+PMC_SUMMARY = "profiles/r04_e2e_pmc.json"
 PMC_NOTE = ("NOT measured in this run: bytes per unit from the committed rocprofv3 PMC summary %s (separate FETCH_SIZE / "
             "WRITE_SIZE passes over `python3 bench.py --clips 1024`, FETCH_SIZE doubled per the gfx950 note of "
             "MI355X_MICROARCH.md), rescaled to this run's units per launch" % PMC_SUMMARY)
@@ -489,7 +489,7 @@ def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with
     gold = os.path.join(REPO, "tests", "golden")
     if with_fixtures and all(os.path.exists(os.path.join(gold, f + ".cptv")) for f in ("possum", "hedgehog")):
         real = [open(os.path.join(gold, f + ".cptv"), "rb").read() for f in ("possum", "hedgehog")]
-        nr = min(n, 4096)
+        nr = min(n, 8192)   # four decode batches of 2048: the three pipeline stages overlap as they do on a directory
         outr, tmr, dtr = measure([real[i % 2] for i in range(nr)], ["fixture_%05d.cptv" % i for i in range(nr)])
         fixtures = {"what": "%d copies of the reference's two fixture recordings (tests/clips/possum.cptv, hedgehog.cptv: "
                             "161 / 120 frames, 1.1 MB each) through the same call" % nr,

@@ -47,7 +47,7 @@ class ClipClassifier:
     def __init__(self, config, model=None, keep_original_predictions=False, tracking_events=False,
                  model_by_country=True):
         self.keep_original_predictions = keep_original_predictions
-        self.batch_files = 1024  # recordings per device batch of process(directory, track=True)
+        self.batch_files = None  # recordings per decode batch of process(directory, track=True); None: bulk.auto_batch_files
         self.last_run = None
         self.config = config
         self.model = model

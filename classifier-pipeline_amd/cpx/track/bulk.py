@@ -761,7 +761,16 @@ def track_predictions(r, ti, b, model_out, classify_seconds):
     return out
 
 
-def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024, want_text=False,
+def auto_batch_files(n_files):
+    """Recordings per decode launch when the caller does not say: the inflate kernel runs one wavefront per recording
+    and a launch of 1,024 leaves the chip at 4 waves per CU (12.7 GB/s of output against 20 at 2,048, 26.5 at 4,096
+    and 29.5 at 8,192: profiles/r04_inflate_sq_counters.json), while the pipeline overlaps decode, tracking and
+    metadata only across batches -- so: a quarter of the run, between 1,024 and 4,096 (8,192 fixture copies through
+    TrackExtractor.extract: 456 k frames/s at 1,024, 542 k at 2,048, 469 k at 4,096)."""
+    return int(min(4096, max(1024, (n_files // 4 + 255) // 256 * 256)))
+
+
+def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=None, want_text=False,
                    stager=None, tracker=None, clip_classifier=None, blobs=None, track_files=1024,
                    decode_bytes=8 << 30, track_frames=400000):
     """extract_file -- or, with a ClipClassifier, process_file(track=True) -- for many recordings at device speed.
@@ -769,13 +778,16 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     "error: ..." string for a skipped file}, tracker with timings).  Files that cannot take the batched path are
     retried through the one-file path.  blobs: the recordings as byte strings already in memory (names in
     `filenames`; nothing is read from disk; one the batch refuses is retried from its bytes by the host reader).
-    batch_files: recordings per decode launch (and per read-ahead batch); track_files: recordings per tracking group."""
+    batch_files: recordings per decode launch (and per read-ahead batch; None: auto_batch_files); track_files: recordings
+    per tracking group."""
     import torch
 
     from .cliptrackextractor import default_engine
     from .trackextractor import extract_file
 
     filenames = [str(f) for f in filenames]
+    if not batch_files:
+        batch_files = auto_batch_files(len(filenames))
     own_stager = stager is None and blobs is None
     if blobs is None:
         stager = stager or FileStager(torch)
@@ -1029,7 +1041,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
     return out, tracker
 
 
-def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=1024,
+def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=None,
                        want_text=False, stager=None, tracker=None):
     """run_files_bulk without classification: what TrackExtractor.extract(directory) runs."""
     return run_files_bulk(filenames, config, to_stdout, save_meta, device, batch_files, want_text, stager, tracker)

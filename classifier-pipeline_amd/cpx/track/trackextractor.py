@@ -19,7 +19,7 @@ class TrackExtractor:
         self.worker_threads = max(1, config.worker_threads)
         self.retrack = retrack
         self.cache_to_disk = config.classify.cache_to_disk if cache_to_disk is None else cache_to_disk
-        self.batch_files = 1024  # files per device batch of extract(directory)
+        self.batch_files = None  # files per device batch of extract(directory); None: bulk.auto_batch_files
         self.last_run = None     # timings of the last extract(directory) (cpx.track.bulk.BulkTracker.timings)
 
     def extract(self, base, to_stdout=False):
@@ -43,8 +43,9 @@ class TrackExtractor:
         todo = shard_files(todo, rank, world)
         device = local_rank if world > 1 else 0
         if self.retrack:  # existing tracks are re-used per file: no batch form
-            for i in range(0, len(todo), self.batch_files):
-                extract_files(todo[i:i + self.batch_files], self.config, self.cache_to_disk, self.retrack, to_stdout,
+            step = self.batch_files or 1024
+            for i in range(0, len(todo), step):
+                extract_files(todo[i:i + step], self.config, self.cache_to_disk, self.retrack, to_stdout,
                               device=device)
             return
         # the file-fed path at device speed (cpx/track/bulk.py): gzip inflate, section index, decode, tracking,

@@ -2,7 +2,7 @@
 # Regenerates the judged evidence under gpurun_out/ev on the GPU box (copy into profiles/ afterwards):
 #   bench lines (default e2e incl. default_config + fs64, f32 math, track stage, config4, ir), rocprofv3 kernel stats
 #   of the default command, PMC passes (FETCH_SIZE / WRITE_SIZE separately, no trace domains) and the PMC summary.
-R=${CPX_ROUND:-r03}
+R=${CPX_ROUND:-r04}
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
 mkdir -p gpurun_out/ev
