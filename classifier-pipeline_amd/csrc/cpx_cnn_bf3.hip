@@ -837,11 +837,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
               float v[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);
+              // (the empty asm keeps these uniform branches branches: if-converted, every item pays the BatchNorm and the
+              // padding selects -- 12 vector instructions -- whether the layer has a prologue / the tile a border or not)
               if (a.in_scale) {
+                asm volatile("");
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(__fmaf_rn(v[j], psc[j], psh[j]), 0.0f);
               }
               if (!interior) {  // (uniform: most tiles skip the selects)
+                asm volatile("");
                 const int px = t8 + 64 * i;
                 const int py = (px * 3641) >> 16, pxx = px - py * W_PW;
                 const bool inside = (unsigned)(iy0 + py) < (unsigned)a.H && (unsigned)(ix0 + pxx) < (unsigned)a.W;
@@ -938,10 +942,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (a.sc_in && a.sc_bias) ob += *reinterpret_cast<const f32x4*>(a.sc_bias + ch);
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      f32x4 v = acc[ct][pt] * os + ob;
+      f32x4 v = acc[ct][pt];
+      if (a.out_scale) {  // (uniform branches kept as branches: see the patch commit)
+        asm volatile("");
+        v = v * os;
+      }
+      v += ob;
       const unsigned o = (opix[pt] + 16u * ct) << 2;
       if (res_n) v += *reinterpret_cast<const f32x4*>(at_off(res_n, o));
       if (a.relu) {
+        asm volatile("");
         v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
       }
       if (ovalid[pt]) *reinterpret_cast<f32x4*>(at_off(out_n, o)) = v;
