@@ -269,6 +269,27 @@ def pmc_traffic(section, units_per_launch):
         return None
 
 
+def aggregate_from_files(per_rank, share, host_cpus):
+    """rank 0's `from_files` object for N > 1: the per-rank results of bench_from_files (gathered with
+    all_gather_object; a rank that failed contributes {"error": ...}) -> per-rank split + the aggregate rate, frames of
+    all ranks over the slowest rank's time (tests/test_bench_launch_cpu.py)."""
+    world = len(per_rank)
+    ok = [r for r in per_rank if r and "error" not in r]
+    agg = {"what": "every rank: %d synthetic recordings (its share) through run_files_bulk on its own GPU, host stages of "
+                   "all ranks on the node's CPUs at the same time" % share,
+           "ranks": world, "host_cpus_usable": host_cpus,
+           "per_rank": [{"rank": i, **({k: r[k] for k in ("files", "frames", "seconds", "frames_per_s", "split_s")}
+                                        if r and "error" not in r else {"error": (r or {}).get("error", "no result")})}
+                        for i, r in enumerate(per_rank)]}
+    if ok:
+        slowest = max(r["seconds"] for r in ok)
+        agg["frames"] = int(sum(r["frames"] for r in ok))
+        agg["seconds_slowest_rank"] = round(slowest, 3)
+        agg["frames_per_s"] = round(agg["frames"] / slowest, 1)
+        agg["roofline_inflate"] = ok[0].get("roofline_inflate")
+    return agg
+
+
 INFLATE_COUNTERS = "profiles/r04_inflate_sq_counters.json"
 
 
@@ -1122,19 +1143,7 @@ def main():
             per_rank = [None] * world
             dist.all_gather_object(per_rank, ff)
             if rank == 0:
-                ok = [r for r in per_rank if r and "error" not in r]
-                agg = {"what": "every rank: %d synthetic recordings (its share) through run_files_bulk on its own GPU, host "
-                               "stages of all ranks on the node's CPUs at the same time" % share,
-                       "ranks": world, "host_cpus_usable": usable_cpus(),
-                       "per_rank": [{"rank": i, **({k: r[k] for k in ("files", "frames", "seconds", "frames_per_s", "split_s")}
-                                                    if r and "error" not in r else {"error": (r or {}).get("error")})}
-                                    for i, r in enumerate(per_rank)]}
-                if ok:
-                    slowest = max(r["seconds"] for r in ok)
-                    agg["frames"] = int(sum(r["frames"] for r in ok))
-                    agg["seconds_slowest_rank"] = round(slowest, 3)
-                    agg["frames_per_s"] = round(agg["frames"] / slowest, 1)
-                line["from_files"] = agg
+                line["from_files"] = aggregate_from_files(per_rank, share, usable_cpus())
     if rank == 0:
         print(json.dumps(line), flush=True)
     if not (extras and (world > 1 or args.from_files > 0)):

@@ -65,3 +65,20 @@ def test_stray_world_size_without_a_launcher_is_ignored():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks"] == [0, 1]
+
+
+def test_per_rank_from_files_aggregation():
+    """bench.py --gpus N, N > 1: every rank runs the file-fed leg on its share; rank 0 reports the per-rank split and
+    frames of all ranks over the slowest rank's time (the gather itself is torch's all_gather_object)."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    def rank(seconds, frames=1000, **kw):
+        return dict({"files": 10, "frames": frames, "seconds": seconds, "frames_per_s": frames / seconds,
+                     "split_s": {"metadata_host": 0.1}, "roofline_inflate": {"frac": 0.68}, "what": "x"}, **kw)
+
+    agg = bench.aggregate_from_files([rank(2.0), rank(4.0, frames=3000), {"error": "RuntimeError: boom"}, None], 1024, 16)
+    assert agg["ranks"] == 4 and agg["frames"] == 4000 and agg["seconds_slowest_rank"] == 4.0 and agg["frames_per_s"] == 1000.0
+    assert [r.get("error") for r in agg["per_rank"]] == [None, None, "RuntimeError: boom", "no result"]
+    assert agg["per_rank"][1]["split_s"] == {"metadata_host": 0.1} and agg["host_cpus_usable"] == 16
+    assert "frames_per_s" not in bench.aggregate_from_files([{"error": "x"}], 512, 8)
