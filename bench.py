@@ -510,7 +510,9 @@ def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with
     gold = os.path.join(REPO, "tests", "golden")
     if with_fixtures and all(os.path.exists(os.path.join(gold, f + ".cptv")) for f in ("possum", "hedgehog")):
         real = [open(os.path.join(gold, f + ".cptv"), "rb").read() for f in ("possum", "hedgehog")]
-        nr = min(n, 8192)   # four decode batches of 2048: the three pipeline stages overlap as they do on a directory
+        # eight decode batches of 2048: the three pipeline stages overlap as they do on a large directory (8,192 copies:
+        # 297-333 k frames/s, 4,096: 275 k -- the first decode and the last metadata are not overlapped with anything)
+        nr = min(2 * n, 16384)
         outr, tmr, dtr = measure([real[i % 2] for i in range(nr)], ["fixture_%05d.cptv" % i for i in range(nr)])
         fixtures = {"what": "%d copies of the reference's two fixture recordings (tests/clips/possum.cptv, hedgehog.cptv: "
                             "161 / 120 frames, 1.1 MB each) through the same call" % nr,
