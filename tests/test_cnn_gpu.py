@@ -34,6 +34,11 @@ CASES = [
     (128, 256, 20, 17, 3, 3, True),   # res4b0_branch2a (stride 3)
     (128, 256, 20, 17, 1, 3, False),  # shortcut4
     (256, 256, 9, 11, 3, 1, True),    # res4*
+    # shapes the network does not have but cpx_conv2d takes on the same kernels (conv_bf3w_kernel: 32 / 64 channels
+    # per group in, 32 / 64 out; one or two column slices per tile)
+    (64, 128, 19, 35, 3, 1, True),
+    (128, 64, 18, 17, 3, 1, True),
+    (128, 128, 33, 16, 3, 1, False),  # VALID: no padding, output 31 x 14
 ]
 
 
