@@ -20,7 +20,11 @@ def thresholds_for_model(model):
 
 
 class TrackBatchResult:
-    """Outputs of one cpx_track_batch call (host copies are made lazily)."""
+    """Outputs of one cpx_track_batch call (host copies are made lazily).
+
+    The device tensors come from torch's allocator while the kernels that fill them run on the engine's stream:
+    hold the result until engine.synchronize() (every host accessor here does that first). A result dropped
+    earlier hands its memory back while it is still being written."""
 
     def __init__(self, engine, total, cap, comps, info, labels, filtered, background):
         self.engine, self.total, self.cap = engine, total, cap

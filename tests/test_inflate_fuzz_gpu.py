@@ -309,8 +309,9 @@ def test_decode_does_not_depend_on_the_co_runner(engine):
         net = wr.WRResNetDevice(other, wr.random_weights(5, seed=1), 5)
         x = torch.rand((256, 160, 160, 2), device=other.device) * 255
         while not stop.is_set():
-            net.forward(x)
-            other.synchronize()
+            y = net.forward(x)   # held until the stream has drained: a dropped output goes back to torch's
+            other.synchronize()  # allocator while the kernels still write it, and the decode would be handed it
+            del y
 
     def nlm_load():
         frames, _ = synth.make_batch(64, 8, seed=5)
@@ -318,8 +319,9 @@ def test_decode_does_not_depend_on_the_co_runner(engine):
         offs = (np.arange(257) * 8).astype(np.int32)
         meta = np.concatenate([other.make_meta(8) for _ in range(256)])
         while not stop.is_set():
-            other.track_batch(dev, offs, meta, want_labels=False, want_filtered=False)
+            res = other.track_batch(dev, offs, meta, want_labels=False, want_filtered=False)
             other.synchronize()
+            del res
 
     try:
         for load in (None, conv_load, nlm_load, None):
