@@ -42,6 +42,15 @@
 #define A_LSHLADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 1, %8\n"
 #define A_SAD(i) "v_sad_u8 %" #i ", %8, %9, %" #i "\n"
 #define A_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 6, 10\n"
+#define A_DOT2BF(i) "v_dot2c_f32_bf16 %" #i ", %8, %9\n"
+#define A_SUBF(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+#define A_FMAF(i) "v_fma_f32 %" #i ", %8, %9, %" #i "\n"
+#define A_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define A_LSHL(i) "v_lshlrev_b32 %" #i ", 16, %" #i "\n"
+#define A_CVTPKBF(i) "v_cvt_pk_bf16_f32 %" #i ", %" #i ", %8\n"
+#define A_MAXI(i) "v_max_i32 %" #i ", %" #i ", %8\n"
+KERNEL(dot2c_f32_bf16, A_DOT2BF) KERNEL(sub_f32, A_SUBF) KERNEL(fma_f32, A_FMAF) KERNEL(and_b32, A_AND) KERNEL(lshlrev_b32, A_LSHL)
+KERNEL(cvt_pk_bf16_f32, A_CVTPKBF) KERNEL(max_i32, A_MAXI)
 KERNEL(add_u32, A_ADD) KERNEL(mad_u32_u24, A_MAD24) KERNEL(mul_u32_u24, A_MUL24) KERNEL(mul_lo_u32, A_MULLO) KERNEL(perm_b32, A_PERM)
 KERNEL(dot2_u32_u16, A_DOT2) KERNEL(dot4_u32_u8, A_DOT4) KERNEL(mad_u32_u16, A_MADU16) KERNEL(pk_add_u16, A_PKADD)
 KERNEL(pk_add_u16_clamp, A_PKADDC) KERNEL(pk_mul_lo_u16, A_PKMUL) KERNEL(pk_mad_u16, A_PKMAD) KERNEL(pk_min_u16, A_PKMIN)
@@ -65,5 +74,6 @@ int main() {
   RUN(mad_u32_u16, 1) RUN(pk_add_u16, 1) RUN(pk_add_u16_clamp, 1) RUN(pk_mul_lo_u16, 1) RUN(pk_mad_u16, 1) RUN(pk_min_u16, 1)
   RUN(pk_lshrrev_b16, 1) RUN(alignbit_b32, 1) RUN(sub_u16_sdwa_bytes, 1) RUN(mul_u32_u24_sdwa_byte, 1) RUN(add3_u32, 1)
   RUN(lshl_add_u32, 1) RUN(sad_u8, 1) RUN(bfe_u32, 1)
+  RUN(dot2c_f32_bf16, 1) RUN(sub_f32, 1) RUN(fma_f32, 1) RUN(and_b32, 1) RUN(lshlrev_b32, 1) RUN(cvt_pk_bf16_f32, 1) RUN(max_i32, 1)
   return 0;
 }
