@@ -834,6 +834,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
           for (int i = 0; i < NP; ++i) {
             if (i * CT + CT <= NITEM || tid < NITEM - i * CT) {
+#ifdef CPX_BF3W_FAKE_SPLIT  // experiment (scratch/patches/README.md): the staged pieces go to LDS as they are -- wrong results, the cost of BatchNorm + split gone
+              {
+                uint2* sp2 = reinterpret_cast<uint2*>(s_patch) + st_e2 + i * (64 * 4);
+                sp2[(0 * 2 * W_NPXP) * 4] = make_uint2(pre_p[i][0], pre_p[i][1]);
+                sp2[(1 * 2 * W_NPXP) * 4] = make_uint2(pre_p[i][2], pre_p[i][3]);
+                sp2[(2 * 2 * W_NPXP) * 4] = make_uint2(pre_p[i][1], pre_p[i][2]);
+                continue;
+              }
+#endif
               float v[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);

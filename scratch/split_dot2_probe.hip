@@ -15,12 +15,10 @@ __device__ __forceinline__ unsigned pack_rne(float a, float b) {
   return r;
 }
 __device__ __forceinline__ float sub_lo(float x, unsigned p) {
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x) : "v"(0x0000bf80u), "v"(p));
-  return x;
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, 0x0000bf80u), __builtin_bit_cast(bf16x2, p), x, false);
 }
 __device__ __forceinline__ float sub_hi(float x, unsigned p) {
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x) : "v"(0xbf800000u), "v"(p));
-  return x;
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, 0xbf800000u), __builtin_bit_cast(bf16x2, p), x, false);
 }
 template <bool RNE>
 __global__ void k(const float* x, int n, unsigned* planes_ref, unsigned* planes_dot, unsigned* bad) {
@@ -41,6 +39,11 @@ __global__ void k(const float* x, int n, unsigned* planes_ref, unsigned* planes_
     d[1] = RNE ? pack_rne(ra, rb) : pack_trunc(ra, rb);
     const float sa = sub_lo(ra, d[1]), sb = sub_hi(rb, d[1]);
     d[2] = RNE ? pack_rne(sa, sb) : pack_trunc(sa, sb);
+  }
+  if (!RNE && p[1] != d[1] && atomicAdd(bad + 1, 0u) == 0 && i < 64) {
+    const float ra = a - __uint_as_float(p[0] << 16), rb = b - __uint_as_float(p[0] & 0xffff0000u);
+    printf("i %d a %08x b %08x p0 %08x ra %08x rb %08x  dot ra %08x rb %08x  p1 %08x d1 %08x\n", i, __float_as_uint(a), __float_as_uint(b), p[0],
+           __float_as_uint(ra), __float_as_uint(rb), __float_as_uint(sub_lo(a, d[0])), __float_as_uint(sub_hi(b, d[0])), p[1], d[1]);
   }
   for (int j = 0; j < 3; ++j) {
     planes_ref[3 * i + j] = p[j];
