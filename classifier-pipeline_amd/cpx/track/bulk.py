@@ -765,9 +765,11 @@ def auto_batch_files(n_files):
     """Recordings per decode launch when the caller does not say: the inflate kernel runs one wavefront per recording
     and a launch of 1,024 leaves the chip at 4 waves per CU (12.7 GB/s of output against 20 at 2,048, 26.5 at 4,096
     and 29.5 at 8,192: profiles/r04_inflate_sq_counters.json), while the pipeline overlaps decode, tracking and
-    metadata only across batches -- so: a quarter of the run, between 1,024 and 4,096 (8,192 fixture copies through
-    TrackExtractor.extract: 456 k frames/s at 1,024, 542 k at 2,048, 469 k at 4,096)."""
-    return int(min(4096, max(1024, (n_files // 4 + 255) // 256 * 256)))
+    metadata only across batches -- so: a quarter of the run, between 1,024 and 2,048.  Measured with the classifier
+    (scratch/from_files_profile.py): 16,384 fixture copies 6.90 / 6.62 / 7.38 / 7.17 s at 1,024 / 2,048 / 3,072 / 4,096,
+    8,192 synthetic recordings 6.08 / 4.97 / 5.34 s at 1,024 / 2,048 / 4,096; tracking only (8,192 fixture copies
+    through TrackExtractor.extract): 456 k frames/s at 1,024, 542 k at 2,048, 469 k at 4,096."""
+    return int(min(2048, max(1024, (n_files // 4 + 255) // 256 * 256)))
 
 
 def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=None, want_text=False,

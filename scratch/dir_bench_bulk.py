@@ -7,7 +7,7 @@ from cpx.config import Config
 from cpx.track.trackextractor import TrackExtractor
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+batch = (None if sys.argv[2] == "auto" else int(sys.argv[2])) if len(sys.argv) > 2 else 1024  # auto: bulk.auto_batch_files
 for dn in (False, True)[: (2 if "--denoise" in sys.argv else 1)]:
     cfg = Config.get_defaults()
     cfg.tracking["thermal"].denoise = dn

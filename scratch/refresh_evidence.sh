@@ -11,7 +11,7 @@ python3 bench.py --cnn-math f32 --cpu-clips 0 --no-extras 2>/dev/null | grep '^{
 python3 bench.py --stage track 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_track.json
 python3 bench.py --config4 --steps 1 --warmup 1 --cpu-clips 8 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_config4.json
 python3 bench.py --stage ir 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_ir.json
-python3 scratch/dir_bench_bulk.py 4096 1024 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_directory_bulk.json
+python3 scratch/dir_bench_bulk.py 4096 auto 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_directory_bulk.json
 python3 scratch/dir_bench_bulk.py 64 1024 --denoise 2>/dev/null | grep '^{' >> gpurun_out/ev/${R}_directory_bulk.json
 python3 scratch/dir_bench_bulk.py 1024 1024 --denoise 2>/dev/null | grep '^{' >> gpurun_out/ev/${R}_directory_bulk.json
 cd /tmp && export TMPDIR=/tmp
