@@ -683,10 +683,16 @@ constexpr int W_PATCH = 3 * 2 * W_NPXP * 2;  // entries
 constexpr int W_WSUB = 3 * 3 * 4 * 32;       // entries of a weight sub-chunk (one kernel row)
 // WALK: the workgroup walks a run of td.run tiles along x (else exactly one tile: the loop and the per-use
 // laundering of the staging bases fold away); LDSBN: BatchNorm scale / shift read back from LDS at each patch commit
-// instead of living in eight registers
-template <bool WALK, bool LDSBN>
+// instead of living in eight registers; NH: 32-column slices of the group's output channels the workgroup computes from
+// ONE staged patch (NH = 2 for 64 columns per group: the patch of a tile is loaded, normalised and split once instead
+// of once per slice -- the slices' weights alternate through the same 18 KB, twice the accumulators)
+template <bool WALK, bool LDSBN, int NH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf3w_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int CT = 512;
+  // per-thread staging / output indices are re-derived from the thread index at each use (WALK: they would be carried
+  // across the tile loop; NH > 1: sixteen more accumulator registers leave no room to keep them across the products --
+  // kept, the compiler spills eight of them to scratch per tile: +22 % HBM traffic on the stage-3 launches, measured)
+  constexpr bool LAUNDER = WALK || NH > 1;
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   uint4* s_patch = lds4;
   uint4* s_w = lds4 + W_PATCH;
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tx_end = WALK ? min((txr + 1) * run, (a.Wo + W_TW - 1) / W_TW) : txr + 1;
   const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
   const int nch = cin_g / KW;
-  const uint4* wg = wimg + (size_t)g * nch * (3 * 36) * cout_g + (size_t)ns * 32;
+  const uint4* wg = wimg + (size_t)g * nch * (3 * 36) * cout_g + (size_t)ns * (32 * NH);
   const int a_base = ((q >> 1) * W_NPXP + (2 * wave) * W_PW + i16) * 2 + (q & 1);
   const int b_base = q * 32 + i16;
   // Staging items: ONE 16-byte piece (4 channels) of a patch pixel's 32-channel chunk, the eight pieces of a pixel on
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr int NP = (NITEM + CT - 1) / CT;
   constexpr int NWI = (W_WSUB + CT - 1) / CT;
   const int my_q8 = tid & 7;
-  const int st_e2 = ((my_q8 >> 2) * W_NPXP + (tid >> 3)) * 4 + (my_q8 & 3);  // uint2 slot of item 0, plane 0; an item further = 64 pixels
+  const int st_e2_0 = ((my_q8 >> 2) * W_NPXP + (tid >> 3)) * 4 + (my_q8 & 3);  // uint2 slot of item 0, plane 0; an item further = 64 pixels
   u32x4 pre_p[NP];
   u32x4 pre_w[NWI];
   // BatchNorm scale / shift of the group's input channels: staged once per workgroup (read back at each patch commit
@@ -743,11 +749,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   // (the per-thread bases are laundered at every use: left visible, the compiler keeps one address register per
   // staged item alive -- and stepping -- across all phases, and the prefetched pieces themselves go to scratch)
-#define BF3W_ISSUE_W(C_, R_)                                                                              \
+#define BF3W_ISSUE_W(C_, R_, HF_)                                                                         \
   {                                                                                                       \
-    const uint4* wc = wg + (size_t)(((C_) * 3 + (R_)) * 36) * cout_g;                                     \
+    const uint4* wc = wg + (size_t)(((C_) * 3 + (R_)) * 36) * cout_g + (HF_) * 32;                        \
     unsigned woff = (unsigned)((tid >> 5) * cout_g + (tid & 31)) << 4;                                    \
-    if (WALK) asm volatile("" : "+v"(woff));                                                              \
+    if (LAUNDER) asm volatile("" : "+v"(woff));                                                           \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                     \
       /* item tid + 512 i = 16 i rows further down; the last slice (rows 32..35) exists for tid < 128 only */ \
       const unsigned wo = (i == NWI - 1 && (W_WSUB % CT) != 0) ? (tid < (W_WSUB % CT) ? woff + ((unsigned)(16 * i * cout_g) << 4) : woff) : woff + ((unsigned)(16 * i * cout_g) << 4); \
@@ -758,7 +764,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define BF3W_ISSUE_P(C_, IX0_)                                                                            \
   {                                                                                                       \
     int t8 = tid >> 3;                                                                                    \
-    if (WALK) asm volatile("" : "+v"(t8));                                                                \
+    if (LAUNDER) asm volatile("" : "+v"(t8));                                                             \
+    int my_q8 = tid & 7;                                                                                  \
+    if (LAUNDER) asm volatile("" : "+v"(my_q8));                                                          \
     if (!LDSBN) {                                                                                         \
       const int ch = g * cin_g + (C_) * KW;                                                               \
       const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);             \
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, a.Cin) + coff) << 2)); \
     }                                                                                                     \
   }
-  BF3W_ISSUE_W(0, 0)
+  BF3W_ISSUE_W(0, 0, 0)
   BF3W_ISSUE_P(0, txr * run * W_TW - a.pad_left)
   // The workgroup walks a run of tiles along x: the next tile's patch and first weights are in flight under the
   // current tile's products exactly as the next chunk's are, so only the first tile of a run waits for its loads
@@ -787,50 +795,71 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const bool full_tile = oy0 + W_TH <= a.Ho && ox0 + W_TW <= a.Wo;
 
   // this lane's two pixels (tile rows 2 wave, 2 wave + 1; column i16) and its channel quad inside a 16-column tile
-  const int ch_l = g * cout_g + ns * 32 + 4 * q;
+  int ch_l;
   unsigned opix[2];  // element offsets of the (clamped) pixels in the output map
   bool ovalid[2];
+  auto out_pixels = [&]() __attribute__((always_inline)) {
+    int t = tid;
+    if (LAUNDER) asm volatile("" : "+v"(t));
+    const int i16_ = t & 15, q_ = (t >> 4) & 3, wave_ = t >> 6;
+    ch_l = g * cout_g + ns * (32 * NH) + 4 * q_;
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int oy = oy0 + 2 * wave + pt, ox = ox0 + i16;
-    ovalid[pt] = full_tile || (oy < a.Ho && ox < a.Wo);
-    opix[pt] = pix_off(min(oy, a.Ho - 1), min(ox, a.Wo - 1), a.Wo, a.Cout) + (unsigned)ch_l;
-  }
+    for (int pt = 0; pt < 2; ++pt) {
+      const int oy = oy0 + 2 * wave_ + pt, ox = ox0 + i16_;
+      ovalid[pt] = full_tile || (oy < a.Ho && ox < a.Wo);
+      opix[pt] = pix_off(min(oy, a.Ho - 1), min(ox, a.Wo - 1), a.Wo, a.Cout) + (unsigned)ch_l;
+    }
+  };
+  out_pixels();
   const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;  // see conv_bf3_kernel
-  f32x4 acc[2][2];
+  f32x4 acc[NH][2][2];
   if (res_in_acc) {
     const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 16u * ct) << 2));
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+          acc[hf][ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 32u * hf + 16u * ct) << 2));
   } else {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[hf][ct][pt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
 
   for (int c = 0; c < nch; ++c) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      if (c > 0 || r > 0 || txi > txr * run) __syncthreads();  // every wave has read the previous phase's fragments
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+      if (c > 0 || r > 0 || hf > 0 || txi > txr * run) __syncthreads();  // every wave has read the previous phase's fragments
       // ---- registers -> LDS: the kernel row's weights (a straight copy) ----
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = tid + i * CT;
         if (item < W_WSUB) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
       }
-      if (r == 0) {
+      if (r == 0 && hf == 0) {
         // ---- the chunk's patch: BatchNorm + ReLU prologue, padding zeroed, split into bf16 planes ----
         {
           f32x4 psc = psc_r, psh = psh_r;
+          int q8c = my_q8;
+          if (LAUNDER) {
+            q8c = tid & 7;
+            asm volatile("" : "+v"(q8c));
+          }
           if (LDSBN && a.in_scale) {
-            psc = s_bn[c * 8 + my_q8];
-            psh = s_bn[(cin_g >> 2) + c * 8 + my_q8];
+            psc = s_bn[c * 8 + q8c];
+            psh = s_bn[(cin_g >> 2) + c * 8 + q8c];
           }
           int t8 = tid >> 3;
-          if (WALK) asm volatile("" : "+v"(t8));
+          if (LAUNDER) asm volatile("" : "+v"(t8));
+          int st_e2 = st_e2_0;
+          if (LAUNDER) st_e2 = ((q8c >> 2) * W_NPXP + t8) * 4 + (q8c & 3);
 #pragma unroll
           for (int i = 0; i < NP; ++i) {
             if (i * CT + CT <= NITEM || tid < NITEM - i * CT) {
@@ -874,14 +903,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
       }
       // ---- global -> registers for what comes next (in flight under this phase's products) ----
-      if (r < 2) {
-        BF3W_ISSUE_W(c, r + 1)
+      if (hf + 1 < NH) {
+        BF3W_ISSUE_W(c, r, hf + 1)
+      } else if (r < 2) {
+        BF3W_ISSUE_W(c, r + 1, 0)
       } else if (c + 1 < nch) {
-        BF3W_ISSUE_W(c + 1, 0)
+        BF3W_ISSUE_W(c + 1, 0, 0)
       } else if (txi + 1 < tx_end) {
-        BF3W_ISSUE_W(0, 0)
+        BF3W_ISSUE_W(0, 0, 0)
       }
-      if (r == 0) {
+      if (r == 0 && hf == 0) {
         if (c + 1 < nch) {
           BF3W_ISSUE_P(c + 1, ix0)
         } else if (txi + 1 < tx_end) {
@@ -905,21 +936,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
           for (int pt = 0; pt < 2; ++pt) {
             // smallest terms first, as conv_bf3_kernel (x = activation planes, w = weight planes)
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][1], acc[ct][pt], 0, 0, 0);
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][2], xv[pt][0], acc[ct][pt], 0, 0, 0);
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][2], acc[ct][pt], 0, 0, 0);
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][0], acc[ct][pt], 0, 0, 0);
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][1], acc[ct][pt], 0, 0, 0);
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][0], acc[ct][pt], 0, 0, 0);
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][1], acc[hf][ct][pt], 0, 0, 0);
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][2], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][2], acc[hf][ct][pt], 0, 0, 0);
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][1], acc[hf][ct][pt], 0, 0, 0);
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
           }
       }
+    }  // column slices
     }
   }
 
   // ---- fused 1x1 shortcut (see conv_bf3_kernel), on v_mfma_f32_16x16x4_f32: A = weights [column][k], B = pixels ----
   if (a.sc_in) {
     const int sc_cg = a.sc_cin / a.groups;
-    const float* wsc = a.sc_w + ((size_t)g * sc_cg + q) * cout_g + ns * 32 + i16;
+    const float* wsc = a.sc_w + ((size_t)g * sc_cg + q) * cout_g + ns * (32 * NH) + i16;
     const float* pin[2];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -927,37 +959,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       pin[pt] = a.sc_in + (((size_t)n * a.sc_H + oy * a.sc_stride) * a.sc_W + ox * a.sc_stride) * a.sc_cin + g * sc_cg + q;
     }
     for (int k4 = 0; k4 < sc_cg; k4 += 4) {
-      float xs[2], ws[2];
+      float xs[2], ws[NH][2];
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) xs[pt] = pin[pt][k4];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) ws[ct] = wsc[(size_t)k4 * cout_g + 16 * ct];
+      for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct) ws[hf][ct] = wsc[(size_t)k4 * cout_g + 32 * hf + 16 * ct];
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[ct], xs[pt], acc[ct][pt], 0, 0, 0);
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[hf][ct], xs[pt], acc[hf][ct][pt], 0, 0, 0);
     }
   }
 
   // ---- epilogue: affine, residual, ReLU and one 16-byte store per accumulator tile, straight from the registers ----
   float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
   const float* res_n = (a.residual && !res_in_acc) ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+  if (LAUNDER) out_pixels();  // (re-derived: see LAUNDER)
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int ch = ch_l + 16 * ct;
+  for (int hc = 0; hc < 2 * NH; ++hc) {
+    const int hf = hc >> 1, ct = hc & 1;
+    const int ch = ch_l + 16 * hc;
     f32x4 os = {1.0f, 1.0f, 1.0f, 1.0f}, ob = {0.0f, 0.0f, 0.0f, 0.0f};
     if (a.out_scale) os = *reinterpret_cast<const f32x4*>(a.out_scale + ch);
     if (a.out_shift) ob = *reinterpret_cast<const f32x4*>(a.out_shift + ch);
     if (a.sc_in && a.sc_bias) ob += *reinterpret_cast<const f32x4*>(a.sc_bias + ch);
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      f32x4 v = acc[ct][pt];
+      f32x4 v = acc[hf][ct][pt];
       if (a.out_scale) {  // (uniform branches kept as branches: see the patch commit)
         asm volatile("");
         v = v * os;
       }
       v += ob;
-      const unsigned o = (opix[pt] + 16u * ct) << 2;
+      const unsigned o = (opix[pt] + 16u * hc) << 2;
       if (res_n) v += *reinterpret_cast<const f32x4*>(at_off(res_n, o));
       if (a.relu) {
         asm volatile("");
@@ -1093,11 +1132,13 @@ __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __res
   }
 }
 
-static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
+template <int NH>
+static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = (size_t)(W_PATCH + W_WSUB) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
   static bool lds_ready[64];
-  constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0;
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN>), lds_ready, 160 * 1024 - 1024)) return -1;
+  // (NH = 2 carries 16 more accumulator registers: the BatchNorm parameters go to LDS there)
+  constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0 || NH > 1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   const int tx = (a.Wo + W_TW - 1) / W_TW;
   // tiles per workgroup: the largest of CPX_BF3W_RUN .. 2 that divides the tiles of a row, else the whole row if it is short
@@ -1108,14 +1149,21 @@ static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.run = run;
   td.tiles_x = (tx + run - 1) / run;
   td.tiles_y = (a.Ho + W_TH - 1) / W_TH;
-  td.nsplit = (a.Cout / a.groups) / 32;
+  td.nsplit = (a.Cout / a.groups) / (32 * NH);
   const long long blocks = (long long)td.tiles_x * td.tiles_y * a.N * td.nsplit;
   if (blocks >= (1 << 22) || td.tiles_x >= 4096 || td.tiles_y >= 4096) return -3;
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN>), dim3((unsigned)blocks, a.groups), dim3(512), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH>), dim3((unsigned)blocks, a.groups), dim3(512), lds, s, a, wimg, td);
   return 0;
+}
+#ifndef CPX_BF3W_NH
+#define CPX_BF3W_NH 2  // 32-column slices per workgroup where the group has 64 columns (1: one slice, two workgroups per tile)
+#endif
+static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
+  if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2>(a, wimg, s);
+  return launch_bf3w_t<1>(a, wimg, s);
 }
 
 template <int NTN, int S, int NB, int TW, int CT, bool C8 = false>

@@ -85,20 +85,20 @@ out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -
                   "--clips 1024 --steps 1 --warmup 0 --cpu-clips 0 (separate passes, scratch/make_pmc_profile.py)",
        "note": "KiB per dispatch, averaged over the launches named; FETCH_SIZE doubled per MI355X_MICROARCH.md, "
                "WRITE_SIZE as is"}
-CONV = "conv_bf3w_kernel<false, false>"
-# stage 2 (64->64 ch, 160x160: 100 tiles per sample) and stage 3 (128->128 ch, 80x80: 25 tiles x 2 column slices) run
-# the same instantiation; their grids differ (100 vs 50 workgroups per sample and group)
+CONV = "conv_bf3w_kernel<"
+# stage 2 (64->64 ch, 160x160: 100 tiles per sample; instantiation <false, false, 1>) and stage 3 (128->128 ch, 80x80:
+# 25 tiles, both 32-column slices in one workgroup; <false, true, 2>): 100 vs 25 workgroups per sample and group
 grids = sorted({g for g, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV)}, reverse=True)
 grid2 = max(grids, key=lambda g: sum(1 for gg, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV) if gg == g) * (g in grids[:2]) + g * 1e-12)
 grid2 = grids[0]
 conv_n = grid2 // (100 * 2 * 512)
-grid3 = 50 * 2 * 512 * conv_n
+grid3 = 25 * 2 * 512 * conv_n
 out["conv_stage2"] = section(
-    "conv_bf3w_kernel<false,false>, stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
+    "conv_bf3w_kernel<false,false,1>, stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
     "pmc_e2e_write", CONV, grid2, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.6,
     "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
 out["conv_stage3"] = section(
-    "conv_bf3w_kernel<false,false>, stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
+    "conv_bf3w_kernel<false,true,2>, stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
     "pmc_e2e_write", CONV, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
     "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
 # one launch walks 1024 clips through their 270 frames (bench.py defaults): clip-frames per launch
