@@ -949,21 +949,28 @@ def main():
                 # input + output (+ residual in 3 of the 5 launches of a shape per forward), float32 NHWC
                 bytes2 = side * side * 64 * 4 * 2.6
                 if bf3 and key3 in conv:
-                    # stage 2 and stage 3 run the same kernel (conv_bf3w_kernel; two instantiations since round 4:
-                    # <false,false,1> = one 32-column slice per workgroup for stage 2, <false,true,2> = both slices of
-                    # a group from one staged patch for stage 3 -- two rows of the rocprof CSV), with the same FLOPs
-                    # per sample: the roofline covers the launches of both, and names each one's rate beside it
-                    n = conv[key][0] + conv[key3][0]
-                    ms = conv[key][1] + conv[key3][1]
-                    fl = conv[key][2] + conv[key3][2]
+                    # stage 2 and stage 3 run the same source kernel (conv_bf3w_kernel) in two instantiations since
+                    # round 4 -- <false,false,1>: one 32-column slice per workgroup (stage 2: 32 columns per group);
+                    # <false,true,2>: both slices of a group from one staged patch (stage 3) -- two rows of the rocprof
+                    # CSV.  `roofline` is the DOMINANT one (stage 2: the top row); the other one and the launches of
+                    # both together (what rounds 2-3 reported, one instantiation then) stand beside it.
+                    def leg(k, pmc_key, byte_scale):
+                        n_, ms_, fl_ = conv[k]
+                        spl = fl_ / n_ / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
+                        ab = spl * bytes2 * byte_scale
+                        tf_ = fl_ / (ms_ / 1e3) / 1e12
+                        return {"achieved": round(tf_, 2), "frac": round(tf_ / (MFMA_BF16_PEAK_TFLOPS / BF16X3_PRODUCTS), 4),
+                                "avg_launch_us": round(ms_ / n_ * 1e3, 2), "launches": n_,
+                                "algorithmic_flops_per_launch": fl_ / n_, "algorithmic_bytes_per_launch": ab,
+                                "traffic": pmc_traffic(pmc_key, spl * area),
+                                "hbm_GBps_algorithmic": round(ab / (ms_ / n_ / 1e3) / 1e9, 1)}
+                    l2, l3 = leg(key, "conv_stage2", 1.0), leg(key3, "conv_stage3", 0.5)  # stage 3 moves half of stage 2's bytes
+                    n, ms, fl = conv[key]
                     samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
-                    algo_bytes = samples_per_launch * bytes2 * 0.75  # stage 3 moves half of stage 2's bytes
-                    t2 = pmc_traffic("conv_stage2", samples_per_launch * area)
-                    t3 = pmc_traffic("conv_stage3", samples_per_launch * area)
-                    traffic = round((t2 + t3) / 2, 1) if t2 is not None and t3 is not None else None
-                    what = ("conv_bf3w_kernel (the 16x16x32 bf16 MFMA form of the split-operand kernel; instantiations "
-                            "<false,false,1> = stage-2 3x3 convs, 64->64 ch at %dx%d, and <false,true,2> = stage-3, 128->128 ch at "
-                            "%dx%d; groups 2)" % (side, side, side // 2, side // 2))
+                    algo_bytes = l2["algorithmic_bytes_per_launch"]
+                    traffic = l2["traffic"]
+                    what = ("conv_bf3w_kernel<false,false,1> (the 16x16x32 bf16 MFMA form of the split-operand kernel, one "
+                            "32-column slice per workgroup: the stage-2 3x3 convs, 64->64 ch at %dx%d, groups 2)" % (side, side))
                 else:
                     n, ms, fl = conv[key]
                     samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
@@ -986,13 +993,14 @@ def main():
                                     "hbm_frac": round(algo_bytes / (ms / n / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "stage2_tflops": round(conv[key][2] / (conv[key][1] / 1e3) / 1e12, 2)}
                 if bf3 and key3 in conv:
-                    s2 = conv[key][2] / (conv[key][1] / 1e3) / 1e12
-                    s3 = conv[key3][2] / (conv[key3][1] / 1e3) / 1e12
-                    line["roofline"]["per_instantiation"] = {
-                        "stage2 <false,false,1>": {"tflops": round(s2, 2), "frac": round(s2 / peak, 4),
-                                                   "avg_launch_us": round(conv[key][1] / conv[key][0] * 1e3, 2), "launches": conv[key][0]},
-                        "stage3 <false,true,2>": {"tflops": round(s3, 2), "frac": round(s3 / peak, 4),
-                                                  "avg_launch_us": round(conv[key3][1] / conv[key3][0] * 1e3, 2), "launches": conv[key3][0]}}
+                    nb, msb, flb = conv[key][0] + conv[key3][0], conv[key][1] + conv[key3][1], conv[key][2] + conv[key3][2]
+                    line["roofline"]["second_instantiation"] = dict(
+                        {"kernel": "conv_bf3w_kernel<false,true,2> (both 32-column slices of a group from one staged patch: the "
+                                   "stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)" % (side // 2, side // 2)}, **l3)
+                    line["roofline"]["both_instantiations"] = {
+                        "what": "all conv_bf3w_kernel launches of the step (the accounting of rounds 2-3, one instantiation then)",
+                        "achieved": round(flb / (msb / 1e3) / 1e12, 2), "frac": round(flb / (msb / 1e3) / 1e12 / peak, 4),
+                        "avg_launch_us": round(msb / nb * 1e3, 2), "launches": nb}
                 tot_ms = sum(v[1] for v in conv.values())
                 tot_fl = sum(v[2] for v in conv.values())
                 line["cnn"] = {"samples_per_s": round(int(r.n_samples) / max(tot_ms / args.steps / 1e3, 1e-9), 1),
