@@ -950,8 +950,8 @@ def main():
                 bytes2 = side * side * 64 * 4 * 2.6
                 if bf3 and key3 in conv:
                     # stage 2 and stage 3 run the same source kernel (conv_bf3w_kernel) in two instantiations since
-                    # round 4 -- <false,false,1>: one 32-column slice per workgroup (stage 2: 32 columns per group);
-                    # <false,true,2>: both slices of a group from one staged patch (stage 3) -- two rows of the rocprof
+                    # round 4 -- <false,false,1,1>: one 32-column slice per workgroup (stage 2: 32 columns per group);
+                    # <false,true,2,1>: both slices of a group from one staged patch (stage 3) -- two rows of the rocprof
                     # CSV.  `roofline` is the DOMINANT one (stage 2: the top row); the other one and the launches of
                     # both together (what rounds 2-3 reported, one instantiation then) stand beside it.
                     def leg(k, pmc_key, byte_scale):
@@ -969,7 +969,7 @@ def main():
                     samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
                     algo_bytes = l2["algorithmic_bytes_per_launch"]
                     traffic = l2["traffic"]
-                    what = ("conv_bf3w_kernel<false,false,1> (the 16x16x32 bf16 MFMA form of the split-operand kernel, one "
+                    what = ("conv_bf3w_kernel<false,false,1,1> (the 16x16x32 bf16 MFMA form of the split-operand kernel, one "
                             "32-column slice per workgroup: the stage-2 3x3 convs, 64->64 ch at %dx%d, groups 2)" % (side, side))
                 else:
                     n, ms, fl = conv[key]
@@ -995,7 +995,7 @@ def main():
                 if bf3 and key3 in conv:
                     nb, msb, flb = conv[key][0] + conv[key3][0], conv[key][1] + conv[key3][1], conv[key][2] + conv[key3][2]
                     line["roofline"]["second_instantiation"] = dict(
-                        {"kernel": "conv_bf3w_kernel<false,true,2> (both 32-column slices of a group from one staged patch: the "
+                        {"kernel": "conv_bf3w_kernel<false,true,2,1> (both 32-column slices of a group from one staged patch: the "
                                    "stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)" % (side // 2, side // 2)}, **l3)
                     line["roofline"]["both_instantiations"] = {
                         "what": "all conv_bf3w_kernel launches of the step (the accounting of rounds 2-3, one instantiation then)",

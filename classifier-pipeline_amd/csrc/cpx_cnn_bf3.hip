@@ -686,13 +686,17 @@ constexpr int W_WSUB = 3 * 3 * 4 * 32;       // entries of a weight sub-chunk (o
 // instead of living in eight registers; NH: 32-column slices of the group's output channels the workgroup computes from
 // ONE staged patch (NH = 2 for 64 columns per group: the patch of a tile is loaded, normalised and split once instead
 // of once per slice -- the slices' weights alternate through the same 18 KB, twice the accumulators)
-template <bool WALK, bool LDSBN, int NH>
+// NG: GROUPS the workgroup walks on its tile, one after the other (experiment, -DCPX_BF3W_NG=2: the second group's patch
+// and first weights are in flight under the first group's products, as the next chunk's are in a layer with 64
+// channels per group, and the tile's index arithmetic is paid once for both -- 171 vs 183 TFLOP/s on stage 2: not shipped)
+template <bool WALK, bool LDSBN, int NH, int NG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf3w_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+  static_assert(NG == 1 || (!WALK && !LDSBN && NH == 1), "the group walk is built for the one-slice, one-tile form");
   constexpr int CT = 512;
   // per-thread staging / output indices are re-derived from the thread index at each use (WALK: they would be carried
   // across the tile loop; NH > 1: sixteen more accumulator registers leave no room to keep them across the products --
   // kept, the compiler spills eight of them to scratch per tile: +22 % HBM traffic on the stage-3 launches, measured)
-  constexpr bool LAUNDER = WALK || NH > 1;
+  constexpr bool LAUNDER = WALK || NH > 1 || NG > 1;
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   uint4* s_patch = lds4;
   uint4* s_w = lds4 + W_PATCH;
@@ -714,14 +718,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #else
   const int n = qd;
 #endif
-  const int g = blockIdx.y;
+  const int g0 = blockIdx.y * NG;
   const int oy0 = tyi * W_TH;
   const int iy0 = oy0 - a.pad_top;
   const int run = WALK ? td.run : 1;
   const int tx_end = WALK ? min((txr + 1) * run, (a.Wo + W_TW - 1) / W_TW) : txr + 1;
-  const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
+  const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin;
   const int nch = cin_g / KW;
-  const uint4* wg = wimg + (size_t)g * nch * (3 * 36) * cout_g + (size_t)ns * (32 * NH);
+  const uint4* wg = wimg + (size_t)ns * (32 * NH);
   const int a_base = ((q >> 1) * W_NPXP + (2 * wave) * W_PW + i16) * 2 + (q & 1);
   const int b_base = q * 32 + i16;
   // Staging items: ONE 16-byte piece (4 channels) of a patch pixel's 32-channel chunk, the eight pieces of a pixel on
@@ -742,16 +746,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   f32x4 psc_r, psh_r;  // (!LDSBN)
   if (LDSBN && a.in_scale) {
     if (tid < cin_g) {
-      reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g * cin_g + tid];
-      reinterpret_cast<float*>(s_bn)[cin_g + tid] = a.in_shift[g * cin_g + tid];
+      reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g0 * cin_g + tid];
+      reinterpret_cast<float*>(s_bn)[cin_g + tid] = a.in_shift[g0 * cin_g + tid];
     }
     __syncthreads();
   }
   // (the per-thread bases are laundered at every use: left visible, the compiler keeps one address register per
   // staged item alive -- and stepping -- across all phases, and the prefetched pieces themselves go to scratch)
-#define BF3W_ISSUE_W(C_, R_, HF_)                                                                         \
+#define BF3W_ISSUE_W(G_, C_, R_, HF_)                                                                     \
   {                                                                                                       \
-    const uint4* wc = wg + (size_t)(((C_) * 3 + (R_)) * 36) * cout_g + (HF_) * 32;                        \
+    const uint4* wc = wg + (size_t)((((G_) * nch + (C_)) * 3 + (R_)) * 36) * cout_g + (HF_) * 32;         \
     unsigned woff = (unsigned)((tid >> 5) * cout_g + (tid & 31)) << 4;                                    \
     if (LAUNDER) asm volatile("" : "+v"(woff));                                                           \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                     \
@@ -761,14 +765,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }                                                                                                     \
   }
   // (branch-free, clamped addresses: see conv_bf3_kernel; out-of-image pixels are zeroed at commit)
-#define BF3W_ISSUE_P(C_, IX0_)                                                                            \
+#define BF3W_ISSUE_P(G_, C_, IX0_)                                                                        \
   {                                                                                                       \
     int t8 = tid >> 3;                                                                                    \
     if (LAUNDER) asm volatile("" : "+v"(t8));                                                             \
     int my_q8 = tid & 7;                                                                                  \
     if (LAUNDER) asm volatile("" : "+v"(my_q8));                                                          \
     if (!LDSBN) {                                                                                         \
-      const int ch = g * cin_g + (C_) * KW;                                                               \
+      const int ch = (G_) * cin_g + (C_) * KW;                                                            \
       const float* scp = a.in_scale ? a.in_scale + ch : reinterpret_cast<const float*>(wimg);             \
       const float* shp = a.in_scale ? a.in_shift + ch : reinterpret_cast<const float*>(wimg);             \
       unsigned qoff = (unsigned)my_q8 << 4;                                                               \
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       psc_r = *reinterpret_cast<const f32x4*>(at_off(scp, qoff));                                         \
       psh_r = *reinterpret_cast<const f32x4*>(at_off(shp, qoff));                                         \
     }                                                                                                     \
-    const unsigned coff = (unsigned)((C_) * KW + 4 * my_q8);                                              \
+    const unsigned coff = (unsigned)((G_) * cin_g + (C_) * KW + 4 * my_q8);                               \
     _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                      \
       const int px = min(t8 + 64 * i, W_NPX - 1);                                                         \
       const int py = (px * 3641) >> 16, pxx = px - py * W_PW; /* px / 18 for px < 324 */                  \
@@ -784,8 +788,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, a.Cin) + coff) << 2)); \
     }                                                                                                     \
   }
-  BF3W_ISSUE_W(0, 0, 0)
-  BF3W_ISSUE_P(0, txr * run * W_TW - a.pad_left)
+  BF3W_ISSUE_W(g0, 0, 0, 0)
+  BF3W_ISSUE_P(g0, 0, txr * run * W_TW - a.pad_left)
   // The workgroup walks a run of tiles along x: the next tile's patch and first weights are in flight under the
   // current tile's products exactly as the next chunk's are, so only the first tile of a run waits for its loads
   // with nothing else to do (the other workgroup of the CU aside).
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   int ch_l;
   unsigned opix[2];  // element offsets of the (clamped) pixels in the output map
   bool ovalid[2];
-  auto out_pixels = [&]() __attribute__((always_inline)) {
+  auto out_pixels = [&](const int g) __attribute__((always_inline)) {
     int t = tid;
     if (LAUNDER) asm volatile("" : "+v"(t));
     const int i16_ = t & 15, q_ = (t >> 4) & 3, wave_ = t >> 6;
@@ -810,9 +814,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       opix[pt] = pix_off(min(oy, a.Ho - 1), min(ox, a.Wo - 1), a.Wo, a.Cout) + (unsigned)ch_l;
     }
   };
-  out_pixels();
   const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;  // see conv_bf3_kernel
   f32x4 acc[NH][2][2];
+  auto init_acc = [&](const int g) __attribute__((always_inline)) {  // a group's accumulators: zero, or its residual
+  out_pixels(g);
   if (res_in_acc) {
     const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout;
 #pragma unroll
@@ -830,13 +835,79 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) acc[hf][ct][pt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
+  };
+  // a group's fused shortcut, affine, residual, ReLU and stores
+  auto finish = [&](const int g) __attribute__((always_inline)) {
 
-  for (int c = 0; c < nch; ++c) {
+  // ---- fused 1x1 shortcut (see conv_bf3_kernel), on v_mfma_f32_16x16x4_f32: A = weights [column][k], B = pixels ----
+  if (a.sc_in) {
+    const int sc_cg = a.sc_cin / a.groups;
+    const float* wsc = a.sc_w + ((size_t)g * sc_cg + q) * cout_g + ns * (32 * NH) + i16;
+    const float* pin[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int oy = min(oy0 + 2 * wave + pt, a.Ho - 1), ox = min(ox0 + i16, a.Wo - 1);
+      pin[pt] = a.sc_in + (((size_t)n * a.sc_H + oy * a.sc_stride) * a.sc_W + ox * a.sc_stride) * a.sc_cin + g * sc_cg + q;
+    }
+    for (int k4 = 0; k4 < sc_cg; k4 += 4) {
+      float xs[2], ws[NH][2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) xs[pt] = pin[pt][k4];
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) ws[hf][ct] = wsc[(size_t)k4 * cout_g + 32 * hf + 16 * ct];
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[hf][ct], xs[pt], acc[hf][ct][pt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: affine, residual, ReLU and one 16-byte store per accumulator tile, straight from the registers ----
+  float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
+  const float* res_n = (a.residual && !res_in_acc) ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+  if (LAUNDER) out_pixels(g);  // (re-derived: see LAUNDER)
+#pragma unroll
+  for (int hc = 0; hc < 2 * NH; ++hc) {
+    const int hf = hc >> 1, ct = hc & 1;
+    const int ch = ch_l + 16 * hc;
+    f32x4 os = {1.0f, 1.0f, 1.0f, 1.0f}, ob = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.out_scale) os = *reinterpret_cast<const f32x4*>(a.out_scale + ch);
+    if (a.out_shift) ob = *reinterpret_cast<const f32x4*>(a.out_shift + ch);
+    if (a.sc_in && a.sc_bias) ob += *reinterpret_cast<const f32x4*>(a.sc_bias + ch);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      f32x4 v = acc[hf][ct][pt];
+      if (a.out_scale) {  // (uniform branches kept as branches: see the patch commit)
+        asm volatile("");
+        v = v * os;
+      }
+      v += ob;
+      const unsigned o = (opix[pt] + 16u * hc) << 2;
+      if (res_n) v += *reinterpret_cast<const f32x4*>(at_off(res_n, o));
+      if (a.relu) {
+        asm volatile("");
+        v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+      }
+      if (ovalid[pt]) *reinterpret_cast<f32x4*>(at_off(out_n, o)) = v;
+    }
+  }
+  };
+  init_acc(g0);
+
+  for (int cc = 0; cc < NG * nch; ++cc) {
+  const int gi = (NG > 1 && cc >= nch) ? 1 : 0;  // (NG <= 2)
+  const int c = cc - gi * nch, g = g0 + gi;
+  {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
-      if (c > 0 || r > 0 || hf > 0 || txi > txr * run) __syncthreads();  // every wave has read the previous phase's fragments
+      if (cc > 0 || r > 0 || hf > 0 || txi > txr * run) __syncthreads();  // every wave has read the previous phase's fragments
       // ---- registers -> LDS: the kernel row's weights (a straight copy) ----
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
@@ -903,20 +974,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
       }
       // ---- global -> registers for what comes next (in flight under this phase's products) ----
+      // (the chunk after this one: the same group's next 32 channels, or the next group's first)
+      const int gn = (c + 1 < nch) ? g : g + 1, cn = (c + 1 < nch) ? c + 1 : 0;
       if (hf + 1 < NH) {
-        BF3W_ISSUE_W(c, r, hf + 1)
+        BF3W_ISSUE_W(g, c, r, hf + 1)
       } else if (r < 2) {
-        BF3W_ISSUE_W(c, r + 1, 0)
-      } else if (c + 1 < nch) {
-        BF3W_ISSUE_W(c + 1, 0, 0)
+        BF3W_ISSUE_W(g, c, r + 1, 0)
+      } else if (cc + 1 < NG * nch) {
+        BF3W_ISSUE_W(gn, cn, 0, 0)
       } else if (txi + 1 < tx_end) {
-        BF3W_ISSUE_W(0, 0, 0)
+        BF3W_ISSUE_W(g0, 0, 0, 0)
       }
       if (r == 0 && hf == 0) {
-        if (c + 1 < nch) {
-          BF3W_ISSUE_P(c + 1, ix0)
+        if (cc + 1 < NG * nch) {
+          BF3W_ISSUE_P(gn, cn, ix0)
         } else if (txi + 1 < tx_end) {
-          BF3W_ISSUE_P(0, ix0 + W_TW)
+          BF3W_ISSUE_P(g0, 0, ix0 + W_TW)
         }
       }
       __syncthreads();
@@ -947,64 +1020,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }  // column slices
     }
   }
-
-  // ---- fused 1x1 shortcut (see conv_bf3_kernel), on v_mfma_f32_16x16x4_f32: A = weights [column][k], B = pixels ----
-  if (a.sc_in) {
-    const int sc_cg = a.sc_cin / a.groups;
-    const float* wsc = a.sc_w + ((size_t)g * sc_cg + q) * cout_g + ns * (32 * NH) + i16;
-    const float* pin[2];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      const int oy = min(oy0 + 2 * wave + pt, a.Ho - 1), ox = min(ox0 + i16, a.Wo - 1);
-      pin[pt] = a.sc_in + (((size_t)n * a.sc_H + oy * a.sc_stride) * a.sc_W + ox * a.sc_stride) * a.sc_cin + g * sc_cg + q;
-    }
-    for (int k4 = 0; k4 < sc_cg; k4 += 4) {
-      float xs[2], ws[NH][2];
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) xs[pt] = pin[pt][k4];
-#pragma unroll
-      for (int hf = 0; hf < NH; ++hf)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) ws[hf][ct] = wsc[(size_t)k4 * cout_g + 32 * hf + 16 * ct];
-#pragma unroll
-      for (int hf = 0; hf < NH; ++hf)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt)
-            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[hf][ct], xs[pt], acc[hf][ct][pt], 0, 0, 0);
-    }
+  if (NG > 1 && c + 1 == nch && cc + 1 < NG * nch) {  // a group but the last is done: its stores, the next one's accumulators
+    finish(g);
+    init_acc(g + 1);
   }
-
-  // ---- epilogue: affine, residual, ReLU and one 16-byte store per accumulator tile, straight from the registers ----
-  float* out_n = a.out + (size_t)n * a.Ho * a.Wo * a.Cout;
-  const float* res_n = (a.residual && !res_in_acc) ? a.residual + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
-  if (LAUNDER) out_pixels();  // (re-derived: see LAUNDER)
-#pragma unroll
-  for (int hc = 0; hc < 2 * NH; ++hc) {
-    const int hf = hc >> 1, ct = hc & 1;
-    const int ch = ch_l + 16 * hc;
-    f32x4 os = {1.0f, 1.0f, 1.0f, 1.0f}, ob = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (a.out_scale) os = *reinterpret_cast<const f32x4*>(a.out_scale + ch);
-    if (a.out_shift) ob = *reinterpret_cast<const f32x4*>(a.out_shift + ch);
-    if (a.sc_in && a.sc_bias) ob += *reinterpret_cast<const f32x4*>(a.sc_bias + ch);
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      f32x4 v = acc[hf][ct][pt];
-      if (a.out_scale) {  // (uniform branches kept as branches: see the patch commit)
-        asm volatile("");
-        v = v * os;
-      }
-      v += ob;
-      const unsigned o = (opix[pt] + 16u * hc) << 2;
-      if (res_n) v += *reinterpret_cast<const f32x4*>(at_off(res_n, o));
-      if (a.relu) {
-        asm volatile("");
-        v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
-      }
-      if (ovalid[pt]) *reinterpret_cast<f32x4*>(at_off(out_n, o)) = v;
-    }
-  }
+  }  // chunks of the tile's groups
+  finish(g0 + NG - 1);
   }  // tiles of the run
 }
 #undef BF3W_ISSUE_W
@@ -1132,13 +1153,13 @@ __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __res
   }
 }
 
-template <int NH>
+template <int NH, int NG>
 static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = (size_t)(W_PATCH + W_WSUB) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
   static bool lds_ready[64];
   // (NH = 2 carries 16 more accumulator registers: the BatchNorm parameters go to LDS there)
   constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0 || NH > 1;
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   const int tx = (a.Wo + W_TW - 1) / W_TW;
   // tiles per workgroup: the largest of CPX_BF3W_RUN .. 2 that divides the tiles of a row, else the whole row if it is short
@@ -1155,15 +1176,20 @@ static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH>), dim3((unsigned)blocks, a.groups), dim3(512), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH, NG>), dim3((unsigned)blocks, a.groups / NG), dim3(512), lds, s, a, wimg, td);
   return 0;
 }
 #ifndef CPX_BF3W_NH
 #define CPX_BF3W_NH 2  // 32-column slices per workgroup where the group has 64 columns (1: one slice, two workgroups per tile)
 #endif
+#ifndef CPX_BF3W_NG
+#define CPX_BF3W_NG 1  // groups a workgroup walks on its tile in the one-slice form (2: measured 6.5 % slower on stage 2, scratch/patches/README.md)
+#endif
 static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
-  if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2>(a, wimg, s);
-  return launch_bf3w_t<1>(a, wimg, s);
+  if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1>(a, wimg, s);
+  constexpr int NG = (CPX_BF3W_NG == 2 && CPX_BF3W_RUN <= 1 && CPX_BF3W_LDSBN == 0) ? 2 : 1;
+  if (NG == 2 && (a.groups & 1) == 0) return launch_bf3w_t<1, NG>(a, wimg, s);
+  return launch_bf3w_t<1, 1>(a, wimg, s);
 }
 
 template <int NTN, int S, int NB, int TW, int CT, bool C8 = false>
