@@ -403,7 +403,7 @@ class TrackEngine:
 
     THUMB_TIERS = ((46, 2304), (80, 4608))
 
-    CNN_MATH = {"f32": 0, "bf16x3": 1}
+    CNN_MATH = {"f32": 0, "bf16x3": 1, "bf16x2": 2}
 
     def set_cnn_math(self, mode):
         """"f32": v_mfma_f32_32x32x2_f32; "bf16x3" (default): exact three-way bf16 split of the float32 operands on

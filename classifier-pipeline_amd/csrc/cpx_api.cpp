@@ -294,6 +294,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   if (const char* env = std::getenv("CPX_CNN_MATH")) {
     if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
     else if (!std::strcmp(env, "bf16x3")) h->cnn_math = CPX_CNN_MATH_BF16X3;
+    else if (!std::strcmp(env, "bf16x2")) h->cnn_math = CPX_CNN_MATH_BF16X2;
   }
   *out = h;
   return CPX_OK;
@@ -803,6 +804,8 @@ struct conv_fuse {
 };
 static bool conv_can_fuse(const cpx_handle* h, const cpx_conv_desc* d);
 
+// the two modes that run the split-operand kernels (bf16 planes on the bf16 matrix pipe)
+static bool split_math(const cpx_handle* h) { return h->cnn_math == CPX_CNN_MATH_BF16X3 || h->cnn_math == CPX_CNN_MATH_BF16X2; }
 // split_weights: the bf16 plane image of d->weights_dev if the caller (a cpx_cnn) keeps one, else NULL
 static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_weights, const conv_fuse* fuse = nullptr) {
   if (!h) return CPX_ERR_INVALID;
@@ -831,7 +834,7 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
   a.in_scale = d->in_scale_dev; a.in_shift = d->in_shift_dev;
   a.out_scale = d->out_scale_dev; a.out_shift = d->out_shift_dev; a.residual = d->residual_dev;
   if (fuse) {
-    if (!(h->cnn_math == CPX_CNN_MATH_BF16X3 && cpx::conv_bf3_supported(a)) || a.out_scale || a.residual)
+    if (!(split_math(h) && cpx::conv_bf3_supported(a)) || a.out_scale || a.residual)
       return fail(h, CPX_ERR_INVALID, "conv_run: shortcut fusion needs the split-operand kernel, no output scale, no residual");
     a.sc_in = fuse->in; a.sc_w = fuse->w; a.sc_bias = fuse->bias;
     a.sc_H = fuse->H; a.sc_W = fuse->W; a.sc_cin = fuse->cin; a.sc_stride = fuse->stride;
@@ -845,7 +848,8 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
     CPX_HIP(h, hipEventRecord(ev.e0, h->stream));
   }
   int rc;
-  if (h->cnn_math == CPX_CNN_MATH_BF16X3 && cpx::conv_bf3_supported(a)) {
+  if (split_math(h) && cpx::conv_bf3_supported(a)) {
+    a.planes = h->cnn_math == CPX_CNN_MATH_BF16X2 ? 2 : 3;
     if (!split_weights) {
       const size_t need = cpx::conv_bf3_weight_bytes(a);
       if (need > h->bf3_scratch_bytes) {
@@ -885,7 +889,7 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* d) { return conv_run(h, d, nu
 
 // the 3x3 stride-1 convolution described by d runs on the split-operand kernel (which can absorb a 1x1 shortcut)
 static bool conv_can_fuse(const cpx_handle* h, const cpx_conv_desc* d) {
-  if (h->cnn_math != CPX_CNN_MATH_BF16X3 || d->out_scale_dev || d->groups < 1) return false;
+  if (!split_math(h) || d->out_scale_dev || d->groups < 1) return false;
   cpx::ConvArgs a{};
   a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups; a.ksize = d->ksize; a.stride = d->stride;
   return cpx::conv_bf3_supported(a);
@@ -893,7 +897,8 @@ static bool conv_can_fuse(const cpx_handle* h, const cpx_conv_desc* d) {
 
 int cpx_set_cnn_math(cpx_handle* h, int mode) {
   if (!h) return CPX_ERR_INVALID;
-  if (mode != CPX_CNN_MATH_F32 && mode != CPX_CNN_MATH_BF16X3) return fail(h, CPX_ERR_INVALID, "cpx_set_cnn_math: unknown mode");
+  if (mode != CPX_CNN_MATH_F32 && mode != CPX_CNN_MATH_BF16X3 && mode != CPX_CNN_MATH_BF16X2)
+    return fail(h, CPX_ERR_INVALID, "cpx_set_cnn_math: unknown mode");
   h->cnn_math = mode;
   return CPX_OK;
 }

@@ -69,6 +69,19 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
   p2 = pack2(sa, sb);
 }
 
+// two float32 -> TWO bf16 planes, each rounded to nearest (v_cvt_pk_bf16_f32): hi + lo carries 16 significand bits,
+// |x - hi - lo| <= 2^-16 |x| (CPX_CNN_MATH_BF16X2: three products per K step instead of six)
+__device__ __forceinline__ unsigned pack2_rne(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split_pair2(float a, float b, unsigned& p0, unsigned& p1) {
+  p0 = pack2_rne(a, b);
+  const float ra = a - bf_lo(p0), rb = b - bf_hi(p0);  // exact
+  p1 = pack2_rne(ra, rb);
+}
+
 constexpr int KC = 16;  // channels per K step of the bf16 MFMA = per staged chunk
 
 // NB bands of 128 output pixels per workgroup, CT threads: four waves share a band (32 pixels each); with CT = 512
@@ -679,8 +692,8 @@ constexpr int KW = 32;
 #endif
 constexpr int W_TW = 16, W_TH = 16, W_PW = 18, W_NPX = 18 * 18;
 constexpr int W_NPXP = 326;  // pixels per (plane, quarter pair) region: 326 * 32 B = 64 mod 128, the two regions' ds_write_b64 lanes then use different banks
-constexpr int W_PATCH = 3 * 2 * W_NPXP * 2;  // entries
-constexpr int W_WSUB = 3 * 3 * 4 * 32;       // entries of a weight sub-chunk (one kernel row)
+constexpr int w_patch_entries(int planes) { return planes * 2 * W_NPXP * 2; }
+constexpr int w_wsub_entries(int planes) { return planes * 3 * 4 * 32; }  // a weight sub-chunk (one kernel row)
 // WALK: the workgroup walks a run of td.run tiles along x (else exactly one tile: the loop and the per-use
 // laundering of the staging bases fold away); LDSBN: BatchNorm scale / shift read back from LDS at each patch commit
 // instead of living in eight registers; NH: 32-column slices of the group's output channels the workgroup computes from
@@ -689,9 +702,15 @@ constexpr int W_WSUB = 3 * 3 * 4 * 32;       // entries of a weight sub-chunk (o
 // NG: GROUPS the workgroup walks on its tile, one after the other (experiment, -DCPX_BF3W_NG=2: the second group's patch
 // and first weights are in flight under the first group's products, as the next chunk's are in a layer with 64
 // channels per group, and the tile's index arithmetic is paid once for both -- 171 vs 183 TFLOP/s on stage 2: not shipped)
-template <bool WALK, bool LDSBN, int NH, int NG>
+// PL: bf16 planes per operand.  3 = the exact split (six products per K step: every term down to 2^-24 of the float32
+// product); 2 = CPX_CNN_MATH_BF16X2: both operands as hi + lo rounded to nearest (16 significand bits, relative error
+// <= 2^-16 each), three products w0 x1 + w1 x0 + w0 x0 -- half the matrix work, two thirds of the staging and LDS.
+template <bool WALK, bool LDSBN, int NH, int NG, int PL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf3w_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   static_assert(NG == 1 || (!WALK && !LDSBN && NH == 1), "the group walk is built for the one-slice, one-tile form");
+  static_assert(PL == 2 || PL == 3, "two or three bf16 planes per operand");
+  constexpr int W_PATCH = PL * 2 * W_NPXP * 2;  // entries
+  constexpr int W_WSUB = PL * 3 * 4 * 32;       // entries of a weight sub-chunk (one kernel row)
   constexpr int CT = 512;
   // per-thread staging / output indices are re-derived from the thread index at each use (WALK: they would be carried
   // across the tile loop; NH > 1: sixteen more accumulator registers leave no room to keep them across the products --
@@ -755,7 +774,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // staged item alive -- and stepping -- across all phases, and the prefetched pieces themselves go to scratch)
 #define BF3W_ISSUE_W(G_, C_, R_, HF_)                                                                     \
   {                                                                                                       \
-    const uint4* wc = wg + (size_t)((((G_) * nch + (C_)) * 3 + (R_)) * 36) * cout_g + (HF_) * 32;         \
+    const uint4* wc = wg + (size_t)((((G_) * nch + (C_)) * 3 + (R_)) * (12 * PL)) * cout_g + (HF_) * 32;  \
     unsigned woff = (unsigned)((tid >> 5) * cout_g + (tid & 31)) << 4;                                    \
     if (LAUNDER) asm volatile("" : "+v"(woff));                                                           \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                     \
@@ -939,7 +958,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 uint2* sp2 = reinterpret_cast<uint2*>(s_patch) + st_e2 + i * (64 * 4);
                 sp2[(0 * 2 * W_NPXP) * 4] = make_uint2(pre_p[i][0], pre_p[i][1]);
                 sp2[(1 * 2 * W_NPXP) * 4] = make_uint2(pre_p[i][2], pre_p[i][3]);
-                sp2[(2 * 2 * W_NPXP) * 4] = make_uint2(pre_p[i][1], pre_p[i][2]);
+                if (PL == 3) sp2[(2 * 2 * W_NPXP) * 4] = make_uint2(pre_p[i][1], pre_p[i][2]);
                 continue;
               }
 #endif
@@ -962,13 +981,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
               }
               unsigned q0[2], q1[2], q2[2];
-              split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
-              split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
+              if (PL == 3) {
+                split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
+                split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
+              } else {
+                split_pair2(v[0], v[1], q0[0], q1[0]);
+                split_pair2(v[2], v[3], q0[1], q1[1]);
+              }
               // channels 4 q8 .. 4 q8 + 3 of the chunk: quarter pair q8 >> 2, 8-byte slot q8 & 3 of the pixel's 32 bytes
               uint2* sp2 = reinterpret_cast<uint2*>(s_patch) + st_e2 + i * (64 * 4);
               sp2[(0 * 2 * W_NPXP) * 4] = make_uint2(q0[0], q0[1]);
               sp2[(1 * 2 * W_NPXP) * 4] = make_uint2(q1[0], q1[1]);
-              sp2[(2 * 2 * W_NPXP) * 4] = make_uint2(q2[0], q2[1]);
+              if (PL == 3) sp2[(2 * 2 * W_NPXP) * 4] = make_uint2(q2[0], q2[1]);
             }
           }
         }
@@ -995,9 +1019,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       __syncthreads();
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        bf16x8 xv[2][3], wv[2][3];
+        bf16x8 xv[2][PL], wv[2][PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < PL; ++p) {
 #pragma unroll
           for (int pt = 0; pt < 2; ++pt)
             xv[pt][p] = __builtin_bit_cast(bf16x8, s_patch[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
@@ -1009,9 +1033,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
           for (int pt = 0; pt < 2; ++pt) {
             // smallest terms first, as conv_bf3_kernel (x = activation planes, w = weight planes)
-            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][1], acc[hf][ct][pt], 0, 0, 0);
-            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][2], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
-            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][2], acc[hf][ct][pt], 0, 0, 0);
+            if (PL == 3) {
+              acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][1], acc[hf][ct][pt], 0, 0, 0);
+              acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][PL - 1], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
+              acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][PL - 1], acc[hf][ct][pt], 0, 0, 0);
+            }
             acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
             acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][1], acc[hf][ct][pt], 0, 0, 0);
             acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
@@ -1121,8 +1147,9 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 
 // packed float32 weights [g][tap][cin_g][cout_g] -> [g][chunk of 32][ky][plane][kx][quarter][cout_g] of 16-byte entries
 // (conv_bf3w_kernel: a (chunk, ky) sub-chunk is 36 rows of cout_g entries)
+// planes = 2: [g][chunk][ky][2][kx][quarter][cout_g], hi / lo rounded to nearest (a sub-chunk is 24 rows)
 __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
-                                                              int cin_g, int cout_g) {
+                                                              int cin_g, int cout_g, int planes) {
   const int nch = cin_g / KW;
   const size_t total = (size_t)groups * nch * 9 * 4 * cout_g;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1142,24 +1169,31 @@ __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __res
     for (int j = 0; j < 8; ++j)
       v[j] = w[(((size_t)g * 9 + ky * 3 + kx) * cin_g + chunk * KW + 8 * qq + j) * cout_g + col];
     uint4 p0, p1, p2;
-    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
-    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
-    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
-    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
-    const size_t base = (((size_t)g * nch + chunk) * 3 + ky) * 36 * cout_g;
+    if (planes == 3) {
+      split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+      split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+      split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+      split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+    } else {
+      split_pair2(v[0], v[1], p0.x, p1.x);
+      split_pair2(v[2], v[3], p0.y, p1.y);
+      split_pair2(v[4], v[5], p0.z, p1.z);
+      split_pair2(v[6], v[7], p0.w, p1.w);
+    }
+    const size_t base = (((size_t)g * nch + chunk) * 3 + ky) * (12 * planes) * cout_g;
     out[base + ((size_t)(0 * 3 + kx) * 4 + qq) * cout_g + col] = p0;
     out[base + ((size_t)(1 * 3 + kx) * 4 + qq) * cout_g + col] = p1;
-    out[base + ((size_t)(2 * 3 + kx) * 4 + qq) * cout_g + col] = p2;
+    if (planes == 3) out[base + ((size_t)(2 * 3 + kx) * 4 + qq) * cout_g + col] = p2;
   }
 }
 
-template <int NH, int NG>
+template <int NH, int NG, int PL>
 static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
-  const size_t lds = (size_t)(W_PATCH + W_WSUB) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
+  const size_t lds = (size_t)(w_patch_entries(PL) + w_wsub_entries(PL)) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
   static bool lds_ready[64];
   // (NH = 2 carries 16 more accumulator registers: the BatchNorm parameters go to LDS there)
   constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0 || NH > 1;
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   const int tx = (a.Wo + W_TW - 1) / W_TW;
   // tiles per workgroup: the largest of CPX_BF3W_RUN .. 2 that divides the tiles of a row, else the whole row if it is short
@@ -1176,7 +1210,7 @@ static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH, NG>), dim3((unsigned)blocks, a.groups / NG), dim3(512), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL>), dim3((unsigned)blocks, a.groups / NG), dim3(512), lds, s, a, wimg, td);
   return 0;
 }
 #ifndef CPX_BF3W_NH
@@ -1185,11 +1219,19 @@ static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
 #ifndef CPX_BF3W_NG
 #define CPX_BF3W_NG 1  // groups a workgroup walks on its tile in the one-slice form (2: measured 6.5 % slower on stage 2, scratch/patches/README.md)
 #endif
+// the three-plane image of a layer, then (these layers only) the two-plane one
+static size_t bf3w_image3_bytes(const ConvArgs& a) { return (size_t)a.groups * (a.Cin / a.groups / KW) * 3 * 36 * (a.Cout / a.groups) * 16; }
+static size_t bf3w_image2_bytes(const ConvArgs& a) { return (size_t)a.groups * (a.Cin / a.groups / KW) * 3 * 24 * (a.Cout / a.groups) * 16; }
 static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
-  if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1>(a, wimg, s);
+  if (a.planes == 2) {
+    const uint4* w2 = wimg + bf3w_image3_bytes(a) / 16;
+    if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1, 2>(a, w2, s);
+    return launch_bf3w_t<1, 1, 2>(a, w2, s);
+  }
+  if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1, 3>(a, wimg, s);
   constexpr int NG = (CPX_BF3W_NG == 2 && CPX_BF3W_RUN <= 1 && CPX_BF3W_LDSBN == 0) ? 2 : 1;
-  if (NG == 2 && (a.groups & 1) == 0) return launch_bf3w_t<1, NG>(a, wimg, s);
-  return launch_bf3w_t<1, 1>(a, wimg, s);
+  if (NG == 2 && (a.groups & 1) == 0) return launch_bf3w_t<1, NG, 3>(a, wimg, s);
+  return launch_bf3w_t<1, 1, 3>(a, wimg, s);
 }
 
 template <int NTN, int S, int NB, int TW, int CT, bool C8 = false>
@@ -1289,8 +1331,10 @@ bool conv_bf3_supported(const ConvArgs& a) {
 }
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
   if (bf3_c8(a)) return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16;
+  if (bf3w_layer(a)) return bf3w_image3_bytes(a) + bf3w_image2_bytes(a);  // both math modes' images, one after the other
   return (size_t)a.groups * (a.Cin / a.groups / KC) * 54 * (a.Cout / a.groups) * 16;
 }
+bool conv_bf3_two_planes(const ConvArgs& a) { return bf3w_layer(a); }
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   if (bf3_c8(a)) {
@@ -1302,7 +1346,9 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   if (bf3w_layer(a)) {
     const size_t total32 = (size_t)a.groups * (cin_g / KW) * 36 * cout_g;
     hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
-                       reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g);
+                       reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g, 3);
+    hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg) + bf3w_image3_bytes(a) / 16, a.groups, cin_g, cout_g, 2);
     return;
   }
   const size_t total = (size_t)a.groups * (cin_g / KC) * 18 * cout_g;

@@ -187,6 +187,9 @@ struct ConvArgs {
   const float* sc_w;     // packed [groups][1][sc_cin / groups][Cout / groups]
   const float* sc_bias;  // [Cout]
   int sc_H, sc_W, sc_cin, sc_stride;
+  // bf16 planes per operand on the split-operand path: 0 / 3 = the exact three-way split, 2 = CPX_CNN_MATH_BF16X2
+  // (the layers conv_bf3_two_planes() names; every other layer keeps three)
+  int planes;
 };
 struct HeadArgs {
   int N, HW, C, L;
@@ -206,6 +209,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 // float32 operands as three bf16 planes on the bf16 matrix pipe (cpx_cnn_bf3.hip)
 bool conv_bf3_supported(const ConvArgs& a);
 size_t conv_bf3_weight_bytes(const ConvArgs& a);
+bool conv_bf3_two_planes(const ConvArgs& a);
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s);
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s);
 void launch_head(const HeadArgs& a, hipStream_t s);
