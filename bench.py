@@ -713,7 +713,7 @@ def main():
                     help="samples per CNN forward (default 2048 at frame size 32 = 54 GB of activations, 512 at 64)")
     ap.add_argument("--frame-size", type=int, default=32, choices=(32, 64),
                     help="side of one tile of the 5x5 network input (SURVEY 8(d) config 3 asks for 32 and 64)")
-    ap.add_argument("--cnn-math", choices=("bf16x3", "f32"), default="bf16x3",
+    ap.add_argument("--cnn-math", choices=("bf16x3", "f32", "bf16x2"), default="bf16x3",
                     help="how the 3x3 stride-1 convolutions multiply their float32 operands (include/cpx.h: cpx_set_cnn_math)")
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="groups of clips per step: the track stage of group k+1 is issued on a second stream beside the "
@@ -921,7 +921,9 @@ def main():
             "vs_baseline": None,
             "dtype": ("u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)"
                       % ("3x3 convs: exact 3-way bf16 operand split, 6 bf16 MFMAs per K step, f32 accumulate"
-                         if args.cnn_math == "bf16x3" else "f32 MFMA")) if e2e else
+                         if args.cnn_math == "bf16x3" else
+                         "stage-2 / stage-3 3x3 convs: two bf16 planes per operand rounded to nearest, 3 bf16 MFMAs per K step; "
+                         "the other 3x3 convs: exact 3-way split; f32 accumulate" if args.cnn_math == "bf16x2" else "f32 MFMA")) if e2e else
                      "u16/i32 (f32 normalise, f64 background weights)",
             "data": "synthetic",
             "config": {
@@ -943,7 +945,8 @@ def main():
             key = 32 * 10000 + 32 * 10 + 1  # the stage-2 3x3 convolutions (32 -> 32 channels per group, stride 1)
             key3 = 64 * 10000 + 64 * 10 + 1  # the stage-3 ones: same FLOPs per sample, half the bytes
             if key in conv and conv[key][1] > 0:
-                bf3 = args.cnn_math == "bf16x3"
+                bf3 = args.cnn_math in ("bf16x3", "bf16x2")
+                products = 3 if args.cnn_math == "bf16x2" else BF16X3_PRODUCTS
                 area = (args.frame_size / 32.0) ** 2  # map area relative to the 160 x 160 maps of frame size 32
                 side = 5 * args.frame_size
                 # input + output (+ residual in 3 of the 5 launches of a shape per forward), float32 NHWC
@@ -959,7 +962,7 @@ def main():
                         spl = fl_ / n_ / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
                         ab = spl * bytes2 * byte_scale
                         tf_ = fl_ / (ms_ / 1e3) / 1e12
-                        return {"achieved": round(tf_, 2), "frac": round(tf_ / (MFMA_BF16_PEAK_TFLOPS / BF16X3_PRODUCTS), 4),
+                        return {"achieved": round(tf_, 2), "frac": round(tf_ / (MFMA_BF16_PEAK_TFLOPS / products), 4),
                                 "avg_launch_us": round(ms_ / n_ * 1e3, 2), "launches": n_,
                                 "algorithmic_flops_per_launch": fl_ / n_, "algorithmic_bytes_per_launch": ab,
                                 "traffic": pmc_traffic(pmc_key, spl * area),
@@ -970,7 +973,8 @@ def main():
                     algo_bytes = l2["algorithmic_bytes_per_launch"]
                     traffic = l2["traffic"]
                     what = ("conv_bf3w_kernel<false,false,1,1> (the 16x16x32 bf16 MFMA form of the split-operand kernel, one "
-                            "32-column slice per workgroup: the stage-2 3x3 convs, 64->64 ch at %dx%d, groups 2)" % (side, side))
+                            "32-column slice per workgroup: the stage-2 3x3 convs, 64->64 ch at %dx%d, groups 2)" % (side, side)
+                            ).replace("1,1>", "1,1,%d>" % (products // 3 + 1))  # (last parameter: bf16 planes per operand)
                 else:
                     n, ms, fl = conv[key]
                     samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
@@ -978,7 +982,7 @@ def main():
                     traffic = None
                     what = "conv_mfma_kernel<8,1,1,3,2,16> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)" % (side, side)
                 tf = fl / (ms / 1e3) / 1e12
-                peak = round(MFMA_BF16_PEAK_TFLOPS / BF16X3_PRODUCTS, 1) if bf3 else MFMA_F32_PEAK_TFLOPS
+                peak = round(MFMA_BF16_PEAK_TFLOPS / products, 1) if bf3 else MFMA_F32_PEAK_TFLOPS
                 line["roofline"] = {"kernel": what,
                                     "bound": "mfma", "achieved": round(tf, 2), "peak": peak,
                                     "unit": "TFLOP/s", "frac": round(tf / peak, 4),
@@ -987,7 +991,7 @@ def main():
                                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
                                     "algorithmic_flops_per_launch": fl / n,
                                     "algorithmic_bytes_per_launch": algo_bytes,
-                                    "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products per float32 multiply-add"
+                                    "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / %d products per float32 multiply-add" % products
                                                   if bf3 else "dense fp32-input MFMA peak"),
                                     "hbm_GBps_algorithmic": round(algo_bytes / (ms / n / 1e3) / 1e9, 1),
                                     "hbm_frac": round(algo_bytes / (ms / n / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -995,8 +999,9 @@ def main():
                 if bf3 and key3 in conv:
                     nb, msb, flb = conv[key][0] + conv[key3][0], conv[key][1] + conv[key3][1], conv[key][2] + conv[key3][2]
                     line["roofline"]["second_instantiation"] = dict(
-                        {"kernel": "conv_bf3w_kernel<false,true,2,1> (both 32-column slices of a group from one staged patch: the "
-                                   "stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)" % (side // 2, side // 2)}, **l3)
+                        {"kernel": ("conv_bf3w_kernel<false,true,2,1> (both 32-column slices of a group from one staged patch: the "
+                                    "stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)" % (side // 2, side // 2)
+                                    ).replace("2,1>", "2,1,%d>" % (products // 3 + 1))}, **l3)
                     line["roofline"]["both_instantiations"] = {
                         "what": "all conv_bf3w_kernel launches of the step (the accounting of rounds 2-3, one instantiation then)",
                         "achieved": round(flb / (msb / 1e3) / 1e12, 2), "frac": round(flb / (msb / 1e3) / 1e12 / peak, 4),
@@ -1022,6 +1027,50 @@ def main():
             # (a) the reference's DEFAULT tracking configuration (denoise = true: NLM between normalise and blur,
             #     SURVEY F7), track stage over a slice of the resident clips
             # (b) frame size 64 (BASELINE north_star's 64 x 64 crops): end to end over a slice
+            # (c) the opt-in math mode CPX_CNN_MATH_BF16X2 over the headline's own step: stages 2-3 with two bf16 planes
+            #     per operand rounded to nearest and three products per K step (include/cpx.h) -- its rate, and how far
+            #     its logits are from the default mode's on the step's own classified segments
+            if args.cnn_math == "bf16x3" and not overlap:
+                ref = state["res"]
+                ref_logits, ref_probs = ref.logits.clone(), ref.probs.clone()
+                eng.set_cnn_math("bf16x2")
+                pipe.run(frames, offs, meta, outputs=outputs)                  # warm-up
+                eng.conv_timing(True)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                r2 = pipe.run(frames, offs, meta, outputs=outputs)
+                torch.cuda.synchronize(device)
+                dt2 = time.perf_counter() - t1
+                c2 = eng.conv_timing()
+                eng.conv_timing(False)
+                eng.set_cnn_math("bf16x3")
+                k2, k3 = 32 * 10000 + 32 * 10 + 1, 64 * 10000 + 64 * 10 + 1
+                leg = {"what": "the same step with CPX_CNN_MATH=bf16x2 (opt-in): the stride-1 3x3 layers with 32 / 64 channels "
+                               "per group (stages 2-3) multiply two bf16 planes per operand, rounded to nearest (<= 2^-16 "
+                               "relative per operand), in three products per K step instead of six; every other layer as "
+                               "the default", "frames_per_s": round(B * T / dt2, 1), "ms_per_step": round(dt2 * 1e3, 2),
+                       "classified_segments": int(r2.n_samples),
+                       "conv_time_ms_per_step": round(sum(v[1] for v in c2.values()), 2),
+                       "samples_per_s": round(int(r2.n_samples) / (sum(v[1] for v in c2.values()) / 1e3), 1),
+                       "max_abs_logit_difference_to_default": float((r2.logits - ref_logits).abs().max()),
+                       "max_abs_probability_difference_to_default": float((r2.probs - ref_probs).abs().max()),
+                       "max_abs_logit": float(ref_logits.abs().max()),
+                       "tracks": int(ref.best.numel())}
+                # tracks whose best label changed, and how close their two best scores were in the default mode (seeded
+                # random weights: near-ties exist; a real model's margins are what its accuracy rests on)
+                moved = (r2.best != ref.best).nonzero().flatten()
+                leg["tracks_with_another_best_label"] = int(moved.numel())
+                if moved.numel():
+                    top2 = ref.scores[moved].float().topk(2, dim=1).values
+                    leg["largest_score_margin_among_them"] = float((top2[:, 0] - top2[:, 1]).max())
+                for name, k in (("stage2", k2), ("stage3", k3)):
+                    if k in c2 and c2[k][1] > 0:
+                        tfe = c2[k][2] / (c2[k][1] / 1e3) / 1e12
+                        leg[name] = {"float32_equivalent_tflops": round(tfe, 2),
+                                     "frac_of_three_product_peak": round(tfe / (MFMA_BF16_PEAK_TFLOPS / 3), 4),
+                                     "avg_launch_us": round(c2[k][1] / c2[k][0] * 1e3, 2)}
+                line["bf16x2"] = leg
+                del ref_logits, ref_probs, r2
             net.close()
             nb = min(B, 512)
             o2 = offs[: nb + 1]

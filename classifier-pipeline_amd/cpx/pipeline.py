@@ -132,6 +132,7 @@ class BatchPipeline:
             C.c_void_p(reqs.data_ptr()), n_tracks, self.n_labels, self.fp_index, self.sq,
             C.c_void_p(out.scores.data_ptr()), C.c_void_p(out.best.data_ptr())))
         out.probs = probs
+        out.logits = logits
         eng.synchronize()  # results are complete when run() returns (callers read them from any stream)
         if two_streams:
             self.net.eng.synchronize()

@@ -693,7 +693,8 @@ constexpr int KW = 32;
 constexpr int W_TW = 16, W_TH = 16, W_PW = 18, W_NPX = 18 * 18;
 constexpr int W_NPXP = 326;  // pixels per (plane, quarter pair) region: 326 * 32 B = 64 mod 128, the two regions' ds_write_b64 lanes then use different banks
 constexpr int w_patch_entries(int planes) { return planes * 2 * W_NPXP * 2; }
-constexpr int w_wsub_entries(int planes) { return planes * 3 * 4 * 32; }  // a weight sub-chunk (one kernel row)
+constexpr int w_rows_resident(int planes) { return planes == 2 ? 3 : 1; }
+constexpr int w_wsub_entries(int planes) { return w_rows_resident(planes) * planes * 3 * 4 * 32; }  // a weight sub-chunk
 // WALK: the workgroup walks a run of td.run tiles along x (else exactly one tile: the loop and the per-use
 // laundering of the staging bases fold away); LDSBN: BatchNorm scale / shift read back from LDS at each patch commit
 // instead of living in eight registers; NH: 32-column slices of the group's output channels the workgroup computes from
@@ -709,13 +710,18 @@ template <bool WALK, bool LDSBN, int NH, int NG, int PL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf3w_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   static_assert(NG == 1 || (!WALK && !LDSBN && NH == 1), "the group walk is built for the one-slice, one-tile form");
   static_assert(PL == 2 || PL == 3, "two or three bf16 planes per operand");
+  // WR: kernel rows of a chunk's weights resident in LDS at a time.  Three planes: one (patch + one row = 79 KB, two
+  // workgroups per CU).  Two planes leave room for all three (41 + 36 KB): one weight commit and two barriers per chunk
+  // and column slice instead of three and six.
+  constexpr int WR = w_rows_resident(PL);
   constexpr int W_PATCH = PL * 2 * W_NPXP * 2;  // entries
-  constexpr int W_WSUB = PL * 3 * 4 * 32;       // entries of a weight sub-chunk (one kernel row)
+  constexpr int W_WROW = PL * 3 * 4 * 32;       // entries of one kernel row's weights (32 columns)
+  constexpr int W_WSUB = WR * W_WROW;           // entries of a weight sub-chunk
   constexpr int CT = 512;
   // per-thread staging / output indices are re-derived from the thread index at each use (WALK: they would be carried
   // across the tile loop; NH > 1: sixteen more accumulator registers leave no room to keep them across the products --
   // kept, the compiler spills eight of them to scratch per tile: +22 % HBM traffic on the stage-3 launches, measured)
-  constexpr bool LAUNDER = WALK || NH > 1 || NG > 1;
+  constexpr bool LAUNDER = WALK || NH > 1 || NG > 1 || PL == 2;  // (PL == 2: twenty prefetch registers for the three weight rows)
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   uint4* s_patch = lds4;
   uint4* s_w = lds4 + W_PATCH;
@@ -922,18 +928,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int gi = (NG > 1 && cc >= nch) ? 1 : 0;  // (NG <= 2)
   const int c = cc - gi * nch, g = g0 + gi;
   {
+    // phases of a chunk: (kernel row, column slice) with one row resident, (column slice) with all three
+    constexpr int NPH = (3 / WR) * NH;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-    for (int hf = 0; hf < NH; ++hf) {
-      if (cc > 0 || r > 0 || hf > 0 || txi > txr * run) __syncthreads();  // every wave has read the previous phase's fragments
+    for (int ph = 0; ph < NPH; ++ph) {
+    {
+      const int r0 = WR == 3 ? 0 : ph / NH, hf = WR == 3 ? ph : ph % NH;
+      if (cc > 0 || ph > 0 || txi > txr * run) __syncthreads();  // every wave has read the previous phase's fragments
       // ---- registers -> LDS: the kernel row's weights (a straight copy) ----
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = tid + i * CT;
         if (item < W_WSUB) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
       }
-      if (r == 0 && hf == 0) {
+      if (ph == 0) {
         // ---- the chunk's patch: BatchNorm + ReLU prologue, padding zeroed, split into bf16 planes ----
         {
           f32x4 psc = psc_r, psh = psh_r;
@@ -1000,16 +1008,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       // ---- global -> registers for what comes next (in flight under this phase's products) ----
       // (the chunk after this one: the same group's next 32 channels, or the next group's first)
       const int gn = (c + 1 < nch) ? g : g + 1, cn = (c + 1 < nch) ? c + 1 : 0;
-      if (hf + 1 < NH) {
-        BF3W_ISSUE_W(g, c, r, hf + 1)
-      } else if (r < 2) {
-        BF3W_ISSUE_W(g, c, r + 1, 0)
+      if (ph + 1 < NPH) {
+        BF3W_ISSUE_W(g, c, (WR == 3 ? 0 : (ph + 1) / NH), (WR == 3 ? ph + 1 : (ph + 1) % NH))
       } else if (cc + 1 < NG * nch) {
         BF3W_ISSUE_W(gn, cn, 0, 0)
       } else if (txi + 1 < tx_end) {
         BF3W_ISSUE_W(g0, 0, 0, 0)
       }
-      if (r == 0 && hf == 0) {
+      if (ph == 0) {
         if (cc + 1 < NG * nch) {
           BF3W_ISSUE_P(gn, cn, ix0)
         } else if (txi + 1 < tx_end) {
@@ -1017,6 +1023,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
       }
       __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < WR; ++rr) {
+      const int r = r0 + rr;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         bf16x8 xv[2][PL], wv[2][PL];
@@ -1026,7 +1035,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           for (int pt = 0; pt < 2; ++pt)
             xv[pt][p] = __builtin_bit_cast(bf16x8, s_patch[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(bf16x8, s_w[(p * 3 + kx) * 128 + b_base + 16 * ct]);
+          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(bf16x8, s_w[rr * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -1043,8 +1052,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
           }
       }
-    }  // column slices
+      }  // resident kernel rows
     }
+    }  // phases of the chunk
   }
   if (NG > 1 && c + 1 == nch && cc + 1 < NG * nch) {  // a group but the last is done: its stores, the next one's accumulators
     finish(g);
@@ -1192,7 +1202,7 @@ static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = (size_t)(w_patch_entries(PL) + w_wsub_entries(PL)) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
   static bool lds_ready[64];
   // (NH = 2 carries 16 more accumulator registers: the BatchNorm parameters go to LDS there)
-  constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0 || NH > 1;
+  constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0 || NH > 1 || PL == 2;
   if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   const int tx = (a.Wo + W_TW - 1) / W_TW;
