@@ -407,7 +407,9 @@ class TrackEngine:
 
     def set_cnn_math(self, mode):
         """"f32": v_mfma_f32_32x32x2_f32; "bf16x3" (default): exact three-way bf16 split of the float32 operands on
-        the bf16 matrix pipe (include/cpx.h: cpx_set_cnn_math).  Same inputs, outputs and tolerance."""
+        the bf16 matrix pipe; "bf16x2" (opt-in): stages 2-3 on two rounded bf16 planes and three products -- not
+        float32 per element (<= 3 x 2^-16), logits within the same bound (include/cpx.h: cpx_set_cnn_math).  Same
+        inputs, outputs and logit tolerance."""
         rc = self.lib.cpx_set_cnn_math(self.h, self.CNN_MATH[mode])
         if rc != 0:
             raise CpxError(rc, self._err())
