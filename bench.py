@@ -922,7 +922,7 @@ def main():
             "dtype": ("u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)"
                       % ("3x3 convs: exact 3-way bf16 operand split, 6 bf16 MFMAs per K step, f32 accumulate"
                          if args.cnn_math == "bf16x3" else
-                         "stage-2 / stage-3 3x3 convs: two bf16 planes per operand rounded to nearest, 3 bf16 MFMAs per K step; "
+                         "stride-1 3x3 convs of stages 2-4: two bf16 planes per operand rounded to nearest, 3 bf16 MFMAs per K step; "
                          "the other 3x3 convs: exact 3-way split; f32 accumulate" if args.cnn_math == "bf16x2" else "f32 MFMA")) if e2e else
                      "u16/i32 (f32 normalise, f64 background weights)",
             "data": "synthetic",
@@ -1027,7 +1027,7 @@ def main():
             # (a) the reference's DEFAULT tracking configuration (denoise = true: NLM between normalise and blur,
             #     SURVEY F7), track stage over a slice of the resident clips
             # (b) frame size 64 (BASELINE north_star's 64 x 64 crops): end to end over a slice
-            # (c) the opt-in math mode CPX_CNN_MATH_BF16X2 over the headline's own step: stages 2-3 with two bf16 planes
+            # (c) the opt-in math mode CPX_CNN_MATH_BF16X2 over the headline's own step: stages 2-4 with two bf16 planes
             #     per operand rounded to nearest and three products per K step (include/cpx.h) -- its rate, and how far
             #     its logits are from the default mode's on the step's own classified segments
             if args.cnn_math == "bf16x3" and not overlap:
@@ -1045,10 +1045,9 @@ def main():
                 eng.conv_timing(False)
                 eng.set_cnn_math("bf16x3")
                 k2, k3 = 32 * 10000 + 32 * 10 + 1, 64 * 10000 + 64 * 10 + 1
-                leg = {"what": "the same step with CPX_CNN_MATH=bf16x2 (opt-in): the stride-1 3x3 layers with 32 / 64 channels "
-                               "per group (stages 2-3) multiply two bf16 planes per operand, rounded to nearest (<= 2^-16 "
-                               "relative per operand), in three products per K step instead of six; every other layer as "
-                               "the default", "frames_per_s": round(B * T / dt2, 1), "ms_per_step": round(dt2 * 1e3, 2),
+                leg = {"what": "the same step with CPX_CNN_MATH=bf16x2 (opt-in): the stride-1 3x3 layers of stages 2-4 multiply two "
+                               "bf16 planes per operand, rounded to nearest (<= 2^-16 relative per operand), in three "
+                               "products per K step instead of six; every other layer as the default", "frames_per_s": round(B * T / dt2, 1), "ms_per_step": round(dt2 * 1e3, 2),
                        "classified_segments": int(r2.n_samples),
                        "conv_time_ms_per_step": round(sum(v[1] for v in c2.values()), 2),
                        "samples_per_s": round(int(r2.n_samples) / (sum(v[1] for v in c2.values()) / 1e3), 1),
@@ -1063,7 +1062,7 @@ def main():
                 if moved.numel():
                     top2 = ref.scores[moved].float().topk(2, dim=1).values
                     leg["largest_score_margin_among_them"] = float((top2[:, 0] - top2[:, 1]).max())
-                for name, k in (("stage2", k2), ("stage3", k3)):
+                for name, k in (("stage2", k2), ("stage3", k3), ("stage4", 128 * 10000 + 128 * 10 + 1)):
                     if k in c2 and c2[k][1] > 0:
                         tfe = c2[k][2] / (c2[k][1] / 1e3) / 1e12
                         leg[name] = {"float32_equivalent_tflops": round(tfe, 2),

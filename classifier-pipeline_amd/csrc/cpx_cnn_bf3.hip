@@ -435,13 +435,14 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
 // 81 %; here a workgroup takes 128 CONSECUTIVE output positions of a sample in row-major order (729 = 5.7 bands:
 // 95 %), stages the input rows they touch at full width, and every lane derives its pixel from its position.  Same
 // staging format, MFMA loop and epilogue as conv_bf3_kernel; the output offset of a position is simply p * Cout.
-template <int NTN, int NPXC>
+// PL: bf16 planes per operand (3: the exact split, six products; 2: CPX_CNN_MATH_BF16X2, three -- see conv_bf3w_kernel)
+template <int NTN, int NPXC, int PL>
 __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3, CT = 256;
   constexpr int COGW = 32 * NTN;
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  uint4* s_patch = lds4;             // [3][2][NPXC]
-  uint4* s_w = lds4 + 6 * NPXC;      // [3][9][2][COGW]
+  uint4* s_patch = lds4;                 // [PL][2][NPXC]
+  uint4* s_w = lds4 + 2 * PL * NPXC;     // [PL][9][2][COGW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   const int iy0 = y_first - a.pad_top, ix0 = -a.pad_left;
   const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
   const int nchunks = cin_g / KC;
-  const uint4* wg = wimg + (size_t)g * nchunks * 54 * cout_g + (size_t)ns * COGW;
+  const uint4* wg = wimg + (size_t)g * nchunks * (18 * PL) * cout_g + (size_t)ns * COGW;
 
   const bool res_in_acc = a.residual != nullptr && a.out_scale == nullptr;  // see conv_bf3_kernel
   f32x16 acc[NTN];
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   const int b_base = kh * COGW + (lane & 31);
 
   constexpr int NP = (2 * NPXC + CT - 1) / CT;
-  constexpr int NW = 54 * COGW;
+  constexpr int NW = 18 * PL * COGW;
   constexpr int NWI = (NW + CT - 1) / CT;
   const int my_h = tid & 1;
   int item_py[NP], item_px[NP], item_e[NP];
@@ -523,11 +524,14 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
         unsigned q0[4], q1[4], q2[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], q0[j], q1[j], q2[j]);
+        for (int j = 0; j < 4; ++j) {
+          if (PL == 3) split_pair(v[2 * j], v[2 * j + 1], q0[j], q1[j], q2[j]);
+          else split_pair2(v[2 * j], v[2 * j + 1], q0[j], q1[j]);
+        }
         u32x4* sp4 = reinterpret_cast<u32x4*>(s_patch);
         sp4[0 * 2 * NPXC + item_e[i]] = u32x4{q0[0], q0[1], q0[2], q0[3]};
         sp4[1 * 2 * NPXC + item_e[i]] = u32x4{q1[0], q1[1], q1[2], q1[3]};
-        sp4[2 * 2 * NPXC + item_e[i]] = u32x4{q2[0], q2[1], q2[2], q2[3]};
+        if (PL == 3) sp4[2 * 2 * NPXC + item_e[i]] = u32x4{q2[0], q2[1], q2[2], q2[3]};
       }
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         pre_p[i][0] = *reinterpret_cast<const f32x4*>(at_off(in_n, soff));
         pre_p[i][1] = *reinterpret_cast<const f32x4*>(at_off(in_n, soff + 16));
       }
-      const u32x4* wc = reinterpret_cast<const u32x4*>(wg + (size_t)(cc + 1) * 54 * cout_g);
+      const u32x4* wc = reinterpret_cast<const u32x4*>(wg + (size_t)(cc + 1) * (18 * PL) * cout_g);
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, NW - 1);
@@ -571,9 +575,9 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
 #pragma unroll
       for (int tap = 0; tap < KS * KS; ++tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
-        bf16x8 av[3], bv[NTN][3];
+        bf16x8 av[PL], bv[NTN][PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < PL; ++p) {
           av[p] = __builtin_bit_cast(bf16x8, s_patch[p * 2 * NPXC + a_base + ky * PW + kx]);
 #pragma unroll
           for (int t = 0; t < NTN; ++t)
@@ -581,9 +585,11 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         }
 #pragma unroll
         for (int t = 0; t < NTN; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[t][1], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][2], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[t][0], acc[t], 0, 0, 0);
+          if (PL == 3) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[t][1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][PL - 1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PL - 1], bv[t][0], acc[t], 0, 0, 0);
+          }
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][1], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[t][0], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][0], acc[t], 0, 0, 0);
@@ -1067,11 +1073,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef BF3W_ISSUE_W
 #undef BF3W_ISSUE_P
 
-template <int NTN, int NPXC>
+template <int NTN, int NPXC, int PL>
 int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
-  const size_t lds = ((size_t)6 * NPXC + (size_t)54 * 32 * NTN) * 16;
+  const size_t lds = ((size_t)2 * PL * NPXC + (size_t)18 * PL * 32 * NTN) * 16;
   static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Ho * a.Wo + 127) / 128;
   td.tiles_y = 1;
@@ -1081,7 +1087,7 @@ int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) + 1;
-  hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC>), dim3((unsigned)blocks, a.groups), dim3(256), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL>), dim3((unsigned)blocks, a.groups), dim3(256), lds, s, a, wimg, td);
   return 0;
 }
 // the flattened tiling applies to stride-1 SAME 3 x 3 layers whose staged rows fit the LDS cap and pays when the
@@ -1125,8 +1131,9 @@ __global__ __launch_bounds__(256) void split_weights8_kernel(const float* __rest
   }
 }
 
+// planes = 2 (CPX_CNN_MATH_BF16X2): [g][chunk][2][9][2][cout_g], hi / lo rounded to nearest
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
-                                                            int cin_g, int cout_g) {
+                                                            int cin_g, int cout_g, int planes) {
   const int nchunks = cin_g / KC;
   const size_t total = (size_t)groups * nchunks * 9 * 2 * cout_g;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1144,14 +1151,21 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     for (int j = 0; j < 8; ++j)
       v[j] = w[(((size_t)g * 9 + tap) * cin_g + chunk * KC + 8 * h + j) * cout_g + col];
     uint4 p0, p1, p2;
-    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
-    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
-    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
-    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
-    const size_t base = ((size_t)g * nchunks + chunk) * 54 * cout_g;
+    if (planes == 3) {
+      split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+      split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+      split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+      split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+    } else {
+      split_pair2(v[0], v[1], p0.x, p1.x);
+      split_pair2(v[2], v[3], p0.y, p1.y);
+      split_pair2(v[4], v[5], p0.z, p1.z);
+      split_pair2(v[6], v[7], p0.w, p1.w);
+    }
+    const size_t base = ((size_t)g * nchunks + chunk) * (18 * planes) * cout_g;
     out[base + ((size_t)(0 * 9 + tap) * 2 + h) * cout_g + col] = p0;
     out[base + ((size_t)(1 * 9 + tap) * 2 + h) * cout_g + col] = p1;
-    out[base + ((size_t)(2 * 9 + tap) * 2 + h) * cout_g + col] = p2;
+    if (planes == 3) out[base + ((size_t)(2 * 9 + tap) * 2 + h) * cout_g + col] = p2;
   }
 }
 
@@ -1339,12 +1353,20 @@ bool conv_bf3_supported(const ConvArgs& a) {
   if (bf3_strided(a)) return true;
   return a.ksize == 3 && a.stride == 1 && cin_g >= KC && (cin_g % KC) == 0 && (cout_g == 32 || cout_g == 64 || cout_g == 128);
 }
+// three-plane image of the layers conv_bf3_kernel / conv_bf3flat_kernel take: [g][chunk of 16][3][9][2][cout_g]
+static size_t image3_bytes(const ConvArgs& a) { return (size_t)a.groups * (a.Cin / a.groups / KC) * 54 * (a.Cout / a.groups) * 16; }
+// stride-1 layers with 128 columns per group (stage 4): the flattened kernel takes them when the map is small
+// (flat_pays, a property of the launch), in either math mode
+static bool flat_layer(const ConvArgs& a) {
+  const int cin_g = a.Cin / a.groups;
+  return !bf3_c8(a) && !bf3w_layer(a) && a.ksize == 3 && a.stride == 1 && a.Cout / a.groups == 128 && cin_g >= KC && (cin_g % KC) == 0;
+}
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
   if (bf3_c8(a)) return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16;
   if (bf3w_layer(a)) return bf3w_image3_bytes(a) + bf3w_image2_bytes(a);  // both math modes' images, one after the other
-  return (size_t)a.groups * (a.Cin / a.groups / KC) * 54 * (a.Cout / a.groups) * 16;
+  return image3_bytes(a) + (flat_layer(a) ? image3_bytes(a) / 3 * 2 : 0);
 }
-bool conv_bf3_two_planes(const ConvArgs& a) { return bf3w_layer(a); }
+bool conv_bf3_two_planes(const ConvArgs& a) { return bf3w_layer(a) || flat_layer(a); }
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   if (bf3_c8(a)) {
@@ -1363,7 +1385,10 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   }
   const size_t total = (size_t)a.groups * (cin_g / KC) * 18 * cout_g;
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
-                     reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g);
+                     reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g, 3);
+  if (flat_layer(a))  // the two-plane image of the layers the flattened kernel may take, behind the three-plane one
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg) + image3_bytes(a) / 16, a.groups, cin_g, cout_g, 2);
 }
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   const int cout_g = a.Cout / a.groups;
@@ -1383,7 +1408,10 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   // 256 staged pixels + two N tiles = 80 KB: two workgroups per CU.  (Wider maps -- 54 x 54 at frame size 64 -- would
   // need 384 staged pixels and then fit only one N tile per workgroup: measured slower than the rectangular bands,
   // 399 vs 371 ms, the patch being activated and split by four column slices instead of two.)
-  if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256)) return launch_bf3flat_t<2, 256>(a, w, s);
+  if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256)) {
+    if (a.planes == 2 && flat_layer(a)) return launch_bf3flat_t<2, 256, 2>(a, w + image3_bytes(a) / 16, s);
+    return launch_bf3flat_t<2, 256, 3>(a, w, s);
+  }
   if (cout_g == 128) return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
   return -2;
 }
