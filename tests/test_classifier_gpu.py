@@ -75,6 +75,41 @@ def test_process_file_track_and_classify(tmp_path, model_dir, name):
         assert pm["tag"] == LABELS[int(np.argmax(score))]
 
 
+def test_process_file_same_metadata_in_the_two_plane_math_mode(tmp_path, model_dir):
+    """CPX_CNN_MATH=bf16x2 (opt-in, include/cpx.h: the stride-1 3x3 layers of stages 2-4 on two rounded bf16 planes and
+    three products) is read when an engine is created; here the cached engines are switched directly.  Same tags, the
+    confidences of the metadata (three decimals) within one unit of their last place."""
+    from cpx.classify.clipclassifier import ClipClassifier
+    from cpx.track import cliptrackextractor as cte
+
+    mdir, _ = model_dir
+    metas = {}
+    try:
+        for mode in ("bf16x3", "bf16x2"):
+            src = tmp_path / ("possum_%s.cptv" % mode)
+            shutil.copy(os.path.join(GOLDEN, "possum.cptv"), src)
+            cc = ClipClassifier(_config(mdir))
+            cc.process_file(str(src), track=True)        # (creates / finds the engines of this recording's geometry)
+            assert cte._ENGINES
+            for eng in cte._ENGINES.values():
+                eng.set_cnn_math(mode)
+            os.remove(src.with_suffix(".txt"))
+            metas[mode] = cc.process_file(str(src), track=True)
+            assert all(eng.get_cnn_math() == mode for eng in cte._ENGINES.values())
+    finally:
+        for eng in cte._ENGINES.values():
+            eng.set_cnn_math("bf16x3")
+    a, b = metas["bf16x3"], metas["bf16x2"]
+    assert len(a["tracks"]) == len(b["tracks"]) > 0
+    worst = 0.0
+    for ta, tb in zip(a["tracks"], b["tracks"]):
+        (pa,), (pb,) = ta["predictions"], tb["predictions"]
+        assert pa["tag"] == pb["tag"] and pa["confident"] == pb["confident"]
+        for l in LABELS:
+            worst = max(worst, abs(pa["all_class_confidences"][l] - pb["all_class_confidences"][l]))
+    assert worst <= 1e-3, worst
+
+
 def test_classify_track_inputs_equal_reference(tmp_path, model_dir):
     """Interpreter.classify_track with the reference's segment frames: the tensor handed to predict()
     is bit-identical to what the reference's own Interpreter built."""
