@@ -99,7 +99,8 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
 // C8: the layer with 8 input channels per group (one 16-byte k half per pixel).  A K = 16 step then pairs two TAPS
 // instead of two channel halves: lanes 0-31 (k half 0) read tap 2 s, lanes 32-63 tap 2 s + 1 of the same 8-channel
 // entry array -- five steps for the nine taps (the tenth tap has zero weights) instead of nine half-empty ones.
-template <int NTN, int S, int NB, int TW, int CT, bool C8>
+// PL: bf16 planes per operand (3: the exact split; 2: CPX_CNN_MATH_BF16X2 -- see conv_bf3w_kernel; not with C8)
+template <int NTN, int S, int NB, int TW, int CT, bool C8, int PL = 3>
 // (the strided forms fill the LDS with one workgroup: their waves may use the registers of the absent second one)
 __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128), S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128)))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3;
@@ -116,8 +117,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   constexpr int QPP = C8 ? 2 : 4;     // 16-byte pieces of float32 input per patch pixel and chunk
   constexpr int NSTEP = C8 ? 5 : 9;   // K = 16 steps per chunk
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-  uint4* s_patch = lds4;                // [3][KH][NPX]
-  uint4* s_w = lds4 + 3 * KH * NPX;     // [3][NSTEP][2][COGW]
+  static_assert(PL == 3 || (PL == 2 && !C8), "two planes: not for the tap-paired 8-channel form");
+  uint4* s_patch = lds4;                // [PL][KH][NPX]
+  uint4* s_w = lds4 + PL * KH * NPX;    // [PL][NSTEP][2][COGW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wset = tid >> 8;
   int bid = blockIdx.x;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   const float* in_n = a.in + (size_t)n * a.H * a.W * a.Cin + (size_t)g * cin_g;
   const int nchunks = C8 ? 1 : cin_g / KC;
   // weight image: [g][chunk][3][NSTEP][2][cout_g] entries
-  const uint4* wg = wimg + (size_t)g * nchunks * (6 * NSTEP) * cout_g + (size_t)ns * COGW;
+  const uint4* wg = wimg + (size_t)g * nchunks * (2 * PL * NSTEP) * cout_g + (size_t)ns * COGW;
   // a tile whose patch lies inside the image needs no padding tests (uniform)
   const bool interior = iy0 >= 0 && iy0 + PH <= a.H && ix0 >= 0 && ix0 + PW <= a.W;
   // a tile whose OUTPUT lies inside the map needs no clamps / bounds tests in the residual preload and the stores, and
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   // happen here; a piece fills the low or high 8 bytes of an LDS entry.
   constexpr int NITEM = NPX * QPP;
   constexpr int NP = (NITEM + CT - 1) / CT;
-  constexpr int NW = 6 * NSTEP * COGW;        // uint4 entries of a weight chunk
+  constexpr int NW = 2 * PL * NSTEP * COGW;   // uint4 entries of a weight chunk
   constexpr int NWI = (NW + CT - 1) / CT;
   const int my_q = tid & (QPP - 1);           // float32 input: CT is a multiple of 4, so a thread keeps its piece
   u32x4 pre_p[NP];
@@ -236,14 +238,19 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
               for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
             }
             unsigned q0[2], q1[2], q2[2];
-            split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
-            split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
+            if (PL == 3) {
+              split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
+              split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
+            } else {
+              split_pair2(v[0], v[1], q0[0], q1[0]);
+              split_pair2(v[2], v[3], q0[1], q1[1]);
+            }
             // channels 4 q .. 4 q + 3 of the chunk: entry of k half q >> 1, its low or high 8 bytes
             uint2* sp2 = reinterpret_cast<uint2*>(s_patch);
             const int e2 = ((my_q >> 1) * NPX + px) * 2 + (my_q & 1);
             sp2[(0 * KH * NPX) * 2 + e2] = make_uint2(q0[0], q0[1]);
             sp2[(1 * KH * NPX) * 2 + e2] = make_uint2(q1[0], q1[1]);
-            sp2[(2 * KH * NPX) * 2 + e2] = make_uint2(q2[0], q2[1]);
+            if (PL == 3) sp2[(2 * KH * NPX) * 2 + e2] = make_uint2(q2[0], q2[1]);
           }
         }
       }
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
         const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
         pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, a.Cin) + (unsigned)(cn + 4 * my_q)) << 2));
       }
-      const uint4* wc = wg + (size_t)(cc + 1) * (6 * NSTEP) * cout_g;
+      const uint4* wc = wg + (size_t)(cc + 1) * (2 * PL * NSTEP) * cout_g;
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int item = min(tid + i * CT, NW - 1);
@@ -303,9 +310,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
           const int ky = st / KS, kx = st - ky * KS;
           koff = ky * PW + kx;
         }
-        bf16x8 av[NTM][3], bv[NTN][3];
+        bf16x8 av[NTM][PL], bv[NTN][PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < PL; ++p) {
 #pragma unroll
           for (int m = 0; m < NTM; ++m)
             av[m][p] = __builtin_bit_cast(bf16x8, s_patch[p * KH * NPX + a_base + m * (WSETS * TB * S * PW) + koff]);
@@ -318,9 +325,11 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
 #pragma unroll
           for (int t = 0; t < NTN; ++t) {
             // smallest terms first: x1*y1, x0*y2, x2*y0, x0*y1, x1*y0, x0*y0
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][1], acc[m][t], 0, 0, 0);
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][2], acc[m][t], 0, 0, 0);
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][2], bv[t][0], acc[m][t], 0, 0, 0);
+            if (PL == 3) {
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][1], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][PL - 1], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][PL - 1], bv[t][0], acc[m][t], 0, 0, 0);
+            }
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][1], acc[m][t], 0, 0, 0);
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][0], acc[m][t], 0, 0, 0);
             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][0], acc[m][t], 0, 0, 0);
@@ -1258,14 +1267,14 @@ static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   return launch_bf3w_t<1, 1, 3>(a, wimg, s);
 }
 
-template <int NTN, int S, int NB, int TW, int CT, bool C8 = false>
+template <int NTN, int S, int NB, int TW, int CT, bool C8 = false, int PL = 3>
 int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int TB = 128 / TW, TH = TB * NB;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-  size_t lds = ((size_t)(C8 ? 3 : 6) * PH * PW + (size_t)(C8 ? 30 : 54) * 32 * NTN) * 16;
+  size_t lds = ((size_t)(C8 ? 3 : 2 * PL) * PH * PW + (size_t)(C8 ? 30 : 18 * PL) * 32 * NTN) * 16;
   if (lds < (CT / 64) * 32 * 32 * sizeof(float)) lds = (CT / 64) * 32 * 32 * sizeof(float);
   static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT, C8>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Wo + TW - 1) / TW;
   td.tiles_y = (a.Ho + TH - 1) / TH;
@@ -1275,7 +1284,7 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT, C8>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
   return 0;
 }
 
@@ -1359,7 +1368,9 @@ static size_t image3_bytes(const ConvArgs& a) { return (size_t)a.groups * (a.Cin
 // (flat_pays, a property of the launch), in either math mode
 static bool flat_layer(const ConvArgs& a) {
   const int cin_g = a.Cin / a.groups;
-  return !bf3_c8(a) && !bf3w_layer(a) && a.ksize == 3 && a.stride == 1 && a.Cout / a.groups == 128 && cin_g >= KC && (cin_g % KC) == 0;
+  if (bf3_c8(a) || bf3w_layer(a) || a.ksize != 3 || cin_g < KC || (cin_g % KC) != 0) return false;
+  // ... and the stride-2 first convolution of stage 3 (conv_bf3_kernel<2,2,2,16,512>)
+  return (a.stride == 1 && a.Cout / a.groups == 128) || (a.stride == 2 && bf3_strided(a));
 }
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
   if (bf3_c8(a)) return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16;
@@ -1396,7 +1407,11 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   if ((long long)a.H * a.W >= (1 << 24) || (long long)a.Ho * a.Wo >= (1 << 24) || a.Cin >= (1 << 24) || a.Cout >= (1 << 24)) return -3;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
   if (bf3_c8(a)) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2, true>(a, w, s);
-  if (a.stride == 2) return bf3_strided(a) ? launch_bf3_t<2, 2, 2, 16, 512>(a, w, s) : -2;
+  if (a.stride == 2) {
+    if (!bf3_strided(a)) return -2;
+    if (a.planes == 2 && flat_layer(a)) return launch_bf3_t<2, 2, 2, 16, 512, false, 2>(a, w + image3_bytes(a) / 16, s);
+    return launch_bf3_t<2, 2, 2, 16, 512>(a, w, s);
+  }
   if (a.stride == 3) return bf3_strided(a) ? launch_bf3_t<CPX_BF3_NTN_ST3, 3, 1, 16, 256>(a, w, s) : -2;
   if (a.stride != 1) return -2;
   if (bf3w_layer(a)) {

@@ -75,39 +75,39 @@ def test_process_file_track_and_classify(tmp_path, model_dir, name):
         assert pm["tag"] == LABELS[int(np.argmax(score))]
 
 
-def test_process_file_same_metadata_in_the_two_plane_math_mode(tmp_path, model_dir):
-    """CPX_CNN_MATH=bf16x2 (opt-in, include/cpx.h: the stride-1 3x3 layers of stages 2-4 on two rounded bf16 planes and
-    three products) is read when an engine is created; here the cached engines are switched directly.  Same tags, the
-    confidences of the metadata (three decimals) within one unit of their last place."""
-    from cpx.classify.clipclassifier import ClipClassifier
+def test_classify_track_same_scores_in_the_two_plane_math_mode(tmp_path, model_dir):
+    """CPX_CNN_MATH=bf16x2 (opt-in, include/cpx.h: the stride-1 3x3 layers of stages 2-4 and the stride-2 one of stage 3
+    on two rounded bf16 planes and three products) is read when an engine is created; here the cached engines are
+    switched directly.  Same explicit segments (process_file draws them at random, as the reference does): the same
+    per-segment predictions and track scores to 1e-5."""
+    from cpx.ml_tools.interpreter import WRResNetInterpreter
     from cpx.track import cliptrackextractor as cte
+    from cpx.track.trackextractor import extract_file
 
     mdir, _ = model_dir
-    metas = {}
+    src = tmp_path / "hedgehog.cptv"
+    shutil.copy(os.path.join(GOLDEN, "hedgehog.cptv"), src)
+    clip, _, _ = extract_file(src, _config(mdir), False, save_meta=False)
+    z = np.load(os.path.join(GOLDEN, "hedgehog_classify_fs32.npz"))
+    interp = WRResNetInterpreter(mdir / "wr.npz")
+    interp.classify_track(clip, clip.tracks[0], segment_frames=z["t0_segments"])   # (creates / finds the engine)
+    got = {}
     try:
         for mode in ("bf16x3", "bf16x2"):
-            src = tmp_path / ("possum_%s.cptv" % mode)
-            shutil.copy(os.path.join(GOLDEN, "possum.cptv"), src)
-            cc = ClipClassifier(_config(mdir))
-            cc.process_file(str(src), track=True)        # (creates / finds the engines of this recording's geometry)
             assert cte._ENGINES
             for eng in cte._ENGINES.values():
                 eng.set_cnn_math(mode)
-            os.remove(src.with_suffix(".txt"))
-            metas[mode] = cc.process_file(str(src), track=True)
-            assert all(eng.get_cnn_math() == mode for eng in cte._ENGINES.values())
+            pred = interp.classify_track(clip, clip.tracks[0], segment_frames=z["t0_segments"])
+            got[mode] = (np.array(pred.class_best_score, dtype=np.float64),
+                         np.array([p.prediction for p in pred.predictions], dtype=np.float64))
     finally:
         for eng in cte._ENGINES.values():
             eng.set_cnn_math("bf16x3")
-    a, b = metas["bf16x3"], metas["bf16x2"]
-    assert len(a["tracks"]) == len(b["tracks"]) > 0
-    worst = 0.0
-    for ta, tb in zip(a["tracks"], b["tracks"]):
-        (pa,), (pb,) = ta["predictions"], tb["predictions"]
-        assert pa["tag"] == pb["tag"] and pa["confident"] == pb["confident"]
-        for l in LABELS:
-            worst = max(worst, abs(pa["all_class_confidences"][l] - pb["all_class_confidences"][l]))
-    assert worst <= 1e-3, worst
+    (sa, pa), (sb, pb) = got["bf16x3"], got["bf16x2"]
+    assert pa.shape == pb.shape and pa.size > 0
+    assert float(np.abs(pa - pb).max()) <= 1e-5, float(np.abs(pa - pb).max())
+    assert float(np.abs(sa - sb).max()) <= 1e-5
+    assert float(np.abs(pa - pb).max()) > 0.0  # (it IS the other arithmetic)
 
 
 def test_classify_track_inputs_equal_reference(tmp_path, model_dir):
