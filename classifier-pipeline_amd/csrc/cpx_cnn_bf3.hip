@@ -1427,7 +1427,11 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
     if (a.planes == 2 && flat_layer(a)) return launch_bf3flat_t<2, 256, 2>(a, w + image3_bytes(a) / 16, s);
     return launch_bf3flat_t<2, 256, 3>(a, w, s);
   }
-  if (cout_g == 128) return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
+  if (cout_g == 128) {
+    if (a.planes == 2 && flat_layer(a))
+      return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4, false, 2>(a, w + image3_bytes(a) / 16, s);
+    return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
+  }
   return -2;
 }
 

@@ -595,8 +595,8 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* desc);
  *   CPX_CNN_MATH_F32     v_mfma_f32_32x32x2_f32 on the operands as they are
  *   CPX_CNN_MATH_BF16X3  each operand split exactly into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K step
  *                        (the cross terms below 2^-26 of a product are dropped); default, 2.67x the MFMA rate
- *   CPX_CNN_MATH_BF16X2  the stride-1 layers with 32 / 64 / 128 channels per group (stages 2, 3 and -- on maps the
- *                        flattened kernel takes -- 4 of WR-ResNet-22-4) and the stride-2 first convolution of stage 3
+ *   CPX_CNN_MATH_BF16X2  the stride-1 layers with 32 / 64 / 128 channels per group (stages 2, 3 and 4 of
+ *                        WR-ResNet-22-4) and the stride-2 first convolution of stage 3
  *                        take each operand as TWO bf16 terms rounded
  *                        to nearest (16 significand bits, relative error <= 2^-16 per operand: 32 times finer than
  *                        TF32) and three products per K step; every other layer as BF16X3.  Logits within 1e-6 of the float32 forward on the test network
