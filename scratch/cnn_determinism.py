@@ -1,0 +1,20 @@
+"""Bitwise repeatability of the network forward (every math mode): N forwards of the same batch, all equal to the first."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'classifier-pipeline_amd'))
+import numpy as np, torch
+from cpx.engine import TrackEngine
+from cpx.ml_tools import wrresnet as wr
+eng = TrackEngine()
+net = wr.WRResNetDevice(eng, wr.random_weights(17, seed=3), 17)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+x = torch.rand((96, 160, 160, 2), device=eng.device) * 255
+for mode in ("bf16x3", "bf16x2", "f32"):
+    eng.set_cnn_math(mode)
+    ref, _ = net.forward(x)
+    ref = ref.clone()
+    bad = 0
+    for i in range(N):
+        l, _ = net.forward(x)
+        bad += 0 if torch.equal(l, ref) else 1
+    print(mode, "forwards", N, "different from the first:", bad)
