@@ -796,7 +796,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define BF3W_ISSUE_W(G_, C_, R_, HF_)                                                                     \
   {                                                                                                       \
     const uint4* wc = wg + (size_t)((((G_) * nch + (C_)) * 3 + (R_)) * (12 * PL)) * cout_g + (HF_) * 32;  \
-    unsigned woff = (unsigned)((tid >> 5) * cout_g + (tid & 31)) << 4;                                    \
+    unsigned woff = (__umul24((unsigned)(tid >> 5), (unsigned)cout_g) + (unsigned)(tid & 31)) << 4;       \
     if (LAUNDER) asm volatile("" : "+v"(woff));                                                           \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                     \
       /* item tid + 512 i = 16 i rows further down; the last slice (rows 32..35) exists for tid < 128 only */ \
@@ -823,7 +823,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const unsigned coff = (unsigned)((G_) * cin_g + (C_) * KW + 4 * my_q8);                               \
     _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                      \
       const int px = min(t8 + 64 * i, W_NPX - 1);                                                         \
-      const int py = (px * 3641) >> 16, pxx = px - py * W_PW; /* px / 18 for px < 324 */                  \
+      /* px / 18 for px < 324; 24-bit multiplies by hand: a laundered index has no known range, and the 32-bit   \
+         v_mul_lo_u32 the compiler then picks takes four issue slots */                                      \
+      const int py = (int)(__umul24((unsigned)px, 3641u) >> 16), pxx = __mul24(py, -W_PW) + px;           \
       const int cy = min(max(iy0 + py, 0), a.H - 1), cx = min(max((IX0_) + pxx, 0), a.W - 1);             \
       pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, a.Cin) + coff) << 2)); \
     }                                                                                                     \
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           int t8 = tid >> 3;
           if (LAUNDER) asm volatile("" : "+v"(t8));
           int st_e2 = st_e2_0;
-          if (LAUNDER) st_e2 = ((q8c >> 2) * W_NPXP + t8) * 4 + (q8c & 3);
+          if (LAUNDER) st_e2 = (int)(__umul24((unsigned)(q8c >> 2), (unsigned)W_NPXP) + (unsigned)t8) * 4 + (q8c & 3);
 #pragma unroll
           for (int i = 0; i < NP; ++i) {
             if (i * CT + CT <= NITEM || tid < NITEM - i * CT) {
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
               if (!interior) {  // (uniform: most tiles skip the selects)
                 asm volatile("");
                 const int px = t8 + 64 * i;
-                const int py = (px * 3641) >> 16, pxx = px - py * W_PW;
+                const int py = (int)(__umul24((unsigned)px, 3641u) >> 16), pxx = __mul24(py, -W_PW) + px;
                 const bool inside = (unsigned)(iy0 + py) < (unsigned)a.H && (unsigned)(ix0 + pxx) < (unsigned)a.W;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
