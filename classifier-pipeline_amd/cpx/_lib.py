@@ -124,7 +124,7 @@ EXPORTS = [
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
     "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index", "cpx_format_regions", "cpx_json_indent", "cpx_ir_merge", "cpx_ir_resize_area",
-    "cpx_ir_frame_statistics",
+    "cpx_ir_frame_statistics", "cpx_cnn_last_overflow", "cpx_cnn_set_activation_bounds",
 ]
 
 IR_FRAME_STATS_DTYPE = np.dtype([("min", "<i4"), ("max", "<i4"), ("sum", "<i8"), ("median_x2", "<i4"), ("reserved", "<i4"),
@@ -197,6 +197,10 @@ def load():
     lib.cpx_set_cnn_math.restype = C.c_int
     lib.cpx_get_cnn_math.argtypes = [vp]
     lib.cpx_get_cnn_math.restype = C.c_int
+    lib.cpx_cnn_last_overflow.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.cpx_cnn_last_overflow.restype = C.c_int
+    lib.cpx_cnn_set_activation_bounds.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    lib.cpx_cnn_set_activation_bounds.restype = C.c_int
     lib.cpx_mog2_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(vp)]
     lib.cpx_mog2_create.restype = C.c_int
     lib.cpx_mog2_apply.argtypes = [vp, vp, C.c_double, vp]
@@ -257,7 +261,7 @@ def load():
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.cpx_last_kernel_timing.restype = C.c_int
-    if lib.cpx_abi_version() != 1:
+    if lib.cpx_abi_version() != 2:
         raise ImportError("libcpx_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -116,6 +116,13 @@ def bn_affine(w, name):
     return scale.astype(np.float32), shift.astype(np.float32)
 
 
+def activation_bound(w, name, sigmas=64.0):
+    """Upper bound of relu(BatchNorm(x)) for the fp16x2 math mode's range scaling (include/cpx.h:
+    cpx_cnn_set_activation_bounds): the normalised input is within `sigmas` standard deviations, so the output is
+    within |beta| + sigmas |gamma|; an input that is not costs a rerun of the layer, never correctness."""
+    return float(np.max(np.abs(w[name + "/beta"]) + sigmas * np.abs(w[name + "/gamma"])))
+
+
 def pack_conv(kernel):
     """Keras HWIO [kh,kw,Cin/g,Cout] -> [g][kh*kw][Cin/g][Cout/g] contiguous."""
     kh, kw, ci, co = kernel.shape
@@ -178,6 +185,9 @@ class WRResNetDevice:
             self.p[name + "/b"] = up(w[name + "/bias"])
         self._bufs = {}
         self._cnn = None
+        # what the 3x3 convolutions' activated inputs can reach, in launch order (fp16x2 range scaling)
+        self.act_bounds = [activation_bound(w, "bn%db%d_branch2%s" % (stage, d, ab))
+                           for stage in (2, 3, 4) for d in range(BLOCKS) for ab in "ab"]
         self._create_native()
 
     def _create_native(self):
@@ -207,6 +217,10 @@ class WRResNetDevice:
         if rc != 0:
             raise CpxError(rc, self.eng._err())
         self._cnn = out
+        bounds = (C.c_float * len(self.act_bounds))(*self.act_bounds)
+        rc = self.lib.cpx_cnn_set_activation_bounds(self._cnn, bounds, len(self.act_bounds))
+        if rc != 0:
+            raise CpxError(rc, self.eng._err())
 
     def close(self):
         if self._cnn is not None:
@@ -318,3 +332,65 @@ class WRResNetDevice:
             raise CpxError(rc, self.eng._err())
         self.eng.synchronize()
         return logits, probs
+
+
+def calibrate_bn_device(engine, weights, x, n_labels=17, var_floor=1e-2):
+    """Set-up utility for SYNTHETIC networks (bench.py, probes; a converted model brings its own statistics): set every
+    BatchNorm's moving mean / variance to the statistics of the calibration batch x (device float32 [N, S, S, 2]) as
+    it flows through the HIP convolutions layer by layer -- what training would have left behind -- so that seeded
+    random kernels give O(1) activations and logits instead of magnitudes no trained network has.  Returns a new
+    weights dict; the per-channel reductions are torch calls on the calibration tensors (set-up, not the hot path)."""
+    t = engine.torch
+    w = dict(weights)
+    net = WRResNetDevice(engine, w, n_labels)
+    dev = engine.device
+
+    def up(a):
+        return t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+    def fit(tensor, name):
+        engine.synchronize()
+        flat = tensor.reshape(-1, tensor.shape[-1]).double()
+        mean = flat.mean(dim=0)
+        var = flat.var(dim=0, unbiased=False)
+        t.cuda.synchronize()
+        w[name + "/moving_mean"] = mean.float().cpu().numpy()
+        w[name + "/moving_variance"] = (var.float() + var_floor).cpu().numpy()
+        return bn_affine(w, name)
+
+    N, H, W, _ = x.shape
+    t.cuda.current_stream(dev).synchronize()
+    cur = net._buf("act0", (N, H, W, FILTERS[0]))
+    net._conv(x, cur, "conv1_1/w", N, H, W, 2, FILTERS[0], 3, 1, True, False, out_shift=net.p["conv1_1/b"])
+    c_in, flip = FILTERS[0], 0
+    for stage in (2, 3, 4):
+        f = FILTERS[stage - 1]
+        for d in range(BLOCKS):
+            b = "%db%d" % (stage, d)
+            s = (stage - 1) if d == 0 else 1
+            Ho, Wo = -(-H // s), -(-W // s)
+            sa, ha = fit(cur, "bn%s_branch2a" % b)
+            net.p["%s/in_scale" % b].copy_(up(sa))
+            net.p["%s/in_shift" % b].copy_(up(ha))
+            t.cuda.synchronize()
+            mid = net._buf("mid", (N, Ho, Wo, f))
+            bias_a = up(w["res%s_branch2a/bias" % b])
+            net._conv(cur, mid, "%s/wa" % b, N, H, W, c_in, f, 3, s, True, False, in_affine=b, out_shift=bias_a)
+            sb, hb = fit(mid, "bn%s_branch2b" % b)
+            net.p["%s/a_scale" % b].copy_(up(sb))
+            net.p["%s/a_shift" % b].copy_(up(w["res%s_branch2a/bias" % b] * sb + hb))
+            t.cuda.synchronize()
+            net._conv(cur, mid, "%s/wa" % b, N, H, W, c_in, f, 3, s, True, True, in_affine=b,
+                      out_scale=net.p["%s/a_scale" % b], out_shift=net.p["%s/a_shift" % b])
+            if d == 0:
+                res = net._buf("sc", (N, Ho, Wo, f))
+                net._conv(cur, res, "sc%d/w" % stage, N, H, W, c_in, f, 1, s, False, False, out_shift=net.p["sc%d/b" % stage])
+            else:
+                res = cur
+            flip ^= 1
+            nxt = net._buf("act%d" % flip, (N, Ho, Wo, f))
+            net._conv(mid, nxt, "%s/wb" % b, N, Ho, Wo, f, f, 3, 1, True, True, out_shift=net.p["%s/bb" % b], residual=res)
+            cur, H, W, c_in = nxt, Ho, Wo, f
+    fit(cur, "final_bn")
+    net.close()
+    return w

@@ -64,6 +64,7 @@ struct cpx_handle {
   bool fuse_shortcut = true;             // CPX_CNN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts as launches of their own
   void* bf3_scratch = nullptr;           // split weights of a cpx_conv2d call that brought none
   size_t bf3_scratch_bytes = 0;
+  int* cnn_ovf = nullptr;                // CPX_CNN_MATH_FP16X2: the overflow word of the forward (or bare convolution) in flight
   unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
   size_t ir_scratch_bytes = 0;
   uint32_t* ir_bitmap = nullptr;
@@ -295,6 +296,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
     else if (!std::strcmp(env, "bf16x3")) h->cnn_math = CPX_CNN_MATH_BF16X3;
     else if (!std::strcmp(env, "bf16x2")) h->cnn_math = CPX_CNN_MATH_BF16X2;
+    else if (!std::strcmp(env, "fp16x2")) h->cnn_math = CPX_CNN_MATH_FP16X2;
   }
   *out = h;
   return CPX_OK;
@@ -316,6 +318,7 @@ void cpx_destroy(cpx_handle* h) {
   if (h->ws_assoc) hipFree(h->ws_assoc);
   if (h->ir_scratch) hipFree(h->ir_scratch);
   if (h->bf3_scratch) hipFree(h->bf3_scratch);
+  if (h->cnn_ovf) hipFree(h->cnn_ovf);
   if (h->ir_bitmap) hipFree(h->ir_bitmap);
   for (auto& e : h->conv_events) {
     hipEventDestroy(e.e0);
@@ -804,10 +807,25 @@ struct conv_fuse {
 };
 static bool conv_can_fuse(const cpx_handle* h, const cpx_conv_desc* d);
 
-// the two modes that run the split-operand kernels (bf16 planes on the bf16 matrix pipe)
-static bool split_math(const cpx_handle* h) { return h->cnn_math == CPX_CNN_MATH_BF16X3 || h->cnn_math == CPX_CNN_MATH_BF16X2; }
+// the modes that run the split-operand kernels (16-bit planes on the bf16 / fp16 matrix pipe)
+static bool split_math(const cpx_handle* h) { return h->cnn_math != CPX_CNN_MATH_F32; }
+// CPX_CNN_MATH_FP16X2: what a network's forward knows about the layer and a bare cpx_conv2d does not
+struct conv_half {
+  float act_scale = 1.0f;   // power of two the activated input is multiplied by before the fp16 split
+  bool keep_flag = false;   // the overflow word belongs to the forward in flight (cleared once, at its start)
+};
+static int ensure_ovf_word(cpx_handle* h) {
+  if (h->cnn_ovf) return CPX_OK;
+  if (hipMalloc((void**)&h->cnn_ovf, 2 * sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(h, CPX_ERR_NOMEM, "cpx_conv2d: overflow word allocation failed");
+  }
+  CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, 2 * sizeof(int), h->stream));
+  return CPX_OK;
+}
 // split_weights: the bf16 plane image of d->weights_dev if the caller (a cpx_cnn) keeps one, else NULL
-static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_weights, const conv_fuse* fuse = nullptr) {
+static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_weights, const conv_fuse* fuse = nullptr,
+                    const conv_half* hf = nullptr) {
   if (!h) return CPX_ERR_INVALID;
   if (!d || !d->in_dev || !d->out_dev || !d->weights_dev) return fail(h, CPX_ERR_INVALID, "cpx_conv2d: null argument");
   if (d->N < 1 || d->H < 1 || d->W < 1 || d->groups < 1 || d->Cin % d->groups || d->Cout % d->groups ||
@@ -850,6 +868,14 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
   int rc;
   if (split_math(h) && cpx::conv_bf3_supported(a)) {
     a.planes = h->cnn_math == CPX_CNN_MATH_BF16X2 ? 2 : 3;
+    // fp16x2: the two-plane layers run on fp16 planes, with the three-plane kernel launched behind as the guarded
+    // rerun (it returns at once unless a scaled activation left fp16's range); every other layer as bf16x3
+    const bool half = h->cnn_math == CPX_CNN_MATH_FP16X2 && cpx::conv_bf3_two_planes(a);
+    if (half) {
+      const int rco = ensure_ovf_word(h);
+      if (rco != CPX_OK) return rco;
+      if (!(hf && hf->keep_flag)) CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, sizeof(int), h->stream));
+    }
     if (!split_weights) {
       const size_t need = cpx::conv_bf3_weight_bytes(a);
       if (need > h->bf3_scratch_bytes) {
@@ -866,7 +892,19 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
       cpx::launch_split_weights(a, h->bf3_scratch, h->stream);
       split_weights = h->bf3_scratch;
     }
-    rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
+    if (half) {
+      cpx::ConvArgs ah = a;
+      ah.planes = 2;
+      ah.half = 1;
+      ah.act_scale = hf ? hf->act_scale : 1.0f;
+      ah.act_unscale = 1.0f / ah.act_scale;  // (a power of two: exact)
+      ah.ovf = h->cnn_ovf;
+      rc = cpx::launch_conv_bf3(ah, split_weights, h->stream);
+      a.guard = h->cnn_ovf;
+      if (rc == 0) rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
+    } else {
+      rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
+    }
     if (rc == -3) {  // more tiles than the split-operand kernel's tile decomposition indexes: float32 path
       // the float32 kernel has no fused shortcut: dropping it silently would lose the block's shortcut branch
       if (fuse) return fail(h, CPX_ERR_UNSUPPORTED, "conv_run: batch too large for the fused-shortcut kernel (split the call)");
@@ -897,12 +935,23 @@ static bool conv_can_fuse(const cpx_handle* h, const cpx_conv_desc* d) {
 
 int cpx_set_cnn_math(cpx_handle* h, int mode) {
   if (!h) return CPX_ERR_INVALID;
-  if (mode != CPX_CNN_MATH_F32 && mode != CPX_CNN_MATH_BF16X3 && mode != CPX_CNN_MATH_BF16X2)
+  if (mode != CPX_CNN_MATH_F32 && mode != CPX_CNN_MATH_BF16X3 && mode != CPX_CNN_MATH_BF16X2 && mode != CPX_CNN_MATH_FP16X2)
     return fail(h, CPX_ERR_INVALID, "cpx_set_cnn_math: unknown mode");
   h->cnn_math = mode;
   return CPX_OK;
 }
 int cpx_get_cnn_math(const cpx_handle* h) { return h ? h->cnn_math : CPX_ERR_INVALID; }
+
+int cpx_cnn_last_overflow(cpx_handle* h, int* overflowed) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!overflowed) return fail(h, CPX_ERR_INVALID, "cpx_cnn_last_overflow: null argument");
+  CPX_ENTER(h);
+  *overflowed = 0;
+  if (!h->cnn_ovf) return CPX_OK;
+  CPX_HIP(h, hipStreamSynchronize(h->stream));
+  CPX_HIP(h, hipMemcpy(overflowed, h->cnn_ovf, sizeof(int), hipMemcpyDeviceToHost));
+  return CPX_OK;
+}
 
 int cpx_cnn_head_ex(cpx_handle* h, const cpx_head_desc* d) {
   if (!h) return CPX_ERR_INVALID;
@@ -1240,6 +1289,13 @@ struct cpx_cnn {
   float* arena = nullptr;  // act0 | act1 | mid | sc
   size_t arena_floats = 0;
   std::vector<std::pair<const float*, void*>> split;  // bf16 plane images of the 3x3 stride-1 weights
+  // CPX_CNN_MATH_FP16X2: the power of two each 3x3 convolution's activated input is multiplied by before the fp16 split
+  // ([stage][block][a / b]; 1 until cpx_cnn_set_activation_bounds says more)
+  float act_scale[3][CPX_WRRESNET_MAX_BLOCKS][2];
+  cpx_cnn() {
+    for (auto& st : act_scale)
+      for (auto& b : st) b[0] = b[1] = 1.0f;
+  }
   const void* split_of(const float* w) const {
     for (const auto& e : split)
       if (e.first == w) return e.second;
@@ -1326,12 +1382,42 @@ void cpx_cnn_destroy(cpx_cnn* cnn) {
   cnn_free(cnn);
 }
 
+int cpx_cnn_set_activation_bounds(cpx_cnn* cnn, const float* bounds, int n) {
+  if (!cnn) return CPX_ERR_INVALID;
+  cpx_handle* h = cnn->h;
+  const cpx_wrresnet_params& p = cnn->p;
+  if (!bounds || n != 3 * p.blocks_per_stage * 2)
+    return fail(h, CPX_ERR_INVALID, "cpx_cnn_set_activation_bounds: expected 3 * blocks_per_stage * 2 bounds");
+  for (int st = 0; st < 3; ++st)
+    for (int d = 0; d < p.blocks_per_stage; ++d)
+      for (int k = 0; k < 2; ++k) {
+        const float b = bounds[(st * p.blocks_per_stage + d) * 2 + k];
+        // the largest power of two that keeps bound * scale at or below 2^15 (half of fp16's range: headroom of two),
+        // between 1 and 2^14; no usable bound: 1
+        int e = 0;
+        if (b > 0.0f && std::isfinite(b)) {
+          int eb = 0;
+          (void)std::frexp(b, &eb);  // b = f 2^eb, f in [0.5, 1): b <= 2^eb
+          e = std::min(std::max(15 - eb, 0), 14);
+        }
+        cnn->act_scale[st][d][k] = std::ldexp(1.0f, e);
+      }
+  return CPX_OK;
+}
+
 int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, float* logits_dev, float* probs_dev) {
   if (!cnn) return CPX_ERR_INVALID;
   cpx_handle* h = cnn->h;
   if (!in_dev || !logits_dev || N < 1 || H < 1 || W < 1) return fail(h, CPX_ERR_INVALID, "cpx_cnn_forward: bad argument");
   CPX_ENTER(h);
   const cpx_wrresnet_params& p = cnn->p;
+  if (h->cnn_math == CPX_CNN_MATH_FP16X2) {  // one overflow word per forward: once set, the rest of the forward runs bf16x3
+    const int rco = ensure_ovf_word(h);
+    if (rco != CPX_OK) return rco;
+    CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, sizeof(int), h->stream));
+  }
+  conv_half hf;
+  hf.keep_flag = true;
   // largest activation: conv1 output (and the stage-2 tensors at stride 1)
   size_t biggest = 0;
   {
@@ -1367,7 +1453,7 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
     d.pad_same = same; d.relu = relu;
     d.in_dev = in; d.out_dev = out; d.weights_dev = w; d.in_scale_dev = in_scale; d.in_shift_dev = in_shift;
     d.out_scale_dev = out_scale; d.out_shift_dev = out_shift; d.residual_dev = residual;
-    return conv_run(h, &d, cnn->split_of(w));
+    return conv_run(h, &d, cnn->split_of(w), nullptr, &hf);
   };
   int rc = conv(in_dev, act[0], p.conv1_w, H, W, p.in_channels, p.filters[0], 3, 1, 1, 0, nullptr, nullptr, nullptr,
                 p.conv1_b, nullptr);
@@ -1380,8 +1466,10 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
       const cpx_wrresnet_block& b = p.block[st][d];
       const int s = d == 0 ? st + 1 : 1;  // wr_block(stride = stage index), wr_resnet.py:27-30
       const int ho = (hh + s - 1) / s, wo = (ww + s - 1) / s;
+      hf.act_scale = cnn->act_scale[st][d][0];
       rc = conv(cur, mid, b.wa, hh, ww, c_in, f, 3, s, 1, 1, b.in_scale, b.in_shift, b.a_scale, b.a_shift, nullptr);
       if (rc != CPX_OK) return rc;
+      hf.act_scale = cnn->act_scale[st][d][1];
       const float* res = cur;
       bool fused = false;
       if (d == 0) {
@@ -1389,7 +1477,9 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
         // on the split-operand kernel (saves writing and re-reading the shortcut tensor), a launch of its own otherwise
         cpx_conv_desc probe{};
         probe.Cin = f; probe.Cout = f; probe.groups = p.groups; probe.ksize = 3; probe.stride = 1;
-        fused = h->fuse_shortcut && conv_can_fuse(h, &probe) && (c_in / p.groups) % 2 == 0;
+        // (the kernels' fused shortcut walks K in fours -- conv_bf3w_kernel -- or in twos: a block input with 2, 6, 10 ...
+        // channels per group keeps the shortcut as a launch of its own rather than depending on which kernel takes the layer)
+        fused = h->fuse_shortcut && conv_can_fuse(h, &probe) && (c_in / p.groups) % 4 == 0;
         if (!fused) {
           rc = conv(cur, sc, p.shortcut_w[st], hh, ww, c_in, f, 1, s, 0, 0, nullptr, nullptr, nullptr, p.shortcut_b[st],
                     nullptr);
@@ -1406,7 +1496,7 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
         dd.N = N; dd.H = ho; dd.W = wo; dd.Cin = f; dd.Cout = f; dd.groups = p.groups; dd.ksize = 3; dd.stride = 1;
         dd.pad_same = 1; dd.relu = 1;
         dd.in_dev = mid; dd.out_dev = act[flip]; dd.weights_dev = b.wb; dd.out_shift_dev = b.bb;
-        rc = conv_run(h, &dd, cnn->split_of(b.wb), &fu);
+        rc = conv_run(h, &dd, cnn->split_of(b.wb), &fu, &hf);
       } else {
         rc = conv(mid, act[flip], b.wb, ho, wo, f, f, 3, 1, 1, 1, nullptr, nullptr, nullptr, b.bb, res);
       }

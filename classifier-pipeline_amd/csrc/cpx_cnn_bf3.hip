@@ -82,6 +82,49 @@ __device__ __forceinline__ void split_pair2(float a, float b, unsigned& p0, unsi
   p1 = pack2_rne(ra, rb);
 }
 
+// CPX_CNN_MATH_FP16X2: two float32 -> two fp16 planes, each rounded to nearest (v_cvt_pk_f16_f32): 11 + 11 significand
+// bits and the sign of the remainder, |x - hi - lo| <= 2^-22 |x| while lo is a normal fp16 (|x| >= 2^-3 after the
+// caller's scaling) and <= 2^-25 absolute below that (v_mfma_*_f16 keeps subnormal inputs: scratch/fp16_probe.hip)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack2_h(float a, float b) {
+  f16x2 v = {(_Float16)a, (_Float16)b};  // v_cvt_pk_f16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split_pair2_h(float a, float b, unsigned& p0, unsigned& p1) {
+  p0 = pack2_h(a, b);
+  asm volatile("" : "+v"(p0));  // (opaque: see split_pair)
+  const f16x2 h = __builtin_bit_cast(f16x2, p0);
+  const float ra = a - (float)h[0], rb = b - (float)h[1];  // exact
+  p1 = pack2_h(ra, rb);
+}
+// the two-plane split of the chosen kind (H: fp16, else bf16)
+template <bool H>
+__device__ __forceinline__ void split2(float a, float b, unsigned& p0, unsigned& p1) {
+  if (H) split_pair2_h(a, b, p0, p1);
+  else split_pair2(a, b, p0, p1);
+}
+// one plane product on the matrix pipe: 16-byte fragments as they come out of LDS
+template <bool H>
+__device__ __forceinline__ f32x4 mfma16(u32x4 w, u32x4 x, f32x4 c) {
+  if (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+template <bool H>
+__device__ __forceinline__ f32x16 mfma32(u32x4 x, u32x4 w, f32x16 c) {
+  if (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, w), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, w), c, 0, 0, 0);
+}
+constexpr float F16_MAX = 65504.0f;
+// entry test shared by the split-operand kernels: a fp16 layer is skipped once the network's overflow word is set (its
+// three-plane rerun follows), the rerun is skipped while it is clear
+#define BF3_ENTRY_GUARD(H_)                          \
+  if (H_) {                                          \
+    if (*a.ovf != 0) return;                         \
+  } else if (a.guard != nullptr && *a.guard == 0) {  \
+    return;                                          \
+  }
+
 constexpr int KC = 16;  // channels per K step of the bf16 MFMA = per staged chunk
 
 // NB bands of 128 output pixels per workgroup, CT threads: four waves share a band (32 pixels each); with CT = 512
@@ -100,7 +143,8 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
 // instead of two channel halves: lanes 0-31 (k half 0) read tap 2 s, lanes 32-63 tap 2 s + 1 of the same 8-channel
 // entry array -- five steps for the nine taps (the tenth tap has zero weights) instead of nine half-empty ones.
 // PL: bf16 planes per operand (3: the exact split; 2: CPX_CNN_MATH_BF16X2 -- see conv_bf3w_kernel; not with C8)
-template <int NTN, int S, int NB, int TW, int CT, bool C8, int PL = 3>
+// H: the two planes are fp16 (CPX_CNN_MATH_FP16X2: ConvArgs::half; PL == 2 only)
+template <int NTN, int S, int NB, int TW, int CT, bool C8, int PL = 3, bool H = false>
 // (the strided forms fill the LDS with one workgroup: their waves may use the registers of the absent second one)
 __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128), S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128)))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3;
@@ -118,6 +162,8 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   constexpr int NSTEP = C8 ? 5 : 9;   // K = 16 steps per chunk
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   static_assert(PL == 3 || (PL == 2 && !C8), "two planes: not for the tap-paired 8-channel form");
+  static_assert(!H || PL == 2, "fp16 planes come in twos");
+  BF3_ENTRY_GUARD(H)
   uint4* s_patch = lds4;                // [PL][KH][NPX]
   uint4* s_w = lds4 + PL * KH * NPX;    // [PL][NSTEP][2][COGW]
 
@@ -155,6 +201,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   if (res_in_acc) {
     const float* res_n = a.residual + (size_t)n * a.Ho * a.Wo * a.Cout + (g * cout_g + ns * COGW);  // (uniform)
     const int rcol = lane & 31;
+    float rs[NTN];  // (H) the accumulators hold act_scale * w_scale[channel] times the sum: so must the residual
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) rs[t] = H ? a.w_scale[g * cout_g + ns * COGW + t * 32 + rcol] * a.act_scale : 1.0f;
     if (full_tile) {
 #pragma unroll
       for (int m = 0; m < NTM; ++m) {
@@ -168,6 +217,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
             const int ic = (r & 3) + 8 * (r >> 2);
             const unsigned ub = (unsigned)(((ic / TW) * a.Wo + (ic % TW)) * a.Cout + t * 32) << 2;  // (scalar)
             acc[m][t][r] = *at_off(res_n, lb + ub);
+            if (H) acc[m][t][r] *= rs[t];
           }
       }
     } else {
@@ -180,6 +230,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
             const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel of the wave tile this register holds
             const int oy = min(oy0 + (wset + m * WSETS) * TB + WR * wave + i / TW, a.Ho - 1), ox = min(ox0 + i % TW, a.Wo - 1);
             acc[m][t][r] = *at_off(res_n, (pix_off(oy, ox, a.Wo, a.Cout) + (unsigned)(t * 32 + rcol)) << 2);
+            if (H) acc[m][t][r] *= rs[t];
           }
     }
   } else {
@@ -212,6 +263,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   for (int cc = -1; cc < nchunks; ++cc) {
     if (cc >= 0) {
       // ---- registers -> LDS: BatchNorm + ReLU prologue, split into bf16 planes ----
+      float vmax = 0.0f;  // (H) largest scaled magnitude this thread stages
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int item = tid + i * CT;
@@ -229,21 +281,25 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);
-            if (a.in_scale) {
+            if (a.in_scale) {  // (H: scale and shift carry act_scale)
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = fmaxf(__fmaf_rn(v[j], psc[j], psh[j]), 0.0f);
+            } else if (H) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] *= a.act_scale;
             }
             if (!interior) {  // (uniform: most tiles skip the selects)
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
             }
+            if (H) vmax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), vmax);
             unsigned q0[2], q1[2], q2[2];
             if (PL == 3) {
               split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
               split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
             } else {
-              split_pair2(v[0], v[1], q0[0], q1[0]);
-              split_pair2(v[2], v[3], q0[1], q1[1]);
+              split2<H>(v[0], v[1], q0[0], q1[0]);
+              split2<H>(v[2], v[3], q0[1], q1[1]);
             }
             // channels 4 q .. 4 q + 3 of the chunk: entry of k half q >> 1, its low or high 8 bytes
             uint2* sp2 = reinterpret_cast<uint2*>(s_patch);
@@ -259,6 +315,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
         const int item = tid + i * CT;
         if (item < NW) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
       }
+      if (H && vmax > F16_MAX) atomicOr(a.ovf, 1);  // out of fp16's range: the three-plane kernel reruns the layer
     }
     // (the next chunk's loads are issued BEFORE the barrier: their registers are free once the commit above has read
     // them, and the time a wave waits for the others at the barrier then counts towards hiding the loads' latency)
@@ -273,6 +330,10 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
         asm volatile("" : "+v"(qoff));
         psc = *reinterpret_cast<const f32x4*>(at_off(scp, qoff));
         psh = *reinterpret_cast<const f32x4*>(at_off(shp, qoff));
+        if (H) {  // relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly
+          psc *= a.act_scale;
+          psh *= a.act_scale;
+        }
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -310,15 +371,15 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
           const int ky = st / KS, kx = st - ky * KS;
           koff = ky * PW + kx;
         }
-        bf16x8 av[NTM][PL], bv[NTN][PL];
+        u32x4 av[NTM][PL], bv[NTN][PL];
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
 #pragma unroll
           for (int m = 0; m < NTM; ++m)
-            av[m][p] = __builtin_bit_cast(bf16x8, s_patch[p * KH * NPX + a_base + m * (WSETS * TB * S * PW) + koff]);
+            av[m][p] = __builtin_bit_cast(u32x4, s_patch[p * KH * NPX + a_base + m * (WSETS * TB * S * PW) + koff]);
 #pragma unroll
           for (int t = 0; t < NTN; ++t)
-            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * NSTEP + st) * 2 * COGW + b_base + t * 32]);
+            bv[t][p] = __builtin_bit_cast(u32x4, s_w[(p * NSTEP + st) * 2 * COGW + b_base + t * 32]);
         }
 #pragma unroll
         for (int m = 0; m < NTM; ++m)
@@ -326,13 +387,13 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
           for (int t = 0; t < NTN; ++t) {
             // smallest terms first: x1*y1, x0*y2, x2*y0, x0*y1, x1*y0, x0*y0
             if (PL == 3) {
-              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][1], acc[m][t], 0, 0, 0);
-              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][PL - 1], acc[m][t], 0, 0, 0);
-              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][PL - 1], bv[t][0], acc[m][t], 0, 0, 0);
+              acc[m][t] = mfma32<false>(av[m][1], bv[t][1], acc[m][t]);
+              acc[m][t] = mfma32<false>(av[m][0], bv[t][PL - 1], acc[m][t]);
+              acc[m][t] = mfma32<false>(av[m][PL - 1], bv[t][0], acc[m][t]);
             }
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][1], acc[m][t], 0, 0, 0);
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][1], bv[t][0], acc[m][t], 0, 0, 0);
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m][0], bv[t][0], acc[m][t], 0, 0, 0);
+            acc[m][t] = mfma32<H>(av[m][0], bv[t][1], acc[m][t]);
+            acc[m][t] = mfma32<H>(av[m][1], bv[t][0], acc[m][t]);
+            acc[m][t] = mfma32<H>(av[m][0], bv[t][0], acc[m][t]);
           }
       }
       __syncthreads();
@@ -344,6 +405,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   if (a.sc_in) {
     const int sc_cg = a.sc_cin / a.groups;
     const float* wsc = a.sc_w + (size_t)g * sc_cg * cout_g + ns * COGW + (lane & 31);
+    float ss[NTN];  // (H) into scaled accumulators: the shortcut's weights take the column's scale
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) ss[t] = H ? a.w_scale[g * cout_g + ns * COGW + t * 32 + (lane & 31)] * a.act_scale : 1.0f;
 #pragma unroll
     for (int m = 0; m < NTM; ++m) {
       const int oy = min(oy0 + (wset + m * WSETS) * TB + prow, a.Ho - 1), ox = min(ox0 + pcol, a.Wo - 1);
@@ -352,8 +416,11 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
       for (int k2 = 0; k2 < sc_cg; k2 += 2) {
         const float av = psc_in[k2];
 #pragma unroll
-        for (int t = 0; t < NTN; ++t)
-          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wsc[(size_t)(k2 + kh) * cout_g + t * 32], acc[m][t], 0, 0, 0);
+        for (int t = 0; t < NTN; ++t) {
+          float wv = wsc[(size_t)(k2 + kh) * cout_g + t * 32];
+          if (H) wv *= ss[t];
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc[m][t], 0, 0, 0);
+        }
       }
     }
   }
@@ -370,7 +437,8 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
 #pragma unroll
     for (int t = 0; t < NTN; ++t) {
       const int ch = ch0 + t * 32 + (lane & 31);
-      const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+      float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+      if (H) os *= a.w_unscale[ch] * a.act_unscale;  // (powers of two: exact)
       const float ob = (a.out_shift ? a.out_shift[ch] : 0.0f) + (a.sc_in && a.sc_bias ? a.sc_bias[ch] : 0.0f);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -445,11 +513,14 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
 // 95 %), stages the input rows they touch at full width, and every lane derives its pixel from its position.  Same
 // staging format, MFMA loop and epilogue as conv_bf3_kernel; the output offset of a position is simply p * Cout.
 // PL: bf16 planes per operand (3: the exact split, six products; 2: CPX_CNN_MATH_BF16X2, three -- see conv_bf3w_kernel)
-template <int NTN, int NPXC, int PL>
+// H: the two planes are fp16 (CPX_CNN_MATH_FP16X2; see conv_bf3_kernel)
+template <int NTN, int NPXC, int PL, bool H = false>
 __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3, CT = 256;
   constexpr int COGW = 32 * NTN;
+  static_assert(!H || PL == 2, "fp16 planes come in twos");
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  BF3_ENTRY_GUARD(H)
   uint4* s_patch = lds4;                 // [PL][2][NPXC]
   uint4* s_w = lds4 + 2 * PL * NPXC;     // [PL][9][2][COGW]
 
@@ -480,12 +551,15 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
     const float* res_n = a.residual + (size_t)n * M * a.Cout + (g * cout_g + ns * COGW);  // (uniform)
     const int rcol = lane & 31;
 #pragma unroll
-    for (int t = 0; t < NTN; ++t)
+    for (int t = 0; t < NTN; ++t) {
+      const float rs = H ? a.w_scale[g * cout_g + ns * COGW + t * 32 + rcol] * a.act_scale : 1.0f;  // (see conv_bf3_kernel)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         acc[t][r] = *at_off(res_n, (__umul24((unsigned)min(p0 + wave * 32 + i, M - 1), (unsigned)a.Cout) + (unsigned)(t * 32 + rcol)) << 2);
+        if (H) acc[t][r] *= rs;
       }
+    }
   } else {
 #pragma unroll
     for (int t = 0; t < NTN; ++t)
@@ -518,6 +592,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   for (int cc = -1; cc < nchunks; ++cc) {
     if (cc >= 0) {
       // ---- registers -> LDS: BatchNorm + ReLU prologue, padding zeroed, split into bf16 planes ----
+      float vmax = 0.0f;  // (H) largest scaled magnitude this thread stages
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int iy = iy0 + item_py[i], ix = ix0 + item_px[i];
@@ -525,17 +600,24 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = pre_p[i][j >> 2][j & 3];
-        if (a.in_scale) {
+        if (a.in_scale) {  // (H: scale and shift carry act_scale)
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(__fmaf_rn(v[j], psc[j >> 2][j & 3], psh[j >> 2][j & 3]), 0.0f);
+        } else if (H) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= a.act_scale;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.0f;
+        if (H) {
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) vmax = fmaxf(fmaxf(fabsf(v[j]), fabsf(v[j + 1])), vmax);
+        }
         unsigned q0[4], q1[4], q2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (PL == 3) split_pair(v[2 * j], v[2 * j + 1], q0[j], q1[j], q2[j]);
-          else split_pair2(v[2 * j], v[2 * j + 1], q0[j], q1[j]);
+          else split2<H>(v[2 * j], v[2 * j + 1], q0[j], q1[j]);
         }
         u32x4* sp4 = reinterpret_cast<u32x4*>(s_patch);
         sp4[0 * 2 * NPXC + item_e[i]] = u32x4{q0[0], q0[1], q0[2], q0[3]};
@@ -547,6 +629,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         const int item = tid + i * CT;
         if (item < NW) reinterpret_cast<u32x4*>(s_w)[item] = pre_w[i];
       }
+      if (H && vmax > F16_MAX) atomicOr(a.ovf, 1);  // out of fp16's range: the three-plane kernel reruns the layer
       __syncthreads();
     }
     if (cc + 1 < nchunks) {
@@ -562,6 +645,13 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
         psc[1] = *reinterpret_cast<const f32x4*>(at_off(scp, hoff + 16));
         psh[0] = *reinterpret_cast<const f32x4*>(at_off(shp, hoff));
         psh[1] = *reinterpret_cast<const f32x4*>(at_off(shp, hoff + 16));
+        if (H) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            psc[k] *= a.act_scale;
+            psh[k] *= a.act_scale;
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -584,24 +674,24 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
 #pragma unroll
       for (int tap = 0; tap < KS * KS; ++tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
-        bf16x8 av[PL], bv[NTN][PL];
+        u32x4 av[PL], bv[NTN][PL];
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
-          av[p] = __builtin_bit_cast(bf16x8, s_patch[p * 2 * NPXC + a_base + ky * PW + kx]);
+          av[p] = __builtin_bit_cast(u32x4, s_patch[p * 2 * NPXC + a_base + ky * PW + kx]);
 #pragma unroll
           for (int t = 0; t < NTN; ++t)
-            bv[t][p] = __builtin_bit_cast(bf16x8, s_w[(p * 9 + tap) * 2 * COGW + b_base + t * 32]);
+            bv[t][p] = __builtin_bit_cast(u32x4, s_w[(p * 9 + tap) * 2 * COGW + b_base + t * 32]);
         }
 #pragma unroll
         for (int t = 0; t < NTN; ++t) {
           if (PL == 3) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[t][1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][PL - 1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PL - 1], bv[t][0], acc[t], 0, 0, 0);
+            acc[t] = mfma32<false>(av[1], bv[t][1], acc[t]);
+            acc[t] = mfma32<false>(av[0], bv[t][PL - 1], acc[t]);
+            acc[t] = mfma32<false>(av[PL - 1], bv[t][0], acc[t]);
           }
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][1], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[t][0], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[t][0], acc[t], 0, 0, 0);
+          acc[t] = mfma32<H>(av[0], bv[t][1], acc[t]);
+          acc[t] = mfma32<H>(av[1], bv[t][0], acc[t]);
+          acc[t] = mfma32<H>(av[0], bv[t][0], acc[t]);
         }
       }
       __syncthreads();
@@ -613,11 +703,17 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
     const float* wsc = a.sc_w + (size_t)g * sc_cg * cout_g + ns * COGW + (lane & 31);
     const float* psc_in = a.sc_in + (((size_t)n * a.sc_H + ly * a.sc_stride) * a.sc_W + lx * a.sc_stride) * a.sc_cin +
                           g * sc_cg + kh;
+    float ss[NTN];  // (H: see conv_bf3_kernel)
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) ss[t] = H ? a.w_scale[g * cout_g + ns * COGW + t * 32 + (lane & 31)] * a.act_scale : 1.0f;
     for (int k2 = 0; k2 < sc_cg; k2 += 2) {
       const float av = psc_in[k2];
 #pragma unroll
-      for (int t = 0; t < NTN; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wsc[(size_t)(k2 + kh) * cout_g + t * 32], acc[t], 0, 0, 0);
+      for (int t = 0; t < NTN; ++t) {
+        float wv = wsc[(size_t)(k2 + kh) * cout_g + t * 32];
+        if (H) wv *= ss[t];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc[t], 0, 0, 0);
+      }
     }
   }
 
@@ -629,7 +725,8 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
 #pragma unroll
   for (int t = 0; t < NTN; ++t) {
     const int ch = ch0 + t * 32 + (lane & 31);
-    const float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+    float os = a.out_scale ? a.out_scale[ch] : 1.0f;
+    if (H) os *= a.w_unscale[ch] * a.act_unscale;  // (powers of two: exact)
     const float ob = (a.out_shift ? a.out_shift[ch] : 0.0f) + (a.sc_in && a.sc_bias ? a.sc_bias[ch] : 0.0f);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -721,10 +818,15 @@ constexpr int w_wsub_entries(int planes) { return w_rows_resident(planes) * plan
 // PL: bf16 planes per operand.  3 = the exact split (six products per K step: every term down to 2^-24 of the float32
 // product); 2 = CPX_CNN_MATH_BF16X2: both operands as hi + lo rounded to nearest (16 significand bits, relative error
 // <= 2^-16 each), three products w0 x1 + w1 x0 + w0 x0 -- half the matrix work, two thirds of the staging and LDS.
-template <bool WALK, bool LDSBN, int NH, int NG, int PL>
+// H (PL == 2): the two planes are fp16 -- CPX_CNN_MATH_FP16X2: 11 + 11 significand bits (2^-22 per operand against 2^-16),
+// three products on v_mfma_f32_16x16x32_f16 at the bf16 form's rate; the operands are scaled by powers of two into
+// fp16's range and the accumulators scaled back in the epilogue (ConvArgs::half)
+template <bool WALK, bool LDSBN, int NH, int NG, int PL, bool H = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf3w_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   static_assert(NG == 1 || (!WALK && !LDSBN && NH == 1), "the group walk is built for the one-slice, one-tile form");
   static_assert(PL == 2 || PL == 3, "two or three bf16 planes per operand");
+  static_assert(!H || (PL == 2 && LDSBN), "fp16 planes come in twos (and with the BatchNorm parameters in LDS)");
+  BF3_ENTRY_GUARD(H)
   // WR: kernel rows of a chunk's weights resident in LDS at a time.  Three planes: one (patch + one row = 79 KB, two
   // workgroups per CU).  Two planes leave room for all three (41 + 36 KB): one weight commit and two barriers per chunk
   // and column slice instead of three and six.
@@ -785,9 +887,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   f32x4* s_bn = reinterpret_cast<f32x4*>(lds4 + W_PATCH + W_WSUB);
   f32x4 psc_r, psh_r;  // (!LDSBN)
   if (LDSBN && a.in_scale) {
-    if (tid < cin_g) {
-      reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g0 * cin_g + tid];
-      reinterpret_cast<float*>(s_bn)[cin_g + tid] = a.in_shift[g0 * cin_g + tid];
+    if (tid < cin_g) {  // (H: relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly)
+      reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g0 * cin_g + tid] * (H ? a.act_scale : 1.0f);
+      reinterpret_cast<float*>(s_bn)[cin_g + tid] = a.in_shift[g0 * cin_g + tid] * (H ? a.act_scale : 1.0f);
     }
     __syncthreads();
   }
@@ -869,6 +971,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
           acc[hf][ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 32u * hf + 16u * ct) << 2));
+    if (H) {  // the accumulators hold act_scale * w_scale[channel] times the sum: so must the residual
+#pragma unroll
+      for (int hc = 0; hc < 2 * NH; ++hc) {
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(a.w_scale + ch_l + 16 * hc) * a.act_scale;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[hc >> 1][hc & 1][pt] *= rs;
+      }
+    }
   } else {
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf)
@@ -891,6 +1001,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int oy = min(oy0 + 2 * wave + pt, a.Ho - 1), ox = min(ox0 + i16, a.Wo - 1);
       pin[pt] = a.sc_in + (((size_t)n * a.sc_H + oy * a.sc_stride) * a.sc_W + ox * a.sc_stride) * a.sc_cin + g * sc_cg + q;
     }
+    float ss[NH][2];  // (H) into scaled accumulators: the shortcut's weights take their column's scale
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        ss[hf][ct] = H ? a.w_scale[g * cout_g + ns * (32 * NH) + 32 * hf + 16 * ct + i16] * a.act_scale : 1.0f;
     for (int k4 = 0; k4 < sc_cg; k4 += 4) {
       float xs[2], ws[NH][2];
 #pragma unroll
@@ -898,7 +1014,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
       for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) ws[hf][ct] = wsc[(size_t)k4 * cout_g + 32 * hf + 16 * ct];
+        for (int ct = 0; ct < 2; ++ct) {
+          ws[hf][ct] = wsc[(size_t)k4 * cout_g + 32 * hf + 16 * ct];
+          if (H) ws[hf][ct] *= ss[hf][ct];
+        }
 #pragma unroll
       for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
@@ -919,12 +1038,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int ch = ch_l + 16 * hc;
     f32x4 os = {1.0f, 1.0f, 1.0f, 1.0f}, ob = {0.0f, 0.0f, 0.0f, 0.0f};
     if (a.out_scale) os = *reinterpret_cast<const f32x4*>(a.out_scale + ch);
+    if (H) os *= *reinterpret_cast<const f32x4*>(a.w_unscale + ch) * a.act_unscale;  // (powers of two: exact)
     if (a.out_shift) ob = *reinterpret_cast<const f32x4*>(a.out_shift + ch);
     if (a.sc_in && a.sc_bias) ob += *reinterpret_cast<const f32x4*>(a.sc_bias + ch);
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
       f32x4 v = acc[hf][ct][pt];
-      if (a.out_scale) {  // (uniform branches kept as branches: see the patch commit)
+      if (H || a.out_scale) {  // (uniform branches kept as branches: see the patch commit)
         asm volatile("");
         v = v * os;
       }
@@ -975,6 +1095,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           if (LAUNDER) asm volatile("" : "+v"(t8));
           int st_e2 = st_e2_0;
           if (LAUNDER) st_e2 = (int)(__umul24((unsigned)(q8c >> 2), (unsigned)W_NPXP) + (unsigned)t8) * 4 + (q8c & 3);
+          float vmax = 0.0f;  // (H) largest scaled magnitude this thread stages
 #pragma unroll
           for (int i = 0; i < NP; ++i) {
             if (i * CT + CT <= NITEM || tid < NITEM - i * CT) {
@@ -992,11 +1113,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
               for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);
               // (the empty asm keeps these uniform branches branches: if-converted, every item pays the BatchNorm and the
               // padding selects -- 12 vector instructions -- whether the layer has a prologue / the tile a border or not)
-              if (a.in_scale) {
+              if (a.in_scale) {  // (H: scale and shift carry act_scale)
                 asm volatile("");
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(__fmaf_rn(v[j], psc[j], psh[j]), 0.0f);
+              } else if (H) {
+                asm volatile("");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= a.act_scale;
               }
+              if (H) vmax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), vmax);
               if (!interior) {  // (uniform: most tiles skip the selects)
                 asm volatile("");
                 const int px = t8 + 64 * i;
@@ -1010,8 +1136,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 split_pair(v[0], v[1], q0[0], q1[0], q2[0]);
                 split_pair(v[2], v[3], q0[1], q1[1], q2[1]);
               } else {
-                split_pair2(v[0], v[1], q0[0], q1[0]);
-                split_pair2(v[2], v[3], q0[1], q1[1]);
+                split2<H>(v[0], v[1], q0[0], q1[0]);
+                split2<H>(v[2], v[3], q0[1], q1[1]);
               }
               // channels 4 q8 .. 4 q8 + 3 of the chunk: quarter pair q8 >> 2, 8-byte slot q8 & 3 of the pixel's 32 bytes
               uint2* sp2 = reinterpret_cast<uint2*>(s_patch) + st_e2 + i * (64 * 4);
@@ -1020,6 +1146,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
               if (PL == 3) sp2[(2 * 2 * W_NPXP) * 4] = make_uint2(q2[0], q2[1]);
             }
           }
+          // out of fp16's range (padding pixels' clamped loads included: conservative): the three-plane kernel reruns the layer
+          if (H && vmax > F16_MAX) atomicOr(a.ovf, 1);
         }
       }
       // ---- global -> registers for what comes next (in flight under this phase's products) ----
@@ -1045,14 +1173,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int r = r0 + rr;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        bf16x8 xv[2][PL], wv[2][PL];
+        u32x4 xv[2][PL], wv[2][PL];
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
 #pragma unroll
           for (int pt = 0; pt < 2; ++pt)
-            xv[pt][p] = __builtin_bit_cast(bf16x8, s_patch[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
+            xv[pt][p] = __builtin_bit_cast(u32x4, s_patch[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(bf16x8, s_w[rr * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
+          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_w[rr * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -1060,13 +1188,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           for (int pt = 0; pt < 2; ++pt) {
             // smallest terms first, as conv_bf3_kernel (x = activation planes, w = weight planes)
             if (PL == 3) {
-              acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][1], acc[hf][ct][pt], 0, 0, 0);
-              acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][PL - 1], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
-              acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][PL - 1], acc[hf][ct][pt], 0, 0, 0);
+              acc[hf][ct][pt] = mfma16<false>(wv[ct][1], xv[pt][1], acc[hf][ct][pt]);
+              acc[hf][ct][pt] = mfma16<false>(wv[ct][PL - 1], xv[pt][0], acc[hf][ct][pt]);
+              acc[hf][ct][pt] = mfma16<false>(wv[ct][0], xv[pt][PL - 1], acc[hf][ct][pt]);
             }
-            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][1], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
-            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][1], acc[hf][ct][pt], 0, 0, 0);
-            acc[hf][ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ct][0], xv[pt][0], acc[hf][ct][pt], 0, 0, 0);
+            acc[hf][ct][pt] = mfma16<H>(wv[ct][1], xv[pt][0], acc[hf][ct][pt]);
+            acc[hf][ct][pt] = mfma16<H>(wv[ct][0], xv[pt][1], acc[hf][ct][pt]);
+            acc[hf][ct][pt] = mfma16<H>(wv[ct][0], xv[pt][0], acc[hf][ct][pt]);
           }
       }
       }  // resident kernel rows
@@ -1084,11 +1212,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef BF3W_ISSUE_W
 #undef BF3W_ISSUE_P
 
-template <int NTN, int NPXC, int PL>
+template <int NTN, int NPXC, int PL, bool H = false>
 int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = ((size_t)2 * PL * NPXC + (size_t)18 * PL * 32 * NTN) * 16;
   static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL, H>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Ho * a.Wo + 127) / 128;
   td.tiles_y = 1;
@@ -1098,7 +1226,7 @@ int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) + 1;
-  hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL>), dim3((unsigned)blocks, a.groups), dim3(256), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL, H>), dim3((unsigned)blocks, a.groups), dim3(256), lds, s, a, wimg, td);
   return 0;
 }
 // the flattened tiling applies to stride-1 SAME 3 x 3 layers whose staged rows fit the LDS cap and pays when the
@@ -1142,9 +1270,28 @@ __global__ __launch_bounds__(256) void split_weights8_kernel(const float* __rest
   }
 }
 
+// CPX_CNN_MATH_FP16X2: the power of two that brings an output channel's largest weight magnitude into [8, 16) -- the
+// hi plane then is a normal fp16 with room to spare and the lo plane of every weight down to 2^-7 of the largest keeps
+// its 11 bits -- and its inverse.  packed float32 weights [g][9][cin_g][cout_g]; one thread per output channel
+__global__ __launch_bounds__(256) void weight_scales_kernel(const float* __restrict__ w, float* __restrict__ wscale,
+                                                            float* __restrict__ wunscale, int groups, int rows, int cout_g) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= groups * cout_g) return;
+  const int g = idx / cout_g, col = idx - g * cout_g;
+  float m = 0.0f;
+  for (int r = 0; r < rows; ++r) m = fmaxf(m, fabsf(w[((size_t)g * rows + r) * cout_g + col]));
+  int e = 0;
+  if (m > 0.0f && m < 3.0e38f) (void)frexpf(m, &e);  // m = f 2^e, f in [0.5, 1)
+  else e = 4;                                          // all-zero (or non-finite) column: scale 1
+  const int kw = min(max(4 - e, -100), 100);
+  wscale[idx] = ldexpf(1.0f, kw);
+  wunscale[idx] = ldexpf(1.0f, -kw);
+}
+
 // planes = 2 (CPX_CNN_MATH_BF16X2): [g][chunk][2][9][2][cout_g], hi / lo rounded to nearest
+// wscale != nullptr (CPX_CNN_MATH_FP16X2, planes == 2): fp16 planes of w * wscale[output channel] (a power of two)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
-                                                            int cin_g, int cout_g, int planes) {
+                                                            int cin_g, int cout_g, int planes, const float* __restrict__ wscale) {
   const int nchunks = cin_g / KC;
   const size_t total = (size_t)groups * nchunks * 9 * 2 * cout_g;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1162,7 +1309,13 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     for (int j = 0; j < 8; ++j)
       v[j] = w[(((size_t)g * 9 + tap) * cin_g + chunk * KC + 8 * h + j) * cout_g + col];
     uint4 p0, p1, p2;
-    if (planes == 3) {
+    if (wscale) {
+      const float ws = wscale[g * cout_g + col];
+      split_pair2_h(v[0] * ws, v[1] * ws, p0.x, p1.x);
+      split_pair2_h(v[2] * ws, v[3] * ws, p0.y, p1.y);
+      split_pair2_h(v[4] * ws, v[5] * ws, p0.z, p1.z);
+      split_pair2_h(v[6] * ws, v[7] * ws, p0.w, p1.w);
+    } else if (planes == 3) {
       split_pair(v[0], v[1], p0.x, p1.x, p2.x);
       split_pair(v[2], v[3], p0.y, p1.y, p2.y);
       split_pair(v[4], v[5], p0.z, p1.z, p2.z);
@@ -1183,8 +1336,9 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // packed float32 weights [g][tap][cin_g][cout_g] -> [g][chunk of 32][ky][plane][kx][quarter][cout_g] of 16-byte entries
 // (conv_bf3w_kernel: a (chunk, ky) sub-chunk is 36 rows of cout_g entries)
 // planes = 2: [g][chunk][ky][2][kx][quarter][cout_g], hi / lo rounded to nearest (a sub-chunk is 24 rows)
+// wscale != nullptr (CPX_CNN_MATH_FP16X2, planes == 2): fp16 planes of w * wscale[output channel]
 __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
-                                                              int cin_g, int cout_g, int planes) {
+                                                              int cin_g, int cout_g, int planes, const float* __restrict__ wscale) {
   const int nch = cin_g / KW;
   const size_t total = (size_t)groups * nch * 9 * 4 * cout_g;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1204,7 +1358,13 @@ __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __res
     for (int j = 0; j < 8; ++j)
       v[j] = w[(((size_t)g * 9 + ky * 3 + kx) * cin_g + chunk * KW + 8 * qq + j) * cout_g + col];
     uint4 p0, p1, p2;
-    if (planes == 3) {
+    if (wscale) {
+      const float ws = wscale[g * cout_g + col];
+      split_pair2_h(v[0] * ws, v[1] * ws, p0.x, p1.x);
+      split_pair2_h(v[2] * ws, v[3] * ws, p0.y, p1.y);
+      split_pair2_h(v[4] * ws, v[5] * ws, p0.z, p1.z);
+      split_pair2_h(v[6] * ws, v[7] * ws, p0.w, p1.w);
+    } else if (planes == 3) {
       split_pair(v[0], v[1], p0.x, p1.x, p2.x);
       split_pair(v[2], v[3], p0.y, p1.y, p2.y);
       split_pair(v[4], v[5], p0.z, p1.z, p2.z);
@@ -1222,13 +1382,13 @@ __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __res
   }
 }
 
-template <int NH, int NG, int PL>
+template <int NH, int NG, int PL, bool H = false>
 static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = (size_t)(w_patch_entries(PL) + w_wsub_entries(PL)) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
   static bool lds_ready[64];
   // (NH = 2 carries 16 more accumulator registers: the BatchNorm parameters go to LDS there)
   constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0 || NH > 1 || PL == 2;
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL, H>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   const int tx = (a.Wo + W_TW - 1) / W_TW;
   // tiles per workgroup: the largest of CPX_BF3W_RUN .. 2 that divides the tiles of a row, else the whole row if it is short
@@ -1245,7 +1405,7 @@ static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL>), dim3((unsigned)blocks, a.groups / NG), dim3(512), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL, H>), dim3((unsigned)blocks, a.groups / NG), dim3(512), lds, s, a, wimg, td);
   return 0;
 }
 #ifndef CPX_BF3W_NH
@@ -1258,6 +1418,11 @@ static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
 static size_t bf3w_image3_bytes(const ConvArgs& a) { return (size_t)a.groups * (a.Cin / a.groups / KW) * 3 * 36 * (a.Cout / a.groups) * 16; }
 static size_t bf3w_image2_bytes(const ConvArgs& a) { return (size_t)a.groups * (a.Cin / a.groups / KW) * 3 * 24 * (a.Cout / a.groups) * 16; }
 static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
+  if (a.planes == 2 && a.half) {  // the fp16 image lies behind the two bf16 ones
+    const uint4* wh = wimg + (bf3w_image3_bytes(a) + bf3w_image2_bytes(a)) / 16;
+    if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1, 2, true>(a, wh, s);
+    return launch_bf3w_t<1, 1, 2, true>(a, wh, s);
+  }
   if (a.planes == 2) {
     const uint4* w2 = wimg + bf3w_image3_bytes(a) / 16;
     if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1, 2>(a, w2, s);
@@ -1269,14 +1434,14 @@ static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   return launch_bf3w_t<1, 1, 3>(a, wimg, s);
 }
 
-template <int NTN, int S, int NB, int TW, int CT, bool C8 = false, int PL = 3>
+template <int NTN, int S, int NB, int TW, int CT, bool C8 = false, int PL = 3, bool H = false>
 int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int TB = 128 / TW, TH = TB * NB;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
   size_t lds = ((size_t)(C8 ? 3 : 2 * PL) * PH * PW + (size_t)(C8 ? 30 : 18 * PL) * 32 * NTN) * 16;
   if (lds < (CT / 64) * 32 * 32 * sizeof(float)) lds = (CT / 64) * 32 * 32 * sizeof(float);
   static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL, H>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Wo + TW - 1) / TW;
   td.tiles_y = (a.Ho + TH - 1) / TH;
@@ -1286,7 +1451,7 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
-  hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL, H>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
   return 0;
 }
 
@@ -1374,12 +1539,22 @@ static bool flat_layer(const ConvArgs& a) {
   // ... and the stride-2 first convolution of stage 3 (conv_bf3_kernel<2,2,2,16,512>)
   return (a.stride == 1 && a.Cout / a.groups == 128) || (a.stride == 2 && bf3_strided(a));
 }
+// the per-channel weight scales of the fp16 image and their inverses: 2 x Cout floats behind the images (16-byte aligned)
+static size_t scales_bytes(const ConvArgs& a) { return ((size_t)2 * a.Cout * sizeof(float) + 15) / 16 * 16; }
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
   if (bf3_c8(a)) return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16;
-  if (bf3w_layer(a)) return bf3w_image3_bytes(a) + bf3w_image2_bytes(a);  // both math modes' images, one after the other
-  return image3_bytes(a) + (flat_layer(a) ? image3_bytes(a) / 3 * 2 : 0);
+  // the images of the three math modes one after the other: three bf16 planes, two bf16 planes, two fp16 planes, scales
+  if (bf3w_layer(a)) return bf3w_image3_bytes(a) + 2 * bf3w_image2_bytes(a) + scales_bytes(a);
+  return image3_bytes(a) + (flat_layer(a) ? 2 * (image3_bytes(a) / 3 * 2) + scales_bytes(a) : 0);
 }
 bool conv_bf3_two_planes(const ConvArgs& a) { return bf3w_layer(a) || flat_layer(a); }
+// where the fp16 image and its scales lie inside a two-plane layer's weight images
+static size_t half_image_offset(const ConvArgs& a) {
+  return bf3w_layer(a) ? bf3w_image3_bytes(a) + bf3w_image2_bytes(a) : image3_bytes(a) + image3_bytes(a) / 3 * 2;
+}
+static size_t scales_offset(const ConvArgs& a) {
+  return bf3w_layer(a) ? bf3w_image3_bytes(a) + 2 * bf3w_image2_bytes(a) : image3_bytes(a) + 2 * (image3_bytes(a) / 3 * 2);
+}
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   if (bf3_c8(a)) {
@@ -1390,27 +1565,45 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   }
   if (bf3w_layer(a)) {
     const size_t total32 = (size_t)a.groups * (cin_g / KW) * 36 * cout_g;
+    float* ws = reinterpret_cast<float*>(reinterpret_cast<char*>(wimg) + scales_offset(a));
+    hipLaunchKernelGGL(weight_scales_kernel, dim3((unsigned)((a.Cout + 255) / 256)), dim3(256), 0, s, a.weights, ws, ws + a.Cout,
+                       a.groups, 9 * cin_g, cout_g);
     hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
-                       reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g, 3);
+                       reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g, 3, nullptr);
     hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
-                       reinterpret_cast<uint4*>(wimg) + bf3w_image3_bytes(a) / 16, a.groups, cin_g, cout_g, 2);
+                       reinterpret_cast<uint4*>(wimg) + bf3w_image3_bytes(a) / 16, a.groups, cin_g, cout_g, 2, nullptr);
+    hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg) + half_image_offset(a) / 16, a.groups, cin_g, cout_g, 2, ws);
     return;
   }
   const size_t total = (size_t)a.groups * (cin_g / KC) * 18 * cout_g;
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
-                     reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g, 3);
-  if (flat_layer(a))  // the two-plane image of the layers the flattened kernel may take, behind the three-plane one
+                     reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g, 3, nullptr);
+  if (flat_layer(a)) {  // the two-plane images of the layers the flattened kernel may take, behind the three-plane one
+    float* ws = reinterpret_cast<float*>(reinterpret_cast<char*>(wimg) + scales_offset(a));
+    hipLaunchKernelGGL(weight_scales_kernel, dim3((unsigned)((a.Cout + 255) / 256)), dim3(256), 0, s, a.weights, ws, ws + a.Cout,
+                       a.groups, 9 * cin_g, cout_g);
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
-                       reinterpret_cast<uint4*>(wimg) + image3_bytes(a) / 16, a.groups, cin_g, cout_g, 2);
+                       reinterpret_cast<uint4*>(wimg) + image3_bytes(a) / 16, a.groups, cin_g, cout_g, 2, nullptr);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg) + half_image_offset(a) / 16, a.groups, cin_g, cout_g, 2, ws);
+  }
 }
-int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
+int launch_conv_bf3(const ConvArgs& a_in, const void* wimg, hipStream_t s) {
+  ConvArgs a = a_in;
   const int cout_g = a.Cout / a.groups;
+  if (a.half) {  // CPX_CNN_MATH_FP16X2: the two-plane layers only, with the network's overflow word
+    if (a.planes != 2 || !conv_bf3_two_planes(a) || a.ovf == nullptr) return -2;
+    a.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wimg) + scales_offset(a));
+    a.w_unscale = a.w_scale + a.Cout;
+  }
   // pixel offsets are formed with 24-bit multiplies (pix_off): a sample of 2^24 pixels or more is out of their range
   if ((long long)a.H * a.W >= (1 << 24) || (long long)a.Ho * a.Wo >= (1 << 24) || a.Cin >= (1 << 24) || a.Cout >= (1 << 24)) return -3;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
   if (bf3_c8(a)) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2, true>(a, w, s);
   if (a.stride == 2) {
     if (!bf3_strided(a)) return -2;
+    if (a.planes == 2 && a.half) return launch_bf3_t<2, 2, 2, 16, 512, false, 2, true>(a, w + half_image_offset(a) / 16, s);
     if (a.planes == 2 && flat_layer(a)) return launch_bf3_t<2, 2, 2, 16, 512, false, 2>(a, w + image3_bytes(a) / 16, s);
     return launch_bf3_t<2, 2, 2, 16, 512>(a, w, s);
   }
@@ -1426,10 +1619,13 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s) {
   // need 384 staged pixels and then fit only one N tile per workgroup: measured slower than the rectangular bands,
   // 399 vs 371 ms, the patch being activated and split by four column slices instead of two.)
   if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256)) {
+    if (a.planes == 2 && a.half) return launch_bf3flat_t<2, 256, 2, true>(a, w + half_image_offset(a) / 16, s);
     if (a.planes == 2 && flat_layer(a)) return launch_bf3flat_t<2, 256, 2>(a, w + image3_bytes(a) / 16, s);
     return launch_bf3flat_t<2, 256, 3>(a, w, s);
   }
   if (cout_g == 128) {
+    if (a.planes == 2 && a.half)
+      return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4, false, 2, true>(a, w + half_image_offset(a) / 16, s);
     if (a.planes == 2 && flat_layer(a))
       return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4, false, 2>(a, w + image3_bytes(a) / 16, s);
     return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);

@@ -190,6 +190,25 @@ struct ConvArgs {
   // bf16 planes per operand on the split-operand path: 0 / 3 = the exact three-way split, 2 = CPX_CNN_MATH_BF16X2
   // (the layers conv_bf3_two_planes() names; every other layer keeps three)
   int planes;
+  // CPX_CNN_MATH_FP16X2 (planes == 2 && half): the two planes are fp16 (11 + 11 significand bits, the products on
+  // v_mfma_f32_*_f16).  fp16 has a range: the activated input is multiplied by act_scale (a power of two: exact) before
+  // the split, the weights of output channel c by w_scale[c] (a power of two chosen per channel when the image is
+  // built); the accumulators then hold act_scale * w_scale[c] times the sum and the epilogue multiplies by
+  // act_unscale * w_unscale[c] (exact).  A scaled activation above fp16's largest finite value sets *ovf (atomicOr);
+  // a workgroup that finds *ovf set on entry returns at once -- the layer is then run again by the three-plane bf16
+  // kernel, which is launched right behind with guard = ovf and returns at once when *guard == 0.
+  int half;
+  float act_scale, act_unscale;
+  const float* w_scale;    // [Cout] 2^kw, behind the plane image
+  const float* w_unscale;  // [Cout] 2^-kw
+  int* ovf;
+  const int* guard;
+  // producer-side split (fp16x2, a block's first convolution feeding its second): out_planes = the output is stored as
+  // the NEXT layer's scaled fp16 planes (per pixel and channel quad 16 bytes: four hi halves, four lo halves) instead of
+  // float32, multiplied by out_act_scale first; in_planes = the input is in that form (no prologue, no split: the
+  // staging is a copy)
+  int out_planes, in_planes;
+  float out_act_scale;
 };
 struct HeadArgs {
   int N, HW, C, L;

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPX_ABI_VERSION 1
+#define CPX_ABI_VERSION 2
 
 typedef enum cpx_status {
   CPX_OK = 0,
@@ -601,12 +601,30 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* desc);
  *                        to nearest (16 significand bits, relative error <= 2^-16 per operand: 32 times finer than
  *                        TF32) and three products per K step; every other layer as BF16X3.  Logits within 1e-6 of the float32 forward on the test network
  *                        (tests/test_cnn_gpu.py, same 2e-4 bound as the other modes)
- * The default can be preset with the environment variable CPX_CNN_MATH=f32|bf16x3|bf16x2 (read by cpx_create). */
+ *   CPX_CNN_MATH_FP16X2  the same layers as BF16X2 take each operand as TWO fp16 terms rounded to nearest (11 + 11
+ *                        significand bits and the sign of the remainder: relative error <= 2^-22 per operand, the
+ *                        dropped lo x lo term <= 2^-22 of a product -- the level of the float32 accumulation error every
+ *                        mode carries) and three products per K step on v_mfma_f32_*_f16, the bf16 forms' rate.  fp16
+ *                        has a range, so the operands are scaled by powers of two (exact; undone in the epilogue): the
+ *                        weights per output channel when their image is built, the activated input per layer by a
+ *                        power of two a network derives from its BatchNorm parameters
+ *                        (cpx_cnn_set_activation_bounds; 1 for a bare cpx_conv2d).  A scaled activation beyond fp16's
+ *                        largest finite value never saturates silently: the kernel raises a device-side word and
+ *                        the layer -- and, inside cpx_cnn_forward, every later two-plane layer of that forward -- is
+ *                        run again by the BF16X3 kernel, which is launched behind every fp16 launch and returns at
+ *                        once while the word is clear (cpx_cnn_last_overflow reads the word).
+ *                        Every other layer as BF16X3.
+ * The default can be preset with the environment variable CPX_CNN_MATH=f32|bf16x3|bf16x2|fp16x2 (read by cpx_create). */
 #define CPX_CNN_MATH_F32 0
 #define CPX_CNN_MATH_BF16X3 1
 #define CPX_CNN_MATH_BF16X2 2
+#define CPX_CNN_MATH_FP16X2 3
 int cpx_set_cnn_math(cpx_handle* h, int mode);
 int cpx_get_cnn_math(const cpx_handle* h);
+/* CPX_CNN_MATH_FP16X2: *overflowed = 1 when the last cpx_cnn_forward (or bare cpx_conv2d) on this handle met an
+ * activation outside fp16's range and fell back to the BF16X3 kernels (results are correct either way; this is for
+ * tests and for whoever wonders where the time went).  Synchronises the handle's stream. */
+int cpx_cnn_last_overflow(cpx_handle* h, int* overflowed);
 /* relu(in * bn_scale + bn_shift) -> mean over H*W -> dense [C][L] + bias -> logits (and sigmoid probs if not NULL) */
 int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
@@ -676,6 +694,13 @@ typedef struct cpx_wrresnet_params {
 typedef struct cpx_cnn cpx_cnn;
 int cpx_cnn_create(cpx_handle* h, const cpx_wrresnet_params* params, cpx_cnn** out);
 void cpx_cnn_destroy(cpx_cnn* cnn);
+/* CPX_CNN_MATH_FP16X2: an upper bound of the ACTIVATED input of each 3x3 convolution of the blocks, in launch order
+ * ([stage][block][branch2a, branch2b]: n = 3 * blocks_per_stage * 2 values) -- e.g. max over channels of
+ * |beta| + 64 |gamma| of the BatchNorm in front of it (the folded scale / shift the parameter struct carries no longer
+ * say).  The network multiplies that input by the largest power of two (<= 2^14) that keeps the bound at or below 2^15
+ * before the fp16 split, so that small activations keep their low plane's bits; a bound that turns out too small costs
+ * time (the overflow rerun), never correctness.  Without this call the scale is 1. */
+int cpx_cnn_set_activation_bounds(cpx_cnn* cnn, const float* bounds, int n);
 /* in_dev float32 [N, H, W, in_channels] (NHWC, values 0..255) -> logits_dev [N, n_labels] and, when not NULL,
  * probs_dev (sigmoid). */
 int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, float* logits_dev, float* probs_dev);

@@ -42,9 +42,9 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=["bf16x3", "f32", "bf16x2"])
+@pytest.fixture(params=["bf16x3", "f32", "bf16x2", "fp16x2"])
 def math(engine, request):
-    """Both ways of multiplying float32 operands on the matrix cores (include/cpx.h: cpx_set_cnn_math)."""
+    """The ways of multiplying float32 operands on the matrix cores (include/cpx.h: cpx_set_cnn_math)."""
     engine.set_cnn_math(request.param)
     assert engine.get_cnn_math() == request.param
     yield request.param
@@ -135,7 +135,7 @@ def test_bf16x3_is_f32_accurate(engine):
                        torch.from_numpy(np.abs(k)).double().permute(3, 2, 0, 1), None, padding=1,
                        groups=2).permute(0, 2, 3, 1).numpy()
         errs = {}
-        for mode in ("f32", "bf16x3", "bf16x2"):
+        for mode in ("f32", "bf16x3", "bf16x2", "fp16x2"):
             engine.set_cnn_math(mode)
             xd = torch.from_numpy(x).to(dev)
             wd = torch.from_numpy(pack_conv(k)).to(dev)
@@ -148,7 +148,10 @@ def test_bf16x3_is_f32_accurate(engine):
             got = out.cpu().numpy().astype(np.float64)
             assert np.isfinite(got).all()
             errs[mode] = float((np.abs(got - want) / mag).max())
+            if mode == "fp16x2":  # (the operands lie inside fp16's range: these are the fp16 kernels' results, not the rerun's)
+                assert not engine.cnn_last_overflow()
         engine.set_cnn_math("bf16x3")
+        print("max |error| / accumulated magnitude vs float64, %d channels: %s" % (Cin, errs))
         # float32 accumulation of K = 9 * Cin / 2 terms: a few 2^-24 relative to the accumulated magnitude
         assert errs["f32"] < 4e-6 and errs["bf16x3"] < 4e-6, errs
         assert errs["bf16x3"] <= 2.0 * errs["f32"] + 2.0 ** -24, errs
@@ -159,6 +162,83 @@ def test_bf16x3_is_f32_accurate(engine):
         assert errs["bf16x2"] <= 3 * 2.0 ** -16, errs
         if Cin <= 128:
             assert errs["bf16x2"] > errs["bf16x3"], errs  # (it IS the other arithmetic)
+        # two fp16 planes rounded to nearest: 11 + 11 bits, each operand off by at most 2^-22 of itself (2^-25 absolute
+        # of the scaled value where the low plane is subnormal), the dropped lo x lo term at most 2^-22 of a product:
+        # the float32 accumulation's own error level, 64 times below bf16x2's
+        assert errs["fp16x2"] <= 2.0 * errs["f32"] + 2.0 ** -22, errs
+        assert errs["fp16x2"] < 4e-6 and errs["fp16x2"] < errs["bf16x2"] / 8, errs
+
+
+def test_fp16x2_out_of_range_reruns_in_bf16x3(engine):
+    """fp16 has a range: an activation the scaling cannot bring below 65504 must not saturate silently.  The fp16
+    kernel raises the device-side overflow word and the three-plane bf16 kernel, launched right behind it, computes
+    the layer again: same bits as the bf16x3 mode, and cpx_cnn_last_overflow says so."""
+    import torch
+
+    from cpx.ml_tools.wrresnet import ConvDesc, pack_conv
+
+    dev = engine.device
+    for Cin, Cout, H, W, stride in ((64, 64, 20, 24, 1), (128, 128, 20, 17, 1), (256, 256, 9, 11, 1), (64, 128, 21, 18, 2)):
+        rng = np.random.default_rng(Cin + stride)
+        x = rng.normal(0, 1, size=(2, H, W, Cin)).astype(np.float32)
+        k = rng.normal(0, 0.1, size=(3, 3, Cin // 2, Cout)).astype(np.float32)
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        outs = {}
+        for big in (False, True):
+            xx = x.copy()
+            if big:
+                xx[1, H // 2, W // 3, 5] = 1.0e5  # one element beyond fp16's largest finite value
+            for mode in ("bf16x3", "fp16x2"):
+                engine.set_cnn_math(mode)
+                xd = torch.from_numpy(xx).to(dev)
+                wd = torch.from_numpy(pack_conv(k)).to(dev)
+                out = torch.full((2, Ho, Wo, Cout), np.nan, dtype=torch.float32, device=dev)
+                ptr = lambda v: C.c_void_p(v.data_ptr())
+                d = ConvDesc(2, H, W, Cin, Cout, 2, 3, stride, 1, 0, ptr(xd), ptr(out), ptr(wd), None, None, None, None, None)
+                torch.cuda.synchronize()
+                assert engine.lib.cpx_conv2d(engine.h, C.byref(d)) == 0, engine._err()
+                engine.synchronize()
+                outs[(big, mode)] = out.cpu().numpy()
+                if mode == "fp16x2":
+                    assert engine.cnn_last_overflow() == big
+        engine.set_cnn_math("bf16x3")
+        assert np.isfinite(outs[(True, "fp16x2")]).all()
+        assert np.array_equal(outs[(True, "fp16x2")], outs[(True, "bf16x3")])       # the rerun IS the bf16x3 kernel
+        assert not np.array_equal(outs[(False, "fp16x2")], outs[(False, "bf16x3")])  # in range: the other arithmetic
+        assert float(np.abs(outs[(False, "fp16x2")] - outs[(False, "bf16x3")]).max()) <= 2e-5 * max(
+            1.0, float(np.abs(outs[(False, "bf16x3")]).max()))
+
+
+def test_fp16x2_network_overflow_is_loud_and_correct(engine):
+    """The whole network in fp16x2 on inputs 1000 times the sensor's range: some layer's activations leave fp16's
+    range, the forward finishes on the bf16x3 kernels and the logits still match the float32 restatement."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(77)
+    x = rng.uniform(0, 255, size=(2, 160, 160, 2)).astype(np.float32)
+    w = co.calibrate_bn(wr.random_weights(17, seed=9), x)
+    engine.set_cnn_math("fp16x2")
+    net = wr.WRResNetDevice(engine, w, 17)
+    logits, _ = net.forward(torch.from_numpy(x).to(engine.device))
+    assert not engine.cnn_last_overflow()
+    want, _ = co.forward(w, x)
+    assert float(np.abs(logits.cpu().numpy() - want).max()) <= LOGIT_ATOL
+    xb = x * np.float32(1000.0)
+    logits_b, _ = net.forward(torch.from_numpy(xb).to(engine.device))
+    assert engine.cnn_last_overflow()
+    want_b, _ = co.forward(w, xb)
+    got_b = logits_b.cpu().numpy()
+    assert np.isfinite(got_b).all()
+    assert float(np.abs(got_b - want_b).max()) <= 2e-4 * max(1.0, float(np.abs(want_b).max()))
+    # the word belongs to ONE forward: the next one, in range again, runs on the fp16 kernels
+    logits_c, _ = net.forward(torch.from_numpy(x).to(engine.device))
+    assert not engine.cnn_last_overflow()
+    assert torch.equal(logits_c, logits)
+    net.close()
+    engine.set_cnn_math("bf16x3")
 
 
 @pytest.mark.parametrize("fs,n", [(32, 3), (64, 1)])
@@ -249,3 +329,23 @@ def test_head_variants_match_oracle(dense_sizes, activation):
         assert np.allclose(probs.cpu().numpy().sum(axis=1), 1.0, atol=1e-5)
     net.close()
     eng.close()
+
+
+def test_calibrate_bn_device_matches_oracle(engine):
+    """wrresnet.calibrate_bn_device (the set-up utility bench.py uses to give its synthetic network BatchNorm statistics
+    that fit its data) against the oracle's calibration of the same weights on the same batch."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(31)
+    x = rng.uniform(0, 255, size=(4, 160, 160, 2)).astype(np.float32)
+    engine.set_cnn_math("bf16x3")
+    got = wr.calibrate_bn_device(engine, wr.random_weights(17, seed=4), torch.from_numpy(x).to(engine.device))
+    want = co.calibrate_bn(wr.random_weights(17, seed=4), x)
+    for k, v in want.items():
+        if k.endswith("moving_mean") or k.endswith("moving_variance"):
+            np.testing.assert_allclose(got[k], v, rtol=2e-3, atol=2e-3, err_msg=k)
+    logits, _ = co.forward(got, x)
+    assert float(np.abs(logits).max()) < 50.0
