@@ -61,7 +61,85 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA
 BF16X3_PRODUCTS = 6            # bf16 MFMA products per float32 multiply-add (csrc/cpx_cnn_bf3.hip)
+# 16-bit MFMA products per float32 multiply-add in the stride-1 layers of stages 2-4, by math mode (include/cpx.h);
+# the fp16 MFMA forms run at the bf16 forms' rate (MI355X_MICROARCH.md, matrix table): same 2500 TFLOP/s dense peak
+PRODUCTS = {"bf16x3": 6, "bf16x2": 3, "fp16x2": 3}
+DEFAULT_CNN_MATH = "fp16x2"
+MATH_DTYPE = {
+    "fp16x2": "stride-1 3x3 convs of stages 2-4 (+ the stride-2 one): two fp16 planes per operand rounded to nearest "
+              "(11 + 11 significand bits), power-of-two range scaling, 3 fp16 MFMAs per K step, device-side rerun in the "
+              "exact split if an activation leaves fp16's range; the other 3x3 convs: exact 3-way bf16 split; f32 accumulate "
+              "-- float32-class: against a float64 convolution at the exact split's and the fp32 MFMA's error level "
+              "(tests/test_cnn_gpu.py::test_bf16x3_is_f32_accurate)",
+    "bf16x3": "3x3 convs: exact 3-way bf16 operand split, 6 bf16 MFMAs per K step, f32 accumulate",
+    "bf16x2": "stride-1 3x3 convs of stages 2-4: two bf16 planes per operand rounded to nearest, 3 bf16 MFMAs per K step; "
+              "the other 3x3 convs: exact 3-way split; f32 accumulate",
+    "f32": "f32 MFMA"}
 N_LABELS = 17
+
+
+def conv_layer_table(conv, math, steps):
+    """Every convolution shape of the step (key = Cin_g * 10000 + Cout_g * 10 + stride, + 5 for 1x1) with the matrix pipe
+    it runs on in this math mode, its float32-equivalent TFLOP/s and the fraction of THAT pipe's dense peak -- so that
+    the layers on the slow pipe (the stride-3 convolution, the 1x1 shortcuts when they are launches of their own) do not
+    hide inside an average."""
+    out = {}
+    for k, (n, ms, fl) in sorted(conv.items()):
+        if ms <= 0:
+            continue
+        cin_g, cout_g, st = k // 10000, (k % 10000) // 10, (k % 10) % 5
+        one = (k % 10) >= 5
+        if cin_g == 1:
+            pipe, peak = "vector (direct kernel: 8 B in, 64 B out per pixel -- HBM-bound)", None
+        elif math == "f32" or one or st == 3:
+            pipe, peak = "fp32 MFMA", MFMA_F32_PEAK_TFLOPS
+        elif cin_g == 8:
+            pipe, peak = "bf16 MFMA, 6 products (exact split)", MFMA_BF16_PEAK_TFLOPS / 6
+        else:
+            pr = PRODUCTS[math]
+            pipe, peak = "%s MFMA, %d products" % ("fp16" if math == "fp16x2" else "bf16", pr), MFMA_BF16_PEAK_TFLOPS / pr
+        tf = fl / (ms / 1e3) / 1e12
+        out[str(k)] = {"channels_per_group": [cin_g, cout_g], "stride": st, "kernel": "1x1" if one else "3x3",
+                       "launches_per_step": n // max(steps, 1), "ms_per_step": round(ms / steps, 2),
+                       "tflops_f32_equivalent": round(tf, 2), "pipe": pipe,
+                       "frac_of_pipe_peak": round(tf / peak, 4) if peak else None}
+    return out
+
+
+def bf3w_kernel_name(cout_g, math):
+    """The instantiation of conv_bf3w_kernel a stride-1 layer with 32 / 64 channels per group runs, as the rocprofv3
+    kernel trace prints it -- the rule of csrc/cpx_cnn_bf3.hip:launch_bf3w_t: <WALK, LDSBN, NH, NG, PL, H, PERSIST> with
+    NH = 2 for 64 columns per group, PL planes per operand, H = fp16 planes, LDSBN = NH > 1 or PL == 2."""
+    nh = 2 if cout_g == 64 else 1
+    pl = 2 if PRODUCTS[math] == 3 else 3
+    b = lambda v: "true" if v else "false"
+    return "conv_bf3w_kernel<false, %s, %d, 1, %d, %s, false>" % (b(nh > 1 or pl == 2), nh, pl, b(math == "fp16x2"))
+
+
+def synthetic_network_weights(torch, wr, eng, frames, offs, meta, outputs, frame_size, n_clips=96, n_cal=48, seed=0):
+    """Seeded random WR-ResNet-22-4 kernels with BatchNorm statistics fitted to THIS workload's own network inputs (the
+    crops of the first clips), as training would have left them: activations and logits are O(1) as in any trained
+    model (plain random statistics give logits beyond 100 and activations no BatchNorm would let through).
+    cpx.ml_tools.wrresnet.calibrate_bn_device runs the calibration through the HIP convolutions; set-up, untimed."""
+    from cpx.pipeline import BatchPipeline
+
+    w = wr.random_weights(N_LABELS, seed=seed)
+    nb = min(n_clips, len(offs) - 1)
+    T = int(offs[1] - offs[0])
+    pipe0 = BatchPipeline(eng, None, n_labels=N_LABELS, fp_index=4, cnn_chunk=n_cal, frame_size=frame_size)
+    r = pipe0.run(frames, offs[: nb + 1], meta[: int(offs[nb])], outputs=outputs, keep_samples=True)
+    if r.samples_dev is None or int(r.samples_dev.shape[0]) < 4:
+        return w
+    x = r.samples_dev[:n_cal].contiguous()
+    prev = eng.get_cnn_math()
+    eng.set_cnn_math("bf16x3")
+    try:
+        w = wr.calibrate_bn_device(eng, w, x, N_LABELS)
+    finally:
+        eng.set_cnn_math(prev)
+    del r, x
+    torch.cuda.empty_cache()
+    return w
 
 
 def usable_cpus():
@@ -557,7 +635,7 @@ class Config4Workload:
     H, W = 120, 160
 
     def __init__(self, torch, device, local_rank, rank, world, n_clips, seed=1234, lo=90, hi=540,
-                 sub_frames=2048 * 270, cnn_chunk=2048, frame_size=32, cnn_math="bf16x3", weights=None, n_labels=N_LABELS):
+                 sub_frames=2048 * 270, cnn_chunk=2048, frame_size=32, cnn_math=DEFAULT_CNN_MATH, weights=None, n_labels=N_LABELS):
         import numpy as np
 
         from cpx.engine import TrackEngine
@@ -574,10 +652,6 @@ class Config4Workload:
         self.eng = TrackEngine(width=self.W, height=self.H, model="lepton3", device=local_rank, max_components=64,
                                max_frames=max(int(hi), 45))
         self.eng.set_cnn_math(cnn_math)
-        self.weights = weights if weights is not None else wr.random_weights(n_labels, seed=0)
-        self.net = wr.WRResNetDevice(self.eng, self.weights, n_labels)
-        self.pipe = BatchPipeline(self.eng, self.net, n_labels=n_labels, fp_index=4, cnn_chunk=cnn_chunk,
-                                  frame_size=frame_size)
         self.batches = []  # (clip ids tensor, frames, offs, meta)
         cap = 0
         for ids in self.subs:
@@ -594,6 +668,16 @@ class Config4Workload:
         self.comps = torch.empty(max(cap, 1) * 64 * 8, dtype=torch.int32, device=device)
         self.info = torch.empty(max(cap, 1) * 20, dtype=torch.int32, device=device)
         self.filt = torch.empty((max(cap, 1), self.H, self.W), dtype=torch.float32, device=device)
+        if weights is None and self.batches:  # BatchNorm statistics fitted to the first batch's own crops (untimed set-up)
+            _, fr0, offs0, meta0 = self.batches[0]
+            tot0 = int(offs0[-1])
+            weights = synthetic_network_weights(torch, wr, self.eng, fr0, offs0, meta0,
+                                                (self.comps[: tot0 * 64 * 8], self.info[: tot0 * 20], None, self.filt[:tot0], None),
+                                                frame_size)
+        self.weights = weights if weights is not None else wr.random_weights(n_labels, seed=0)
+        self.net = wr.WRResNetDevice(self.eng, self.weights, n_labels)
+        self.pipe = BatchPipeline(self.eng, self.net, n_labels=n_labels, fp_index=4, cnn_chunk=cnn_chunk,
+                                  frame_size=frame_size)
         self.frames_local = int(sum(int(self.lengths[i]) for i in self.mine))
         self.frames_total = int(self.lengths.sum())
         self.last = None
@@ -675,7 +759,7 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu, a
                 "value": round(wl.frames_total * steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
                 "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": "u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)" % args.cnn_math,
+                "dtype": "u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)" % MATH_DTYPE[args.cnn_math],
                 "data": "synthetic",
                 "config": {"workload": "BASELINE configs[3]: %d seeded synthetic clips of 90-540 frames, LPT-sharded by frame "
                                        "count over the ranks, device batches of <= %d frames, track -> 25-frame segments -> "
@@ -713,7 +797,7 @@ def main():
                     help="samples per CNN forward (default 2048 at frame size 32 = 54 GB of activations, 512 at 64)")
     ap.add_argument("--frame-size", type=int, default=32, choices=(32, 64),
                     help="side of one tile of the 5x5 network input (SURVEY 8(d) config 3 asks for 32 and 64)")
-    ap.add_argument("--cnn-math", choices=("bf16x3", "f32", "bf16x2"), default="bf16x3",
+    ap.add_argument("--cnn-math", choices=("fp16x2", "bf16x3", "f32", "bf16x2"), default=DEFAULT_CNN_MATH,
                     help="how the 3x3 stride-1 convolutions multiply their float32 operands (include/cpx.h: cpx_set_cnn_math)")
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="groups of clips per step: the track stage of group k+1 is issued on a second stream beside the "
@@ -822,7 +906,8 @@ def main():
     filt = torch.empty((total, H, W), dtype=torch.float32, device=device)
     labels = None if e2e else torch.empty((total, H, W), dtype=torch.int32, device=device)
     outputs = (comps, info, labels, filt, None)
-    weights = wr.random_weights(N_LABELS, seed=0)
+    weights = (synthetic_network_weights(torch, wr, eng, frames, offs, meta, outputs, args.frame_size) if e2e
+               else wr.random_weights(N_LABELS, seed=0))
     # the network lives on a second handle (= second HIP stream) so that the HBM-bound track stage of one group of
     # clips overlaps the MFMA-bound network of the previous group (BatchPipeline sub_batches)
     overlap = e2e and args.sub_batches > 1
@@ -920,15 +1005,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)"
-                      % ("3x3 convs: exact 3-way bf16 operand split, 6 bf16 MFMAs per K step, f32 accumulate"
-                         if args.cnn_math == "bf16x3" else
-                         "stride-1 3x3 convs of stages 2-4: two bf16 planes per operand rounded to nearest, 3 bf16 MFMAs per K step; "
-                         "the other 3x3 convs: exact 3-way split; f32 accumulate" if args.cnn_math == "bf16x2" else "f32 MFMA")) if e2e else
-                     "u16/i32 (f32 normalise, f64 background weights)",
+                      % MATH_DTYPE[args.cnn_math]) if e2e else "u16/i32 (f32 normalise, f64 background weights)",
             "data": "synthetic",
             "config": {
                 "workload": ("synthetic 160x120 uint16 clips -> track (BASELINE configs[1]) -> 25-frame segments -> "
-                             "crop/tile + WR-ResNet-22-4 forward (configs[2]/[3]), seeded random weights") if e2e else
+                             "crop/tile + WR-ResNet-22-4 forward (configs[2]/[3]), seeded random kernels with BatchNorm "
+                             "statistics fitted to the workload's own crops") if e2e else
                             "BASELINE.json configs[1]: synthetic 160x120 uint16 clips, background + region-label kernels",
                 "clips_per_gpu": B,
                 "frames_per_clip": T,
@@ -945,8 +1027,8 @@ def main():
             key = 32 * 10000 + 32 * 10 + 1  # the stage-2 3x3 convolutions (32 -> 32 channels per group, stride 1)
             key3 = 64 * 10000 + 64 * 10 + 1  # the stage-3 ones: same FLOPs per sample, half the bytes
             if key in conv and conv[key][1] > 0:
-                bf3 = args.cnn_math in ("bf16x3", "bf16x2")
-                products = 3 if args.cnn_math == "bf16x2" else BF16X3_PRODUCTS
+                bf3 = args.cnn_math in PRODUCTS
+                products = PRODUCTS.get(args.cnn_math, BF16X3_PRODUCTS)
                 area = (args.frame_size / 32.0) ** 2  # map area relative to the 160 x 160 maps of frame size 32
                 side = 5 * args.frame_size
                 # input + output (+ residual in 3 of the 5 launches of a shape per forward), float32 NHWC
@@ -972,9 +1054,8 @@ def main():
                     samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
                     algo_bytes = l2["algorithmic_bytes_per_launch"]
                     traffic = l2["traffic"]
-                    what = ("conv_bf3w_kernel<false,false,1,1> (the 16x16x32 bf16 MFMA form of the split-operand kernel, one "
-                            "32-column slice per workgroup: the stage-2 3x3 convs, 64->64 ch at %dx%d, groups 2)" % (side, side)
-                            ).replace("1,1>", "1,1,%d>" % (products // 3 + 1))  # (last parameter: bf16 planes per operand)
+                    what = ("%s (the 16x16x32 MFMA form of the split-operand kernel, one 32-column slice per workgroup: the "
+                            "stage-2 3x3 convs, 64->64 ch at %dx%d, groups 2)" % (bf3w_kernel_name(32, args.cnn_math), side, side))
                 else:
                     n, ms, fl = conv[key]
                     samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
@@ -983,25 +1064,36 @@ def main():
                     what = "conv_mfma_kernel<8,1,1,3,2,16> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)" % (side, side)
                 tf = fl / (ms / 1e3) / 1e12
                 peak = round(MFMA_BF16_PEAK_TFLOPS / products, 1) if bf3 else MFMA_F32_PEAK_TFLOPS
+                hbm_gbs = algo_bytes / (ms / n / 1e3) / 1e9
+                # which roof binds: with six products per multiply-add the matrix pipe (0.44 of its roof against 0.4 of
+                # HBM's); with three the same layer moves the same bytes in 0.6 of the time and sits closer to the HBM roof
+                # than to the halved matrix one -- the object reports the nearer roof and keeps the other beside it
+                hbm_bound = bf3 and hbm_gbs / HBM_PEAK_GBS > tf / peak
                 line["roofline"] = {"kernel": what,
-                                    "bound": "mfma", "achieved": round(tf, 2), "peak": peak,
-                                    "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                    "bound": "hbm" if hbm_bound else "mfma",
+                                    "achieved": round(hbm_gbs, 1) if hbm_bound else round(tf, 2),
+                                    "peak": HBM_PEAK_GBS if hbm_bound else peak,
+                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                                    "frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if hbm_bound else round(tf / peak, 4),
+                                    "mfma": {"achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
                                     "traffic": traffic,
                                     "traffic_source": PMC_NOTE if traffic is not None else None,
                                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
                                     "algorithmic_flops_per_launch": fl / n,
                                     "algorithmic_bytes_per_launch": algo_bytes,
-                                    "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / %d products per float32 multiply-add" % products
-                                                  if bf3 else "dense fp32-input MFMA peak"),
+                                    "peak_note": (("HBM3E 8 TB/s against the launch's algorithmic bytes (input + output + residual, "
+                                                   "float32 NHWC); mfma: " if hbm_bound else "") +
+                                                  ("dense 16-bit MFMA peak 2500 TFLOP/s / %d products per float32 multiply-add" % products
+                                                   if bf3 else "dense fp32-input MFMA peak")),
                                     "hbm_GBps_algorithmic": round(algo_bytes / (ms / n / 1e3) / 1e9, 1),
                                     "hbm_frac": round(algo_bytes / (ms / n / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "stage2_tflops": round(conv[key][2] / (conv[key][1] / 1e3) / 1e12, 2)}
                 if bf3 and key3 in conv:
                     nb, msb, flb = conv[key][0] + conv[key3][0], conv[key][1] + conv[key3][1], conv[key][2] + conv[key3][2]
                     line["roofline"]["second_instantiation"] = dict(
-                        {"kernel": ("conv_bf3w_kernel<false,true,2,1> (both 32-column slices of a group from one staged patch: the "
-                                    "stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)" % (side // 2, side // 2)
-                                    ).replace("2,1>", "2,1,%d>" % (products // 3 + 1))}, **l3)
+                        {"kernel": ("%s (both 32-column slices of a group from one staged patch: the stage-3 3x3 convs, "
+                                    "128->128 ch at %dx%d, groups 2)" % (bf3w_kernel_name(64, args.cnn_math), side // 2, side // 2))},
+                        **l3)
                     line["roofline"]["both_instantiations"] = {
                         "what": "all conv_bf3w_kernel launches of the step (the accounting of rounds 2-3, one instantiation then)",
                         "achieved": round(flb / (msb / 1e3) / 1e12, 2), "frac": round(flb / (msb / 1e3) / 1e12 / peak, 4),
@@ -1014,7 +1106,8 @@ def main():
                                "conv_tflops_all_layers": round(tot_fl / (tot_ms / 1e3) / 1e12, 2),
                                "track_kernel_ms_per_step": round(kernel_ms / args.steps, 2),
                                "math": args.cnn_math,
-                               "layers_ms_per_step": {str(k): round(v[1] / args.steps, 2) for k, v in sorted(conv.items())}}
+                               "layers_ms_per_step": {str(k): round(v[1] / args.steps, 2) for k, v in sorted(conv.items())},
+                               "layers": conv_layer_table(conv, args.cnn_math, args.steps)}
             else:
                 line["roofline"] = track_roof
             line["roofline_track"] = track_roof
@@ -1030,46 +1123,56 @@ def main():
             # (c) the opt-in math mode CPX_CNN_MATH_BF16X2 over the headline's own step: stages 2-4 with two bf16 planes
             #     per operand rounded to nearest and three products per K step (include/cpx.h) -- its rate, and how far
             #     its logits are from the default mode's on the step's own classified segments
-            if args.cnn_math == "bf16x3" and not overlap:
+            if args.cnn_math in PRODUCTS and not overlap:
                 ref = state["res"]
                 ref_logits, ref_probs = ref.logits.clone(), ref.probs.clone()
-                eng.set_cnn_math("bf16x2")
-                pipe.run(frames, offs, meta, outputs=outputs)                  # warm-up
-                eng.conv_timing(True)
-                torch.cuda.synchronize(device)
-                t1 = time.perf_counter()
-                r2 = pipe.run(frames, offs, meta, outputs=outputs)
-                torch.cuda.synchronize(device)
-                dt2 = time.perf_counter() - t1
-                c2 = eng.conv_timing()
-                eng.conv_timing(False)
-                eng.set_cnn_math("bf16x3")
-                k2, k3 = 32 * 10000 + 32 * 10 + 1, 64 * 10000 + 64 * 10 + 1
-                leg = {"what": "the same step with CPX_CNN_MATH=bf16x2 (opt-in): the stride-1 3x3 layers of stages 2-4 multiply two "
-                               "bf16 planes per operand, rounded to nearest (<= 2^-16 relative per operand), in three "
-                               "products per K step instead of six; every other layer as the default", "frames_per_s": round(B * T / dt2, 1), "ms_per_step": round(dt2 * 1e3, 2),
-                       "classified_segments": int(r2.n_samples),
-                       "conv_time_ms_per_step": round(sum(v[1] for v in c2.values()), 2),
-                       "samples_per_s": round(int(r2.n_samples) / (sum(v[1] for v in c2.values()) / 1e3), 1),
-                       "max_abs_logit_difference_to_default": float((r2.logits - ref_logits).abs().max()),
-                       "max_abs_probability_difference_to_default": float((r2.probs - ref_probs).abs().max()),
-                       "max_abs_logit": float(ref_logits.abs().max()),
-                       "tracks": int(ref.best.numel())}
-                # tracks whose best label changed, and how close their two best scores were in the default mode (seeded
-                # random weights: near-ties exist; a real model's margins are what its accuracy rests on)
-                moved = (r2.best != ref.best).nonzero().flatten()
-                leg["tracks_with_another_best_label"] = int(moved.numel())
-                if moved.numel():
-                    top2 = ref.scores[moved].float().topk(2, dim=1).values
-                    leg["largest_score_margin_among_them"] = float((top2[:, 0] - top2[:, 1]).max())
-                for name, k in (("stage2", k2), ("stage3", k3), ("stage4", 128 * 10000 + 128 * 10 + 1)):
-                    if k in c2 and c2[k][1] > 0:
-                        tfe = c2[k][2] / (c2[k][1] / 1e3) / 1e12
-                        leg[name] = {"float32_equivalent_tflops": round(tfe, 2),
-                                     "frac_of_three_product_peak": round(tfe / (MFMA_BF16_PEAK_TFLOPS / 3), 4),
-                                     "avg_launch_us": round(c2[k][1] / c2[k][0] * 1e3, 2)}
-                line["bf16x2"] = leg
-                del ref_logits, ref_probs, r2
+                ref_overflow = eng.cnn_last_overflow() if args.cnn_math == "fp16x2" else False
+                line["cnn"]["fp16_overflow_rerun_in_last_forward"] = bool(ref_overflow)
+                what = {"bf16x3": "the exact mode: every operand split into three bf16 planes, six products per K step",
+                        "bf16x2": "opt-in: the stride-1 3x3 layers of stages 2-4 multiply two bf16 planes per operand, rounded "
+                                  "to nearest (<= 2^-16 relative per operand), in three products per K step; NOT float32 per element",
+                        "fp16x2": "two fp16 planes per operand (<= 2^-22 relative per operand), three products per K step"}
+                for other in ("bf16x3", "bf16x2", "fp16x2"):
+                    if other == args.cnn_math:
+                        continue
+                    eng.set_cnn_math(other)
+                    pipe.run(frames, offs, meta, outputs=outputs)                  # warm-up
+                    eng.conv_timing(True)
+                    torch.cuda.synchronize(device)
+                    t1 = time.perf_counter()
+                    r2 = pipe.run(frames, offs, meta, outputs=outputs)
+                    torch.cuda.synchronize(device)
+                    dt2 = time.perf_counter() - t1
+                    c2 = eng.conv_timing()
+                    eng.conv_timing(False)
+                    eng.set_cnn_math(args.cnn_math)
+                    k2, k3 = 32 * 10000 + 32 * 10 + 1, 64 * 10000 + 64 * 10 + 1
+                    leg = {"what": "the same step with CPX_CNN_MATH=%s (%s); every other layer as in the headline's mode (%s)"
+                                   % (other, what[other], args.cnn_math),
+                           "frames_per_s": round(B * T / dt2, 1), "ms_per_step": round(dt2 * 1e3, 2),
+                           "classified_segments": int(r2.n_samples),
+                           "conv_time_ms_per_step": round(sum(v[1] for v in c2.values()), 2),
+                           "samples_per_s": round(int(r2.n_samples) / (sum(v[1] for v in c2.values()) / 1e3), 1),
+                           "max_abs_logit_difference_to_headline_mode": float((r2.logits - ref_logits).abs().max()),
+                           "max_abs_probability_difference_to_headline_mode": float((r2.probs - ref_probs).abs().max()),
+                           "max_abs_logit": float(ref_logits.abs().max()),
+                           "tracks": int(ref.best.numel())}
+                    # tracks whose best label changed, and how close their two best scores were in the headline's mode
+                    # (seeded random kernels: near-ties exist; a real model's margins are what its accuracy rests on)
+                    moved = (r2.best != ref.best).nonzero().flatten()
+                    leg["tracks_with_another_best_label"] = int(moved.numel())
+                    if moved.numel():
+                        top2 = ref.scores[moved].float().topk(2, dim=1).values
+                        leg["largest_score_margin_among_them"] = float((top2[:, 0] - top2[:, 1]).max())
+                    for name, k in (("stage2", k2), ("stage3", k3), ("stage4", 128 * 10000 + 128 * 10 + 1)):
+                        if k in c2 and c2[k][1] > 0:
+                            tfe = c2[k][2] / (c2[k][1] / 1e3) / 1e12
+                            leg[name] = {"float32_equivalent_tflops": round(tfe, 2),
+                                         "frac_of_pipe_peak": round(tfe / (MFMA_BF16_PEAK_TFLOPS / PRODUCTS[other]), 4),
+                                         "avg_launch_us": round(c2[k][1] / c2[k][0] * 1e3, 2)}
+                    line[other] = leg
+                    del r2
+                del ref_logits, ref_probs
             net.close()
             nb = min(B, 512)
             o2 = offs[: nb + 1]
@@ -1166,7 +1269,8 @@ def main():
             if k2 in c64 and k3 in c64 and c64[k2][1] + c64[k3][1] > 0:
                 tf64 = (c64[k2][2] + c64[k3][2]) / ((c64[k2][1] + c64[k3][1]) / 1e3) / 1e12
                 f64["stage2_3_conv_tflops"] = round(tf64, 2)
-                f64["stage2_3_conv_frac"] = round(tf64 / (MFMA_BF16_PEAK_TFLOPS / BF16X3_PRODUCTS), 4)
+                f64["stage2_3_conv_frac"] = round(tf64 / (MFMA_BF16_PEAK_TFLOPS / PRODUCTS.get(args.cnn_math, BF16X3_PRODUCTS)), 4)
+                f64["math"] = args.cnn_math
             line["fs64"] = f64
             net64.close()
     # ---- after the timed region, in the same process(es): what the headline does not cover ----

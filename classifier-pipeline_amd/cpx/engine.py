@@ -404,14 +404,15 @@ class TrackEngine:
     THUMB_TIERS = ((46, 2304), (80, 4608))
 
     CNN_MATH = {"f32": 0, "bf16x3": 1, "bf16x2": 2, "fp16x2": 3}
+    DEFAULT_CNN_MATH = "fp16x2"  # what cpx_create sets unless CPX_CNN_MATH says otherwise
 
     def set_cnn_math(self, mode):
-        """"f32": v_mfma_f32_32x32x2_f32; "bf16x3" (default): exact three-way bf16 split of the float32 operands on
-        the bf16 matrix pipe; "bf16x2" (opt-in): stages 2-3 on two rounded bf16 planes and three products -- not
-        float32 per element (<= 3 x 2^-16), logits within the same bound; "fp16x2": the same layers on two rounded
-        fp16 planes (11 + 11 bits: 2^-22 per operand), operands scaled by powers of two into fp16's range, a
-        device-side rerun in bf16x3 if an activation leaves it (include/cpx.h: cpx_set_cnn_math).  Same inputs,
-        outputs and logit tolerance."""
+        """"f32": v_mfma_f32_32x32x2_f32; "bf16x3": exact three-way bf16 split of the float32 operands on the bf16
+        matrix pipe (six products); "bf16x2" (opt-in): stages 2-4 on two rounded bf16 planes and three products -- not
+        float32 per element (<= 3 x 2^-16), logits within the same bound; "fp16x2" (default): the same layers on two
+        rounded fp16 planes (11 + 11 bits: 2^-22 per operand, the float32 kernels' own error level against a float64
+        convolution), operands scaled by powers of two into fp16's range, a device-side rerun in bf16x3 if an
+        activation leaves it (include/cpx.h: cpx_set_cnn_math).  Same inputs, outputs and logit tolerance."""
         rc = self.lib.cpx_set_cnn_math(self.h, self.CNN_MATH[mode])
         if rc != 0:
             raise CpxError(rc, self._err())

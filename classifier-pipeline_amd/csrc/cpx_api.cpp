@@ -60,11 +60,12 @@ struct cpx_handle {
   int last_B = 0;  // clips of the last track call: whose state cpx_get_background / CPX_TRACK_KEEP_BACKGROUND refer to
   struct StagedBackground { std::vector<uint16_t> bg, kcnt; double average; };
   std::map<int, StagedBackground> staged_bg;  // cpx_set_background: applied by the next track call
-  int cnn_math = CPX_CNN_MATH_BF16X3;    // cpx_set_cnn_math / CPX_CNN_MATH
+  int cnn_math = CPX_CNN_MATH_FP16X2;    // cpx_set_cnn_math / CPX_CNN_MATH (the default: include/cpx.h)
   bool fuse_shortcut = true;             // CPX_CNN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts as launches of their own
   void* bf3_scratch = nullptr;           // split weights of a cpx_conv2d call that brought none
   size_t bf3_scratch_bytes = 0;
   int* cnn_ovf = nullptr;                // CPX_CNN_MATH_FP16X2: the overflow word of the forward (or bare convolution) in flight
+  bool planes_handover = true;           // CPX_CNN_PLANES_HANDOVER=0: fp16x2 keeps `mid` float32 (every layer splits its own input)
   unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
   size_t ir_scratch_bytes = 0;
   uint32_t* ir_bitmap = nullptr;
@@ -292,6 +293,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   if (const char* env = std::getenv("CPX_TRACK_SPLIT_MIN_CLIPS")) h->split_min_clips = std::atoi(env);
   if (const char* env = std::getenv("CPX_TRACK_PER_STEP")) h->track_per_step = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_FUSE_SHORTCUT")) h->fuse_shortcut = std::atoi(env) != 0;
+  if (const char* env = std::getenv("CPX_CNN_PLANES_HANDOVER")) h->planes_handover = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_MATH")) {
     if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
     else if (!std::strcmp(env, "bf16x3")) h->cnn_math = CPX_CNN_MATH_BF16X3;
@@ -813,6 +815,10 @@ static bool split_math(const cpx_handle* h) { return h->cnn_math != CPX_CNN_MATH
 struct conv_half {
   float act_scale = 1.0f;   // power of two the activated input is multiplied by before the fp16 split
   bool keep_flag = false;   // the overflow word belongs to the forward in flight (cleared once, at its start)
+  // producer-side split between a block's two convolutions (cpx_cnn_forward decides; ConvArgs::out_planes / in_planes)
+  bool out_planes = false;  // store the output as the next layer's fp16 planes, scaled by out_act_scale
+  float out_act_scale = 1.0f;
+  bool in_planes = false;   // the input is in that form
 };
 static int ensure_ovf_word(cpx_handle* h) {
   if (h->cnn_ovf) return CPX_OK;
@@ -871,7 +877,8 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
     // fp16x2: the two-plane layers run on fp16 planes, with the three-plane kernel launched behind as the guarded
     // rerun (it returns at once unless a scaled activation left fp16's range); every other layer as bf16x3
     const bool half = h->cnn_math == CPX_CNN_MATH_FP16X2 && cpx::conv_bf3_two_planes(a);
-    if (half) {
+    const bool planes_out = h->cnn_math == CPX_CNN_MATH_FP16X2 && hf && hf->out_planes;
+    if (half || planes_out) {
       const int rco = ensure_ovf_word(h);
       if (rco != CPX_OK) return rco;
       if (!(hf && hf->keep_flag)) CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, sizeof(int), h->stream));
@@ -892,13 +899,20 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
       cpx::launch_split_weights(a, h->bf3_scratch, h->stream);
       split_weights = h->bf3_scratch;
     }
-    if (half) {
+    if (half || planes_out) {
       cpx::ConvArgs ah = a;
-      ah.planes = 2;
-      ah.half = 1;
-      ah.act_scale = hf ? hf->act_scale : 1.0f;
-      ah.act_unscale = 1.0f / ah.act_scale;  // (a power of two: exact)
+      if (half) {
+        ah.planes = 2;
+        ah.half = 1;
+        ah.act_scale = hf ? hf->act_scale : 1.0f;
+        ah.act_unscale = 1.0f / ah.act_scale;  // (a power of two: exact)
+        ah.in_planes = hf && hf->in_planes;
+      }
       ah.ovf = h->cnn_ovf;
+      if (planes_out) {
+        ah.out_planes = 1;
+        ah.out_act_scale = hf->out_act_scale;
+      }
       rc = cpx::launch_conv_bf3(ah, split_weights, h->stream);
       a.guard = h->cnn_ovf;
       if (rc == 0) rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
@@ -1466,10 +1480,27 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
       const cpx_wrresnet_block& b = p.block[st][d];
       const int s = d == 0 ? st + 1 : 1;  // wr_block(stride = stage index), wr_resnet.py:27-30
       const int ho = (hh + s - 1) / s, wo = (ww + s - 1) / s;
+      // fp16x2: where the first convolution's kernel can store fp16 planes and the second one's can stage them, `mid`
+      // travels as the second convolution's scaled planes (same bytes as float32) and its staging is a copy
+      bool planes_pair = false;
+      if (h->cnn_math == CPX_CNN_MATH_FP16X2 && h->planes_handover) {
+        cpx::ConvArgs pa{}, pb{};
+        pa.N = N; pa.H = hh; pa.W = ww; pa.Ho = ho; pa.Wo = wo; pa.Cin = c_in; pa.Cout = f; pa.groups = p.groups; pa.ksize = 3;
+        pa.stride = s; pa.pad_top = pa.pad_left = 1;
+        pb = pa;
+        pb.H = ho; pb.W = wo; pb.Cin = f; pb.stride = 1;
+        planes_pair = c_in % p.groups == 0 && f % p.groups == 0 && cpx::conv_bf3_can_store_planes(pa) &&
+                      cpx::conv_bf3_two_planes(pb) && cpx::conv_bf3_can_load_planes(pb);
+      }
       hf.act_scale = cnn->act_scale[st][d][0];
+      hf.out_planes = planes_pair;
+      hf.out_act_scale = cnn->act_scale[st][d][1];
+      hf.in_planes = false;
       rc = conv(cur, mid, b.wa, hh, ww, c_in, f, 3, s, 1, 1, b.in_scale, b.in_shift, b.a_scale, b.a_shift, nullptr);
       if (rc != CPX_OK) return rc;
       hf.act_scale = cnn->act_scale[st][d][1];
+      hf.out_planes = false;
+      hf.in_planes = planes_pair;
       const float* res = cur;
       bool fused = false;
       if (d == 0) {

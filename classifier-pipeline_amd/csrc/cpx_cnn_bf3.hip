@@ -19,6 +19,8 @@
 // Activations stay float32 in HBM; the split happens on the way into LDS.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "cpx_kernels.h"
 
 namespace cpx {
@@ -116,6 +118,15 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 x, u32x4 w, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, w), c, 0, 0, 0);
 }
 constexpr float F16_MAX = 65504.0f;
+// producer-side split (ConvArgs::out_planes): four consecutive channels of one pixel, activated and already multiplied by
+// the consumer's act_scale, as the consumer stages them: [hi 0..3 | lo 0..3] in the 16 bytes the float32 values would take
+__device__ __forceinline__ u32x4 planes_of(f32x4 v) {
+  unsigned h0, h1, l0, l1;
+  split_pair2_h(v.x, v.y, h0, l0);
+  split_pair2_h(v.z, v.w, h1, l1);
+  return u32x4{h0, h1, l0, l1};
+}
+__device__ __forceinline__ float max_abs4(f32x4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 // entry test shared by the split-operand kernels: a fp16 layer is skipped once the network's overflow word is set (its
 // three-plane rerun follows), the rerun is skipped while it is clear
 #define BF3_ENTRY_GUARD(H_)                          \
@@ -135,7 +146,20 @@ struct TileDiv {
   unsigned long long m_nsplit, m_tx, m_ty;
   int nsplit, tiles_x, tiles_y;
   int run;  // conv_bf3w_kernel: tiles per workgroup along x (tiles_x then counts runs)
+  int total;  // PERSIST: workgroup-sized units of work along x (the grid then is smaller and each workgroup walks its share)
 };
+// PERSIST (last template parameter of the three kernels): the form the guarded bf16x3 rerun of a fp16x2 layer is launched
+// in.  A rerun that has nothing to do must cost nothing: 409,600 workgroups that load one word and leave take 174 us
+// (two resident per CU: each costs a dispatch round trip), 1,024 take 2.5 us (profiles/r05_fp16_probe.txt) -- so the
+// rerun is a small grid whose workgroups walk the tiles, bid0 = blockIdx.x, + gridDim.x, ... < td.total, with a barrier
+// between tiles (the LDS images are reused).  The ordinary launches keep one tile per workgroup: the loop folds away.
+#define BF3_TILE_LOOP_BEGIN for (int bid0 = blockIdx.x;;) {
+#define BF3_TILE_LOOP_END        \
+  if (!PERSIST) break;           \
+  bid0 += gridDim.x;             \
+  if (bid0 >= td.total) break;   \
+  __syncthreads();               \
+  }
 __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)n * m) >> 42); }
 
 // (two workgroups per CU is what the LDS footprint allows: the register budget is pinned to match)
@@ -144,7 +168,7 @@ __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (
 // entry array -- five steps for the nine taps (the tenth tap has zero weights) instead of nine half-empty ones.
 // PL: bf16 planes per operand (3: the exact split; 2: CPX_CNN_MATH_BF16X2 -- see conv_bf3w_kernel; not with C8)
 // H: the two planes are fp16 (CPX_CNN_MATH_FP16X2: ConvArgs::half; PL == 2 only)
-template <int NTN, int S, int NB, int TW, int CT, bool C8, int PL = 3, bool H = false>
+template <int NTN, int S, int NB, int TW, int CT, bool C8, int PL = 3, bool H = false, bool PERSIST = false>
 // (the strided forms fill the LDS with one workgroup: their waves may use the registers of the absent second one)
 __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128), S > 1 ? CT / 256 : (CT >= 1024 ? 4 : CT / 128)))) void conv_bf3_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3;
@@ -168,8 +192,9 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
   uint4* s_w = lds4 + PL * KH * NPX;    // [PL][NSTEP][2][COGW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wset = tid >> 8;
-  int bid = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-contiguous tiles (cpx_cnn.hip)
+  BF3_TILE_LOOP_BEGIN
+  int bid = bid0;
+  if (!PERSIST && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-contiguous tiles (cpx_cnn.hip)
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   int q = div_magic(bid, td.m_nsplit);
   const int ns = bid - q * td.nsplit;  // the column slices of one tile run next to each other: they share the patch in L2
@@ -439,7 +464,11 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
       const int ch = ch0 + t * 32 + (lane & 31);
       float os = a.out_scale ? a.out_scale[ch] : 1.0f;
       if (H) os *= a.w_unscale[ch] * a.act_unscale;  // (powers of two: exact)
-      const float ob = (a.out_shift ? a.out_shift[ch] : 0.0f) + (a.sc_in && a.sc_bias ? a.sc_bias[ch] : 0.0f);
+      float ob = (a.out_shift ? a.out_shift[ch] : 0.0f) + (a.sc_in && a.sc_bias ? a.sc_bias[ch] : 0.0f);
+      if (a.out_planes) {  // the consumer's range scale rides on the affine: relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k)
+        os *= a.out_act_scale;
+        ob *= a.out_act_scale;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // pixel index inside the wave tile
@@ -480,7 +509,13 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
           if (a.relu) {
             v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
           }
-          *reinterpret_cast<float4*>(at_off(out_n, lb + ub)) = v;
+          if (a.out_planes) {  // (uniform) the next layer's fp16 planes instead of float32
+            const f32x4 vv = {v.x, v.y, v.z, v.w};
+            if (max_abs4(vv) > F16_MAX) atomicOr(a.ovf, 1);
+            *reinterpret_cast<u32x4*>(at_off(out_n, lb + ub)) = planes_of(vv);
+          } else {
+            *reinterpret_cast<float4*>(at_off(out_n, lb + ub)) = v;
+          }
         }
       } else {
 #pragma unroll
@@ -494,7 +529,13 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
             if (a.relu) {
               v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
             }
-            *reinterpret_cast<float4*>(at_off(out_n, (unsigned)o << 2)) = v;
+            if (a.out_planes) {
+              const f32x4 vv = {v.x, v.y, v.z, v.w};
+              if (max_abs4(vv) > F16_MAX) atomicOr(a.ovf, 1);
+              *reinterpret_cast<u32x4*>(at_off(out_n, (unsigned)o << 2)) = planes_of(vv);
+            } else {
+              *reinterpret_cast<float4*>(at_off(out_n, (unsigned)o << 2)) = v;
+            }
           }
         }
       }
@@ -505,6 +546,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
       }
     }
   }
+  BF3_TILE_LOOP_END
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -514,7 +556,7 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
 // staging format, MFMA loop and epilogue as conv_bf3_kernel; the output offset of a position is simply p * Cout.
 // PL: bf16 planes per operand (3: the exact split, six products; 2: CPX_CNN_MATH_BF16X2, three -- see conv_bf3w_kernel)
 // H: the two planes are fp16 (CPX_CNN_MATH_FP16X2; see conv_bf3_kernel)
-template <int NTN, int NPXC, int PL, bool H = false>
+template <int NTN, int NPXC, int PL, bool H = false, bool PERSIST = false>
 __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   constexpr int KS = 3, CT = 256;
   constexpr int COGW = 32 * NTN;
@@ -525,8 +567,9 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   uint4* s_w = lds4 + 2 * PL * NPXC;     // [PL][9][2][COGW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  BF3_TILE_LOOP_BEGIN
+  int bid = bid0;
+  if (!PERSIST && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   int q = div_magic(bid, td.m_nsplit);
   const int ns = bid - q * td.nsplit;
@@ -774,6 +817,7 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
+  BF3_TILE_LOOP_END
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -821,7 +865,7 @@ constexpr int w_wsub_entries(int planes) { return w_rows_resident(planes) * plan
 // H (PL == 2): the two planes are fp16 -- CPX_CNN_MATH_FP16X2: 11 + 11 significand bits (2^-22 per operand against 2^-16),
 // three products on v_mfma_f32_16x16x32_f16 at the bf16 form's rate; the operands are scaled by powers of two into
 // fp16's range and the accumulators scaled back in the epilogue (ConvArgs::half)
-template <bool WALK, bool LDSBN, int NH, int NG, int PL, bool H = false>
+template <bool WALK, bool LDSBN, int NH, int NG, int PL, bool H = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bf3w_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
   static_assert(NG == 1 || (!WALK && !LDSBN && NH == 1), "the group walk is built for the one-slice, one-tile form");
   static_assert(PL == 2 || PL == 3, "two or three bf16 planes per operand");
@@ -844,8 +888,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   uint4* s_w = lds4 + W_PATCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
-  int bid = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-contiguous tiles (cpx_cnn.hip)
+  BF3_TILE_LOOP_BEGIN
+  int bid = bid0;
+  if (!PERSIST && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-contiguous tiles (cpx_cnn.hip)
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   int qd = div_magic(bid, td.m_nsplit);
   const int ns = bid - qd * td.nsplit;
@@ -885,7 +930,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // BatchNorm scale / shift of the group's input channels: staged once per workgroup (read back at each patch commit
   // instead of living in eight registers across the phases)
   f32x4* s_bn = reinterpret_cast<f32x4*>(lds4 + W_PATCH + W_WSUB);
-  f32x4 psc_r, psh_r;  // (!LDSBN)
+  // (!LDSBN; with LDSBN they are never written and their copies below never read: initialising them costs eight
+  // instructions per tile for nothing)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+  f32x4 psc_r, psh_r;
   if (LDSBN && a.in_scale) {
     if (tid < cin_g) {  // (H: relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly)
       reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g0 * cin_g + tid] * (H ? a.act_scale : 1.0f);
@@ -1041,10 +1090,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (H) os *= *reinterpret_cast<const f32x4*>(a.w_unscale + ch) * a.act_unscale;  // (powers of two: exact)
     if (a.out_shift) ob = *reinterpret_cast<const f32x4*>(a.out_shift + ch);
     if (a.sc_in && a.sc_bias) ob += *reinterpret_cast<const f32x4*>(a.sc_bias + ch);
+    if (a.out_planes) {  // the consumer's range scale rides on the affine: relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k)
+      os *= a.out_act_scale;
+      ob *= a.out_act_scale;
+    }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
       f32x4 v = acc[hf][ct][pt];
-      if (H || a.out_scale) {  // (uniform branches kept as branches: see the patch commit)
+      if (H || a.out_scale || a.out_planes) {  // (uniform branches kept as branches: see the patch commit)
         asm volatile("");
         v = v * os;
       }
@@ -1055,7 +1108,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         asm volatile("");
         v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
       }
-      if (ovalid[pt]) *reinterpret_cast<f32x4*>(at_off(out_n, o)) = v;
+      if (a.out_planes) {  // (uniform) the next layer's fp16 planes instead of float32: its staging is a copy
+        asm volatile("");
+        if (max_abs4(v) > F16_MAX) atomicOr(a.ovf, 1);
+        if (ovalid[pt]) *reinterpret_cast<u32x4*>(at_off(out_n, o)) = planes_of(v);
+      } else {
+        if (ovalid[pt]) *reinterpret_cast<f32x4*>(at_off(out_n, o)) = v;
+      }
     }
   }
   };
@@ -1082,6 +1141,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // ---- the chunk's patch: BatchNorm + ReLU prologue, padding zeroed, split into bf16 planes ----
         {
           f32x4 psc = psc_r, psh = psh_r;
+#pragma clang diagnostic pop
           int q8c = my_q8;
           if (LAUNDER) {
             q8c = tid & 7;
@@ -1108,6 +1168,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 continue;
               }
 #endif
+              if (H && a.in_planes) {  // (uniform) the producer stored this layer's planes: [hi 0..3 | lo 0..3] per piece
+                asm volatile("");
+                u32x4 pv = pre_p[i];
+                if (!interior) {
+                  asm volatile("");
+                  const int px = t8 + 64 * i;
+                  const int py = (int)(__umul24((unsigned)px, 3641u) >> 16), pxx = __mul24(py, -W_PW) + px;
+                  const bool inside = (unsigned)(iy0 + py) < (unsigned)a.H && (unsigned)(ix0 + pxx) < (unsigned)a.W;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) pv[j] = inside ? pv[j] : 0u;
+                }
+                uint2* sp2 = reinterpret_cast<uint2*>(s_patch) + st_e2 + i * (64 * 4);
+                sp2[(0 * 2 * W_NPXP) * 4] = make_uint2(pv[0], pv[1]);
+                sp2[(1 * 2 * W_NPXP) * 4] = make_uint2(pv[2], pv[3]);
+                continue;
+              }
               float v[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(pre_p[i][j]);
@@ -1208,14 +1284,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }  // chunks of the tile's groups
   finish(g0 + NG - 1);
   }  // tiles of the run
+  BF3_TILE_LOOP_END
 }
 #undef BF3W_ISSUE_W
 #undef BF3W_ISSUE_P
 
+constexpr long long RERUN_GRID = 1024;  // workgroups along x of a guarded rerun (four per CU and group row)
 template <int NTN, int NPXC, int PL, bool H = false>
 int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = ((size_t)2 * PL * NPXC + (size_t)18 * PL * 32 * NTN) * 16;
-  static bool lds_ready[64];
+  static bool lds_ready[64], lds_ready_p[64];
   if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL, H>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Ho * a.Wo + 127) / 128;
@@ -1226,6 +1304,12 @@ int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) + 1;
+  td.total = (int)blocks;
+  if constexpr (PL == 3 && !H) if (a.guard != nullptr) {  // the guarded rerun of a fp16x2 layer: a small grid that walks the tiles (PERSIST)
+    if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL, false, true>), lds_ready_p, 160 * 1024 - 1024)) return -1;
+    hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL, false, true>), dim3((unsigned)std::min<long long>(blocks, RERUN_GRID), a.groups), dim3(256), lds, s, a, wimg, td);
+    return 0;
+  }
   hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL, H>), dim3((unsigned)blocks, a.groups), dim3(256), lds, s, a, wimg, td);
   return 0;
 }
@@ -1385,7 +1469,7 @@ __global__ __launch_bounds__(256) void split_weights32_kernel(const float* __res
 template <int NH, int NG, int PL, bool H = false>
 static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   const size_t lds = (size_t)(w_patch_entries(PL) + w_wsub_entries(PL)) * 16 + (size_t)(a.Cin / a.groups) * 8;  // + BatchNorm scale / shift
-  static bool lds_ready[64];
+  static bool lds_ready[64], lds_ready_p[64];
   // (NH = 2 carries 16 more accumulator registers: the BatchNorm parameters go to LDS there)
   constexpr bool WALK = CPX_BF3W_RUN > 1, LDSBN = CPX_BF3W_LDSBN != 0 || NH > 1 || PL == 2;
   if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL, H>), lds_ready, 160 * 1024 - 1024)) return -1;
@@ -1405,6 +1489,12 @@ static int launch_bf3w_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
+  td.total = (int)blocks;
+  if constexpr (PL == 3 && !H) if (a.guard != nullptr) {  // the guarded rerun of a fp16x2 layer: a small grid that walks the tiles (PERSIST)
+    if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL, false, true>), lds_ready_p, 160 * 1024 - 1024)) return -1;
+    hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL, false, true>), dim3((unsigned)std::min<long long>(blocks, RERUN_GRID), a.groups / NG), dim3(512), lds, s, a, wimg, td);
+    return 0;
+  }
   hipLaunchKernelGGL((conv_bf3w_kernel<WALK, LDSBN, NH, NG, PL, H>), dim3((unsigned)blocks, a.groups / NG), dim3(512), lds, s, a, wimg, td);
   return 0;
 }
@@ -1440,7 +1530,7 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
   size_t lds = ((size_t)(C8 ? 3 : 2 * PL) * PH * PW + (size_t)(C8 ? 30 : 18 * PL) * 32 * NTN) * 16;
   if (lds < (CT / 64) * 32 * 32 * sizeof(float)) lds = (CT / 64) * 32 * 32 * sizeof(float);
-  static bool lds_ready[64];
+  static bool lds_ready[64], lds_ready_p[64];
   if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL, H>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
   td.tiles_x = (a.Wo + TW - 1) / TW;
@@ -1451,6 +1541,12 @@ int launch_bf3_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_nsplit = (1ull << 42) / td.nsplit + 1;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
+  td.total = (int)blocks;
+  if constexpr (PL == 3 && !H) if (a.guard != nullptr) {  // the guarded rerun of a fp16x2 layer: a small grid that walks the tiles (PERSIST)
+    if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL, false, true>), lds_ready_p, 160 * 1024 - 1024)) return -1;
+    hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL, false, true>), dim3((unsigned)std::min<long long>(blocks, RERUN_GRID), a.groups), dim3(CT), lds, s, a, wimg, td);
+    return 0;
+  }
   hipLaunchKernelGGL((conv_bf3_kernel<NTN, S, NB, TW, CT, C8, PL, H>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
   return 0;
 }
@@ -1548,6 +1644,16 @@ size_t conv_bf3_weight_bytes(const ConvArgs& a) {
   return image3_bytes(a) + (flat_layer(a) ? 2 * (image3_bytes(a) / 3 * 2) + scales_bytes(a) : 0);
 }
 bool conv_bf3_two_planes(const ConvArgs& a) { return bf3w_layer(a) || flat_layer(a); }
+// producer-side split (ConvArgs::out_planes / in_planes): the kernels whose epilogue can store the next layer's fp16
+// planes -- conv_bf3w_kernel and conv_bf3_kernel, i.e. every split-operand launch but the flattened one -- and the one
+// whose staging can take them (conv_bf3w_kernel in fp16x2).  `a` describes the launch (H, W, Ho, Wo filled in).
+bool conv_bf3_can_store_planes(const ConvArgs& a) {
+  if (!conv_bf3_supported(a) || (a.Cout / a.groups) % 4 != 0) return false;
+  if (a.stride != 1) return a.stride == 2 && bf3_strided(a);
+  if (a.Cout / a.groups == 128) return !flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256);
+  return true;
+}
+bool conv_bf3_can_load_planes(const ConvArgs& a) { return bf3w_layer(a); }
 // where the fp16 image and its scales lie inside a two-plane layer's weight images
 static size_t half_image_offset(const ConvArgs& a) {
   return bf3w_layer(a) ? bf3w_image3_bytes(a) + bf3w_image2_bytes(a) : image3_bytes(a) + image3_bytes(a) / 3 * 2;
@@ -1594,11 +1700,14 @@ int launch_conv_bf3(const ConvArgs& a_in, const void* wimg, hipStream_t s) {
   const int cout_g = a.Cout / a.groups;
   if (a.half) {  // CPX_CNN_MATH_FP16X2: the two-plane layers only, with the network's overflow word
     if (a.planes != 2 || !conv_bf3_two_planes(a) || a.ovf == nullptr) return -2;
+    if (a.in_planes && !conv_bf3_can_load_planes(a)) return -2;
     a.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wimg) + scales_offset(a));
     a.w_unscale = a.w_scale + a.Cout;
   }
   // pixel offsets are formed with 24-bit multiplies (pix_off): a sample of 2^24 pixels or more is out of their range
   if ((long long)a.H * a.W >= (1 << 24) || (long long)a.Ho * a.Wo >= (1 << 24) || a.Cin >= (1 << 24) || a.Cout >= (1 << 24)) return -3;
+  if (a.in_planes && !a.half) return -2;
+  if (a.out_planes && (a.ovf == nullptr || !conv_bf3_can_store_planes(a) || a.residual != nullptr)) return -2;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
   if (bf3_c8(a)) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2, true>(a, w, s);
   if (a.stride == 2) {

@@ -229,6 +229,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 bool conv_bf3_supported(const ConvArgs& a);
 size_t conv_bf3_weight_bytes(const ConvArgs& a);
 bool conv_bf3_two_planes(const ConvArgs& a);
+bool conv_bf3_can_store_planes(const ConvArgs& a);
+bool conv_bf3_can_load_planes(const ConvArgs& a);
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s);
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s);
 void launch_head(const HeadArgs& a, hipStream_t s);

@@ -8,10 +8,11 @@ from cpx.ml_tools import wrresnet as wr
 eng = TrackEngine()
 if len(sys.argv) > 1: eng.set_cnn_math(sys.argv[1])
 w = wr.random_weights(17, seed=3)
-net = wr.WRResNetDevice(eng, w, 17)
 total = 2048
 xall = torch.rand((total,160,160,2), device=eng.device)*255
-for N in (4, 8, 16, 32, 64, 128, 256, 512, 2048):
+w = wr.calibrate_bn_device(eng, w, xall[:32].contiguous())
+net = wr.WRResNetDevice(eng, w, 17)
+for N in (8, 16, 24, 32, 64, 128, 512, 2048):
     logits = torch.empty((total, 17), device=eng.device)
     torch.cuda.synchronize()
     net.forward_async(xall[:N], logits[:N])
@@ -20,4 +21,4 @@ for N in (4, 8, 16, 32, 64, 128, 256, 512, 2048):
         for i in range(0, total, N):
             net.forward_async(xall[i:i+N], logits[i:i+N])
     eng.synchronize(); torch.cuda.synchronize(); dt=(time.time()-t)/2
-    print(eng.get_cnn_math(), 'N', N, 'samples/s', round(total/dt,1), 'TFLOP/s', round(total*12.62e9/dt/1e12,2), flush=True)
+    print(eng.get_cnn_math(), 'overflow', eng.cnn_last_overflow(), 'N', N, 'samples/s', round(total/dt,1), 'TFLOP/s', round(total*12.62e9/dt/1e12,2), flush=True)

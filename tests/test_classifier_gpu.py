@@ -93,7 +93,7 @@ def test_classify_track_same_scores_in_the_two_plane_math_mode(tmp_path, model_d
     interp.classify_track(clip, clip.tracks[0], segment_frames=z["t0_segments"])   # (creates / finds the engine)
     got = {}
     try:
-        for mode in ("bf16x3", "bf16x2"):
+        for mode in ("bf16x3", "bf16x2", "fp16x2"):
             assert cte._ENGINES
             for eng in cte._ENGINES.values():
                 eng.set_cnn_math(mode)
@@ -102,12 +102,13 @@ def test_classify_track_same_scores_in_the_two_plane_math_mode(tmp_path, model_d
                          np.array([p.prediction for p in pred.predictions], dtype=np.float64))
     finally:
         for eng in cte._ENGINES.values():
-            eng.set_cnn_math("bf16x3")
-    (sa, pa), (sb, pb) = got["bf16x3"], got["bf16x2"]
-    assert pa.shape == pb.shape and pa.size > 0
-    assert float(np.abs(pa - pb).max()) <= 1e-5, float(np.abs(pa - pb).max())
-    assert float(np.abs(sa - sb).max()) <= 1e-5
-    assert float(np.abs(pa - pb).max()) > 0.0  # (it IS the other arithmetic)
+            eng.set_cnn_math(eng.DEFAULT_CNN_MATH)
+    for other in ("bf16x2", "fp16x2"):
+        (sa, pa), (sb, pb) = got["bf16x3"], got[other]
+        assert pa.shape == pb.shape and pa.size > 0
+        assert float(np.abs(pa - pb).max()) <= 1e-5, (other, float(np.abs(pa - pb).max()))
+        assert float(np.abs(sa - sb).max()) <= 1e-5
+        assert float(np.abs(pa - pb).max()) > 0.0  # (it IS the other arithmetic)
 
 
 def test_classify_track_inputs_equal_reference(tmp_path, model_dir):
