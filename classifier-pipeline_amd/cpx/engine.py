@@ -52,6 +52,19 @@ class TrackBatchResult:
             raise CpxError(int(self.info["status"][bad[0]]), "frame %d: %d components exceed capacity"
                            % (int(bad[0]), int(self.info["n_components"][bad[0]])))
 
+    def overflowed(self, clip_offsets):
+        """{clip index: components its fullest refused frame needs} for the clips with a frame beyond the engine's
+        max_components (cpx_frame_info.status = CPX_ERR_OVERFLOW; n_components then holds the count found)."""
+        info = self.info
+        bad = np.nonzero((info["frame_number"] >= 0) & (info["status"] != 0))[0]
+        out = {}
+        if bad.size:
+            offs = np.asarray(clip_offsets)
+            for f in bad:
+                b = int(np.searchsorted(offs, f, side="right") - 1)
+                out[b] = max(out.get(b, 0), int(info["n_components"][f]))
+        return out
+
     def components(self, f):
         n = int(self.info["n_components"][f])
         return self.comps[f, :n]
@@ -94,11 +107,16 @@ class AssocBatchResult:
             self._host = (pool, tracks, ntr, status, regions, rc)
         return self._host
 
-    def check(self):
+    def check(self, clip=None):
+        """Raise when the association of any clip (or of `clip` only) ran out of track slots."""
         status = self._fetch()[3]
-        bad = np.nonzero(status != 0)[0]
+        bad = np.nonzero(status != 0)[0] if clip is None else (np.array([clip]) if status[clip] != 0 else np.array([], int))
         if bad.size:
             raise CpxError(int(status[bad[0]]), "clip %d: track capacity exceeded" % int(bad[0]))
+
+    def overflowed(self):
+        """Clips whose association ran out of simultaneous (max_active_tracks) or total (max_tracks) track slots."""
+        return [int(b) for b in np.nonzero(self._fetch()[3] != 0)[0]]
 
     def clip_tracks(self, b):
         """-> list of (track_record, regions[n_frames]) for clip b, in creation (id) order."""
@@ -184,6 +202,40 @@ class TrackStream:
                 raise CpxError(rc, eng._err())
         eng.synchronize()
         return f
+
+    def replay(self, old, flags=0, associate=True):
+        """Take over the frames another stream of the same clip has consumed (a stream whose capacities turned out too
+        small) and run them again here, in one call per stage: this stream then stands where the old one stood."""
+        eng, n = self.engine, old.n
+        if n > self.cap_frames:
+            raise CpxError(-1, "replay of %d frames into a stream of %d" % (n, self.cap_frames))
+        self.frames_dev[:n].copy_(old.frames_dev[:n])
+        self.meta[:n] = old.meta[:n]
+        self.n = n
+        if n == 0 or (n == 1 and self.meta[0]["background_frame"]):
+            return
+        eng.torch.cuda.current_stream(eng.device).synchronize()
+        eng.track_calls = getattr(eng, "track_calls", 0) + 1
+        mp = C.c_void_p(self.meta.ctypes.data)
+        rc = eng.lib.cpx_track_frame_ex(eng.h, self._p(self.frames_dev), mp, 0, n, self._p(self.comps), self._p(self.info),
+                                        self._p(self.labels), self._p(self.filtered), self._p(self.background), int(flags))
+        if rc != 0:
+            raise CpxError(rc, eng._err())
+        self.n_tracked = n
+        if associate:
+            rc = eng.lib.cpx_associate_frame(eng.h, C.byref(self.params), mp, 0, n, self._p(self.comps), self._p(self.info),
+                                             self._p(self.pool), self._p(self.tracks), self._p(self.ntracks),
+                                             self._p(self.status), self._p(self.regions), self._p(self.rcounts))
+            if rc != 0:
+                raise CpxError(rc, eng._err())
+        eng.synchronize()
+
+    def overflow(self):
+        """(components the fullest refused frame needs or 0, association out of track slots) over the frames so far."""
+        info = self.info[: self.n * 20].cpu().numpy().view(FRAME_INFO_DTYPE)
+        bad = (info["frame_number"] >= 0) & (info["status"] != 0)
+        need = int(info["n_components"][bad].max()) if bad.any() else 0
+        return need, int(self.status.item()) != 0
 
     def frame_info(self, f):
         return self.info[f * 20:(f + 1) * 20].cpu().numpy().view(FRAME_INFO_DTYPE)[0]
@@ -281,11 +333,85 @@ class TrackEngine:
         if rc != 0:
             raise CpxError(rc, "cpx_create")
         self.width, self.height, self.cap = width, height, max_components
+        self._ctor = dict(width=width, height=height, model=model, device=device, edge_pixels=edge_pixels,
+                          background_thresh=self.cfg.background_thresh, weight_add=self.cfg.weight_add,
+                          max_frames=max_frames, denoise=denoise)
+        self._grown = {}
 
     def close(self):
+        for eng in getattr(self, "_grown", {}).values():
+            eng.close()
+        self._grown = {}
         if self.h:
             self.lib.cpx_destroy(self.h)
             self.h = C.c_void_p()
+
+    # ---- no recording is lost to a capacity -------------------------------------------------------------------
+    # The reference has no limit on components per frame (cliptrackextractor.py:236-247), simultaneous tracks or tracks
+    # per clip (cliptracker.py:202-247).  The kernels work on caller-sized tables and report CPX_ERR_OVERFLOW with the
+    # count they found; the host layer owns the sizes, so it is the one that grows them: the clip that did not fit is
+    # run again, alone, on a sibling handle with the capacities it needs (doubled until nothing overflows).
+    def MAX_COMPONENTS_EVER(self):
+        return ((self.height + 1) // 2) * ((self.width + 1) // 2)  # at most one 8-connected component per 2 x 2 block
+
+    def grown(self, max_components, max_frames=None):
+        """A sibling engine (same geometry / thresholds / denoise) whose per-frame component capacity is the power of
+        two >= max_components (capped at one component per 2 x 2 block); cached, closed with this engine."""
+        cap = self.grown_capacity(max_components)
+        eng = self._grown.get(cap)
+        if eng is None or (max_frames and eng.cfg.max_frames < max_frames):
+            if eng is not None:
+                eng.close()
+            eng = self.sibling(cap, max_frames)
+            self._grown[cap] = eng
+        return eng
+
+    def grown_capacity(self, max_components):
+        cap = 128
+        while cap < max_components:
+            cap *= 2
+        return max(min(cap, self.MAX_COMPONENTS_EVER()), int(max_components))
+
+    def sibling(self, max_components, max_frames=None):
+        """An independent engine (a handle of its own) with this one's geometry / thresholds / denoise."""
+        args = dict(self._ctor)
+        if max_frames:
+            args["max_frames"] = max(int(max_frames), args["max_frames"])
+        return TrackEngine(max_components=int(max_components), **args)
+
+    def track_clip_grown(self, frames_dev, meta, params=None, need_components=0, want_labels=False, want_filtered=True,
+                         want_background=False, flags=0, want_regions=True, associate=True):
+        """One clip (device frames [n, H, W], its cpx_frame_meta rows) tracked -- and, with `associate`, associated
+        with track capacities of `params` -- on engines grown until neither stage reports CPX_ERR_OVERFLOW.
+        -> (engine used, TrackBatchResult, AssocBatchResult or None, params used)."""
+        from .tracking import TrackParams
+
+        n = int(frames_dev.shape[0])
+        offs = np.array([0, n], np.int32)
+        need = max(int(need_components), self.cap)
+        params = params or make_track_params(self.width, self.height, self.cfg.edge_pixels)
+        while True:
+            eng = self if need <= self.cap else self.grown(need, max_frames=n)
+            res = eng.track_batch(frames_dev, offs, meta, want_labels=want_labels, want_filtered=want_filtered,
+                                  want_background=want_background, flags=flags)
+            over = res.overflowed(offs)
+            if over:
+                if over[0] <= eng.cap:
+                    raise CpxError(-5, "a frame reports %d components and still does not fit %d" % (over[0], eng.cap))
+                need = over[0]
+                continue
+            if not associate:
+                return eng, res, None, params
+            while True:
+                assoc = eng.associate_batch(res, offs, meta, params=params, want_regions=want_regions)
+                if not assoc.overflowed():
+                    return eng, res, assoc, params
+                if params.max_active_tracks >= 65536:
+                    raise CpxError(-5, "track capacity exceeded at 65536 simultaneous tracks")
+                grown = TrackParams.from_buffer_copy(params)
+                grown.max_active_tracks = params.max_active_tracks * 2
+                grown.max_tracks = params.max_tracks * 2
+                params = grown
 
     def __del__(self):
         try:

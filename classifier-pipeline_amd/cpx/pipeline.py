@@ -28,6 +28,8 @@ class BatchResult:
         self.limits_dev = None     # cpx_track_limits [n_tracks]
         self.probs = None          # device float [n_samples, L]
         self.parts = None          # overlapped run: the per-group results
+        self.overflowed = []       # clips whose tables overflowed in this pass (run again on larger ones by run())
+        self.regrown = []          # (clip, components capacity, max_active_tracks, max_tracks) of the clips run again
         self.clip0 = 0
         self.track_timing = (0.0, 0)
 
@@ -71,13 +73,60 @@ class BatchPipeline:
 
     def _run_on_stream(self, frames_dev, clip_offsets, meta, outputs, classify, keep_samples):
         eng, t = self.eng, self.eng.torch
-        lib, h = eng.lib, eng.h
-        dev = eng.device
         out = self._front(frames_dev, clip_offsets, meta, outputs, classify)
         if not classify or out.n_tracks == 0 or out.n_samples == 0:
             eng.synchronize()
-            return out
-        return self.classify_front(out, frames_dev, keep_samples)
+        else:
+            out = self.classify_front(out, frames_dev, keep_samples)
+        if out.overflowed:
+            out = self._regrow(out, frames_dev, clip_offsets, meta, classify, keep_samples)
+        return out
+
+    def _regrow(self, out, frames_dev, clip_offsets, meta, classify, keep_samples):
+        """No recording is lost to a capacity: the clips whose frames held more components, or which had more tracks,
+        than this pass's tables (reference: no limits, cliptrackextractor.py:236-247, cliptracker.py:202-247) reported
+        no tracks; each is run again alone on tables grown to fit and its tracks join the batch's."""
+        from .tracking import FilterParams
+
+        eng, t = self.eng, self.eng.torch
+        offs = np.ascontiguousarray(clip_offsets, dtype=np.int32)
+        meta = np.ascontiguousarray(meta)
+        parts = [out]
+        for b in out.overflowed:
+            f0, f1 = int(offs[b]), int(offs[b + 1])
+            fr = frames_dev[f0:f1]
+            eng_k, res_k, assoc_k, tp_k = eng.track_clip_grown(fr, meta[f0:f1], params=self.tp, want_filtered=True,
+                                                               want_regions=self.want_regions)
+            fp_k = FilterParams.from_buffer_copy(self.fp)
+            fp_k.max_active_tracks, fp_k.max_tracks_per_clip = tp_k.max_active_tracks, tp_k.max_tracks
+            sub = BatchPipeline(eng_k, self.net, n_labels=self.n_labels, fp_index=self.fp_index, frame_size=self.fs,
+                                square_width=self.sq, track_params=tp_k, filter_params=fp_k, cnn_chunk=self.cnn_chunk,
+                                want_regions=self.want_regions, limits_flags=self.limits_flags)
+            with t.cuda.stream(eng_k.torch_stream()):
+                part = sub._front(fr, np.array([0, f1 - f0], np.int32), meta[f0:f1], None, classify, pre=(res_k, assoc_k))
+                if classify and part.n_tracks and part.n_samples:
+                    part = sub.classify_front(part, fr, keep_samples)
+                else:
+                    eng_k.synchronize()
+            part.clip0 = b
+            out.regrown.append((b, eng_k.cap, tp_k.max_active_tracks, tp_k.max_tracks))
+            parts.append(part)
+        live = [p for p in parts if p.n_tracks and p.track_clip is not None]
+        out.parts = parts
+        out.n_tracks = sum(p.n_tracks for p in parts)
+        out.n_samples = sum(p.n_samples for p in parts)
+        if live:
+            tcs = []
+            for p in live:
+                tc = p.track_clip.clone()
+                tc[:, 0] += p.clip0
+                tcs.append(tc)
+            out.track_clip = t.cat(tcs)
+            for name in ("scores", "best", "probs", "logits"):
+                vals = [getattr(p, name, None) for p in live]
+                if all(v is not None for v in vals):
+                    setattr(out, name, t.cat(vals))
+        return out
 
     def classify_front(self, out, frames_dev, keep_samples=False):
         """Stages 5b-7 for a _front result: crop / tile, network, aggregation (on the current stream = the handle's).
@@ -138,8 +187,9 @@ class BatchPipeline:
             self.net.eng.synchronize()
         return out
 
-    def _front(self, frames_dev, clip_offsets, meta, outputs, classify=True):
-        """Stages 1-5a on the track engine: track, association, end-of-clip filtering, segment plan, limits."""
+    def _front(self, frames_dev, clip_offsets, meta, outputs, classify=True, pre=None):
+        """Stages 1-5a on the track engine: track, association, end-of-clip filtering, segment plan, limits.
+        pre: (TrackBatchResult, AssocBatchResult) of these clips when stages 1-2 have run already (_regrow)."""
         eng, t = self.eng, self.eng.torch
         lib, h = eng.lib, eng.h
         dev = eng.device
@@ -148,8 +198,11 @@ class BatchPipeline:
         B = offs.size - 1
         out = BatchResult()
         # ---- 1. track stage (one launch per time step), 2. association ----
-        out.track = eng.track_batch(frames_dev, offs, meta, want_filtered=True, outputs=outputs)
-        out.assoc = eng.associate_batch(out.track, offs, meta, params=self.tp, want_regions=self.want_regions)
+        if pre is not None:
+            out.track, out.assoc = pre
+        else:
+            out.track = eng.track_batch(frames_dev, offs, meta, want_filtered=True, outputs=outputs)
+            out.assoc = eng.associate_batch(out.track, offs, meta, params=self.tp, want_regions=self.want_regions)
         # ---- 3. end of clip: trim / stats / rejects / plan sizes ----
         mt = self.tp.max_tracks
         summ = t.zeros(B * mt * 30, dtype=t.int32, device=dev)
@@ -170,6 +223,9 @@ class BatchPipeline:
         if not on_stream:
             eng.synchronize()
         out.counts = counts.cpu().numpy()   # the one host wait of a run: the work counts size what follows
+        # (with it: which clips outgrew the tables -- a frame with more components than max_components, more tracks than
+        # the association's slots; such a clip reported no tracks above and run() tracks it again on larger tables)
+        out.overflowed = [int(b) for b in np.nonzero(out.assoc.status_dev.cpu().numpy())[0]]
         totals = out.counts.sum(axis=0)
         out.track_timing = eng.last_kernel_timing()  # (ms, launches) of this group's frame-kernel launches
         n_tracks, n_refs, n_samples = int(totals[0]), int(totals[1]), int(totals[2])

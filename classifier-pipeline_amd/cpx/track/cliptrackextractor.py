@@ -334,9 +334,10 @@ class ClipTrackExtractor(ClipTracker):
                 clips[i]._background_calculated()
             meta = np.concatenate(metas)
             t0 = time.time()
+            track_flags = 0 if self.update_background else TRACK_FREEZE_BACKGROUND
             res = eng.track_batch(frames_dev, offs, meta, want_labels=True, want_filtered=True, want_background=True,
-                                  flags=0 if self.update_background else TRACK_FREEZE_BACKGROUND)
-            assoc = None
+                                  flags=track_flags)
+            assoc = params = None
             if self.do_tracking and not any(clips[i].from_metadata for i in members):
                 c0 = clips[members[0]]
                 params = make_track_params(
@@ -344,7 +345,10 @@ class ClipTrackExtractor(ClipTracker):
                     self.config.cropped_regions_strategy, self.config.filter_regions_pre_match,
                     self.config.aoi_min_mass, self.config.aoi_pixel_variance, self.config.params, c0.frames_per_second)
                 assoc = eng.associate_batch(res, offs, meta, params=params)
-            res.check()
+            # a clip with a frame of more components, or with more tracks, than the batch's tables hold is run again
+            # alone on tables grown to fit (TrackEngine.track_clip_grown); the others keep the batch's results
+            over = res.overflowed(offs)
+            regrow = set(over) | (set(assoc.overflowed()) if assoc is not None else set())
             self.timings["device_s"] = time.time() - t0
             labels = res.labels() if host_images else None
             filtered = res.filtered() if (host_images or self.calculate_filtered) else None
@@ -352,6 +356,18 @@ class ClipTrackExtractor(ClipTracker):
             for k, i in enumerate(members):
                 f0, n = int(offs[k]), int(offs[k + 1] - offs[k])
                 thermal = pix_all[f0:f0 + n] if host_images else None
+                if k in regrow:
+                    logging.info("%s: %s; tracking it again with larger tables", clips[i].source_file,
+                                 ("%d components in a frame" % over[k]) if k in over else "track capacity exceeded")
+                    fr_k = frames_dev[f0:f0 + n]
+                    eng_k, res_k, assoc_k, _ = eng.track_clip_grown(
+                        fr_k, meta[f0:f0 + n], params=params, need_components=over.get(k, 0), want_labels=True,
+                        want_filtered=True, want_background=True, flags=track_flags, associate=assoc is not None)
+                    self._collect_clip(clips[i], 0, 0, n, thermal, eng_k, fr_k, res_k, assoc_k,
+                                       res_k.labels() if host_images else None,
+                                       res_k.filtered() if (host_images or self.calculate_filtered) else None,
+                                       res_k.background()[0], key[3])
+                    continue
                 self._collect_clip(clips[i], k, f0, n, thermal, eng, frames_dev, res, assoc, labels, filtered,
                                    backgrounds[k], key[3])
                 if self.calc_stats:
@@ -405,6 +421,9 @@ class ClipTrackExtractor(ClipTracker):
             flags = TRACK_FREEZE_BACKGROUND
         f = stream.append(frame.pix, frame.time_on, frame.last_ffc_time, associate=self.do_tracking, flags=flags)
         fi = stream.frame_info(f)
+        if int(fi["status"]) != 0 or (self.do_tracking and int(stream.status.item()) != 0):
+            stream = self._regrow_stream(st, flags)
+            fi = stream.frame_info(f)
         thermal = np.array(frame.pix, dtype=np.uint16, copy=True)
         P = clip.res_x * clip.res_y
         stats = (np.uint16(fi["thermal_min"]), np.uint16(fi["thermal_max"]), np.float64(fi["thermal_median"]),
@@ -473,7 +492,7 @@ class ClipTrackExtractor(ClipTracker):
             self._stream = None
         eng = TrackEngine(width=clip.res_x, height=clip.res_y, device=self.device, edge_pixels=self.config.edge_pixels,
                           background_thresh=clip.background_thresh, weight_add=weight_add, max_components=64,
-                          max_frames=max(capacity, 1024), denoise=bool(self.config.denoise))
+                          max_frames=max(capacity, 1024), denoise=bool(self.config.denoise))  # (grown on demand: _regrow_stream)
         params = make_track_params(
             clip.res_x, clip.res_y, self.config.edge_pixels, self.config.frame_padding, self.min_dimension,
             self.config.cropped_regions_strategy, self.config.filter_regions_pre_match, self.config.aoi_min_mass,
@@ -484,6 +503,39 @@ class ClipTrackExtractor(ClipTracker):
         self._stream = dict(clip=clip, stream=stream, tracks={}, weight_add=weight_add, engine=eng,
                             device_state=DeviceClipState(eng, stream.frames_dev, stream.result, []))
         return self._stream
+
+    def _regrow_stream(self, st, flags):
+        """A frame with more components, or a clip with more tracks, than the open stream's tables hold (the reference
+        has no such limit): a new stream with tables grown to fit takes over the frames consumed so far and runs them
+        again, so the clip stands where it stood, on larger tables.  A caller-owned background model cannot be replayed
+        (its past states are gone): that case reports the overflow."""
+        from ..engine import CpxError
+        from ..tracking import TrackParams
+
+        if self._external_bg is not None:
+            raise CpxError(-5, "a frame exceeds the stream's component / track capacity and the background model is "
+                               "caller-owned: its earlier states cannot be replayed")
+        cur, cur_eng = st["stream"], st["engine"]
+        while True:
+            need, tracks_full = cur.overflow()
+            if need <= cur_eng.cap and not tracks_full:
+                break
+            params = cur.params
+            if tracks_full:
+                params = TrackParams.from_buffer_copy(params)
+                params.max_active_tracks, params.max_tracks = cur.params.max_active_tracks * 2, cur.params.max_tracks * 2
+            eng = cur_eng.sibling(cur_eng.grown_capacity(max(need, cur_eng.cap)), max_frames=cur.cap_frames)
+            new = eng.open_stream(cur.cap_frames, params, want_labels=True)
+            new.replay(cur, flags=flags, associate=self.do_tracking)
+            cur_eng.close()  # (a stream owns its handle: the outgrown one goes)
+            cur, cur_eng = new, eng
+        index = st["device_state"]._index
+        st["stream"], st["engine"] = cur, cur_eng
+        st["device_state"] = DeviceClipState(cur_eng, cur.frames_dev, cur.result, [])
+        st["device_state"]._index = index
+        logging.info("stream tables grown to %d components, %d / %d tracks", cur_eng.cap,
+                     cur.params.max_active_tracks, cur.params.max_tracks)
+        return cur
 
     # ---- device path --------------------------------------------------------------------------------
     def _track_clip(self, clip, process_background=False):
@@ -499,20 +551,29 @@ class ClipTrackExtractor(ClipTracker):
         want_images = self.keep_frames
         frames_dev = self._frames_dev
         # update_background = False: the model stays as init_clip seeded it (cliptrackextractor.py:169)
+        track_flags = 0 if self.update_background else TRACK_FREEZE_BACKGROUND
         res = eng.track_batch(frames_dev, offs, meta, want_labels=want_images, want_filtered=True,
-                              want_background=True, flags=0 if self.update_background else TRACK_FREEZE_BACKGROUND)
+                              want_background=True, flags=track_flags)
         self._meta = meta
-        self._final_state = None   # read on demand (final_state), after the stream has drained anyway
-        self._final_engine = eng
-        self._final_call = eng.track_calls
-        assoc = None
+        assoc = params = None
         if self.do_tracking and not clip.from_metadata:
             params = make_track_params(
                 clip.res_x, clip.res_y, self.config.edge_pixels, self.config.frame_padding, self.min_dimension,
                 self.config.cropped_regions_strategy, self.config.filter_regions_pre_match, self.config.aoi_min_mass,
                 self.config.aoi_pixel_variance, self.config.params, clip.frames_per_second)
             assoc = eng.associate_batch(res, offs, meta, params=params)
-        res.check()
+        over = res.overflowed(offs)
+        if over or (assoc is not None and assoc.overflowed()):
+            # more components in a frame, or more tracks, than the tables hold: the reference has no such limit
+            # (cliptrackextractor.py:236-247, cliptracker.py:202-247) -- run the clip again on tables grown to fit
+            logging.info("%s: %s; tracking it again with larger tables", clip.source_file,
+                         ("%d components in a frame" % over[0]) if over else "track capacity exceeded")
+            eng, res, assoc, params = eng.track_clip_grown(
+                frames_dev, meta, params=params, need_components=over.get(0, 0), want_labels=want_images,
+                want_filtered=True, want_background=True, flags=track_flags, associate=assoc is not None)
+        self._final_state = None   # read on demand (final_state), after the stream has drained anyway
+        self._final_engine = eng
+        self._final_call = eng.track_calls
         self.timings["device_s"] = time.time() - t0
         labels = res.labels() if want_images else None
         filtered = res.filtered() if (want_images or self.calculate_filtered) else None
@@ -548,7 +609,7 @@ class ClipTrackExtractor(ClipTracker):
         if getattr(self, "_final_engine", None) is eng and b == 0 and n == len(self._frames or ()):
             self.background_alg._weights_from = self  # background_weight is fetched when somebody reads it
         if assoc is not None:
-            assoc.check()
+            assoc.check(b)
             clip.tracks = [Track.from_device(clip, rec, regs, self.tracker_version, self.config)
                            for rec, regs in assoc.clip_tracks(b)]
             last_frame = clip.current_frame

@@ -113,7 +113,7 @@ int fail(cpx_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t bg, wsum, kcnt, filt, cstate, u8, carry, bgavg, total;
+  size_t bg, wsum, kcnt, filt, cstate, u8, carry, bgavg, big, total;
 };
 
 WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
@@ -137,6 +137,11 @@ WsLayout ws_layout(const cpx_config& c, int B, bool need_filt_state) {
   off = align_up(off + (size_t)B * 2 * sizeof(cpx::FrameCarry), 256);
   l.bgavg = off;
   off = align_up(off + (size_t)B * sizeof(double), 256);
+  // a handle whose frames may hold more components than the frame kernel's LDS tables: the same tables per clip in HBM
+  // (eight statistics rows + the rank row of max_components entries; cpx_track.hip phase 7)
+  l.big = off;
+  if (c.max_components > cpx::track_lds_components())
+    off = align_up(off + (size_t)B * 9 * c.max_components * sizeof(uint32_t), 256);
   l.total = off;
   return l;
 }
@@ -436,6 +441,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.u8_state = (unsigned char*)(base + l.u8);
   a.carry = (cpx::FrameCarry*)(base + l.carry);
   a.bgavg = (double*)(base + l.bgavg);
+  a.big_stat = c.max_components > cpx::track_lds_components() ? (uint32_t*)(base + l.big) : nullptr;
   a.nlm_flip = c.denoise ? 1 : 0;
   a.nlm_lut = h->nlm_lut_dev;
   a.comps_out = comps_dev;

@@ -55,7 +55,10 @@ __global__ __launch_bounds__(64) void cpx_assoc_kernel(AssocArgs a) {
     }
     if (a.region_counts) a.region_counts[fidx] = nreg;
   }
-  a.n_tracks[b] = c.n_tracks;
+  // a clip that ran out of table space (components of a frame, simultaneous or total tracks) has no usable track list:
+  // it reports none, so that the stages behind spend nothing on it, and its status says why -- the caller runs it again
+  // on larger tables (cpx.engine.TrackEngine.track_clip_grown)
+  a.n_tracks[b] = c.status != 0 ? 0 : c.n_tracks;
   a.status[b] = c.status;
   AssocResume r;
   r.n_active = c.n_active;

@@ -80,6 +80,7 @@ struct TrackArgs {
   unsigned char* u8_state;  // [B][P] normalised uint8 image between front / NLM / back (denoise only)
   FrameCarry* carry;        // [B]
   const int* nlm_lut;       // [64] fixed-point NLM weights (denoise only)
+  uint32_t* big_stat;       // [B][9][cap_out] component tables in HBM for frames beyond the LDS tables, or nullptr
   // outputs
   Component* comps_out;     // [total_frames * cap_out]
   FrameInfo* info_out;      // [total_frames]

@@ -793,28 +793,46 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       const u32 root = uf_find(s_par, slot);
       if (root == slot) {
         const u32 cid = atomicAdd(s_ncomp_p, 1u);
-        if (cid < (u32)CAP) s_cid[slot] = (uint16_t)cid;
+        s_cid[slot] = (uint16_t)cid;  // (at most one component per 2 x 2 block: < 2^16 at any supported resolution)
       }
     }
   }
   __syncthreads();
   const int ncomp_all = uni((int)*s_ncomp_p);
-  const bool overflow = ncomp_all > CAP || ncomp_all > a.cap_out;
+  // More components than the LDS tables hold (CAP): a handle created with max_components > CAP brings per-clip tables in
+  // HBM (a.big_stat: the same eight statistics rows + the rank row, a.cap_out entries each) and the frame takes the same
+  // code on those -- slower (global atomics, an O(n^2) ranking over thousands), but a frame of hot pixels or rain is
+  // a frame the reference processes too (cliptrackextractor.py:236-247 has no limit).  Without them, or beyond the
+  // caller's own capacity, the frame reports CPX_ERR_OVERFLOW and the count it needs.
+  const bool big = ncomp_all > CAP && a.big_stat != nullptr && ncomp_all <= a.cap_out;
+  const bool overflow = !big && (ncomp_all > CAP || ncomp_all > a.cap_out);
   const int ncomp = overflow ? 0 : ncomp_all;
+  const bool has_prev = cs.has_prev != 0;
+  double* s_part = reinterpret_cast<double*>(s_rowI);  // [2][NWAVE][2]: the un-closed bit rows are dead by now
 
+  // phases 7 and 8 over statistics tables `stat` [8][SC] and ranks `rnk` [SC]: the LDS ones (SC = CAP, every ordinary
+  // frame) or the clip's HBM ones (SC = a.cap_out); a generic lambda, so that each call is compiled for its address space
+  auto label_phases = [&](auto* stat, auto* rnk, const int SC, const bool in_hbm) __attribute__((always_inline)) {
+  // tables in HBM: what one wave wrote (stores, atomics at L2) must be what another reads after the barrier, and the
+  // CU's vector cache may still hold the lines from the clip's previous frame -- write back / invalidate around it
+  auto phase_sync = [&]() __attribute__((always_inline)) {
+    if (in_hbm) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (in_hbm) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  };
   // ---- phase 7: statistics per component ------------------------------------------------
-  // s_stat rows: 0 area, 1 minx, 2 maxx, 3 miny, 4 maxy, 5 sumx, 6 sumy, 7 key
+  // stat rows: 0 area, 1 minx, 2 maxx, 3 miny, 4 maxy, 5 sumx, 6 sumy, 7 key
   for (int i = tid; i < ncomp; i += NT) {
-    s_stat[0 * CAP + i] = 0;
-    s_stat[1 * CAP + i] = 0xFFFFFFFFu;
-    s_stat[2 * CAP + i] = 0;
-    s_stat[3 * CAP + i] = 0xFFFFFFFFu;
-    s_stat[4 * CAP + i] = 0;
-    s_stat[5 * CAP + i] = 0;
-    s_stat[6 * CAP + i] = 0;
-    s_stat[7 * CAP + i] = 0xFFFFFFFFu;
+    stat[0 * SC + i] = 0;
+    stat[1 * SC + i] = 0xFFFFFFFFu;
+    stat[2 * SC + i] = 0;
+    stat[3 * SC + i] = 0xFFFFFFFFu;
+    stat[4 * SC + i] = 0;
+    stat[5 * SC + i] = 0;
+    stat[6 * SC + i] = 0;
+    stat[7 * SC + i] = 0xFFFFFFFFu;
   }
-  __syncthreads();
+  phase_sync();
   if (ncomp > 0) {
     for (int i = tid; i < H * RW; i += NT) {
       const int y = i / RW, w = i - y * RW;
@@ -830,26 +848,26 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
         const u32 root = uf_find(s_par, slot);
         const u32 cid = s_cid[root];
         const u32 len = (u32)(xe - xs + 1);
-        atomicAdd(&s_stat[0 * CAP + cid], len);
-        atomicMin(&s_stat[1 * CAP + cid], (u32)xs);
-        atomicMax(&s_stat[2 * CAP + cid], (u32)xe);
-        atomicMin(&s_stat[3 * CAP + cid], (u32)y);
-        atomicMax(&s_stat[4 * CAP + cid], (u32)y);
-        atomicAdd(&s_stat[5 * CAP + cid], (u32)((xs + xe) * (int)len / 2));
-        atomicAdd(&s_stat[6 * CAP + cid], (u32)y * len);
-        atomicMin(&s_stat[7 * CAP + cid], (u32)((y >> 1) * SW + (xs >> 1)));
+        atomicAdd(&stat[0 * SC + cid], len);
+        atomicMin(&stat[1 * SC + cid], (u32)xs);
+        atomicMax(&stat[2 * SC + cid], (u32)xe);
+        atomicMin(&stat[3 * SC + cid], (u32)y);
+        atomicMax(&stat[4 * SC + cid], (u32)y);
+        atomicAdd(&stat[5 * SC + cid], (u32)((xs + xe) * (int)len / 2));
+        atomicAdd(&stat[6 * SC + cid], (u32)y * len);
+        atomicMin(&stat[7 * SC + cid], (u32)((y >> 1) * SW + (xs >> 1)));
       }
     }
   }
-  __syncthreads();
+  phase_sync();
   // OpenCV numbers components by the raster position of their first 2x2 block (SURVEY a7')
   for (int i = tid; i < ncomp; i += NT) {
-    const u32 k = s_stat[7 * CAP + i];
+    const u32 k = stat[7 * SC + i];
     u32 rank = 0;
-    for (int j = 0; j < ncomp; ++j) rank += (s_stat[7 * CAP + j] < k) ? 1u : 0u;
-    s_rank[i] = rank;
+    for (int j = 0; j < ncomp; ++j) rank += (stat[7 * SC + j] < k) ? 1u : 0u;
+    rnk[i] = rank;
   }
-  __syncthreads();
+  phase_sync();
 
   // ---- phase 8a: label image (Frame.mask) ------------------------------------------------------
   if (a.labels_out) {
@@ -866,7 +884,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
           if (nib & (1u << j)) {
             const int xs = run_start(rowL, x0 + j);
             const u32 root = uf_find(s_par, (u32)(y * SW + (xs >> 1)));
-            lab[j] = (int)s_rank[s_cid[root]] + 1;
+            lab[j] = (int)rnk[s_cid[root]] + 1;
           }
         }
       } else if (nib) {
@@ -881,7 +899,6 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   // normalize() promotes to float64 for these float64 frames (NumPy >= 2 scalar promotion).
   // Small boxes: one wave each.  Large boxes: the whole workgroup, partials combined in wave order.
   Component* Cout = a.comps_out + (size_t)fidx * a.cap_out;
-  const bool has_prev = cs.has_prev != 0;
   const double cmin = (double)s_R->fmin, cmax = (double)s_R->fmax;
   const double pmin = (double)cs.prev_fmin, pmax = (double)cs.prev_fmax;
   auto delta_at = [&](int q) -> double {
@@ -899,18 +916,17 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     o.y = by;
     o.width = bw;
     o.height = bh;
-    o.area = (int)s_stat[0 * CAP + cidx];
-    o.sum_x = (int)s_stat[5 * CAP + cidx];
-    o.sum_y = (int)s_stat[6 * CAP + cidx];
+    o.area = (int)stat[0 * SC + cidx];
+    o.sum_x = (int)stat[5 * SC + cidx];
+    o.sum_y = (int)stat[6 * SC + cidx];
     o.pixel_variance = var;
-    Cout[s_rank[cidx]] = o;
+    Cout[rnk[cidx]] = o;
   };
   constexpr int BIG = 512;  // pixels: above this a box is summed by the whole workgroup
-  double* s_part = reinterpret_cast<double*>(s_rowI);  // [2][NWAVE][2]: the un-closed bit rows are dead by now
   int par = 0;
   for (int cidx = 0; cidx < ncomp; ++cidx) {
-    const int bx = (int)s_stat[1 * CAP + cidx], by = (int)s_stat[3 * CAP + cidx];
-    const int bw = (int)s_stat[2 * CAP + cidx] - bx + 1, bh = (int)s_stat[4 * CAP + cidx] - by + 1;
+    const int bx = (int)stat[1 * SC + cidx], by = (int)stat[3 * SC + cidx];
+    const int bw = (int)stat[2 * SC + cidx] - bx + 1, bh = (int)stat[4 * SC + cidx] - by + 1;
     const int n = bw * bh;
     if (n > BIG && has_prev) {
       double s1 = 0.0, s2 = 0.0;
@@ -926,7 +942,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
         s_part[(par * NWAVE + wave) * 2] = s1;
         s_part[(par * NWAVE + wave) * 2 + 1] = s2;
       }
-      __syncthreads();
+      phase_sync();
       if (tid == 0) {
         double t1 = 0.0, t2 = 0.0;
         for (int w = 0; w < NWAVE; ++w) {
@@ -957,6 +973,10 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       if (lane == 0) emit(cidx, bx, by, bw, bh, var);
     }
   }
+
+  };
+  if (big) label_phases(a.big_stat + (size_t)b * 9 * a.cap_out, a.big_stat + (size_t)b * 9 * a.cap_out + (size_t)8 * a.cap_out, a.cap_out, true);
+  else label_phases(s_stat, s_rank, CAP, false);
 
   // ---- per-frame record + clip state -------------------------------------------------------------------
   const Red1 R = *s_R;  // (written two phases ago; every thread keeps the new clip state for the clip's next frame)

@@ -321,7 +321,9 @@ int cpx_track_batch(cpx_handle* h, const uint16_t* frames_dev, const int32_t* cl
  * Inputs are the outputs of cpx_track_batch (same clip_offsets / meta).
  * pool_dev     cpx_region [total_frames * max_active_tracks]  track histories
  * tracks_dev   cpx_track_record [B * max_tracks], n_tracks_dev int32 [B]
- * status_dev   int32 [B]: 0 or CPX_ERR_OVERFLOW (more simultaneous / total tracks than capacity)
+ * status_dev   int32 [B]: 0 or CPX_ERR_OVERFLOW (more simultaneous / total tracks than capacity, or a frame of the clip
+ *              with more components than max_components); n_tracks_dev of such a clip is 0: run it again on larger
+ *              tables (the reference has no limits: cliptracker.py:202-247)
  * regions_dev  cpx_region [total_frames * max_components] or NULL (clip.region_history),
  * region_counts_dev int32 [total_frames] or NULL
  */
