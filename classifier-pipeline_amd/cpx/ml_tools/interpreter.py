@@ -269,7 +269,9 @@ class Interpreter:
 
 
 class WRResNetInterpreter(Interpreter):
-    """WR-ResNet on the MFMA kernels; model = <name>.npz (Keras-layout weights) + <name>.json."""
+    """WR-ResNet on the MFMA kernels; model = <name>.npz (Keras-layout weights) or a released <name>.tflite (read in
+    pure Python on load: cpx/ml_tools/tflite_reader.py -- what the reference's LiteInterpreter takes,
+    interpreter.py:520-560) + the sidecar <name>.json."""
 
     TYPE = "cpx-hip"
 
@@ -294,7 +296,13 @@ class WRResNetInterpreter(Interpreter):
 
         from .wrresnet import head_of
 
-        self._weights = load_weights(self.model_file.with_suffix(".npz"))
+        if self.model_file.suffix == ".tflite":
+            from .tflite_reader import load_tflite
+
+            logging.info("Reading TFLite model %s", self.model_file)
+            self._weights = load_tflite(self.model_file)
+        else:
+            self._weights = load_weights(self.model_file.with_suffix(".npz"))
         n = self._weights["prediction/bias"].shape[0]
         if n != len(self.labels):
             raise ValueError("model has %d outputs but %d labels" % (n, len(self.labels)))
@@ -348,10 +356,16 @@ def inc3_preprocess(x):
 def get_interpreter(model, run_over_network=False, load_model=True, seed=None):
     """Factory with the reference's signature (interpreter.py:597-628)."""
     suffix = Path(model.model_file).suffix
-    if model.type not in (None, WRResNetInterpreter.TYPE) or suffix not in (".npz", ".json", ""):
+    if suffix in (".keras", ".h5", ".pb", ".sav"):
+        # interpreter.py:597-628 hands these to TensorFlow (KerasModel) or joblib (ForestModel): neither runtime is part
+        # of this build -- a Keras WR-ResNet converts once, where TensorFlow is installed
         raise NotImplementedError(
-            "model type %r (%s): cpx runs WR-ResNet models converted to <name>.npz + <name>.json "
-            "(TensorFlow / TFLite / RandomForest runtimes are not part of this build)" % (model.type, model.model_file))
+            "%s: convert the Keras model once with `python tools/keras_to_npz.py %s <name>` (runs where TensorFlow is "
+            "installed) and pass <name>.npz; a released .tflite model is read directly" % (model.model_file, model.model_file))
+    if model.type not in (None, WRResNetInterpreter.TYPE, "tflite", "keras") or suffix not in (".npz", ".json", "", ".tflite"):
+        raise NotImplementedError(
+            "model type %r (%s): cpx runs WR-ResNet models as <name>.npz + <name>.json or as a released <name>.tflite "
+            "(TensorFlow / RandomForest runtimes are not part of this build)" % (model.type, model.model_file))
     classifier = WRResNetInterpreter(model.model_file, run_over_network, load_model)
     classifier.id = model.id
     classifier.port = model.port

@@ -185,10 +185,19 @@ class WRResNetDevice:
             self.p[name + "/b"] = up(w[name + "/bias"])
         self._bufs = {}
         self._cnn = None
-        # what the 3x3 convolutions' activated inputs can reach, in launch order (fp16x2 range scaling)
-        self.act_bounds = [activation_bound(w, "bn%db%d_branch2%s" % (stage, d, ab))
-                           for stage in (2, 3, 4) for d in range(BLOCKS) for ab in "ab"]
+        # what the 3x3 convolutions' activated inputs can reach, in launch order (fp16x2 range scaling): from the
+        # BatchNorm parameters where the archive has them; a model whose BatchNorms arrive folded into scale / shift (a
+        # .tflite: moving_variance is the reader's identity marker) says nothing about its activations' spread -- there
+        # the bounds are measured on a seeded probe batch, with headroom (_measure_activation_bounds)
+        names = ["bn%db%d_branch2%s" % (stage, d, ab) for stage in (2, 3, 4) for d in range(BLOCKS) for ab in "ab"]
+        self.act_bounds = [activation_bound(w, n) for n in names]
+        folded = [bool(np.allclose(w[n + "/moving_variance"], 1.0 - BN_EPS) and np.all(w[n + "/moving_mean"] == 0))
+                  for n in names]
         self._create_native()
+        if any(folded):
+            measured = self._measure_activation_bounds()
+            self.act_bounds = [m if f else b for b, m, f in zip(self.act_bounds, measured, folded)]
+            self._set_activation_bounds()
 
     def _create_native(self):
         ptr = lambda key: self.p[key].data_ptr()
@@ -217,10 +226,29 @@ class WRResNetDevice:
         if rc != 0:
             raise CpxError(rc, self.eng._err())
         self._cnn = out
+        self._set_activation_bounds()
+
+    def _set_activation_bounds(self):
         bounds = (C.c_float * len(self.act_bounds))(*self.act_bounds)
         rc = self.lib.cpx_cnn_set_activation_bounds(self._cnn, bounds, len(self.act_bounds))
         if rc != 0:
             raise CpxError(rc, self.eng._err())
+
+    def _measure_activation_bounds(self, headroom=32.0, n=2, seed=12345):
+        """The largest activated input of every 3x3 convolution on a seeded probe batch (uniform 0..255 tiles through the
+        network layer by layer, exact-split math), times `headroom`: deterministic for a given model; an input that goes
+        beyond it costs the overflow rerun, never correctness."""
+        t = self.torch
+        rng = np.random.default_rng(seed)
+        x = t.from_numpy(rng.uniform(0, 255, size=(n, 160, 160, 2)).astype(np.float32)).to(self.eng.device)
+        prev = self.eng.get_cnn_math()
+        self.eng.set_cnn_math("bf16x3")
+        seen = []
+        try:
+            self.forward_layerwise(x, want_probs=False, _probe=seen)
+        finally:
+            self.eng.set_cnn_math(prev)
+        return [max(float(v) * headroom, 1e-3) for v in seen]
 
     def close(self):
         if self._cnn is not None:
@@ -280,7 +308,7 @@ class WRResNetDevice:
         if rc != 0:
             raise CpxError(rc, self.eng._err())
 
-    def forward_layerwise(self, x, want_probs=True):
+    def forward_layerwise(self, x, want_probs=True, _probe=None):
         """The same network issued layer by layer through cpx_conv2d / cpx_cnn_head (what a caller binding the
         building blocks directly would write); tests compare it with forward()."""
         t = self.torch
@@ -298,8 +326,14 @@ class WRResNetDevice:
                 s = stride if d == 0 else 1
                 Ho, Wo = -(-H // s), -(-W // s)
                 mid = self._buf("mid", (N, Ho, Wo, f))
+                if _probe is not None:  # the activated input of branch2a: relu(BatchNorm 2a(block input))
+                    self.eng.synchronize()
+                    _probe.append(t.relu(cur * self.p["%s/in_scale" % b] + self.p["%s/in_shift" % b]).max().item())
                 self._conv(cur, mid, "%s/wa" % b, N, H, W, c_in, f, 3, s, True, True, in_affine=b,
                            out_scale=self.p["%s/a_scale" % b], out_shift=self.p["%s/a_shift" % b])
+                if _probe is not None:  # branch2b reads `mid` as it is
+                    self.eng.synchronize()
+                    _probe.append(mid.max().item())
                 if d == 0:
                     sc = self._buf("sc", (N, Ho, Wo, f))
                     self._conv(cur, sc, "sc%d/w" % stage, N, H, W, c_in, f, 1, s, False, False,

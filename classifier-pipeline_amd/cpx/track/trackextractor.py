@@ -32,16 +32,31 @@ class TrackExtractor:
             return
         # one GPU per process (the reference forks a pool of CPU workers, trackextractor.py:60-120): the files of a
         # directory go through the device in batches -- decoded, tracked and associated together
-        todo = []
+        todo, gray, videos = [], [], []
         for folder, _, files in os.walk(base):
             for name in sorted(files):
-                if os.path.splitext(name)[1] == ".cptv":
+                ext = os.path.splitext(name)[1]
+                if ext == ".cptv":
                     todo.append(os.path.join(folder, name))
+                elif ext in (".y4m",):  # raw-gray IR recordings (cpx/track/grayvideo.py): one at a time
+                    gray.append(os.path.join(folder, name))
+                elif ext in (".mp4", ".avi"):
+                    videos.append(os.path.join(folder, name))
+        if videos:
+            # the reference walks these too (trackextractor.py:72-76) and decodes them with cv2.VideoCapture; no video
+            # decoder is built here (out of scope) -- convert to .y4m / .npy gray frames first
+            logging.warning("%d .mp4 / .avi recordings skipped (no video decoder in this build): %s ...", len(videos),
+                            videos[0])
         # under torchrun (one process per GPU) every rank takes its share of the files and its own device; each file's
         # metadata is written by the rank that tracked it, no collective is needed
         rank, world, local_rank = rank_world()
         todo = shard_files(todo, rank, world)
         device = local_rank if world > 1 else 0
+        for path in shard_files(gray, rank, world):
+            try:
+                extract_file(path, self.config, self.cache_to_disk, self.retrack, to_stdout)
+            except Exception:  # noqa: BLE001 -- one bad recording does not stop a directory run
+                logging.exception("%s failed", path)
         if self.retrack:  # existing tracks are re-used per file: no batch form
             step = self.batch_files or 1024
             for i in range(0, len(todo), step):

@@ -351,3 +351,37 @@ def test_calibrate_bn_device_matches_oracle(engine):
             np.testing.assert_allclose(got[k], v, rtol=2e-3, atol=2e-3, err_msg=k)
     logits, _ = co.forward(got, x)
     assert float(np.abs(logits).max()) < 50.0
+
+
+def test_tflite_model_runs_in_fp16x2_without_the_rerun(engine, tmp_path):
+    """A .tflite model's BatchNorms arrive folded (scale / shift, no statistics): the fp16 range scaling of its layers comes
+    from a seeded probe forward at load (WRResNetDevice._measure_activation_bounds).  Its forward in the default math must
+    stay on the fp16 kernels (no overflow rerun) and match the float32 restatement of the ORIGINAL weights."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.ml_tools import wrresnet as wr
+    from cpx.ml_tools.tflite_reader import load_tflite
+    from test_tflite_import_cpu import tflite_of
+
+    rng = np.random.default_rng(41)
+    x = rng.uniform(0, 255, size=(3, 160, 160, 2)).astype(np.float32)
+    w = co.calibrate_bn(wr.random_weights(17, seed=8), x)
+    p = tmp_path / "m.tflite"
+    p.write_bytes(tflite_of(w, ()))
+    lite = load_tflite(p)
+    engine.set_cnn_math("fp16x2")
+    net = wr.WRResNetDevice(engine, lite, 17)
+    plain = wr.WRResNetDevice(engine, w, 17)
+    assert all(b > 0 for b in net.act_bounds) and net.act_bounds != plain.act_bounds
+    logits, _ = net.forward(torch.from_numpy(x).to(engine.device))
+    assert not engine.cnn_last_overflow()
+    want, _ = co.forward(w, x)
+    assert float(np.abs(logits.cpu().numpy() - want).max()) <= LOGIT_ATOL
+    # smooth inputs (what real crops look like) reach further than the noise probe: still inside the headroom
+    xs = np.repeat(np.repeat(rng.uniform(0, 255, size=(2, 20, 20, 2)).astype(np.float32), 8, axis=1), 8, axis=2)
+    net.forward(torch.from_numpy(xs).to(engine.device))
+    assert not engine.cnn_last_overflow()
+    net.close()
+    plain.close()
+    engine.set_cnn_math(engine.DEFAULT_CNN_MATH)

@@ -244,3 +244,30 @@ def test_not_a_tflite_file_is_refused():
     tool = _tool()
     with pytest.raises(ValueError):
         tool.Graph(b"\0" * 64)
+
+
+def test_get_interpreter_reads_a_tflite_model_on_load(tmp_path):
+    """get_interpreter on a `.tflite` path (what the reference's LiteInterpreter takes, interpreter.py:520-560,597-628):
+    the flatbuffer is converted on load by the package's own reader; Keras / RandomForest files name their converter."""
+    import json
+
+    import cnn_oracle as co
+    from cpx.config.config import ModelConfig
+    from cpx.ml_tools import wrresnet as wr
+    from cpx.ml_tools.interpreter import get_interpreter
+
+    w = wr.random_weights(17, seed=6)
+    x = np.random.default_rng(4).uniform(0, 255, size=(2, 160, 160, 2)).astype(np.float32)
+    w = co.calibrate_bn(w, x)
+    (tmp_path / "model.tflite").write_bytes(tflite_of(w, ()))
+    labels = ["l%d" % i for i in range(17)]
+    with open(tmp_path / "model.json", "w") as fh:
+        json.dump({"labels": labels, "hyperparams": {"frame_size": 32}, "type": "thermal"}, fh)
+    interp = get_interpreter(ModelConfig.load({"id": 1, "name": "lite", "model_file": str(tmp_path / "model.tflite")}))
+    assert interp.labels == labels and interp._weights is not None
+    want, _ = co.forward(w, x)
+    have, _ = co.forward(interp._weights, x)
+    assert float(np.abs(want - have).max()) <= 2e-4
+    for name in ("model.keras", "model.h5", "forest.sav"):
+        with pytest.raises(NotImplementedError, match="keras_to_npz"):
+            get_interpreter(ModelConfig.load({"id": 2, "name": "k", "model_file": str(tmp_path / name)}))
