@@ -112,9 +112,12 @@ class ClipClassifier:
         # (clipclassifier.py:60-83,254-256): it comes from the recording's existing metadata file
         location = self.first_location(todo)
         classifiers = [self.get_classifier(m, location) for m in models]
+        # (a model served over the network -- the families whose networks are not built here, or any run_over_network
+        # model -- has no device network for the bulk path's batched forward: its samples go to the server per file)
         per_file = bool(reuse_frames) or any(c.params.square_width == 1 for c in classifiers) \
-            or len(set(c.limits_flags() for c in classifiers)) > 1
-        if per_file:  # saved frames decide the segments / single-frame models / mixed normalisation variants
+            or len(set(c.limits_flags() for c in classifiers)) > 1 \
+            or any(c.run_over_network or getattr(c, "_weights", None) is None for c in classifiers)
+        if per_file:  # saved frames decide the segments / single-frame models / mixed normalisation variants / served models
             for i in range(0, len(todo), 64):
                 self.process_files(todo[i:i + 64], reuse_frames=reuse_frames,
                                    calculate_thumbnails=calculate_thumbnails, device=local_rank if world > 1 else 0)

@@ -426,6 +426,9 @@ class BulkTracker:
             for model, interp in classifiers:
                 if interp.params.square_width != sq:
                     raise NotImplementedError("models with different square_width in one run")
+                if interp.run_over_network or getattr(interp, "_weights", None) is None:
+                    raise NotImplementedError("a model served over the network has no device network for the batched "
+                                              "forward: classify such models per file (ClipClassifier.process_files)")
                 fpi = interp.labels.index("false-positive") if "false-positive" in interp.labels else -1
                 mp = BatchPipeline(eng, interp._network(eng), n_labels=len(interp.labels), fp_index=fpi,
                                    frame_size=interp.params.frame_size, square_width=sq, track_params=tp,

@@ -489,11 +489,22 @@ CPX_HD inline void assoc_frame(AssocClip& c, int nreg, int frame_number) {
     ScoreRec q = c.scores[best];
     c.scores[best].track = -1;
     remaining -= 1;
-    if (c.active[q.track].matched || c.used[q.region]) continue;
+    if (c.active[q.track].matched || c.used[q.region]) continue;  // (matched == 2: blanked below)
     c.used[q.region] = 1;
+    // cliptracker.py:164-199: with filter_regions_pre_match off the area-of-interest filter runs AFTER the matching: a
+    // region too faint or too small still takes its track's match (and is used up), but the track gets a blank frame
+    // instead of it -- "rather than if we filter earlier and match this track to a different region"
+    const RegionRec& mr = c.regs[q.region];
+    if (!c.p->filter_regions_pre_match &&
+        ((double)mr.pixel_variance < c.p->aoi_pixel_variance || (double)mr.mass < c.p->aoi_min_mass)) {
+      c.active[q.track].matched = 2;
+      continue;
+    }
     track_add_region(c, c.active[q.track], c.regs[q.region]);
     c.active[q.track].matched = 1;
   }
+  for (int ti = 0; ti < c.n_active; ++ti)
+    if (c.active[ti].matched == 2) c.active[ti].matched = 0;  // a blanked track is an unmatched one from here on
   // ---- new tracks for unmatched regions, in region-id order -----------------
   const int n_old = c.n_active;
   for (int ri = 0; ri < nreg; ++ri) {

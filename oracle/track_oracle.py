@@ -172,14 +172,16 @@ class WeightedBackground:
     def process_frame(self, frame):
         """motiondetector.py:197-237.  `frame` is uint16 or the float64 window mean."""
         e = self.edge
-        f = np.int32(frame[e:-e, e:-e])
+        H, W = frame.shape
+        inner_of = lambda a: a[e:H - e, e:W - e]  # (edge_pixels may be 0: a [e:-e] slice would be empty)
+        f = np.int32(inner_of(frame))
         if self.background is None:
             self.background = np.empty(frame.shape)
-            self.background[e:-e, e:-e] = f
+            inner_of(self.background)[:, :] = f
             self.average = np.average(f)  # un-rounded float (:209)
             self._set_edges()
             return
-        inner = self.background[e:-e, e:-e]
+        inner = inner_of(self.background)
         cond = inner < f - self.weight
         new_bg = np.where(cond, inner, f)
         self.weight = np.where(cond, self.weight + self.weight_add, 0)
@@ -557,13 +559,21 @@ def apply_matchings(state, regions):
         scores.extend(t.match(regions))
     scores.sort(key=lambda r: r[1].since_seen + float(".{}".format(r[1].id)))
     scores.sort(key=lambda r: r[0])
-    matched, used = [], set()
+    matched, used, blanked = [], set(), []
     unmatched = list(regions)
     for score, track, region in scores:
-        if track in matched or id(region) in used:
+        if track in matched or id(region) in used or track in blanked:
             continue
         used.add(id(region))
         unmatched.remove(region)
+        # cliptracker.py:164-199: with filter_regions_pre_match off the area-of-interest filter runs AFTER the matching: a
+        # region too faint or too small still takes its track's match (and is used up), but the track gets a blank frame
+        # instead of it -- "rather than if we filter earlier and match this track to a different region"
+        if not cfg.filter_regions_pre_match and (
+            region.pixel_variance < cfg.aoi_pixel_variance or region.mass < cfg.aoi_min_mass
+        ):
+            blanked.append(track)
+            continue
         track.add_region(region)
         matched.append(track)
     new_tracks = []

@@ -299,3 +299,51 @@ def test_classify_service_socket(tmp_path, model_dir):
         assert os.path.exists(src.with_suffix(".txt"))
     finally:
         service.stop()
+
+
+def test_process_directory_with_a_served_model(tmp_path, model_dir):
+    """ClipClassifier.process(directory) with a model served over the network (run_over_network: what the families whose
+    networks are not built here need): the bulk path has no device network for it, so the recordings go per file and
+    their samples to the server -- the same predictions as the local model, one device pass per file."""
+    import threading
+
+    from cpx import servemodel
+    from cpx.classify.clipclassifier import ClipClassifier
+    from cpx.config import Config
+    from cpx.config.config import ModelConfig
+    from cpx.ml_tools.interpreter import get_interpreter
+
+    mdir, w = model_dir
+    local = get_interpreter(ModelConfig.load({"id": 3, "name": "wr", "model_file": str(mdir / "wr.npz")}))
+    server = servemodel.make_server(local, 0)
+    port = server.server_address[1]
+    th = threading.Thread(target=server.serve_forever, daemon=True)
+    th.start()
+    try:
+        a, b = tmp_path / "served", tmp_path / "local"
+        for d in (a, b):
+            d.mkdir()
+            for name in ("possum", "hedgehog"):
+                shutil.copy(os.path.join(GOLDEN, name + ".cptv"), d / (name + ".cptv"))
+        metas = {}
+        for d, served in ((a, True), (b, False)):
+            cfg = Config.get_defaults()
+            cfg.tracking["thermal"].denoise = False
+            cfg.classify.models = [ModelConfig.load({"id": 7, "name": "wr-test", "model_file": str(mdir / "wr.npz"),
+                                                     "run_over_network": served, "port": port})]
+            cc = ClipClassifier(cfg)
+            cc.process(str(d), track=True)
+            for name in ("possum", "hedgehog"):
+                with open(d / (name + ".txt")) as fh:
+                    metas[(served, name)] = json.load(fh)
+        for name in ("possum", "hedgehog"):
+            ma, mb = metas[(True, name)], metas[(False, name)]
+            assert len(ma["tracks"]) == len(mb["tracks"]) >= 1
+            for ta, tb in zip(ma["tracks"], mb["tracks"]):
+                assert len(ta["predictions"]) == len(tb["predictions"]) == 1
+                # (process_file draws its segments at random, the bulk path plans them with identity draws: the two runs
+                # classify different segments of the same track -- what must agree is that both classified it)
+                assert ta["predictions"][0]["model_id"] == tb["predictions"][0]["model_id"] == 7
+    finally:
+        server.shutdown()
+        server.server_close()

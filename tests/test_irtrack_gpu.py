@@ -40,7 +40,10 @@ def _ir_oracle_config():
     cfg = to.OracleConfig("lepton3")
     # the reference's IR TrackingConfig (config/trackingconfig.py:179-208)
     cfg.edge_pixels, cfg.frame_padding, cfg.min_dimension = 0, 10, 10
-    cfg.aoi_min_mass, cfg.aoi_pixel_variance, cfg.filter_regions_pre_match = 0, 0, False
+    # (areas_of_interest is zeroed for IR there, but the ATTRIBUTES the tracker reads keep the thermal placeholders 4.0 /
+    # 2.0 unless a YAML is loaded -- pinned by tests/golden/config_golden.json; with filter_regions_pre_match off they
+    # act after the matching: a faint matched region becomes a blank frame of its track, cliptracker.py:164-199)
+    cfg.aoi_min_mass, cfg.aoi_pixel_variance, cfg.filter_regions_pre_match = 4.0, 2.0, False
     cfg.base_distance_change, cfg.min_mass_change, cfg.mass_change_percent = 12000, None, None
     cfg.max_distance, cfg.velocity_multiplier, cfg.base_velocity, cfg.fps = 30752, 8, 10, 10
     return cfg
