@@ -186,15 +186,51 @@ def spawn_ranks(n, argv):
     return proc.wait()
 
 
-def dry_launch(args):
-    """--dry-launch: the ranks rendezvous over gloo, report themselves and leave -- the launch path of --gpus N checked
-    without a GPU (tests/test_bench_launch_cpu.py)."""
+# keys every default (e2e) line carries, whatever N: the driver compares the N = 1 line of the scaling run with the
+# default run's; --dry-launch emits the same skeleton (values None) so that a CPU host can check the assembly
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "roofline_track", "cnn", "per_rank")
+MULTI_RANK_KEYS = ("config4", "from_files")
+
+
+def per_rank_summary(times_s, steps, loads=None):
+    """What attributes a scaling result: every rank's own ms per step (before the max), their spread, and the load
+    imbalance of the partition (max over mean of the ranks' frame counts; 1.0 for the weak-scaling leg by construction)."""
+    ms = [round(t / max(steps, 1) * 1e3, 3) for t in times_s]
+    out = {"ms_per_step": ms, "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+           "slowest_over_fastest": round(max(ms) / max(min(ms), 1e-9), 4)}
+    if loads:
+        out["frames_per_rank"] = [int(v) for v in loads]
+        out["imbalance"] = round(max(loads) / (sum(loads) / len(loads)), 4)
+    return out
+
+
+def dry_launch(args, numa=None):
+    """--dry-launch: the ranks rendezvous over gloo and run the HOST side of a multi-GPU bench run -- the NUMA pinning,
+    the LPT partition of configs[3], one gather_records exchange of records of its width, the per-rank from_files
+    aggregation (all_gather_object), the per-rank timing summary -- with the device work left out; rank 0 prints the line
+    skeleton.  The launch path of --gpus N checked without a GPU (tests/test_bench_launch_cpu.py spawns 2 and 8 ranks)."""
     import torch
     import torch.distributed as dist
+
+    from cpx.sharding import gather_records, partition_clips
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     seen = [rank]
+    T = args.frames
+    lengths = config4_lengths(10000)
+    shards = partition_clips(lengths, world)
+    loads = [int(lengths[s].sum()) for s in shards]
+    mine = shards[rank]
+    rec = torch.empty((len(mine), 2 + N_LABELS), dtype=torch.int32)
+    rec[:, 0] = torch.tensor(mine, dtype=torch.int32)
+    rec[:, 1:] = rank
+    ff = {"files": max(512, args.from_files // world) if world > 1 else args.from_files, "frames": 270 * 512,
+          "seconds": 1.0 + 0.05 * rank, "frames_per_s": 270 * 512 / (1.0 + 0.05 * rank), "split_s": {}, "what": "dry launch",
+          "roofline_inflate": {"frac": None}, "numa": numa}
+    times = [1.0 + 0.01 * rank]
+    gathered = rec
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
@@ -202,12 +238,29 @@ def dry_launch(args):
         t[rank] = rank + 1
         dist.all_reduce(t)
         seen = [int(v) - 1 for v in t]
+        gathered = gather_records(rec, dist)
+        tt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tt, torch.tensor([times[0]], dtype=torch.float64))
+        times = [float(v.item()) for v in tt]
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, ff)
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        per_rank = [ff]
     if rank == 0:
-        print(json.dumps({"metric": "CPTV frames/s end-to-end (track+classify) at 160x120", "value": None, "unit": "frames/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_launch": True,
-                          "ranks": seen}), flush=True)
+        line = {k: None for k in LINE_KEYS}
+        line.update({"metric": "CPTV frames/s end-to-end (track+classify) at 160x120", "unit": "frames/s",
+                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                     "scaling": "weak", "data": "synthetic", "dry_launch": True, "ranks": seen,
+                     "config": {"workload": "dry launch: host logic only", "frames_per_clip": T},
+                     "per_rank": per_rank_summary(times, 1, [4096 * T] * world)})
+        if world > 1:
+            line["config4"] = {"scaling": "strong", "clips": 10000, "frames_total": int(lengths.sum()),
+                               "frames_per_rank": loads, "imbalance": round(max(loads) / (sum(loads) / len(loads)), 4),
+                               "records_gathered": int(gathered.shape[0]), "record_width": int(gathered.shape[1])}
+            line["from_files"] = aggregate_from_files(per_rank, ff["files"], usable_cpus())
+        print(json.dumps(line), flush=True)
 
 
 def synth_on_device(torch, device, n_clips, n_frames, seed, h=120, w=160, chunk=64):
@@ -356,8 +409,9 @@ def aggregate_from_files(per_rank, share, host_cpus):
     agg = {"what": "every rank: %d synthetic recordings (its share) through run_files_bulk on its own GPU, host stages of "
                    "all ranks on the node's CPUs at the same time" % share,
            "ranks": world, "host_cpus_usable": host_cpus,
-           "per_rank": [{"rank": i, **({k: r[k] for k in ("files", "frames", "seconds", "frames_per_s", "split_s")}
-                                        if r and "error" not in r else {"error": (r or {}).get("error", "no result")})}
+           "per_rank": [{"rank": i, "numa": (r or {}).get("numa"),
+                         **({k: r[k] for k in ("files", "frames", "seconds", "frames_per_s", "split_s")}
+                            if r and "error" not in r else {"error": (r or {}).get("error", "no result")})}
                         for i, r in enumerate(per_rank)]}
     if ok:
         slowest = max(r["seconds"] for r in ok)
@@ -745,10 +799,12 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu, a
         gather_s += wl.last_gather_s
     fence()
     elapsed = time.perf_counter() - t0
+    rank_times = [elapsed]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        every = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([elapsed], dtype=torch.float64, device=device))
+        rank_times = [float(v.item()) for v in every]
+        elapsed = max(rank_times)
     for r in wl.last:
         r.track.check()
         r.assoc.check()
@@ -770,7 +826,8 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu, a
                            "device_batches_rank0": len(wl.subs), "records_gathered": int(gathered.shape[0]),
                            "record_width": int(gathered.shape[1]), "frame_size": args.frame_size,
                            "cnn_chunk": args.cnn_chunk, "n_labels": N_LABELS,
-                           "gather_ms_per_step_rank0": round(gather_s / steps * 1e3, 3)}}
+                           "gather_ms_per_step_rank0": round(gather_s / steps * 1e3, 3)},
+                "per_rank": per_rank_summary(rank_times, steps, loads)}
         line.update(cpu)
         if not as_sub_object:
             print(json.dumps(line), flush=True)
@@ -832,8 +889,15 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but the launcher started %s ranks (WORLD_SIZE)\n"
                          % (args.gpus, os.environ["WORLD_SIZE"]))
         raise SystemExit(2)
+    # a launched rank keeps its host threads on the CPUs of its GPU's NUMA node (cpx.sharding.pin_to_gpu_numa: sysfs only,
+    # before numpy / torch start their thread pools -- threads inherit the affinity; no numactl wrapper, no re-exec)
+    numa = None
+    if launched and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from cpx.sharding import pin_to_gpu_numa
+
+        numa = pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")))
     if args.dry_launch:
-        return dry_launch(args)
+        return dry_launch(args, numa)
 
     import numpy as np
     import torch
@@ -959,10 +1023,12 @@ def main():
     elapsed = time.perf_counter() - t0
     conv = ceng.conv_timing() if e2e else {}
     ceng.conv_timing(False)
+    rank_times = [elapsed]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        every = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([elapsed], dtype=torch.float64, device=device))
+        rank_times = [float(v.item()) for v in every]  # each rank's own time: what a < N-fold result is attributed with
+        elapsed = max(rank_times)
     res.check()
 
     if rank == 0:
@@ -1007,6 +1073,7 @@ def main():
             "dtype": ("u16/i32 track stage (f32 normalise, f64 gates); f32 crop/tile; f32 CNN (%s)"
                       % MATH_DTYPE[args.cnn_math]) if e2e else "u16/i32 (f32 normalise, f64 background weights)",
             "data": "synthetic",
+            "per_rank": dict(per_rank_summary(rank_times, args.steps, [B * T] * world), numa=numa),
             "config": {
                 "workload": ("synthetic 160x120 uint16 clips -> track (BASELINE configs[1]) -> 25-frame segments -> "
                              "crop/tile + WR-ResNet-22-4 forward (configs[2]/[3]), seeded random kernels with BatchNorm "
@@ -1299,7 +1366,8 @@ def main():
             line["config4"] = {"what": cfg4["workload"], "scaling": "strong", "value": sub["value"], "unit": "frames/s",
                                "ms_per_step": sub["ms_per_step"], "steps": sub["steps"], "clips": cfg4["clips"],
                                "frames_total": cfg4["frames_total"], "frames_per_rank": cfg4["frames_per_rank"],
-                               "imbalance": cfg4["imbalance"], "records_gathered": cfg4["records_gathered"],
+                               "imbalance": cfg4["imbalance"], "per_rank": sub.get("per_rank"),
+                               "records_gathered": cfg4["records_gathered"],
                                "gather_ms_per_step_rank0": cfg4["gather_ms_per_step_rank0"]}
     if extras and args.from_files > 0:
         # N > 1: every rank runs the file-fed path over ITS share of the recordings (shard_files' partition: recordings
@@ -1310,6 +1378,8 @@ def main():
             ff = bench_from_files(args, torch, np, local_rank, weights, T, n_files=share, with_fixtures=world == 1)
         except Exception as e:  # noqa: BLE001 -- the headline line above is complete: report, do not lose it
             ff = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        if isinstance(ff, dict) and world > 1:
+            ff["numa"] = numa
         if world == 1:
             line["from_files"] = ff
         else:

@@ -102,6 +102,10 @@ class ClipClassifier:
                     todo.append(os.path.join(folder, name))
         rank, world, local_rank = rank_world()  # under torchrun: this rank's share of the files, on its own GPU
         todo = shard_files(todo, rank, world)
+        if world > 1:  # the reader / staging threads started below stay on the CPUs next to this rank's GPU
+            from ..sharding import pin_to_gpu_numa
+
+            logging.info("rank %d: %s", rank, pin_to_gpu_numa(local_rank))
         if not track:
             for filename in todo:
                 self.process_file(filename, cache=cache, reuse_frames=reuse_frames, track=False,

@@ -4,7 +4,7 @@ over files, track/trackextractor.py:80-85).  The only exchange is one
 all-gather of fixed-width per-clip result records so that every rank (or
 rank 0) can write the metadata."""
 
-import numpy as np
+
 
 
 def partition_clips(frame_counts, world_size):
@@ -145,3 +145,76 @@ def unpack_records(records):
     import torch
 
     return records[:, 0], records[:, 1], records[:, 2:].contiguous().view(torch.float32)
+
+
+def _parse_cpulist(text):
+    """'0-15,32-47' -> {0..15, 32..47} (sysfs cpulist format)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(local_rank, sysfs="/sys", visible=None):
+    """NUMA node of this rank's GPU, from sysfs alone (no HIP call: it runs before anything touches the GPU): the AMD
+    display-class PCI functions under /sys/class/drm/card*/device in PCI-address order are the HIP devices, the
+    local_rank-th of them -- after HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when one is set -- is this rank's.
+    -> node id, or None when sysfs does not say (no such card, numa_node = -1: a single-node host)."""
+    import glob
+    import os
+
+    cards = {}
+    for dev in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")):
+        try:
+            with open(os.path.join(dev, "vendor")) as fh:
+                if fh.read().strip().lower() != "0x1002":
+                    continue
+            addr = os.path.basename(os.path.realpath(dev))
+            with open(os.path.join(dev, "numa_node")) as fh:
+                cards[addr] = int(fh.read().strip())
+        except (OSError, ValueError):
+            continue
+    nodes = [cards[a] for a in sorted(cards)]
+    if visible is None:
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if visible:
+        try:
+            nodes = [nodes[int(v)] for v in visible.split(",") if v.strip() != ""]
+        except (ValueError, IndexError):
+            return None
+    if local_rank < 0 or local_rank >= len(nodes) or nodes[local_rank] < 0:
+        return None
+    return nodes[local_rank]
+
+
+def pin_to_gpu_numa(local_rank, sysfs="/sys", apply=True):
+    """Keep this rank's host threads (file readers, pinned-memory staging, metadata text: the file-fed path needs ~1.4 CPUs
+    per rank, tests/test_host_scaling_cpu.py) on the CPUs of its GPU's NUMA node, so that eight ranks do not stage
+    through each other's memory controllers.  os.sched_setaffinity on the calling thread BEFORE any other thread starts
+    (threads inherit it); no numactl wrapper, no re-exec.  Nothing happens when sysfs does not name a node, or when the
+    node's CPUs and the CPUs this process may use do not intersect.
+    -> {"node": id or None, "cpus": CPUs now usable, "pinned": whether the affinity was narrowed}."""
+    import os
+
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"node": None, "cpus": os.cpu_count() or 1, "pinned": False}
+    node = gpu_numa_node(local_rank, sysfs)
+    out = {"node": node, "cpus": len(allowed), "pinned": False}
+    if node is None:
+        return out
+    try:
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as fh:
+            want = _parse_cpulist(fh.read()) & allowed
+    except (OSError, ValueError):
+        return out
+    if not want or want == allowed:
+        return out
+    if apply:
+        os.sched_setaffinity(0, want)
+    out.update(cpus=len(want), pinned=bool(apply))
+    return out

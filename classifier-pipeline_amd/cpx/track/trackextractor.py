@@ -52,6 +52,10 @@ class TrackExtractor:
         rank, world, local_rank = rank_world()
         todo = shard_files(todo, rank, world)
         device = local_rank if world > 1 else 0
+        if world > 1:  # the reader / staging threads started below stay on the CPUs next to this rank's GPU
+            from ..sharding import pin_to_gpu_numa
+
+            logging.info("rank %d: %s", rank, pin_to_gpu_numa(local_rank))
         for path in shard_files(gray, rank, world):
             try:
                 extract_file(path, self.config, self.cache_to_disk, self.retrack, to_stdout)

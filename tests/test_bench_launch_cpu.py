@@ -24,6 +24,46 @@ def test_gpus_2_spawns_two_ranks():
     assert line["n_gpus"] == 2 and line["ranks"] == [0, 1] and line["steps"] == 3 and line["dry_launch"] is True
 
 
+def test_gpus_8_spawns_eight_ranks_and_assembles_the_line():
+    """The first real 8-GPU run must not be the first time eight ranks meet: --gpus 8 --dry-launch runs the host side of
+    the multi-GPU bench on gloo -- LPT partition of configs[3], one gather_records exchange, the per-rank from_files
+    aggregation, per-rank timings -- and rank 0's line has the keys of the real one."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--dry-launch", "--steps", "2"],
+                         env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    (line,) = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert line["n_gpus"] == 8 and line["ranks"] == list(range(8)) and line["dry_launch"] is True
+    for k in bench.LINE_KEYS + bench.MULTI_RANK_KEYS:
+        assert k in line, k
+    c4 = line["config4"]
+    assert len(c4["frames_per_rank"]) == 8 and sum(c4["frames_per_rank"]) == c4["frames_total"]
+    assert 1.0 <= c4["imbalance"] < 1.001                       # LPT over 10,000 clips of 90-540 frames
+    assert c4["records_gathered"] == 10000 and c4["record_width"] == 2 + bench.N_LABELS
+    ff = line["from_files"]
+    assert ff["ranks"] == 8 and len(ff["per_rank"]) == 8 and all("numa" in r for r in ff["per_rank"])
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and pr["ms_per_step_max"] >= pr["ms_per_step_min"] and pr["imbalance"] == 1.0
+
+
+def test_gpus_1_skeleton_has_the_default_lines_keys():
+    """N = 1 of the driver's scaling run is compared with the default run: same keys (minus the multi-rank objects)."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--dry-launch"],
+                         env=_env(), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    (line,) = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert all(k in line for k in bench.LINE_KEYS) and not any(k in line for k in bench.MULTI_RANK_KEYS)
+    # ... and the real line is assembled with the same names (the source names every key of the skeleton)
+    src = open(os.path.join(REPO, "bench.py")).read()
+    for k in bench.LINE_KEYS:
+        assert '"%s"' % k in src, k
+
+
 def test_gpus_1_runs_in_process():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--dry-launch"],
                          env=_env(), capture_output=True, text=True, timeout=120)

@@ -99,3 +99,52 @@ def test_host_stages_of_eight_ranks_scale_with_the_cpus():
     finally:
         del os.environ["LOCAL_WORLD_SIZE"]
     assert host_threads_per_rank(16) == max(1, min(16, cpus))
+
+
+def test_ranks_pin_to_their_gpus_numa_node(tmp_path):
+    """cpx.sharding.pin_to_gpu_numa on a fake sysfs of a two-socket node with four GPUs (and another vendor's display
+    function in between): the rank's card by PCI order, HIP_VISIBLE_DEVICES honoured, numa_node -1 and unknown cards left
+    alone, the affinity only ever narrowed to CPUs the process already had."""
+    import os
+
+    from cpx import sharding
+
+    sysfs = tmp_path / "sys"
+    cards = [("0000:05:00.0", "0x1002", 0), ("0000:26:00.0", "0x1002", 0), ("0000:30:00.0", "0x1a03", 0),
+             ("0000:85:00.0", "0x1002", 1), ("0000:a6:00.0", "0x1002", 1)]
+    for k, (addr, vendor, node) in enumerate(cards):
+        dev = sysfs / "devices" / "pci0000:00" / addr
+        dev.mkdir(parents=True)
+        (dev / "vendor").write_text(vendor + "\n")
+        (dev / "numa_node").write_text("%d\n" % node)
+        card = sysfs / "class" / "drm" / ("card%d" % k)
+        card.mkdir(parents=True)
+        os.symlink(dev, card / "device")
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    lists = {0: allowed[:half], 1: allowed[half:] or allowed[:1]}
+    for node, cpus in lists.items():
+        d = sysfs / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    assert [sharding.gpu_numa_node(r, str(sysfs), visible="") for r in range(5)] == [0, 0, 1, 1, None]
+    assert sharding.gpu_numa_node(0, str(sysfs), visible="3,2") == 1
+    assert sharding.gpu_numa_node(0, str(sysfs), visible="9") is None
+    got = sharding.pin_to_gpu_numa(2, str(sysfs), apply=False)
+    assert got["node"] == 1 and got["cpus"] == len(set(lists[1]) & set(allowed))
+    assert sharding._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    # applied in a child process (the affinity of THIS test process stays as it is)
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); from cpx import sharding; r = sharding.pin_to_gpu_numa(0, %r); "
+            "print(r['pinned'], sorted(os.sched_getaffinity(0)) == %r)" % (
+                os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "classifier-pipeline_amd"),
+                str(sysfs), sorted(lists[0])))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    if len(allowed) > 1:
+        assert out.stdout.split() == ["True", "True"], out.stdout
+    # a host whose sysfs names no node: nothing changes
+    (sysfs / "devices" / "pci0000:00" / "0000:05:00.0" / "numa_node").write_text("-1\n")
+    assert sharding.pin_to_gpu_numa(0, str(sysfs), apply=False) == {"node": None, "cpus": len(allowed), "pinned": False}
