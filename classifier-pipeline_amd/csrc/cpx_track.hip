@@ -1240,8 +1240,12 @@ __device__ __forceinline__ u32 lds_addr(const void* p) { return (u32)reinterpret
 
 // WC = the frame width when it is known at compile time (160: row strides fold into instruction offsets and the
 // pass-B row loads pair up as ds_read2_b32), 0 = any supported width.
+#ifndef CPX_NLM_WPE5   // experiment switch: waves per SIMD the BH <= 5 forms are compiled for (8 = two workgroups per CU)
+#define CPX_NLM_WPE5 4
+#endif
 template <int BH, int WC>
-__global__ __launch_bounds__(NT_NLM) void cpx_nlm_kernel(TrackArgs a, int t) {
+__global__ __launch_bounds__(NT_NLM) __attribute__((amdgpu_waves_per_eu(BH <= 5 ? CPX_NLM_WPE5 : 4, BH <= 5 ? CPX_NLM_WPE5 : 4)))
+void cpx_nlm_kernel(TrackArgs a, int t) {
   const int b = blockIdx.x;
   const int nproc = a.proc_off[b + 1] - a.proc_off[b];
   if (t >= nproc) return;
