@@ -1551,11 +1551,25 @@ void cpx_nlm_kernel(TrackArgs a, int t) {
 #ifdef CPX_NLM_DB
   pass_a(0, Hh);
   __syncthreads();
+#ifdef CPX_NLM_STAGGER   // experiment: half of the waves take the two passes of an interval in the other order
+  const bool b_first = ((tid >> 6) & CPX_NLM_STAGGER) != 0;
+  for (int q = 0; q < 220; ++q) {
+    if (b_first) {
+      pass_b(q, (q & 1) ? Hh1 : Hh);
+      if (q + 1 < 220) pass_a(q + 1, ((q + 1) & 1) ? Hh1 : Hh);
+    } else {
+      if (q + 1 < 220) pass_a(q + 1, ((q + 1) & 1) ? Hh1 : Hh);
+      pass_b(q, (q & 1) ? Hh1 : Hh);
+    }
+    __syncthreads();
+  }
+#else
   for (int q = 0; q < 220; ++q) {
     if (q + 1 < 220) pass_a(q + 1, ((q + 1) & 1) ? Hh1 : Hh);
     pass_b(q, (q & 1) ? Hh1 : Hh);
     __syncthreads();
   }
+#endif
 #else
   for (int q = 0; q < 220; ++q) {
     pass_a(q, Hh);
