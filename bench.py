@@ -130,7 +130,9 @@ def synthetic_network_weights(torch, wr, eng, frames, offs, meta, outputs, frame
     r = pipe0.run(frames, offs[: nb + 1], meta[: int(offs[nb])], outputs=outputs, keep_samples=True)
     if r.samples_dev is None or int(r.samples_dev.shape[0]) < 4:
         return w
-    x = r.samples_dev[:n_cal].contiguous()
+    n_all = int(r.samples_dev.shape[0])   # evenly spread over every clip's segments, not the first clips' only
+    pick = torch.linspace(0, n_all - 1, min(n_cal, n_all), device=r.samples_dev.device).round().long()
+    x = r.samples_dev[pick].contiguous()
     prev = eng.get_cnn_math()
     eng.set_cnn_math("bf16x3")
     try:
@@ -579,7 +581,7 @@ def bench_ir(args, torch, np, dist, device, rank, world, local_rank):
         dist.destroy_process_group()
 
 
-def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with_fixtures=True):
+def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with_fixtures=True, meta_pool=None):
     """The file-fed form of the headline path: `--from-files` synthetic recordings as CPTV byte
     strings in host memory (32 distinct clips of the headline's generator, T frames, gzip level 6, replicated) -> cpx.track.bulk.run_files_bulk
     with a ClipClassifier: upload, gzip inflate + section index + frame decode on the device, track, segments,
@@ -618,20 +620,27 @@ def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with
     batch = 2048   # recordings per decode launch (tracked in groups of 1024)
     cc = ClipClassifier(cfg)
 
-    def measure(blobs, names):
+    def overflow_forwards():
+        from cpx.track import cliptrackextractor as cte
+
+        return int(sum(e.cnn_overflow_forwards(reset=True) for e in cte._ENGINES.values() if e.h))
+
+    def measure(blobs, names, cc=cc, cfg=cfg):
         torch.cuda.empty_cache()   # (the previous workload's cached blocks have other sizes: start from a clean pool)
         # warm-up = the same pass once: engines, model, and the pinned / device allocators grown to the pipeline's
         # working set (three batches in flight), as in a service that has been running
         run_files_bulk(names, cfg, save_meta=False, want_text=True, device=local_rank, batch_files=batch,
-                       clip_classifier=cc, blobs=blobs)
+                       clip_classifier=cc, blobs=blobs, meta_pool=meta_pool)
         torch.cuda.synchronize()
+        overflow_forwards()
         t0 = time.perf_counter()
         out, tracker = run_files_bulk(names, cfg, save_meta=False, want_text=True, device=local_rank,
-                                      batch_files=batch, clip_classifier=cc, blobs=blobs)
+                                      batch_files=batch, clip_classifier=cc, blobs=blobs, meta_pool=meta_pool)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         bad = [k for k, v in out.items() if v.startswith("error")]
         assert not bad, bad[:3]
+        tracker.timings["fp16_overflow_forwards"] = overflow_forwards()
         return out, tracker.timings, dt
 
     blobs = [distinct[i % len(distinct)] for i in range(n)]
@@ -642,14 +651,54 @@ def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with
     gold = os.path.join(REPO, "tests", "golden")
     if with_fixtures and all(os.path.exists(os.path.join(gold, f + ".cptv")) for f in ("possum", "hedgehog")):
         real = [open(os.path.join(gold, f + ".cptv"), "rb").read() for f in ("possum", "hedgehog")]
+        # a network's BatchNorm statistics belong to its data: the synthetic network of this leg gets them from the
+        # fixture recordings' own crops (as the headline's got them from the synthetic clips' crops) -- statistics of another
+        # distribution put real crops' activations far outside what the layers were normalised for (and, in fp16x2, beyond
+        # the range scaling: every such forward then pays the bf16x3 rerun)
+        cc_fx, cfg_fx = cc, cfg
+        try:
+            from cpx.cptv import CptvReader
+            from cpx.engine import TrackEngine
+
+            eng_fx = TrackEngine(model="lepton3", device=local_rank, max_frames=512)
+            fr, lens, metas = [], [], []
+            for name in ("possum", "hedgehog"):
+                frames_f = CptvReader(os.path.join(gold, name + ".cptv")).read_all()
+                fr.append(np.stack([f.pix for f in frames_f]).astype(np.uint16))
+                lens.append(len(frames_f))
+                metas.append(eng_fx.make_meta(len(frames_f), [f.time_on for f in frames_f], [f.last_ffc_time for f in frames_f],
+                                              [bool(f.background_frame) for f in frames_f]))
+            offs_f = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            w_fx = synthetic_network_weights(torch, wr, eng_fx, eng_fx.upload_frames(np.concatenate(fr)), offs_f,
+                                             np.concatenate(metas), None, 32, n_clips=2)
+            eng_fx.close()
+            wr.save_model(os.path.join(tmp, "wr_fx"), w_fx, labels, hyperparams={"frame_size": 32})
+            cfg2 = Config.get_defaults()
+            cfg2.tracking["thermal"].denoise = False
+            cfg2.classify.models = [ModelConfig.load({"id": 1, "name": "wr-bench", "model_file": os.path.join(tmp, "wr_fx.npz")})]
+            cfg2.classify.meta_to_stdout = False
+            cc_fx, cfg_fx = ClipClassifier(cfg2), cfg2
+        except Exception as e:  # noqa: BLE001 -- the leg still runs, on the synthetic clips' statistics
+            sys.stderr.write("from_files: fixture calibration failed (%s: %s)\n" % (type(e).__name__, e))
         # eight decode batches of 2048: the three pipeline stages overlap as they do on a large directory (8,192 copies:
         # 297-333 k frames/s, 4,096: 275 k -- the first decode and the last metadata are not overlapped with anything)
         nr = min(2 * n, 16384)
-        outr, tmr, dtr = measure([real[i % 2] for i in range(nr)], ["fixture_%05d.cptv" % i for i in range(nr)])
+        outr, tmr, dtr = measure([real[i % 2] for i in range(nr)], ["fixture_%05d.cptv" % i for i in range(nr)], cc=cc_fx, cfg=cfg_fx)
         fixtures = {"what": "%d copies of the reference's two fixture recordings (tests/clips/possum.cptv, hedgehog.cptv: "
                             "161 / 120 frames, 1.1 MB each) through the same call" % nr,
                     "files": nr, "frames": int(tmr["frames"]), "seconds": round(dtr, 3),
-                    "frames_per_s": round(tmr["frames"] / dtr, 1), "files_per_s": round(nr / dtr, 1)}
+                    "frames_per_s": round(tmr["frames"] / dtr, 1), "files_per_s": round(nr / dtr, 1),
+                    "network": "the same seeded kernels, BatchNorm statistics fitted to these recordings' own crops" if cc_fx is not cc
+                               else "the synthetic clips' network",
+                    "fp16_overflow_forwards": tmr.get("fp16_overflow_forwards"),
+                    "split_s": {"stage_pinned_copy": round(tmr.get("stage_s", 0.0), 3),
+                                "upload_inflate_index_unpack": round(tmr["decode_s"], 3),
+                                "main_thread_waiting_for_decode": round(tmr.get("wait_decode_s", 0.0), 3),
+                                "track_classify_thumbnails_device": round(tmr["device_s"], 3),
+                                "metadata_host": round(tmr["host_s"], 3),
+                                "metadata_workers": meta_pool.workers if meta_pool is not None else 0,
+                                "metadata_submit_main_thread": round(tmr.get("host_submit_s", 0.0), 3),
+                                "metadata_collect_main_thread": round(tmr.get("host_collect_s", 0.0), 3)}}
     n_tracks = sum(text.count('"tracking_score"') for text in out.values())
     n_pred = sum(text.count('"all_class_confidences"') for text in out.values())
     return {"what": "%d synthetic recordings (%d frames each: %d distinct clips of the headline's generator, gzip level 6, %.2f MB per file) as byte strings "
@@ -661,13 +710,17 @@ def bench_from_files(args, torch, np, local_rank, weights, T, n_files=None, with
             "files": n, "frames": int(tm["frames"]), "seconds": round(dt, 3),
             "frames_per_s": round(tm["frames"] / dt, 1), "files_per_s": round(n / dt, 1),
             "tracks_in_metadata": n_tracks, "tracks_with_predictions": n_pred,
+            "fp16_overflow_forwards": tm.get("fp16_overflow_forwards"),
             "metadata_bytes": int(sum(len(v) for v in out.values())),
             "split_s": {"note": "the first two run in a worker thread beside the others (a HIP stream of its own)",
                         "stage_pinned_copy": round(tm.get("stage_s", 0.0), 3),
                         "upload_inflate_index_unpack": round(tm["decode_s"], 3),
                         "main_thread_waiting_for_decode": round(tm.get("wait_decode_s", 0.0), 3),
                         "track_classify_thumbnails_device": round(tm["device_s"], 3),
-                        "metadata_host": round(tm["host_s"], 3), "collect": round(tm["write_s"], 3)},
+                        "metadata_host": round(tm["host_s"], 3), "collect": round(tm["write_s"], 3),
+                        "metadata_workers": meta_pool.workers if meta_pool is not None else 0,
+                        "metadata_submit_main_thread": round(tm.get("host_submit_s", 0.0), 3),
+                        "metadata_collect_main_thread": round(tm.get("host_collect_s", 0.0), 3)},
             "encode_synthetic_files_s": round(encode_s, 2), "denoise": False,
             **({"device_split_s": {k: round(v, 3) for k, v in tm["device_split_s"].items()}} if "device_split_s" in tm else {})}
 
@@ -870,6 +923,9 @@ def main():
                     help="--config4: frames per device batch (their per-frame outputs must fit HBM beside the clips)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only launch the ranks (gloo rendezvous, no GPU work): checks the --gpus N path on a CPU host")
+    ap.add_argument("--meta-workers", type=int, default=2,
+                    help="metadata worker processes of the from_files leg (cpx.track.bulk.MetaPool: what a directory run "
+                         "of this size starts; 0 = the stage stays in the process)")
     ap.add_argument("--from-files", type=int, default=8192,
                     help="recordings of the from_files measurement of the default run (0 = skip)")
     args = ap.parse_args()
@@ -925,6 +981,14 @@ def main():
             allc["host_cores_visible"] = host
             allc["note"] = "one worker per usable CPU (scheduler affinity capped by the cgroup CPU quota)"
             cpu["cpu_baseline_all_cores"] = allc
+    # the file-fed leg formats its metadata text in worker processes (cpx.track.bulk.MetaPool): started here, while this
+    # process has not initialised the GPU (device_count() does not)
+    meta_pool = None
+    if args.meta_workers > 0 and args.stage == "e2e" and args.from_files > 0 and not args.no_extras and not args.denoise \
+            and args.frame_size == 32 and not args.config4 and torch.cuda.device_count() > 0:
+        from cpx.track.bulk import MetaPool
+
+        meta_pool = MetaPool.make(args.meta_workers)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -1375,7 +1439,8 @@ def main():
         # path is the host (staging, metadata text), not a collective, so the per-rank split is what is reported
         share = args.from_files if world == 1 else max(512, args.from_files // world)
         try:
-            ff = bench_from_files(args, torch, np, local_rank, weights, T, n_files=share, with_fixtures=world == 1)
+            ff = bench_from_files(args, torch, np, local_rank, weights, T, n_files=share, with_fixtures=world == 1,
+                                  meta_pool=meta_pool)
         except Exception as e:  # noqa: BLE001 -- the headline line above is complete: report, do not lose it
             ff = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         if isinstance(ff, dict) and world > 1:
@@ -1387,6 +1452,8 @@ def main():
             dist.all_gather_object(per_rank, ff)
             if rank == 0:
                 line["from_files"] = aggregate_from_files(per_rank, share, usable_cpus())
+    if meta_pool is not None:
+        meta_pool.close()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if not (extras and (world > 1 or args.from_files > 0)):

@@ -124,7 +124,7 @@ EXPORTS = [
     "cpx_mog2_create", "cpx_mog2_apply", "cpx_mog2_background", "cpx_mog2_destroy",
     "cpx_track_batch_ex", "cpx_track_frame_ex", "cpx_set_background", "cpx_get_background", "cpx_track_limits_batch_ex",
     "cpx_cnn_head_ex", "cpx_ir_delta_variance", "cpx_cptv_inflate", "cpx_cptv_gather_index", "cpx_format_regions", "cpx_json_indent", "cpx_ir_merge", "cpx_ir_resize_area",
-    "cpx_ir_frame_statistics", "cpx_cnn_last_overflow", "cpx_cnn_set_activation_bounds",
+    "cpx_ir_frame_statistics", "cpx_cnn_last_overflow", "cpx_cnn_set_activation_bounds", "cpx_cnn_overflow_forwards",
 ]
 
 IR_FRAME_STATS_DTYPE = np.dtype([("min", "<i4"), ("max", "<i4"), ("sum", "<i8"), ("median_x2", "<i4"), ("reserved", "<i4"),
@@ -199,6 +199,8 @@ def load():
     lib.cpx_get_cnn_math.restype = C.c_int
     lib.cpx_cnn_last_overflow.argtypes = [vp, C.POINTER(C.c_int)]
     lib.cpx_cnn_last_overflow.restype = C.c_int
+    lib.cpx_cnn_overflow_forwards.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
+    lib.cpx_cnn_overflow_forwards.restype = C.c_int
     lib.cpx_cnn_set_activation_bounds.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     lib.cpx_cnn_set_activation_bounds.restype = C.c_int
     lib.cpx_mog2_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(vp)]

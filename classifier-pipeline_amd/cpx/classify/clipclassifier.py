@@ -48,6 +48,7 @@ class ClipClassifier:
                  model_by_country=True):
         self.keep_original_predictions = keep_original_predictions
         self.batch_files = None  # recordings per decode batch of process(directory, track=True); None: bulk.auto_batch_files
+        self.meta_pool_min_files = 2048  # metadata worker processes (bulk.MetaPool) for directories this large; None = never
         self.last_run = None
         self.config = config
         self.model = model
@@ -129,10 +130,17 @@ class ClipClassifier:
         # the file-fed path at device speed (cpx/track/bulk.py): the recordings of a device batch are decoded, tracked,
         # cut into segments (the reference's get_segments with every random draw the identity: cpx_plan_segments),
         # cropped, classified and written without per-frame Python objects; a recording that fails is retried on its own
-        from ..track.bulk import run_files_bulk
+        from ..track.bulk import MetaPool, run_files_bulk
 
-        _, tracker = run_files_bulk(todo, self.config, device=local_rank if world > 1 else 0,
-                                    batch_files=self.batch_files, clip_classifier=self)
+        # a large directory: the metadata text is formatted by worker processes -- possible only while this process has
+        # not touched the GPU yet (MetaPool.make returns None afterwards; the models above were read, not uploaded)
+        pool = MetaPool.make() if self.meta_pool_min_files is not None and len(todo) >= self.meta_pool_min_files else None
+        try:
+            _, tracker = run_files_bulk(todo, self.config, device=local_rank if world > 1 else 0,
+                                        batch_files=self.batch_files, clip_classifier=self, meta_pool=pool)
+        finally:
+            if pool is not None:
+                pool.close()
         self.last_run = tracker.timings
 
     @staticmethod

@@ -552,6 +552,14 @@ class TrackEngine:
             raise CpxError(rc, self._err())
         return bool(out.value)
 
+    def cnn_overflow_forwards(self, reset=False):
+        """fp16x2: forwards on this engine that fell back to the bf16x3 kernels so far (cpx_cnn_overflow_forwards)."""
+        out = C.c_int(0)
+        rc = self.lib.cpx_cnn_overflow_forwards(self.h, C.byref(out), 1 if reset else 0)
+        if rc != 0:
+            raise CpxError(rc, self._err())
+        return int(out.value)
+
     def get_cnn_math(self):
         return {v: k for k, v in self.CNN_MATH.items()}[self.lib.cpx_get_cnn_math(self.h)]
 

@@ -320,9 +320,14 @@ class WRResNetInterpreter(Interpreter):
     def _network(self, engine):
         from .wrresnet import WRResNetDevice
 
-        if self._net is None or self._net.eng is not engine:
-            self._net = WRResNetDevice(engine, self._weights, len(self.labels))
-        return self._net
+        # one device network per engine (= per handle / HIP stream): callers that alternate between engines -- the bulk
+        # path's device lanes -- must not rebuild it at every switch
+        nets = self.__dict__.setdefault("_nets", {})
+        net = nets.get(id(engine))
+        if net is None or net.eng is not engine or not engine.h:
+            net = nets[id(engine)] = WRResNetDevice(engine, self._weights, len(self.labels))
+        self._net = net
+        return net
 
     def shape(self):
         return 1, (None,) + tuple(self.params.output_dim)

@@ -303,8 +303,15 @@ class WRResNetDevice:
         (the caller orders x's producer with an event and synchronises the engine before reading)."""
         N, H, W, cin = x.shape
         assert cin == 2 and x.is_contiguous() and logits.is_contiguous()
-        rc = self.lib.cpx_cnn_forward(self._cnn, C.c_void_p(x.data_ptr()), N, H, W, C.c_void_p(logits.data_ptr()),
-                                      C.c_void_p(probs.data_ptr()) if probs is not None else None)
+        for attempt in range(2):
+            rc = self.lib.cpx_cnn_forward(self._cnn, C.c_void_p(x.data_ptr()), N, H, W, C.c_void_p(logits.data_ptr()),
+                                          C.c_void_p(probs.data_ptr()) if probs is not None else None)
+            if rc == -6 and attempt == 0:   # CPX_ERR_NOMEM: the handle's activation buffers are a plain hipMalloc, and what
+                # torch's allocator holds in its cache is invisible to it -- hand that back and try once more
+                self.eng.synchronize()
+                self.torch.cuda.empty_cache()
+                continue
+            break
         if rc != 0:
             raise CpxError(rc, self.eng._err())
 

@@ -4,6 +4,7 @@ crop / tile, CNN forward, per-track aggregation.  This is what bench.py times; t
 drop-in classes (cpx.track / cpx.classify) run the same kernels one clip at a time."""
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -166,6 +167,13 @@ class BatchPipeline:
                     ev.record(s_eng)
                     s_net.wait_event(ev)
                 self.net.forward_async(buf, logits[s0:s1], probs[s0:s1])
+                if os.environ.get("CPX_CNN_DEBUG_OVF") and self.net.eng.cnn_last_overflow():
+                    per = buf.reshape(buf.shape[0], -1)
+                    mx = per.abs().amax(dim=1)
+                    print("overflow forward: samples %d..%d, input max %.1f min %.1f nan %d; per-sample max: top %s; "
+                          "logits max %.2f" % (s0, s1, float(mx.max()), float(per.min()), int(t.isnan(per).sum()),
+                                               [round(float(v), 1) for v in mx.topk(min(5, mx.numel())).values],
+                                               float(logits[s0:s1].abs().max())), flush=True)
                 if two_streams:
                     ev = t.cuda.Event()
                     ev.record(s_net)

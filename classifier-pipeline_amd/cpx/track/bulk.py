@@ -22,6 +22,7 @@ import ctypes as C
 import json
 import logging
 import os
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 from datetime import datetime, timedelta
@@ -365,7 +366,7 @@ class BulkTracker:
         self.timings = {"decode_s": 0.0, "device_s": 0.0, "host_s": 0.0, "write_s": 0.0, "files": 0, "frames": 0}
 
     # ---- device ----------------------------------------------------------------------------------------------
-    def track_group(self, group, clips, classifiers=()):
+    def track_group(self, group, clips, classifiers=(), lane=0):
         """-> dict of host arrays for the group's clips (clips[k]: the Clip object of group.files[k]).
         classifiers: [(model config, interpreter)] -- every kept track's segments (cpx_plan_segments: the reference's
         get_segments under identity draws) are cropped, tiled and run through each model's network."""
@@ -378,7 +379,17 @@ class BulkTracker:
         weight_add = (1 if c0.camera_model == "lepton3.5" else 0.1) / self.extractor.weighting_percent
         longest = int(np.diff(group.offs).max())
         eng = get_engine(W, H, c0.background_thresh, weight_add, cfg.edge_pixels, self.device, max_frames=longest,
-                         denoise=bool(cfg.denoise))
+                         denoise=bool(cfg.denoise), lane=lane)
+        # Everything this group allocates and every torch operation on it runs with the engine's stream as torch's
+        # current stream: the caching allocator hands a freed block only to allocations on the stream it was made for,
+        # so two lanes (two threads, two engines) never receive each other's blocks while the other's kernels -- which
+        # torch does not know about: they are cpx launches on the handle's stream -- may still be using them
+        with eng.torch.cuda.stream(eng.torch_stream()):
+            return self._track_group(eng, group, clips, classifiers, cfg, c0, W, H)
+
+    def _track_group(self, eng, group, clips, classifiers, cfg, c0, W, H):
+        from ..pipeline import BatchPipeline
+
         t, dev = eng.torch, eng.device
         self.lib = eng.lib
         offs = group.offs
@@ -708,6 +719,144 @@ class BulkTracker:
         return text
 
 
+class _View:
+    """Plain attribute bag: what the metadata stage reads of a Clip / interpreter / model, in a form that pickles."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def clip_view(clip):
+    return _View(camera_model=clip.camera_model, background_thresh=clip.background_thresh,
+                 video_start_time=clip.video_start_time, frames_per_second=clip.frames_per_second, _id=clip._id)
+
+
+def model_views(model_out):
+    """model_out of track_group without the interpreter objects (they own device networks): per model the probabilities,
+    the seconds, and what track_predictions reads of the interpreter and the model configuration."""
+    out = []
+    for mo in model_out:
+        it = mo["interp"]
+        out.append(dict(probs=mo["probs"], seconds=mo["seconds"], model=_View(id=mo["model"].id),
+                        interp=_View(labels=list(it.labels), thresholds=it.thresholds,
+                                     params=_View(smooth_predictions=it.params.smooth_predictions,
+                                                  square_width=it.params.square_width))))
+    return out
+
+
+def format_group(tracker, job):
+    """The metadata text of every recording of a tracked group: the host stage of the file-fed path as a function of plain
+    data (`job`: what track_group returned + views of the clips / models), so that it runs in this process or in a
+    metadata worker process (MetaPool) alike.  -> (texts {file index: text}, retry {file index: why}, frames, seconds)."""
+    th = time.time()
+    r, files, paths, offs = job["r"], job["files"], job["paths"], job["offs"]
+    clips, existing, indent = job["clips"], job["existing"], job["indent"]
+    texts, retry, frames = {}, {}, 0
+    per_clip = {}
+    for ti, (b, j) in enumerate(r["kept"]):
+        per_clip.setdefault(b, []).append(ti)
+    upos = np.searchsorted(r["usable"], r["tr_off"])   # usable-region index ranges per kept track
+    n_kept = max(len(r["kept"]), 1)
+    for b, i in enumerate(files):
+        if b in r["failed"]:
+            retry[i] = "%s: %s" % (paths[b], r["failed"][b])
+            continue
+        try:  # (fault isolation: a recording whose results do not serialise is retried on its own)
+            n_proc = len(r["proc_idx"][b])
+            tracks = []
+            for ti in per_clip.get(b, ()):
+                _, j = r["kept"][ti]
+                regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
+                use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
+                st = r["stats"][upos[ti]:upos[ti + 1]]
+                tr = dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st))
+                if job["classify"]:
+                    secs = sum(mo["seconds"] for mo in r["model_out"]) / n_kept
+                    tr["predictions"] = track_predictions(r, ti, b, r["model_out"], secs)
+                tracks.append(tr)
+            trackless = None
+            if not tracks:
+                kind, payload = r["best_region"].get(b, ("none", None))
+                trackless = _trackless_region(kind, payload)
+            texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[b], job["tracking_time"],
+                                             existing[b], indent, models=job["model_meta"])
+            frames += int(offs[b + 1] - offs[b])
+        except Exception as e:  # noqa: BLE001
+            texts.pop(i, None)
+            retry[i] = "%s: %s: %s" % (paths[b], type(e).__name__, e)
+    return texts, retry, frames, time.time() - th
+
+
+# ---- metadata worker processes ---------------------------------------------------------------------------------------
+# The host stage is Python (dictionaries, json, a few NumPy calls per track): one interpreter lock.  With a classifier
+# over real recordings it is as long as the device stage (0.23 ms per recording), and every moment it holds the lock the
+# device thread cannot launch (16,384 fixture recordings: 7.1 s with the stage in this process, 5.9 s with the stage
+# left out).  The reference spreads its files over a multiprocessing.Pool (trackextractor.py:80-85); here the DEVICE work
+# stays in one process per GPU and only the text formatting goes to worker processes -- which never touch the GPU.
+# They are started as NEW programs ("spawn": a child process that execs a fresh interpreter, as subprocess.run does --
+# never a fork that keeps running with this process's GPU state, never an exec of this process itself), preferably before
+# this process initialises the GPU: by TrackExtractor.extract / ClipClassifier.process / bench.py at their start -- or not
+# at all, and the stage runs in-process as before.
+_WORKER_TRACKERS = {}
+
+
+def _worker_format(config_blob, job):
+    import pickle
+
+    tracker = _WORKER_TRACKERS.get(config_blob)
+    if tracker is None:
+        from .. import _lib
+
+        tracker = BulkTracker(pickle.loads(config_blob), 0)
+        tracker.lib = _lib.load()   # (the host entry points cpx_format_regions / cpx_json_indent: no GPU call)
+        _WORKER_TRACKERS.clear()
+        _WORKER_TRACKERS[config_blob] = tracker
+    return format_group(tracker, job)
+
+
+def _worker_ready(_):
+    import numpy  # noqa: F401  (the imports a job needs, paid before the first one arrives)
+
+    from .. import _lib
+
+    _lib.load()
+    return os.getpid()
+
+
+class MetaPool:
+    """`workers` processes that format metadata text (format_group); make() returns None when they cannot be started
+    (the stage then stays in-process)."""
+
+    def __init__(self, workers):
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+
+        self.workers = int(workers)
+        self.pool = ProcessPoolExecutor(max_workers=self.workers, mp_context=multiprocessing.get_context("spawn"))
+        self.pids = sorted(set(self.pool.map(_worker_ready, range(4 * self.workers))))
+
+    @staticmethod
+    def make(workers=None):
+        if workers is None:
+            from ..sharding import host_threads_per_rank
+
+            # two: on the 16-CPU GPU boxes of this pool four workers took enough CPU time from the staging / decode
+            # threads to slow the run (bench from_files, 8,192 noisy recordings: 462 k frames/s without workers, 453 k
+            # with two, 267-325 k with four); a rank of a shared node gets fewer
+            workers = max(1, min(2, host_threads_per_rank(16) // 4))
+        try:
+            return MetaPool(workers)
+        except Exception as e:  # noqa: BLE001 -- no pool is a slower run, not a failed one
+            logging.warning("metadata worker pool not started (%s: %s): formatting in-process", type(e).__name__, e)
+            return None
+
+    def submit(self, config_blob, job):
+        return self.pool.submit(_worker_format, config_blob, job)
+
+    def close(self):
+        self.pool.shutdown(wait=True, cancel_futures=True)
+
+
 def _trackless_region(kind, payload):
     """What best_trackless_thumb returns, as the metadata dictionary of that Region."""
     from .region import Region
@@ -777,7 +926,7 @@ def auto_batch_files(n_files):
 
 def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=None, want_text=False,
                    stager=None, tracker=None, clip_classifier=None, blobs=None, track_files=1024,
-                   decode_bytes=8 << 30, track_frames=400000):
+                   decode_bytes=8 << 30, track_frames=400000, meta_pool=None, device_lanes=2):
     """extract_file -- or, with a ClipClassifier, process_file(track=True) -- for many recordings at device speed.
     Writes <file>.txt (or prints with to_stdout) and returns ({filename: metadata text (want_text) or True, or an
     "error: ..." string for a skipped file}, tracker with timings).  Files that cannot take the batched path are
@@ -878,7 +1027,23 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         return staged, decoded, stage_s, time.time() - t1
 
     worker = ThreadPoolExecutor(max_workers=1)
-    dev_worker = ThreadPoolExecutor(max_workers=1)
+    # Device lanes: a device phase is a chain of launches with host steps between them (work counts that size the next
+    # buffers, the kept tracks' region gather, thumbnail requests): while the host does those the device has nothing
+    # of that group to run -- 24 % of the wall time with one group at a time (rocprofv3 kernel trace of 8,192 fixture
+    # recordings, scratch/gpu_busy_from_trace.py).  Two groups in flight, each on an engine (handle = stream + tracking
+    # workspace) of its own, fill each other's gaps.
+    # How many lanes the run uses is decided once, from what its second batch had to wait for: a run bound by the DECODE stage
+    # (large noisy recordings: this thread sits waiting for the inflate) keeps one lane -- a second one only takes device
+    # time from the inflate kernel (8,192 synthetic recordings: 462 k frames/s with one lane, 295 k with two) -- a run
+    # bound by the device phase (real recordings: many tracks and segments per frame) takes two (16,384 fixture
+    # recordings: 322 k -> 409 k).  Two lanes hold the device memory of one: half-sized groups and network calls.
+    n_lanes = max(1, int(os.environ.get("CPX_BULK_LANES", device_lanes)))
+    lanes_now = [1]
+    base_track_files, base_track_frames = track_files, track_frames
+    dev_worker = ThreadPoolExecutor(max_workers=n_lanes)
+    lane_free = list(range(n_lanes))
+    lane_cond = threading.Condition()   # device phases running at once: at most lanes_now (groups are submitted one ahead)
+    lanes_busy = [0]
     fut = worker.submit(produce, 0) if batches else None
 
     # Three stages in flight: the decode of batch k+1 (worker above), the device phase of group g+1 (dev_worker: track,
@@ -908,14 +1073,24 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             clips.append(clip)
             existing.append(meta)
         # (lepton3 and "no model" files share thresholds but not the metadata's camera_model: grouped by model)
+        with lane_cond:
+            while lanes_busy[0] >= lanes_now[0]:
+                lane_cond.wait()
+            lanes_busy[0] += 1
+            lane = lane_free.pop()
         try:
-            r = tracker.track_group(group, clips, classifiers)
+            r = tracker.track_group(group, clips, classifiers, lane=lane)
         except torch.cuda.OutOfMemoryError as e:   # (budgets too generous for this device: memory released, members retried)
             r = RuntimeError("device out of memory for a group of %d recordings / %d frames: %s"
                              % (len(group.files), int(group.offs[-1]), str(e).splitlines()[0]))
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001 -- the whole group failed (CpxError or anything else): every member goes the slow way
             r = e
+        finally:
+            with lane_cond:
+                lanes_busy[0] -= 1
+                lane_free.append(lane)
+                lane_cond.notify_all()
         if not isinstance(r, Exception):
             for k, why in pre_failed.items():
                 r["failed"].setdefault(k, why)
@@ -931,13 +1106,11 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             return
         th = time.time()
         offs = group.offs
-        per_clip = {}
-        for ti, (b, j) in enumerate(r["kept"]):
-            per_clip.setdefault(b, []).append(ti)
-        # usable-region index ranges per kept track
-        upos = np.searchsorted(r["usable"], r["tr_off"])
-        tracking_time = (time.time() - ctx["t0"]) / max(ctx["n_ok"], 1)
-        n_kept = max(len(r["kept"]), 1)
+        if os.environ.get("CPX_BULK_SKIP_META"):  # experiment switch: how long the run takes without the metadata stage
+            for b, i in enumerate(group.files):
+                texts[i] = "{}"
+                tracker.timings["frames"] += int(offs[b + 1] - offs[b])
+            return
         model_meta = None
         if classifiers:
             model_meta = []
@@ -945,37 +1118,40 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
                 d = mo["model"].as_dict()
                 d["classify_time"] = float(round(mo["seconds"] / max(len(group.files), 1), 1))
                 model_meta.append(d)
-        for b, i in enumerate(group.files):
-            if b in r["failed"]:
-                retry[i] = "%s: %s" % (paths[i], r["failed"][b])
-                continue
-            try:  # (fault isolation: a recording whose results do not serialise is retried on its own)
-                n_proc = len(r["proc_idx"][b])
-                tracks = []
-                for ti in per_clip.get(b, ()):
-                    _, j = r["kept"][ti]
-                    regs = r["regions"][r["tr_off"][ti]:r["tr_off"][ti + 1]]
-                    use = r["usable"][upos[ti]:upos[ti + 1]] - r["tr_off"][ti]
-                    st = r["stats"][upos[ti]:upos[ti + 1]]
-                    tr = dict(summary=r["summ"][b, j], regions=regs, thumb=tracker.thumbnail_of(regs, use, st))
-                    if classifiers:
-                        secs = sum(mo["seconds"] for mo in r["model_out"]) / n_kept
-                        tr["predictions"] = track_predictions(r, ti, b, r["model_out"], secs)
-                    tracks.append(tr)
-                trackless = None
-                if not tracks:
-                    kind, payload = r["best_region"].get(b, ("none", None))
-                    trackless = _trackless_region(kind, payload)
-                texts[i] = tracker.metadata_text(clips[b], n_proc, tracks, trackless, paths[i], tracking_time,
-                                                 existing[b], indent, models=model_meta)
-                tracker.timings["frames"] += int(offs[b + 1] - offs[b])
-            except Exception as e:  # noqa: BLE001
-                texts.pop(i, None)
-                retry[i] = "%s: %s: %s" % (paths[i], type(e).__name__, e)
+        keys = ("summ", "kept", "kept_pipe", "tr_off", "regions", "usable", "stats", "failed", "best_region", "proc_idx",
+                "samples")
+        job = dict(r=dict({k: r[k] for k in keys}, model_out=model_views(r["model_out"])), files=list(group.files),
+                   paths=[paths[i] for i in group.files], offs=np.asarray(offs), clips=[clip_view(c) for c in clips],
+                   existing=existing, indent=indent, classify=bool(classifiers), model_meta=model_meta,
+                   tracking_time=(time.time() - ctx["t0"]) / max(ctx["n_ok"], 1))
+        if meta_pool is not None:   # formatted by a worker process; collected when the batch closes
+            ctx["futures"].append(meta_pool.submit(config_blob, job))
+            tracker.timings["host_submit_s"] = tracker.timings.get("host_submit_s", 0.0) + time.time() - th
+            return
+        got_texts, got_retry, frames, _ = format_group(tracker, job)
+        texts.update(got_texts)
+        retry.update(got_retry)
+        tracker.timings["frames"] += frames
         tracker.timings["host_s"] += time.time() - th
 
     def close_batch(ctx):
         paths, texts, retry = ctx["paths"], ctx["texts"], ctx["retry"]
+        tw = time.time()
+        for f in ctx["futures"]:   # the groups' texts from the metadata workers
+            try:
+                got_texts, got_retry, frames, secs = f.result()
+            except Exception as e:  # noqa: BLE001 -- a worker that died: its recordings go the one-file way
+                logging.warning("metadata worker failed (%s: %s)", type(e).__name__, e)
+                continue
+            texts.update(got_texts)
+            retry.update(got_retry)
+            tracker.timings["frames"] += frames
+            tracker.timings["host_s"] += secs
+        tracker.timings["host_collect_s"] = tracker.timings.get("host_collect_s", 0.0) + time.time() - tw
+        if ctx["futures"]:   # (a recording no worker answered for is retried on its own, like any other failure)
+            for i in range(len(paths)):
+                if i not in texts and i not in retry and i in ctx["expected"]:
+                    retry[i] = "%s: no metadata came back" % paths[i]
         tw = time.time()
         for i, text in texts.items():
             if indent is None and (to_stdout or clip_classifier is not None):
@@ -1005,18 +1181,40 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
                 logging.error("could not process %s: %s", paths[i], e)
                 out[paths[i]] = "error: %s" % (e,)
 
-    pending = None   # (ctx, group, future of its device phase)
+    config_blob = None
+    if meta_pool is not None:
+        import pickle
+
+        config_blob = pickle.dumps(config)
+    pending = []   # (ctx, group, future of its device phase), oldest first: at most lanes_now of them
+    last_batch_t0 = [time.time()]
 
     def drain():
-        nonlocal pending
-        if pending is not None:
-            ctx, group, f = pending
-            pending = None
+        if pending:
+            ctx, group, f = pending.pop(0)
             host_phase(ctx, group, f.result())
             ctx["open"] -= 1
             if ctx["open"] == 0 and ctx["submitted"]:
-                close_batch(ctx)
+                closing.append(ctx)
+        close_ready()
 
+    closing = []   # batches whose groups are all through the device, in order; closed when their texts are there
+
+    def close_ready(block=False):
+        # (with metadata workers a batch's texts arrive later: this thread must not wait for them -- it is the one that
+        # hands the next groups to the device thread)
+        while closing and (block or all(f.done() for f in closing[0]["futures"])):
+            close_batch(closing.pop(0))
+
+    # Three Python threads share one interpreter lock: the metadata thread formats text (holds it), the device thread
+    # comes back from every device wait / ctypes call needing it -- and CPython makes a waiter wait a full switch interval
+    # (5 ms by default) before the holder is asked to yield.  A device phase is dozens of such returns per group: with the
+    # default interval the device thread spent more time queueing for the lock than on the device (16,384 fixture
+    # recordings: 10.2 s with the metadata stage, 5.9 s without it).  0.2 ms for the duration of the run.
+    import sys as _sys
+
+    switch_interval = _sys.getswitchinterval()
+    _sys.setswitchinterval(float(os.environ.get("CPX_BULK_SWITCH_INTERVAL", "0.0002")))
     try:
         for bi, paths in enumerate(batches):
             t0 = time.time()
@@ -1024,20 +1222,36 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             fut = worker.submit(produce, bi + 1) if bi + 1 < len(batches) else None
             tracker.timings["stage_s"] = tracker.timings.get("stage_s", 0.0) + stage_s
             tracker.timings["decode_s"] += decode_s
-            tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + time.time() - t0
+            waited = time.time() - t0
+            tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + waited
+            if n_lanes > 1 and bi == 1:   # (the first batch's decode has nothing to hide behind: it says nothing; decided once
+                # -- a lane's engine, network buffers and allocator pool stay behind when it is dropped again)
+                lap_s = max(t0 - last_batch_t0[0], 1e-6)   # the first batch's turn of this loop
+                lanes_now[0] = 1 if waited > 0.2 * (lap_s + waited) else n_lanes
+                tracker.timings["device_lanes"] = lanes_now[0]
+            last_batch_t0[0] = time.time()
+            k = lanes_now[0]
+            track_files, track_frames = max(64, base_track_files // k), max(20000, base_track_frames // k)
+            tracker.cnn_chunk = max(256, 2048 // k)
             groups = [sub for g in decoded.groups for sub in g.split(track_files, track_frames)]
             ctx = dict(paths=paths, base=order[bi], texts={}, retry=dict(decoded.errors), t0=t0, open=len(groups), submitted=False,
-                       n_ok=sum(len(g.files) for g in decoded.groups))
+                       n_ok=sum(len(g.files) for g in decoded.groups), futures=[],
+                       expected=set(i for g in groups for i in g.files))
             for gi, group in enumerate(groups):
                 f = dev_worker.submit(device_phase, paths, group)
                 ctx["submitted"] = gi + 1 == len(groups)
-                drain()                      # the previous group's metadata, while this one is on the device
-                pending = (ctx, group, f)
+                pending.append((ctx, group, f))
+                while len(pending) > lanes_now[0]:   # the oldest group's metadata, while the newer ones are on the device
+                    drain()
             if not groups:
-                close_batch(ctx)
+                closing.append(ctx)
+                close_ready()
             del staged, decoded
-        drain()
+        while pending:
+            drain()
+        close_ready(block=True)
     finally:  # (an exception that does escape must not leave three executors running)
+        _sys.setswitchinterval(switch_interval)
         dev_worker.shutdown(wait=True)
         worker.shutdown(wait=True)
         stage_worker.shutdown(wait=True)
@@ -1047,6 +1261,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
 
 
 def extract_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0, batch_files=None,
-                       want_text=False, stager=None, tracker=None):
+                       want_text=False, stager=None, tracker=None, meta_pool=None):
     """run_files_bulk without classification: what TrackExtractor.extract(directory) runs."""
-    return run_files_bulk(filenames, config, to_stdout, save_meta, device, batch_files, want_text, stager, tracker)
+    return run_files_bulk(filenames, config, to_stdout, save_meta, device, batch_files, want_text, stager, tracker,
+                          meta_pool=meta_pool)

@@ -28,10 +28,12 @@ _ENGINES = {}
 
 
 def get_engine(width, height, background_thresh, weight_add, edge_pixels=1, device=0, max_frames=4096,
-               max_components=64, denoise=False):
-    """One device engine per (geometry, thresholds, denoise) in this process."""
+               max_components=64, denoise=False, lane=0):
+    """One device engine per (geometry, thresholds, denoise) in this process -- per `lane`: a handle is one HIP stream and
+    one tracking workspace, so two threads that drive the device at the same time (the bulk path's two device lanes) take
+    a lane each."""
     key = (width, height, float(background_thresh), float(weight_add), edge_pixels, device, max_components,
-           bool(denoise))
+           bool(denoise)) + ((lane,) if lane else ())
     eng = _ENGINES.get(key)
     if eng is None or eng.cfg.max_frames < max_frames:
         if eng is not None:

@@ -21,6 +21,9 @@ class TrackExtractor:
         self.cache_to_disk = config.classify.cache_to_disk if cache_to_disk is None else cache_to_disk
         self.batch_files = None  # files per device batch of extract(directory); None: bulk.auto_batch_files
         self.last_run = None     # timings of the last extract(directory) (cpx.track.bulk.BulkTracker.timings)
+        # metadata worker processes (bulk.MetaPool) for directories at least this large (their start costs seconds);
+        # None = never
+        self.meta_pool_min_files = 2048
 
     def extract(self, base, to_stdout=False):
         base = Path(base)
@@ -70,10 +73,17 @@ class TrackExtractor:
         # the file-fed path at device speed (cpx/track/bulk.py): gzip inflate, section index, decode, tracking,
         # end-of-clip statistics and thumbnails on the device for `batch_files` recordings at a time, the next batch
         # read from disk meanwhile; a recording that fails is logged, retried on its own and otherwise skipped
-        from .bulk import extract_files_bulk
+        from .bulk import MetaPool, extract_files_bulk
 
-        _, tracker = extract_files_bulk(todo, self.config, to_stdout=to_stdout, device=device,
-                                        batch_files=self.batch_files)
+        # a large directory: the metadata text is formatted by worker processes (started here, before this process has
+        # touched the GPU -- MetaPool.make returns None afterwards and the stage stays in-process)
+        pool = MetaPool.make() if self.meta_pool_min_files is not None and len(todo) >= self.meta_pool_min_files else None
+        try:
+            _, tracker = extract_files_bulk(todo, self.config, to_stdout=to_stdout, device=device,
+                                            batch_files=self.batch_files, meta_pool=pool)
+        finally:
+            if pool is not None:
+                pool.close()
         self.last_run = tracker.timings
 
 

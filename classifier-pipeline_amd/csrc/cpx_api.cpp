@@ -64,6 +64,11 @@ struct cpx_handle {
   bool fuse_shortcut = true;             // CPX_CNN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts as launches of their own
   void* bf3_scratch = nullptr;           // split weights of a cpx_conv2d call that brought none
   size_t bf3_scratch_bytes = 0;
+  // activation buffers of cpx_cnn_forward (act0 | act1 | mid | sc), grown to the largest call seen and shared by every
+  // network of the handle: forwards on one handle are serialised on its stream, and a second network (another model, another
+  // leg of a run) must not bring 54 GB of its own (2,048 samples at frame size 32)
+  float* cnn_arena = nullptr;
+  size_t cnn_arena_floats = 0;
   int* cnn_ovf = nullptr;                // CPX_CNN_MATH_FP16X2: the overflow word of the forward (or bare convolution) in flight
   bool planes_handover = true;           // CPX_CNN_PLANES_HANDOVER=0: fp16x2 keeps `mid` float32 (every layer splits its own input)
   unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
@@ -326,6 +331,7 @@ void cpx_destroy(cpx_handle* h) {
   if (h->ir_scratch) hipFree(h->ir_scratch);
   if (h->bf3_scratch) hipFree(h->bf3_scratch);
   if (h->cnn_ovf) hipFree(h->cnn_ovf);
+  if (h->cnn_arena) hipFree(h->cnn_arena);
   if (h->ir_bitmap) hipFree(h->ir_bitmap);
   for (auto& e : h->conv_events) {
     hipEventDestroy(e.e0);
@@ -821,18 +827,24 @@ static bool split_math(const cpx_handle* h) { return h->cnn_math != CPX_CNN_MATH
 struct conv_half {
   float act_scale = 1.0f;   // power of two the activated input is multiplied by before the fp16 split
   bool keep_flag = false;   // the overflow word belongs to the forward in flight (cleared once, at its start)
+  int word = 0;             // which overflow word: 0 = a bare convolution's, 2 + b = block b of the forward in flight
   // producer-side split between a block's two convolutions (cpx_cnn_forward decides; ConvArgs::out_planes / in_planes)
   bool out_planes = false;  // store the output as the next layer's fp16 planes, scaled by out_act_scale
   float out_act_scale = 1.0f;
   bool in_planes = false;   // the input is in that form
 };
+// the handle's overflow words: [0] the last bare convolution's / whether the last forward raised any, [1] forwards that did,
+// [2 + b] block b of the forward in flight.  One word per BLOCK, not per forward: an activation out of fp16's range sends
+// the rest of ITS block (the two convolutions hand fp16 planes to each other) to the bf16x3 kernels; the next block is
+// back on the fp16 ones
+constexpr int OVF_WORDS = 2 + 3 * CPX_WRRESNET_MAX_BLOCKS;
 static int ensure_ovf_word(cpx_handle* h) {
   if (h->cnn_ovf) return CPX_OK;
-  if (hipMalloc((void**)&h->cnn_ovf, 2 * sizeof(int)) != hipSuccess) {
+  if (hipMalloc((void**)&h->cnn_ovf, OVF_WORDS * sizeof(int)) != hipSuccess) {
     (void)hipGetLastError();
     return fail(h, CPX_ERR_NOMEM, "cpx_conv2d: overflow word allocation failed");
   }
-  CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, 2 * sizeof(int), h->stream));
+  CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, OVF_WORDS * sizeof(int), h->stream));
   return CPX_OK;
 }
 // split_weights: the bf16 plane image of d->weights_dev if the caller (a cpx_cnn) keeps one, else NULL
@@ -914,13 +926,13 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
         ah.act_unscale = 1.0f / ah.act_scale;  // (a power of two: exact)
         ah.in_planes = hf && hf->in_planes;
       }
-      ah.ovf = h->cnn_ovf;
+      ah.ovf = h->cnn_ovf + (hf ? hf->word : 0);
       if (planes_out) {
         ah.out_planes = 1;
         ah.out_act_scale = hf->out_act_scale;
       }
       rc = cpx::launch_conv_bf3(ah, split_weights, h->stream);
-      a.guard = h->cnn_ovf;
+      a.guard = h->cnn_ovf + (hf ? hf->word : 0);
       if (rc == 0) rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
     } else {
       rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
@@ -961,6 +973,18 @@ int cpx_set_cnn_math(cpx_handle* h, int mode) {
   return CPX_OK;
 }
 int cpx_get_cnn_math(const cpx_handle* h) { return h ? h->cnn_math : CPX_ERR_INVALID; }
+
+int cpx_cnn_overflow_forwards(cpx_handle* h, int* count, int reset) {
+  if (!h) return CPX_ERR_INVALID;
+  if (!count) return fail(h, CPX_ERR_INVALID, "cpx_cnn_overflow_forwards: null argument");
+  CPX_ENTER(h);
+  *count = 0;
+  if (!h->cnn_ovf) return CPX_OK;
+  CPX_HIP(h, hipStreamSynchronize(h->stream));
+  CPX_HIP(h, hipMemcpy(count, h->cnn_ovf + 1, sizeof(int), hipMemcpyDeviceToHost));
+  if (reset) CPX_HIP(h, hipMemset(h->cnn_ovf + 1, 0, sizeof(int)));
+  return CPX_OK;
+}
 
 int cpx_cnn_last_overflow(cpx_handle* h, int* overflowed) {
   if (!h) return CPX_ERR_INVALID;
@@ -1306,8 +1330,6 @@ int cpx_trackless_thumb_batch(cpx_handle* h, const uint16_t* frames_dev, const i
 struct cpx_cnn {
   cpx_handle* h = nullptr;
   cpx_wrresnet_params p{};
-  float* arena = nullptr;  // act0 | act1 | mid | sc
-  size_t arena_floats = 0;
   std::vector<std::pair<const float*, void*>> split;  // bf16 plane images of the 3x3 stride-1 weights
   // CPX_CNN_MATH_FP16X2: the power of two each 3x3 convolution's activated input is multiplied by before the fp16 split
   // ([stage][block][a / b]; 1 until cpx_cnn_set_activation_bounds says more)
@@ -1324,7 +1346,6 @@ struct cpx_cnn {
 };
 
 static void cnn_free(cpx_cnn* c) {
-  if (c->arena) hipFree(c->arena);
   for (auto& e : c->split) hipFree(e.second);
   delete c;
 }
@@ -1412,13 +1433,14 @@ int cpx_cnn_set_activation_bounds(cpx_cnn* cnn, const float* bounds, int n) {
     for (int d = 0; d < p.blocks_per_stage; ++d)
       for (int k = 0; k < 2; ++k) {
         const float b = bounds[(st * p.blocks_per_stage + d) * 2 + k];
-        // the largest power of two that keeps bound * scale at or below 2^15 (half of fp16's range: headroom of two),
-        // between 1 and 2^14; no usable bound: 1
+        // the largest power of two that keeps bound * scale at or below 2^12, between 1 and 2^14; no usable bound: 1.
+        // (2^12, not 2^15: sixteen times the bound still fits fp16 -- a bound from BatchNorm statistics is a guess, and
+        // headroom is cheap: the low plane of every activation above 2^-3 / scale keeps all its bits either way)
         int e = 0;
         if (b > 0.0f && std::isfinite(b)) {
           int eb = 0;
           (void)std::frexp(b, &eb);  // b = f 2^eb, f in [0.5, 1): b <= 2^eb
-          e = std::min(std::max(15 - eb, 0), 14);
+          e = std::min(std::max(12 - eb, 0), 14);
         }
         cnn->act_scale[st][d][k] = std::ldexp(1.0f, e);
       }
@@ -1431,10 +1453,10 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
   if (!in_dev || !logits_dev || N < 1 || H < 1 || W < 1) return fail(h, CPX_ERR_INVALID, "cpx_cnn_forward: bad argument");
   CPX_ENTER(h);
   const cpx_wrresnet_params& p = cnn->p;
-  if (h->cnn_math == CPX_CNN_MATH_FP16X2) {  // one overflow word per forward: once set, the rest of the forward runs bf16x3
+  if (h->cnn_math == CPX_CNN_MATH_FP16X2) {  // the blocks' overflow words start clear
     const int rco = ensure_ovf_word(h);
     if (rco != CPX_OK) return rco;
-    CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, sizeof(int), h->stream));
+    CPX_HIP(h, hipMemsetAsync(h->cnn_ovf + 2, 0, (OVF_WORDS - 2) * sizeof(int), h->stream));
   }
   conv_half hf;
   hf.keep_flag = true;
@@ -1451,20 +1473,20 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
     }
   }
   biggest = align_up(biggest, 64);
-  if (4 * biggest > cnn->arena_floats) {
-    if (cnn->arena) {
+  if (4 * biggest > h->cnn_arena_floats) {
+    if (h->cnn_arena) {
       CPX_HIP(h, hipStreamSynchronize(h->stream));
-      hipFree(cnn->arena);
+      hipFree(h->cnn_arena);
     }
-    cnn->arena = nullptr;
-    cnn->arena_floats = 0;
-    hipError_t e = hipMalloc((void**)&cnn->arena, 4 * biggest * sizeof(float));
+    h->cnn_arena = nullptr;
+    h->cnn_arena_floats = 0;
+    hipError_t e = hipMalloc((void**)&h->cnn_arena, 4 * biggest * sizeof(float));
     if (e != hipSuccess) return fail(h, CPX_ERR_NOMEM, "cpx_cnn_forward: activation hipMalloc", e);
-    cnn->arena_floats = 4 * biggest;
+    h->cnn_arena_floats = 4 * biggest;
   }
-  float* act[2] = {cnn->arena, cnn->arena + biggest};
-  float* mid = cnn->arena + 2 * biggest;
-  float* sc = cnn->arena + 3 * biggest;
+  float* act[2] = {h->cnn_arena, h->cnn_arena + biggest};
+  float* mid = h->cnn_arena + 2 * biggest;
+  float* sc = h->cnn_arena + 3 * biggest;
   auto conv = [&](const float* in, float* out, const float* w, int hh, int ww, int cin, int cout, int k, int stride,
                   int same, int relu, const float* in_scale, const float* in_shift, const float* out_scale,
                   const float* out_shift, const float* residual) {
@@ -1498,6 +1520,7 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
         planes_pair = c_in % p.groups == 0 && f % p.groups == 0 && cpx::conv_bf3_can_store_planes(pa) &&
                       cpx::conv_bf3_two_planes(pb) && cpx::conv_bf3_can_load_planes(pb);
       }
+      hf.word = 2 + st * p.blocks_per_stage + d;
       hf.act_scale = cnn->act_scale[st][d][0];
       hf.out_planes = planes_pair;
       hf.out_act_scale = cnn->act_scale[st][d][1];
@@ -1555,7 +1578,21 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
   }
   hd.in_dev = cur; hd.bn_scale_dev = p.final_scale; hd.bn_shift_dev = p.final_shift;
   hd.dense_w_dev = p.dense_w; hd.dense_b_dev = p.dense_b; hd.logits_dev = logits_dev; hd.probs_dev = probs_dev;
-  return cpx_cnn_head_ex(h, &hd);
+  rc = cpx_cnn_head_ex(h, &hd);
+  if (rc == CPX_OK && h->cnn_math == CPX_CNN_MATH_FP16X2)
+    cpx::launch_count_overflow(h->cnn_ovf, 3 * p.blocks_per_stage, h->stream);
+  if (rc == CPX_OK && h->cnn_math == CPX_CNN_MATH_FP16X2 && std::getenv("CPX_CNN_DEBUG_OVF")) {
+    // diagnostic (synchronises): which blocks of this forward left fp16's range
+    int words[OVF_WORDS];
+    if (hipStreamSynchronize(h->stream) == hipSuccess &&
+        hipMemcpy(words, h->cnn_ovf, sizeof(words), hipMemcpyDeviceToHost) == hipSuccess && words[0]) {
+      std::fprintf(stderr, "cpx_cnn_forward: N = %d, fp16 overflow in blocks", N);
+      for (int k = 0; k < 3 * p.blocks_per_stage; ++k)
+        if (words[2 + k]) std::fprintf(stderr, " %d.%d", k / p.blocks_per_stage + 2, k % p.blocks_per_stage);
+      std::fprintf(stderr, "\n");
+    }
+  }
+  return rc;
 }
 
 int cpx_ir_delta_variance(cpx_handle* h, const uint8_t* cur_dev, const uint8_t* prev_dev, int width, int height,

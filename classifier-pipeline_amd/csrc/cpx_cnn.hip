@@ -498,6 +498,20 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   return -2;
 }
 
+// fp16x2 bookkeeping at the end of a forward: ovf[2 ..] are the overflow words of the forward's blocks; ovf[0] = whether
+// any of them was raised (what cpx_cnn_last_overflow reads), ovf[1] counts the forwards in which one was
+__global__ void count_overflow_kernel(int* ovf, int n_words) {
+  if (threadIdx.x == 0) {
+    int any = 0;
+    for (int k = 0; k < n_words; ++k) any |= ovf[2 + k];
+    ovf[0] = any;
+    if (any) ovf[1] += 1;
+  }
+}
+void launch_count_overflow(int* ovf, int n_words, hipStream_t s) {
+  hipLaunchKernelGGL(count_overflow_kernel, dim3(1), dim3(64), 0, s, ovf, n_words);
+}
+
 void launch_head(const HeadArgs& a, hipStream_t s) {
   int vmax = a.C > a.L ? a.C : a.L;
   for (int k = 0; k < a.n_hidden; ++k) vmax = a.hidden_sizes[k] > vmax ? a.hidden_sizes[k] : vmax;

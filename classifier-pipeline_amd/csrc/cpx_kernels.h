@@ -235,6 +235,7 @@ bool conv_bf3_can_load_planes(const ConvArgs& a);
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s);
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s);
 void launch_head(const HeadArgs& a, hipStream_t s);
+void launch_count_overflow(int* ovf, int n_words, hipStream_t s);
 
 struct CptvArgs {
   int W, H;

@@ -627,6 +627,9 @@ int cpx_get_cnn_math(const cpx_handle* h);
  * activation outside fp16's range and fell back to the BF16X3 kernels (results are correct either way; this is for
  * tests and for whoever wonders where the time went).  Synchronises the handle's stream. */
 int cpx_cnn_last_overflow(cpx_handle* h, int* overflowed);
+/* ... and how many cpx_cnn_forward calls on this handle did so since the handle was created (or since the last call with
+ * reset != 0): a network whose activation bounds do not fit its data pays the rerun often, and this is where that shows. */
+int cpx_cnn_overflow_forwards(cpx_handle* h, int* count, int reset);
 /* relu(in * bn_scale + bn_shift) -> mean over H*W -> dense [C][L] + bias -> logits (and sigmoid probs if not NULL) */
 int cpx_cnn_head(cpx_handle* h, const float* in_dev, int N, int HW, int C, const float* bn_scale_dev,
                  const float* bn_shift_dev, const float* dense_w_dev, const float* dense_b_dev, int L,
@@ -658,9 +661,9 @@ int cpx_cnn_head_ex(cpx_handle* h, const cpx_head_desc* desc);
  * stages of `blocks_per_stage` pre-activation blocks (+ 1x1 shortcut in the first block of a stage, strides
  * 1 / 2 / 3, wr_resnet.py:5-98), final BatchNorm + ReLU, global average pooling, Dense(n_labels) + sigmoid
  * (kerasmodel.py:308-350).  The parameter struct holds device pointers (float32) laid out as cpx_conv2d /
- * cpx_cnn_head take them; BatchNorm layers arrive folded to scale / shift.  The object keeps its own
- * activation buffers (grown to the largest N seen) and enqueues 3 + 6 * 3 + 1 kernels per call on the
- * handle's stream. */
+ * cpx_cnn_head take them; BatchNorm layers arrive folded to scale / shift.  The activation buffers belong to
+ * the handle (grown to the largest N seen, shared by every network created on it: forwards on a handle are
+ * serialised on its stream); a call enqueues 3 + 6 * 3 + 1 kernels on the handle's stream. */
 typedef struct cpx_wrresnet_block {
   const float* in_scale;  /* BatchNorm 2a (applied with ReLU to the block input) */
   const float* in_shift;

@@ -16,7 +16,11 @@ classify = "--no-classify" not in sys.argv
 BATCH = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 2048
 labels = ["bird", "cat", "deer", "dog", "false-positive", "hedgehog", "human", "kiwi", "leporidae", "mustelid", "penguin", "possum", "rodent", "sheep", "vehicle", "wallaby", "land-bird"]
 tmp = tempfile.mkdtemp()
-wr.save_model(os.path.join(tmp, "wr"), wr.random_weights(17, seed=0), labels, hyperparams={"frame_size": 32})
+from cpx.engine import TrackEngine
+_e = TrackEngine()
+_w = wr.calibrate_bn_device(_e, wr.random_weights(17, seed=0), torch.rand((32, 160, 160, 2), device=_e.device) * 255)
+_e.close()
+wr.save_model(os.path.join(tmp, "wr"), _w, labels, hyperparams={"frame_size": 32})
 cfg = Config.get_defaults(); cfg.tracking["thermal"].denoise = False
 cfg.classify.models = [ModelConfig.load({"id": 1, "name": "wr-bench", "model_file": os.path.join(tmp, "wr.npz")})]
 sys.path.insert(0, REPO)
@@ -39,5 +43,8 @@ if "--cprofile" in sys.argv:
     pr.enable()
 out, tr = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=min(N, BATCH), clip_classifier=cc, blobs=blobs)
 pr.disable()
+from cpx.track import cliptrackextractor as _cte
+print("fp16 overflow rerun in the last forward:", [e.cnn_last_overflow() for e in _cte._ENGINES.values()], [e.get_cnn_math() for e in _cte._ENGINES.values()])
 print("seconds", round(time.time() - t0, 3), {k: round(v, 3) if isinstance(v, float) else v for k, v in tr.timings.items()})
-st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(28); print(st.getvalue()[:6000])
+if "--cprofile" in sys.argv:
+    st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(28); print(st.getvalue()[:6000])

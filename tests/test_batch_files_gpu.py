@@ -289,3 +289,51 @@ def test_in_memory_recordings_fail_alone_and_valid_ones_are_never_lost(golden_di
     for k in (2, 3, 4):
         assert out[names[k]].startswith("error"), (names[k], out[names[k]][:200])
     assert not out[names[5]].startswith("error") and len(json.loads(out[names[5]])["tracks"]) == 1
+
+
+def test_metadata_worker_processes_write_the_same_text(golden_dir, tmp_path, model_dir=None):
+    """run_files_bulk with a MetaPool (the metadata text formatted by worker processes that never touch the GPU) gives,
+    recording for recording, the text the in-process stage gives -- with and without a classifier."""
+    import re
+
+    import cnn_oracle as co
+    from cpx.classify.clipclassifier import ClipClassifier
+    from cpx.config import Config
+    from cpx.config.config import ModelConfig
+    from cpx.ml_tools import wrresnet as wr
+    from cpx.track.bulk import MetaPool, run_files_bulk
+
+    paths = [str(p) for p in _files(golden_dir, tmp_path)] * 3
+    names = ["%02d_%s" % (k, os.path.basename(p)) for k, p in enumerate(paths)]
+    blobs = [open(p, "rb").read() for p in paths]
+    labels = ["bird", "cat", "deer", "dog", "false-positive", "hedgehog", "human", "kiwi", "leporidae", "mustelid", "penguin",
+              "possum", "rodent", "sheep", "vehicle", "wallaby", "land-bird"]
+    rng = np.random.default_rng(3)
+    w = co.calibrate_bn(wr.random_weights(17, seed=1), rng.uniform(0, 255, size=(2, 160, 160, 2)).astype(np.float32))
+    wr.save_model(tmp_path / "wr", w, labels, hyperparams={"frame_size": 32})
+    cfg = Config.get_defaults()
+    cfg.tracking["thermal"].denoise = False
+    cfg.classify.models = [ModelConfig.load({"id": 1, "name": "wr", "model_file": str(tmp_path / "wr.npz")})]
+    pool = MetaPool.make(2)
+    assert pool is not None and len(pool.pids) >= 1 and os.getpid() not in pool.pids
+
+    def strip(text):
+        text = re.sub(r'"tracking_time": [0-9.e+-]+', '"tracking_time": 0', text)
+        text = re.sub(r'"classify_time": [0-9.e+-]+', '"classify_time": 0', text)
+        text = re.sub(r'"predicted_time": [0-9.e+-]+', '"predicted_time": 0', text)
+        return re.sub(r'"id": [0-9]+,(\s+)"start_time"', r'"id": 0,\1"start_time"', text)   # Clip.CLIP_ID: a per-process counter
+
+    try:
+        for cc in (None, ClipClassifier(cfg)):
+            plain, _ = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=8, clip_classifier=cc,
+                                      blobs=blobs, track_files=5)
+            pooled, tr = run_files_bulk(names, cfg, save_meta=False, want_text=True, batch_files=8, clip_classifier=cc,
+                                        blobs=blobs, track_files=5, meta_pool=pool)
+            assert set(plain) == set(pooled) == set(names)
+            for n in names:
+                assert not plain[n].startswith("error") and strip(plain[n]) == strip(pooled[n]), n
+            assert tr.timings["files"] == len(names) and tr.timings["frames"] > 0
+            if cc is not None:
+                assert any('"all_class_confidences"' in v for v in pooled.values())
+    finally:
+        pool.close()
