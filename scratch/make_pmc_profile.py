@@ -15,7 +15,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("CPX_ROUND", "r04")
+ROUND = os.environ.get("CPX_ROUND", "r05")
 
 
 def rocprof_check():
@@ -94,11 +94,11 @@ grid2 = grids[0]
 conv_n = grid2 // (100 * 2 * 512)
 grid3 = 25 * 2 * 512 * conv_n
 out["conv_stage2"] = section(
-    "conv_bf3w_kernel<false,false,1,1,3>, stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
+    "conv_bf3w_kernel<false, true, 1, 1, 2, true, false> (fp16x2, the default math), stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
     "pmc_e2e_write", CONV, grid2, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.6,
     "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
 out["conv_stage3"] = section(
-    "conv_bf3w_kernel<false,true,2,1,3>, stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
+    "conv_bf3w_kernel<false, true, 2, 1, 2, true, false> (fp16x2), stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
     "pmc_e2e_write", CONV, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
     "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
 # one launch walks 1024 clips through their 270 frames (bench.py defaults): clip-frames per launch

@@ -2,12 +2,13 @@
 # Regenerates the judged evidence under gpurun_out/ev on the GPU box (copy into profiles/ afterwards):
 #   bench lines (default e2e incl. default_config + fs64, f32 math, track stage, config4, ir), rocprofv3 kernel stats
 #   of the default command, PMC passes (FETCH_SIZE / WRITE_SIZE separately, no trace domains) and the PMC summary.
-R=${CPX_ROUND:-r04}
+R=${CPX_ROUND:-r05}
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
 mkdir -p gpurun_out/ev
 python3 bench.py 2> gpurun_out/ev/bench_e2e.err | grep '^{' > gpurun_out/ev/${R}_bench_e2e.json
 python3 bench.py --cnn-math f32 --cpu-clips 0 --no-extras 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_e2e_f32math.json
+python3 bench.py --cnn-math bf16x3 --cpu-clips 0 --no-extras 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_e2e_bf16x3.json
 python3 bench.py --stage track 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_track.json
 python3 bench.py --config4 --steps 1 --warmup 1 --cpu-clips 8 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_config4.json
 python3 bench.py --stage ir 2>/dev/null | grep '^{' > gpurun_out/ev/${R}_bench_ir.json

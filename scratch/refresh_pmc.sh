@@ -1,6 +1,6 @@
 #!/bin/bash
 # the PMC part of refresh_evidence.sh alone (FETCH_SIZE / WRITE_SIZE in separate passes, no trace domains)
-R=${CPX_ROUND:-r04}
+R=${CPX_ROUND:-r05}
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
 mkdir -p gpurun_out/ev
