@@ -71,6 +71,7 @@ struct cpx_handle {
   size_t cnn_arena_floats = 0;
   int* cnn_ovf = nullptr;                // CPX_CNN_MATH_FP16X2: the overflow word of the forward (or bare convolution) in flight
   bool planes_handover = true;           // CPX_CNN_PLANES_HANDOVER=0: fp16x2 keeps `mid` float32 (every layer splits its own input)
+  bool block_fusion = true;              // CPX_CNN_BLOCK_FUSION=0: fp16x2 runs the stage-2 blocks as two launches each (conv_block32_kernel off)
   unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
   size_t ir_scratch_bytes = 0;
   uint32_t* ir_bitmap = nullptr;
@@ -304,6 +305,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   if (const char* env = std::getenv("CPX_TRACK_PER_STEP")) h->track_per_step = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_FUSE_SHORTCUT")) h->fuse_shortcut = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_PLANES_HANDOVER")) h->planes_handover = std::atoi(env) != 0;
+  if (const char* env = std::getenv("CPX_CNN_BLOCK_FUSION")) h->block_fusion = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_MATH")) {
     if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
     else if (!std::strcmp(env, "bf16x3")) h->cnn_math = CPX_CNN_MATH_BF16X3;
@@ -832,6 +834,9 @@ struct conv_half {
   bool out_planes = false;  // store the output as the next layer's fp16 planes, scaled by out_act_scale
   float out_act_scale = 1.0f;
   bool in_planes = false;   // the input is in that form
+  // the fp16 work of this layer was done by a fused block launch (conv_block32_kernel): only the guarded three-plane
+  // rerun is launched, and no timing record is taken (the block launch has its own)
+  bool rerun_only = false;
 };
 // the handle's overflow words: [0] the last bare convolution's / whether the last forward raised any, [1] forwards that did,
 // [2 + b] block b of the forward in flight.  One word per BLOCK, not per forward: an activation out of fp16's range sends
@@ -882,7 +887,8 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
     a.sc_H = fuse->H; a.sc_W = fuse->W; a.sc_cin = fuse->cin; a.sc_stride = fuse->stride;
   }
   cpx_handle::ConvEv ev{};
-  if (h->conv_timing) {
+  const bool timed = h->conv_timing && !(hf && hf->rerun_only);
+  if (timed) {
     ev.key = (a.Cin / a.groups) * 10000 + (a.Cout / a.groups) * 10 + a.stride + (a.ksize == 1 ? 5 : 0);
     ev.flops = 2.0 * a.N * a.Ho * a.Wo * a.Cout * (double)(a.Cin / a.groups) * a.ksize * a.ksize;
     if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess)
@@ -931,7 +937,7 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
         ah.out_planes = 1;
         ah.out_act_scale = hf->out_act_scale;
       }
-      rc = cpx::launch_conv_bf3(ah, split_weights, h->stream);
+      rc = (hf && hf->rerun_only) ? 0 : cpx::launch_conv_bf3(ah, split_weights, h->stream);
       a.guard = h->cnn_ovf + (hf ? hf->word : 0);
       if (rc == 0) rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
     } else {
@@ -945,7 +951,7 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
   } else {
     rc = cpx::launch_conv(a, h->stream);
   }
-  if (h->conv_timing) {
+  if (timed) {
     CPX_HIP(h, hipEventRecord(ev.e1, h->stream));
     h->conv_events.push_back(ev);
   }
@@ -1521,6 +1527,43 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
                       cpx::conv_bf3_two_planes(pb) && cpx::conv_bf3_can_load_planes(pb);
       }
       hf.word = 2 + st * p.blocks_per_stage + d;
+      // fp16x2: a block whose two convolutions are stride-1 with 32 channels per group (stage 2 past its first block) is
+      // ONE launch -- `mid` stays in LDS (conv_block32_kernel); the two guarded three-plane launches follow as its rerun
+      hf.rerun_only = false;
+      if (h->cnn_math == CPX_CNN_MATH_FP16X2 && h->block_fusion && s == 1 && c_in == f && b.in_scale && cnn->split_of(b.wa) &&
+          cnn->split_of(b.wb)) {
+        cpx::ConvArgs ca{}, cb{};
+        ca.N = N; ca.H = hh; ca.W = ww; ca.Ho = hh; ca.Wo = ww; ca.Cin = f; ca.Cout = f; ca.groups = p.groups; ca.ksize = 3; ca.stride = 1;
+        ca.relu = 1; ca.pad_top = ca.pad_left = 1; ca.planes = 2; ca.half = 1; ca.ovf = h->cnn_ovf + hf.word;
+        cb = ca;
+        ca.in = cur; ca.out = mid; ca.weights = b.wa; ca.in_scale = b.in_scale; ca.in_shift = b.in_shift;
+        ca.out_scale = b.a_scale; ca.out_shift = b.a_shift;
+        ca.act_scale = cnn->act_scale[st][d][0]; ca.act_unscale = 1.0f / ca.act_scale;
+        cb.in = mid; cb.out = act[flip ^ 1]; cb.weights = b.wb; cb.out_shift = b.bb; cb.residual = cur;
+        cb.act_scale = cnn->act_scale[st][d][1]; cb.act_unscale = 1.0f / cb.act_scale;
+        if (f % p.groups == 0 && cpx::conv_block32_supported(ca, cb)) {
+          cpx_handle::ConvEv ev{};
+          if (h->conv_timing) {
+            ev.key = 32 * 10000 + 32 * 10 + 4;  // ("stride 4": the fused block; both convolutions' products)
+            ev.flops = 2 * 2.0 * N * hh * ww * f * (double)(f / p.groups) * 9;
+            if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess)
+              return fail(h, CPX_ERR_HIP, "cpx_cnn_forward: event creation failed");
+            CPX_HIP(h, hipEventRecord(ev.e0, h->stream));
+          }
+          const int rb = cpx::launch_conv_block32(ca, cb, cnn->split_of(b.wa), cnn->split_of(b.wb), h->stream);
+          if (rb == 0) {
+            hf.rerun_only = true;
+            if (h->conv_timing) {
+              CPX_HIP(h, hipEventRecord(ev.e1, h->stream));
+              h->conv_events.push_back(ev);
+            }
+          } else {
+            if (h->conv_timing) { hipEventDestroy(ev.e0); hipEventDestroy(ev.e1); }
+            if (rb != -2 && rb != -3) return fail(h, CPX_ERR_HIP, "cpx_cnn_forward: block kernel configuration failed");
+          }
+        }
+      }
+      if (hf.rerun_only) planes_pair = false;  // (the rerun hands float32 over)
       hf.act_scale = cnn->act_scale[st][d][0];
       hf.out_planes = planes_pair;
       hf.out_act_scale = cnn->act_scale[st][d][1];

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "cpx_kernels.h"
 
@@ -95,10 +96,11 @@ __device__ __forceinline__ unsigned pack2_h(float a, float b) {
 }
 __device__ __forceinline__ void split_pair2_h(float a, float b, unsigned& p0, unsigned& p1) {
   p0 = pack2_h(a, b);
-  asm volatile("" : "+v"(p0));  // (opaque: see split_pair)
-  const f16x2 h = __builtin_bit_cast(f16x2, p0);
-  const float ra = a - (float)h[0], rb = b - (float)h[1];  // exact
-  p1 = pack2_h(ra, rb);
+  // lo = fp16(x - hi): the difference is exact in float32, so ONE mixed-precision fused multiply-add per element (x * 1.0 - hi,
+  // float32 inside, rounded to nearest fp16 once, into the low / high half of p1) is the same value as convert-back, subtract,
+  // convert -- three instructions per pair instead of six
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(p1) : "v"(a), "v"(p0));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(p1) : "v"(b), "v"(p0));
 }
 // the two-plane split of the chosen kind (H: fp16, else bf16)
 template <bool H>
@@ -125,6 +127,11 @@ __device__ __forceinline__ u32x4 planes_of(f32x4 v) {
   split_pair2_h(v.x, v.y, h0, l0);
   split_pair2_h(v.z, v.w, h1, l1);
   return u32x4{h0, h1, l0, l1};
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 __device__ __forceinline__ float max_abs4(f32x4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 // entry test shared by the split-operand kernels: a fp16 layer is skipped once the network's overflow word is set (its
@@ -1289,6 +1296,297 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef BF3W_ISSUE_W
 #undef BF3W_ISSUE_P
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_block32_kernel: a whole residual block of stage 2 (two stride-1 3x3 convolutions, 32 channels per group in and
+// out, wr_resnet.py wr_block) in ONE launch, CPX_CNN_MATH_FP16X2 only.
+//
+// Why: with three products per K step the stage-2 launches of conv_bf3w_kernel are bound by HBM, not by the matrix pipe
+// (4.1 TB/s, profiles/r05_cnn_probe_handover.txt): per sample and block the first convolution reads `cur` and writes
+// `mid` (2 x 6.55 MB), the second reads `mid` and `cur` (the residual) and writes the block's output (3 x 6.55 MB).
+// Here `mid` never leaves the CU: per 16 x 16 output tile the workgroup stages the 20 x 20 input patch once, computes the
+// 18 x 18 tile of `mid` the second convolution needs (1.27 x the first convolution's products: the halo is recomputed),
+// applies the folded BatchNorm + ReLU and the second convolution's range scale to the accumulators and writes them to LDS
+// as the second convolution's fp16 planes -- over the patch, which is dead by then -- and runs the second convolution from
+// there.  HBM sees `cur` in (halo re-reads come from L2) and the output out: 13.1 MB instead of 32.8.
+//
+// LDS: [patch 20 x 20, later mid 18 x 18: 51,456 B][weights a: 36,864 B][weights b: 36,864 B][BatchNorm: 256 B] = 125 KB:
+// one workgroup per CU, so the workgroup is persistent -- both weight images are loaded once, the tiles are walked with
+// the next tile's patch in flight (registers) under the second convolution's products.  Layouts, fragment addressing and
+// the order of the products are conv_bf3w_kernel's (PL = 2, H): the results are bit-identical to the two launches.
+// First convolution: 324 pixels of mid = 21 groups of 16 (the last one 4 pixels), wave w takes groups w, w + 8, w + 16.
+constexpr int B_PW = 20, B_NPX = 400;
+constexpr int B_NPXP = 402;  // 402 * 32 B = 64 mod 128 (see W_NPXP)
+constexpr int B_R0 = 2 * 2 * B_NPXP * 2;    // entries of the patch region (the mid image, 2 * 2 * W_NPXP * 2, fits inside)
+constexpr int B_WIMG = 3 * 2 * 3 * 4 * 32;  // entries of one convolution's fp16 image of one group
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_block32_kernel(ConvArgs a, ConvArgs b, const uint4* __restrict__ wa, const uint4* __restrict__ wb, TileDiv td) {
+  if (*a.ovf != 0) return;  // (the block's guarded three-plane launches follow)
+  constexpr int CT = 512;
+  constexpr int W_WROW = 2 * 3 * 4 * 32;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+  uint4* s_r0 = lds4;
+  uint4* s_wa = lds4 + B_R0;
+  uint4* s_wb = s_wa + B_WIMG;
+  f32x4* s_bn = reinterpret_cast<f32x4*>(s_wb + B_WIMG);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+  const int g = blockIdx.y;
+  const int C = a.Cin;
+  for (int i = tid; i < B_WIMG; i += CT) {
+    reinterpret_cast<u32x4*>(s_wa)[i] = reinterpret_cast<const u32x4*>(wa)[g * B_WIMG + i];
+    reinterpret_cast<u32x4*>(s_wb)[i] = reinterpret_cast<const u32x4*>(wb)[g * B_WIMG + i];
+  }
+  if (tid < 32) {  // relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly
+    reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g * 32 + tid] * a.act_scale;
+    reinterpret_cast<float*>(s_bn)[32 + tid] = a.in_shift[g * 32 + tid] * a.act_scale;
+  }
+  // tiles: every XCD walks its own contiguous eighth of the tile space (the workgroups of a launch go round-robin over
+  // the XCDs), the workgroups of an XCD side by side in it: neighbours' halos meet in that XCD's L2
+  const int per_xcd = (td.total + 7) >> 3;
+  auto tile_of = [&](int t) { return (t & 7) * per_xcd + (t >> 3); };
+  int n, oy0, ox0;
+  auto decode = [&](int tile) {
+    int qd = div_magic(tile, td.m_tx);
+    ox0 = (tile - qd * td.tiles_x) * W_TW;
+    tile = qd;
+    qd = div_magic(tile, td.m_ty);
+    oy0 = (tile - qd * td.tiles_y) * W_TH;
+    n = qd;
+  };
+  constexpr int NITEM = B_NPX * 8;
+  constexpr int NP = (NITEM + CT - 1) / CT;  // 7 (the seventh for threads 0..127)
+  u32x4 pre_p[NP];
+  auto issue_patch = [&]() __attribute__((always_inline)) {  // global -> registers: the 20 x 20 patch of tile (n, oy0, ox0), clamped
+    int t8 = tid >> 3;
+    asm volatile("" : "+v"(t8));
+    int q8 = tid & 7;
+    asm volatile("" : "+v"(q8));
+    const float* in_n = a.in + (size_t)n * a.H * a.W * C;
+    const unsigned coff = (unsigned)(g * 32 + 4 * q8);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int px = min(t8 + 64 * i, B_NPX - 1);
+      const int py = (int)(__umul24((unsigned)px, 3277u) >> 16), pxx = __mul24(py, -B_PW) + px;  // px / 20 for px < 400
+      const int cy = min(max(oy0 - 2 + py, 0), a.H - 1), cx = min(max(ox0 - 2 + pxx, 0), a.W - 1);
+      pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, C) + coff) << 2));
+    }
+  };
+  int t = blockIdx.x;
+  // (td.total >= 8 gridDim.x is not required: a workgroup whose first tile does not exist has none)
+  while (t < 8 * per_xcd && tile_of(t) >= td.total) t += gridDim.x;
+  if (t >= 8 * per_xcd) return;
+  decode(tile_of(t));
+  issue_patch();
+  // what a thread needs of the channel parameters is the same for every tile: registers (one workgroup per CU: 256 to spend)
+  const int ch_l = g * 32 + 4 * q;
+  f32x4 os_a[2], ob_a[2], rs_b[2], os_b[2], ob_b[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int ch = ch_l + 16 * ct;
+    os_a[ct] = *reinterpret_cast<const f32x4*>(a.w_unscale + ch) * (a.act_unscale * b.act_scale);  // (powers of two: exact)
+    if (a.out_scale) os_a[ct] *= *reinterpret_cast<const f32x4*>(a.out_scale + ch);
+    ob_a[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.out_shift) ob_a[ct] = *reinterpret_cast<const f32x4*>(a.out_shift + ch) * b.act_scale;
+    rs_b[ct] = *reinterpret_cast<const f32x4*>(b.w_scale + ch) * b.act_scale;
+    os_b[ct] = *reinterpret_cast<const f32x4*>(b.w_unscale + ch) * b.act_unscale;
+    ob_b[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (b.out_shift) ob_b[ct] = *reinterpret_cast<const f32x4*>(b.out_shift + ch);
+  }
+  __syncthreads();  // weights and BatchNorm parameters are in LDS
+  const f32x4 psc = s_bn[tid & 7], psh = s_bn[8 + (tid & 7)];
+  // out of fp16's range = a high plane that came out infinite.  Every staged value is >= 0 (ReLU), so fp16 bit patterns order
+  // as unsigned halves: the running maximum of the high planes, two packed halves per instruction
+  unsigned hmax = 0u;
+  // registers -> the patch's fp16 planes, in place ([hi 0..1, hi 2..3, lo 0..1, lo 2..3]): BatchNorm + ReLU prologue,
+  // padding zeroed.  (py0, px0): the patch's origin in the image
+  auto convert_item = [&](const int i, const int py0, const int px0, const bool interior) __attribute__((always_inline)) {
+    float v[4];
+    {
+      const f32x4 y = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, pre_p[i]), psc, psh);  // (two v_pk_fma_f32)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(y[j], 0.0f);
+    }
+    if (!interior) {
+      asm volatile("");
+      const int px = (tid >> 3) + 64 * i;
+      const int py = (int)(__umul24((unsigned)px, 3277u) >> 16), pxx = __mul24(py, -B_PW) + px;
+      const bool inside = (unsigned)(py0 + py) < (unsigned)a.H && (unsigned)(px0 + pxx) < (unsigned)a.W;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = inside ? v[j] : 0.0f;
+    }
+    unsigned h0, h1, l0, l1;
+    split_pair2_h(v[0], v[1], h0, l0);
+    split_pair2_h(v[2], v[3], h1, l1);
+    hmax = pk_max_u16(pk_max_u16(hmax, h0), h1);
+    pre_p[i] = u32x4{h0, h1, l0, l1};
+  };
+  auto commit_patch = [&]() __attribute__((always_inline)) {  // converted registers -> LDS
+    int t8 = tid >> 3;
+    asm volatile("" : "+v"(t8));
+    int q8 = tid & 7;
+    asm volatile("" : "+v"(q8));
+    const int st_e2 = (int)(__umul24((unsigned)(q8 >> 2), (unsigned)B_NPXP) + (unsigned)t8) * 4 + (q8 & 3);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (i * CT + CT <= NITEM || tid < NITEM - i * CT) {
+        uint2* sp2 = reinterpret_cast<uint2*>(s_r0) + st_e2 + i * (64 * 4);
+        sp2[(0 * 2 * B_NPXP) * 4] = make_uint2(pre_p[i][0], pre_p[i][1]);
+        sp2[(1 * 2 * B_NPXP) * 4] = make_uint2(pre_p[i][2], pre_p[i][3]);
+      }
+    }
+  };
+  auto tile_interior = [&]() { return oy0 - 2 >= 0 && oy0 + 18 <= a.H && ox0 - 2 >= 0 && ox0 + 18 <= a.W; };
+  {
+    const bool interior = tile_interior();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) convert_item(i, oy0 - 2, ox0 - 2, interior);
+  }
+  for (;;) {
+    commit_patch();
+    const int n_cur = n, oy_cur = oy0, ox_cur = ox0;
+    const bool interior_cur = tile_interior();
+    // ---- the second convolution's accumulators start as the residual (the block's input at the tile): in flight under
+    //      the first convolution, as is the NEXT tile's patch ----
+    f32x4 acc[2][2];
+    unsigned opix[2];
+    bool ovalid[2];
+    {
+      const float* res_n = b.residual + (size_t)n_cur * a.H * a.W * C;
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const int oy = oy_cur + 2 * wave + pt, ox = ox_cur + i16;
+        ovalid[pt] = oy < a.H && ox < a.W;
+        opix[pt] = pix_off(min(oy, a.H - 1), min(ox, a.W - 1), a.W, C) + (unsigned)ch_l;
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 16u * ct) << 2));
+    }
+    t += gridDim.x;
+    const bool more = t < 8 * per_xcd && tile_of(t) < td.total;  // (a workgroup's tiles ascend within its XCD's eighth: the first missing one ends it)
+    if (more) {
+      decode(tile_of(t));
+      issue_patch();
+    }
+    const bool interior_next = tile_interior();
+    __syncthreads();
+    // ---- first convolution: mid pixel groups wave, wave + 8, wave + 16 (< 21) x 32 columns ----
+    f32x4 acc1[3][2];
+    int abase1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int p = min(16 * (wave + 8 * j) + i16, W_NPX - 1);
+      const int my = (int)(__umul24((unsigned)p, 3641u) >> 16), mx = p - my * W_PW;  // p / 18 for p < 324
+      abase1[j] = ((q >> 1) * B_NPXP + my * B_PW + mx) * 2 + (q & 1);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc1[j][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const int b_base = q * 32 + i16;
+    const bool third = wave < 5;  // (uniform) group wave + 16 exists
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        u32x4 wv[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_wa[r * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (j < 2 || third) {
+            u32x4 xv[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) xv[p] = __builtin_bit_cast(u32x4, s_r0[p * (4 * B_NPXP) + abase1[j] + (r * B_PW + kx) * 2]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              acc1[j][ct] = mfma16<true>(wv[ct][1], xv[0], acc1[j][ct]);
+              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[1], acc1[j][ct]);
+              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[0], acc1[j][ct]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // every wave has read its patch fragments: the region becomes mid
+    // ---- mid = relu(acc * a_scale + a_shift), times the second convolution's range scale, as its fp16 planes in LDS;
+    //      pixels outside the image are that convolution's zero padding ----
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int c4 = 4 * ct + q;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int p = 16 * (wave + 8 * j) + i16;
+        if (p < W_NPX) {
+          f32x4 v = acc1[j][ct] * os_a[ct] + ob_a[ct];
+          v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+          u32x4 pv = planes_of(v);
+          hmax = pk_max_u16(pk_max_u16(hmax, pv[0]), pv[1]);
+          if (!interior_cur) {  // (uniform)
+            asm volatile("");
+            const int my = (int)(__umul24((unsigned)p, 3641u) >> 16), mx = p - my * W_PW;
+            const bool inside = (unsigned)(oy_cur - 1 + my) < (unsigned)a.H && (unsigned)(ox_cur - 1 + mx) < (unsigned)a.W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[k] = inside ? pv[k] : 0u;
+          }
+          uint2* sp2 = reinterpret_cast<uint2*>(s_r0) + ((c4 >> 2) * W_NPXP + p) * 4 + (c4 & 3);
+          sp2[(0 * 2 * W_NPXP) * 4] = make_uint2(pv[0], pv[1]);
+          sp2[(1 * 2 * W_NPXP) * 4] = make_uint2(pv[2], pv[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) acc[ct][pt] *= rs_b[ct];  // the accumulators hold act_scale * w_scale[channel] times the sum: so must the residual
+    __syncthreads();
+    // ---- second convolution: conv_bf3w_kernel's loop on the mid image; between its taps the next tile's patch (landed
+    //      during the first convolution) takes its prologue and split, one item per tap: vector work under the products ----
+    {
+      const int a_base = ((q >> 1) * W_NPXP + (2 * wave) * W_PW + i16) * 2 + (q & 1);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          u32x4 xv[2][2], wv[2][2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) xv[pt][p] = __builtin_bit_cast(u32x4, s_r0[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_wb[r * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
+          }
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+              acc[ct][pt] = mfma16<true>(wv[ct][1], xv[pt][0], acc[ct][pt]);
+              acc[ct][pt] = mfma16<true>(wv[ct][0], xv[pt][1], acc[ct][pt]);
+              acc[ct][pt] = mfma16<true>(wv[ct][0], xv[pt][0], acc[ct][pt]);
+            }
+          if (r * 3 + kx < NP && more) convert_item(r * 3 + kx, oy0 - 2, ox0 - 2, interior_next);
+        }
+      }
+    }
+    // ---- epilogue: unscale, bias, ReLU, one 16-byte store per accumulator tile ----
+    {
+      float* out_n = b.out + (size_t)n_cur * a.H * a.W * C;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          f32x4 v = acc[ct][pt] * os_b[ct];
+          v += ob_b[ct];
+          v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+          if (ovalid[pt]) *reinterpret_cast<f32x4*>(at_off(out_n, (opix[pt] + 16u * ct) << 2)) = v;
+        }
+      }
+    }
+    if (!more) break;
+    __syncthreads();  // every wave has read its mid fragments: the region takes the next patch
+  }
+  if ((hmax & 0xFFFFu) >= 0x7C00u || (hmax >> 16) >= 0x7C00u) atomicOr(a.ovf, 1);  // (infinity or NaN)
+}
+
 constexpr long long RERUN_GRID = 1024;  // workgroups along x of a guarded rerun (four per CU and group row)
 template <int NTN, int NPXC, int PL, bool H = false>
 int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
@@ -1740,6 +2038,55 @@ int launch_conv_bf3(const ConvArgs& a_in, const void* wimg, hipStream_t s) {
     return launch_bf3_t<CPX_BF3_NTN_S4, 1, CPX_BF3_NB_S4, 32, CPX_BF3_CT_S4>(a, w, s);
   }
   return -2;
+}
+
+// a stage-2 residual block in one launch (conv_block32_kernel): `a` the first convolution (BatchNorm prologue, folded
+// BatchNorm + ReLU epilogue), `b` the second (bias, residual = the block's input, ReLU); fp16x2 with both act_scale set
+bool conv_block32_supported(const ConvArgs& a, const ConvArgs& b) {
+  const auto plain = [](const ConvArgs& c) {
+    return c.ksize == 3 && c.stride == 1 && c.Cin == c.Cout && c.Cin / c.groups == 32 && c.relu && c.pad_top == 1 && c.pad_left == 1 &&
+           c.sc_in == nullptr && !c.out_planes && !c.in_planes;
+  };
+  return plain(a) && plain(b) && a.in_scale && a.in_shift && !a.residual && !b.in_scale && !b.out_scale && b.residual == a.in &&
+         a.Cin == b.Cin && a.groups == b.groups && a.H == b.H && a.W == b.W && a.N == b.N && a.ovf != nullptr;
+}
+int launch_conv_block32(const ConvArgs& a_in, const ConvArgs& b_in, const void* wimg_a, const void* wimg_b, hipStream_t s) {
+  ConvArgs a = a_in, b = b_in;
+  if (!conv_block32_supported(a, b)) return -2;
+  if ((long long)a.H * a.W >= (1 << 24)) return -3;
+  a.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wimg_a) + scales_offset(a));
+  a.w_unscale = a.w_scale + a.Cout;
+  b.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wimg_b) + scales_offset(b));
+  b.w_unscale = b.w_scale + b.Cout;
+  const uint4* wa = reinterpret_cast<const uint4*>(wimg_a) + half_image_offset(a) / 16;
+  const uint4* wb = reinterpret_cast<const uint4*>(wimg_b) + half_image_offset(b) / 16;
+  TileDiv td{};
+  td.tiles_x = (a.W + W_TW - 1) / W_TW;
+  td.tiles_y = (a.H + W_TH - 1) / W_TH;
+  td.nsplit = 1;
+  const long long tiles = (long long)td.tiles_x * td.tiles_y * a.N;
+  if (tiles >= (1 << 22) - 8 || td.tiles_x >= 4096 || td.tiles_y >= 4096) return -3;
+  td.m_nsplit = (1ull << 42) + 1;
+  td.m_tx = (1ull << 42) / td.tiles_x + 1;
+  td.m_ty = (1ull << 42) / td.tiles_y + 1;
+  td.total = (int)tiles;
+  const size_t lds = (size_t)(B_R0 + 2 * B_WIMG) * 16 + 256;
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel), lds_ready, 160 * 1024 - 1024)) return -1;
+  // one workgroup per CU (125 KB of LDS), shared among the groups; a multiple of eight per group so that blockIdx.x & 7 is the XCD
+  static int grid_x[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  if (grid_x[dev] == 0) {
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    grid_x[dev] = cus;
+  }
+  int gx = std::max(8, grid_x[dev] / a.groups / 8 * 8);
+  if (const char* e = std::getenv("CPX_BLOCK32_GRID")) gx = std::max(8, std::atoi(e) / 8 * 8);
+  gx = (int)std::min<long long>(gx, (tiles + 7) / 8 * 8);
+  hipLaunchKernelGGL(conv_block32_kernel, dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
+  return 0;
 }
 
 }  // namespace cpx

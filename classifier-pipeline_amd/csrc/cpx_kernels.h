@@ -234,6 +234,10 @@ bool conv_bf3_can_store_planes(const ConvArgs& a);
 bool conv_bf3_can_load_planes(const ConvArgs& a);
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s);
 int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s);
+// a stage-2 residual block (two stride-1 3x3 convolutions, 32 channels per group) in one fp16x2 launch: `a` / `b` the two
+// convolutions as launch_conv_bf3 would take them (half, act_scale, ovf set), wimg_a / wimg_b their weight images
+bool conv_block32_supported(const ConvArgs& a, const ConvArgs& b);
+int launch_conv_block32(const ConvArgs& a, const ConvArgs& b, const void* wimg_a, const void* wimg_b, hipStream_t s);
 void launch_head(const HeadArgs& a, hipStream_t s);
 void launch_count_overflow(int* ovf, int n_words, hipStream_t s);
 

@@ -307,6 +307,45 @@ def test_fused_shortcut_equals_separate_launch(engine, monkeypatch):
     assert float(np.abs(fused.cpu().numpy() - want).max()) <= LOGIT_ATOL
 
 
+@pytest.mark.parametrize("side,n", [(160, 3), (150, 2), (37, 1)])
+def test_fused_block_is_bitwise_the_two_launches(engine, monkeypatch, side, n):
+    """fp16x2 runs a stage-2 block past the first as ONE launch (conv_block32_kernel: `mid` stays in LDS); an engine
+    created with CPX_CNN_BLOCK_FUSION=0 runs its two convolutions as two.  Same planes, same products in the same
+    order: the logits are the same bits -- on whole tiles, ragged ones (150 = 9 x 16 + 6) and a map of three tiles."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.engine import TrackEngine
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(300 + side)
+    x = rng.uniform(0, 255, size=(n, side, side, 2)).astype(np.float32)
+    w = co.calibrate_bn(wr.random_weights(17, seed=8), x)
+    engine.set_cnn_math("fp16x2")
+    net = wr.WRResNetDevice(engine, w, 17)
+    engine.conv_timing(True)
+    fused, _ = net.forward(torch.from_numpy(x).to(engine.device))
+    launches = engine.conv_timing()
+    engine.conv_timing(False)
+    assert not engine.cnn_last_overflow()
+    assert 320324 in launches and 320321 in launches, launches   # the block launches (key "stride 4"); block 0's second convolution
+    assert launches[320324][0] == 2 and launches[320321][0] == 1, launches
+    net.close()
+    monkeypatch.setenv("CPX_CNN_BLOCK_FUSION", "0")
+    eng2 = TrackEngine(model="lepton3")
+    monkeypatch.delenv("CPX_CNN_BLOCK_FUSION")
+    eng2.set_cnn_math("fp16x2")
+    net2 = wr.WRResNetDevice(eng2, w, 17)
+    two, _ = net2.forward(torch.from_numpy(x).to(eng2.device))
+    assert not eng2.cnn_last_overflow()
+    net2.close()
+    eng2.close()
+    engine.set_cnn_math(engine.DEFAULT_CNN_MATH)
+    assert torch.equal(fused.cpu(), two.cpu()), float((fused.cpu() - two.cpu()).abs().max())
+    want, _ = co.forward(w, x)
+    assert float(np.abs(fused.cpu().numpy() - want).max()) <= LOGIT_ATOL
+
+
 @pytest.mark.parametrize("dense_sizes,activation", [((48, 24), "softmax"), ((40,), "sigmoid"), (None, "softmax")])
 def test_head_variants_match_oracle(dense_sizes, activation):
     """KerasModel.build_model's head variants (kerasmodel.py:337-345): hidden Dense(relu) layers of dense_sizes and
