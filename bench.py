@@ -16,13 +16,16 @@ N > 1: the driver launches one rank per GPU (torch.distributed.run); clips shard
 no data-path collective; the per-track result records are all-gathered once per step over RCCL.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel of the step.  e2e: the stage-2 3x3 grouped convolution
-                (conv_bf3_kernel<1,1,2,16,512,false> in the rocprof CSV, an instantiation the stage-3 3x3 convolutions share:
-                the roofline covers both; conv_mfma_kernel<8,1,1,3,2,16>, stage 2 only, with --cnn-math f32):
-                algorithmic FLOPs (2*M*N*K of the float32 convolution) of its launches / their HIP-event time on the
-                handle's stream.  Peak: with the default bf16x3 math every float32 multiply-add is six bf16 MFMA
-                multiply-adds, so the dense bf16 MFMA peak / 6; with f32 math the fp32-MFMA dense peak.  --stage track:
-                cpx_frame_kernel, HBM-bound, 614,400 algorithmic bytes per frame.
+  roofline      the kernel the step spends most of its time in (its `dominant` field says which and how long).  e2e, default
+                fp16x2 math: cpx_frame_kernel (one launch per step, HBM-bound: 460,800 moved bytes per frame without the label
+                image) -- the convolutions stopped being the largest kernel when the fp16x2 mode halved their products and the
+                stage-2 blocks became one launch each.  Every other kernel above a tenth of the step stands under
+                roofline.kernels: conv_stage3 (conv_bf3w_kernel<..., 2, ...>), conv_block (conv_block32_kernel), conv_stage2
+                (conv_bf3w_kernel<..., 1, ...>), each with algorithmic FLOPs (2*M*N*K of the float32 convolution) and bytes of its
+                launches / their HIP-event time on the handle's stream, against both roofs (`bound` = the nearer one): HBM 8 TB/s;
+                the dense 16-bit MFMA peak / products per float32 multiply-add (3 in fp16x2 / bf16x2, 6 in bf16x3), the fp32-MFMA
+                dense peak with --cnn-math f32.  --stage track: cpx_frame_kernel, 614,400 algorithmic bytes per frame.
+  roofline_conv the largest convolution kernel of the step, the same object as its entry under roofline.kernels.
   roofline_track  (e2e) the same HBM accounting for cpx_frame_kernel inside the same run.
   cpu_baseline  the oracle chain ("port": NumPy tracker + NumPy crop/tile + PyTorch-CPU forward, 1 core)
                 timed on a bounded sample of the same workload on this host (rank 0, N = 1 only);
@@ -99,7 +102,11 @@ def conv_layer_table(conv, math, steps):
             pr = PRODUCTS[math]
             pipe, peak = "%s MFMA, %d products" % ("fp16" if math == "fp16x2" else "bf16", pr), MFMA_BF16_PEAK_TFLOPS / pr
         tf = fl / (ms / 1e3) / 1e12
-        out[str(k)] = {"channels_per_group": [cin_g, cout_g], "stride": st, "kernel": "1x1" if one else "3x3",
+        block = st == 4  # conv_block32_kernel: a residual block's two stride-1 3x3 convolutions in one launch
+        if block:
+            st = 1
+        out[str(k)] = {"channels_per_group": [cin_g, cout_g], "stride": st,
+                       "kernel": "3x3 + 3x3 (a residual block in one launch)" if block else "1x1" if one else "3x3",
                        "launches_per_step": n // max(steps, 1), "ms_per_step": round(ms / steps, 2),
                        "tflops_f32_equivalent": round(tf, 2), "pipe": pipe,
                        "frac_of_pipe_peak": round(tf / peak, 4) if peak else None}
@@ -191,7 +198,7 @@ def spawn_ranks(n, argv):
 # keys every default (e2e) line carries, whatever N: the driver compares the N = 1 line of the scaling run with the
 # default run's; --dry-launch emits the same skeleton (values None) so that a CPU host can check the assembly
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-             "vs_baseline", "dtype", "data", "config", "roofline", "roofline_track", "cnn", "per_rank")
+             "vs_baseline", "dtype", "data", "config", "roofline", "roofline_conv", "roofline_track", "cnn", "per_rank")
 MULTI_RANK_KEYS = ("config4", "from_files")
 
 
@@ -1155,80 +1162,79 @@ def main():
             line["config"].update({"kept_tracks_per_step": int(r.n_tracks), "classified_segments_per_step": int(r.n_samples),
                                    "frame_size": args.frame_size, "n_labels": N_LABELS, "cnn_chunk": args.cnn_chunk,
                                    "sub_batches": args.sub_batches})
-            key = 32 * 10000 + 32 * 10 + 1  # the stage-2 3x3 convolutions (32 -> 32 channels per group, stride 1)
+            key = 32 * 10000 + 32 * 10 + 1  # the stage-2 3x3 convolutions launched on their own (32 -> 32 channels per group, stride 1)
+            key4 = 32 * 10000 + 32 * 10 + 4  # conv_block32_kernel: a stage-2 residual block (two of those convolutions) in one launch
             key3 = 64 * 10000 + 64 * 10 + 1  # the stage-3 ones: same FLOPs per sample, half the bytes
-            if key in conv and conv[key][1] > 0:
+            if (key in conv and conv[key][1] > 0) or (key4 in conv and conv[key4][1] > 0):
                 bf3 = args.cnn_math in PRODUCTS
                 products = PRODUCTS.get(args.cnn_math, BF16X3_PRODUCTS)
                 area = (args.frame_size / 32.0) ** 2  # map area relative to the 160 x 160 maps of frame size 32
                 side = 5 * args.frame_size
-                # input + output (+ residual in 3 of the 5 launches of a shape per forward), float32 NHWC
-                bytes2 = side * side * 64 * 4 * 2.6
-                if bf3 and key3 in conv:
-                    # stage 2 and stage 3 run the same source kernel (conv_bf3w_kernel) in two instantiations since
-                    # round 4 -- <false,false,1,1>: one 32-column slice per workgroup (stage 2: 32 columns per group);
-                    # <false,true,2,1>: both slices of a group from one staged patch (stage 3) -- two rows of the rocprof
-                    # CSV.  `roofline` is the DOMINANT one (stage 2: the top row); the other one and the launches of
-                    # both together (what rounds 2-3 reported, one instantiation then) stand beside it.
-                    def leg(k, pmc_key, byte_scale):
-                        n_, ms_, fl_ = conv[k]
-                        spl = fl_ / n_ / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
-                        ab = spl * bytes2 * byte_scale
-                        tf_ = fl_ / (ms_ / 1e3) / 1e12
-                        return {"achieved": round(tf_, 2), "frac": round(tf_ / (MFMA_BF16_PEAK_TFLOPS / products), 4),
-                                "avg_launch_us": round(ms_ / n_ * 1e3, 2), "launches": n_,
-                                "algorithmic_flops_per_launch": fl_ / n_, "algorithmic_bytes_per_launch": ab,
-                                "traffic": pmc_traffic(pmc_key, spl * area),
-                                "hbm_GBps_algorithmic": round(ab / (ms_ / n_ / 1e3) / 1e9, 1)}
-                    l2, l3 = leg(key, "conv_stage2", 1.0), leg(key3, "conv_stage3", 0.5)  # stage 3 moves half of stage 2's bytes
-                    n, ms, fl = conv[key]
-                    samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
-                    algo_bytes = l2["algorithmic_bytes_per_launch"]
-                    traffic = l2["traffic"]
-                    what = ("%s (the 16x16x32 MFMA form of the split-operand kernel, one 32-column slice per workgroup: the "
-                            "stage-2 3x3 convs, 64->64 ch at %dx%d, groups 2)" % (bf3w_kernel_name(32, args.cnn_math), side, side))
-                else:
-                    n, ms, fl = conv[key]
-                    samples_per_launch = fl / n / (STAGE2_CONV_FLOPS_PER_SAMPLE * area)
-                    algo_bytes = samples_per_launch * bytes2
-                    traffic = None
-                    what = "conv_mfma_kernel<8,1,1,3,2,16> (stage-2 3x3 conv, 64->64 ch, groups 2, %dx%d)" % (side, side)
-                tf = fl / (ms / 1e3) / 1e12
+                tensor2 = side * side * 64 * 4  # bytes of one stage-2 activation tensor of one sample (float32 NHWC)
                 peak = round(MFMA_BF16_PEAK_TFLOPS / products, 1) if bf3 else MFMA_F32_PEAK_TFLOPS
-                hbm_gbs = algo_bytes / (ms / n / 1e3) / 1e9
-                # which roof binds: with six products per multiply-add the matrix pipe (0.44 of its roof against 0.4 of
-                # HBM's); with three the same layer moves the same bytes in 0.6 of the time and sits closer to the HBM roof
-                # than to the halved matrix one -- the object reports the nearer roof and keeps the other beside it
-                hbm_bound = bf3 and hbm_gbs / HBM_PEAK_GBS > tf / peak
-                line["roofline"] = {"kernel": what,
-                                    "bound": "hbm" if hbm_bound else "mfma",
-                                    "achieved": round(hbm_gbs, 1) if hbm_bound else round(tf, 2),
-                                    "peak": HBM_PEAK_GBS if hbm_bound else peak,
-                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                                    "frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if hbm_bound else round(tf / peak, 4),
-                                    "mfma": {"achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
-                                    "traffic": traffic,
-                                    "traffic_source": PMC_NOTE if traffic is not None else None,
-                                    "avg_launch_us": round(ms / n * 1e3, 2), "launches": n,
-                                    "algorithmic_flops_per_launch": fl / n,
-                                    "algorithmic_bytes_per_launch": algo_bytes,
-                                    "peak_note": (("HBM3E 8 TB/s against the launch's algorithmic bytes (input + output + residual, "
-                                                   "float32 NHWC); mfma: " if hbm_bound else "") +
-                                                  ("dense 16-bit MFMA peak 2500 TFLOP/s / %d products per float32 multiply-add" % products
-                                                   if bf3 else "dense fp32-input MFMA peak")),
-                                    "hbm_GBps_algorithmic": round(algo_bytes / (ms / n / 1e3) / 1e9, 1),
-                                    "hbm_frac": round(algo_bytes / (ms / n / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "stage2_tflops": round(conv[key][2] / (conv[key][1] / 1e3) / 1e12, 2)}
+                fused = key4 in conv and conv[key4][1] > 0
+
+                def leg(k, pmc_key, kernel, tensors, note, convs=1):
+                    """One convolution kernel of the step: its launches' algorithmic FLOPs and bytes against their HIP-event
+                    time; the roof it sits nearer to is `bound`, the other one stays beside it."""
+                    n_, ms_, fl_ = conv[k]
+                    spl = fl_ / n_ / (convs * STAGE2_CONV_FLOPS_PER_SAMPLE * area)  # samples per launch
+                    ab = spl * tensor2 * tensors
+                    tf_ = fl_ / (ms_ / 1e3) / 1e12
+                    gbs = ab / (ms_ / n_ / 1e3) / 1e9
+                    hbm_bound = bf3 and gbs / HBM_PEAK_GBS > tf_ / peak
+                    tr = pmc_traffic(pmc_key, spl * area)
+                    return {"kernel": kernel, "bound": "hbm" if hbm_bound else "mfma",
+                            "achieved": round(gbs, 1) if hbm_bound else round(tf_, 2),
+                            "peak": HBM_PEAK_GBS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4) if hbm_bound else round(tf_ / peak, 4),
+                            "mfma": {"achieved": round(tf_, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf_ / peak, 4)},
+                            "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                            "traffic": tr, "traffic_source": PMC_NOTE if tr is not None else None,
+                            "avg_launch_us": round(ms_ / n_ * 1e3, 2), "launches": n_, "ms_per_step": round(ms_ / args.steps, 2),
+                            "algorithmic_flops_per_launch": fl_ / n_, "algorithmic_bytes_per_launch": ab,
+                            "algorithmic_bytes_note": note,
+                            "peak_note": ("HBM3E 8 TB/s; " if bf3 else "") +
+                                         ("dense 16-bit MFMA peak 2500 TFLOP/s / %d products per float32 multiply-add" % products
+                                          if bf3 else "dense fp32-input MFMA peak")}
+                kernels = {}
+                if key in conv and conv[key][1] > 0:
+                    if bf3:
+                        kernels["conv_stage2"] = leg(
+                            key, "conv_stage2",
+                            "%s (the 16x16x32 MFMA form of the split-operand kernel, one 32-column slice per workgroup: the stage-2 "
+                            "3x3 convs launched on their own, 64->64 ch at %dx%d, groups 2)" % (bf3w_kernel_name(32, args.cnn_math), side, side),
+                            2.25 if fused else 2.6,
+                            "the second convolution of the stage's first block: mid in, output out, the fused 1x1 shortcut's 16-channel input"
+                            if fused else "input + output (+ residual in 3 of the 5 launches of this shape per forward)")
+                    else:
+                        kernels["conv_stage2"] = leg(key, "conv_stage2", "conv_mfma_kernel<8,1,1,3,2,16> (stage-2 3x3 conv, 64->64 ch, "
+                                                     "groups 2, %dx%d)" % (side, side), 2.6, "input + output (+ residual in 3 of 5)")
+                if fused:
+                    kernels["conv_block"] = leg(
+                        key4, "conv_block",
+                        "conv_block32_kernel (a stage-2 residual block past the first in one launch: two 3x3 convs 64->64 ch at %dx%d, "
+                        "groups 2, the tensor between them kept in LDS; FLOPs of both, the recomputed halo not counted)" % (side, side),
+                        2.0, "the block's input in, its output out (the residual is the input: halo re-reads and the residual come from L2)",
+                        convs=2)
                 if bf3 and key3 in conv:
-                    nb, msb, flb = conv[key][0] + conv[key3][0], conv[key][1] + conv[key3][1], conv[key][2] + conv[key3][2]
-                    line["roofline"]["second_instantiation"] = dict(
-                        {"kernel": ("%s (both 32-column slices of a group from one staged patch: the stage-3 3x3 convs, "
-                                    "128->128 ch at %dx%d, groups 2)" % (bf3w_kernel_name(64, args.cnn_math), side // 2, side // 2))},
-                        **l3)
-                    line["roofline"]["both_instantiations"] = {
-                        "what": "all conv_bf3w_kernel launches of the step (the accounting of rounds 2-3, one instantiation then)",
-                        "achieved": round(flb / (msb / 1e3) / 1e12, 2), "frac": round(flb / (msb / 1e3) / 1e12 / peak, 4),
-                        "avg_launch_us": round(msb / nb * 1e3, 2), "launches": nb}
+                    kernels["conv_stage3"] = leg(
+                        key3, "conv_stage3",
+                        "%s (both 32-column slices of a group from one staged patch: the stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)"
+                        % (bf3w_kernel_name(64, args.cnn_math), side // 2, side // 2), 0.5 * 2.6,
+                        "input + output (+ residual in 3 of the 5 launches of this shape per forward); half of a stage-2 tensor each")
+                # `roofline` is the kernel the step spends most of its time in -- since the fp16x2 mode and the fused blocks that
+                # is the track kernel (one launch per step), not a convolution; every kernel above a tenth of the step stands
+                # beside it under `kernels`, `roofline_conv` names the largest convolution kernel
+                kernels["track"] = dict(track_roof, ms_per_step=round(kernel_ms / args.steps, 2))
+                dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+                conv_dom = max((k for k in kernels if k != "track"), key=lambda k: kernels[k]["ms_per_step"])
+                line["roofline"] = dict(kernels[dom], dominant="%s: %.1f ms of the %.1f ms step" % (
+                    dom, kernels[dom]["ms_per_step"], elapsed * 1e3 / args.steps),
+                    kernels={k: v for k, v in kernels.items() if k != dom})
+                line["roofline_conv"] = dict(kernels[conv_dom], which=conv_dom)
+                if key in conv and conv[key][1] > 0:
+                    line["roofline"]["stage2_tflops"] = round(conv[key][2] / (conv[key][1] / 1e3) / 1e12, 2)
                 tot_ms = sum(v[1] for v in conv.values())
                 tot_fl = sum(v[2] for v in conv.values())
                 line["cnn"] = {"samples_per_s": round(int(r.n_samples) / max(tot_ms / args.steps / 1e3, 1e-9), 1),
@@ -1241,6 +1247,7 @@ def main():
                                "layers": conv_layer_table(conv, args.cnn_math, args.steps)}
             else:
                 line["roofline"] = track_roof
+                line["roofline_conv"] = None
             line["roofline_track"] = track_roof
         else:
             line["config"]["outputs"] = "components + label image + filtered image"

@@ -93,10 +93,19 @@ grid2 = max(grids, key=lambda g: sum(1 for gg, _ in rows("pmc_e2e_fetch", "FETCH
 grid2 = grids[0]
 conv_n = grid2 // (100 * 2 * 512)
 grid3 = 25 * 2 * 512 * conv_n
+BLOCK = "conv_block32_kernel"
+fused = bool(rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK))
 out["conv_stage2"] = section(
     "conv_bf3w_kernel<false, true, 1, 1, 2, true, false> (fp16x2, the default math), stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
-    "pmc_e2e_write", CONV, grid2, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.6,
+    "pmc_e2e_write", CONV, grid2, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * (2.25 if fused else 2.6),
+    "the second convolution of the stage's first block (the others run inside conv_block32_kernel): mid in, output out, the "
+    "fused shortcut's 16-channel input: N*160*160*64*4 B * 2.25" if fused else
     "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
+if fused:
+    out["conv_block"] = section(
+        "conv_block32_kernel (fp16x2), a stage-2 residual block of %d samples in one launch (two 3x3 convs 64->64 ch, 160x160)" % conv_n,
+        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK, None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.0,
+        "the block's input in, its output out: N*160*160*64*4 B * 2 (halo re-reads and the residual are L2 hits by design)")
 out["conv_stage3"] = section(
     "conv_bf3w_kernel<false, true, 2, 1, 2, true, false> (fp16x2), stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
     "pmc_e2e_write", CONV, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
