@@ -823,6 +823,9 @@ def _worker_ready(_):
     return os.getpid()
 
 
+_SPAWN_PATCH_LOCK = threading.Lock()
+
+
 class MetaPool:
     """`workers` processes that format metadata text (format_group); make() returns None when they cannot be started
     (the stage then stays in-process)."""
@@ -831,9 +834,28 @@ class MetaPool:
         import multiprocessing
         from concurrent.futures import ProcessPoolExecutor
 
+        import multiprocessing.spawn as mp_spawn
+
         self.workers = int(workers)
         self.pool = ProcessPoolExecutor(max_workers=self.workers, mp_context=multiprocessing.get_context("spawn"))
-        self.pids = sorted(set(self.pool.map(_worker_ready, range(4 * self.workers))))
+        # A spawned child normally re-imports the parent's __main__ -- i.e. runs the CALLER's script again, top to bottom,
+        # unless that script hides its body behind `if __name__ == "__main__"` (a directory run started from such a script
+        # ran once per worker more, concurrently).  The workers need nothing from __main__ (their functions live in this
+        # module), so the start-up data goes without it.  The executor starts all its workers at the first submit.
+        with _SPAWN_PATCH_LOCK:
+            orig = mp_spawn.get_preparation_data
+
+            def without_main(name):
+                d = orig(name)
+                d.pop("init_main_from_path", None)
+                d.pop("init_main_from_name", None)
+                return d
+
+            mp_spawn.get_preparation_data = without_main
+            try:
+                self.pids = sorted(set(self.pool.map(_worker_ready, range(4 * self.workers))))
+            finally:
+                mp_spawn.get_preparation_data = orig
 
     @staticmethod
     def make(workers=None):
