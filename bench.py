@@ -92,8 +92,11 @@ def conv_layer_table(conv, math, steps):
             continue
         cin_g, cout_g, st = k // 10000, (k % 10000) // 10, (k % 10) % 5
         one = (k % 10) >= 5
+        block = (k % 10) % 5 == 4  # conv_block32_kernel: a residual block's two stride-1 3x3 convolutions in one launch (fp16x2)
         if cin_g == 1:
             pipe, peak = "vector (direct kernel: 8 B in, 64 B out per pixel -- HBM-bound)", None
+        elif block:
+            pipe, peak = "fp16 MFMA, 3 products", MFMA_BF16_PEAK_TFLOPS / 3
         elif math == "f32" or one or st == 3:
             pipe, peak = "fp32 MFMA", MFMA_F32_PEAK_TFLOPS
         elif cin_g == 8:
@@ -102,7 +105,6 @@ def conv_layer_table(conv, math, steps):
             pr = PRODUCTS[math]
             pipe, peak = "%s MFMA, %d products" % ("fp16" if math == "fp16x2" else "bf16", pr), MFMA_BF16_PEAK_TFLOPS / pr
         tf = fl / (ms / 1e3) / 1e12
-        block = st == 4  # conv_block32_kernel: a residual block's two stride-1 3x3 convolutions in one launch
         if block:
             st = 1
         out[str(k)] = {"channels_per_group": [cin_g, cout_g], "stride": st,
@@ -1164,6 +1166,7 @@ def main():
                                    "sub_batches": args.sub_batches})
             key = 32 * 10000 + 32 * 10 + 1  # the stage-2 3x3 convolutions launched on their own (32 -> 32 channels per group, stride 1)
             key4 = 32 * 10000 + 32 * 10 + 4  # conv_block32_kernel: a stage-2 residual block (two of those convolutions) in one launch
+            key0 = 8 * 10000 + 32 * 10 + 4  # conv_block32_kernel<true>: the stage's first block (8 -> 32 -> 32 channels per group + the 1x1 shortcut)
             key3 = 64 * 10000 + 64 * 10 + 1  # the stage-3 ones: same FLOPs per sample, half the bytes
             if (key in conv and conv[key][1] > 0) or (key4 in conv and conv[key4][1] > 0):
                 bf3 = args.cnn_math in PRODUCTS
@@ -1217,6 +1220,12 @@ def main():
                         "groups 2, the tensor between them kept in LDS; FLOPs of both, the recomputed halo not counted)" % (side, side),
                         2.0, "the block's input in, its output out (the residual is the input: halo re-reads and the residual come from L2)",
                         convs=2)
+                if key0 in conv and conv[key0][1] > 0:
+                    kernels["conv_block0"] = leg(
+                        key0, "conv_block0",
+                        "conv_block32_kernel<true> (the first residual block of stage 2 in one launch: 3x3 conv 16->64 ch, 3x3 conv "
+                        "64->64 ch + the 1x1 shortcut 16->64, %dx%d, groups 2; FLOPs of the two 3x3 convolutions)" % (side, side),
+                        1.25, "the block's 16-channel input in, its 64-channel output out", convs=1.25)
                 if bf3 and key3 in conv:
                     kernels["conv_stage3"] = leg(
                         key3, "conv_stage3",

@@ -853,9 +853,16 @@ class MetaPool:
 
             mp_spawn.get_preparation_data = without_main
             try:
-                self.pids = sorted(set(self.pool.map(_worker_ready, range(4 * self.workers))))
+                # (not waited for: the processes are created inside submit; their imports -- about a second -- run
+                # beside the first decode batch, and jobs queue behind these)
+                self._ready = [self.pool.submit(_worker_ready, k) for k in range(4 * self.workers)]
             finally:
                 mp_spawn.get_preparation_data = orig
+
+    @property
+    def pids(self):
+        """process ids of the workers that answered (waits for their start-up)"""
+        return sorted({f.result() for f in self._ready})
 
     @staticmethod
     def make(workers=None):

@@ -71,7 +71,7 @@ struct cpx_handle {
   size_t cnn_arena_floats = 0;
   int* cnn_ovf = nullptr;                // CPX_CNN_MATH_FP16X2: the overflow word of the forward (or bare convolution) in flight
   bool planes_handover = true;           // CPX_CNN_PLANES_HANDOVER=0: fp16x2 keeps `mid` float32 (every layer splits its own input)
-  bool block_fusion = true;              // CPX_CNN_BLOCK_FUSION=0: fp16x2 runs the stage-2 blocks as two launches each (conv_block32_kernel off)
+  int block_fusion = 2;                  // CPX_CNN_BLOCK_FUSION: fp16x2 runs as ONE launch (conv_block32_kernel) 2 = every stage-2 block, 1 = all but the stage's first, 0 = none
   unsigned char* ir_scratch = nullptr;  // cpx_ir_detect: slots for frames whose run / component tables outgrow LDS
   size_t ir_scratch_bytes = 0;
   uint32_t* ir_bitmap = nullptr;
@@ -305,7 +305,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   if (const char* env = std::getenv("CPX_TRACK_PER_STEP")) h->track_per_step = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_FUSE_SHORTCUT")) h->fuse_shortcut = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_PLANES_HANDOVER")) h->planes_handover = std::atoi(env) != 0;
-  if (const char* env = std::getenv("CPX_CNN_BLOCK_FUSION")) h->block_fusion = std::atoi(env) != 0;
+  if (const char* env = std::getenv("CPX_CNN_BLOCK_FUSION")) h->block_fusion = std::min(std::max(std::atoi(env), 0), 2);
   if (const char* env = std::getenv("CPX_CNN_MATH")) {
     if (!std::strcmp(env, "f32")) h->cnn_math = CPX_CNN_MATH_F32;
     else if (!std::strcmp(env, "bf16x3")) h->cnn_math = CPX_CNN_MATH_BF16X3;
@@ -902,7 +902,8 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
     // rerun (it returns at once unless a scaled activation left fp16's range); every other layer as bf16x3
     const bool half = h->cnn_math == CPX_CNN_MATH_FP16X2 && cpx::conv_bf3_two_planes(a);
     const bool planes_out = h->cnn_math == CPX_CNN_MATH_FP16X2 && hf && hf->out_planes;
-    if (half || planes_out) {
+    const bool rerun = hf && hf->rerun_only;  // (any split-operand layer: the 8-channel one of a fused first block too)
+    if (half || planes_out || rerun) {
       const int rco = ensure_ovf_word(h);
       if (rco != CPX_OK) return rco;
       if (!(hf && hf->keep_flag)) CPX_HIP(h, hipMemsetAsync(h->cnn_ovf, 0, sizeof(int), h->stream));
@@ -923,7 +924,7 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
       cpx::launch_split_weights(a, h->bf3_scratch, h->stream);
       split_weights = h->bf3_scratch;
     }
-    if (half || planes_out) {
+    if (half || planes_out || rerun) {
       cpx::ConvArgs ah = a;
       if (half) {
         ah.planes = 2;
@@ -937,7 +938,7 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
         ah.out_planes = 1;
         ah.out_act_scale = hf->out_act_scale;
       }
-      rc = (hf && hf->rerun_only) ? 0 : cpx::launch_conv_bf3(ah, split_weights, h->stream);
+      rc = rerun ? 0 : cpx::launch_conv_bf3(ah, split_weights, h->stream);
       a.guard = h->cnn_ovf + (hf ? hf->word : 0);
       if (rc == 0) rc = cpx::launch_conv_bf3(a, split_weights, h->stream);
     } else {
@@ -1530,22 +1531,32 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
       // fp16x2: a block whose two convolutions are stride-1 with 32 channels per group (stage 2 past its first block) is
       // ONE launch -- `mid` stays in LDS (conv_block32_kernel); the two guarded three-plane launches follow as its rerun
       hf.rerun_only = false;
-      if (h->cnn_math == CPX_CNN_MATH_FP16X2 && h->block_fusion && s == 1 && c_in == f && b.in_scale && cnn->split_of(b.wa) &&
-          cnn->split_of(b.wb)) {
+      // ... the stage's first block too (8 input channels per group; its 1x1 shortcut inside the second convolution)
+      const bool first8 = d == 0 && s == 1 && c_in / p.groups == 8 && h->block_fusion >= 2 && h->fuse_shortcut;
+      if (h->cnn_math == CPX_CNN_MATH_FP16X2 && h->block_fusion && s == 1 && (c_in == f || first8) && b.in_scale && cnn->split_of(b.wa) &&
+          cnn->split_of(b.wb) && c_in % p.groups == 0 && f % p.groups == 0) {
         cpx::ConvArgs ca{}, cb{};
         ca.N = N; ca.H = hh; ca.W = ww; ca.Ho = hh; ca.Wo = ww; ca.Cin = f; ca.Cout = f; ca.groups = p.groups; ca.ksize = 3; ca.stride = 1;
         ca.relu = 1; ca.pad_top = ca.pad_left = 1; ca.planes = 2; ca.half = 1; ca.ovf = h->cnn_ovf + hf.word;
         cb = ca;
+        ca.Cin = c_in;
         ca.in = cur; ca.out = mid; ca.weights = b.wa; ca.in_scale = b.in_scale; ca.in_shift = b.in_shift;
         ca.out_scale = b.a_scale; ca.out_shift = b.a_shift;
         ca.act_scale = cnn->act_scale[st][d][0]; ca.act_unscale = 1.0f / ca.act_scale;
-        cb.in = mid; cb.out = act[flip ^ 1]; cb.weights = b.wb; cb.out_shift = b.bb; cb.residual = cur;
+        cb.in = mid; cb.out = act[flip ^ 1]; cb.weights = b.wb; cb.out_shift = b.bb;
+        if (first8) {
+          cb.sc_in = cur; cb.sc_w = p.shortcut_w[st]; cb.sc_bias = p.shortcut_b[st];
+          cb.sc_H = hh; cb.sc_W = ww; cb.sc_cin = c_in; cb.sc_stride = 1;
+        } else {
+          cb.residual = cur;
+        }
         cb.act_scale = cnn->act_scale[st][d][1]; cb.act_unscale = 1.0f / cb.act_scale;
-        if (f % p.groups == 0 && cpx::conv_block32_supported(ca, cb)) {
+        if (cpx::conv_block32_supported(ca, cb)) {
           cpx_handle::ConvEv ev{};
           if (h->conv_timing) {
-            ev.key = 32 * 10000 + 32 * 10 + 4;  // ("stride 4": the fused block; both convolutions' products)
-            ev.flops = 2 * 2.0 * N * hh * ww * f * (double)(f / p.groups) * 9;
+            // ("stride 4": a fused block; both convolutions' products, the shortcut's not counted)
+            ev.key = (c_in / p.groups) * 10000 + 32 * 10 + 4;
+            ev.flops = 2.0 * N * hh * ww * f * ((double)(c_in / p.groups) + (double)(f / p.groups)) * 9;
             if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess)
               return fail(h, CPX_ERR_HIP, "cpx_cnn_forward: event creation failed");
             CPX_HIP(h, hipEventRecord(ev.e0, h->stream));

@@ -1318,26 +1318,41 @@ constexpr int B_PW = 20, B_NPX = 400;
 constexpr int B_NPXP = 402;  // 402 * 32 B = 64 mod 128 (see W_NPXP)
 constexpr int B_R0 = 2 * 2 * B_NPXP * 2;    // entries of the patch region (the mid image, 2 * 2 * W_NPXP * 2, fits inside)
 constexpr int B_WIMG = 3 * 2 * 3 * 4 * 32;  // entries of one convolution's fp16 image of one group
+// C8: the stage's FIRST block -- its first convolution takes 8 input channels per group (16 -> 64 channels), its second one adds
+// the 1x1 shortcut of the block's input instead of a residual.  What changes: the patch is one 16-byte entry per pixel and
+// plane ([plane][pixel], 8 channels); a K = 32 step of the first convolution pairs FOUR TAPS (lane quarter q of step t reads tap
+// 4 t + q: three steps for the nine taps, the last three quarters of the third read a zero entry; weight image
+// [t][plane][quarter][column], split_weights8h_kernel); the second convolution's accumulators start at zero and take the
+// shortcut on v_mfma_f32_16x16x4_f32 before the epilogue, as conv_bf3w_kernel's do.
+constexpr int B8_NPXP = B_NPX + 2;             // entries per plane of the 8-channel patch (a region of its own): 400 pixels, one zero entry, one spare
+constexpr int B8_WIMG = 3 * 2 * 4 * 32;        // entries of the first convolution's fp16 image of one group (C8)
+template <bool C8>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_block32_kernel(ConvArgs a, ConvArgs b, const uint4* __restrict__ wa, const uint4* __restrict__ wb, TileDiv td) {
   if (*a.ovf != 0) return;  // (the block's guarded three-plane launches follow)
+  constexpr int WA_IMG = C8 ? B8_WIMG : B_WIMG;
+  constexpr int CING = C8 ? 8 : 32;  // input channels per group of the first convolution
   constexpr int CT = 512;
   constexpr int W_WROW = 2 * 3 * 4 * 32;
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   uint4* s_r0 = lds4;
   uint4* s_wa = lds4 + B_R0;
-  uint4* s_wb = s_wa + B_WIMG;
+  uint4* s_wb = s_wa + WA_IMG;
   f32x4* s_bn = reinterpret_cast<f32x4*>(s_wb + B_WIMG);
+  // the patch: the region mid takes over later -- or (C8: 13 KB, and a zero entry that must survive) a region of its own
+  uint4* s_px = C8 ? reinterpret_cast<uint4*>(s_bn) + 16 : s_r0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
   const int g = blockIdx.y;
-  const int C = a.Cin;
+  const int C = b.Cout;    // channels of mid and of the output (the block's input has a.Cin: the same unless C8)
+  const int CI = a.Cin;
   for (int i = tid; i < B_WIMG; i += CT) {
-    reinterpret_cast<u32x4*>(s_wa)[i] = reinterpret_cast<const u32x4*>(wa)[g * B_WIMG + i];
+    if (i < WA_IMG) reinterpret_cast<u32x4*>(s_wa)[i] = reinterpret_cast<const u32x4*>(wa)[g * WA_IMG + i];
     reinterpret_cast<u32x4*>(s_wb)[i] = reinterpret_cast<const u32x4*>(wb)[g * B_WIMG + i];
   }
-  if (tid < 32) {  // relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly
-    reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g * 32 + tid] * a.act_scale;
-    reinterpret_cast<float*>(s_bn)[32 + tid] = a.in_shift[g * 32 + tid] * a.act_scale;
+  if (tid < CING) {  // relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly
+    reinterpret_cast<float*>(s_bn)[tid] = a.in_scale[g * CING + tid] * a.act_scale;
+    reinterpret_cast<float*>(s_bn)[CING + tid] = a.in_shift[g * CING + tid] * a.act_scale;
   }
+  if (C8 && tid < 2) reinterpret_cast<u32x4*>(s_px)[tid * B8_NPXP + B_NPX] = u32x4{0u, 0u, 0u, 0u};  // the zero entry of either plane
   // tiles: every XCD walks its own contiguous eighth of the tile space (the workgroups of a launch go round-robin over
   // the XCDs), the workgroups of an XCD side by side in it: neighbours' halos meet in that XCD's L2
   const int per_xcd = (td.total + 7) >> 3;
@@ -1351,22 +1366,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     oy0 = (tile - qd * td.tiles_y) * W_TH;
     n = qd;
   };
-  constexpr int NITEM = B_NPX * 8;
-  constexpr int NP = (NITEM + CT - 1) / CT;  // 7 (the seventh for threads 0..127)
+  constexpr int PIECES = CING / 4;           // 16-byte pieces (4 channels) of a patch pixel
+  constexpr int NITEM = B_NPX * PIECES;
+  constexpr int NP = (NITEM + CT - 1) / CT;  // 7 (the seventh for threads 0..127); C8: 2 (the second for threads 0..287)
+  constexpr int PSH = C8 ? 1 : 3, PPI = CT >> PSH;  // item tid + 512 i = pixel (tid >> PSH) + PPI i, piece tid & (PIECES - 1)
   u32x4 pre_p[NP];
   auto issue_patch = [&]() __attribute__((always_inline)) {  // global -> registers: the 20 x 20 patch of tile (n, oy0, ox0), clamped
-    int t8 = tid >> 3;
+    int t8 = tid >> PSH;
     asm volatile("" : "+v"(t8));
-    int q8 = tid & 7;
+    int q8 = tid & (PIECES - 1);
     asm volatile("" : "+v"(q8));
-    const float* in_n = a.in + (size_t)n * a.H * a.W * C;
-    const unsigned coff = (unsigned)(g * 32 + 4 * q8);
+    const float* in_n = a.in + (size_t)n * a.H * a.W * CI;
+    const unsigned coff = (unsigned)(g * CING + 4 * q8);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int px = min(t8 + 64 * i, B_NPX - 1);
+      const int px = min(t8 + PPI * i, B_NPX - 1);
       const int py = (int)(__umul24((unsigned)px, 3277u) >> 16), pxx = __mul24(py, -B_PW) + px;  // px / 20 for px < 400
       const int cy = min(max(oy0 - 2 + py, 0), a.H - 1), cx = min(max(ox0 - 2 + pxx, 0), a.W - 1);
-      pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, C) + coff) << 2));
+      pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, CI) + coff) << 2));
     }
   };
   int t = blockIdx.x;
@@ -1385,13 +1402,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (a.out_scale) os_a[ct] *= *reinterpret_cast<const f32x4*>(a.out_scale + ch);
     ob_a[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (a.out_shift) ob_a[ct] = *reinterpret_cast<const f32x4*>(a.out_shift + ch) * b.act_scale;
-    rs_b[ct] = *reinterpret_cast<const f32x4*>(b.w_scale + ch) * b.act_scale;
+    rs_b[ct] = *reinterpret_cast<const f32x4*>(b.w_scale + ch) * b.act_scale;  // (the residual's scale; C8: the shortcut weights')
     os_b[ct] = *reinterpret_cast<const f32x4*>(b.w_unscale + ch) * b.act_unscale;
     ob_b[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (b.out_shift) ob_b[ct] = *reinterpret_cast<const f32x4*>(b.out_shift + ch);
+    if (C8 && b.sc_bias) ob_b[ct] += *reinterpret_cast<const f32x4*>(b.sc_bias + ch);
   }
   __syncthreads();  // weights and BatchNorm parameters are in LDS
-  const f32x4 psc = s_bn[tid & 7], psh = s_bn[8 + (tid & 7)];
+  const f32x4 psc = s_bn[tid & (PIECES - 1)], psh = s_bn[PIECES + (tid & (PIECES - 1))];
   // out of fp16's range = a high plane that came out infinite.  Every staged value is >= 0 (ReLU), so fp16 bit patterns order
   // as unsigned halves: the running maximum of the high planes, two packed halves per instruction
   unsigned hmax = 0u;
@@ -1406,7 +1424,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (!interior) {
       asm volatile("");
-      const int px = (tid >> 3) + 64 * i;
+      const int px = (tid >> PSH) + PPI * i;
       const int py = (int)(__umul24((unsigned)px, 3277u) >> 16), pxx = __mul24(py, -B_PW) + px;
       const bool inside = (unsigned)(py0 + py) < (unsigned)a.H && (unsigned)(px0 + pxx) < (unsigned)a.W;
 #pragma unroll
@@ -1419,10 +1437,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     pre_p[i] = u32x4{h0, h1, l0, l1};
   };
   auto commit_patch = [&]() __attribute__((always_inline)) {  // converted registers -> LDS
-    int t8 = tid >> 3;
+    int t8 = tid >> PSH;
     asm volatile("" : "+v"(t8));
-    int q8 = tid & 7;
+    int q8 = tid & (PIECES - 1);
     asm volatile("" : "+v"(q8));
+    if (C8) {  // [plane][pixel] of 16-byte entries: piece 0 / 1 = the entry's low / high 8 bytes
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (i * CT + CT <= NITEM || tid < NITEM - i * CT) {
+          uint2* sp2 = reinterpret_cast<uint2*>(s_px) + (t8 + PPI * i) * 2 + q8;
+          sp2[0] = make_uint2(pre_p[i][0], pre_p[i][1]);
+          sp2[B8_NPXP * 2] = make_uint2(pre_p[i][2], pre_p[i][3]);
+        }
+      }
+      return;
+    }
     const int st_e2 = (int)(__umul24((unsigned)(q8 >> 2), (unsigned)B_NPXP) + (unsigned)t8) * 4 + (q8 & 3);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -1448,18 +1477,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 acc[2][2];
     unsigned opix[2];
     bool ovalid[2];
+    unsigned spix[2];  // (C8) element offsets of the lane's two pixels in the block's input, channel g * 8 + q: the shortcut's operand
     {
-      const float* res_n = b.residual + (size_t)n_cur * a.H * a.W * C;
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
         const int oy = oy_cur + 2 * wave + pt, ox = ox_cur + i16;
         ovalid[pt] = oy < a.H && ox < a.W;
         opix[pt] = pix_off(min(oy, a.H - 1), min(ox, a.W - 1), a.W, C) + (unsigned)ch_l;
+        spix[pt] = pix_off(min(oy, a.H - 1), min(ox, a.W - 1), a.W, CI) + (unsigned)(g * CING + q);
       }
+      if (C8) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 16u * ct) << 2));
+          for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      } else {
+        const float* res_n = b.residual + (size_t)n_cur * a.H * a.W * C;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 16u * ct) << 2));
+      }
     }
     t += gridDim.x;
     const bool more = t < 8 * per_xcd && tile_of(t) < td.total;  // (a workgroup's tiles ascend within its XCD's eighth: the first missing one ends it)
@@ -1476,12 +1514,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 3; ++j) {
       const int p = min(16 * (wave + 8 * j) + i16, W_NPX - 1);
       const int my = (int)(__umul24((unsigned)p, 3641u) >> 16), mx = p - my * W_PW;  // p / 18 for p < 324
-      abase1[j] = ((q >> 1) * B_NPXP + my * B_PW + mx) * 2 + (q & 1);
+      abase1[j] = C8 ? my * B_PW + mx : ((q >> 1) * B_NPXP + my * B_PW + mx) * 2 + (q & 1);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc1[j][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     const int b_base = q * 32 + i16;
     const bool third = wave < 5;  // (uniform) group wave + 16 exists
+    if constexpr (C8) {
+#pragma unroll
+      for (int t4 = 0; t4 < 3; ++t4) {
+        // this lane quarter's tap of the step: 4 t4 + q, at patch offset ky * 20 + kx; beyond the ninth tap: the zero entry
+        const int tap = 4 * t4 + q;
+        const int ky = (tap * 11) >> 5;  // tap / 3 for tap < 12
+        const int toff = ky * B_PW + (tap - 3 * ky);
+        u32x4 wv[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_wa[(t4 * 2 + p) * 128 + b_base + 16 * ct]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (j < 2 || third) {
+            const int e = tap < 9 ? abase1[j] + toff : B_NPX;
+            u32x4 xv[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) xv[p] = __builtin_bit_cast(u32x4, s_px[p * B8_NPXP + e]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              acc1[j][ct] = mfma16<true>(wv[ct][1], xv[0], acc1[j][ct]);
+              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[1], acc1[j][ct]);
+              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[0], acc1[j][ct]);
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -1506,6 +1573,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
         }
       }
+    }
     }
     __syncthreads();  // every wave has read its patch fragments: the region becomes mid
     // ---- mid = relu(acc * a_scale + a_shift), times the second convolution's range scale, as its fp16 planes in LDS;
@@ -1537,7 +1605,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) acc[ct][pt] *= rs_b[ct];  // the accumulators hold act_scale * w_scale[channel] times the sum: so must the residual
+      for (int pt = 0; pt < 2; ++pt)
+        if (!C8) acc[ct][pt] *= rs_b[ct];  // the accumulators hold act_scale * w_scale[channel] times the sum: so must the residual
     __syncthreads();
     // ---- second convolution: conv_bf3w_kernel's loop on the mid image; between its taps the next tile's patch (landed
     //      during the first convolution) takes its prologue and split, one item per tap: vector work under the products ----
@@ -1565,6 +1634,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
           if (r * 3 + kx < NP && more) convert_item(r * 3 + kx, oy0 - 2, ox0 - 2, interior_next);
         }
+      }
+    }
+    if constexpr (C8) {
+      // ---- the block's 1x1 shortcut (conv_bf3w_kernel's): A = weights [column][k] times their column's scale, B = pixels ----
+      const float* sc_n = b.sc_in + (size_t)n_cur * a.H * a.W * CI;
+      const float* wsc = b.sc_w + ((size_t)g * CING + q) * 32 + i16;
+      float ss[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) ss[ct] = b.w_scale[g * 32 + 16 * ct + i16] * b.act_scale;
+#pragma unroll
+      for (int k4 = 0; k4 < CING; k4 += 4) {
+        float xs[2], ws[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) xs[pt] = *at_off(sc_n, (spix[pt] + (unsigned)k4) << 2);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) ws[ct] = wsc[(size_t)k4 * 32 + 16 * ct] * ss[ct];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[ct], xs[pt], acc[ct][pt], 0, 0, 0);
       }
     }
     // ---- epilogue: unscale, bias, ReLU, one 16-byte store per accumulator tile ----
@@ -1668,6 +1757,30 @@ __global__ __launch_bounds__(256) void weight_scales_kernel(const float* __restr
   const int kw = min(max(4 - e, -100), 100);
   wscale[idx] = ldexpf(1.0f, kw);
   wunscale[idx] = ldexpf(1.0f, -kw);
+}
+
+// the 8-channel layer's fp16 image for conv_block32_kernel<true>: packed float32 weights [g][9][8][32] ->
+// [g][step t][plane][quarter q][column] of 16-byte entries = the 8 channels of tap 4 t + q (zero beyond the ninth tap),
+// times wscale[output channel]
+__global__ __launch_bounds__(256) void split_weights8h_kernel(const float* __restrict__ w, uint4* __restrict__ out, int groups,
+                                                              const float* __restrict__ wscale) {
+  const size_t total = (size_t)groups * 3 * 4 * 32;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(idx & 31), qq = (int)((idx >> 5) & 3), t = (int)((idx >> 7) % 3), g = (int)(idx / 384);
+    const int tap = 4 * t + qq;
+    const float ws = wscale[g * 32 + col];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tap < 9 ? w[(((size_t)g * 9 + tap) * 8 + j) * 32 + col] * ws : 0.0f;
+    uint4 p0, p1;
+    split_pair2_h(v[0], v[1], p0.x, p1.x);
+    split_pair2_h(v[2], v[3], p0.y, p1.y);
+    split_pair2_h(v[4], v[5], p0.z, p1.z);
+    split_pair2_h(v[6], v[7], p0.w, p1.w);
+    const size_t base = (size_t)g * B8_WIMG;
+    out[base + (size_t)(t * 2 + 0) * 128 + qq * 32 + col] = p0;
+    out[base + (size_t)(t * 2 + 1) * 128 + qq * 32 + col] = p1;
+  }
 }
 
 // planes = 2 (CPX_CNN_MATH_BF16X2): [g][chunk][2][9][2][cout_g], hi / lo rounded to nearest
@@ -1935,8 +2048,11 @@ static bool flat_layer(const ConvArgs& a) {
 }
 // the per-channel weight scales of the fp16 image and their inverses: 2 x Cout floats behind the images (16-byte aligned)
 static size_t scales_bytes(const ConvArgs& a) { return ((size_t)2 * a.Cout * sizeof(float) + 15) / 16 * 16; }
+// the 8-channel layer: its three-plane tap-paired image, then the fp16 tap-quad image of conv_block32_kernel<true> and its scales
+static size_t c8_image3_bytes(const ConvArgs& a) { return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16; }
+static size_t c8_half_bytes(const ConvArgs& a) { return (size_t)a.groups * B8_WIMG * 16; }
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
-  if (bf3_c8(a)) return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16;
+  if (bf3_c8(a)) return c8_image3_bytes(a) + c8_half_bytes(a) + scales_bytes(a);
   // the images of the three math modes one after the other: three bf16 planes, two bf16 planes, two fp16 planes, scales
   if (bf3w_layer(a)) return bf3w_image3_bytes(a) + 2 * bf3w_image2_bytes(a) + scales_bytes(a);
   return image3_bytes(a) + (flat_layer(a) ? 2 * (image3_bytes(a) / 3 * 2) + scales_bytes(a) : 0);
@@ -1954,9 +2070,11 @@ bool conv_bf3_can_store_planes(const ConvArgs& a) {
 bool conv_bf3_can_load_planes(const ConvArgs& a) { return bf3w_layer(a); }
 // where the fp16 image and its scales lie inside a two-plane layer's weight images
 static size_t half_image_offset(const ConvArgs& a) {
+  if (bf3_c8(a)) return c8_image3_bytes(a);
   return bf3w_layer(a) ? bf3w_image3_bytes(a) + bf3w_image2_bytes(a) : image3_bytes(a) + image3_bytes(a) / 3 * 2;
 }
 static size_t scales_offset(const ConvArgs& a) {
+  if (bf3_c8(a)) return c8_image3_bytes(a) + c8_half_bytes(a);
   return bf3w_layer(a) ? bf3w_image3_bytes(a) + 2 * bf3w_image2_bytes(a) : image3_bytes(a) + 2 * (image3_bytes(a) / 3 * 2);
 }
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
@@ -1965,6 +2083,11 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
     const size_t total8 = (size_t)a.groups * 10 * cout_g;
     hipLaunchKernelGGL(split_weights8_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, a.weights,
                        reinterpret_cast<uint4*>(wimg), a.groups, cout_g);
+    float* ws = reinterpret_cast<float*>(reinterpret_cast<char*>(wimg) + scales_offset(a));
+    hipLaunchKernelGGL(weight_scales_kernel, dim3((unsigned)((a.Cout + 255) / 256)), dim3(256), 0, s, a.weights, ws, ws + a.Cout,
+                       a.groups, 9 * cin_g, cout_g);
+    hipLaunchKernelGGL(split_weights8h_kernel, dim3((unsigned)((a.groups * 384 + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg) + half_image_offset(a) / 16, a.groups, ws);
     return;
   }
   if (bf3w_layer(a)) {
@@ -2044,11 +2167,16 @@ int launch_conv_bf3(const ConvArgs& a_in, const void* wimg, hipStream_t s) {
 // BatchNorm + ReLU epilogue), `b` the second (bias, residual = the block's input, ReLU); fp16x2 with both act_scale set
 bool conv_block32_supported(const ConvArgs& a, const ConvArgs& b) {
   const auto plain = [](const ConvArgs& c) {
-    return c.ksize == 3 && c.stride == 1 && c.Cin == c.Cout && c.Cin / c.groups == 32 && c.relu && c.pad_top == 1 && c.pad_left == 1 &&
-           c.sc_in == nullptr && !c.out_planes && !c.in_planes;
+    return c.ksize == 3 && c.stride == 1 && c.Cout / c.groups == 32 && c.relu && c.pad_top == 1 && c.pad_left == 1 && !c.out_planes &&
+           !c.in_planes;
   };
-  return plain(a) && plain(b) && a.in_scale && a.in_shift && !a.residual && !b.in_scale && !b.out_scale && b.residual == a.in &&
-         a.Cin == b.Cin && a.groups == b.groups && a.H == b.H && a.W == b.W && a.N == b.N && a.ovf != nullptr;
+  if (!(plain(a) && plain(b) && a.in_scale && a.in_shift && !a.residual && !a.sc_in && !b.in_scale && !b.out_scale &&
+        a.Cout == b.Cin && b.Cin == b.Cout && a.groups == b.groups && a.H == b.H && a.W == b.W && a.N == b.N && a.ovf != nullptr))
+    return false;
+  if (a.Cin / a.groups == 8)  // the stage's first block: the second convolution adds the 1x1 shortcut of the block's input
+    return b.residual == nullptr && b.sc_in == a.in && b.sc_w != nullptr && b.sc_cin == a.Cin && b.sc_stride == 1 && b.sc_H == a.H &&
+           b.sc_W == a.W;
+  return a.Cin == a.Cout && b.residual == a.in && b.sc_in == nullptr;
 }
 int launch_conv_block32(const ConvArgs& a_in, const ConvArgs& b_in, const void* wimg_a, const void* wimg_b, hipStream_t s) {
   ConvArgs a = a_in, b = b_in;
@@ -2070,9 +2198,12 @@ int launch_conv_block32(const ConvArgs& a_in, const ConvArgs& b_in, const void* 
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
   td.total = (int)tiles;
-  const size_t lds = (size_t)(B_R0 + 2 * B_WIMG) * 16 + 256;
-  static bool lds_ready[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel), lds_ready, 160 * 1024 - 1024)) return -1;
+  const bool c8 = a.Cin / a.groups == 8;
+  const size_t lds = c8 ? (size_t)(B_R0 + B8_WIMG + B_WIMG) * 16 + 256 + (size_t)2 * B8_NPXP * 16 : (size_t)(B_R0 + 2 * B_WIMG) * 16 + 256;
+  static bool lds_ready[64], lds_ready8[64];
+  if (c8 ? !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<true>), lds_ready8, 160 * 1024 - 1024)
+         : !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<false>), lds_ready, 160 * 1024 - 1024))
+    return -1;
   // one workgroup per CU (125 KB of LDS), shared among the groups; a multiple of eight per group so that blockIdx.x & 7 is the XCD
   static int grid_x[64];
   int dev = 0;
@@ -2085,7 +2216,8 @@ int launch_conv_block32(const ConvArgs& a_in, const ConvArgs& b_in, const void* 
   int gx = std::max(8, grid_x[dev] / a.groups / 8 * 8);
   if (const char* e = std::getenv("CPX_BLOCK32_GRID")) gx = std::max(8, std::atoi(e) / 8 * 8);
   gx = (int)std::min<long long>(gx, (tiles + 7) / 8 * 8);
-  hipLaunchKernelGGL(conv_block32_kernel, dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
+  if (c8) hipLaunchKernelGGL(conv_block32_kernel<true>, dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
+  else hipLaunchKernelGGL(conv_block32_kernel<false>, dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
   return 0;
 }
 

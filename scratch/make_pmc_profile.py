@@ -88,27 +88,35 @@ out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -
 CONV = "conv_bf3w_kernel<"
 # stage 2 (64->64 ch, 160x160: 100 tiles per sample; instantiation <false, false, 1>) and stage 3 (128->128 ch, 80x80:
 # 25 tiles, both 32-column slices in one workgroup; <false, true, 2>): 100 vs 25 workgroups per sample and group
-grids = sorted({g for g, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV)}, reverse=True)
-grid2 = max(grids, key=lambda g: sum(1 for gg, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV) if gg == g) * (g in grids[:2]) + g * 1e-12)
-grid2 = grids[0]
-conv_n = grid2 // (100 * 2 * 512)
-grid3 = 25 * 2 * 512 * conv_n
+# samples per launch from the stage-3 instantiation's grid (25 tiles x 2 groups x 512 threads per sample); the stage-2
+# instantiation only launches when the stage's first block is not fused (CPX_CNN_BLOCK_FUSION < 2)
+CONV3, CONV2 = CONV + "false, true, 2,", CONV + "false, true, 1,"
+grid3 = max(g for g, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV3))
+conv_n = grid3 // (25 * 2 * 512)
+grid2 = 100 * 2 * 512 * conv_n
+has2 = any(g == grid2 for g, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV2))
 BLOCK = "conv_block32_kernel"
 fused = bool(rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK))
-out["conv_stage2"] = section(
-    "conv_bf3w_kernel<false, true, 1, 1, 2, true, false> (fp16x2, the default math), stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
-    "pmc_e2e_write", CONV, grid2, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * (2.25 if fused else 2.6),
-    "the second convolution of the stage's first block (the others run inside conv_block32_kernel): mid in, output out, the "
-    "fused shortcut's 16-channel input: N*160*160*64*4 B * 2.25" if fused else
-    "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
+if has2:
+  out["conv_stage2"] = section(
+      "conv_bf3w_kernel<false, true, 1, 1, 2, true, false> (fp16x2, the default math), stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
+      "pmc_e2e_write", CONV2, grid2, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * (2.25 if fused else 2.6),
+      "the second convolution of the stage's first block (the others run inside conv_block32_kernel): mid in, output out, the "
+      "fused shortcut's 16-channel input: N*160*160*64*4 B * 2.25" if fused else
+      "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
+if rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK + "<true>"):
+    out["conv_block0"] = section(
+        "conv_block32_kernel<true> (fp16x2), the first residual block of stage 2 of %d samples in one launch" % conv_n,
+        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK + "<true>", None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 1.25,
+        "the block's 16-channel input in, its 64-channel output out: N*160*160*64*4 B * 1.25")
 if fused:
     out["conv_block"] = section(
         "conv_block32_kernel (fp16x2), a stage-2 residual block of %d samples in one launch (two 3x3 convs 64->64 ch, 160x160)" % conv_n,
-        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK, None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.0,
+        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK + "<false>", None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.0,
         "the block's input in, its output out: N*160*160*64*4 B * 2 (halo re-reads and the residual are L2 hits by design)")
 out["conv_stage3"] = section(
     "conv_bf3w_kernel<false, true, 2, 1, 2, true, false> (fp16x2), stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
-    "pmc_e2e_write", CONV, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
+    "pmc_e2e_write", CONV3, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
     "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
 # one launch walks 1024 clips through their 270 frames (bench.py defaults): clip-frames per launch
 FRAMES = int(os.environ.get("CPX_BENCH_FRAMES", "270"))
