@@ -1408,7 +1408,7 @@ void cpx_nlm_kernel(TrackArgs a, int t) {
     const int cc = bx + coff;
     // (rows past the band's last one feed only outputs that are never stored; the array has BH spare rows for them)
     const uint16_t* hr0 = Hh + (cc & ~1) + __umul24((u32)rbase, (u32)HS);
-    if constexpr (WC == 160 && BH == 10 && NLM_ASM_HV) {  // sixteen rows off one address register (row stride 352 bytes)
+    if constexpr (WC == 160 && BH == 10 && NLM_ASM_HV) {  // sixteen rows off one address register (row stride 2 HS = 368 bytes: HS = W + 24 uint16 entries)
       constexpr int RS = 2 * ((160 + 24 + 7) & ~7);
       const u32 ad = lds_addr(hr0);
       if (coff & 1) {  // the pair straddles two aligned words (bx is even: the parity is the offset's)
