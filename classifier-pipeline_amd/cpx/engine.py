@@ -24,7 +24,12 @@ class TrackBatchResult:
 
     The device tensors come from torch's allocator while the kernels that fill them run on the engine's stream:
     hold the result until engine.synchronize() (every host accessor here does that first). A result dropped
-    earlier hands its memory back while it is still being written."""
+    earlier hands its memory back while it is still being written.  (Tensor.record_stream on the handle's stream would
+    move that duty to the allocator -- tried in round 5 and withdrawn: the allocator records an event on the recorded
+    stream when the tensor is freed, and a handle's stream dies with the handle (grown / sibling engines are closed
+    while results of theirs are still referenced): the free then touches a destroyed HIP stream.  Code that needs
+    allocator-enforced lifetimes runs under `with torch.cuda.stream(engine.torch_stream())`, as cpx.pipeline and the
+    bulk lanes do.)"""
 
     def __init__(self, engine, total, cap, comps, info, labels, filtered, background):
         self.engine, self.total, self.cap = engine, total, cap
