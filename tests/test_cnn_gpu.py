@@ -242,6 +242,41 @@ def test_fp16x2_network_overflow_is_loud_and_correct(engine):
     engine.set_cnn_math(engine.DEFAULT_CNN_MATH)
 
 
+@pytest.mark.parametrize("scale", [8.0, 30.0, 100.0, 300.0, 1000.0])
+def test_fp16x2_partial_overflow_is_correct(engine, scale):
+    """Inputs 8 ... 1000 times the range the BatchNorm statistics were fitted to: depending on the factor none, some or all
+    of the blocks leave fp16's range (one overflow word per block; the fused stage-2 blocks rerun as their two guarded
+    three-plane launches).  Whatever mix of fp16 and rerun blocks a forward ends up with, its logits are the exact mode's
+    to float32 accuracy, and the forward says whether anything was rerun."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(515)
+    x = rng.uniform(0, 255, size=(2, 160, 160, 2)).astype(np.float32)
+    w = co.calibrate_bn(wr.random_weights(17, seed=21), x)
+    xs = torch.from_numpy(x * np.float32(scale)).to(engine.device)
+    engine.set_cnn_math("bf16x3")
+    net = wr.WRResNetDevice(engine, w, 17)
+    want, _ = net.forward(xs)
+    want = want.clone()
+    engine.set_cnn_math("fp16x2")
+    n0 = engine.cnn_overflow_forwards(reset=True)
+    got, _ = net.forward(xs)
+    reran = engine.cnn_last_overflow()
+    assert engine.cnn_overflow_forwards(reset=True) == (1 if reran else 0)
+    assert torch.isfinite(got).all()
+    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= tol, (scale, reran, float((got - want).abs().max()), tol)
+    if scale >= 1000.0:
+        assert reran
+    print("scale", scale, "rerun", reran)
+    net.close()
+    engine.set_cnn_math(engine.DEFAULT_CNN_MATH)
+    del n0
+
+
 @pytest.mark.parametrize("fs,n", [(32, 3), (64, 1)])
 def test_wrresnet_logits_match_oracle(engine, math, fs, n):
     import torch
