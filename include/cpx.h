@@ -612,9 +612,12 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* desc);
  *                        power of two a network derives from its BatchNorm parameters
  *                        (cpx_cnn_set_activation_bounds; 1 for a bare cpx_conv2d).  A scaled activation beyond fp16's
  *                        largest finite value never saturates silently: the kernel raises a device-side word and
- *                        the layer -- and, inside cpx_cnn_forward, every later two-plane layer of that forward -- is
+ *                        the layer -- inside cpx_cnn_forward: the rest of its residual BLOCK, one word per block -- is
  *                        run again by the BF16X3 kernel, which is launched behind every fp16 launch and returns at
- *                        once while the word is clear (cpx_cnn_last_overflow reads the word).
+ *                        once while the word is clear (cpx_cnn_last_overflow reads whether any block did).
+ *                        Inside cpx_cnn_forward the residual blocks whose convolutions are stride 1 with 32 output
+ *                        channels per group (stage 2 of WR-ResNet-22-4) run as ONE launch each, the tensor between
+ *                        their two convolutions kept on chip (environment CPX_CNN_BLOCK_FUSION=0|1|2, default 2).
  *                        Every other layer as BF16X3.
  * The default can be preset with the environment variable CPX_CNN_MATH=f32|bf16x3|bf16x2|fp16x2 (read by cpx_create). */
 #define CPX_CNN_MATH_F32 0
@@ -702,8 +705,9 @@ void cpx_cnn_destroy(cpx_cnn* cnn);
 /* CPX_CNN_MATH_FP16X2: an upper bound of the ACTIVATED input of each 3x3 convolution of the blocks, in launch order
  * ([stage][block][branch2a, branch2b]: n = 3 * blocks_per_stage * 2 values) -- e.g. max over channels of
  * |beta| + 64 |gamma| of the BatchNorm in front of it (the folded scale / shift the parameter struct carries no longer
- * say).  The network multiplies that input by the largest power of two (<= 2^14) that keeps the bound at or below 2^15
- * before the fp16 split, so that small activations keep their low plane's bits; a bound that turns out too small costs
+ * say).  The network multiplies that input by the largest power of two (<= 2^14) that keeps the bound at or below 2^12
+ * (sixteen-fold headroom below fp16's largest value: a bound from statistics is a guess) before the fp16 split, so that
+ * small activations keep their low plane's bits; a bound that turns out too small costs
  * time (the overflow rerun), never correctness.  Without this call the scale is 1. */
 int cpx_cnn_set_activation_bounds(cpx_cnn* cnn, const float* bounds, int n);
 /* in_dev float32 [N, H, W, in_channels] (NHWC, values 0..255) -> logits_dev [N, n_labels] and, when not NULL,
