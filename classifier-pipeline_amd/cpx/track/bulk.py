@@ -864,6 +864,11 @@ class MetaPool:
         """process ids of the workers that answered (waits for their start-up)"""
         return sorted({f.result() for f in self._ready})
 
+    def usable(self):
+        """False once a worker's start-up is known to have failed (import error, killed process): the caller then
+        formats in-process instead of sending every group to a pool that answers with exceptions."""
+        return not any(f.done() and (f.cancelled() or f.exception() is not None) for f in self._ready)
+
     @staticmethod
     def make(workers=None):
         if workers is None:
@@ -1153,7 +1158,7 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
                    paths=[paths[i] for i in group.files], offs=np.asarray(offs), clips=[clip_view(c) for c in clips],
                    existing=existing, indent=indent, classify=bool(classifiers), model_meta=model_meta,
                    tracking_time=(time.time() - ctx["t0"]) / max(ctx["n_ok"], 1))
-        if meta_pool is not None:   # formatted by a worker process; collected when the batch closes
+        if meta_pool is not None and meta_pool.usable():   # formatted by a worker process; collected when the batch closes
             ctx["futures"].append(meta_pool.submit(config_blob, job))
             tracker.timings["host_submit_s"] = tracker.timings.get("host_submit_s", 0.0) + time.time() - th
             return
