@@ -1371,20 +1371,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int NP = (NITEM + CT - 1) / CT;  // 7 (the seventh for threads 0..127); C8: 2 (the second for threads 0..287)
   constexpr int PSH = C8 ? 1 : 3, PPI = CT >> PSH;  // item tid + 512 i = pixel (tid >> PSH) + PPI i, piece tid & (PIECES - 1)
   u32x4 pre_p[NP];
-  auto issue_patch = [&]() __attribute__((always_inline)) {  // global -> registers: the 20 x 20 patch of tile (n, oy0, ox0), clamped
+  // global -> registers: item i of the 20 x 20 patch of tile (n, oy0, ox0), clamped
+  auto issue_item = [&](const int i) __attribute__((always_inline)) {
     int t8 = tid >> PSH;
     asm volatile("" : "+v"(t8));
     int q8 = tid & (PIECES - 1);
     asm volatile("" : "+v"(q8));
     const float* in_n = a.in + (size_t)n * a.H * a.W * CI;
     const unsigned coff = (unsigned)(g * CING + 4 * q8);
+    const int px = min(t8 + PPI * i, B_NPX - 1);
+    const int py = (int)(__umul24((unsigned)px, 3277u) >> 16), pxx = __mul24(py, -B_PW) + px;  // px / 20 for px < 400
+    const int cy = min(max(oy0 - 2 + py, 0), a.H - 1), cx = min(max(ox0 - 2 + pxx, 0), a.W - 1);
+    pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, CI) + coff) << 2));
+  };
+  auto issue_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int px = min(t8 + PPI * i, B_NPX - 1);
-      const int py = (int)(__umul24((unsigned)px, 3277u) >> 16), pxx = __mul24(py, -B_PW) + px;  // px / 20 for px < 400
-      const int cy = min(max(oy0 - 2 + py, 0), a.H - 1), cx = min(max(ox0 - 2 + pxx, 0), a.W - 1);
-      pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, CI) + coff) << 2));
-    }
+    for (int i = 0; i < NP; ++i) issue_item(i);
   };
   int t = blockIdx.x;
   // (td.total >= 8 gridDim.x is not required: a workgroup whose first tile does not exist has none)
@@ -1468,17 +1470,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < NP; ++i) convert_item(i, oy0 - 2, ox0 - 2, interior);
   }
+#ifdef CPX_B32_STAMPS  // (experiment, scratch/build_conv_variant.sh: where a tile's time goes -- cycle stamps of waves 0 and 7 of one workgroup)
+  long long st_last = clock64(), st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int st_tiles = 0;
+  const bool st_on = blockIdx.x == 8 && blockIdx.y == 0 && (tid == 0 || tid == 448);
+#define B32_STAMP(i_) if (st_on) { const long long now_ = clock64(); st_acc[i_] += now_ - st_last; st_last = now_; }
+#else
+#define B32_STAMP(i_)
+#endif
   for (;;) {
     commit_patch();
+    B32_STAMP(0)
     const int n_cur = n, oy_cur = oy0, ox_cur = ox0;
     const bool interior_cur = tile_interior();
-    // ---- the second convolution's accumulators start as the residual (the block's input at the tile): in flight under
-    //      the first convolution, as is the NEXT tile's patch ----
+    // ---- what goes in flight under the first convolution, in pieces BETWEEN its K steps (address arithmetic and load issue
+    //      run beside the matrix pipe instead of in front of the barrier: cycle stamps put them at 1,200-2,200 cycles of a
+    //      tile's 18,000 there): the second convolution's accumulators = the residual (the block's input at the tile), the
+    //      next tile's coordinates, its patch item by item ----
     f32x4 acc[2][2];
     unsigned opix[2];
     bool ovalid[2];
     unsigned spix[2];  // (C8) element offsets of the lane's two pixels in the block's input, channel g * 8 + q: the shortcut's operand
-    {
+    bool more = false, interior_next = false;
+    auto piece_residual = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
         const int oy = oy_cur + 2 * wave + pt, ox = ox_cur + i16;
@@ -1498,28 +1512,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = *reinterpret_cast<const f32x4*>(at_off(res_n, (opix[pt] + 16u * ct) << 2));
       }
-    }
-    t += gridDim.x;
-    const bool more = t < 8 * per_xcd && tile_of(t) < td.total;  // (a workgroup's tiles ascend within its XCD's eighth: the first missing one ends it)
-    if (more) {
-      decode(tile_of(t));
-      issue_patch();
-    }
-    const bool interior_next = tile_interior();
+    };
+    auto piece_next_tile = [&]() __attribute__((always_inline)) {
+      t += gridDim.x;
+      more = t < 8 * per_xcd && tile_of(t) < td.total;  // (a workgroup's tiles ascend within its XCD's eighth: the first missing one ends it)
+      if (more) decode(tile_of(t));
+      interior_next = tile_interior();
+    };
+    B32_STAMP(1)
     __syncthreads();
-    // ---- first convolution: mid pixel groups wave, wave + 8, wave + 16 (< 21) x 32 columns ----
+    B32_STAMP(2)
+    // ---- first convolution: 21 groups of 16 mid pixels x two 16-column tiles.  Waves 0-3 take groups w, w + 8, w + 16; waves
+    //      4-7 groups w, w + 8; the 21st group (4 valid pixels) is split by column tile between waves 4 and 5 -- waves w and
+    //      w + 4 share a SIMD, so the SIMDs carry 11, 11, 10, 10 (group, tile) units (with three whole groups on wave 4
+    //      SIMD 0 carried 12 and every tile waited ~2,000 cycles for it at the barrier) ----
     f32x4 acc1[3][2];
     int abase1[3];
+    const bool third_full = wave < 4;                // (uniform)
+    const bool third_half = wave == 4 || wave == 5;  // (uniform) one column tile of group 20: tile wave - 4
+    const int g3 = third_full ? wave + 16 : 20;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int p = min(16 * (wave + 8 * j) + i16, W_NPX - 1);
+      const int p = min(16 * (j < 2 ? wave + 8 * j : g3) + i16, W_NPX - 1);
       const int my = (int)(__umul24((unsigned)p, 3641u) >> 16), mx = p - my * W_PW;  // p / 18 for p < 324
       abase1[j] = C8 ? my * B_PW + mx : ((q >> 1) * B_NPXP + my * B_PW + mx) * 2 + (q & 1);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc1[j][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     const int b_base = q * 32 + i16;
-    const bool third = wave < 5;  // (uniform) group wave + 16 exists
     if constexpr (C8) {
 #pragma unroll
       for (int t4 = 0; t4 < 3; ++t4) {
@@ -1534,20 +1554,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_wa[(t4 * 2 + p) * 128 + b_base + 16 * ct]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          if (j < 2 || third) {
+          if (j < 2 || third_full || third_half) {
             const int e = tap < 9 ? abase1[j] + toff : B_NPX;
             u32x4 xv[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) xv[p] = __builtin_bit_cast(u32x4, s_px[p * B8_NPXP + e]);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-              acc1[j][ct] = mfma16<true>(wv[ct][1], xv[0], acc1[j][ct]);
-              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[1], acc1[j][ct]);
-              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[0], acc1[j][ct]);
+              if (j < 2 || third_full || ct == wave - 4) {
+                acc1[j][ct] = mfma16<true>(wv[ct][1], xv[0], acc1[j][ct]);
+                acc1[j][ct] = mfma16<true>(wv[ct][0], xv[1], acc1[j][ct]);
+                acc1[j][ct] = mfma16<true>(wv[ct][0], xv[0], acc1[j][ct]);
+              }
             }
           }
         }
+        if (t4 == 0) {
+          piece_residual();
+          piece_next_tile();
+        } else if (more) {
+          issue_item(t4 - 1);
+        }
       }
+      static_assert(!C8 || NP == 2, "the patch items of the 8-channel form ride on the second and third K step");
     } else {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1560,22 +1589,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_wa[r * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          if (j < 2 || third) {
+          if (j < 2 || third_full || third_half) {
             u32x4 xv[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) xv[p] = __builtin_bit_cast(u32x4, s_r0[p * (4 * B_NPXP) + abase1[j] + (r * B_PW + kx) * 2]);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-              acc1[j][ct] = mfma16<true>(wv[ct][1], xv[0], acc1[j][ct]);
-              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[1], acc1[j][ct]);
-              acc1[j][ct] = mfma16<true>(wv[ct][0], xv[0], acc1[j][ct]);
+              if (j < 2 || third_full || ct == wave - 4) {
+                acc1[j][ct] = mfma16<true>(wv[ct][1], xv[0], acc1[j][ct]);
+                acc1[j][ct] = mfma16<true>(wv[ct][0], xv[1], acc1[j][ct]);
+                acc1[j][ct] = mfma16<true>(wv[ct][0], xv[0], acc1[j][ct]);
+              }
             }
           }
         }
+        const int tp = r * 3 + kx;
+        if (tp == 0) piece_residual();
+        else if (tp == 1) piece_next_tile();
+        else if (more) issue_item(tp - 2);
       }
     }
+    static_assert(C8 || NP == 7, "the patch items ride on K steps 2..8 of the first convolution");
     }
+    B32_STAMP(3)
     __syncthreads();  // every wave has read its patch fragments: the region becomes mid
+    B32_STAMP(4)
     // ---- mid = relu(acc * a_scale + a_shift), times the second convolution's range scale, as its fp16 planes in LDS;
     //      pixels outside the image are that convolution's zero padding ----
 #pragma unroll
@@ -1583,8 +1621,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int c4 = 4 * ct + q;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const int p = 16 * (wave + 8 * j) + i16;
-        if (p < W_NPX) {
+        const int p = 16 * (j < 2 ? wave + 8 * j : g3) + i16;
+        if (p < W_NPX && (j < 2 || third_full || (third_half && ct == wave - 4))) {
           f32x4 v = acc1[j][ct] * os_a[ct] + ob_a[ct];
           v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
           u32x4 pv = planes_of(v);
@@ -1607,7 +1645,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
         if (!C8) acc[ct][pt] *= rs_b[ct];  // the accumulators hold act_scale * w_scale[channel] times the sum: so must the residual
+    B32_STAMP(5)
     __syncthreads();
+    B32_STAMP(6)
     // ---- second convolution: conv_bf3w_kernel's loop on the mid image; between its taps the next tile's patch (landed
     //      during the first convolution) takes its prologue and split, one item per tap: vector work under the products ----
     {
@@ -1656,6 +1696,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[ct], xs[pt], acc[ct][pt], 0, 0, 0);
       }
     }
+    B32_STAMP(7)
     // ---- epilogue: unscale, bias, ReLU, one 16-byte store per accumulator tile ----
     {
       float* out_n = b.out + (size_t)n_cur * a.H * a.W * C;
@@ -1670,9 +1711,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     }
+    B32_STAMP(8)
+#ifdef CPX_B32_STAMPS
+    ++st_tiles;
+#endif
     if (!more) break;
     __syncthreads();  // every wave has read its mid fragments: the region takes the next patch
+    B32_STAMP(9)
   }
+#ifdef CPX_B32_STAMPS
+  if (st_on)
+    printf("b32 stamps C8 %d wave %d tiles %d: commit %lld issue %lld bar1 %lld phaseA %lld bar2 %lld midepi %lld bar3 %lld phaseB %lld outepi %lld bar4 %lld\n",
+           (int)C8, wave, st_tiles, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6], st_acc[7], st_acc[8], st_acc[9]);
+#endif
+#undef B32_STAMP
   if ((hmax & 0xFFFFu) >= 0x7C00u || (hmax >> 16) >= 0x7C00u) atomicOr(a.ovf, 1);  // (infinity or NaN)
 }
 
