@@ -1578,36 +1578,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       static_assert(!C8 || NP == 2, "the patch items of the 8-channel form ride on the second and third K step");
     } else {
+    // (as in the second convolution: tap k + 1's fragments are requested before tap k's products)
+    u32x4 wv[2][2][2], xv[2][3][2];  // [buffer][column tile | group][plane]
+    const bool third_any = third_full || third_half;
+    auto frags = [&](const int tp, const int bf) __attribute__((always_inline)) {
+      const int r = tp / 3, kx = tp - 3 * r;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+      for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        u32x4 wv[2][2];
+        for (int ct = 0; ct < 2; ++ct) wv[bf][ct][p] = __builtin_bit_cast(u32x4, s_wa[r * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int j = 0; j < 3; ++j)
+          if (j < 2 || third_any) xv[bf][j][p] = __builtin_bit_cast(u32x4, s_r0[p * (4 * B_NPXP) + abase1[j] + (r * B_PW + kx) * 2]);
+      }
+    };
+    frags(0, 0);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_wa[r * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
+    for (int tp = 0; tp < 9; ++tp) {
+      const int bf = tp & 1;
+      if (tp + 1 < 9) frags(tp + 1, bf ^ 1);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (j < 2 || third_full || third_half) {
-            u32x4 xv[2];
+      for (int j = 0; j < 3; ++j) {
+        if (j < 2 || third_any) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) xv[p] = __builtin_bit_cast(u32x4, s_r0[p * (4 * B_NPXP) + abase1[j] + (r * B_PW + kx) * 2]);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-              if (j < 2 || third_full || ct == wave - 4) {
-                acc1[j][ct] = mfma16<true>(wv[ct][1], xv[0], acc1[j][ct]);
-                acc1[j][ct] = mfma16<true>(wv[ct][0], xv[1], acc1[j][ct]);
-                acc1[j][ct] = mfma16<true>(wv[ct][0], xv[0], acc1[j][ct]);
-              }
+          for (int ct = 0; ct < 2; ++ct) {
+            if (j < 2 || third_full || ct == wave - 4) {
+              acc1[j][ct] = mfma16<true>(wv[bf][ct][1], xv[bf][j][0], acc1[j][ct]);
+              acc1[j][ct] = mfma16<true>(wv[bf][ct][0], xv[bf][j][1], acc1[j][ct]);
+              acc1[j][ct] = mfma16<true>(wv[bf][ct][0], xv[bf][j][0], acc1[j][ct]);
             }
           }
         }
-        const int tp = r * 3 + kx;
-        if (tp == 0) piece_residual();
-        else if (tp == 1) piece_next_tile();
-        else if (more) issue_item(tp - 2);
       }
+      if (tp == 0) piece_residual();
+      else if (tp == 1) piece_next_tile();
+      else if (more) issue_item(tp - 2);
     }
     static_assert(C8 || NP == 7, "the patch items ride on K steps 2..8 of the first convolution");
     }
@@ -1652,28 +1657,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //      during the first convolution) takes its prologue and split, one item per tap: vector work under the products ----
     {
       const int a_base = ((q >> 1) * W_NPXP + (2 * wave) * W_PW + i16) * 2 + (q & 1);
+      // (the fragments of tap k + 1 are requested before the products of tap k: their LDS round trip runs under those
+      //  products and the prologue work between the taps, not in front of the next tap's first product)
+      u32x4 xv[2][2][2], wv[2][2][2];  // [buffer][pixel row | column tile][plane]
+      auto frags = [&](const int tp, const int bf) __attribute__((always_inline)) {
+        const int r = tp / 3, kx = tp - 3 * r;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+        for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          u32x4 xv[2][2], wv[2][2];
+          for (int pt = 0; pt < 2; ++pt) xv[bf][pt][p] = __builtin_bit_cast(u32x4, s_r0[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) xv[pt][p] = __builtin_bit_cast(u32x4, s_r0[p * (4 * W_NPXP) + a_base + ((pt + r) * W_PW + kx) * 2]);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) wv[ct][p] = __builtin_bit_cast(u32x4, s_wb[r * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
-          }
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-              acc[ct][pt] = mfma16<true>(wv[ct][1], xv[pt][0], acc[ct][pt]);
-              acc[ct][pt] = mfma16<true>(wv[ct][0], xv[pt][1], acc[ct][pt]);
-              acc[ct][pt] = mfma16<true>(wv[ct][0], xv[pt][0], acc[ct][pt]);
-            }
-          if (r * 3 + kx < NP && more) convert_item(r * 3 + kx, oy0 - 2, ox0 - 2, interior_next);
+          for (int ct = 0; ct < 2; ++ct) wv[bf][ct][p] = __builtin_bit_cast(u32x4, s_wb[r * W_WROW + (p * 3 + kx) * 128 + b_base + 16 * ct]);
         }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int bf = tp & 1;
+        if (tp + 1 < 9) frags(tp + 1, bf ^ 1);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            acc[ct][pt] = mfma16<true>(wv[bf][ct][1], xv[bf][pt][0], acc[ct][pt]);
+            acc[ct][pt] = mfma16<true>(wv[bf][ct][0], xv[bf][pt][1], acc[ct][pt]);
+            acc[ct][pt] = mfma16<true>(wv[bf][ct][0], xv[bf][pt][0], acc[ct][pt]);
+          }
+#ifndef CPX_B32_NO_CONVERT
+        if (tp < NP && more) convert_item(tp, oy0 - 2, ox0 - 2, interior_next);
+#endif
       }
     }
     if constexpr (C8) {
