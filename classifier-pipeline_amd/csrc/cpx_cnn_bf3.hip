@@ -1617,7 +1617,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert(C8 || NP == 7, "the patch items ride on K steps 2..8 of the first convolution");
     }
     B32_STAMP(3)
-    __syncthreads();  // every wave has read its patch fragments: the region becomes mid
+    // every wave has read its patch fragments: the region becomes mid (C8: the patch has a region of its own -- a wave
+    // writes its share of mid as soon as its own products are done)
+    if (!C8) __syncthreads();
     B32_STAMP(4)
     // ---- mid = relu(acc * a_scale + a_shift), times the second convolution's range scale, as its fp16 planes in LDS;
     //      pixels outside the image are that convolution's zero padding ----
