@@ -1730,7 +1730,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ++st_tiles;
 #endif
     if (!more) break;
-    __syncthreads();  // every wave has read its mid fragments: the region takes the next patch
+    // every wave has read its mid fragments: the region takes the next patch (C8: the patch goes to its own region, and the
+    // barrier behind the commit is passed only by waves that are through with this tile's mid)
+    if (!C8) __syncthreads();
     B32_STAMP(9)
   }
 #ifdef CPX_B32_STAMPS
