@@ -1258,10 +1258,16 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
             tracker.timings["decode_s"] += decode_s
             waited = time.time() - t0
             tracker.timings["wait_decode_s"] = tracker.timings.get("wait_decode_s", 0.0) + waited
-            if n_lanes > 1 and bi == 1:   # (the first batch's decode has nothing to hide behind: it says nothing; decided once
-                # -- a lane's engine, network buffers and allocator pool stay behind when it is dropped again)
+            if n_lanes > 1 and bi == 1:
+                # decided once, at the second batch (a lane's engine, network buffers and allocator pool stay behind when
+                # it is dropped again, and a lane added later allocates on top of buffers sized for one: measured, out of
+                # memory beside the bench's resident clips).  Decode-bound runs keep one lane -- two lanes slow their decode
+                # (8,192 noise recordings: 6.1 s against 4.7 s).  The wait for this batch's decode alone does not tell:
+                # the first batch's device phase carries the run's allocations and can hide a decode that steady batches
+                # will wait for; the decode's own duration against that turn does
                 lap_s = max(t0 - last_batch_t0[0], 1e-6)   # the first batch's turn of this loop
-                lanes_now[0] = 1 if waited > 0.2 * (lap_s + waited) else n_lanes
+                decode_bound = waited > 0.2 * (lap_s + waited) or decode_s > 0.5 * lap_s
+                lanes_now[0] = 1 if decode_bound else n_lanes
                 tracker.timings["device_lanes"] = lanes_now[0]
             last_batch_t0[0] = time.time()
             k = lanes_now[0]
