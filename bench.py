@@ -249,7 +249,8 @@ def dry_launch(args, numa=None):
         t[rank] = rank + 1
         dist.all_reduce(t)
         seen = [int(v) - 1 for v in t]
-        gathered = gather_records(rec, dist)
+        # capacity from the plan: the largest shard's clip count (one record per clip here)
+        gathered = gather_records(rec, dist, capacity=max(len(sh) for sh in shards)).records()
         tt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(tt, torch.tensor([times[0]], dtype=torch.float64))
         times = [float(v.item()) for v in tt]
@@ -796,6 +797,9 @@ class Config4Workload:
                                   frame_size=frame_size)
         self.frames_local = int(sum(int(self.lengths[i]) for i in self.mine))
         self.frames_total = int(self.lengths.sum())
+        # the collective's slab size, from the plan alone (identical on every rank): the largest shard's clips x the
+        # tracks a clip may keep
+        self.record_capacity = max(len(sh) for sh in self.shards) * self.pipe.tp.max_tracks
         self.last = None
 
     def clip_frames(self, clip_id):
@@ -820,7 +824,7 @@ class Config4Workload:
         self.last = results
         t.cuda.synchronize(self.device)
         t0 = time.perf_counter()
-        out = gather_records(rec, dist)
+        out = gather_records(rec, dist, capacity=self.record_capacity)
         t.cuda.synchronize(self.device)
         self.last_gather_s = time.perf_counter() - t0
         return out
@@ -870,6 +874,7 @@ def bench_config4(args, torch, np, dist, device, rank, world, local_rank, cpu, a
     for r in wl.last:
         r.track.check()
         r.assoc.check()
+    gathered = gathered.records()  # outside the timed region: the step itself never reads the device
     line = None
     if rank == 0:
         loads = [int(wl.lengths[s].sum()) for s in wl.shards]
@@ -1065,7 +1070,7 @@ def main():
                     rec = pack_records(res.track_clip[:, 0] + rank * B, res.track_clip[:, 1], res.scores)
                 else:
                     rec = torch.empty((0, 2 + N_LABELS), dtype=torch.int32, device=device)
-                state["gathered"] = gather_records(rec, dist)
+                state["gathered"] = gather_records(rec, dist, capacity=B * pipe.tp.max_tracks)
             return res.track
         res = eng.track_batch(frames, offs, meta, outputs=outputs)
         eng.synchronize()
@@ -1073,7 +1078,7 @@ def main():
         if dist is not None:
             nc = info.view(total, 20)[:, 1].view(B, T).sum(dim=1).to(torch.int32)
             rec = torch.stack([torch.arange(B, device=device, dtype=torch.int32) + rank * B, nc], dim=1)
-            state["gathered"] = gather_records(rec, dist)
+            state["gathered"] = gather_records(rec, dist, capacity=B)
         return res
 
     def fence():

@@ -83,28 +83,68 @@ def shard_files(paths, rank, world_size):
     return [paths[i] for i in partition_clips(sizes, world_size)[rank]]
 
 
-def gather_records(records, dist=None, device=None):
-    """records: int32 tensor [n_local, width] (clip id in column 0).  Pads every
-    rank to the global maximum with -1 rows, all_gathers once, returns the
-    concatenation without padding, sorted by clip id (same on every rank)."""
+class GatheredRecords:
+    """What the step's one collective returned: every rank's slab `[1 + capacity, width]` side by side.  Row 0 of a slab
+    is its header (column 0: the rank's true record count, the rest 0), the records follow, unused rows are -1.  Nothing
+    here reads the device: `slabs` and `counts` are device tensors a later kernel (or the next step) can consume;
+    `records()` is the one place that synchronises, for the caller that writes metadata on the host."""
+
+    def __init__(self, slabs, capacity, world):
+        self.slabs = slabs              # [world, 1 + capacity, width]
+        self.capacity = int(capacity)
+        self.world = int(world)
+
+    @property
+    def width(self):
+        return int(self.slabs.shape[2])
+
+    @property
+    def counts(self):
+        """Per-rank true record counts, on the slabs' device (a view: no copy, no sync)."""
+        return self.slabs[:, 0, 0]
+
+    def records(self):
+        """-> [n, width], the padding dropped, sorted by clip id (stable: a rank's own order is kept inside a clip);
+        identical on every rank.  Raises on every rank alike when some rank had more records than the capacity the plan
+        promised (its surplus never entered the collective)."""
+        body = self.slabs[:, 1:, :].reshape(-1, self.width)
+        counts = self.counts
+        if bool((counts > self.capacity).any()):
+            raise RuntimeError("gather_records: a rank produced %d records, capacity %d: size the capacity from the "
+                               "plan (clips per rank x tracks per clip)" % (int(counts.max()), self.capacity))
+        import torch
+
+        out = body[body[:, 0] >= 0]
+        return out[torch.argsort(out[:, 0], stable=True)]
+
+
+def gather_records(records, dist=None, capacity=None):
+    """records: int32 tensor [n_local, width] (clip id, >= 0, in column 0) -> GatheredRecords.
+    ONE collective per step and no host synchronisation (what replaces the reference's
+    multiprocessing.Pool over files, track/trackextractor.py:80-85): every rank contributes a slab of the same,
+    plan-derived size -- `capacity` rows, e.g. clips per rank x tracks per clip, known before the step runs -- with its
+    record count carried in the slab's header row, so no rank has to learn another's count before the exchange.
+    `capacity` may be omitted only outside a process group (one rank: the slab is the records themselves)."""
     import torch
 
-    if dist is None or not dist.is_initialized():
-        out = records
-    else:
-        world = dist.get_world_size()
-        n = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
-        counts = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts, n)
-        cap = int(max(int(c.item()) for c in counts))
-        width = records.shape[1]
-        padded = torch.full((cap, width), -1, dtype=records.dtype, device=records.device)
-        padded[: records.shape[0]] = records
-        gathered = torch.empty((world * cap, width), dtype=records.dtype, device=records.device)
-        dist.all_gather_into_tensor(gathered, padded)
-        out = gathered[gathered[:, 0] >= 0]
-    order = torch.argsort(out[:, 0], stable=True)
-    return out[order]
+    n, width = int(records.shape[0]), int(records.shape[1])
+    grouped = dist is not None and dist.is_initialized()
+    if capacity is None:
+        if grouped:
+            raise ValueError("gather_records under a process group needs the plan's capacity (rows per rank)")
+        capacity = n
+    capacity = int(capacity)
+    slab = torch.full((1 + capacity, width), -1, dtype=records.dtype, device=records.device)
+    slab[0] = 0
+    slab[0, 0] = n
+    keep = min(n, capacity)
+    slab[1:1 + keep] = records[:keep]
+    if not grouped:
+        return GatheredRecords(slab.unsqueeze(0), capacity, 1)
+    world = dist.get_world_size()
+    slabs = torch.empty((world * (1 + capacity), width), dtype=records.dtype, device=records.device)
+    dist.all_gather_into_tensor(slabs, slab)   # the concatenated form: what gloo accepts as well as RCCL
+    return GatheredRecords(slabs.view(world, 1 + capacity, width), capacity, world)
 
 
 def plan_sub_batches(frame_counts, clip_ids, max_frames, max_clips=4096):

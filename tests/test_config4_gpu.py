@@ -50,8 +50,9 @@ def test_config4_rank0_shard_matches_oracle_chain():
         assert len(wl.subs) >= 3 and sorted(i for sb in wl.subs for i in sb) == wl.mine   # several device batches
         for sb in wl.subs:
             assert sum(int(lengths[i]) for i in sb) <= 700 or len(sb) == 1
-        rec = wl.step(dist)
-        rec2 = wl.step(dist)
+        got = wl.step(dist)
+        assert got.world == 1 and got.capacity == wl.record_capacity and int(got.counts[0]) <= got.capacity
+        rec, rec2 = got.records(), wl.step(dist).records()
         assert torch.equal(rec, rec2)                      # a step is a pure function of the resident clips
         clip_ids, track_ids, scores = (v.cpu().numpy() for v in unpack_records(rec))
         assert rec.shape[1] == 2 + 17 and rec.dtype == torch.int32

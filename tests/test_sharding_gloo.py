@@ -64,7 +64,39 @@ WORKER = textwrap.dedent(
     counts = np.random.default_rng(1).integers(20, 400, size=37)
     mine = partition_clips(counts, world)[rank]
     rec = torch.tensor([[i, int(counts[i]), i * 7 %% 5, rank] for i in mine], dtype=torch.int32).reshape(-1, 4)
-    out = gather_records(rec, dist)
+    # ONE collective per step and no host read inside it (VERDICT r05 item 4): every collective entry point of
+    # torch.distributed is wrapped and counted, and Tensor.item / tolist / cpu / __bool__ raise while the step runs
+    calls = []
+    names = [n for n in dir(dist) if n.startswith(("all_", "broadcast", "reduce", "gather", "scatter", "send", "recv", "barrier"))
+             and callable(getattr(dist, n))]
+    saved = {n: getattr(dist, n) for n in names}
+    def wrap(n):
+        def f(*a, **k):
+            calls.append(n)
+            return saved[n](*a, **k)
+        return f
+    for n in names:
+        setattr(dist, n, wrap(n))
+    host_reads = ("item", "tolist", "cpu", "numpy", "__bool__", "__int__", "__index__", "__float__")
+    saved_t = {n: getattr(torch.Tensor, n) for n in host_reads}
+    def forbid(n):
+        def f(self, *a, **k):
+            raise AssertionError("host read of a tensor inside the step: " + n)
+        return f
+    for n in host_reads:
+        setattr(torch.Tensor, n, forbid(n))
+    cap = max(len(s) for s in partition_clips(counts, world))
+    try:
+        got = gather_records(rec, dist, capacity=cap)
+    finally:
+        for n in host_reads:
+            setattr(torch.Tensor, n, saved_t[n])
+        for n in names:
+            setattr(dist, n, saved[n])
+    assert calls == ["all_gather_into_tensor"], calls
+    assert got.world == world and got.capacity == cap and got.slabs.shape == (world, 1 + cap, 4)
+    assert got.counts.tolist() == [len(s) for s in partition_clips(counts, world)]
+    out = got.records()
     assert out.shape == (37, 4), out.shape
     assert out[:, 0].tolist() == list(range(37))
     assert out[:, 1].tolist() == [int(c) for c in counts]
@@ -72,7 +104,7 @@ WORKER = textwrap.dedent(
     assert out[:, 3].tolist() == [owners[i] for i in range(37)]
     # a rank whose clips produced no record still enters the collective (bench.py does this every step)
     rec2 = rec if rank == 0 else torch.empty((0, 4), dtype=torch.int32)
-    out2 = gather_records(rec2, dist)
+    out2 = gather_records(rec2, dist, capacity=cap).records()
     assert out2.shape == (len(partition_clips(counts, world)[0]), 4) and (out2[:, 3] == 0).all()
     # the configs[3] record [clip_id, track_id, 17 x f32] over the LPT shards of variable-length clips (bench.py --config4)
     from cpx.sharding import pack_records, unpack_records, plan_sub_batches
@@ -91,7 +123,19 @@ WORKER = textwrap.dedent(
         if rows:
             recs.append(pack_records(torch.tensor([r[0] for r in rows]), torch.tensor([r[1] for r in rows]), torch.from_numpy(sc)))
     mine = torch.cat(recs) if recs else torch.empty((0, 19), dtype=torch.int32)
-    allrec = gather_records(mine, dist)
+    allrec = gather_records(mine, dist, capacity=2 * max(len(s) for s in shards)).records()
+    # a rank beyond the plan's capacity is reported on EVERY rank alike (the count travels in the slab's header)
+    over = gather_records(mine, dist, capacity=len(table(shards[0])[0]) - 1)   # rank 0 alone is one over
+    try:
+        over.records()
+        raise SystemExit("capacity overflow went unnoticed")
+    except RuntimeError as e:
+        assert "capacity" in str(e)
+    try:
+        gather_records(mine, dist)
+        raise SystemExit("a grouped gather without a capacity was accepted")
+    except ValueError:
+        pass
     rows, sc = table(range(61))
     cid, tid, got = unpack_records(allrec)
     assert allrec.shape == (len(rows), 19) and allrec.dtype == torch.int32
