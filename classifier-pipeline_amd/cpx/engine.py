@@ -22,20 +22,20 @@ def thresholds_for_model(model):
 class TrackBatchResult:
     """Outputs of one cpx_track_batch call (host copies are made lazily).
 
-    The device tensors come from torch's allocator while the kernels that fill them run on the engine's stream:
-    hold the result until engine.synchronize() (every host accessor here does that first). A result dropped
-    earlier hands its memory back while it is still being written.  (Tensor.record_stream on the handle's stream would
-    move that duty to the allocator -- tried in round 5 and withdrawn: the allocator records an event on the recorded
-    stream when the tensor is freed, and a handle's stream dies with the handle (grown / sibling engines are closed
-    while results of theirs are still referenced): the free then touches a destroyed HIP stream.  Code that needs
-    allocator-enforced lifetimes runs under `with torch.cuda.stream(engine.torch_stream())`, as cpx.pipeline and the
-    bulk lanes do.)"""
+    Lifetimes are the allocator's business, not the caller's: the engine allocates every output under its own stream
+    (`TrackEngine._own_stream`), so a result dropped while its kernels are still running hands its blocks back to THAT
+    stream's pool, where the next allocation is ordered behind those kernels; allocations on any other stream never see
+    the blocks.  A result also keeps its engine's handle -- hence the stream -- alive: `TrackEngine.close()` on an
+    engine with live results (a grown / sibling engine the parent closes) is deferred until the last of them dies.
+    What stays the consumer's duty is torch's ordinary multi-stream rule: read the device tensors on the engine's
+    stream or after `engine.synchronize()` (every host accessor here synchronises first)."""
 
     def __init__(self, engine, total, cap, comps, info, labels, filtered, background):
         self.engine, self.total, self.cap = engine, total, cap
         self.comps_dev, self.info_dev = comps, info
         self.labels_dev, self.filtered_dev, self.background_dev = labels, filtered, background
         self._info = self._comps = None
+        engine._retain(self)
 
     @property
     def info(self):
@@ -96,6 +96,7 @@ class AssocBatchResult:
         self.pool_dev, self.tracks_dev, self.ntracks_dev, self.status_dev = pool, tracks, ntracks, status
         self.regions_dev, self.rcounts_dev = regions, rcounts
         self._host = None
+        engine._retain(self)
 
     def _fetch(self):
         if self._host is None:
@@ -342,14 +343,48 @@ class TrackEngine:
                           background_thresh=self.cfg.background_thresh, weight_add=self.cfg.weight_add,
                           max_frames=max_frames, denoise=denoise)
         self._grown = {}
+        self._live_results = 0      # results whose device tensors live in this handle's stream pool
+        self._close_deferred = False
 
     def close(self):
+        """Destroys the handle (and its HIP stream) -- at once when no result of this engine is alive, else when the last
+        one dies: their tensors were allocated under the stream and must be handed back to a stream that still exists."""
         for eng in getattr(self, "_grown", {}).values():
             eng.close()
         self._grown = {}
+        if getattr(self, "_live_results", 0) > 0:
+            self._close_deferred = True
+            return
+        self._destroy()
+
+    def _destroy(self):
         if self.h:
             self.lib.cpx_destroy(self.h)
             self.h = C.c_void_p()
+        self._torch_stream = None
+
+    def _retain(self, result):
+        """`result` holds device tensors of this engine's stream: keep the stream until it is collected."""
+        import weakref
+
+        self._live_results += 1
+        weakref.finalize(result, self._release).atexit = False   # (the bound method keeps the engine alive until then)
+
+    def _release(self):
+        self._live_results -= 1
+        if self._live_results == 0 and self._close_deferred:
+            self._close_deferred = False
+            try:
+                self._destroy()
+            except Exception:
+                pass
+
+    def _own_stream(self):
+        """Context for allocating a call's outputs: order the handle's stream behind what the caller has enqueued on
+        torch's current stream (sync_inputs), then make the handle's stream current, so that the outputs' blocks belong
+        to its pool and zero-fills run on it."""
+        self.sync_inputs()
+        return self.torch.cuda.stream(self.torch_stream())
 
     # ---- no recording is lost to a capacity -------------------------------------------------------------------
     # The reference has no limit on components per frame (cliptrackextractor.py:236-247), simultaneous tracks or tracks
@@ -576,11 +611,11 @@ class TrackEngine:
         if images_dev.dtype != t.uint8 or images_dev.dim() != 3 or not images_dev.is_contiguous():
             raise ValueError("ir_detect wants a contiguous uint8 [n, H, W] device tensor")
         n, H, W = (int(v) for v in images_dev.shape)
-        comps = t.empty((n, max_components, COMPONENT_DTYPE.itemsize // 4), dtype=t.int32, device=self.device)
-        counts = t.zeros(n, dtype=t.int32, device=self.device)
-        status = t.zeros(n, dtype=t.int32, device=self.device)
-        labels = t.empty((n, H, W), dtype=t.int32, device=self.device) if want_labels else None
-        self.sync_inputs()
+        with self._own_stream():
+            comps = t.empty((n, max_components, COMPONENT_DTYPE.itemsize // 4), dtype=t.int32, device=self.device)
+            counts = t.zeros(n, dtype=t.int32, device=self.device)
+            status = t.zeros(n, dtype=t.int32, device=self.device)
+            labels = t.empty((n, H, W), dtype=t.int32, device=self.device) if want_labels else None
         rc = self.lib.cpx_ir_detect(self.h, C.c_void_p(images_dev.data_ptr()), n, W, H, int(threshold),
                                     int(max_components), C.c_void_p(comps.data_ptr()), C.c_void_p(counts.data_ptr()),
                                     C.c_void_p(status.data_ptr()),
@@ -606,8 +641,8 @@ class TrackEngine:
         single = images_dev.dim() == 2
         src = (images_dev[None] if single else images_dev).contiguous()
         n, H, W = (int(v) for v in src.shape)
-        out = t.empty((n, H // factor, W // factor), dtype=t.uint8, device=self.device)
-        self.sync_inputs()
+        with self._own_stream():
+            out = t.empty((n, H // factor, W // factor), dtype=t.uint8, device=self.device)
         rc = self.lib.cpx_ir_resize_area(self.h, C.c_void_p(src.data_ptr()), n, W, H, int(factor), C.c_void_p(out.data_ptr()))
         if rc != 0:
             raise CpxError(rc, self._err())
@@ -705,16 +740,16 @@ class TrackEngine:
         total = int(offs[-1])
         meta = np.ascontiguousarray(meta, dtype=FRAME_META_DTYPE)
         assert meta.size == total and frames_dev.shape[0] >= total
-        P = self.width * self.height
         if outputs is None:
-            comps = t.empty(total * self.cap * 8, dtype=t.int32, device=self.device)
-            info = t.empty(total * 20, dtype=t.int32, device=self.device)
-            labels = t.empty((total, self.height, self.width), dtype=t.int32, device=self.device) if want_labels else None
-            filt = t.empty((total, self.height, self.width), dtype=t.float32, device=self.device) if want_filtered else None
-            bgo = t.empty((B, self.height, self.width), dtype=t.float32, device=self.device) if want_background else None
+            with self._own_stream():
+                comps = t.empty(total * self.cap * 8, dtype=t.int32, device=self.device)
+                info = t.empty(total * 20, dtype=t.int32, device=self.device)
+                labels = t.empty((total, self.height, self.width), dtype=t.int32, device=self.device) if want_labels else None
+                filt = t.empty((total, self.height, self.width), dtype=t.float32, device=self.device) if want_filtered else None
+                bgo = t.empty((B, self.height, self.width), dtype=t.float32, device=self.device) if want_background else None
         else:
             comps, info, labels, filt, bgo = outputs
-        self.sync_inputs()  # inputs were produced on torch's stream
+            self.sync_inputs()  # inputs were produced on torch's stream
         self.track_calls = getattr(self, "track_calls", 0) + 1  # whose state cpx_get_background would read
         rc = self.lib.cpx_track_batch_ex(
             self.h, C.c_void_p(frames_dev.data_ptr()), offs.ctypes.data_as(C.POINTER(C.c_int32)),
@@ -735,13 +770,13 @@ class TrackEngine:
         meta = np.ascontiguousarray(meta, dtype=FRAME_META_DTYPE)
         params = params or make_track_params(self.width, self.height, self.cfg.edge_pixels)
         ma, mt = params.max_active_tracks, params.max_tracks
-        pool = t.zeros(total * ma * 14, dtype=t.int32, device=self.device)
-        tracks = t.zeros(B * mt * 8, dtype=t.int32, device=self.device)
-        ntr = t.zeros(B, dtype=t.int32, device=self.device)
-        status = t.zeros(B, dtype=t.int32, device=self.device)
-        regions = t.zeros(total * self.cap * 14, dtype=t.int32, device=self.device) if want_regions else None
-        rcounts = t.zeros(total, dtype=t.int32, device=self.device) if want_regions else None
-        self.sync_inputs()
+        with self._own_stream():
+            pool = t.zeros(total * ma * 14, dtype=t.int32, device=self.device)
+            tracks = t.zeros(B * mt * 8, dtype=t.int32, device=self.device)
+            ntr = t.zeros(B, dtype=t.int32, device=self.device)
+            status = t.zeros(B, dtype=t.int32, device=self.device)
+            regions = t.zeros(total * self.cap * 14, dtype=t.int32, device=self.device) if want_regions else None
+            rcounts = t.zeros(total, dtype=t.int32, device=self.device) if want_regions else None
         rc = self.lib.cpx_associate_batch(
             self.h, C.byref(params), offs.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(meta.ctypes.data), B,
             C.c_void_p(track_result.comps_dev.data_ptr()), C.c_void_p(track_result.info_dev.data_ptr()),

@@ -62,42 +62,36 @@ class Clip:
 
     def __init__(self, trackconfig, sourcefile, background=None, calc_stats=True, model=None, type="thermal",
                  fps=FRAMES_PER_SECOND):
-        self._id = Clip.CLIP_ID
-        Clip.CLIP_ID += 1
-        Track._track_id = 1
-        self.disable_background_subtraction = False
-        self.current_frame = -1
-        self.ffc_affected = False
-        self.crop_rectangle = None
-        self.region_history = []
-        self.active_tracks = set()
-        self.tracks = []
-        self.filtered_tracks = []
+        # The attribute set is the reference's (track/clip.py:56-120: extractor, classifier and metadata writers read
+        # them by name); grouped here by what owns them.
+        # -- identity and source --
+        self._id, Clip.CLIP_ID = Clip.CLIP_ID, Clip.CLIP_ID + 1
+        Track._track_id = 1                      # track ids restart with every clip
+        self.source_file, self.type, self.config = sourcefile, type, trackconfig
+        self.frames_per_second = fps
         self.from_metadata = False
-        self.video_start_time = None
-        self.location = None
-        self.frame_buffer = None
-        self.device = None
+        self.video_start_time = self.location = self.device = self.station_id = self.tags = None
+        # -- camera geometry and per-model thresholds (filled by set_res / set_model) --
+        self.res_x = self.res_y = self.crop_rectangle = None
+        self.camera_model = self.threshold_config = None
+        self.background_thresh = self.temp_thresh = None
+        self.track_min_delta = self.track_max_delta = None
+        # -- background state --
         self._background = None
         self.background_calculated = False
-        self.res_x = None
-        self.res_y = None
         self.background_frames = 0
-        self.config = trackconfig
-        self.frames_per_second = fps
-        self.station_id = None
-        self.calc_stats = calc_stats
-        self.source_file = sourcefile
-        self.stats = ClipStats()
-        self.camera_model = None
-        self.threshold_config = None
-        self.track_min_delta = None
-        self.track_max_delta = None
-        self.background_thresh = None
-        self.temp_thresh = None
+        self.disable_background_subtraction = False
+        # -- frames as they stream through --
+        self.current_frame = -1
+        self.frame_buffer = None
+        self.ffc_affected = False
         self.ffc_frames = []
-        self.tags = None
-        self.type = type
+        self.calc_stats = calc_stats
+        self.stats = ClipStats()
+        # -- what tracking produces --
+        self.region_history = []
+        self.active_tracks = set()
+        self.tracks, self.filtered_tracks = [], []
         self.thumb_info = None
         self.set_model(model)
         if background is not None:

@@ -623,72 +623,78 @@ class IRTrackExtractor(ClipTracker):
             track.set_end_s(clip.frames_per_second)
         return False
 
-    def inside_trap_bottom(self, track, scale=None):
-        """irtrackextractor.py:661-697."""
-        region = track.last_bound.copy()
-        if region.width < 60 or region.height < 40:
-            return False
+    # --- trap geometry (reference behaviour: irtrackextractor.py:660-778, pinned by tests/golden/irtrap_golden.json) ---
+    # The picture is 640 x 480 with y growing downwards; the two trap walls are lines in a y-up frame, so a box corner
+    # (x, y_picture) is probed at (x, 480 - y_picture).  Both tests share three steps: (1) boxes under 60 x 40 are not
+    # judged; (2) the first judged box fixes the side the track came from; (3) two corners of the box are probed against
+    # the wedge between the walls.  They differ in the margins of step 2, in which corners are probed, and in the verdict.
+    PICTURE_W, PICTURE_H = 640, 480
+    MIN_JUDGED_W, MIN_JUDGED_H = 60, 40
+
+    @staticmethod
+    def _entry_side(box, side_margin, bottom_margin=100, top_limit=300):
+        """Step 2: the Direction bits of the picture edges the box reaches into, else TOP / MIDDLE by how low it hangs."""
+        touched = ((box.left < side_margin, Direction.LEFT),
+                   (box.right > IRTrackExtractor.PICTURE_W - side_margin, Direction.RIGHT),
+                   (box.bottom > IRTrackExtractor.PICTURE_H - bottom_margin, Direction.BOTTOM))
+        bits = 0
+        for reaches, bit in touched:
+            if reaches:
+                bits |= bit
+        if bits:
+            return bits
+        return Direction.TOP if box.bottom < top_limit else Direction.MIDDLE
+
+    def _judged_box(self, track, side_margin):
+        """Steps 1 and 2 -> a copy of the track's last box, or None when it is too small to judge."""
+        box = track.last_bound.copy()
+        if box.width < self.MIN_JUDGED_W or box.height < self.MIN_JUDGED_H:
+            return None
         if track.direction == 0:
-            if region.left < 100:
-                track.direction |= Direction.LEFT
-            if region.right > (640 - 100):
-                track.direction |= Direction.RIGHT
-            if region.bottom > (480 - 100):
-                track.direction |= Direction.BOTTOM
-            if track.direction == 0:
-                if region.bottom < 300:
-                    track.direction |= Direction.TOP
-                else:
-                    track.direction = Direction.MIDDLE
-        p = (region.left, 480 - region.bottom)
-        inside = self.left_bottom.is_below(p) and self.left_bottom.is_right(p)
-        p = (region.right, 480 - region.bottom)
-        inside = inside and (self.right_bottom.is_below(p) and self.right_bottom.is_left(p))
-        x_diff = p[0] - self.right_bottom.x_res(p[1])
-        inside = inside and abs(x_diff) > 150
+            track.direction = self._entry_side(box, side_margin)
+        return box
+
+    def _wall_probes(self, x_at_left_wall, x_at_right_wall, y_picture):
+        """Step 3 -> (both probes inside the wedge, |x distance of each probe to its wall|).  A probe is inside when it is
+        not above its wall and on the wedge's side of it (a probe exactly on the left wall is inside, one exactly on the
+        right wall is not: Line.is_left is the strict comparison)."""
+        y = self.PICTURE_H - y_picture
+        pl, pr = (x_at_left_wall, y), (x_at_right_wall, y)
+        lw, rw = self.left_bottom, self.right_bottom
+        inside = (not lw.is_above(pl)) and (not lw.is_left(pl)) and (not rw.is_above(pr)) and rw.is_left(pr)
+        return inside, abs(pl[0] - lw.x_res(y)), abs(pr[0] - rw.x_res(y))
+
+    def inside_trap_bottom(self, track, scale=None):
+        """The box's BOTTOM corners sit inside the wedge and its right one is more than 150 px from the right wall."""
+        box = self._judged_box(track, side_margin=100)
+        if box is None:
+            return False
+        inside, _, to_right_wall = self._wall_probes(box.left, box.right, box.bottom)
+        inside = inside and to_right_wall > 150
         track.last_bound.in_trap = inside
         track.update_trapped_state()
         return inside
 
     def inside_trap_top(self, track, scale=None):
-        """irtrackextractor.py:699-778."""
-        SIDE_ALLOWANCE, TOP_ALLOWANCE, BOTTOM_ALLOWANCE = 150, 300, 100
-        region = track.last_bound.copy()
-        if region.width < 60 or region.height < 40:
+        """The box's TOP corners, crossed over (its right corner against the left wall, its left one against the right
+        wall), sit inside the wedge; the verdict then depends on the side the track came from."""
+        box = self._judged_box(track, side_margin=150)
+        if box is None:
             return False
-        if track.direction == 0:
-            if region.left < SIDE_ALLOWANCE:
-                track.direction |= Direction.LEFT
-            if region.right > (640 - SIDE_ALLOWANCE):
-                track.direction |= Direction.RIGHT
-            if region.bottom > (480 - BOTTOM_ALLOWANCE):
-                track.direction |= Direction.BOTTOM
-            if track.direction == 0:
-                if region.bottom < TOP_ALLOWANCE:
-                    track.direction |= Direction.TOP
-                else:
-                    track.direction = Direction.MIDDLE
-        p = (region.right, 480 - region.top)
-        inside = self.left_bottom.is_below(p) and self.left_bottom.is_right(p)
-        left_percent = abs(p[0] - self.left_bottom.x_res(p[1])) / region.width
-        p = (region.left, 480 - region.top)
-        inside = inside and self.right_bottom.is_below(p) and self.right_bottom.is_left(p)
-        right_percent = abs(p[0] - self.right_bottom.x_res(p[1])) / region.width
-        if not inside:
-            return False
-        in_trap = False
-        if left_percent < 0.5 and right_percent < 0.5:
-            return False
-        if track.direction & Direction.LEFT and region.left > 40 and left_percent > 0.5:
-            in_trap = True
-        elif track.direction & Direction.RIGHT and region.right < 580 and right_percent > 0.5:
-            in_trap = True
-        if track.direction == Direction.TOP and region.bottom > 300:
-            in_trap = True
-        if track.direction == Direction.BOTTOM and region.bottom < 480 - 50:
-            in_trap = True
-        if track.direction == Direction.MIDDLE and region.left > 40 and region.right < 580:
-            in_trap = True
+        inside, to_left_wall, to_right_wall = self._wall_probes(box.right, box.left, box.top)
+        share_l, share_r = to_left_wall / box.width, to_right_wall / box.width
+        if not inside or (share_l < 0.5 and share_r < 0.5):
+            return False                       # (the track's trapped state is left as it was, as the reference leaves it)
+        came = track.direction
+        clear_l, clear_r = box.left > 40, box.right < 580
+        verdicts = (
+            bool(came & Direction.LEFT) and clear_l and share_l > 0.5,
+            bool(came & Direction.RIGHT) and clear_r and share_r > 0.5,
+            came == Direction.TOP and box.bottom > 300,
+            came == Direction.BOTTOM and box.bottom < self.PICTURE_H - 50,
+            came == Direction.MIDDLE and clear_l and clear_r,
+        )
+        in_trap = any(verdicts)
         track.last_bound.in_trap = in_trap
         track.update_trapped_state()
         return in_trap

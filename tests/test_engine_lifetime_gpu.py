@@ -1,0 +1,110 @@
+"""Result lifetimes are enforced by the allocator, not by a warning.  TrackEngine allocates the outputs
+of track_batch / associate_batch / ir_detect / ir_resize_area under its own HIP stream: a result dropped while its kernels
+run gives its blocks back to THAT stream's pool, so an allocation on torch's default stream can never be handed memory a
+kernel is still writing, and a later call on the engine is ordered behind the kernels.  A result also keeps its engine's
+stream alive past TrackEngine.close()."""
+import gc
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(eng, n_clips=192, frames=120, seed=9, base=12):
+    """`n_clips` clips of `frames` frames on the device: `base` synthetic clips repeated (the generator is host code)."""
+    from cpx import synth
+
+    base = min(base, n_clips)
+    fr, _ = synth.make_batch(base, frames, seed=seed)
+    dev = eng.upload_frames(fr).repeat((n_clips + base - 1) // base, 1, 1)[: n_clips * frames].contiguous()
+    offs = (np.arange(n_clips + 1, dtype=np.int64) * frames).astype(np.int32)
+    return dev, offs, eng.make_meta(n_clips * frames)
+
+
+def test_dropped_result_does_not_leak_into_other_streams_allocations():
+    import torch
+
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3", device=0, max_frames=256)
+    frames, offs, meta = _batch(eng)
+    total = int(offs[-1])
+    held = eng.track_batch(frames, offs, meta, want_labels=True, want_filtered=True)
+    want_f, want_l, want_info = held.filtered(), held.labels(), held.info.copy()   # (synchronises)
+    shape_f = tuple(held.filtered_dev.shape)
+    for trial in range(4):
+        res = eng.track_batch(frames, offs, meta, want_labels=True, want_filtered=True)   # in flight: tens of milliseconds
+        del res                                                                            # dropped at once
+        gc.collect()
+        # an allocation-heavy co-runner on the default stream: tensors of exactly the sizes just freed, filled with a
+        # pattern.  Handed the dropped result's blocks, they would be written by the track kernels still running.
+        junk_f = [torch.full(shape_f, 7.0, dtype=torch.float32, device=eng.device) for _ in range(3)]
+        junk_l = [torch.full(shape_f, -3, dtype=torch.int32, device=eng.device) for _ in range(3)]
+        junk_c = [torch.full((total * eng.cap * 8,), -5, dtype=torch.int32, device=eng.device) for _ in range(2)]
+        again = eng.track_batch(frames, offs, meta, want_labels=True, want_filtered=True)
+        torch.cuda.synchronize()
+        eng.synchronize()
+        assert all(bool((j == 7.0).all()) for j in junk_f), trial
+        assert all(bool((j == -3).all()) for j in junk_l), trial
+        assert all(bool((j == -5).all()) for j in junk_c), trial
+        assert np.array_equal(again.filtered(), want_f) and np.array_equal(again.labels(), want_l), trial
+        assert np.array_equal(again.info, want_info), trial
+        del junk_f, junk_l, junk_c, again
+    # the association's outputs follow the same rule
+    a_held = eng.associate_batch(held, offs, meta)
+    tracks_want = [a_held.clip_tracks(b) for b in range(4)]
+    tmp = eng.associate_batch(held, offs, meta)
+    del tmp
+    junk = [torch.full((total * 16 * 14,), 11, dtype=torch.int32, device=eng.device) for _ in range(3)]
+    a2 = eng.associate_batch(held, offs, meta)
+    torch.cuda.synchronize()
+    eng.synchronize()
+    assert all(bool((j == 11).all()) for j in junk)
+    for b in range(4):
+        got = a2.clip_tracks(b)
+        assert len(got) == len(tracks_want[b])
+        for (r0, g0), (r1, g1) in zip(got, tracks_want[b]):
+            assert r0.tobytes() == r1.tobytes() and g0.tobytes() == g1.tobytes()
+    eng.close()
+
+
+def test_outputs_belong_to_the_engines_stream_pool():
+    """The blocks are the stream's: what a dropped result frees is what the engine's next call of the same shape gets, and
+    never what an equal-sized allocation on the default stream gets."""
+    import torch
+
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3", device=0, max_frames=64)
+    frames, offs, meta = _batch(eng, n_clips=8, frames=40)
+    r = eng.track_batch(frames, offs, meta, want_filtered=True)
+    ptr, shape = r.filtered_dev.data_ptr(), tuple(r.filtered_dev.shape)
+    del r
+    other = torch.empty(shape, dtype=torch.float32, device=eng.device)      # default stream
+    assert other.data_ptr() != ptr
+    r2 = eng.track_batch(frames, offs, meta, want_filtered=True)
+    assert r2.filtered_dev.data_ptr() == ptr
+    r2.check()
+    eng.close()
+
+
+def test_close_waits_for_live_results():
+    """A grown / sibling engine closed while a result of it is referenced keeps its handle (and stream) until the result
+    dies: the result stays readable, its memory goes back to a living stream, the handle is destroyed afterwards."""
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3", device=0, max_frames=64)
+    sib = eng.sibling(128)
+    frames, offs, meta = _batch(sib, n_clips=4, frames=30)
+    res = sib.track_batch(frames, offs, meta, want_filtered=True)
+    ref = eng.track_batch(frames, offs, meta, want_filtered=True).filtered()
+    sib.close()
+    assert sib.h and sib._close_deferred          # deferred: a result is alive
+    assert np.array_equal(res.filtered(), ref)
+    del res
+    gc.collect()
+    assert not sib.h and not sib._close_deferred  # destroyed when the last result died
+    sib.close()                                   # idempotent
+    eng.close()
+    assert not eng.h
