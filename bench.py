@@ -995,8 +995,8 @@ def main():
             allc["host_cores_visible"] = host
             allc["note"] = "one worker per usable CPU (scheduler affinity capped by the cgroup CPU quota)"
             cpu["cpu_baseline_all_cores"] = allc
-    # the file-fed leg formats its metadata text in worker processes (cpx.track.bulk.MetaPool): started here, while this
-    # process has not initialised the GPU (device_count() does not)
+    # the file-fed leg formats its metadata text in worker processes (cpx.track.bulk.MetaPool: spawned children that
+    # never touch the GPU): started here, ahead of this process's first call that initialises it
     meta_pool = None
     if args.meta_workers > 0 and args.stage == "e2e" and args.from_files > 0 and not args.no_extras and not args.denoise \
             and args.frame_size == 32 and not args.config4 and torch.cuda.device_count() > 0:

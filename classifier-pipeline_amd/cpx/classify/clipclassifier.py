@@ -132,8 +132,8 @@ class ClipClassifier:
         # cropped, classified and written without per-frame Python objects; a recording that fails is retried on its own
         from ..track.bulk import MetaPool, run_files_bulk
 
-        # a large directory: the metadata text is formatted by worker processes -- possible only while this process has
-        # not touched the GPU yet (MetaPool.make returns None afterwards; the models above were read, not uploaded)
+        # a large directory: the metadata text is formatted by worker processes (spawned children that never touch the
+        # GPU), started while this process has not touched it either: the models above were read, not uploaded
         pool = MetaPool.make() if self.meta_pool_min_files is not None and len(todo) >= self.meta_pool_min_files else None
         try:
             _, tracker = run_files_bulk(todo, self.config, device=local_rank if world > 1 else 0,

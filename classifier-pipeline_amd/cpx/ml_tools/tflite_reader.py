@@ -1,10 +1,13 @@
-"""Pure-Python reader of a released TFLite WR-ResNet model (.tflite): the flatbuffer is parsed here -- TensorFlow is not
-needed, only NumPy -- and the float32 graph is walked into the Keras-layout weights of cpx/ml_tools/wrresnet.py.
+"""Pure-Python reader of ONE kind of TFLite model: a float32 WR-ResNet graph (.tflite).  The flatbuffer is parsed here --
+TensorFlow is not needed, only NumPy -- and the graph is walked into the Keras-layout weights of cpx/ml_tools/wrresnet.py.
 
-The reference loads this artefact with LiteInterpreter (src/ml_tools/interpreter.py:520-560) and get_interpreter picks it
-by the file's suffix (interpreter.py:597-628); its CI downloads one (.github/workflows/release.yml:46).  Here
-get_interpreter on a `.tflite` path converts on load (load_tflite below); tools/tflite_to_npz.py writes the same arrays
-to an .npz.
+The reference loads any `.tflite` with LiteInterpreter (src/ml_tools/interpreter.py:520-560), picked by the file's suffix
+(interpreter.py:597-628).  This reader does NOT cover that: the artefact the reference's own CI classifies with
+(.github/workflows/release.yml:46 downloads `inc3-tflite-15122023.tar`) is an Inception-v3, another topology, and is
+REFUSED here with the operator that stopped the walk; get_interpreter then sends such a model to a model server, as it
+does every family but WR-ResNet (cpx/ml_tools/interpreter.py).  Only a WR-ResNet-22-4 exported to float32 TFLite is read:
+get_interpreter on such a path converts on load (load_tflite below); tools/tflite_to_npz.py writes the same arrays to an
+.npz.
 
 What is read: the float32 graph of WR-ResNet-22-4 (src/ml_tools/resnet/wr_resnet.py:5-98) as the TFLite converter
 writes it -- CONV_2D (filter OHWI, bias, fused ReLU: a convolution with the BatchNorm that follows it folded in), MUL +

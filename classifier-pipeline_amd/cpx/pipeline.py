@@ -344,6 +344,12 @@ class BatchPipeline:
             out.scores = t.cat([p.scores for p in live])
             out.best = t.cat([p.best for p in live])
             out.probs = t.cat([p.probs for p in live])
+        # a clip that outgrew its group's tables reported no tracks above (cpx_assoc_kernel: n_tracks = 0): as in the
+        # one-stream form it is tracked again alone on grown tables and its tracks join the batch's
+        out.overflowed = sorted(p.clip0 + b for p in parts for b in p.overflowed)
+        if out.overflowed:
+            with t.cuda.stream(eng.torch_stream()):
+                out = self._regrow(out, frames_dev, clip_offsets, meta, True, False)
         return out
 
 

@@ -837,6 +837,7 @@ class MetaPool:
         import multiprocessing.spawn as mp_spawn
 
         self.workers = int(workers)
+        self.broken = False     # set when a submit was refused (a worker died mid-run: BrokenProcessPool)
         self.pool = ProcessPoolExecutor(max_workers=self.workers, mp_context=multiprocessing.get_context("spawn"))
         # A spawned child normally re-imports the parent's __main__ -- i.e. runs the CALLER's script again, top to bottom,
         # unless that script hides its body behind `if __name__ == "__main__"` (a directory run started from such a script
@@ -867,7 +868,7 @@ class MetaPool:
     def usable(self):
         """False once a worker's start-up is known to have failed (import error, killed process): the caller then
         formats in-process instead of sending every group to a pool that answers with exceptions."""
-        return not any(f.done() and (f.cancelled() or f.exception() is not None) for f in self._ready)
+        return not self.broken and not any(f.done() and (f.cancelled() or f.exception() is not None) for f in self._ready)
 
     @staticmethod
     def make(workers=None):
@@ -879,13 +880,29 @@ class MetaPool:
             # with two, 267-325 k with four); a rank of a shared node gets fewer
             workers = max(1, min(2, host_threads_per_rank(16) // 4))
         try:
+            import torch
+
+            if torch.cuda.is_initialized():
+                # the workers are spawned children (fresh processes, nothing of HIP inherited), so this is allowed; callers
+                # nevertheless start the pool BEFORE their first GPU work where they can (TrackExtractor.extract,
+                # bench.py), and this line makes the other case visible
+                logging.info("metadata worker pool started from a process that has initialised the GPU")
             return MetaPool(workers)
         except Exception as e:  # noqa: BLE001 -- no pool is a slower run, not a failed one
             logging.warning("metadata worker pool not started (%s: %s): formatting in-process", type(e).__name__, e)
             return None
 
     def submit(self, config_blob, job):
-        return self.pool.submit(_worker_format, config_blob, job)
+        """-> the job's future, or None when the executor refuses work (a worker killed mid-run breaks the whole
+        ProcessPoolExecutor; every later submit raises at once): the pool is then marked unusable and the caller formats
+        in-process."""
+        try:
+            return self.pool.submit(_worker_format, config_blob, job)
+        except Exception as e:  # noqa: BLE001 -- BrokenProcessPool, RuntimeError after shutdown
+            logging.warning("metadata worker pool refused a job (%s: %s): formatting in-process from here on",
+                            type(e).__name__, e)
+            self.broken = True
+            return None
 
     def close(self):
         self.pool.shutdown(wait=True, cancel_futures=True)
@@ -1159,9 +1176,11 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
                    existing=existing, indent=indent, classify=bool(classifiers), model_meta=model_meta,
                    tracking_time=(time.time() - ctx["t0"]) / max(ctx["n_ok"], 1))
         if meta_pool is not None and meta_pool.usable():   # formatted by a worker process; collected when the batch closes
-            ctx["futures"].append(meta_pool.submit(config_blob, job))
-            tracker.timings["host_submit_s"] = tracker.timings.get("host_submit_s", 0.0) + time.time() - th
-            return
+            fut = meta_pool.submit(config_blob, job)
+            if fut is not None:
+                ctx["futures"].append(fut)
+                tracker.timings["host_submit_s"] = tracker.timings.get("host_submit_s", 0.0) + time.time() - th
+                return
         got_texts, got_retry, frames, _ = format_group(tracker, job)
         texts.update(got_texts)
         retry.update(got_retry)

@@ -59,6 +59,14 @@ class TrackExtractor:
             from ..sharding import pin_to_gpu_numa
 
             logging.info("rank %d: %s", rank, pin_to_gpu_numa(local_rank))
+        # a large directory: the metadata text of the file-fed path is formatted by worker processes.  They are spawned
+        # children that never touch the GPU; they are started here, BEFORE this process's first GPU work (the .y4m
+        # recordings below run on the device), so that nothing of HIP exists in the parent when they start
+        pool = None
+        if not self.retrack and self.meta_pool_min_files is not None and len(todo) >= self.meta_pool_min_files:
+            from .bulk import MetaPool
+
+            pool = MetaPool.make()
         for path in shard_files(gray, rank, world):
             try:
                 extract_file(path, self.config, self.cache_to_disk, self.retrack, to_stdout)
@@ -73,11 +81,8 @@ class TrackExtractor:
         # the file-fed path at device speed (cpx/track/bulk.py): gzip inflate, section index, decode, tracking,
         # end-of-clip statistics and thumbnails on the device for `batch_files` recordings at a time, the next batch
         # read from disk meanwhile; a recording that fails is logged, retried on its own and otherwise skipped
-        from .bulk import MetaPool, extract_files_bulk
+        from .bulk import extract_files_bulk
 
-        # a large directory: the metadata text is formatted by worker processes (started here, before this process has
-        # touched the GPU -- MetaPool.make returns None afterwards and the stage stays in-process)
-        pool = MetaPool.make() if self.meta_pool_min_files is not None and len(todo) >= self.meta_pool_min_files else None
         try:
             _, tracker = extract_files_bulk(todo, self.config, to_stdout=to_stdout, device=device,
                                             batch_files=self.batch_files, meta_pool=pool)

@@ -900,7 +900,10 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
     a.planes = h->cnn_math == CPX_CNN_MATH_BF16X2 ? 2 : 3;
     // fp16x2: the two-plane layers run on fp16 planes, with the three-plane kernel launched behind as the guarded
     // rerun (it returns at once unless a scaled activation left fp16's range); every other layer as bf16x3
-    const bool half = h->cnn_math == CPX_CNN_MATH_FP16X2 && cpx::conv_bf3_two_planes(a);
+    // (an output that aliases the residual or the input -- an in-place add -- must not be written twice: the guarded
+    // rerun would read what the fp16 pass has already stored.  Such a call runs bf16x3 directly.)
+    const bool aliased = a.out == a.residual || a.out == a.in;
+    const bool half = h->cnn_math == CPX_CNN_MATH_FP16X2 && cpx::conv_bf3_two_planes(a) && !aliased;
     const bool planes_out = h->cnn_math == CPX_CNN_MATH_FP16X2 && hf && hf->out_planes;
     const bool rerun = hf && hf->rerun_only;  // (any split-operand layer: the 8-channel one of a fused first block too)
     if (half || planes_out || rerun) {
@@ -1533,7 +1536,7 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
       hf.rerun_only = false;
       // ... the stage's first block too (8 input channels per group; its 1x1 shortcut inside the second convolution)
       const bool first8 = d == 0 && s == 1 && c_in / p.groups == 8 && h->block_fusion >= 2 && h->fuse_shortcut;
-      if (h->cnn_math == CPX_CNN_MATH_FP16X2 && h->block_fusion && s == 1 && (c_in == f || first8) && b.in_scale && cnn->split_of(b.wa) &&
+      if (h->cnn_math == CPX_CNN_MATH_FP16X2 && h->block_fusion && s == 1 && ((d != 0 && c_in == f) || first8) && b.in_scale && cnn->split_of(b.wa) &&
           cnn->split_of(b.wb) && c_in % p.groups == 0 && f % p.groups == 0) {
         cpx::ConvArgs ca{}, cb{};
         ca.N = N; ca.H = hh; ca.W = ww; ca.Ho = hh; ca.Wo = ww; ca.Cin = f; ca.Cout = f; ca.groups = p.groups; ca.ksize = 3; ca.stride = 1;

@@ -619,6 +619,13 @@ int cpx_conv2d(cpx_handle* h, const cpx_conv_desc* desc);
  *                        channels per group (stage 2 of WR-ResNet-22-4) run as ONE launch each, the tensor between
  *                        their two convolutions kept on chip (environment CPX_CNN_BLOCK_FUSION=0|1|2, default 2).
  *                        Every other layer as BF16X3.
+ *                        Two conditions on the 2^-22 figure and on the rerun, both met inside cpx_cnn_forward and the
+ *                        caller's to meet for a bare cpx_conv2d (activation scale 1): (1) the low plane is an fp16
+ *                        too -- an activated input below 2^-3 (times the layer's scale) keeps fewer than 11 low bits,
+ *                        absolute error up to 2^-25, and a value below about 3e-8 contributes nothing; a caller whose
+ *                        activations are that small selects BF16X3; (2) no aliasing: out_dev must not be residual_dev
+ *                        or in_dev.  cpx_conv2d detects that case and runs the layer as BF16X3 directly (the rerun would
+ *                        otherwise add a residual the fp16 pass has already overwritten).
  * The default can be preset with the environment variable CPX_CNN_MATH=f32|bf16x3|bf16x2|fp16x2 (read by cpx_create). */
 #define CPX_CNN_MATH_F32 0
 #define CPX_CNN_MATH_BF16X3 1

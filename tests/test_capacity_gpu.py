@@ -226,7 +226,8 @@ def test_batch_pipeline_regrows_the_clip_that_overflowed(eng):
     offs = (np.arange(5) * T).astype(np.int32)
     meta = eng.make_meta(4 * T)
     x = torch.rand((8, 160, 160, 2), device=eng.device) * 255
-    net = wr.WRResNetDevice(eng, wr.calibrate_bn_device(eng, wr.random_weights(17, seed=2), x), 17)
+    w = wr.calibrate_bn_device(eng, wr.random_weights(17, seed=2), x)
+    net = wr.WRResNetDevice(eng, w, 17)
     pipe = BatchPipeline(eng, net, n_labels=17, fp_index=4, cnn_chunk=64)
     res = pipe.run(frames, offs, meta)
     assert res.overflowed == [1] and [r[0] for r in res.regrown] == [1]
@@ -248,4 +249,20 @@ def test_batch_pipeline_regrows_the_clip_that_overflowed(eng):
     r3 = plain.run(fr3, (np.arange(4) * T).astype(np.int32), meta[: 3 * T])
     others = res.scores[torch.from_numpy(~mine).to(res.scores.device)]
     assert torch.equal(others, r3.scores)
+    # the overlapped form (sub_batches > 1, the network on a second engine = a second stream) regrows too: the crowded
+    # clip sits in the first of two groups; same tracks, same scores as the one-stream run
+    from cpx.engine import TrackEngine
+
+    ceng = TrackEngine(model="lepton3", device=0, max_frames=45)
+    net2 = wr.WRResNetDevice(ceng, w, 17)
+    pipe2 = BatchPipeline(eng, net2, n_labels=17, fp_index=4, cnn_chunk=64)
+    res2 = pipe2.run(frames, offs, meta, sub_batches=2)
+    assert res2.overflowed == [1] and [r[0] for r in res2.regrown] == [1]
+    tc2 = res2.track_clip.cpu().numpy()
+    order, order2 = np.lexsort((tc[:, 1], tc[:, 0])), np.lexsort((tc2[:, 1], tc2[:, 0]))
+    assert np.array_equal(tc[order], tc2[order2])
+    assert torch.equal(res.scores[torch.from_numpy(order).to(res.scores.device)],
+                       res2.scores[torch.from_numpy(order2).to(res2.scores.device)])
+    net2.close()
+    ceng.close()
     net.close()
