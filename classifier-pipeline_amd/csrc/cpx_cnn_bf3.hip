@@ -1989,6 +1989,13 @@ static size_t bf3w_image2_bytes(const ConvArgs& a) { return (size_t)a.groups * (
 static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   if (a.planes == 2 && a.half) {  // the fp16 image lies behind the two bf16 ones
     const uint4* wh = wimg + (bf3w_image3_bytes(a) + bf3w_image2_bytes(a)) / 16;
+    // 64 -> 64 channels per group: weights in registers (cpx_cnn_rw.hip) -- but for the launch that carries a stage's 1x1
+    // shortcut: that side product (strided float32 operands) stays with this kernel, measured faster than the shortcut as a
+    // launch of its own + conv_rw64_kernel with its output as residual (profiles/r06_conv_rw_experiments.md)
+    if (conv_rw_layer(a) && !a.in_planes && !a.out_planes && !a.sc_in) {
+      const int rc = launch_conv_rw64(a, wh, s);
+      if (rc != -2) return rc;
+    }
     if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1, 2, true>(a, wh, s);
     return launch_bf3w_t<1, 1, 2, true>(a, wh, s);
   }
@@ -2135,7 +2142,7 @@ bool conv_bf3_can_store_planes(const ConvArgs& a) {
   if (a.Cout / a.groups == 128) return !flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256);
   return true;
 }
-bool conv_bf3_can_load_planes(const ConvArgs& a) { return bf3w_layer(a); }
+bool conv_bf3_can_load_planes(const ConvArgs& a) { return bf3w_layer(a) && !conv_rw_layer(a); }  // (conv_rw64_kernel stages float32)
 // where the fp16 image and its scales lie inside a two-plane layer's weight images
 static size_t half_image_offset(const ConvArgs& a) {
   if (bf3_c8(a)) return c8_image3_bytes(a);
