@@ -70,6 +70,9 @@ constexpr int CT = 256;
 
 template <int KC, int NTN, int S, int KS, int NTM, int TW>
 __global__ __launch_bounds__(CT) void conv_mfma_kernel(ConvArgs a) {
+  // (the guarded rerun of a fp16x2 layer that has no split-operand kernel -- the stride-3 convolution: nothing to do unless the
+  // layer left fp16's range)
+  if (a.guard != nullptr && *a.guard == 0) return;
   constexpr int TB = 128 / TW;        // rows of a band
   constexpr int WR = 32 / TW;         // rows of a wave's 32-pixel tile
   constexpr int TH = TB * NTM;        // output tile of a workgroup: NTM bands

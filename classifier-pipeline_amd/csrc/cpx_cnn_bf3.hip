@@ -1993,7 +1993,7 @@ static int launch_bf3w(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
     // shortcut: that side product (strided float32 operands) stays with this kernel, measured faster than the shortcut as a
     // launch of its own + conv_rw64_kernel with its output as residual (profiles/r06_conv_rw_experiments.md)
     if (conv_rw_layer(a) && !a.in_planes && !a.out_planes && !a.sc_in) {
-      const int rc = launch_conv_rw64(a, wh, s);
+      const int rc = launch_conv_rw(a, wh, s);
       if (rc != -2) return rc;
     }
     if (CPX_BF3W_NH == 2 && a.Cout / a.groups == 64) return launch_bf3w_t<2, 1, 2, true>(a, wh, s);
@@ -2105,10 +2105,18 @@ static bool bf3w_layer(const ConvArgs& a) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   return CPX_BF3W && a.ksize == 3 && a.stride == 1 && cin_g >= KW && (cin_g % KW) == 0 && (cout_g == 32 || cout_g == 64) && cin_g <= 64;
 }
+// the strided first convolutions conv_rw_kernel takes in fp16x2 (cpx_cnn_rw.hip): the stride-2 one has this file's kernels for
+// the other modes and the rerun; the stride-3 one has none here -- every launch of it that is not conv_rw_kernel's goes to the
+// float32 kernel (launch_conv, which honours ConvArgs::guard), as all of them did before round 6
+static bool rw_stride3(const ConvArgs& a) { return conv_rw_kind(a) == 3; }
+static bool rw_stride2(const ConvArgs& a) { return conv_rw_kind(a) == 2; }
+// [g][chunk of 32][ky][plane 2][kx][quarter][cout_g] of 16-byte entries (split_weights32_kernel)
+static size_t rw_image_bytes(const ConvArgs& a) { return (size_t)a.groups * (a.Cin / a.groups / KW) * 3 * 24 * (a.Cout / a.groups) * 16; }
 bool conv_bf3_supported(const ConvArgs& a) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
   if (a.ksize == 3 && a.stride == 1 && bf3_c8(a)) return true;
   if (bf3_strided(a)) return true;
+  if (rw_stride3(a)) return true;
   return a.ksize == 3 && a.stride == 1 && cin_g >= KC && (cin_g % KC) == 0 && (cout_g == 32 || cout_g == 64 || cout_g == 128);
 }
 // three-plane image of the layers conv_bf3_kernel / conv_bf3flat_kernel take: [g][chunk of 16][3][9][2][cout_g]
@@ -2127,12 +2135,14 @@ static size_t scales_bytes(const ConvArgs& a) { return ((size_t)2 * a.Cout * siz
 static size_t c8_image3_bytes(const ConvArgs& a) { return (size_t)a.groups * 30 * (a.Cout / a.groups) * 16; }
 static size_t c8_half_bytes(const ConvArgs& a) { return (size_t)a.groups * B8_WIMG * 16; }
 size_t conv_bf3_weight_bytes(const ConvArgs& a) {
+  if (rw_stride3(a)) return rw_image_bytes(a) + scales_bytes(a);
+  if (rw_stride2(a) && flat_layer(a)) return image3_bytes(a) + 2 * (image3_bytes(a) / 3 * 2) + scales_bytes(a) + rw_image_bytes(a);
   if (bf3_c8(a)) return c8_image3_bytes(a) + c8_half_bytes(a) + scales_bytes(a);
   // the images of the three math modes one after the other: three bf16 planes, two bf16 planes, two fp16 planes, scales
   if (bf3w_layer(a)) return bf3w_image3_bytes(a) + 2 * bf3w_image2_bytes(a) + scales_bytes(a);
   return image3_bytes(a) + (flat_layer(a) ? 2 * (image3_bytes(a) / 3 * 2) + scales_bytes(a) : 0);
 }
-bool conv_bf3_two_planes(const ConvArgs& a) { return bf3w_layer(a) || flat_layer(a); }
+bool conv_bf3_two_planes(const ConvArgs& a) { return bf3w_layer(a) || flat_layer(a) || rw_stride3(a); }
 // producer-side split (ConvArgs::out_planes / in_planes): the kernels whose epilogue can store the next layer's fp16
 // planes -- conv_bf3w_kernel and conv_bf3_kernel, i.e. every split-operand launch but the flattened one -- and the one
 // whose staging can take them (conv_bf3w_kernel in fp16x2).  `a` describes the launch (H, W, Ho, Wo filled in).
@@ -2145,15 +2155,28 @@ bool conv_bf3_can_store_planes(const ConvArgs& a) {
 bool conv_bf3_can_load_planes(const ConvArgs& a) { return bf3w_layer(a) && !conv_rw_layer(a); }  // (conv_rw64_kernel stages float32)
 // where the fp16 image and its scales lie inside a two-plane layer's weight images
 static size_t half_image_offset(const ConvArgs& a) {
+  if (rw_stride3(a)) return 0;
   if (bf3_c8(a)) return c8_image3_bytes(a);
   return bf3w_layer(a) ? bf3w_image3_bytes(a) + bf3w_image2_bytes(a) : image3_bytes(a) + image3_bytes(a) / 3 * 2;
 }
+// the 32-channel-chunk fp16 image conv_rw_kernel reads of the stride-2 layer: behind this file's images and the scales
+static size_t rw2_image_offset(const ConvArgs& a) { return image3_bytes(a) + 2 * (image3_bytes(a) / 3 * 2) + scales_bytes(a); }
 static size_t scales_offset(const ConvArgs& a) {
+  if (rw_stride3(a)) return rw_image_bytes(a);
   if (bf3_c8(a)) return c8_image3_bytes(a) + c8_half_bytes(a);
   return bf3w_layer(a) ? bf3w_image3_bytes(a) + 2 * bf3w_image2_bytes(a) : image3_bytes(a) + 2 * (image3_bytes(a) / 3 * 2);
 }
 void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
   const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  if (rw_stride3(a)) {
+    const size_t total32 = (size_t)a.groups * (cin_g / KW) * 36 * cout_g;
+    float* ws = reinterpret_cast<float*>(reinterpret_cast<char*>(wimg) + scales_offset(a));
+    hipLaunchKernelGGL(weight_scales_kernel, dim3((unsigned)((a.Cout + 255) / 256)), dim3(256), 0, s, a.weights, ws, ws + a.Cout,
+                       a.groups, 9 * cin_g, cout_g);
+    hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
+                       reinterpret_cast<uint4*>(wimg), a.groups, cin_g, cout_g, 2, ws);
+    return;
+  }
   if (bf3_c8(a)) {
     const size_t total8 = (size_t)a.groups * 10 * cout_g;
     hipLaunchKernelGGL(split_weights8_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, a.weights,
@@ -2189,11 +2212,17 @@ void launch_split_weights(const ConvArgs& a, void* wimg, hipStream_t s) {
                        reinterpret_cast<uint4*>(wimg) + image3_bytes(a) / 16, a.groups, cin_g, cout_g, 2, nullptr);
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.weights,
                        reinterpret_cast<uint4*>(wimg) + half_image_offset(a) / 16, a.groups, cin_g, cout_g, 2, ws);
+    if (rw_stride2(a)) {
+      const size_t total32 = (size_t)a.groups * (cin_g / KW) * 36 * cout_g;
+      hipLaunchKernelGGL(split_weights32_kernel, dim3((unsigned)((total32 + 255) / 256)), dim3(256), 0, s, a.weights,
+                         reinterpret_cast<uint4*>(wimg) + rw2_image_offset(a) / 16, a.groups, cin_g, cout_g, 2, ws);
+    }
   }
 }
 int launch_conv_bf3(const ConvArgs& a_in, const void* wimg, hipStream_t s) {
   ConvArgs a = a_in;
   const int cout_g = a.Cout / a.groups;
+  if (a.stride == 3 && rw_stride3(a) && !a.half) return launch_conv(a, s);  // (the float32 kernel: also the guarded rerun)
   if (a.half) {  // CPX_CNN_MATH_FP16X2: the two-plane layers only, with the network's overflow word
     if (a.planes != 2 || !conv_bf3_two_planes(a) || a.ovf == nullptr) return -2;
     if (a.in_planes && !conv_bf3_can_load_planes(a)) return -2;
@@ -2208,9 +2237,19 @@ int launch_conv_bf3(const ConvArgs& a_in, const void* wimg, hipStream_t s) {
   if (bf3_c8(a)) return launch_bf3_t<1, 1, CPX_BF3_NB_S2, CPX_BF3_TW_S2, CPX_BF3_CT_S2, true>(a, w, s);
   if (a.stride == 2) {
     if (!bf3_strided(a)) return -2;
+    if (a.planes == 2 && a.half && rw_stride2(a) && flat_layer(a) && !a.out_planes && !a.in_planes) {
+      const int rc = launch_conv_rw(a, w + rw2_image_offset(a) / 16, s);
+      if (rc != -2) return rc;
+    }
     if (a.planes == 2 && a.half) return launch_bf3_t<2, 2, 2, 16, 512, false, 2, true>(a, w + half_image_offset(a) / 16, s);
     if (a.planes == 2 && flat_layer(a)) return launch_bf3_t<2, 2, 2, 16, 512, false, 2>(a, w + image3_bytes(a) / 16, s);
     return launch_bf3_t<2, 2, 2, 16, 512>(a, w, s);
+  }
+  if (a.stride == 3 && a.half && rw_stride3(a)) {
+    const int rc = launch_conv_rw(a, w + half_image_offset(a) / 16, s);
+    // (a form conv_rw_kernel does not take -- a residual on a strided layer: the float32 kernel computes it here, and its
+    // guarded twin behind finds the overflow word clear)
+    return rc == -2 ? launch_conv(a, s) : rc;
   }
   if (a.stride == 3) return bf3_strided(a) ? launch_bf3_t<CPX_BF3_NTN_ST3, 3, 1, 16, 256>(a, w, s) : -2;
   if (a.stride != 1) return -2;

@@ -79,58 +79,72 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 __device__ __forceinline__ int div_magic(int n, unsigned long long m) { return (int)(((unsigned long long)n * m) >> 42); }
 
-constexpr int RW_TW = 16, RW_TH = 16, RW_PW = 18, RW_NPX = 18 * 18;
-constexpr int RW_NPXP = 354;                   // pixels per (plane, quarter pair) region: the 324 of the patch + the 28 slots the last staging round's idle
-                                               // threads write (no predicate in the stream), 354 * 32 B = 64 mod 128 (cpx_cnn_bf3.hip: W_NPXP)
-constexpr int RW_BUF = 2 * 2 * RW_NPXP * 2;    // 16-byte entries of one 32-channel chunk: [plane][quarter pair][pixel][2]
-constexpr int RW_CG = 64;                      // channels per group, in and out
+constexpr int RW_TW = 16;                      // output columns of a tile = the pixels of one B fragment
 constexpr int RW_CT = 256;                     // threads: four waves, one per SIMD
-constexpr int RW_ROWS = 16;                    // output rows of a wave: the whole tile
-constexpr int RW_PPI = RW_CT / 8;              // pixels per staging round
-constexpr int RW_NP = 11;                      // staging items per thread and chunk: 324 pixels x 8 pieces = 2,592 = 10 x 256 + 32
-constexpr int RW_STEPS = 3 * (RW_ROWS + 2);    // (kx, patch row) steps of a chunk
+constexpr int RW_PPI = RW_CT / 8;              // patch pixels per staging round (eight 16-byte pieces per pixel and chunk)
+constexpr int RW_WC = 64;                      // output channels of a workgroup: 16 per wave
 
-// LDS: [chunk buffer 0][chunk buffer 1][BatchNorm scale 64, shift 64][per-channel epilogue parameters: 3 x 64]
+// Geometry of an instantiation.  S: stride; NCH: 32-channel chunks of the group's input channels; ROWS: output rows of a tile
+// (every wave computes all of them for its 16 channels).
+template <int S, int NCH, int ROWS>
+struct RwGeo {
+  static constexpr int PW = 15 * S + 3, PH = (ROWS - 1) * S + 3, NPX = PH * PW;   // the staged patch of one tile
+  static constexpr int NP = (NPX * 8 + RW_CT - 1) / RW_CT;                           // staging items per thread and chunk
+  // pixels per (plane, quarter pair) region: the patch + the slots the last staging round's idle threads write (no
+  // predicate in the stream); NPXP * 32 B = 64 mod 128 (cpx_cnn_bf3.hip: W_NPXP)
+  static constexpr int NPXP = (NP * RW_PPI + 3) / 4 * 4 + 2;
+  static constexpr int BUF = 2 * 2 * NPXP * 2;                                       // 16-byte entries of one chunk buffer
+  static constexpr int STEPS = 3 * PH;                                               // (kx, patch row) steps of a chunk
+  static constexpr int CING = 32 * NCH;
+  static constexpr size_t LDS = (size_t)2 * BUF * 16 + (size_t)(2 * CING + 3 * RW_WC) * sizeof(float);
+};
+
+// LDS: [chunk buffer 0][chunk buffer 1][BatchNorm scale, shift of the group's input channels][per-channel epilogue parameters: 3 x 64]
 // BN: the layer has a BatchNorm + ReLU prologue (a template parameter, like every other condition inside the product stream:
 // a branch there ends the scheduling region, and with one wave per SIMD nothing else fills the matrix pipe meanwhile)
 // RES: the layer adds a residual tensor (requested into registers beside the tile's last products, added in the epilogue)
-template <bool BN, bool RES>
-__global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_rw64_kernel(ConvArgs a, const uint4* __restrict__ wimg, RwTiles td) {
-  if (*a.ovf != 0) return;  // (the guarded three-plane launch follows)
+template <int S, int NCH, int ROWS, bool BN, bool RES>
+__global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_rw_kernel(ConvArgs a, const uint4* __restrict__ wimg, RwTiles td) {
+  using G = RwGeo<S, NCH, ROWS>;
+  constexpr int PW = G::PW, NPX = G::NPX, NP = G::NP, NPXP = G::NPXP, BUF = G::BUF, STEPS = G::STEPS, CING = G::CING, PH = G::PH;
+  if (*a.ovf != 0) return;  // (the guarded rerun follows)
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
   uint4* s_buf = lds4;
-  float* s_bn = reinterpret_cast<float*>(lds4 + 2 * RW_BUF);
-  float* s_par = s_bn + 2 * RW_CG;  // [os 64][ob 64][rs 64]
+  float* s_bn = reinterpret_cast<float*>(lds4 + 2 * BUF);
+  float* s_par = s_bn + 2 * CING;  // [os 64][ob 64][rs 64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
-  const int ct = wave;  // the wave's 16-column tile of the group's 64 output channels
-  const int g = blockIdx.y;
+  const int ct = wave;  // the wave's 16-column tile of the workgroup's 64 output channels
+  const int cout_g = a.Cout / a.groups, nhalf = cout_g / RW_WC;
+  const int g = blockIdx.y / nhalf, half = blockIdx.y - g * nhalf;  // group; which 64 of its output channels
   constexpr bool has_bn = BN;
 
-  // ---- the wave's weights: fp16 image [g][chunk][ky][plane][kx][quarter][64] of 16-byte entries (split_weights32_kernel) ----
-  u32x4 Wr[2][9][2];
+  // ---- the wave's weights: fp16 image [g][chunk][ky][plane][kx][quarter][cout_g] of 16-byte entries (split_weights32_kernel) ----
+  u32x4 Wr[NCH][9][2];
   {
-    const u32x4* wg = reinterpret_cast<const u32x4*>(wimg) + (size_t)g * 2 * 3 * 24 * RW_CG + (q * RW_CG + ct * 16 + i16);
+    const u32x4* wg = reinterpret_cast<const u32x4*>(wimg) + (size_t)g * NCH * 3 * 24 * cout_g + (q * cout_g + half * RW_WC + ct * 16 + i16);
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int p = 0; p < 2; ++p) Wr[c][ky * 3 + kx][p] = wg[((c * 3 + ky) * 24 + (p * 3 + kx) * 4) * RW_CG];
+          for (int p = 0; p < 2; ++p) Wr[c][ky * 3 + kx][p] = wg[(size_t)((c * 3 + ky) * 24 + (p * 3 + kx) * 4) * cout_g];
   }
-  if (tid < RW_CG) {
-    const int ch = g * RW_CG + tid;
-    // relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly
-    s_bn[tid] = has_bn ? a.in_scale[ch] * a.act_scale : a.act_scale;
-    s_bn[RW_CG + tid] = has_bn ? a.in_shift[ch] * a.act_scale : 0.0f;
+  if (tid < CING) {  // relu(x s + b) 2^k = relu(x (s 2^k) + b 2^k), exactly
+    const int ci = g * CING + tid;
+    s_bn[tid] = has_bn ? a.in_scale[ci] * a.act_scale : a.act_scale;
+    s_bn[CING + tid] = has_bn ? a.in_shift[ci] * a.act_scale : 0.0f;
+  }
+  if (tid < RW_WC) {
+    const int ch = g * cout_g + half * RW_WC + tid;
     float os = a.w_unscale[ch] * a.act_unscale;  // (powers of two: exact)
     if (a.out_scale) os *= a.out_scale[ch];
     float ob = a.out_shift ? a.out_shift[ch] : 0.0f;
     if (a.sc_in && a.sc_bias) ob += a.sc_bias[ch];
     s_par[tid] = os;
-    s_par[RW_CG + tid] = ob;
-    s_par[2 * RW_CG + tid] = a.w_scale[ch] * a.act_scale;  // what the accumulators are scaled by: the residual's and the shortcut's factor
+    s_par[RW_WC + tid] = ob;
+    s_par[2 * RW_WC + tid] = a.w_scale[ch] * a.act_scale;  // what the accumulators are scaled by: the fused shortcut's factor
   }
 
   // ---- tiles: every XCD walks its own contiguous eighth of the tile space (conv_block32_kernel) ----
@@ -141,33 +155,41 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     ox_ = (tile - qd * td.tiles_x) * RW_TW;
     tile = qd;
     qd = div_magic(tile, td.m_ty);
-    oy_ = (tile - qd * td.tiles_y) * RW_TH;
+    oy_ = (tile - qd * td.tiles_y) * ROWS;
     n_ = qd;
   };
   int t = blockIdx.x;
   while (t < 8 * per_xcd && tile_of(t) >= td.total) t += gridDim.x;
   if (t >= 8 * per_xcd) return;
-  int n0, oy0, ox0, n1 = 0, oy1 = 0, ox1 = 0;
+  // the next tile of this workgroup, or (none left) the given one again: the last tiles stage themselves once more -- into
+  // registers and a buffer nobody reads -- rather than branch in the stream
+  auto advance = [&](int& n_, int& oy_, int& ox_) {
+    t += gridDim.x;
+    const bool more = t < 8 * per_xcd && tile_of(t) < td.total;  // (a workgroup's tiles ascend within its XCD's eighth)
+    if (more) decode(tile_of(t), n_, oy_, ox_);
+    return more;
+  };
+  int n0, oy0, ox0, n1, oy1, ox1, n2, oy2, ox2;
   decode(tile_of(t), n0, oy0, ox0);
 
   // ---- staging: item i of a thread = one 16-byte piece (4 channels) of patch pixel (tid >> 3) + 32 i, piece tid & 7.
   //      What depends on the thread alone is computed once per launch: each item's patch row / column, the byte offset of its
   //      LDS slot (the items of a thread lie 1 KB apart: immediate offsets of one base per buffer), the piece's BatchNorm
-  //      parameters of both chunks.  Per item and tile that leaves: two clamps (v_med3_i32), three multiply-adds for the
-  //      address, two compares for the padding ----
-  u32x4 pre_p[RW_NP];
+  //      parameters.  Per item and tile that leaves: two clamps (v_med3_i32), three multiply-adds for the address, two
+  //      compares for the padding ----
+  u32x4 pre_p[NP];
   const int q8 = tid & 7;
-  int ipos[RW_NP];  // patch row << 8 | column of item i (the slots past the patch repeat its last pixel)
+  int ipos[NP];  // patch row << 8 | column of item i (the slots past the patch repeat its last pixel)
 #pragma unroll
-  for (int i = 0; i < RW_NP; ++i) {
-    const int px = min((tid >> 3) + RW_PPI * i, RW_NPX - 1);
-    const int py = (px * 3641) >> 16;  // px / 18 for px < 324
-    ipos[i] = (py << 8) | (px - py * RW_PW);
+  for (int i = 0; i < NP; ++i) {
+    const int px = min((tid >> 3) + RW_PPI * i, NPX - 1);
+    const int py = px / PW;
+    ipos[i] = (py << 8) | (px - py * PW);
   }
   // channels 4 q8 .. 4 q8 + 3 of a chunk: quarter pair q8 >> 2, 8-byte slot q8 & 3 of the pixel's 32 bytes
-  const unsigned st_base = (unsigned)((((q8 >> 2) * RW_NPXP + (tid >> 3)) * 4 + (q8 & 3)) * 8);
-  f32x4 psc[2], psh[2];  // filled behind the barrier that publishes s_bn
-  const unsigned coff0 = (unsigned)(g * RW_CG + 4 * q8);
+  const unsigned st_base = (unsigned)((((q8 >> 2) * NPXP + (tid >> 3)) * 4 + (q8 & 3)) * 8);
+  f32x4 psc[NCH], psh[NCH];  // filled behind the barrier that publishes s_bn
+  const unsigned coff0 = (unsigned)(g * CING + 4 * q8);
   auto med3 = [](int x, int lo, int hi) __attribute__((always_inline)) {
     int r;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "s"(hi));
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   const int Hm1 = a.H - 1, Wm1 = a.W - 1;
   auto issue_item = [&](const int i, const int c, const int n_, const int oy_, const int ox_) __attribute__((always_inline)) {
     const float* in_n = a.in + (size_t)n_ * a.H * a.W * a.Cin;  // (uniform)
-    const int iy = oy_ - 1 + (ipos[i] >> 8), ix = ox_ - 1 + (ipos[i] & 0xFF);
+    const int iy = oy_ * S - a.pad_top + (ipos[i] >> 8), ix = ox_ * S - a.pad_left + (ipos[i] & 0xFF);
     const int cy = med3(iy, 0, Hm1), cx = med3(ix, 0, Wm1);  // a clamped address is always loaded; padding is zeroed at commit
     pre_p[i] = *reinterpret_cast<const u32x4*>(at_off(in_n, (pix_off(cy, cx, a.W, a.Cin) + coff0 + (unsigned)(c * 32)) << 2));
   };
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
     }
     // zero padding, as TensorFlow pads the activated tensor
-    const int iy = oy_ - 1 + (ipos[i] >> 8), ix = ox_ - 1 + (ipos[i] & 0xFF);
+    const int iy = oy_ * S - a.pad_top + (ipos[i] >> 8), ix = ox_ * S - a.pad_left + (ipos[i] & 0xFF);
     const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
 #pragma unroll
     for (int j = 0; j < 4; ++j) pre_p[i][j] = __float_as_uint(inside ? v[j] : 0.0f);
@@ -213,25 +235,21 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     if (has_bn) hmax = pk_max_u16(pk_max_u16(hmax, h0), h1);
     else hmax = pk_max_u16(pk_max_u16(hmax, h0 & 0x7FFF7FFFu), h1 & 0x7FFF7FFFu);
     unsigned char* sp = reinterpret_cast<unsigned char*>(s_buf) + st_base;
-    *reinterpret_cast<uint2*>(sp + (bsel * RW_BUF * 16 + i * (RW_PPI * 32))) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(sp + (bsel * RW_BUF * 16 + 2 * RW_NPXP * 32 + i * (RW_PPI * 32))) = make_uint2(l0, l1);
-  };
-  auto commit_item = [&](const int i, const int c, const int bsel, const int oy_, const int ox_) __attribute__((always_inline)) {
-    activate_item(i, c, oy_, ox_);
-    store_item(i, bsel);
+    *reinterpret_cast<uint2*>(sp + (bsel * BUF * 16 + i * (RW_PPI * 32))) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(sp + (bsel * BUF * 16 + 2 * NPXP * 32 + i * (RW_PPI * 32))) = make_uint2(l0, l1);
   };
 
-  // ---- accumulators: 16 output rows x (16 pixels x 16 channels); a lane holds channels ct 16 + 4 q .. + 3 of pixel column i16 ----
-  f32x4 acc[RW_ROWS];
-  const int ch_l = g * RW_CG + ct * 16 + 4 * q;
+  // ---- accumulators: ROWS output rows x (16 pixels x 16 channels); a lane holds channels ct 16 + 4 q .. + 3 of pixel column i16 ----
+  f32x4 acc[ROWS];
+  const int ch_l = g * cout_g + half * RW_WC + ct * 16 + 4 * q;
   auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int o = 0; o < RW_ROWS; ++o) acc[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int o = 0; o < ROWS; ++o) acc[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   };
   // the tile's residual rows: one wave per SIMD leaves registers to spare, so they are requested beside the products of the
-  // tile's second chunk and have landed when the epilogue adds them (in the accumulators before the first product, as
+  // tile's last chunk and have landed when the epilogue adds them (in the accumulators before the first product, as
   // conv_bf3w_kernel has them, the first products of every tile waited out a trip to HBM: SQ_WAIT_ANY 46 % of the cycles)
-  f32x4 rres[RES ? RW_ROWS : 1];
+  f32x4 rres[RES ? ROWS : 1];
   auto issue_res = [&](const int o, const int n_, const int oy_, const int ox_) __attribute__((always_inline)) {
     if constexpr (RES) {
       const float* res_n = a.residual + (size_t)n_ * a.Ho * a.Wo * a.Cout;  // (uniform)
@@ -240,33 +258,33 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     }
   };
 
-  // ---- the products of one chunk from buffer `C`: 3 kx x 18 patch rows, each row's fragment pair feeding the output rows
-  //      it is tap row 0, 1, 2 of; `between(s)` is called after step s (54 steps) with the staging work that rides along.
-  //      Fragments are requested RW_AHEAD steps before their products (one wave per SIMD: distance instead of a partner) ----
-  const int a_base = ((q >> 1) * RW_NPXP + i16) * 2 + (q & 1);
+  // ---- the products of chunk C from buffer B: 3 kx x PH patch rows, each row's fragment pair feeding the output rows it is
+  //      tap row 0, 1, 2 of (stride 1: up to three; stride 3: exactly one); `between(s)` is called after step s with the
+  //      staging work that rides along.  Fragments are requested RW_AHEAD steps before their products (one wave per SIMD:
+  //      distance instead of a partner) ----
+  const int a_base = ((q >> 1) * NPXP + S * i16) * 2 + (q & 1);
   constexpr int RW_AHEAD = 3, RW_RING = 4;
-  auto compute = [&](auto cc, auto&& between) __attribute__((always_inline)) {
-    constexpr int C = decltype(cc)::value;
-    const uint4* sb = s_buf + C * RW_BUF + a_base;
+  auto compute = [&](auto cc, auto bc, auto&& between) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value, B = decltype(bc)::value;
+    const uint4* sb = s_buf + B * BUF + a_base;
     u32x4 xh[RW_RING], xl[RW_RING];
     auto frag = [&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
-      constexpr int kx = s / (RW_ROWS + 2), i = s - (RW_ROWS + 2) * kx, bf = s % RW_RING;
-      xh[bf] = __builtin_bit_cast(u32x4, sb[(i * RW_PW + kx) * 2]);
-      xl[bf] = __builtin_bit_cast(u32x4, sb[4 * RW_NPXP + (i * RW_PW + kx) * 2]);
+      constexpr int kx = s / PH, i = s - PH * kx, bf = s % RW_RING;
+      xh[bf] = __builtin_bit_cast(u32x4, sb[(i * PW + kx) * 2]);
+      xl[bf] = __builtin_bit_cast(u32x4, sb[4 * NPXP + (i * PW + kx) * 2]);
     };
     static_for<0, RW_AHEAD>(frag);
-    static_for<0, RW_STEPS>([&](auto sc) __attribute__((always_inline)) {
+    static_for<0, STEPS>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
-      constexpr int kx = s / (RW_ROWS + 2), i = s - (RW_ROWS + 2) * kx, bf = s % RW_RING;
-      if constexpr (s + RW_AHEAD < RW_STEPS) frag(std::integral_constant<int, s + RW_AHEAD>{});
-      // the three plane products of a tap in their order, but the (up to three) output rows of the step taking turns: no
-      // product waits for the one issued just before it
+      constexpr int kx = s / PH, i = s - PH * kx, bf = s % RW_RING;
+      if constexpr (s + RW_AHEAD < STEPS) frag(std::integral_constant<int, s + RW_AHEAD>{});
+      // the three plane products of a tap in their order, the output rows of the step taking turns
       static_for<0, 3>([&](auto pc) __attribute__((always_inline)) {
         constexpr int pr = decltype(pc)::value;
         static_for<0, 3>([&](auto rc) __attribute__((always_inline)) {
-          constexpr int r = decltype(rc)::value, o = i - r;
-          if constexpr (o >= 0 && o < RW_ROWS) {
+          constexpr int r = decltype(rc)::value, d = i - r, o = d / S;
+          if constexpr (d >= 0 && d % S == 0 && o < ROWS) {
             if constexpr (pr == 0) acc[o] = mfma_h(Wr[C][r * 3 + kx][1], xh[bf], acc[o]);
             if constexpr (pr == 1) acc[o] = mfma_h(Wr[C][r * 3 + kx][0], xl[bf], acc[o]);
             if constexpr (pr == 2) acc[o] = mfma_h(Wr[C][r * 3 + kx][0], xh[bf], acc[o]);
@@ -279,19 +297,42 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       __builtin_amdgcn_sched_barrier(0);
     });
   };
+  // one unit of the stream: the products of (chunk C, buffer B) and, spread over its steps, the staging of what follows:
+  // the NP items in registers (chunk CC of the tile at (oyc, oxc)) take their prologue and go to the other buffer, three
+  // slots per item (activate, split + store, next request) dealt evenly over the steps; the request that refills an item's
+  // registers is chunk CI of the tile (ni, oyi, oxi); LAST: the tile's residual rows are requested too
+  auto unit = [&](auto cc, auto bc, auto ccc, auto cic, auto lastc, const int oyc, const int oxc, const int ni, const int oyi,
+                  const int oxi) __attribute__((always_inline)) {
+    constexpr int B = decltype(bc)::value, CC = decltype(ccc)::value, CI = decltype(cic)::value;
+    constexpr bool LAST = decltype(lastc)::value;
+    compute(cc, bc, [&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int jlo = (s * 3 * NP + STEPS - 1) / STEPS, jhi = ((s + 1) * 3 * NP + STEPS - 1) / STEPS;
+      static_for<jlo, (jhi < 3 * NP ? jhi : 3 * NP)>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value, i = j / 3, k = j % 3;
+        if constexpr (k == 0) activate_item(i, CC, oyc, oxc);
+        if constexpr (k == 1) store_item(i, B ^ 1);
+        if constexpr (k == 2) issue_item(i, CI, ni, oyi, oxi);
+      });
+      if constexpr (LAST && RES) {
+        constexpr int olo = (s * ROWS + STEPS - 1) / STEPS, ohi = ((s + 1) * ROWS + STEPS - 1) / STEPS;
+        static_for<olo, (ohi < ROWS ? ohi : ROWS)>([&](auto oc) __attribute__((always_inline)) { issue_res(decltype(oc)::value, n0, oy0, ox0); });
+      }
+    });
+  };
 
   // ---- epilogue of a tile: fused 1x1 shortcut (float32 MFMA, as conv_bf3w_kernel), affine, residual, ReLU, 16-byte stores ----
   auto finish = [&](const int n_, const int oy_, const int ox_) __attribute__((always_inline)) {
     const int ox = min(ox_ + i16, a.Wo - 1);
     if (a.sc_in) {
       const int sc_cg = a.sc_cin / a.groups;
-      const float* wsc = a.sc_w + ((size_t)g * sc_cg + q) * RW_CG + ct * 16 + i16;
-      const float ss = s_par[2 * RW_CG + ct * 16 + i16];
+      const float* wsc = a.sc_w + ((size_t)g * sc_cg + q) * cout_g + half * RW_WC + ct * 16 + i16;
+      const float ss = s_par[2 * RW_WC + ct * 16 + i16];
       const float* sc_n = a.sc_in + (size_t)n_ * a.sc_H * a.sc_W * a.sc_cin + g * sc_cg + q;
       for (int k4 = 0; k4 < sc_cg; k4 += 4) {
-        const float ws = wsc[(size_t)k4 * RW_CG] * ss;
+        const float ws = wsc[(size_t)k4 * cout_g] * ss;
 #pragma unroll
-        for (int o = 0; o < RW_ROWS; ++o) {
+        for (int o = 0; o < ROWS; ++o) {
           const int oy = min(oy_ + o, a.Ho - 1);
           const float xs = sc_n[((size_t)(oy * a.sc_stride) * a.sc_W + ox * a.sc_stride) * a.sc_cin + k4];
           acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws, xs, acc[o], 0, 0, 0);
@@ -300,10 +341,10 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     }
     float* out_n = a.out + (size_t)n_ * a.Ho * a.Wo * a.Cout;
     const f32x4 os = *reinterpret_cast<const f32x4*>(s_par + ct * 16 + 4 * q);
-    const f32x4 ob = *reinterpret_cast<const f32x4*>(s_par + RW_CG + ct * 16 + 4 * q);
+    const f32x4 ob = *reinterpret_cast<const f32x4*>(s_par + RW_WC + ct * 16 + 4 * q);
     const bool xok = ox_ + i16 < a.Wo;
 #pragma unroll
-    for (int o = 0; o < RW_ROWS; ++o) {
+    for (int o = 0; o < ROWS; ++o) {
       const int oy = oy_ + o;
       const unsigned off = (pix_off(min(oy, a.Ho - 1), ox, a.Wo, a.Cout) + (unsigned)ch_l) << 2;
       f32x4 v = acc[o] * os + ob;
@@ -318,96 +359,111 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 
   // ---- prologue: the first tile's first chunk goes through the registers with nothing beside it ----
 #pragma unroll
-  for (int i = 0; i < RW_NP; ++i) issue_item(i, 0, n0, oy0, ox0);
+  for (int i = 0; i < NP; ++i) issue_item(i, 0, n0, oy0, ox0);
   __syncthreads();  // BatchNorm and epilogue parameters are in LDS
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     psc[c] = *reinterpret_cast<const f32x4*>(s_bn + c * 32 + 4 * q8);
-    psh[c] = *reinterpret_cast<const f32x4*>(s_bn + RW_CG + c * 32 + 4 * q8);
+    psh[c] = *reinterpret_cast<const f32x4*>(s_bn + CING + c * 32 + 4 * q8);
   }
 #pragma unroll
-  for (int i = 0; i < RW_NP; ++i) commit_item(i, 0, 0, oy0, ox0);
+  for (int i = 0; i < NP; ++i) {
+    activate_item(i, 0, oy0, ox0);
+    store_item(i, 0);
+  }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  if constexpr (NCH == 2) {
+    // units (tile, chunk 0) from buffer 0, (tile, chunk 1) from buffer 1
 #pragma unroll
-  for (int i = 0; i < RW_NP; ++i) issue_item(i, 1, n0, oy0, ox0);
-  init_acc();
-
-  for (;;) {
-    t += gridDim.x;
-    const bool more = t < 8 * per_xcd && tile_of(t) < td.total;  // (a workgroup's tiles ascend within its XCD's eighth)
-    if (more) {
-      decode(tile_of(t), n1, oy1, ox1);
-    } else {  // (the last tile stages itself again -- into registers and a buffer nobody reads -- rather than branch in the stream)
-      n1 = n0; oy1 = oy0; ox1 = ox0;
-    }
-    // ---- chunk 0 of the tile (buffer 0); beside its products: chunk 1 -> buffer 1, the next tile's chunk 0 -> registers ----
-    __syncthreads();
-    compute(std::integral_constant<int, 0>{}, [&](auto sc) __attribute__((always_inline)) {
-      // item i of the staging rides on steps 5 i + 1 (activate), + 2 (split, store), + 3 (the next request into its registers)
-      constexpr int s = decltype(sc)::value, i = s / 5, k = s % 5;
-      if constexpr (i < RW_NP) {
-        if constexpr (k == 1) activate_item(i, 1, oy0, ox0);
-        if constexpr (k == 2) store_item(i, 1);
-        if constexpr (k == 3) issue_item(i, 0, n1, oy1, ox1);
-      }
-    });
-    // ---- chunk 1 (buffer 1); beside its products: the next tile's chunk 0 -> buffer 0, its chunk 1 -> registers ----
-    __syncthreads();
-    compute(std::integral_constant<int, 1>{}, [&](auto sc) __attribute__((always_inline)) {
-      constexpr int s = decltype(sc)::value, i = s / 5, k = s % 5;
-      if constexpr (i < RW_NP) {
-        if constexpr (k == 1) activate_item(i, 0, oy1, ox1);
-        if constexpr (k == 2) store_item(i, 0);
-        if constexpr (k == 3) issue_item(i, 1, n1, oy1, ox1);
-        if constexpr (k == 4 && 2 * i + 1 < RW_ROWS) {  // (+ 4: two rows of this tile's residual)
-          issue_res(2 * i, n0, oy0, ox0);
-          issue_res(2 * i + 1, n0, oy0, ox0);
-        }
-      }
-    });
-    finish(n0, oy0, ox0);
-    if (!more) break;
-    n0 = n1; oy0 = oy1; ox0 = ox1;
+    for (int i = 0; i < NP; ++i) issue_item(i, 1, n0, oy0, ox0);
     init_acc();
+    for (;;) {
+      n1 = n0; oy1 = oy0; ox1 = ox0;
+      const bool more = advance(n1, oy1, ox1);
+      // beside chunk 0's products: chunk 1 -> buffer 1, the next tile's chunk 0 -> registers
+      __syncthreads();
+      unit(I0{}, I0{}, I1{}, I0{}, No{}, oy0, ox0, n1, oy1, ox1);
+      // beside chunk 1's: the next tile's chunk 0 -> buffer 0, its chunk 1 -> registers, this tile's residual -> registers
+      __syncthreads();
+      unit(I1{}, I1{}, I0{}, I1{}, Yes{}, oy1, ox1, n1, oy1, ox1);
+      finish(n0, oy0, ox0);
+      if (!more) break;
+      n0 = n1; oy0 = oy1; ox0 = ox1;
+      init_acc();
+    }
+  } else {
+    // one chunk per tile: the tiles alternate between the buffers; beside tile k's products tile k + 1 (in registers) goes
+    // to the other buffer and tile k + 2 is requested
+    n1 = n0; oy1 = oy0; ox1 = ox0;
+    bool more1 = advance(n1, oy1, ox1);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) issue_item(i, 0, n1, oy1, ox1);
+    init_acc();
+    for (;;) {
+      n2 = n1; oy2 = oy1; ox2 = ox1;
+      bool more2 = more1 && advance(n2, oy2, ox2);
+      __syncthreads();
+      unit(I0{}, I0{}, I0{}, I0{}, Yes{}, oy1, ox1, n2, oy2, ox2);
+      finish(n0, oy0, ox0);
+      if (!more1) break;
+      n0 = n1; oy0 = oy1; ox0 = ox1; n1 = n2; oy1 = oy2; ox1 = ox2; more1 = more2;
+      init_acc();
+      n2 = n1; oy2 = oy1; ox2 = ox1;
+      more2 = more1 && advance(n2, oy2, ox2);
+      __syncthreads();
+      unit(I0{}, I1{}, I0{}, I0{}, Yes{}, oy1, ox1, n2, oy2, ox2);
+      finish(n0, oy0, ox0);
+      if (!more1) break;
+      n0 = n1; oy0 = oy1; ox0 = ox1; n1 = n2; oy1 = oy2; ox1 = ox2; more1 = more2;
+      init_acc();
+    }
   }
   if ((hmax & 0x7FFFu) >= 0x7C00u || ((hmax >> 16) & 0x7FFFu) >= 0x7C00u) atomicOr(a.ovf, 1);  // (infinity or NaN: out of fp16's range)
 }
 
 }  // namespace
 
-// the layers conv_rw64_kernel takes: fp16x2, 3x3, stride 1, SAME, 64 channels per group in and out (stage 3 of WR-ResNet-22-4)
-bool conv_rw_layer(const ConvArgs& a) {
-  static const bool enabled = [] {
+// the layers conv_rw_kernel takes (fp16x2, 3x3, SAME padding; channels per group in -> out):
+//   1  stride 1, 64 -> 64   (stage 3 of WR-ResNet-22-4: the convolutions of its blocks but the strided first one)
+//   2  stride 2, 32 -> 64   (that strided first one)
+//   3  stride 3, 64 -> 128  (stage 4's)
+// CPX_CNN_RW: bit k - 1 enables kind k (default: all; 0 = none)
+int conv_rw_kind(const ConvArgs& a) {
+  static const int enabled = [] {
     const char* e = std::getenv("CPX_CNN_RW");
-    return e == nullptr || std::atoi(e) != 0;
+    return e == nullptr ? 7 : std::atoi(e);
   }();
-  return enabled && a.ksize == 3 && a.stride == 1 && a.Cin / a.groups == RW_CG && a.Cout / a.groups == RW_CG && a.Cin % a.groups == 0 &&
-         a.Cout % a.groups == 0;
+  if (a.ksize != 3 || a.groups < 1 || a.Cin % a.groups || a.Cout % a.groups) return 0;
+  const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+  int kind = 0;
+  if (a.stride == 1 && cin_g == 64 && cout_g == 64) kind = 1;
+  else if (a.stride == 2 && cin_g == 32 && cout_g == 64) kind = 2;
+  else if (a.stride == 3 && cin_g == 64 && cout_g == 128) kind = 3;
+  return (kind && ((enabled >> (kind - 1)) & 1)) ? kind : 0;
 }
+bool conv_rw_layer(const ConvArgs& a) { return conv_rw_kind(a) == 1; }
 
-// `wimg`: the layer's fp16 plane image (split_weights32_kernel with scales); a.w_scale / a.w_unscale / a.ovf / act_scale set
-int launch_conv_rw64(const ConvArgs& a, const void* wimg, hipStream_t s) {
-  if (!conv_rw_layer(a) || !a.half || a.planes != 2 || a.ovf == nullptr || a.in_planes || a.out_planes) return -2;
-  if (a.pad_top != 1 || a.pad_left != 1 || a.H != a.Ho || a.W != a.Wo) return -2;
-  if (a.sc_in && ((a.sc_cin / a.groups) & 3)) return -2;  // the fused shortcut walks K in fours
-  if ((long long)a.H * a.W >= (1 << 24)) return -3;
+namespace {
+template <int S, int NCH, int ROWS, bool BN, bool RES>
+int launch_rw_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
+  using G = RwGeo<S, NCH, ROWS>;
+  static_assert(G::LDS <= 160 * 1024 - 1024, "two chunk buffers must fit the CU's LDS");
   RwTiles td{};
   td.tiles_x = (a.Wo + RW_TW - 1) / RW_TW;
-  td.tiles_y = (a.Ho + RW_TH - 1) / RW_TH;
+  td.tiles_y = (a.Ho + ROWS - 1) / ROWS;
   const long long tiles = (long long)td.tiles_x * td.tiles_y * a.N;
   if (tiles >= (1 << 22) - 8 || td.tiles_x >= 4096 || td.tiles_y >= 4096) return -3;
   td.m_tx = (1ull << 42) / td.tiles_x + 1;
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
   td.total = (int)tiles;
-  const size_t lds = (size_t)2 * RW_BUF * 16 + (size_t)5 * RW_CG * sizeof(float);
-  static bool lds_ready[4][64];
-  const int variant = (a.in_scale ? 2 : 0) + (a.residual ? 1 : 0);
-  const void* fn = variant == 3 ? reinterpret_cast<const void*>(conv_rw64_kernel<true, true>)
-                   : variant == 2 ? reinterpret_cast<const void*>(conv_rw64_kernel<true, false>)
-                   : variant == 1 ? reinterpret_cast<const void*>(conv_rw64_kernel<false, true>)
-                                  : reinterpret_cast<const void*>(conv_rw64_kernel<false, false>);
-  if (!cpx_dyn_lds_ready(fn, lds_ready[variant], 160 * 1024 - 1024)) return -1;
-  // one workgroup per CU (four waves, each with a SIMD's whole register file), shared among the groups; a multiple of
-  // eight per group so that blockIdx.x & 7 names the XCD
+  static bool lds_ready[64];
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_rw_kernel<S, NCH, ROWS, BN, RES>), lds_ready, 160 * 1024 - 1024)) return -1;
+  // one workgroup per CU (four waves, each with a SIMD's whole register file), shared among the (group, 64-channel half)
+  // pairs; a multiple of eight per pair so that blockIdx.x & 7 names the XCD -- the halves of a group then walk the same tiles
+  // on the same XCD at the same time and share the patch in its L2
   static int cus_of[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
@@ -416,16 +472,34 @@ int launch_conv_rw64(const ConvArgs& a, const void* wimg, hipStream_t s) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
     cus_of[dev] = cus;
   }
-  int gx = std::max(8, cus_of[dev] / a.groups / 8 * 8);
+  const int ny = a.groups * ((a.Cout / a.groups) / RW_WC);
+  int gx = std::max(8, cus_of[dev] / ny / 8 * 8);
   if (const char* e = std::getenv("CPX_RW_GRID")) gx = std::max(8, std::atoi(e) / 8 * 8);
   gx = (int)std::min<long long>(gx, (tiles + 7) / 8 * 8);
-  const dim3 grid((unsigned)gx, a.groups), block(RW_CT);
-  const uint4* wi = reinterpret_cast<const uint4*>(wimg);
-  if (variant == 3) hipLaunchKernelGGL((conv_rw64_kernel<true, true>), grid, block, lds, s, a, wi, td);
-  else if (variant == 2) hipLaunchKernelGGL((conv_rw64_kernel<true, false>), grid, block, lds, s, a, wi, td);
-  else if (variant == 1) hipLaunchKernelGGL((conv_rw64_kernel<false, true>), grid, block, lds, s, a, wi, td);
-  else hipLaunchKernelGGL((conv_rw64_kernel<false, false>), grid, block, lds, s, a, wi, td);
+  hipLaunchKernelGGL((conv_rw_kernel<S, NCH, ROWS, BN, RES>), dim3((unsigned)gx, (unsigned)ny), dim3(RW_CT), G::LDS, s, a, wimg, td);
   return 0;
+}
+}  // namespace
+
+// `wimg`: the layer's fp16 plane image in 32-channel chunks (split_weights32_kernel with scales); a.w_scale / a.w_unscale /
+// a.ovf / act_scale set.  -2: not a launch this kernel takes (the caller's other kernels do)
+int launch_conv_rw(const ConvArgs& a, const void* wimg, hipStream_t s) {
+  const int kind = conv_rw_kind(a);
+  if (!kind || !a.half || a.planes != 2 || a.ovf == nullptr || a.in_planes || a.out_planes) return -2;
+  if ((long long)a.H * a.W >= (1 << 24) || (long long)a.Ho * a.Wo >= (1 << 24)) return -3;
+  if (a.sc_in && ((a.sc_cin / a.groups) & 3)) return -2;  // the fused shortcut walks K in fours
+  const uint4* wi = reinterpret_cast<const uint4*>(wimg);
+  const bool bn = a.in_scale != nullptr, res = a.residual != nullptr;
+  if (kind == 1) {
+    if (a.pad_top != 1 || a.pad_left != 1 || a.H != a.Ho || a.W != a.Wo) return -2;
+    if (bn && res) return launch_rw_t<1, 2, 16, true, true>(a, wi, s);
+    if (bn) return launch_rw_t<1, 2, 16, true, false>(a, wi, s);
+    if (res) return launch_rw_t<1, 2, 16, false, true>(a, wi, s);
+    return launch_rw_t<1, 2, 16, false, false>(a, wi, s);
+  }
+  if (res || a.sc_in || a.pad_top < 0 || a.pad_top > 1 || a.pad_left < 0 || a.pad_left > 1) return -2;  // (a stage's first convolution)
+  if (kind == 2) return bn ? launch_rw_t<2, 1, 8, true, false>(a, wi, s) : launch_rw_t<2, 1, 8, false, false>(a, wi, s);
+  return bn ? launch_rw_t<3, 2, 4, true, false>(a, wi, s) : launch_rw_t<3, 2, 4, false, false>(a, wi, s);
 }
 
 }  // namespace cpx

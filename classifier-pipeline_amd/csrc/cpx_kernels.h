@@ -238,10 +238,11 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s);
 // convolutions as launch_conv_bf3 would take them (half, act_scale, ovf set), wimg_a / wimg_b their weight images
 bool conv_block32_supported(const ConvArgs& a, const ConvArgs& b);
 int launch_conv_block32(const ConvArgs& a, const ConvArgs& b, const void* wimg_a, const void* wimg_b, hipStream_t s);
-// fp16x2 3x3 stride-1 layers with 64 channels per group in and out: the weights resident in registers (cpx_cnn_rw.hip);
-// `wimg` = the layer's fp16 plane image
-bool conv_rw_layer(const ConvArgs& a);
-int launch_conv_rw64(const ConvArgs& a, const void* wimg, hipStream_t s);
+// fp16x2 3x3 layers whose weights fit a workgroup's registers (cpx_cnn_rw.hip): kind 1 = stride 1, 64 -> 64 channels per
+// group; 2 = stride 2, 32 -> 64; 3 = stride 3, 64 -> 128; 0 = not taken.  `wimg` = the layer's fp16 plane image in 32-channel chunks
+int conv_rw_kind(const ConvArgs& a);
+bool conv_rw_layer(const ConvArgs& a);  // kind 1
+int launch_conv_rw(const ConvArgs& a, const void* wimg, hipStream_t s);
 void launch_head(const HeadArgs& a, hipStream_t s);
 void launch_count_overflow(int* ovf, int n_words, hipStream_t s);
 
