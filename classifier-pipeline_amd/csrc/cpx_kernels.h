@@ -8,17 +8,21 @@
 #include "cpx.h"
 
 // Tunables of the track kernel (one workgroup per clip-frame).
+// 768 threads (round 6; 1,024 before): two workgroups per CU either way (82 KB of LDS each), i.e. 24 waves = 6 per SIMD
+// instead of 8, which raises the register budget from 64 to 80 per lane -- the kernel takes 70 and no longer spills
+// (ScratchSize 36 -> 0 B per lane; 401 -> 385 us per frame step of 4,096 clips, scratch/track_ab.sh; 896 threads put
+// only one workgroup on a CU (562 us), 640 and 512 were slower: 467 and 409 us)
 #ifndef CPX_TRACK_THREADS
-#define CPX_TRACK_THREADS 1024
+#define CPX_TRACK_THREADS 768
 #endif
 #ifndef CPX_TRACK_CHUNKS
-#define CPX_TRACK_CHUNKS 5  // 4-pixel chunks per thread: W*H <= 4*5*1024 = 20480
+#define CPX_TRACK_CHUNKS 7  // 4-pixel chunks per thread: W*H <= 4*7*768 = 21504
 #endif
 #ifndef CPX_TRACK_LDS_COMPONENTS
 #define CPX_TRACK_LDS_COMPONENTS 256
 #endif
 #ifndef CPX_TRACK_MIN_WAVES_PER_SIMD
-#define CPX_TRACK_MIN_WAVES_PER_SIMD 8  // __launch_bounds__ 2nd argument (waves per SIMD)
+#define CPX_TRACK_MIN_WAVES_PER_SIMD 6  // __launch_bounds__ 2nd argument (waves per SIMD)
 #endif
 
 namespace cpx {

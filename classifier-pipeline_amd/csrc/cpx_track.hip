@@ -264,7 +264,7 @@ constexpr int WTAB_LDS = 512;
 __host__ __device__ inline size_t wtab_lds_offset(int W, int H) {
   const size_t P = (size_t)W * H;
   const size_t used = 3 * P + 2 * (size_t)H * RW * 8 + (size_t)9 * CAP * 4 + (NWAVE + 1) * sizeof(Red1) + NWAVE * 2 * sizeof(int) + 16 +
-                      3 * NWAVE * sizeof(u32) + 16;
+                      3 * NWAVE * sizeof(u32) + 16 + 16;  // (+ 16: s_keep, the record's scalars parked across the labelling phases)
   return (used + 15) & ~(size_t)15;
 }
 // values every lane holds alike (read from LDS or through a vector load) -> scalar registers
@@ -316,6 +316,10 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   // into ONE flat load of a selected address, which waits for every outstanding vector-memory operation
   typedef __attribute__((address_space(3))) const double LdsDouble;
   typedef __attribute__((address_space(3))) const u32 LdsU32;
+  // four scalars of the frame record (avg_change, norm_min, norm_max, threshold) are computed in phase 3 and stored at the very
+  // end of the step; kept in registers in between they cost four of the 64 the labelling phases have and went to scratch
+  // (36 B per lane of scratch = 12 % more HBM traffic than the layout needs, profiles/r05_e2e_pmc.json).  Parked here instead.
+  int* s_keep = reinterpret_cast<int*>(smem + wtab_lds_offset(W, H)) - 4;
   LdsDouble* s_wtab = (LdsDouble*)(smem + wtab_lds_offset(W, H));
   LdsU32* s_wthr = (LdsU32*)(smem + wtab_lds_offset(W, H) + WTAB_LDS * sizeof(double));
 
@@ -675,6 +679,12 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     return;
   }
 
+  if (tid == 0) {  // (read back by the same thread at the end of the step: no barrier needed for it)
+    s_keep[0] = avg_change;
+    s_keep[1] = mn;
+    s_keep[2] = mx;
+    s_keep[3] = __float_as_int(thresh);
+  }
   // ---- phase 4a: horizontal [1 4 6 4 1], BORDER_REFLECT_101 -----------------------
   const int ngroup = P >> 3;
   const int gpr = W >> 3;  // 8-pixel groups per row
@@ -979,7 +989,15 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   else label_phases(s_stat, s_rank, CAP, false);
 
   // ---- per-frame record + clip state -------------------------------------------------------------------
-  const Red1 R = *s_R;  // (written two phases ago; every thread keeps the new clip state for the clip's next frame)
+  // (written two phases ago; every thread keeps the new clip state for the clip's next frame.  Read through a volatile
+  // pointer: thread 0 wrote the record itself and the compiler otherwise forwards the stored values -- i.e. carries seven
+  // registers across all the labelling phases, which at 64 registers per lane means through scratch)
+  Red1 R;
+  {
+    volatile Red1* vr = s_R;
+    R.sumpix = vr->sumpix; R.minpix = vr->minpix; R.maxpix = vr->maxpix; R.fmin = vr->fmin; R.fmax = vr->fmax;
+    R.sumbg = vr->sumbg; R.changed = vr->changed; R.sumabs = vr->sumabs;
+  }
   ClipState ns;
   // motiondetector.py:224-226: average = int(round(np.average(background))) when any pixel changed
   ns.bg_average = R.changed ? rint((double)R.sumbg / (double)((W - 2 * e) * (H - 2 * e))) : cs.bg_average;
@@ -993,16 +1011,19 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     fi.n_components = overflow ? ncomp_all : ncomp;
     fi.status = overflow ? -5 : 0;
     fi.ffc_affected = a.proc_ffc[pbase + t];
-    fi.avg_change = avg_change;
-    fi.norm_min = mn;
-    fi.norm_max = mx;
-    fi.threshold = thresh;
+    // (parked in LDS before the labelling phases; volatile: the values must not be carried in registers instead)
+    volatile int* keep = s_keep;
+    fi.avg_change = keep[0];
+    fi.norm_min = keep[1];
+    fi.norm_max = keep[2];
+    fi.threshold = __int_as_float(keep[3]);
     fi.filt_min = R.fmin;
     fi.filt_max = R.fmax;
     fi.thermal_min = (int)R.minpix;
     fi.thermal_max = (int)R.maxpix;
     fi.thermal_sum = R.sumpix;
-    fi.thermal_median = a.info_out[fidx].thermal_median;  // cpx_median_kernel put it there before this kernel started
+    // cpx_median_kernel put it there before this kernel started (volatile: loaded here, not at the top of the step)
+    fi.thermal_median = *reinterpret_cast<volatile const float*>(&a.info_out[fidx].thermal_median);
     fi.filtered_abs_sum = R.sumabs;
     fi.background_average = ns.bg_average;
     fi.background_changed = (int)R.changed;
