@@ -97,7 +97,7 @@ def conv_layer_table(conv, math, steps):
             pipe, peak = "vector (direct kernel: 8 B in, 64 B out per pixel -- HBM-bound)", None
         elif block:
             pipe, peak = "fp16 MFMA, 3 products", MFMA_BF16_PEAK_TFLOPS / 3
-        elif math == "f32" or one or st == 3:
+        elif math == "f32" or one or (st == 3 and math != "fp16x2"):  # (fp16x2: the stride-3 layer runs conv_rw_kernel<3, 2, 4>)
             pipe, peak = "fp32 MFMA", MFMA_F32_PEAK_TFLOPS
         elif cin_g == 8:
             pipe, peak = "bf16 MFMA, 6 products (exact split)", MFMA_BF16_PEAK_TFLOPS / 6
@@ -1232,10 +1232,14 @@ def main():
                         "64->64 ch + the 1x1 shortcut 16->64, %dx%d, groups 2; FLOPs of the two 3x3 convolutions)" % (side, side),
                         1.25, "the block's 16-channel input in, its 64-channel output out", convs=1.25)
                 if bf3 and key3 in conv:
+                    k3name = ("conv_rw_kernel<1, 2, 16, *, *> (weights resident in registers, one wave per SIMD, pixel-row fragments "
+                              "shared by the three tap rows; the one launch in five that carries the stage's 1x1 shortcut stays on %s: "
+                              "the stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)" % (bf3w_kernel_name(64, args.cnn_math), side // 2, side // 2)
+                              if args.cnn_math == "fp16x2" and os.environ.get("CPX_CNN_RW", "7") not in ("0", "2", "4", "6") else
+                              "%s (both 32-column slices of a group from one staged patch: the stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)"
+                              % (bf3w_kernel_name(64, args.cnn_math), side // 2, side // 2))
                     kernels["conv_stage3"] = leg(
-                        key3, "conv_stage3",
-                        "%s (both 32-column slices of a group from one staged patch: the stage-3 3x3 convs, 128->128 ch at %dx%d, groups 2)"
-                        % (bf3w_kernel_name(64, args.cnn_math), side // 2, side // 2), 0.5 * 2.6,
+                        key3, "conv_stage3", k3name, 0.5 * 2.6,
                         "input + output (+ residual in 3 of the 5 launches of this shape per forward); half of a stage-2 tensor each")
                 # `roofline` is the kernel the step spends most of its time in -- since the fp16x2 mode and the fused blocks that
                 # is the track kernel (one launch per step), not a convolution; every kernel above a tenth of the step stands
@@ -1247,6 +1251,19 @@ def main():
                     dom, kernels[dom]["ms_per_step"], elapsed * 1e3 / args.steps),
                     kernels={k: v for k, v in kernels.items() if k != dom})
                 line["roofline_conv"] = dict(kernels[conv_dom], which=conv_dom)
+                # the whole network against the matrix pipe: float32-equivalent FLOPs of every convolution of
+                # the step / the step's convolution time, against the 16-bit MFMA peak over the products one float32 multiply-add
+                # costs in this mode -- conv1 (vector kernel) and whatever runs on the fp32 MFMA are inside the time, so this
+                # is a lower bound of what the split-operand kernels reach
+                tot_ms_c = sum(v[1] for v in conv.values())
+                tot_fl_c = sum(v[2] for v in conv.values())
+                agg_tf = tot_fl_c / (tot_ms_c / 1e3) / 1e12
+                line["roofline"]["conv_aggregate"] = {
+                    "bound": "mfma", "achieved": round(agg_tf, 2), "peak": peak, "unit": "TFLOP/s (float32-equivalent)",
+                    "frac": round(agg_tf / peak, 4), "mfma_issued_tflops": round(agg_tf * products, 1) if bf3 else None,
+                    "frac_of_16bit_mfma_peak": round(agg_tf * products / MFMA_BF16_PEAK_TFLOPS, 4) if bf3 else None,
+                    "ms_per_step": round(tot_ms_c / args.steps, 2), "share_of_step": round(tot_ms_c / args.steps / (elapsed * 1e3 / args.steps), 4),
+                    "note": "all convolution launches of the step (cpx_conv_timing_report: HIP events on the handle's stream)"}
                 if key in conv and conv[key][1] > 0:
                     line["roofline"]["stage2_tflops"] = round(conv[key][2] / (conv[key][1] / 1e3) / 1e12, 2)
                 tot_ms = sum(v[1] for v in conv.values())

@@ -343,17 +343,29 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     const f32x4 os = *reinterpret_cast<const f32x4*>(s_par + ct * 16 + 4 * q);
     const f32x4 ob = *reinterpret_cast<const f32x4*>(s_par + RW_WC + ct * 16 + 4 * q);
     const bool xok = ox_ + i16 < a.Wo;
+    // nothing runs beside the epilogue on this SIMD: every instruction here is matrix-pipe idle time.  One fused multiply-add
+    // per value (the affine's one rounding instead of two: inside the layer's tolerance, another float32 order like the tap
+    // order), one per-lane offset for the tile + a uniform row stride, whole tiles without per-row tests
+    const unsigned off0 = (pix_off(min(oy_, a.Ho - 1), ox, a.Wo, a.Cout) + (unsigned)ch_l) << 2;
+    const unsigned row_bytes = (unsigned)(a.Wo * a.Cout) << 2;  // (uniform)
+    const bool whole = oy_ + ROWS <= a.Ho;                      // (uniform)
+    auto row = [&](const int o, const bool ok, const unsigned off) __attribute__((always_inline)) {
+      f32x4 v;
 #pragma unroll
-    for (int o = 0; o < ROWS; ++o) {
-      const int oy = oy_ + o;
-      const unsigned off = (pix_off(min(oy, a.Ho - 1), ox, a.Wo, a.Cout) + (unsigned)ch_l) << 2;
-      f32x4 v = acc[o] * os + ob;
+      for (int j = 0; j < 4; ++j) v[j] = __fmaf_rn(acc[o][j], os[j], ob[j]);
       if constexpr (RES) v += rres[o];
       if (a.relu) {
         asm volatile("");
         v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
       }
-      if (xok && oy < a.Ho) *reinterpret_cast<f32x4*>(at_off(out_n, off)) = v;
+      if (ok) *reinterpret_cast<f32x4*>(at_off(out_n, off)) = v;
+    };
+    if (whole) {
+#pragma unroll
+      for (int o = 0; o < ROWS; ++o) row(o, xok, off0 + (unsigned)o * row_bytes);
+    } else {
+#pragma unroll
+      for (int o = 0; o < ROWS; ++o) row(o, xok && oy_ + o < a.Ho, off0 + (unsigned)min(o, a.Ho - 1 - oy_) * row_bytes);
     }
   };
 
