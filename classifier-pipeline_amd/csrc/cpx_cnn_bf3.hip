@@ -563,9 +563,12 @@ __global__ __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(S > 1 ? CT /
 // staging format, MFMA loop and epilogue as conv_bf3_kernel; the output offset of a position is simply p * Cout.
 // PL: bf16 planes per operand (3: the exact split, six products; 2: CPX_CNN_MATH_BF16X2, three -- see conv_bf3w_kernel)
 // H: the two planes are fp16 (CPX_CNN_MATH_FP16X2; see conv_bf3_kernel)
-template <int NTN, int NPXC, int PL, bool H = false, bool PERSIST = false>
-__global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
-  constexpr int KS = 3, CT = 256;
+// CT: threads = 64 x the 32-position wave tiles of a workgroup's band (256: 128 positions; 512: 256 positions -- a staged
+// weight chunk then feeds twice the products: at 128 positions three workgroups per CU pull 37 KB of weights each per 16-channel
+// chunk, ~50 B per clock and CU out of L2, which is about what an XCD's L2 delivers)
+template <int NTN, int NPXC, int PL, bool H = false, bool PERSIST = false, int CT = 256>
+__global__ __launch_bounds__(CT) void conv_bf3flat_kernel(ConvArgs a, const uint4* __restrict__ wimg, TileDiv td) {
+  constexpr int KS = 3, BAND = CT / 2;
   constexpr int COGW = 32 * NTN;
   static_assert(!H || PL == 2, "fp16 planes come in twos");
   extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
@@ -586,8 +589,8 @@ __global__ __launch_bounds__(256) void conv_bf3flat_kernel(ConvArgs a, const uin
   const int n = q;
   const int g = blockIdx.y;
   const int M = a.Ho * a.Wo;
-  const int p0 = ti * 128;
-  const int y_first = p0 / a.Wo, y_last = min(p0 + 127, M - 1) / a.Wo;
+  const int p0 = ti * BAND;
+  const int y_first = p0 / a.Wo, y_last = min(p0 + BAND - 1, M - 1) / a.Wo;
   const int PW = a.W + 2, PH = y_last - y_first + 3;  // stride 1, 3 x 3, SAME: one halo row / column each side
   const int npx = PH * PW;
   const int iy0 = y_first - a.pad_top, ix0 = -a.pad_left;
@@ -1745,13 +1748,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 constexpr long long RERUN_GRID = 1024;  // workgroups along x of a guarded rerun (four per CU and group row)
-template <int NTN, int NPXC, int PL, bool H = false>
+template <int NTN, int NPXC, int PL, bool H = false, int CT = 256>
 int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
-  const size_t lds = ((size_t)2 * PL * NPXC + (size_t)18 * PL * 32 * NTN) * 16;
+  constexpr int BAND = CT / 2;
+  const size_t lds = std::max(((size_t)2 * PL * NPXC + (size_t)18 * PL * 32 * NTN) * 16, (size_t)(CT / 64) * 32 * 32 * sizeof(float));
   static bool lds_ready[64], lds_ready_p[64];
-  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL, H>), lds_ready, 160 * 1024 - 1024)) return -1;
+  if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL, H, false, CT>), lds_ready, 160 * 1024 - 1024)) return -1;
   TileDiv td;
-  td.tiles_x = (a.Ho * a.Wo + 127) / 128;
+  td.tiles_x = (a.Ho * a.Wo + BAND - 1) / BAND;
   td.tiles_y = 1;
   td.nsplit = (a.Cout / a.groups) / (32 * NTN);
   const long long blocks = (long long)td.tiles_x * a.N * td.nsplit;
@@ -1761,24 +1765,27 @@ int launch_bf3flat_t(const ConvArgs& a, const uint4* wimg, hipStream_t s) {
   td.m_ty = (1ull << 42) + 1;
   td.total = (int)blocks;
   if constexpr (PL == 3 && !H) if (a.guard != nullptr) {  // the guarded rerun of a fp16x2 layer: a small grid that walks the tiles (PERSIST)
-    if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL, false, true>), lds_ready_p, 160 * 1024 - 1024)) return -1;
-    hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL, false, true>), dim3((unsigned)std::min<long long>(blocks, RERUN_GRID), a.groups), dim3(256), lds, s, a, wimg, td);
+    if (!cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_bf3flat_kernel<NTN, NPXC, PL, false, true, CT>), lds_ready_p, 160 * 1024 - 1024)) return -1;
+    hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL, false, true, CT>), dim3((unsigned)std::min<long long>(blocks, RERUN_GRID), a.groups), dim3(CT), lds, s, a, wimg, td);
     return 0;
   }
-  hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL, H>), dim3((unsigned)blocks, a.groups), dim3(256), lds, s, a, wimg, td);
+  hipLaunchKernelGGL((conv_bf3flat_kernel<NTN, NPXC, PL, H, false, CT>), dim3((unsigned)blocks, a.groups), dim3(CT), lds, s, a, wimg, td);
   return 0;
 }
 // the flattened tiling applies to stride-1 SAME 3 x 3 layers whose staged rows fit the LDS cap and pays when the
 // rectangular bands waste more than 8 % over it
-static bool flat_pays(const ConvArgs& a, int TW, int TH, int npx_cap) {
+static bool flat_pays(const ConvArgs& a, int TW, int TH, int npx_cap, int band = 128) {
   if (a.stride != 1 || a.ksize != 3 || a.pad_top != 1 || a.pad_left != 1 || a.H != a.Ho || a.W != a.Wo) return false;
   const int M = a.Ho * a.Wo;
-  const int rows = (127 + a.Wo - 1) / a.Wo + 1;
+  const int rows = (band - 1 + a.Wo - 1) / a.Wo + 1;
   if ((rows + 2) * (a.W + 2) > npx_cap) return false;
   const double rect = (double)M / ((double)((a.Wo + TW - 1) / TW) * TW * ((a.Ho + TH - 1) / TH) * TH);
-  const double flat = (double)M / ((double)((M + 127) / 128) * 128);
+  const double flat = (double)M / ((double)((M + band - 1) / band) * band);
   return flat > rect + 0.08;
 }
+#ifndef CPX_BF3FLAT_WIDE
+#define CPX_BF3FLAT_WIDE 0  // fp16x2: 256-position bands (512 threads) where the staged rows fit 384 pixels -- measured SLOWER on stage 4 (36.5 vs 31.4 ms per 15 launches of 1,536 samples, profiles/r06_conv_rw_experiments.md): not shipped
+#endif
 
 // packed float32 weights [g][tap][cin_g][cout_g] -> bf16 plane image [g][chunk][3][9][2][cout_g] of 16-byte entries
 // cin_g == 8: [g][3][5][2][cout_g], the entry of (step s, k half h) = the 8 channels of tap 2 s + h (zeros for tap 9)
@@ -2263,6 +2270,8 @@ int launch_conv_bf3(const ConvArgs& a_in, const void* wimg, hipStream_t s) {
   // need 384 staged pixels and then fit only one N tile per workgroup: measured slower than the rectangular bands,
   // 399 vs 371 ms, the patch being activated and split by four column slices instead of two.)
   if (cout_g == 128 && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 256)) {
+    if (a.planes == 2 && a.half && CPX_BF3FLAT_WIDE && flat_pays(a, 32, 4 * CPX_BF3_NB_S4, 384, 256))
+      return launch_bf3flat_t<2, 384, 2, true, 512>(a, w + half_image_offset(a) / 16, s);
     if (a.planes == 2 && a.half) return launch_bf3flat_t<2, 256, 2, true>(a, w + half_image_offset(a) / 16, s);
     if (a.planes == 2 && flat_layer(a)) return launch_bf3flat_t<2, 256, 2>(a, w + image3_bytes(a) / 16, s);
     return launch_bf3flat_t<2, 256, 3>(a, w, s);
@@ -2313,6 +2322,12 @@ int launch_conv_block32(const ConvArgs& a_in, const ConvArgs& b_in, const void* 
   td.m_ty = (1ull << 42) / td.tiles_y + 1;
   td.total = (int)tiles;
   const bool c8 = a.Cin / a.groups == 8;
+  // blocks past the stage's first: the two convolutions on different waves (cpx_cnn_blk.hip) unless CPX_BLOCK32_SPLIT=0
+  static const bool split_roles = [] {
+    const char* e = std::getenv("CPX_BLOCK32_SPLIT");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  if (!c8 && split_roles) return launch_conv_block32s(a, b, wa, wb, s);
   const size_t lds = c8 ? (size_t)(B_R0 + B8_WIMG + B_WIMG) * 16 + 256 + (size_t)2 * B8_NPXP * 16 : (size_t)(B_R0 + 2 * B_WIMG) * 16 + 256;
   static bool lds_ready[64], lds_ready8[64];
   if (c8 ? !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<true>), lds_ready8, 160 * 1024 - 1024)

@@ -242,6 +242,9 @@ int launch_conv_bf3(const ConvArgs& a, const void* wimg, hipStream_t s);
 // convolutions as launch_conv_bf3 would take them (half, act_scale, ovf set), wimg_a / wimg_b their weight images
 bool conv_block32_supported(const ConvArgs& a, const ConvArgs& b);
 int launch_conv_block32(const ConvArgs& a, const ConvArgs& b, const void* wimg_a, const void* wimg_b, hipStream_t s);
+// the same block with the two convolutions on different waves of the workgroup (cpx_cnn_blk.hip); a / b prepared by
+// launch_conv_block32 (w_scale / w_unscale set), wa / wb the fp16 plane images
+int launch_conv_block32s(const ConvArgs& a, const ConvArgs& b, const void* wa, const void* wb, hipStream_t s);
 // fp16x2 3x3 layers whose weights fit a workgroup's registers (cpx_cnn_rw.hip): kind 1 = stride 1, 64 -> 64 channels per
 // group; 2 = stride 2, 32 -> 64; 3 = stride 3, 64 -> 128; 0 = not taken.  `wimg` = the layer's fp16 plane image in 32-channel chunks
 int conv_rw_kind(const ConvArgs& a);

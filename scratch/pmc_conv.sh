@@ -28,6 +28,6 @@ for name, cs in acc.items():
     out[name]["launches"] = len(next(iter(cs.values())))
 json.dump(out, open("gpurun_out/pmc_conv_summary.json", "w"), indent=1)
 for name, cs in sorted(out.items()):
-    if "bf3w" in name or "block32" in name or "rw64" in name: print(name, {k: round(v) for k, v in cs.items()})
+    if "block32" in name or "rw_kernel<1" in name: print(name, {k: round(v) for k, v in cs.items()})
 PY
 rm -rf gpurun_out/pmc_conv_[0-9]*/
