@@ -3,11 +3,13 @@ PyTorch CPU float32 restatement (oracle/cnn_oracle.py).  Tolerance: the north st
 logits (absolute; logits are O(1) with calibrated BatchNorm statistics), checked at 2e-4 here.
 Logits-vs-TensorFlow is parity-unpinned (no TF / weights in the container)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 LOGIT_ATOL = 2e-4  # north star: 1e-3
 
@@ -343,11 +345,13 @@ def test_fused_shortcut_equals_separate_launch(engine, monkeypatch):
 
 
 @pytest.mark.parametrize("side,n", [(160, 3), (150, 2), (37, 1)])
-def test_fused_block_is_bitwise_the_two_launches(monkeypatch, side, n):
-    """fp16x2 runs a stage-2 block past the first as ONE launch (conv_block32_kernel: `mid` stays in LDS;
-    CPX_CNN_BLOCK_FUSION=1 fuses exactly those); an engine created with CPX_CNN_BLOCK_FUSION=0 runs the two convolutions as
-    two.  Same planes, same products in the same order: the logits are the same bits -- on whole tiles, ragged ones
-    (150 = 9 x 16 + 6) and a map of three tiles."""
+def test_fused_block_matches_the_two_launches(monkeypatch, side, n):
+    """fp16x2 runs a stage-2 block past the first as ONE launch (`mid` stays in LDS; CPX_CNN_BLOCK_FUSION=1 fuses exactly
+    those); an engine created with CPX_CNN_BLOCK_FUSION=0 runs the two convolutions as two.  Three one-launch forms
+    (CPX_BLOCK32_SPLIT): 0 = conv_block32_kernel -- same planes, same products in the same order as the two launches: the
+    logits are the SAME BITS; 1 (default) = conv_block32s_kernel and 2 = conv_block32p_kernel, the two convolutions on
+    different waves, taps summed kx-major: another float32 order of the same terms, logits within 1e-5 (relative to the largest
+    logit).  On whole tiles, ragged ones (150 = 9 x 16 + 6) and a map of three tiles."""
     import torch
 
     import cnn_oracle as co
@@ -358,28 +362,59 @@ def test_fused_block_is_bitwise_the_two_launches(monkeypatch, side, n):
     x = rng.uniform(0, 255, size=(n, side, side, 2)).astype(np.float32)
     w = co.calibrate_bn(wr.random_weights(17, seed=8), x)
     out = {}
-    for fusion in ("1", "0"):
-        monkeypatch.setenv("CPX_CNN_BLOCK_FUSION", fusion)
-        eng = TrackEngine(model="lepton3")
-        monkeypatch.delenv("CPX_CNN_BLOCK_FUSION")
-        eng.set_cnn_math("fp16x2")
-        net = wr.WRResNetDevice(eng, w, 17)
-        eng.conv_timing(True)
-        logits, _ = net.forward(torch.from_numpy(x).to(eng.device))
-        launches = eng.conv_timing()
-        eng.conv_timing(False)
-        assert not eng.cnn_last_overflow()
-        # key "stride 4" = a block launch; 320321 = a stage-2 convolution launched on its own
-        if fusion == "1":
-            assert launches[320324][0] == 2 and launches[320321][0] == 1 and 80324 not in launches, launches
-        else:
-            assert 320324 not in launches and launches[320321][0] == 5, launches
-        out[fusion] = logits.cpu()
-        net.close()
-        eng.close()
-    assert torch.equal(out["1"], out["0"]), float((out["1"] - out["0"]).abs().max())
+    for fusion, split in (("0", None), ("1", "0"), ("1", "1"), ("1", "2")):
+        # (CPX_BLOCK32_SPLIT is read once per process by the launcher: the forms other than the first one seen run in a child)
+        out[(fusion, split)] = _block_form_logits(w, x, fusion, split)
+    two = out[("0", None)]
+    assert torch.equal(out[("1", "0")], two), float((out[("1", "0")] - two).abs().max())
+    scale = max(1.0, float(two.abs().max()))
+    for split in ("1", "2"):
+        d = float((out[("1", split)] - two).abs().max())
+        assert d <= 1e-5 * scale, (split, d)
     want, _ = co.forward(w, x)
-    assert float(np.abs(out["1"].numpy() - want).max()) <= LOGIT_ATOL
+    for k, v in out.items():
+        assert float(np.abs(v.numpy() - want).max()) <= LOGIT_ATOL, k
+
+
+def _block_form_logits(w, x, fusion, split):
+    """Logits of one forward in a fresh process with CPX_CNN_BLOCK_FUSION / CPX_BLOCK32_SPLIT set (both are read once)."""
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+
+    import torch
+
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "in.pkl"), "wb") as fh:
+            pickle.dump((w, x), fh)
+        code = (
+            "import os, sys, pickle, numpy as np, torch\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from cpx.engine import TrackEngine\n"
+            "from cpx.ml_tools import wrresnet as wr\n"
+            "w, x = pickle.load(open(%r, 'rb'))\n"
+            "eng = TrackEngine(model='lepton3'); eng.set_cnn_math('fp16x2')\n"
+            "net = wr.WRResNetDevice(eng, w, 17)\n"
+            "eng.conv_timing(True)\n"
+            "logits, _ = net.forward(torch.from_numpy(x).to(eng.device))\n"
+            "launches = eng.conv_timing()\n"
+            "assert not eng.cnn_last_overflow()\n"
+            "fusion = os.environ['CPX_CNN_BLOCK_FUSION']\n"
+            "# key 'stride 4' = a block launch; 320321 = a stage-2 convolution launched on its own\n"
+            "if fusion == '1': assert launches[320324][0] == 2 and launches[320321][0] == 1 and 80324 not in launches, launches\n"
+            "else: assert 320324 not in launches and launches[320321][0] == 5, launches\n"
+            "pickle.dump(logits.cpu().numpy(), open(%r, 'wb'))\n"
+            % (os.path.join(REPO, "classifier-pipeline_amd"), os.path.join(REPO, "oracle"), os.path.join(td, "in.pkl"),
+               os.path.join(td, "out.pkl")))
+        env = dict(os.environ, CPX_CNN_BLOCK_FUSION=fusion)
+        env.pop("CPX_BLOCK32_SPLIT", None)
+        if split is not None:
+            env["CPX_BLOCK32_SPLIT"] = split
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        with open(os.path.join(td, "out.pkl"), "rb") as fh:
+            return torch.from_numpy(pickle.load(fh))
 
 
 @pytest.mark.parametrize("side,n", [(160, 3), (150, 2), (37, 1)])
