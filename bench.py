@@ -392,9 +392,9 @@ def _oracle_warm(_):
 STAGE2_CONV_FLOPS_PER_SAMPLE = 2.0 * 160 * 160 * 64 * 32 * 9
 
 
-PMC_SUMMARY = "profiles/r05_e2e_pmc.json"
+PMC_SUMMARY = "profiles/r06_e2e_pmc.json"
 PMC_NOTE = ("NOT measured in this run: bytes per unit from the committed rocprofv3 PMC summary %s (separate FETCH_SIZE / "
-            "WRITE_SIZE passes over `python3 bench.py --clips 1024`, FETCH_SIZE doubled per the gfx950 note of "
+            "WRITE_SIZE passes over `python3 bench.py --steps 1 --warmup 0` at the bench's own 4,096 clips, FETCH_SIZE doubled per the gfx950 note of "
             "MI355X_MICROARCH.md), rescaled to this run's units per launch" % PMC_SUMMARY)
 
 

@@ -332,11 +332,13 @@ __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
   // below, which writes slots of OTHER lanes' pixels
   const int lane0 = threadIdx.x & 63;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx - lane0 < total; idx += (size_t)gridDim.x * blockDim.x) {
-    size_t p = idx < total ? idx : total - 1;
-    const int ox = (int)(p % a.Wo);
-    p /= a.Wo;
-    const int oy = (int)(p % a.Ho);
-    const int n = (int)(p / a.Ho);
+    // (32-bit index arithmetic: launch_conv refuses a launch of 2^32 pixels or more; the 64-bit divisions cost more vector
+    // instructions per pixel than the convolution itself)
+    unsigned p = (unsigned)(idx < total ? idx : total - 1);
+    const unsigned prow = p / (unsigned)a.Wo;
+    const int ox = (int)(p - prow * (unsigned)a.Wo);
+    const int n = (int)(prow / (unsigned)a.Ho);
+    const int oy = (int)(prow - (unsigned)n * (unsigned)a.Ho);
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
@@ -364,9 +366,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
         const float* w0 = a.weights + (ky * 3 + kx) * 8;       // group 0: [tap][1][8]
         const float* w1 = a.weights + 72 + (ky * 3 + kx) * 8;  // group 1
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          acc[c] += v.x * w0[c];
-          acc[8 + c] += v.y * w1[c];
+        for (int c = 0; c < 8; ++c) {  // (fused multiply-adds: half the vector instructions of this vector-bound kernel)
+          acc[c] = __fmaf_rn(v.x, w0[c], acc[c]);
+          acc[8 + c] = __fmaf_rn(v.y, w1[c], acc[8 + c]);
         }
       }
     // the 64 bytes of a pixel go through the wave's 4 KB of LDS so that a store instruction writes 1 KB of
@@ -474,6 +476,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (cin_g == 1 && cout_g == 8 && a.groups == 2 && a.ksize == 3 && a.stride == 1 && !a.in_scale && !a.out_scale &&
       a.out_shift && !a.residual && !a.relu) {
     const size_t total = (size_t)a.N * a.Ho * a.Wo;
+    if (total >= (1ull << 32)) return -3;  // (conv1_kernel indexes pixels in 32 bits)
     const int blocks = (int)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256);
     hipLaunchKernelGGL(conv1_kernel, dim3(blocks), dim3(256), 0, s, a);
     return 0;

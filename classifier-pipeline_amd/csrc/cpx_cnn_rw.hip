@@ -263,7 +263,10 @@ __global__ __launch_bounds__(RW_CT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   //      staging work that rides along.  Fragments are requested RW_AHEAD steps before their products (one wave per SIMD:
   //      distance instead of a partner) ----
   const int a_base = ((q >> 1) * NPXP + S * i16) * 2 + (q & 1);
-  constexpr int RW_AHEAD = 3, RW_RING = 4;
+#ifndef CPX_RW_AHEAD
+#define CPX_RW_AHEAD 3
+#endif
+  constexpr int RW_AHEAD = CPX_RW_AHEAD, RW_RING = CPX_RW_AHEAD + 1;
   auto compute = [&](auto cc, auto bc, auto&& between) __attribute__((always_inline)) {
     constexpr int C = decltype(cc)::value, B = decltype(bc)::value;
     const uint4* sb = s_buf + B * BUF + a_base;

@@ -1365,17 +1365,21 @@ void cpx_nlm_kernel(TrackArgs a, int t) {
       const int sa0 = NLM_R - 3 + c0, sb0 = sa0 + dx;   // byte of a row where the 18 values of segment 0 start (>= 0; sa0 = 0 mod 4)
       const int bbase = sb0 & ~3;                       // 4-byte aligned start of the b values; the shift is wave-uniform
       const u32 bsel = 0x03020100u + 0x01010101u * (u32)(sb0 & 3);
-      const int items = nrows * nseg;
-      // (row, segment) of this thread's first item and the step of 1024 items, without a division per item
+      // (row, segment) of this thread's first item, without a division
       const u32 mg = (1u << 20) / (u32)nseg + 1u;        // floor(i / nseg) = (i * mg) >> 20 for i < 1024, nseg < 1024
       int rr = (int)((__umul24((u32)tid, mg)) >> 20);
       int sg = tid - rr * nseg;
-      const int drr = NT_NLM / nseg, dsg = NT_NLM - drr * nseg;
-      for (int it = tid; it < items; it += NT_NLM) {
-        const int er = rr + NLM_R - 3 - dy;                // padded row of the a values
-        const int so = __umul24((u32)sg, 12u);
-        const u32* pa = reinterpret_cast<const u32*>(ext + __umul24((u32)er, (u32)ES) + sa0 + so);
-        const u32* pb = reinterpret_cast<const u32*>(ext + __umul24((u32)(er + dy), (u32)ES) + bbase + so);
+      const int drr = NT_NLM / nseg;   // rows one sweep of the block covers
+      // a thread keeps its SEGMENT and walks rows in a constant stride of drr rows (the threads past drr * nseg idle): the
+      // three per-item addresses advance by wave-uniform constants instead of being rebuilt from (row, segment) per item
+      // (measured 3.667 -> 3.623 us per frame, profiles/r06_nlm_experiments.md)
+      const bool has_seg = rr < drr;
+      const int so = __umul24((u32)sg, 12u);
+      const u32* pa = reinterpret_cast<const u32*>(ext + __umul24((u32)(rr + NLM_R - 3 - dy), (u32)ES) + sa0 + so);
+      const u32* pb = reinterpret_cast<const u32*>(ext + __umul24((u32)(rr + NLM_R - 3), (u32)ES) + bbase + so);
+      uint2* hp = reinterpret_cast<uint2*>(Hh + __umul24((u32)rr, (u32)HS) + so);
+      const int stepE = (drr * ES) >> 2, stepH = (drr * HS) >> 2;   // (uniform; in dwords / uint2: ES and HS are multiples of 8)
+      for (; has_seg && rr < nrows; rr += drr, pa += stepE, pb += stepE, hp += stepH) {
         u32 ra[5], qb[6];
 #pragma unroll
         for (int k = 0; k < 5; ++k) ra[k] = pa[k];
@@ -1411,16 +1415,9 @@ void cpx_nlm_kernel(TrackArgs a, int t) {
         u32 o[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) o[m] = as_u32(__builtin_elementwise_min(sadd(sadd(G[m], sadd(G[m + 1], G[m + 2])), D[m + 3]), cap));
-        uint2* hp = reinterpret_cast<uint2*>(Hh + __umul24((u32)rr, (u32)HS) + so);   // 24 bytes, 8-byte aligned
         hp[0] = make_uint2(o[0], o[1]);
         hp[1] = make_uint2(o[2], o[3]);
         hp[2] = make_uint2(o[4], o[5]);
-        rr += drr;
-        sg += dsg;
-        if (sg >= nseg) {
-          sg -= nseg;
-          ++rr;
-        }
       }
     }
   };

@@ -1,10 +1,10 @@
 """Builds profiles/<round>_e2e_pmc.json (round = $CPX_ROUND, default r02) from the rocprofv3 counter CSVs of four passes (run on the GPU box from the repo
 root, after `cd /tmp && export TMPDIR=/tmp && cd -`):
 
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_e2e_fetch -- python3 bench.py --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_e2e_write -- python3 bench.py --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_trk_fetch -- python3 bench.py --stage track --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_trk_write -- python3 bench.py --stage track --clips 1024 --steps 1 --warmup 0 --cpu-clips 0
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_e2e_fetch -- python3 bench.py --steps 1 --warmup 0 --cpu-clips 0 --no-extras --from-files 0   (the bench's own 4,096 clips)
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_e2e_write -- python3 bench.py --steps 1 --warmup 0 --cpu-clips 0 --no-extras --from-files 0   (the bench's own 4,096 clips)
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_trk_fetch -- python3 bench.py --stage track --steps 1 --warmup 0 --cpu-clips 0 --no-extras --from-files 0   (the bench's own 4,096 clips)
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_trk_write -- python3 bench.py --stage track --steps 1 --warmup 0 --cpu-clips 0 --no-extras --from-files 0   (the bench's own 4,096 clips)
 
 FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-byte read requests at 64 bytes; Infinity-Cache hits are
 counted too); WRITE_SIZE is taken as is.  Values are KiB per dispatch."""
@@ -15,7 +15,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("CPX_ROUND", "r05")
+ROUND = os.environ.get("CPX_ROUND", "r06")
+CLIPS = int(os.environ.get("CPX_PMC_CLIPS", "4096"))  # clips per GPU of the profiled bench command (round 6: the bench's own size)
 
 
 def rocprof_check():
@@ -51,7 +52,7 @@ def rows(dirname, counter, kernel_sub, phase=None):
     path = max(glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*_counter_collection.csv")),
                key=os.path.getmtime)  # the newest pass (gpurun merges outputs, older passes stay around)
     rs = [(int(r["Dispatch_Id"]), int(r["Grid_Size"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path))
-          if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
+          if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ((kernel_sub,) if isinstance(kernel_sub, str) else kernel_sub))]
     rs.sort()
     out = [(g, v) for _, g, v in rs]
     if phase is not None:
@@ -68,6 +69,11 @@ def common_grid(dirname, counter, kernel_sub):
 
 def avg(dirname, counter, kernel_sub, grid=None, phase=None):
     vals = [v for g, v in rows(dirname, counter, kernel_sub, phase) if grid is None or g == grid]
+    if grid is None and vals:
+        # persistent kernels launch one grid whatever the batch: the launches of the untimed BatchNorm calibration (48 samples)
+        # are told apart by their traffic -- only launches with at least half the largest value count
+        top = max(vals)
+        vals = [v for v in vals if v * 2 >= top]
     return sum(vals) / len(vals), len(vals)
 
 
@@ -82,7 +88,7 @@ def section(kernel, fetch_dir, write_dir, kernel_sub, grid, units, unit, algo, n
 
 
 out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py [--stage track] "
-                  "--clips 1024 --steps 1 --warmup 0 --cpu-clips 0 (separate passes, scratch/make_pmc_profile.py)",
+                  "--clips %d --steps 1 --warmup 0 --cpu-clips 0 --no-extras (separate passes, scratch/make_pmc_profile.py)" % CLIPS,
        "note": "KiB per dispatch, averaged over the launches named; FETCH_SIZE doubled per MI355X_MICROARCH.md, "
                "WRITE_SIZE as is"}
 CONV = "conv_bf3w_kernel<"
@@ -96,7 +102,8 @@ conv_n = grid3 // (25 * 2 * 512)
 grid2 = 100 * 2 * 512 * conv_n
 has2 = any(g == grid2 for g, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", CONV2))
 BLOCK = "conv_block32_kernel"
-fused = bool(rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK))
+BLOCKS = "conv_block32s_kernel"  # round 6: the blocks past the stage's first (the two convolutions on different waves)
+fused = bool(rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK)) or bool(rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCKS))
 if has2:
   out["conv_stage2"] = section(
       "conv_bf3w_kernel<false, true, 1, 1, 2, true, false> (fp16x2, the default math), stage-2 launches of %d samples (64->64 ch, 160x160)" % conv_n, "pmc_e2e_fetch",
@@ -111,24 +118,48 @@ if rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK + "<true>"):
         "the block's 16-channel input in, its 64-channel output out: N*160*160*64*4 B * 1.25")
 if fused:
     out["conv_block"] = section(
-        "conv_block32_kernel (fp16x2), a stage-2 residual block of %d samples in one launch (two 3x3 convs 64->64 ch, 160x160)" % conv_n,
-        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK + "<false>", None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.0,
+        "conv_block32s_kernel / conv_block32_kernel<false> (fp16x2), a stage-2 residual block of %d samples in one launch (two 3x3 convs 64->64 ch, 160x160)" % conv_n,
+        "pmc_e2e_fetch", "pmc_e2e_write", (BLOCKS, BLOCK + "<false>"), None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.0,
         "the block's input in, its output out: N*160*160*64*4 B * 2 (halo re-reads and the residual are L2 hits by design)")
-out["conv_stage3"] = section(
-    "conv_bf3w_kernel<false, true, 2, 1, 2, true, false> (fp16x2), stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
-    "pmc_e2e_write", CONV3, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
-    "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
-# one launch walks 1024 clips through their 270 frames (bench.py defaults): clip-frames per launch
+RW3 = "conv_rw_kernel<1, 2, 16"
+if rows("pmc_e2e_fetch", "FETCH_SIZE", RW3):
+    # round 6: four of the five stage-3 launches of this shape per forward run conv_rw_kernel<1, 2, 16, ...> (two with a BatchNorm
+    # prologue, two with a residual), the one that carries the stage's 1x1 shortcut stays on conv_bf3w_kernel: the mean over all
+    # of them is the per-launch traffic of bench.py's `conv_stage3` leg (its time is the mean over the same five)
+    out["conv_stage3"] = section(
+        "conv_rw_kernel<1, 2, 16, *, *> x 4 + conv_bf3w_kernel<false, true, 2, 1, 2, true, false> x 1 per forward (fp16x2), stage-3 "
+        "launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch", "pmc_e2e_write", (RW3, CONV3), None, conv_n, "samples",
+        conv_n * 80 * 80 * 128 * 4 * 2.6,
+        "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
+    for name, sub, mult, note in (("conv_stage3_rw_bn", RW3 + ", true, false>", 2.0, "input + output: N*80*80*128*4 B * 2"),
+                                  ("conv_stage3_rw_res", RW3 + ", false, true>", 3.0, "input + residual + output: N*80*80*128*4 B * 3")):
+        if rows("pmc_e2e_fetch", "FETCH_SIZE", sub):
+            out[name] = section(sub.replace("conv_rw_kernel", "conv_rw_kernel") + " (fp16x2), launches of %d samples" % conv_n,
+                                "pmc_e2e_fetch", "pmc_e2e_write", sub, None, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * mult, note)
+    for name, sub, algo, note in (
+            ("conv_stride2_rw", "conv_rw_kernel<2, 1, 8", conv_n * (160 * 160 * 64 + 80 * 80 * 128) * 4,
+             "the stride-2 first convolution of stage 3: N*(160*160*64 + 80*80*128)*4 B"),
+            ("conv_stride3_rw", "conv_rw_kernel<3, 2, 4", conv_n * (80 * 80 * 128 + 27 * 27 * 256) * 4,
+             "the stride-3 first convolution of stage 4: N*(80*80*128 + 27*27*256)*4 B")):
+        if rows("pmc_e2e_fetch", "FETCH_SIZE", sub):
+            out[name] = section(sub + ", true, false> (fp16x2), launches of %d samples" % conv_n, "pmc_e2e_fetch", "pmc_e2e_write", sub,
+                                None, conv_n, "samples", algo, note)
+else:
+    out["conv_stage3"] = section(
+        "conv_bf3w_kernel<false, true, 2, 1, 2, true, false> (fp16x2), stage-3 launches of %d samples (128->128 ch, 80x80)" % conv_n, "pmc_e2e_fetch",
+        "pmc_e2e_write", CONV3, grid3, conv_n, "samples", conv_n * 80 * 80 * 128 * 4 * 2.6,
+        "input + output (+ residual in 3 of the 5 stage-3 convolutions of this shape): N*80*80*128*4 B * 2.6")
+# one launch walks CLIPS clips through their 270 frames (bench.py defaults): clip-frames per launch
 FRAMES = int(os.environ.get("CPX_BENCH_FRAMES", "270"))
 out["frame_kernel_e2e"] = section(
-    "cpx_frame_kernel, one launch = 1024 clips x %d frames, no label image (end-to-end configuration)" % FRAMES, "pmc_e2e_fetch",
+    "cpx_frame_kernel, one launch = %d clips x %d frames, no label image (end-to-end configuration)" % (CLIPS, FRAMES), "pmc_e2e_fetch",
     "pmc_e2e_write", "cpx_frame_kernel", max(g for g, _ in rows("pmc_e2e_fetch", "FETCH_SIZE", "cpx_frame_kernel")),  # (the BatchNorm calibration of the synthetic network tracks 96 clips first: not that launch)
-    1024 * FRAMES, "clip-frames", (614400 - 76800) * 1024 * FRAMES,
+    CLIPS * FRAMES, "clip-frames", (614400 - 76800) * CLIPS * FRAMES,
     "SURVEY 8(d): 614,400 B per frame minus the 76,800 B label image")
 if glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_trk_fetch", "*", "*_counter_collection.csv")):
     out["frame_kernel_track"] = section(
-        "cpx_frame_kernel, one launch = 1024 clips x %d frames, label image written (BASELINE configs[1])" % FRAMES, "pmc_trk_fetch",
-        "pmc_trk_write", "cpx_frame_kernel", None, 1024 * FRAMES, "clip-frames", 614400 * 1024 * FRAMES, "SURVEY 8(d): 614,400 B per frame")
+        "cpx_frame_kernel, one launch = %d clips x %d frames, label image written (BASELINE configs[1])" % (CLIPS, FRAMES), "pmc_trk_fetch",
+        "pmc_trk_write", "cpx_frame_kernel", None, CLIPS * FRAMES, "clip-frames", 614400 * CLIPS * FRAMES, "SURVEY 8(d): 614,400 B per frame")
 json.dump(out, open(os.path.join(ROOT, "profiles", ROUND + "_e2e_pmc.json"), "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict):
