@@ -279,16 +279,17 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
   }
   // integer form of `bg < f - w_k` for integer bg, f (cpx_track.hip, streaming pass): keep <=> f - bg >= hi_k,
   // hi_k = floor(w_k) + 1.  Exact whenever w_k is an integer or at least 1e-6 away from one (f - w_k is then no
-  // integer and its float64 rounding, < 2e-11 for f < 65536, cannot reach one).  Otherwise bit 31 is set and the
-  // kernel decides f - bg == rint(w_k) with the float64 expression; hi_k = rint(w_k) + 1 then.
+  // integer and its float64 rounding, < 2e-11 for f < 65536, cannot reach one).  Otherwise ("near") the kernel decides
+  // f - bg == rint(w_k) with the float64 expression; hi_k = rint(w_k) + 1 then.  The entry is 2 hi_k - near_k: the kernel
+  // keeps on 2 (f - bg) + 1 > entry and evaluates the float64 expression on equality (odd entries only).
   std::vector<uint32_t> thr(h->wtab_len);
   for (int k = 0; k < h->wtab_len; ++k) {
     const double wk = wt[k], m = std::nearbyint(wk);
     const bool exact = (wk == m), near = !exact && std::fabs(wk - m) < 1e-6;
     double hi = near ? m + 1.0 : std::floor(wk) + 1.0;
     if (!(hi >= 0.0)) hi = 0.0;                    // (negative weight_add: never reached by a sane config)
-    if (hi > 1073741824.0) hi = 1073741824.0;      // beyond any f - bg: never kept
-    thr[k] = (uint32_t)hi | (near ? 0x80000000u : 0u);
+    if (hi > 536870912.0) hi = 536870912.0;        // beyond any f - bg: never kept (and 2 hi a positive int32)
+    thr[k] = 2u * (uint32_t)hi - (near ? 1u : 0u);
   }
   if (hipMalloc((void**)&h->wthr_dev, thr.size() * sizeof(uint32_t)) != hipSuccess ||
       hipMemcpy(h->wthr_dev, thr.data(), thr.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
@@ -479,8 +480,10 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
     CPX_HIP(h, hipStreamSynchronize(h->stream));  // the staged vectors die here
     h->staged_bg.clear();
   }
-  // medians of all new frames first (independent of the clips' frame order; the frame kernel copies them into the
-  // records it writes): one workgroup per (clip, step)
+  // medians of all new frames first (independent of the clips' frame order; their word of the records is theirs alone,
+  // the frame kernel stores around it): one workgroup per (clip, step).  Nothing orders the two kernels, but running
+  // them side by side on two streams gains nothing (the call takes 123.1 ms against 122.6 ms,
+  // profiles/r06_track_experiments.md): in front, on the one stream.
   if ((long long)B * (max_proc - t_begin) > 2147483647LL) return fail(h, CPX_ERR_INVALID, "batch too large for one launch");
   cpx::launch_median(a, B, t_begin, max_proc, h->stream);
   CPX_HIP(h, hipEventRecord(h->ev0, h->stream));  // (ev0 .. ev1 bracket the frame / NLM kernels)

@@ -71,7 +71,7 @@ struct TrackArgs {
   const int* order;         // [B] clips by falling number of processed frames (workgroup index -> clip), or nullptr
   const double* wtab;       // [max_frames+2] k-fold float64 accumulation of weight_add
   int wtab_len;             // entries of wtab / wthr
-  const uint32_t* wthr;     // [wtab_len] hi_k = floor(w_k) + 1 | bit 31: w_k within 1e-6 of an integer, not equal to it
+  const uint32_t* wthr;     // [wtab_len] 2 hi_k - near_k: hi_k = floor(w_k) + 1; near_k: w_k within 1e-6 of an integer, not equal to it
   // per-clip state
   int nlm_flip;             // 1: a denoiser wrote the hand-over image into the other slot (back half reads that)
   double* bgavg;            // [B] background average after the last front half (split steps only)

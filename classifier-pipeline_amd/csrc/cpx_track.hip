@@ -264,7 +264,7 @@ constexpr int WTAB_LDS = 512;
 __host__ __device__ inline size_t wtab_lds_offset(int W, int H) {
   const size_t P = (size_t)W * H;
   const size_t used = 3 * P + 2 * (size_t)H * RW * 8 + (size_t)9 * CAP * 4 + (NWAVE + 1) * sizeof(Red1) + NWAVE * 2 * sizeof(int) + 16 +
-                      3 * NWAVE * sizeof(u32) + 16 + 16;  // (+ 16: s_keep, the record's scalars parked across the labelling phases)
+                      3 * NWAVE * sizeof(u32) + 16 + 16 + 16;  // (+ 16: s_keep, the record's scalars parked across the labelling phases; + 16: s_mag)
   return (used + 15) & ~(size_t)15;
 }
 // values every lane holds alike (read from LDS or through a vector load) -> scalar registers
@@ -320,6 +320,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   // end of the step; kept in registers in between they cost four of the 64 the labelling phases have and went to scratch
   // (36 B per lane of scratch = 12 % more HBM traffic than the layout needs, profiles/r05_e2e_pmc.json).  Parked here instead.
   int* s_keep = reinterpret_cast<int*>(smem + wtab_lds_offset(W, H)) - 4;
+  u32* s_mag = reinterpret_cast<u32*>(s_keep) - 4;  // the frame's normalisation as an integer division: multiplier, shift (phase 3)
   LdsDouble* s_wtab = (LdsDouble*)(smem + wtab_lds_offset(W, H));
   LdsU32* s_wthr = (LdsU32*)(smem + wtab_lds_offset(W, H) + WTAB_LDS * sizeof(double));
 
@@ -358,7 +359,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   if (mode != 2) {
   // ---- phase 1a: thermal frame -> LDS (phase 1b reads it there), sum / min / max ----------------
   // (np.median(thermal) of ClipStats is not on the dependency chain of the clip's frames: cpx_median_kernel
-  // computes it for all frames at once and the record at the end of the step picks it up)
+  // computes it for all frames at once and writes its word of the record; the step's store of the record leaves that word alone)
   {
     u32 sumpix = 0, minpix = 0xFFFFFFFFu, maxpix = 0;
     // all loads first and unconditionally (clamped address): a load inside `if (c < nchunk)` is waited for before
@@ -486,22 +487,41 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       int nb[2];
       float fo[2];
       u32 xs2[2];
+      // |pix - bg| of both pixels + the running sum in one v_sad_u16 on the packed pairs (written per pixel on the unpacked
+      // values the compiler spent 11 instructions per two steps on SDWA min / max pairs)
+#ifndef CPX_TRACK_SAD32
+      sabs = __builtin_amdgcn_sad_u16(pq, (u32)bgv[0] | ((u32)bgv[1] << 16), sabs);
+#else
+      sabs = __usad((u32)pix[0], (u32)bgv[0], sabs);
+      sabs = __usad((u32)pix[1], (u32)bgv[1], sabs);
+#endif
+      // interior test per pixel; with the usual one-pixel border the column tests are the ones the background selects made
+      bool colin[2];
+      if (edge1) {
+        colin[0] = x0 != 0;
+        colin[1] = x0 != W - 2;
+      } else {
+        colin[0] = x0 >= e && x0 <= W - 1 - e;
+        colin[1] = x0 + 1 >= e && x0 + 1 <= W - 1 - e;
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int d = pix[j] - bgv[j];  // filtered = float32(pix) - background (cliptrackextractor.py:212)
         fo[j] = (float)d;
         r.fmin = min(r.fmin, d);
         r.fmax = max(r.fmax, d);
-        sabs = __usad((u32)pix[j], (u32)bgv[j], sabs);  // |pix - bg| + sum in one v_sad_u32
         int xs = d - avg_change;  // cliptracker.py:109-114
         xs = xs < 0 ? 0 : xs;
         xs2[j] = (u32)xs;
         // background feed: np.int32(np.mean(last <=45 frames)) == window_sum // n (cliptrackextractor.py:173-176)
         wsv[j] = wsv[j] + (u32)pix[j] - (u32)oldp[j];
         const int f = (nwin > 1) ? (int)__umulhi(wsv[j], div_magic) : (int)wsv[j];  // == wsv / nwin exactly
-        const int x = x0 + j;
         nb[j] = bgv[j];
-        if (row_in && x >= e && x <= W - 1 - e) {
+#ifndef CPX_TRACK_COLTEST
+        if (row_in && colin[j]) {
+#else
+        if (row_in && x0 + j >= e && x0 + j <= W - 1 - e) {
+#endif
           // motiondetector.py:212-223: bg' = bg if bg < f - w else f ; w' = w + add if (same) else 0
           // keep <=> bg < fl64(f - w_k), w_k = k-fold float64 accumulation of weight_add.  For integers bg, f that is
           // d = f - bg >= hi_k with hi_k = floor(w_k) + 1 from a table (csrc/cpx_api.cpp:weight_thresholds) -- unless
@@ -511,10 +531,12 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
           // waits for the prefetched loads; longer runs of kept frames go to the tables in memory.
           const int kk = kv[j];
           const int d2 = f - bgv[j];
-          const u32 th = s_wthr[min(kk, WTHR_LDS - 1)];
-          const int hi = (int)(th & 0x7FFFFFFFu);
-          bool keep = d2 >= hi;
-          if (kk >= WTHR_LDS || ((th >> 31) && d2 == hi - 1)) {
+          // (the table holds 2 hi_k - near_k: keep <=> 2 d + 1 > entry; the float64 expression decides on equality, which
+          // only an odd entry -- a near one -- can reach)
+          const int th = (int)s_wthr[min(kk, WTHR_LDS - 1)];
+          const int c2 = 2 * d2 + 1;
+          bool keep = c2 > th;
+          if (kk >= WTHR_LDS || c2 == th) {
             // (the loads are consumed INSIDE the branch: a value merged after it would put the wait for them, and
             // with it for every prefetched load, on the common path)
             int far;
@@ -597,6 +619,17 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       q.maxpix = maxpix;
       q.changed = q.changed != 0;
       *s_R = q;
+      {  // phase 3 divides by span = max - min of the shifted, clipped frame: multiplier and shift of that division, once per frame
+        int lo = q.fmin - avg_change, hi = q.fmax - avg_change;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi < 0 ? 0 : hi;
+        const u32 d = (u32)(hi - lo);
+        const int l = d > 1u ? 32 - __clz((int)(d - 1u)) : 0;   // ceil(log2 d)
+        // floor(2^(24 + l) / d) + 1 < 2^25 + 1.  In float64: the quotient is below 2^25 and, unless it is an integer (d a power of
+        // two: exact), at least 1 / d >= 2^-17 away from one -- the division's error (< 2^-28) cannot carry the floor
+        s_mag[0] = d ? (u32)floor(__longlong_as_double((long long)(1023 + 24 + l) << 52) / (double)d) + 1u : 0u;
+        s_mag[1] = (u32)l;
+      }
     }
   }
   __syncthreads();
@@ -607,6 +640,13 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
   mx = mx < 0 ? 0 : mx;
 
   // ---- phase 3: normalise to 0..255 (float32, imageprocessing.py:151-169) -> uint8 in LDS
+  // np.uint8(float32(255 * (x - mn)) / float32(mx - mn)).  With span = mx - mn <= 65793 the product n = 255 (x - mn) < 2^24 is exact
+  // in float32, and the correctly rounded quotient truncates to floor(n / span): n / span <= 255 lies at least 1 / span > 2^-17
+  // below the next integer unless it is one, and 2^-17 is half an ulp of [128, 256) -- rounding to nearest cannot reach it.  So
+  // the phase is an integer division by a per-frame constant: floor(n m / 2^(24 + l)) with m = floor(2^(24 + l) / span) + 1,
+  // l = ceil(log2 span), exact for every n < 2^24 (Granlund & Montgomery 1994, theorem 4.2: 2^(24+l) <= m span <= 2^(24+l) + 2^l);
+  // as instructions: mad_u32_u24 ((x - mn) 255 2^8 < 2^32), mul_hi_u32, shift -- 3 instead of the 16 of an IEEE division.
+  // Wider spans (pixels and background 65 k apart) take the float32 expression itself.
   {
     const float fmn = (float)mn, fmx = (float)mx;
     const float span = fmx - fmn;
@@ -615,24 +655,39 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     } else {
       thresh = __fmul_rn(__fdiv_rn((float)a.background_thresh, span), 255.0f);
     }
+    if (mx == mn) {
+      const u32 fill = (mx == 0) ? 0u : 0x01010101u;  // zeros, or data / max == 1
 #pragma unroll 1
-    for (int c = tid; c < nchunk; c += NT) {
-      {
+      for (int c = tid; c < nchunk; c += NT) *reinterpret_cast<u32*>(s_u8 + (c << 2)) = fill;
+#ifndef CPX_NORM_FLOAT   // (experiment switch: -DCPX_NORM_FLOAT = the float32 expression for every span)
+    } else if (mx - mn <= 65793) {
+#else
+    } else if (false) {
+#endif
+      const u32 mg = (u32)uni((int)s_mag[0]);
+      const int lsh = uni((int)s_mag[1]);
+      const u32 cadd = 0u - (u32)mn * 65280u;
+#pragma unroll 1
+      for (int c = tid; c < nchunk; c += NT) {
+        const uint2 ql = *reinterpret_cast<const uint2*>(s_tmp + (c << 2));
+        const u32 qh = *reinterpret_cast<const u32*>(s_u8 + (c << 2));
+        const u32 xv[4] = {(ql.x & 0xFFFFu) | ((qh & 0xFFu) << 16), (ql.x >> 16) | (((qh >> 8) & 0xFFu) << 16),
+                           (ql.y & 0xFFFFu) | (((qh >> 16) & 0xFFu) << 16), (ql.y >> 16) | ((qh >> 24) << 16)};
+        u32 o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o |= (__umulhi(__umul24(xv[j], 65280u) + cadd, mg) >> lsh) << (8 * j);
+        *reinterpret_cast<u32*>(s_u8 + (c << 2)) = o;
+      }
+    } else {
+#pragma unroll 1
+      for (int c = tid; c < nchunk; c += NT) {
         const uint2 ql = *reinterpret_cast<const uint2*>(s_tmp + (c << 2));
         const u32 qh = *reinterpret_cast<const u32*>(s_u8 + (c << 2));
         const int xv[4] = {(int)((ql.x & 0xFFFFu) | ((qh & 0xFFu) << 16)), (int)((ql.x >> 16) | (((qh >> 8) & 0xFFu) << 16)),
                            (int)((ql.y & 0xFFFFu) | (((qh >> 16) & 0xFFu) << 16)), (int)((ql.y >> 16) | ((qh >> 24) << 16))};
         unsigned char o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float val;
-          if (mx == mn) {
-            val = (mx == 0) ? 0.0f : 1.0f;  // zeros, or data / max == 1
-          } else {
-            val = __fdiv_rn(__fmul_rn(255.0f, (float)xv[j] - fmn), span);
-          }
-          o[j] = (unsigned char)(int)val;  // np.uint8() truncation
-        }
+        for (int j = 0; j < 4; ++j) o[j] = (unsigned char)(int)__fdiv_rn(__fmul_rn(255.0f, (float)xv[j] - fmn), span);  // np.uint8() truncation
         *reinterpret_cast<uchar4*>(s_u8 + (c << 2)) = make_uchar4(o[0], o[1], o[2], o[3]);
       }
     }
@@ -685,6 +740,86 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     s_keep[2] = mx;
     s_keep[3] = __float_as_int(thresh);
   }
+#ifndef CPX_BLUR_SCALAR
+  // ---- phase 4a: horizontal [1 4 6 4 1], BORDER_REFLECT_101 -----------------------
+  // Packed 16-bit arithmetic, two pixels per instruction (sums <= 16 * 255): a group of 8 output pixels reads the 16 bytes
+  // around it with three aligned LDS loads (the reflections only exist at the two ends of a row: byte shuffles of the group
+  // itself), spreads the 12 pixels it needs into pairs (p[2j], p[2j+1]) = E_j and (p[2j+1], p[2j+2]) = O_j with v_perm /
+  // v_alignbit, and out pair j = E_j + E_j+2 + 4 (O_j + O_j+1) + 6 E_j+1: 4 packed instructions per two pixels.  (Per pixel
+  // on 32-bit values this phase and the next were ~25 of the kernel's 145 vector instructions per pixel.)
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const int ngroup = P >> 3;
+  const int gpr = W >> 3;  // 8-pixel groups per row
+  auto as_us2 = [](u32 v) -> us2 { return __builtin_bit_cast(us2, v); };
+  auto as_u32 = [](us2 v) -> u32 { return __builtin_bit_cast(u32, v); };
+  // row of group g without an integer division (run-time width): (g + 0.5) / gpr is at least 0.5 / gpr >= 0.02 away from an
+  // integer, g < 2560 -- float32 cannot misplace it.  The group's pixels start at 8 g (W = 8 gpr).
+  const float inv_gpr = 1.0f / (float)gpr;
+  auto row_of = [&](int g) -> int { return (int)(((float)g + 0.5f) * inv_gpr); };
+  for (int g = tid; g < ngroup; g += NT) {
+    const int x0 = (g - (int)__umul24((u32)row_of(g), (u32)gpr)) << 3;
+    const int at = g << 3;
+    const uint2 mid = *reinterpret_cast<const uint2*>(s_u8 + at);              // pixels x0 .. x0 + 7
+    u32 left = *reinterpret_cast<const u32*>(s_u8 + max(at - 4, 0));           // x0 - 4 .. x0 - 1 (bytes 2, 3 are used)
+    u32 right = *reinterpret_cast<const u32*>(s_u8 + at + 8);                  // x0 + 8 .. x0 + 11 (bytes 0, 1 are used)
+    // REFLECT_101: p[-1] = p[1], p[-2] = p[2]; p[W] = p[W - 2], p[W + 1] = p[W - 3]
+    left = (x0 == 0) ? __builtin_amdgcn_perm(0u, mid.x, 0x01020C0Cu) : left;
+    right = (x0 == W - 8) ? __builtin_amdgcn_perm(0u, mid.y, 0x0C0C0102u) : right;
+    us2 E[6], O[5];
+    E[0] = as_us2(__builtin_amdgcn_perm(0u, left, 0x0C030C02u));
+    E[1] = as_us2(__builtin_amdgcn_perm(0u, mid.x, 0x0C010C00u));
+    E[2] = as_us2(__builtin_amdgcn_perm(0u, mid.x, 0x0C030C02u));
+    E[3] = as_us2(__builtin_amdgcn_perm(0u, mid.y, 0x0C010C00u));
+    E[4] = as_us2(__builtin_amdgcn_perm(0u, mid.y, 0x0C030C02u));
+    E[5] = as_us2(__builtin_amdgcn_perm(0u, right, 0x0C010C00u));
+#pragma unroll
+    for (int k = 0; k < 5; ++k) O[k] = as_us2(__builtin_amdgcn_alignbit(as_u32(E[k + 1]), as_u32(E[k]), 16));
+    u32 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = as_u32((E[k] + E[k + 2]) + (O[k] + O[k + 1]) * (unsigned short)4 + E[k + 1] * (unsigned short)6);
+    *reinterpret_cast<uint4*>(s_tmp + at) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  __syncthreads();
+  // ---- phase 4b: vertical pass, (S + 128) >> 8, floor-threshold -> bit rows ---------
+  // packed as well (sums <= 16 * 4080 = 65280 fit 16 bits): rows y-2 + y+2, 4 (y-1 + y+1), 6 y.  ((S + 128) >> 8) > ithr is
+  // S >= 256 (ithr + 1) - 128 =: T, i.e. the saturating difference S - (T - 1) is non-zero; T <= 0 sets every pixel, T > 65280 none.
+  {
+    const int ic = ithr < -2 ? -2 : (ithr > 300 ? 300 : ithr);
+    const int T = 256 * (ic + 1) - 128;
+    const u32 tm1 = (u32)(T <= 0 ? 0 : (T > 65535 ? 65535 : T - 1));
+    const us2 tsub = as_us2(tm1 | (tm1 << 16)), one = as_us2(0x00010001u);
+    for (int g = tid; g < ngroup; g += NT) {
+      const int y = row_of(g), xg = g - (int)__umul24((u32)y, (u32)gpr);
+      // rows y-2, y-1, y+1, y+2 reflected at the borders, as distances from this row (no multiplication by the run-time width)
+      const int da = (y >= 2) ? -2 * W : (y == 0 ? 2 * W : 0);
+      const int db = (y >= 1) ? -W : W;
+      const int dc = (y + 1 < H) ? W : -W;
+      const int dd = (y + 2 < H) ? 2 * W : (y + 2 == H ? 0 : -2 * W);
+      const uint16_t* c0 = s_tmp + (g << 3);
+      const uint4 qa = *reinterpret_cast<const uint4*>(c0 + da);
+      const uint4 qb = *reinterpret_cast<const uint4*>(c0 + db);
+      const uint4 q0 = *reinterpret_cast<const uint4*>(c0);
+      const uint4 qc = *reinterpret_cast<const uint4*>(c0 + dc);
+      const uint4 qd = *reinterpret_cast<const uint4*>(c0 + dd);
+      const u32 ra[4] = {qa.x, qa.y, qa.z, qa.w}, rb[4] = {qb.x, qb.y, qb.z, qb.w}, r0[4] = {q0.x, q0.y, q0.z, q0.w},
+                rc[4] = {qc.x, qc.y, qc.z, qc.w}, rd[4] = {qd.x, qd.y, qd.z, qd.w};
+      u32 m = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const us2 S = (as_us2(ra[k]) + as_us2(rd[k])) + (as_us2(rb[k]) + as_us2(rc[k])) * (unsigned short)4 + as_us2(r0[k]) * (unsigned short)6;
+        // 0 / 1 per half: min(saturating S - (T - 1), 1).  (As vector code the compiler turns this into a compare and a select per
+        // half and a byte shuffle: twice the instructions.)
+        u32 hit;
+        asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(hit) : "v"(as_u32(S)), "v"(as_u32(tsub)), "v"(as_u32(one)));
+        m |= hit << (2 * k);   // bits 2k and 16 + 2k
+      }
+      u32 bits = (m | (m >> 15)) & 0xFFu;
+      bits = (T <= 0) ? 0xFFu : bits;
+      reinterpret_cast<unsigned char*>(s_rowI)[(int)__umul24((u32)y, (u32)(RW * 8)) + xg] = (unsigned char)bits;
+    }
+  }
+  __syncthreads();
+#else
   // ---- phase 4a: horizontal [1 4 6 4 1], BORDER_REFLECT_101 -----------------------
   const int ngroup = P >> 3;
   const int gpr = W >> 3;  // 8-pixel groups per row
@@ -734,6 +869,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     reinterpret_cast<unsigned char*>(s_rowI)[y * (RW * 8) + (x0 >> 3)] = (unsigned char)bits;
   }
   __syncthreads();
+#endif
   // ---- phase 5: MORPH_CLOSE with the 1x2 element ----------------------
   for (int i = tid; i < H * RW; i += NT) {
     const int y = i / RW;
@@ -1022,13 +1158,22 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     fi.thermal_min = (int)R.minpix;
     fi.thermal_max = (int)R.maxpix;
     fi.thermal_sum = R.sumpix;
-    // cpx_median_kernel put it there before this kernel started (volatile: loaded here, not at the top of the step)
-    fi.thermal_median = *reinterpret_cast<volatile const float*>(&a.info_out[fidx].thermal_median);
+    fi.thermal_median = 0.0f;  // (not stored: the field is cpx_median_kernel's)
     fi.filtered_abs_sum = R.sumabs;
     fi.background_average = ns.bg_average;
     fi.background_changed = (int)R.changed;
     fi.reserved = 0;
-    a.info_out[fidx] = fi;
+    {  // the record without its thermal_median word (offset 52): cpx_median_kernel writes that one (no load of it here)
+      static_assert(sizeof(cpx_frame_info) == 80 && offsetof(cpx_frame_info, thermal_median) == 52, "record layout");
+      uint2 q[10];
+      __builtin_memcpy(q, &fi, sizeof(fi));
+      uint2* o = reinterpret_cast<uint2*>(&a.info_out[fidx]);   // (the record's alignment is 8)
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        if (i != 6) o[i] = q[i];
+      }
+      reinterpret_cast<u32*>(o)[12] = q[6].x;
+    }
     a.cstate[b] = ns;
   }
   cs = uniform_state(ns);
