@@ -1068,6 +1068,82 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     o.pixel_variance = var;
     Cout[rnk[cidx]] = o;
   };
+#ifndef CPX_VAR_PER_WAVE
+  // The components of a frame share the workgroup's waves: with nc components in a round (at most NWAVE), NWAVE / nc waves sum
+  // each one's box, partials meet in LDS, the first lane of a group combines them in wave order.  (One wave per component left
+  // eleven of twelve waves waiting on the usual one or two boxes, seven trips to L2 long: the phase was 9 % of the step.)
+  // Box pixel k -> (row, column) by a float32 reciprocal and one correction step (k < 20480: the estimate is off by at most one);
+  // normalised values by float32 division when it provably equals float32(float64 division): integer operands below 2^24,
+  // i.e. spans <= 65793 (the quotient of such integers is 2^-41 relative away from any float32 rounding boundary it is not on,
+  // float64's own rounding moves it by 2^-53).
+  const int icmin = s_R->fmin, icmax = s_R->fmax, ipmin = cs.prev_fmin, ipmax = cs.prev_fmax;
+  const bool narrow = (icmax - icmin <= 65793) && (ipmax - ipmin <= 65793) && icmax < 65536 && icmin > -65536 &&
+                      ipmax < 65536 && ipmin > -65536;
+  auto delta32_at = [&](int q) -> double {
+    const float cv = *at_off(filt_cur, (unsigned)q << 2), pv = *at_off(filt_prev, (unsigned)q << 2);
+    float an, bn;
+    if (icmax == icmin) an = (icmax == 0) ? 0.0f : __fdiv_rn(cv, (float)icmax);
+    else an = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(cv, (float)icmin)), (float)(icmax - icmin));
+    if (ipmax == ipmin) bn = (ipmax == 0) ? 0.0f : __fdiv_rn(pv, (float)ipmax);
+    else bn = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(pv, (float)ipmin)), (float)(ipmax - ipmin));
+    return (double)fabsf(an - bn);
+  };
+  if (!has_prev) {
+    for (int cidx = tid; cidx < ncomp; cidx += NT) {
+      const int bx = (int)stat[1 * SC + cidx], by = (int)stat[3 * SC + cidx];
+      emit(cidx, bx, by, (int)stat[2 * SC + cidx] - bx + 1, (int)stat[4 * SC + cidx] - by + 1, 0.0f);
+    }
+  } else {
+    int par = 0;
+    for (int base = 0; base < ncomp; base += NWAVE) {
+      const int nc = min(NWAVE, ncomp - base);
+      const int G = NWAVE / nc;                       // waves per component (uniform)
+      const int ci = (int)((u32)wave / (u32)G), wi = wave - ci * G;   // (per wave: uniform within it)
+      const bool mine = ci < nc;
+      const int cidx = base + (mine ? ci : 0);
+      const int bx = (int)stat[1 * SC + cidx], by = (int)stat[3 * SC + cidx];
+      const int bw = (int)stat[2 * SC + cidx] - bx + 1, bh = (int)stat[4 * SC + cidx] - by + 1;
+      const int n = bw * bh;
+      if (mine) {
+        const float inv_bw = 1.0f / (float)bw;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = wi * 64 + lane; k < n; k += 64 * G) {
+          int yy = (int)((float)k * inv_bw);
+          int xx = k - (int)__umul24((u32)yy, (u32)bw);
+          if (xx < 0) {
+            --yy;
+            xx += bw;
+          } else if (xx >= bw) {
+            ++yy;
+            xx -= bw;
+          }
+          const int q = (by + yy) * W + bx + xx;
+          const double d = narrow ? delta32_at(q) : delta_at(q);
+          s1 += d;
+          s2 += d * d;
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+          s_part[(par * NWAVE + wave) * 2] = s1;
+          s_part[(par * NWAVE + wave) * 2 + 1] = s2;
+        }
+      }
+      phase_sync();
+      if (mine && wi == 0 && lane == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < G; ++w) {
+          t1 += s_part[(par * NWAVE + wave + w) * 2];
+          t2 += s_part[(par * NWAVE + wave + w) * 2 + 1];
+        }
+        const double mean = t1 / (double)n;
+        const double var = t2 / (double)n - mean * mean;
+        emit(cidx, bx, by, bw, bh, (float)(var < 0.0 ? 0.0 : var));
+      }
+      par ^= 1;
+    }
+  }
+#else
   constexpr int BIG = 512;  // pixels: above this a box is summed by the whole workgroup
   int par = 0;
   for (int cidx = 0; cidx < ncomp; ++cidx) {
@@ -1120,6 +1196,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
     }
   }
 
+#endif
   };
   if (big) label_phases(a.big_stat + (size_t)b * 9 * a.cap_out, a.big_stat + (size_t)b * 9 * a.cap_out + (size_t)8 * a.cap_out, a.cap_out, true);
   else label_phases(s_stat, s_rank, CAP, false);
