@@ -138,6 +138,11 @@ __device__ __forceinline__ u32 wave_count_le_halves(u32 packed, u32 bound) {
   return c0 + c1;
 }
 
+__device__ __forceinline__ u32 pk_add_u16(u32 x, u32 y) {  // v_pk_add_u16
+  typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(u32, (us2_t)(__builtin_bit_cast(us2_t, x) + __builtin_bit_cast(us2_t, y)));
+}
+
 // ---- bit-row helpers (rows are RW little-endian 64-bit words, bit x = pixel x) ----
 __device__ __forceinline__ int run_start(const u64* row, int x) {
   int w = x >> 6;
@@ -1309,6 +1314,10 @@ namespace {
 constexpr int NT_MED = 256;
 constexpr int NW_MED = NT_MED / 64;
 constexpr int MCH = (4 * NCH * NT / 4 + NT_MED - 1) / NT_MED;  // 4-pixel chunks per thread at the largest frame
+#ifndef CPX_MED_SCALAR_PART
+#define CPX_MED_SCALAR_PART 40   // per cent of a thread's registers counted through the scalar unit (see the bisection loop)
+#endif
+constexpr int MED_SCALAR = MCH * CPX_MED_SCALAR_PART / 100;
 }  // namespace
 __global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0, int nsteps) {
   const int b = (int)(blockIdx.x / (unsigned)nsteps), t = t0 + (int)(blockIdx.x - (unsigned)b * (unsigned)nsteps);
@@ -1360,9 +1369,28 @@ __global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0,
   while (lo < hi) {  // uniform: every thread sees the same block totals
     const u32 mid = (lo + hi) >> 1;
     u32 cnt = 0;
+    // The compare + s_bcnt1 form costs two scalar instructions per value and the CU has ONE scalar unit for its four SIMDs: alone
+    // it ran that unit at ~80 % (profiles/r06_track_experiments.md).  So the last MCH - MED_SCALAR registers count on the vector
+    // side instead, packed: saturating v - mid is non-zero exactly for v > mid, min(., 1) makes it a flag, a packed add keeps a
+    // count per lane and half (3 vector instructions per two values); <= is the complement (the padding counts as > mid).
 #pragma unroll
-    for (int i = 0; i < MCH; ++i) {
+    for (int i = 0; i < MED_SCALAR; ++i) {
       cnt += wave_count_le_halves(pk[i][0], mid) + wave_count_le_halves(pk[i][1], mid);
+    }
+    {
+      const u32 midpk = mid | (mid << 16);
+      u32 gt = 0;
+#pragma unroll
+      for (int i = MED_SCALAR; i < MCH; ++i) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          u32 f;
+          asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(f) : "v"(pk[i][hh]), "v"(midpk), "v"(0x00010001u));
+          gt = pk_add_u16(gt, f);
+        }
+      }
+      const u32 gtw = wave_sum((gt & 0xFFFFu) + (gt >> 16));
+      cnt += (u32)(64 * 4 * (MCH - MED_SCALAR)) - gtw;
     }
     if (lane == 0) s_cnt[par * NW_MED + wave] = cnt;
     __syncthreads();
