@@ -37,8 +37,11 @@ for name, cs in acc.items():
     if "duration_ns" in o and o["duration_ns"] > 0:
         o["clock_GHz"] = o["GRBM_GUI_ACTIVE"] / 8 / o["duration_ns"]
         o["mfma_busy_frac_of_cycles"] = o["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (o["GRBM_GUI_ACTIVE"] / 8)
-        # 16-bit MFMA FLOPs issued: 16,384 per instruction (16x16x32 and 32x32x16 alike) against the 2.5 PFLOP/s dense peak
-        o["mfma_issued_tflops"] = o["SQ_INSTS_MFMA"] * 16384 / o["duration_ns"] / 1e3
+        # 16-bit MFMA FLOPs issued against the 2.5 PFLOP/s dense peak: 16,384 per v_mfma_f32_16x16x32_f16, 32,768 per
+        # v_mfma_f32_32x32x16_f16 (the flattened kernel and conv_bf3_kernel)
+        per = 32768 if ("conv_bf3flat_kernel" in name or name.startswith("conv_bf3_kernel<")) else 16384
+        o["mfma_flops_per_instruction"] = per
+        o["mfma_issued_tflops"] = o["SQ_INSTS_MFMA"] * per / o["duration_ns"] / 1e3
         o["frac_of_16bit_mfma_peak"] = o["mfma_issued_tflops"] / 2500.0
     out[name] = o
 json.dump(out, open(f"gpurun_out/pmc_{tag}_summary.json", "w"), indent=1)
