@@ -114,7 +114,7 @@ HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1
 
 
 EXPORTS = [
-    "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize",
+    "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize", "cpx_join_medians",
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_counts_prefix", "cpx_plan_segments", "cpx_aggregate_predictions",
@@ -132,7 +132,7 @@ IR_FRAME_STATS_DTYPE = np.dtype([("min", "<i4"), ("max", "<i4"), ("sum", "<i8"),
 assert IR_FRAME_STATS_DTYPE.itemsize == 32
 
 # flags of cpx_track_batch_ex / cpx_track_frame_ex and cpx_track_limits_batch_ex (include/cpx.h)
-TRACK_KEEP_BACKGROUND, TRACK_FREEZE_ON_FFC, TRACK_FREEZE_BACKGROUND = 1, 2, 4
+TRACK_KEEP_BACKGROUND, TRACK_FREEZE_ON_FFC, TRACK_FREEZE_BACKGROUND, TRACK_DEFER_MEDIANS = 1, 2, 4, 8
 LIMITS_POST_PROCESS, LIMITS_THERMAL_DIFF_NORM, LIMITS_NO_DIFF_NORM, LIMITS_ALWAYS_CLIP, LIMITS_SWAP_CHANNELS = 1, 2, 4, 8, 16
 LIMITS_TF_SCALING = 32
 
@@ -167,6 +167,8 @@ def load():
     lib.cpx_stream.restype = vp
     lib.cpx_synchronize.argtypes = [vp]
     lib.cpx_synchronize.restype = C.c_int
+    lib.cpx_join_medians.argtypes = [vp]
+    lib.cpx_join_medians.restype = C.c_int
     lib.cpx_track_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp]
     lib.cpx_track_batch.restype = C.c_int
     lib.cpx_associate_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -263,7 +265,7 @@ def load():
     lib.cpx_track_workspace_bytes.restype = C.c_size_t
     lib.cpx_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.cpx_last_kernel_timing.restype = C.c_int
-    if lib.cpx_abi_version() != 2:
+    if lib.cpx_abi_version() != 3:
         raise ImportError("libcpx_hip.so ABI version mismatch")
     _lib = lib
     return lib

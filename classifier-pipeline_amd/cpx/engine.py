@@ -372,6 +372,11 @@ class TrackEngine:
 
     def _release(self):
         self._live_results -= 1
+        # a result of a TRACK_DEFER_MEDIANS call dropped before anything read its medians: its blocks return to this stream's
+        # pool while the median kernel may still write them from the second stream -- order the stream behind it (a stream
+        # wait; nothing pending: a no-op)
+        if self.h:
+            self.lib.cpx_join_medians(self.h)
         if self._live_results == 0 and self._close_deferred:
             self._close_deferred = False
             try:

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from ._lib import CROP_REQ_DTYPE, REGION_REF_DTYPE, CpxError
+from ._lib import CROP_REQ_DTYPE, REGION_REF_DTYPE, TRACK_DEFER_MEDIANS, CpxError
 from .tracking import TRACK_SUMMARY_DTYPE, make_filter_params, make_track_params
 
 
@@ -212,7 +212,10 @@ class BatchPipeline:
         if pre is not None:
             out.track, out.assoc = pre
         else:
-            out.track = eng.track_batch(frames_dev, offs, meta, want_filtered=True, outputs=outputs)
+            # (the per-frame medians run on the handle's second stream beside the association, finalisation and plan below,
+            # none of which reads them; cpx_track_limits_batch_ex / cpx_crop_tile / engine.synchronize() wait for them)
+            out.track = eng.track_batch(frames_dev, offs, meta, want_filtered=True, outputs=outputs,
+                                        flags=TRACK_DEFER_MEDIANS)
             out.assoc = eng.associate_batch(out.track, offs, meta, params=self.tp, want_regions=self.want_regions)
         # ---- 3. end of clip: trim / stats / rejects / plan sizes ----
         mt = self.tp.max_tracks

@@ -51,6 +51,9 @@ struct cpx_handle {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
   int split_min_clips = 0;  // 0 = never split
+  // CPX_TRACK_DEFER_MEDIANS: the median kernel of the last track call runs on stream2; ev_median marks its end
+  bool medians_pending = false;
+  hipEvent_t ev_median = nullptr;
   bool track_per_step = false;  // CPX_TRACK_PER_STEP=1: one launch per frame step (the form before the per-clip walk)
   std::vector<struct cpx_cnn*> cnns;  // networks created on this handle (destroyed with it)
   std::vector<struct cpx_mog2*> mog2s;  // background models created on this handle
@@ -241,6 +244,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
       hipEventCreateWithFlags(&h->ev_front[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_back[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_back[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_median, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     cpx_destroy(h);
     return CPX_ERR_HIP;
@@ -348,6 +352,7 @@ void cpx_destroy(cpx_handle* h) {
     hipStreamSynchronize(h->stream2);
     hipStreamDestroy(h->stream2);
   }
+  if (h->ev_median) hipEventDestroy(h->ev_median);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -358,8 +363,25 @@ const char* cpx_last_error(const cpx_handle* h) { return h ? h->err.c_str() : "n
 
 void* cpx_stream(cpx_handle* h) { return h ? (void*)h->stream : nullptr; }
 
+// Medians of a CPX_TRACK_DEFER_MEDIANS call still in flight on stream2: what is enqueued on the handle's stream from here
+// on runs behind them.  Called by every entry point that reads cpx_frame_info.thermal_median or reuses the buffers the
+// median kernel reads and writes.
+static int join_medians(cpx_handle* h) {
+  if (h->medians_pending) {
+    h->medians_pending = false;
+    CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_median, 0));
+  }
+  return CPX_OK;
+}
+
+int cpx_join_medians(cpx_handle* h) {
+  if (!h) return CPX_ERR_INVALID;
+  return join_medians(h);
+}
+
 int cpx_synchronize(cpx_handle* h) {
   if (!h) return CPX_ERR_INVALID;
+  if (int rc = join_medians(h)) return rc;
   CPX_HIP(h, hipStreamSynchronize(h->stream));
   return CPX_OK;
 }
@@ -378,8 +400,10 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
                      cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
                      float* background_dev, int flags) {
   CPX_ENTER(h);
-  if (flags & ~(CPX_TRACK_KEEP_BACKGROUND | CPX_TRACK_FREEZE_ON_FFC | CPX_TRACK_FREEZE_BACKGROUND))
+  if (flags & ~(CPX_TRACK_KEEP_BACKGROUND | CPX_TRACK_FREEZE_ON_FFC | CPX_TRACK_FREEZE_BACKGROUND | CPX_TRACK_DEFER_MEDIANS))
     return fail(h, CPX_ERR_INVALID, "track: unknown flag");
+  if (int jrc = join_medians(h)) return jrc;  // (a previous call's medians read the frames / write the records this one may reuse)
+  const bool defer_medians = (flags & CPX_TRACK_DEFER_MEDIANS) != 0;
   const cpx_config& c = h->cfg;
   Schedule sc;
   int rc = build_schedule(h, clip_offsets, meta, B, &sc);
@@ -485,7 +509,8 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   // them side by side on two streams gains nothing (the call takes 123.1 ms against 122.6 ms,
   // profiles/r06_track_experiments.md): in front, on the one stream.
   if ((long long)B * (max_proc - t_begin) > 2147483647LL) return fail(h, CPX_ERR_INVALID, "batch too large for one launch");
-  cpx::launch_median(a, B, t_begin, max_proc, h->stream);
+  // CPX_TRACK_DEFER_MEDIANS: behind the frame kernel on the second stream instead (below), beside the caller's next stages
+  if (!defer_medians) cpx::launch_median(a, B, t_begin, max_proc, h->stream);
   CPX_HIP(h, hipEventRecord(h->ev0, h->stream));  // (ev0 .. ev1 bracket the frame / NLM kernels)
   // (with the internal ping-pong of filtered frames the back half of step t would read what the front half of
   // step t+1 overwrites: split only when the caller keeps every filtered frame)
@@ -521,6 +546,12 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
     if (max_proc - t_begin >= 2) CPX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_back[(max_proc - 2) & 1], 0));
   }
   CPX_HIP(h, hipEventRecord(h->ev1, h->stream));
+  if (defer_medians) {
+    CPX_HIP(h, hipStreamWaitEvent(h->stream2, h->ev1, 0));  // (the records' memset and the frame kernels are in front of ev1)
+    cpx::launch_median(a, B, t_begin, max_proc, h->stream2);
+    CPX_HIP(h, hipEventRecord(h->ev_median, h->stream2));
+    h->medians_pending = true;
+  }
   h->last_launches = launches;
   h->timing_valid = true;
   if (background_dev) cpx::launch_export_background(a, B, background_dev, h->stream);
@@ -780,6 +811,7 @@ int cpx_track_limits_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const f
     return fail(h, CPX_ERR_INVALID, "cpx_track_limits_batch: bad argument");
   if (n_tracks == 0) return CPX_OK;
   CPX_ENTER(h);
+  if (int jrc = join_medians(h)) return jrc;  // (reads cpx_frame_info.thermal_median)
   cpx::ClassifyArgs a = classify_args(h);
   a.limits_flags = flags;
   a.frames = frames_dev;
@@ -803,6 +835,7 @@ int cpx_crop_tile(cpx_handle* h, const uint16_t* frames_dev, const float* filter
     return fail(h, CPX_ERR_UNSUPPORTED, "cpx_crop_tile: frame_size must be 1..128, square_width 1..16");
   if (n_reqs == 0) return CPX_OK;
   CPX_ENTER(h);
+  if (int jrc = join_medians(h)) return jrc;  // (reads cpx_frame_info.thermal_median)
   cpx::ClassifyArgs a = classify_args(h);
   a.frames = frames_dev;
   a.filtered = filtered_dev;
@@ -1274,6 +1307,7 @@ int cpx_thumb_stats_ex(cpx_handle* h, const uint16_t* frames_dev, const int32_t*
     return fail(h, CPX_ERR_INVALID, "cpx_thumb_stats: bad argument");
   if (n_refs == 0) return CPX_OK;
   CPX_ENTER(h);
+  if (int jrc = join_medians(h)) return jrc;  // (reads cpx_frame_info.thermal_median)
   cpx::ThumbArgs a{};
   a.W = h->cfg.width;
   a.H = h->cfg.height;

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPX_ABI_VERSION 2
+#define CPX_ABI_VERSION 3
 
 typedef enum cpx_status {
   CPX_OK = 0,
@@ -173,10 +173,25 @@ int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_m
  *                                65,535 frames in a row (two hours at 9 fps) across chained calls wraps to 0
  *   CPX_TRACK_FREEZE_ON_FFC      FFC-affected frames leave background, weights and average untouched
  *   CPX_TRACK_FREEZE_BACKGROUND  no frame updates them (update_background = False: the caller owns the model)
+ *   CPX_TRACK_DEFER_MEDIANS      (cpx_track_batch_ex; ABI 3) cpx_frame_info.thermal_median -- np.median(thermal) of
+ *                                ClipStats.add_frame, track/clip.py:474-487, which only the clip statistics and the
+ *                                classifier's crops read -- is computed on the handle's SECOND stream behind the frame
+ *                                kernel, beside whatever the caller enqueues next on cpx_stream(h): the association,
+ *                                finalisation and segment-plan stages do not read it and are latency-bound, the medians
+ *                                cost nothing next to them (10 ms of a 377 ms step of 4096 clips).  The medians are
+ *                                complete for every later entry point of the handle that reads them
+ *                                (cpx_track_limits_batch(_ex), cpx_crop_tile, cpx_thumb_stats(_ex)), for the next
+ *                                cpx_track_* call, after cpx_synchronize(h), and for work enqueued on cpx_stream(h) after
+ *                                cpx_join_medians(h) -- NOT for a caller who only synchronises cpx_stream(h) itself.
+ *                                frames_dev and info_dev must stay allocated until one of those.
  * cpx_track_batch / cpx_track_frame are the _ex calls with flags 0. */
 #define CPX_TRACK_KEEP_BACKGROUND 1
 #define CPX_TRACK_FREEZE_ON_FFC 2
 #define CPX_TRACK_FREEZE_BACKGROUND 4
+#define CPX_TRACK_DEFER_MEDIANS 8
+/* Orders everything enqueued on cpx_stream(h) from here on behind the medians a CPX_TRACK_DEFER_MEDIANS call left in
+ * flight (a stream wait, the host does not block); nothing to do otherwise. */
+int cpx_join_medians(cpx_handle* h);
 int cpx_track_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
                        const cpx_frame_meta* meta, int B, cpx_component* comps_dev, cpx_frame_info* info_dev,
                        int32_t* labels_dev, float* filtered_dev, float* background_dev, int flags);

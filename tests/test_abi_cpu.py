@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.EXPORTS)
-    assert lib.cpx_abi_version() == 2
+    assert lib.cpx_abi_version() == 3
 
 
 def test_create_fails_loudly_without_gpu():

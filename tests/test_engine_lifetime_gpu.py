@@ -108,3 +108,37 @@ def test_close_waits_for_live_results():
     sib.close()                                   # idempotent
     eng.close()
     assert not eng.h
+
+
+def test_deferred_medians_are_complete_for_their_readers():
+    """CPX_TRACK_DEFER_MEDIANS (include/cpx.h): the medians run on the handle's second stream behind the frame kernel.  They
+    must be what the in-front form computes -- read after engine.synchronize(), by a stream-ordered reader after
+    cpx_join_medians, and by the limits kernel (which subtracts them) -- and a following track call must not overtake them."""
+    import ctypes as C
+
+    import torch
+
+    from cpx._lib import TRACK_DEFER_MEDIANS
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3", device=0, max_frames=128)
+    frames, offs, meta = _batch(eng, n_clips=256, frames=90)
+    want = eng.track_batch(frames, offs, meta, want_filtered=True).info["thermal_median"].copy()
+    assert np.all(want > 0)
+    for trial in range(3):
+        res = eng.track_batch(frames, offs, meta, want_filtered=True, flags=TRACK_DEFER_MEDIANS)
+        assert np.array_equal(res.info["thermal_median"], want), trial          # (host accessor: engine.synchronize())
+        # a stream-ordered device reader: join, then a copy on the engine's stream
+        res = eng.track_batch(frames, offs, meta, want_filtered=True, flags=TRACK_DEFER_MEDIANS)
+        assert eng.lib.cpx_join_medians(eng.h) == 0
+        with torch.cuda.stream(eng.torch_stream()):
+            med = res.info_dev.view(-1, 20)[:, 13].clone()
+        eng.torch_stream().synchronize()
+        assert np.array_equal(med.cpu().numpy().view(np.float32), want), trial
+        # two deferred calls back to back into the same buffers: the second call's memset of the records waits for the first
+        # call's medians, and its own medians are the ones read
+        outputs = (res.comps_dev, res.info_dev, None, res.filtered_dev, None)
+        eng.track_batch(frames, offs, meta, outputs=outputs, flags=TRACK_DEFER_MEDIANS)
+        again = eng.track_batch(frames, offs, meta, outputs=outputs, flags=TRACK_DEFER_MEDIANS)
+        assert np.array_equal(again.info["thermal_median"], want), trial
+    eng.close()
