@@ -51,6 +51,7 @@ struct cpx_handle {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
   int split_min_clips = 0;  // 0 = never split
+  bool fuse_conv1 = true;   // conv1_1 inside the fused first block of stage 2 (CPX_CNN_FUSE_CONV1=0: a launch of its own)
   // CPX_TRACK_DEFER_MEDIANS: the median kernel of the last track call runs on stream2; ev_median marks its end
   bool medians_pending = false;
   hipEvent_t ev_median = nullptr;
@@ -307,6 +308,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     return CPX_ERR_HIP;
   }
   if (const char* env = std::getenv("CPX_TRACK_SPLIT_MIN_CLIPS")) h->split_min_clips = std::atoi(env);
+  if (const char* env = std::getenv("CPX_CNN_FUSE_CONV1")) h->fuse_conv1 = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_TRACK_PER_STEP")) h->track_per_step = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_FUSE_SHORTCUT")) h->fuse_shortcut = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_PLANES_HANDOVER")) h->planes_handover = std::atoi(env) != 0;
@@ -989,6 +991,11 @@ static int conv_run(cpx_handle* h, const cpx_conv_desc* d, const void* split_wei
       rc = cpx::launch_conv(a, h->stream);
     }
   } else {
+    if (hf && hf->rerun_only) {  // (conv1_1 behind a fused first block that computed it: only that block's rerun needs the tensor)
+      const int rco = ensure_ovf_word(h);
+      if (rco != CPX_OK) return rco;
+      a.guard = h->cnn_ovf + hf->word;
+    }
     rc = cpx::launch_conv(a, h->stream);
   }
   if (timed) {
@@ -1544,8 +1551,18 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
     d.out_scale_dev = out_scale; d.out_shift_dev = out_shift; d.residual_dev = residual;
     return conv_run(h, &d, cnn->split_of(w), nullptr, &hf);
   };
-  int rc = conv(in_dev, act[0], p.conv1_w, H, W, p.in_channels, p.filters[0], 3, 1, 1, 0, nullptr, nullptr, nullptr,
-                p.conv1_b, nullptr);
+  // conv1_1.  fp16x2 with the stage-2 first block fused: that block's kernel computes this layer while it stages its patch
+  // (conv_block32_kernel<true, true>) and the launch here becomes the block's guarded rerun's -- unless the block turns out not
+  // to be fusable, in which case it is launched in front of it as ever
+  auto conv1 = [&]() {
+    return conv(in_dev, act[0], p.conv1_w, H, W, p.in_channels, p.filters[0], 3, 1, 1, 0, nullptr, nullptr, nullptr, p.conv1_b,
+                nullptr);
+  };
+  bool c1_pending = h->cnn_math == CPX_CNN_MATH_FP16X2 && h->block_fusion >= 2 && h->fuse_shortcut && h->fuse_conv1 &&
+                    p.groups == 2 && p.in_channels == 2 && p.filters[0] == 16 && p.blocks_per_stage >= 1;
+  bool c1_fused = false;
+  int rc = CPX_OK;
+  if (!c1_pending) rc = conv1();
   if (rc != CPX_OK) return rc;
   float* cur = act[0];
   int flip = 0, c_in = p.filters[0], hh = H, ww = W;
@@ -1591,19 +1608,32 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
           cb.residual = cur;
         }
         cb.act_scale = cnn->act_scale[st][d][1]; cb.act_unscale = 1.0f / cb.act_scale;
+        const bool c1_try = first8 && c1_pending && st == 0 && d == 0;
+        if (c1_try) {
+          ca.c1_in = in_dev; ca.c1_w = p.conv1_w; ca.c1_b = p.conv1_b;
+        }
         if (cpx::conv_block32_supported(ca, cb)) {
           cpx_handle::ConvEv ev{};
           if (h->conv_timing) {
-            // ("stride 4": a fused block; both convolutions' products, the shortcut's not counted)
+            // ("stride 4": a fused block; both convolutions' products -- and conv1_1's when it is computed inside --, the shortcut's not counted)
             ev.key = (c_in / p.groups) * 10000 + 32 * 10 + 4;
             ev.flops = 2.0 * N * hh * ww * f * ((double)(c_in / p.groups) + (double)(f / p.groups)) * 9;
+            if (c1_try) ev.flops += 2.0 * N * hh * ww * c_in * (double)(p.in_channels / p.groups) * 9;
             if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess)
               return fail(h, CPX_ERR_HIP, "cpx_cnn_forward: event creation failed");
             CPX_HIP(h, hipEventRecord(ev.e0, h->stream));
           }
-          const int rb = cpx::launch_conv_block32(ca, cb, cnn->split_of(b.wa), cnn->split_of(b.wb), h->stream);
+          int rb = cpx::launch_conv_block32(ca, cb, cnn->split_of(b.wa), cnn->split_of(b.wb), h->stream);
+          if (rb != 0 && c1_try) {  // not with conv1_1 inside: the layer as a launch of its own, then the block as before
+            c1_pending = false;
+            rc = conv1();
+            if (rc != CPX_OK) return rc;
+            ca.c1_in = ca.c1_w = ca.c1_b = nullptr;
+            rb = cpx::launch_conv_block32(ca, cb, cnn->split_of(b.wa), cnn->split_of(b.wb), h->stream);
+          }
           if (rb == 0) {
             hf.rerun_only = true;
+            c1_fused = c1_try && c1_pending;
             if (h->conv_timing) {
               CPX_HIP(h, hipEventRecord(ev.e1, h->stream));
               h->conv_events.push_back(ev);
@@ -1613,6 +1643,14 @@ int cpx_cnn_forward(cpx_cnn* cnn, const float* in_dev, int N, int H, int W, floa
             if (rb != -2 && rb != -3) return fail(h, CPX_ERR_HIP, "cpx_cnn_forward: block kernel configuration failed");
           }
         }
+      }
+      if (c1_pending) {  // conv1_1: in front of a first block that did not take it, or guarded, as the head of that block's rerun
+        c1_pending = false;
+        const bool was = hf.rerun_only;
+        hf.rerun_only = c1_fused;
+        rc = conv1();
+        hf.rerun_only = was;
+        if (rc != CPX_OK) return rc;
       }
       if (hf.rerun_only) planes_pair = false;  // (the rerun hands float32 over)
       hf.act_scale = cnn->act_scale[st][d][0];

@@ -325,6 +325,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 // only): one thread per pixel computes all 16 output channels -- float2 input loads, four 16-byte stores per
 // pixel (64 contiguous bytes), weights through uniform (scalar) loads.  HBM-bound: 8 B read, 64 B written per pixel.
 __global__ __launch_bounds__(256) void conv1_kernel(ConvArgs a) {
+  // (guarded: behind a fused first block that computed this layer itself, the tensor is only needed by the block's rerun)
+  if (a.guard != nullptr && *a.guard == 0) return;
   __shared__ float4 s_out[4 * 256];
   const size_t total = (size_t)a.N * a.Ho * a.Wo;
   // the loop condition is wave-uniform (a wave's first pixel): in the last wave of a launch whose pixel count is not a

@@ -1329,8 +1329,18 @@ constexpr int B_WIMG = 3 * 2 * 3 * 4 * 32;  // entries of one convolution's fp16
 // shortcut on v_mfma_f32_16x16x4_f32 before the epilogue, as conv_bf3w_kernel's do.
 constexpr int B8_NPXP = B_NPX + 2;             // entries per plane of the 8-channel patch (a region of its own): 400 pixels, one zero entry, one spare
 constexpr int B8_WIMG = 3 * 2 * 4 * 32;        // entries of the first convolution's fp16 image of one group (C8)
-template <bool C8>
+// C1 (with C8, round 6): the network's first convolution (conv1_1: 3x3, ONE input channel and 8 output channels per group, bias)
+// is computed here too, while the patch is staged -- a thread takes a patch pixel, reads the nine raw input values around it and
+// forms the pixel's 8 channels of the block's input with conv1_kernel's own multiply-adds in its order (the same float32 values),
+// instead of loading them: the 64 B per pixel conv1_kernel wrote and this kernel read back (31 GB per step of 9,659 samples: a
+// 5.3 ms launch and the patch loads of this one) never exist.  The 1x1 shortcut takes its operand -- the block's input at the
+// output pixels -- from a float32 copy of the tile's centre in LDS (two buffers: the next tile is staged under this tile's
+// second convolution).  A rerun after an fp16 overflow needs the tensor in memory: conv1_kernel is launched behind, guarded.
+constexpr int B_C1W = 96;                 // floats: conv1's weights [9][8] and bias [8] of one group (+ padding)
+constexpr int B_C1C = 256 * 8;            // floats per buffer of the centre copy: 16 x 16 pixels x 8 channels
+template <bool C8, bool C1 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_block32_kernel(ConvArgs a, ConvArgs b, const uint4* __restrict__ wa, const uint4* __restrict__ wb, TileDiv td) {
+  static_assert(!C1 || C8, "conv1 is fused into the stage's first block only");
   if (*a.ovf != 0) return;  // (the block's guarded three-plane launches follow)
   constexpr int WA_IMG = C8 ? B8_WIMG : B_WIMG;
   constexpr int CING = C8 ? 8 : 32;  // input channels per group of the first convolution
@@ -1343,6 +1353,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4* s_bn = reinterpret_cast<f32x4*>(s_wb + B_WIMG);
   // the patch: the region mid takes over later -- or (C8: 13 KB, and a zero entry that must survive) a region of its own
   uint4* s_px = C8 ? reinterpret_cast<uint4*>(s_bn) + 16 : s_r0;
+  float* s_c1w = reinterpret_cast<float*>(s_px + 2 * B8_NPXP);  // (C1) [9][8] weights, [8] bias
+  float* s_c1c = s_c1w + B_C1W;                                  // (C1) [2][256][8] the block's input at the tile's 16 x 16 output pixels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
   const int g = blockIdx.y;
   const int C = b.Cout;    // channels of mid and of the output (the block's input has a.Cin: the same unless C8)
@@ -1356,6 +1368,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     reinterpret_cast<float*>(s_bn)[CING + tid] = a.in_shift[g * CING + tid] * a.act_scale;
   }
   if (C8 && tid < 2) reinterpret_cast<u32x4*>(s_px)[tid * B8_NPXP + B_NPX] = u32x4{0u, 0u, 0u, 0u};  // the zero entry of either plane
+  if (C1 && tid < 80) s_c1w[tid] = tid < 72 ? a.c1_w[g * 72 + tid] : a.c1_b[g * 8 + tid - 72];
   // tiles: every XCD walks its own contiguous eighth of the tile space (the workgroups of a launch go round-robin over
   // the XCDs), the workgroups of an XCD side by side in it: neighbours' halos meet in that XCD's L2
   const int per_xcd = (td.total + 7) >> 3;
@@ -1391,12 +1404,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < NP; ++i) issue_item(i);
   };
+  // (C1) one thread per patch pixel: the nine raw input values of conv1's window around it (channel g), clamped addresses
+  float c1_raw[C1 ? 9 : 1];
+  auto c1_pixel = [&](int& py, int& pxx) __attribute__((always_inline)) {
+    int t8 = tid;
+    asm volatile("" : "+v"(t8));
+    const int px = min(t8, B_NPX - 1);
+    py = (int)(__umul24((unsigned)px, 3277u) >> 16);
+    pxx = __mul24(py, -B_PW) + px;
+  };
+  auto issue_c1 = [&]() __attribute__((always_inline)) {
+    if constexpr (C1) {
+      int py, pxx;
+      c1_pixel(py, pxx);
+      const float* in_n = a.c1_in + (size_t)n * a.H * a.W * a.groups + g;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int cy = min(max(oy0 - 3 + py + ky, 0), a.H - 1), cx = min(max(ox0 - 3 + pxx + kx, 0), a.W - 1);
+          c1_raw[ky * 3 + kx] = *at_off(in_n, (unsigned)((cy * a.W + cx) * a.groups) << 2);
+        }
+    }
+  };
   int t = blockIdx.x;
   // (td.total >= 8 gridDim.x is not required: a workgroup whose first tile does not exist has none)
   while (t < 8 * per_xcd && tile_of(t) >= td.total) t += gridDim.x;
   if (t >= 8 * per_xcd) return;
   decode(tile_of(t));
-  issue_patch();
+  if constexpr (C1) issue_c1();
+  else issue_patch();
   // what a thread needs of the channel parameters is the same for every tile: registers (one workgroup per CU: 256 to spend)
   const int ch_l = g * 32 + 4 * q;
   f32x4 os_a[2], ob_a[2], rs_b[2], os_b[2], ob_b[2];
@@ -1415,6 +1452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();  // weights and BatchNorm parameters are in LDS
   const f32x4 psc = s_bn[tid & (PIECES - 1)], psh = s_bn[PIECES + (tid & (PIECES - 1))];
+  const f32x4 psc1 = s_bn[C1 ? 1 : 0], psh1 = s_bn[PIECES + (C1 ? 1 : 0)], psc0 = s_bn[0], psh0 = s_bn[PIECES];  // (C1: a thread converts both pieces)
   // out of fp16's range = a high plane that came out infinite.  Every staged value is >= 0 (ReLU), so fp16 bit patterns order
   // as unsigned halves: the running maximum of the high planes, two packed halves per instruction
   unsigned hmax = 0u;
@@ -1446,6 +1484,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" : "+v"(t8));
     int q8 = tid & (PIECES - 1);
     asm volatile("" : "+v"(q8));
+    if constexpr (C1) {  // a thread holds its pixel's whole entries
+      int tpx = tid;
+      asm volatile("" : "+v"(tpx));
+      if (tpx < B_NPX) {
+        reinterpret_cast<u32x4*>(s_px)[tpx] = pre_p[0];
+        reinterpret_cast<u32x4*>(s_px)[B8_NPXP + tpx] = pre_p[1];
+      }
+      return;
+    }
     if (C8) {  // [plane][pixel] of 16-byte entries: piece 0 / 1 = the entry's low / high 8 bytes
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -1467,11 +1514,79 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   };
-  auto tile_interior = [&]() { return oy0 - 2 >= 0 && oy0 + 18 <= a.H && ox0 - 2 >= 0 && ox0 + 18 <= a.W; };
+  // (C1) the pixel's 8 channels of the block's input from the nine raw values (conv1_kernel's multiply-adds, in its order, plus the
+  // bias), their float32 copy for the shortcut if the pixel is one of the tile's outputs, then the prologue and the split of both
+  // pieces: pre_p[0] / pre_p[1] = the pixel's entry of the high / low plane.  (py0, px0): the patch's origin in the image
+  // In three parts (a kernel row each; the last one finishes the pixel): under the second convolution's products a part rides on one
+  // tap -- the whole pixel in one lump (~150 vector instructions) stuck out from under a tap's twelve products.
+  float acc8[C1 ? 8 : 1];
+  auto convert_c1 = [&](const int part, const int py0, const int px0, const bool interior, const int buf) __attribute__((always_inline)) {
+    if constexpr (C1) {
+      int py, pxx;
+      c1_pixel(py, pxx);
+      if (part == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc8[c] = 0.0f;
+      }
+#pragma unroll
+      for (int tp = 3 * part; tp < 3 * part + 3; ++tp) {
+        float v = c1_raw[tp];
+        if (!interior) {  // conv1's own zero padding
+          const int ky = tp / 3, kx = tp - 3 * ky;
+          v = ((unsigned)(py0 - 1 + py + ky) < (unsigned)a.H && (unsigned)(px0 - 1 + pxx + kx) < (unsigned)a.W) ? v : 0.0f;
+        }
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_c1w + tp * 8), w1 = *reinterpret_cast<const f32x4*>(s_c1w + tp * 8 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc8[c] = __fmaf_rn(v, w0[c], acc8[c]);
+          acc8[4 + c] = __fmaf_rn(v, w1[c], acc8[4 + c]);
+        }
+      }
+      if (part < 2) return;
+      const f32x4 bs0 = *reinterpret_cast<const f32x4*>(s_c1w + 72), bs1 = *reinterpret_cast<const f32x4*>(s_c1w + 76);
+      f32x4 x0, x1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        x0[c] = acc8[c] + bs0[c];
+        x1[c] = acc8[4 + c] + bs1[c];
+      }
+      if ((unsigned)(py - 2) < 16u && (unsigned)(pxx - 2) < 16u && tid < B_NPX) {
+        f32x4* cc = reinterpret_cast<f32x4*>(s_c1c + buf * B_C1C + ((py - 2) * 16 + (pxx - 2)) * 8);
+        cc[0] = x0;
+        cc[1] = x1;
+      }
+      f32x4 y0 = __builtin_elementwise_fma(x0, psc0, psh0), y1 = __builtin_elementwise_fma(x1, psc1, psh1);
+      const bool inside = interior || ((unsigned)(py0 + py) < (unsigned)a.H && (unsigned)(px0 + pxx) < (unsigned)a.W);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y0[j] = inside ? fmaxf(y0[j], 0.0f) : 0.0f;
+        y1[j] = inside ? fmaxf(y1[j], 0.0f) : 0.0f;
+      }
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+      split_pair2_h(y0[0], y0[1], h0, l0);
+      split_pair2_h(y0[2], y0[3], h1, l1);
+      split_pair2_h(y1[0], y1[1], h2, l2);
+      split_pair2_h(y1[2], y1[3], h3, l3);
+      hmax = pk_max_u16(pk_max_u16(pk_max_u16(pk_max_u16(hmax, h0), h1), h2), h3);
+      pre_p[0] = u32x4{h0, h1, h2, h3};
+      pre_p[1] = u32x4{l0, l1, l2, l3};
+    }
+  };
+  // (C1: conv1's window reaches one pixel further than the patch)
+  auto tile_interior = [&]() {
+    constexpr int M = C1 ? 3 : 2;
+    return oy0 - M >= 0 && oy0 + 16 + M <= a.H && ox0 - M >= 0 && ox0 + 16 + M <= a.W;
+  };
+  int cbuf = 0;  // (C1) which centre buffer the tile in hand reads
   {
     const bool interior = tile_interior();
+    if constexpr (C1) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) convert_item(i, oy0 - 2, ox0 - 2, interior);
+      for (int part = 0; part < 3; ++part) convert_c1(part, oy0 - 2, ox0 - 2, interior, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) convert_item(i, oy0 - 2, ox0 - 2, interior);
+    }
   }
 #ifdef CPX_B32_STAMPS  // (experiment, scratch/build_conv_variant.sh: where a tile's time goes -- cycle stamps of waves 0 and 7 of one workgroup)
   long long st_last = clock64(), st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1576,7 +1691,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           piece_residual();
           piece_next_tile();
         } else if (more) {
-          issue_item(t4 - 1);
+          if constexpr (C1) {
+            if (t4 == 1) issue_c1();
+          } else {
+            issue_item(t4 - 1);
+          }
         }
       }
       static_assert(!C8 || NP == 2, "the patch items of the 8-channel form ride on the second and third K step");
@@ -1689,7 +1808,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             acc[ct][pt] = mfma16<true>(wv[bf][ct][0], xv[bf][pt][0], acc[ct][pt]);
           }
 #ifndef CPX_B32_NO_CONVERT
-        if (tp < NP && more) convert_item(tp, oy0 - 2, ox0 - 2, interior_next);
+        if constexpr (C1) {
+          if (tp < 3 && more) convert_c1(tp, oy0 - 2, ox0 - 2, interior_next, cbuf ^ 1);  // (in one lump on the first tap: 24,641 against 24,691 samples/s)
+        } else {
+          if (tp < NP && more) convert_item(tp, oy0 - 2, ox0 - 2, interior_next);
+        }
 #endif
       }
     }
@@ -1704,7 +1827,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int k4 = 0; k4 < CING; k4 += 4) {
         float xs[2], ws[2];
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) xs[pt] = *at_off(sc_n, (spix[pt] + (unsigned)k4) << 2);
+        for (int pt = 0; pt < 2; ++pt)
+          xs[pt] = C1 ? s_c1c[cbuf * B_C1C + ((2 * wave + pt) * 16 + i16) * 8 + q + k4] : *at_off(sc_n, (spix[pt] + (unsigned)k4) << 2);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) ws[ct] = wsc[(size_t)k4 * 32 + 16 * ct] * ss[ct];
 #pragma unroll
@@ -1733,6 +1857,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ++st_tiles;
 #endif
     if (!more) break;
+    cbuf ^= 1;
     // every wave has read its mid fragments: the region takes the next patch (C8: the patch goes to its own region, and the
     // barrier behind the commit is passed only by waves that are through with this tile's mid)
     if (!C8) __syncthreads();
@@ -2328,10 +2453,15 @@ int launch_conv_block32(const ConvArgs& a_in, const ConvArgs& b_in, const void* 
     return e == nullptr || std::atoi(e) != 0;
   }();
   if (!c8 && split_roles) return launch_conv_block32s(a, b, wa, wb, s);
-  const size_t lds = c8 ? (size_t)(B_R0 + B8_WIMG + B_WIMG) * 16 + 256 + (size_t)2 * B8_NPXP * 16 : (size_t)(B_R0 + 2 * B_WIMG) * 16 + 256;
-  static bool lds_ready[64], lds_ready8[64];
-  if (c8 ? !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<true>), lds_ready8, 160 * 1024 - 1024)
-         : !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<false>), lds_ready, 160 * 1024 - 1024))
+  // conv1 computed inside (ConvArgs::c1_in): the network's first convolution must be the shape the kernel restates
+  const bool c1 = c8 && a.c1_in != nullptr;
+  if (c1 && !(a.groups == 2 && a.c1_w != nullptr && a.c1_b != nullptr)) return -2;
+  const size_t lds = c8 ? (size_t)(B_R0 + B8_WIMG + B_WIMG) * 16 + 256 + (size_t)2 * B8_NPXP * 16 + (c1 ? (size_t)(B_C1W + 2 * B_C1C) * 4 : 0)
+                        : (size_t)(B_R0 + 2 * B_WIMG) * 16 + 256;
+  static bool lds_ready[64], lds_ready8[64], lds_ready1[64];
+  if (c1 ? !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<true, true>), lds_ready1, 160 * 1024 - 1024)
+      : c8 ? !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<true>), lds_ready8, 160 * 1024 - 1024)
+           : !cpx_dyn_lds_ready(reinterpret_cast<const void*>(conv_block32_kernel<false>), lds_ready, 160 * 1024 - 1024))
     return -1;
   // one workgroup per CU (125 KB of LDS), shared among the groups; a multiple of eight per group so that blockIdx.x & 7 is the XCD
   static int grid_x[64];
@@ -2345,7 +2475,8 @@ int launch_conv_block32(const ConvArgs& a_in, const ConvArgs& b_in, const void* 
   int gx = std::max(8, grid_x[dev] / a.groups / 8 * 8);
   if (const char* e = std::getenv("CPX_BLOCK32_GRID")) gx = std::max(8, std::atoi(e) / 8 * 8);
   gx = (int)std::min<long long>(gx, (tiles + 7) / 8 * 8);
-  if (c8) hipLaunchKernelGGL(conv_block32_kernel<true>, dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
+  if (c1) hipLaunchKernelGGL((conv_block32_kernel<true, true>), dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
+  else if (c8) hipLaunchKernelGGL(conv_block32_kernel<true>, dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
   else hipLaunchKernelGGL(conv_block32_kernel<false>, dim3((unsigned)gx, a.groups), dim3(512), lds, s, a, b, wa, wb, td);
   return 0;
 }

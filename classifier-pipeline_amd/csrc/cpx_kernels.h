@@ -192,6 +192,11 @@ struct ConvArgs {
   const float* sc_w;     // packed [groups][1][sc_cin / groups][Cout / groups]
   const float* sc_bias;  // [Cout]
   int sc_H, sc_W, sc_cin, sc_stride;
+  // conv_block32_kernel<true, true> only: the network's first convolution computed while the block's patch is staged (`in` is
+  // then never read): its raw input [N, H, W, groups], packed weights [groups][9][1][8] and bias [8 groups]
+  const float* c1_in;
+  const float* c1_w;
+  const float* c1_b;
   // bf16 planes per operand on the split-operand path: 0 / 3 = the exact three-way split, 2 = CPX_CNN_MATH_BF16X2
   // (the layers conv_bf3_two_planes() names; every other layer keeps three)
   int planes;

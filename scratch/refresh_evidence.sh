@@ -31,7 +31,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_ff
 f=$(ls -t $ROOT/gpurun_out/prof_ff/*/*kernel_stats.csv | head -1); cp "$f" $ROOT/gpurun_out/ev/${R}_from_files_kernel_stats.csv; rm -rf $ROOT/gpurun_out/prof_ff
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_ff -- python3 $ROOT/scratch/from_files_profile.py 16384 270 --fixtures > $ROOT/gpurun_out/ev/prof_from_files_fixture.log 2>&1
 f=$(ls -t $ROOT/gpurun_out/prof_ff/*/*kernel_stats.csv | head -1); cp "$f" $ROOT/gpurun_out/ev/${R}_from_files_fixture_kernel_stats.csv; rm -rf $ROOT/gpurun_out/prof_ff
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_e2e -- python3 $ROOT/bench.py --cpu-clips 0 --no-extras > $ROOT/gpurun_out/ev/prof_e2e.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_e2e -- python3 $ROOT/bench.py --cpu-clips 0 --no-extras --from-files 0 > $ROOT/gpurun_out/ev/prof_e2e.log 2>&1
 cd $ROOT
 f=$(ls -t gpurun_out/prof_e2e/*/*kernel_stats.csv | head -1); cp "$f" gpurun_out/ev/${R}_e2e_kernel_stats.csv
 # the counter CSVs are large: keep only the summary

@@ -457,6 +457,47 @@ def test_fused_first_block_matches_the_launches_it_replaces(engine, monkeypatch,
     assert float(np.abs(fused.cpu().numpy() - want).max()) <= LOGIT_ATOL
 
 
+@pytest.mark.parametrize("side,n", [(160, 3), (150, 2), (37, 1), (20, 2)])
+def test_conv1_inside_the_first_block_is_bitwise_the_launch(engine, monkeypatch, side, n):
+    """Round 6: the fused first block of stage 2 computes conv1_1 itself while it stages its patch (conv_block32_kernel<true, true>):
+    conv1_kernel's multiply-adds in its order, so the logits are those of the separate launch bit for bit
+    (CPX_CNN_FUSE_CONV1=0, read when a handle is created); no conv1 launch is timed in the fused form."""
+    import torch
+
+    import cnn_oracle as co
+    from cpx.engine import TrackEngine
+    from cpx.ml_tools import wrresnet as wr
+
+    rng = np.random.default_rng(950 + side)
+    x = rng.uniform(0, 255, size=(n, side, side, 2)).astype(np.float32)
+    x[:, ::7, :, 1] = 0.0
+    w = co.calibrate_bn(wr.random_weights(17, seed=14), x)
+    engine.set_cnn_math("fp16x2")
+    net = wr.WRResNetDevice(engine, w, 17)
+    engine.conv_timing(True)
+    fused, _ = net.forward(torch.from_numpy(x).to(engine.device))
+    launches = engine.conv_timing()
+    engine.conv_timing(False)
+    assert not engine.cnn_last_overflow()
+    assert 10081 not in launches and launches[80324][0] == 1, launches
+    net.close()
+    monkeypatch.setenv("CPX_CNN_FUSE_CONV1", "0")
+    eng2 = TrackEngine(model="lepton3")
+    monkeypatch.delenv("CPX_CNN_FUSE_CONV1")
+    eng2.set_cnn_math("fp16x2")
+    net2 = wr.WRResNetDevice(eng2, w, 17)
+    eng2.conv_timing(True)
+    ref, _ = net2.forward(torch.from_numpy(x).to(eng2.device))
+    launches2 = eng2.conv_timing()
+    assert launches2[10081][0] == 1 and launches2[80324][0] == 1, launches2
+    net2.close()
+    eng2.close()
+    engine.set_cnn_math(engine.DEFAULT_CNN_MATH)
+    assert torch.equal(fused.cpu(), ref.cpu()), float((fused.cpu() - ref.cpu()).abs().max())
+    want, _ = co.forward(w, x)
+    assert float(np.abs(fused.cpu().numpy() - want).max()) <= LOGIT_ATOL
+
+
 def test_fused_block_walks_any_share_of_the_tiles(engine, monkeypatch):
     """conv_block32_kernel is persistent: a workgroup walks its XCD's eighth of the tiles with a stride of the grid.  With
     CPX_BLOCK32_GRID=8 (one workgroup per XCD and group; read at every launch) each one walks 38 tiles of a 3-sample
