@@ -1226,11 +1226,19 @@ def main():
                         2.0, "the block's input in, its output out (the residual is the input: halo re-reads and the residual come from L2)",
                         convs=2)
                 if key0 in conv and conv[key0][1] > 0:
+                    # round 6: no conv1_1 launch of its own = the layer is computed inside this kernel (its FLOPs are in the record)
+                    c1_inside = (1 * 10000 + 8 * 10 + 1) not in conv
                     kernels["conv_block0"] = leg(
                         key0, "conv_block0",
-                        "conv_block32_kernel<true> (the first residual block of stage 2 in one launch: 3x3 conv 16->64 ch, 3x3 conv "
-                        "64->64 ch + the 1x1 shortcut 16->64, %dx%d, groups 2; FLOPs of the two 3x3 convolutions)" % (side, side),
-                        1.25, "the block's 16-channel input in, its 64-channel output out", convs=1.25)
+                        ("conv_block32_kernel<true, true> (conv1_1 2->16 ch computed while the patch is staged + the first residual block of "
+                         "stage 2 in one launch: 3x3 conv 16->64 ch, 3x3 conv 64->64 ch + the 1x1 shortcut 16->64, %dx%d, groups 2; FLOPs of "
+                         "the three 3x3 convolutions)" if c1_inside else
+                         "conv_block32_kernel<true> (the first residual block of stage 2 in one launch: 3x3 conv 16->64 ch, 3x3 conv "
+                         "64->64 ch + the 1x1 shortcut 16->64, %dx%d, groups 2; FLOPs of the two 3x3 convolutions)") % (side, side),
+                        (2 + 64) / 64.0 if c1_inside else 1.25,
+                        "the 2-channel sample in, the block's 64-channel output out" if c1_inside else
+                        "the block's 16-channel input in, its 64-channel output out",
+                        convs=1.25 + (16.0 / (64 * 32) if c1_inside else 0.0))
                 if bf3 and key3 in conv:
                     k3name = ("conv_rw_kernel<1, 2, 16, *, *> (weights resident in registers, one wave per SIMD, pixel-row fragments "
                               "shared by the three tap rows; the one launch in five that carries the stage's 1x1 shortcut stays on %s: "

@@ -111,15 +111,21 @@ if has2:
       "the second convolution of the stage's first block (the others run inside conv_block32_kernel): mid in, output out, the "
       "fused shortcut's 16-channel input: N*160*160*64*4 B * 2.25" if fused else
       "input + output (+ residual in 3 of the 5 stage-2 convolutions of this shape): N*160*160*64*4 B * 2.6")
-if rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK + "<true>"):
+if rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK + "<true, true>"):
+    # round 6: conv1_1 computed inside (conv_block32_kernel<true, true>): the 2-channel sample in, the 64-channel output out
+    out["conv_block0"] = section(
+        "conv_block32_kernel<true, true> (fp16x2), conv1_1 + the first residual block of stage 2 of %d samples in one launch" % conv_n,
+        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK + "<true, true>", None, conv_n, "samples", conv_n * 160 * 160 * (2 + 64) * 4,
+        "the 2-channel sample in, the block's 64-channel output out: N*160*160*(2 + 64)*4 B")
+elif rows("pmc_e2e_fetch", "FETCH_SIZE", BLOCK + "<true"):
     out["conv_block0"] = section(
         "conv_block32_kernel<true> (fp16x2), the first residual block of stage 2 of %d samples in one launch" % conv_n,
-        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK + "<true>", None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 1.25,
+        "pmc_e2e_fetch", "pmc_e2e_write", BLOCK + "<true", None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 1.25,
         "the block's 16-channel input in, its 64-channel output out: N*160*160*64*4 B * 1.25")
 if fused:
     out["conv_block"] = section(
         "conv_block32s_kernel / conv_block32_kernel<false> (fp16x2), a stage-2 residual block of %d samples in one launch (two 3x3 convs 64->64 ch, 160x160)" % conv_n,
-        "pmc_e2e_fetch", "pmc_e2e_write", (BLOCKS, BLOCK + "<false>"), None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.0,
+        "pmc_e2e_fetch", "pmc_e2e_write", (BLOCKS, BLOCK + "<false"), None, conv_n, "samples", conv_n * 160 * 160 * 64 * 4 * 2.0,
         "the block's input in, its output out: N*160*160*64*4 B * 2 (halo re-reads and the residual are L2 hits by design)")
 RW3 = "conv_rw_kernel<1, 2, 16"
 if rows("pmc_e2e_fetch", "FETCH_SIZE", RW3):
