@@ -257,6 +257,9 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
   float* out = a.out + ((size_t)q.sample * OW + (size_t)ty * fs) * OW * 2 + (size_t)tx * fs * 2;
   float tmn = INFINITY, tmx = -INFINITY, fmn = INFINITY, fmx = -INFINITY;
   const float fspan = __fsub_rn(lim.filt_max, lim.filt_min);
+  // the filtered channel's value waits in LDS for the thermal one (which needs the tile's own minimum and maximum): the two
+  // channels of a pixel then leave in ONE 8-byte store -- written one channel per pass, every 32-byte sector of the sample was
+  // written twice, half each time (the kernel was bound by exactly that: 319 MB in 0.9 ms)
   for (int k = threadIdx.x; k < n; k += LT) {
     const int yy = k / fs, xx = k - yy * fs;
     float tv = pmin, fv = 0.0f;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
       else fo = (float)(255.0 * ((double)fv - dmin) / (dmax - dmin));
     } else if (lim.filt_max == lim.filt_min) fo = (lim.filt_max == 0.0f) ? 0.0f : __fdiv_rn(fv, lim.filt_max);
     else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, lim.filt_min)), fspan);
-    out[((size_t)yy * OW + xx) * 2 + cfi] = fin(fo);
+    s_f[k] = fin(fo);
   }
   tmn = block_min(tmn, sc);
   tmx = block_max(tmx, sc);
@@ -326,14 +329,15 @@ __global__ __launch_bounds__(LT) void cpx_crop_kernel(ClassifyArgs a) {
     float to;
     if (tmx == tmn) to = (tmx == 0.0f) ? 0.0f : __fdiv_rn(tv, tmx);
     else to = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(tv, tmn)), tspan);
-    out[((size_t)yy * OW + xx) * 2 + cth] = fin(to);
+    float fo = s_f[k];  // (finished above unless the tile normalises it itself)
     if (own) {
-      const float fv = s_f[k];
-      float fo;
+      const float fv = fo;
       if (fmx == fmn) fo = (fmx == 0.0f) ? 0.0f : __fdiv_rn(fv, fmx);
       else fo = __fdiv_rn(__fmul_rn(255.0f, __fsub_rn(fv, fmn)), ospan);
-      out[((size_t)yy * OW + xx) * 2 + cfi] = fin(fo);
+      fo = fin(fo);
     }
+    const float tf = fin(to);
+    *reinterpret_cast<float2*>(out + ((size_t)yy * OW + xx) * 2) = cth == 0 ? make_float2(tf, fo) : make_float2(fo, tf);
   }
 }
 
