@@ -114,7 +114,7 @@ HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1
 
 
 EXPORTS = [
-    "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize", "cpx_join_medians",
+    "cpx_abi_version", "cpx_create", "cpx_destroy", "cpx_last_error", "cpx_stream", "cpx_synchronize", "cpx_join_medians", "cpx_release_memory",
     "cpx_track_batch", "cpx_track_workspace_bytes", "cpx_last_kernel_timing", "cpx_associate_batch",
     "cpx_track_limits_batch", "cpx_crop_tile", "cpx_conv2d", "cpx_cnn_head",
     "cpx_finalize_tracks", "cpx_counts_prefix", "cpx_plan_segments", "cpx_aggregate_predictions",
@@ -169,6 +169,8 @@ def load():
     lib.cpx_synchronize.restype = C.c_int
     lib.cpx_join_medians.argtypes = [vp]
     lib.cpx_join_medians.restype = C.c_int
+    lib.cpx_release_memory.argtypes = [vp]
+    lib.cpx_release_memory.restype = C.c_int
     lib.cpx_track_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp]
     lib.cpx_track_batch.restype = C.c_int
     lib.cpx_associate_batch.argtypes = [vp, vp, i32p, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -353,7 +353,11 @@ class TrackEngine:
             eng.close()
         self._grown = {}
         if getattr(self, "_live_results", 0) > 0:
+            # the stream stays for the results' buffers; what the handle itself holds on the device (the network's activation
+            # arena -- tens of GB --, workspaces) goes now: a closed engine that lingers must not cost the next one its memory
             self._close_deferred = True
+            if self.h:
+                self.lib.cpx_release_memory(self.h)
             return
         self._destroy()
 

@@ -1134,6 +1134,12 @@ def run_files_bulk(filenames, config, to_stdout=False, save_meta=True, device=0,
         except torch.cuda.OutOfMemoryError as e:   # (budgets too generous for this device: memory released, members retried)
             r = RuntimeError("device out of memory for a group of %d recordings / %d frames: %s"
                              % (len(group.files), int(group.offs[-1]), str(e).splitlines()[0]))
+            if os.environ.get("CPX_BULK_OOM_DEBUG"):
+                import sys as _sys
+                free_b, total_b = torch.cuda.mem_get_info()
+                _sys.stderr.write("OOM DEBUG: free %.1f GiB of %.1f; torch allocated %.1f reserved %.1f GiB; lanes %s\n%s\n" % (
+                    free_b / 2**30, total_b / 2**30, torch.cuda.memory_allocated() / 2**30, torch.cuda.memory_reserved() / 2**30,
+                    lanes_now[0], torch.cuda.memory_summary(abbreviated=True)))
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001 -- the whole group failed (CpxError or anything else): every member goes the slow way
             r = e

@@ -381,6 +381,31 @@ int cpx_join_medians(cpx_handle* h) {
   return join_medians(h);
 }
 
+int cpx_release_memory(cpx_handle* h) {
+  if (!h) return CPX_ERR_INVALID;
+  CPX_ENTER(h);
+  if (int rc = join_medians(h)) return rc;
+  CPX_HIP(h, hipStreamSynchronize(h->stream));
+  CPX_HIP(h, hipStreamSynchronize(h->stream2));
+  if (h->cnn_arena) hipFree(h->cnn_arena);
+  h->cnn_arena = nullptr;
+  h->cnn_arena_floats = 0;
+  if (h->bf3_scratch) hipFree(h->bf3_scratch);
+  h->bf3_scratch = nullptr;
+  h->bf3_scratch_bytes = 0;
+  if (h->ws) hipFree(h->ws);
+  h->ws = nullptr;
+  h->ws_bytes = 0;
+  h->last_B = 0;
+  if (h->ws_assoc) hipFree(h->ws_assoc);
+  h->ws_assoc = nullptr;
+  h->ws_assoc_bytes = 0;
+  if (h->ir_scratch) hipFree(h->ir_scratch);
+  h->ir_scratch = nullptr;
+  h->ir_scratch_bytes = 0;
+  return CPX_OK;
+}
+
 int cpx_synchronize(cpx_handle* h) {
   if (!h) return CPX_ERR_INVALID;
   if (int rc = join_medians(h)) return rc;

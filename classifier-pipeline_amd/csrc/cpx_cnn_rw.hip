@@ -22,6 +22,12 @@
 // Arithmetic: conv_bf3w_kernel's fp16x2 (two fp16 planes per operand, three products w_lo x_hi + w_hi x_lo + w_hi x_hi, float32
 // accumulate, powers-of-two scales, overflow word + guarded bf16x3 rerun: include/cpx.h CPX_CNN_MATH_FP16X2); the taps are
 // summed kx-major (kx, then ky) instead of ky-major -- another float32 order of the same terms.
+// The same kernel at stride 2 and 3 (template parameters S, NCH, ROWS; RwGeo below): conv_rw_kernel<2, 1, 8> is the first
+// convolution of stage 3 (32 -> 64 channels per group: one 32-channel chunk per tile, 16 x 8 output tiles from 33 x 17 patches,
+// the two buffers alternate per tile; HBM-bound at 5.05 TB/s), conv_rw_kernel<3, 2, 4> the first convolution of stage 4
+// (64 -> 128: 16 x 4 output tiles from 48 x 12 patches, a workgroup computes 64 of the 128 output channels of its group).
+// Measurements of every step on the way, the forms that lost and what was considered and not built:
+// profiles/r06_conv_rw_experiments.md; counters of the shipped forms: profiles/r06_conv_sq_counters.json, r06_conv_traffic.json.
 // Reference semantics: /root/reference/src/ml_tools/resnet/wr_resnet.py:49-98 (wr_block: BN -> ReLU -> conv3x3 -> BN -> ReLU ->
 // conv3x3 -> add), kerasmodel.py:441-454.
 #include <hip/hip_runtime.h>

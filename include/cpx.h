@@ -192,6 +192,12 @@ int cpx_track_frame(cpx_handle* h, const uint16_t* frames_dev, const cpx_frame_m
 /* Orders everything enqueued on cpx_stream(h) from here on behind the medians a CPX_TRACK_DEFER_MEDIANS call left in
  * flight (a stream wait, the host does not block); nothing to do otherwise. */
 int cpx_join_medians(cpx_handle* h);
+/* Waits for the handle's streams and frees the device memory the handle allocates on demand and can allocate again: the
+ * network's activation arena (four times the largest activation of the largest batch seen: 41 GB at 1,559 samples of
+ * 160 x 160), the weight-split scratch, the track / association workspaces (with them the state CPX_TRACK_KEEP_BACKGROUND,
+ * cpx_get_background and the *_frame calls continue from) and the IR scratch.  For a handle that is kept (its stream still
+ * owns result buffers) but will not run soon; cpx_destroy frees everything. */
+int cpx_release_memory(cpx_handle* h);
 int cpx_track_batch_ex(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
                        const cpx_frame_meta* meta, int B, cpx_component* comps_dev, cpx_frame_info* info_dev,
                        int32_t* labels_dev, float* filtered_dev, float* background_dev, int flags);

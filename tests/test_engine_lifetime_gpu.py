@@ -142,3 +142,27 @@ def test_deferred_medians_are_complete_for_their_readers():
         again = eng.track_batch(frames, offs, meta, outputs=outputs, flags=TRACK_DEFER_MEDIANS)
         assert np.array_equal(again.info["thermal_median"], want), trial
     eng.close()
+
+
+def test_deferred_close_gives_the_handles_own_memory_back():
+    """An engine closed while a result of it lives keeps its stream, not its memory: the workspaces (and the network's
+    activation arena -- 41 GB at the bench's chunk) are released at close(); the bench's file-fed leg ran out of memory beside
+    three such lingering engines before this was so."""
+    import torch
+
+    from cpx.engine import TrackEngine
+
+    eng = TrackEngine(model="lepton3", device=0, max_frames=128)
+    frames, offs, meta = _batch(eng, n_clips=512, frames=100)
+    res = eng.track_batch(frames, offs, meta, want_filtered=True)
+    want = res.filtered()[:3].copy()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    eng.close()
+    assert eng.h and eng._close_deferred
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 - free0 >= 512 * 160 * 120 * 8, (free0, free1)   # at least the clips' background / window state
+    assert np.array_equal(res.filtered()[:3], want)                 # the result is still readable
+    del res
+    gc.collect()
+    assert not eng.h
