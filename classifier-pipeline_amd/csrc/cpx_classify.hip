@@ -41,6 +41,12 @@ __device__ __forceinline__ T wmax(T v) {
 }
 
 constexpr int LT = 256;  // threads of both kernels
+// the limits kernel: sixteen waves per track -- a wave walks its share of the track's regions through three dependent trips to
+// memory each, and the longest track of a batch is the kernel's time (four waves: 1.6 ms per 4096 clips; sixteen: see profiles/r06_track_experiments.md)
+#ifndef CPX_LIMITS_THREADS
+#define CPX_LIMITS_THREADS 1024
+#endif
+constexpr int LTL = CPX_LIMITS_THREADS, LWL = LTL / 64;
 constexpr int LW = LT / 64;
 
 // block-wide reductions through a small LDS scratch (all threads get the result)
@@ -76,11 +82,11 @@ __device__ __forceinline__ u32 block_sum_u32(u32 v, u32* sc) {
 // ---------------------------------------------------------------------------------------
 // get_limits + the clip_thermals_at_zero test, one workgroup per track
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
+__global__ __launch_bounds__(LTL) void cpx_limits_kernel(ClassifyArgs a) {
   // the track's regions are dealt to the workgroup's waves; a wave handles a region with shuffles only (no
   // workgroup barrier inside the per-region median bisection), the waves meet once at the end
-  __shared__ float s_mn[LW], s_mx[LW], s_tmn[LW], s_tmx[LW];
-  __shared__ int s_clip[LW];
+  __shared__ float s_mn[LWL], s_mx[LWL], s_tmn[LWL], s_tmx[LWL];
+  __shared__ int s_clip[LWL];
   const int t = blockIdx.x;
   const int r0 = a.track_offsets[t], r1 = a.track_offsets[t + 1];
   const int W = a.W, P = a.W * a.H;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
   float mn = INFINITY, mx = post ? -INFINITY : 0.0f;
   float tmn = INFINITY, tmx = -INFINITY;  // thermal_norm_limits: thermal - median over the whole frame (get_limits)
   int clip0 = 1;
-  for (int r = r0 + wave; r < r1; r += LW) {
+  for (int r = r0 + wave; r < r1; r += LWL) {
     const cpx_region_ref ref = a.refs[r];
     if (ref.width <= 0 || ref.height <= 0) continue;
     if (post && !ref.in_segment) continue;
@@ -155,13 +161,13 @@ __global__ __launch_bounds__(LT) void cpx_limits_kernel(ClassifyArgs a) {
     cpx_track_limits o;
     float fmn = s_mn[0], fmx = s_mx[0];
     int c0 = s_clip[0];
-    for (int w = 1; w < LW; ++w) {
+    for (int w = 1; w < LWL; ++w) {
       fmn = fminf(fmn, s_mn[w]);
       fmx = fmaxf(fmx, s_mx[w]);
       c0 &= s_clip[w];
     }
     float ftmn = s_tmn[0], ftmx = s_tmx[0];
-    for (int w = 1; w < LW; ++w) {
+    for (int w = 1; w < LWL; ++w) {
       ftmn = fminf(ftmn, s_tmn[w]);
       ftmx = fmaxf(ftmx, s_tmx[w]);
     }
@@ -408,7 +414,7 @@ void launch_aggregate(const AggregateArgs& a, hipStream_t s) {
 }
 
 void launch_limits(const ClassifyArgs& a, int n_tracks, hipStream_t s) {
-  hipLaunchKernelGGL(cpx_limits_kernel, dim3(n_tracks), dim3(LT), 0, s, a);
+  hipLaunchKernelGGL(cpx_limits_kernel, dim3(n_tracks), dim3(LTL), 0, s, a);
 }
 void launch_crop(const ClassifyArgs& a, int n_reqs, hipStream_t s) {
   hipLaunchKernelGGL(cpx_crop_kernel, dim3(n_reqs), dim3(LT), (size_t)2 * a.frame_size * a.frame_size * sizeof(float), s, a);
