@@ -26,6 +26,7 @@
 //   phase 7  per-run statistics -> components, 2x2-block raster ordering
 //   phase 8  label image (optional), one wave per component delta-variance
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include <stdint.h>
 
@@ -1328,7 +1329,7 @@ __global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* F = a.frames + (size_t)fidx * P;
   __shared__ u32 s_cnt[3 * NW_MED];
-  __shared__ u32 s_mm[2 * NW_MED];
+  __shared__ u32 s_mm[3 * NW_MED];
   u32 pk[MCH][2];
   // all loads first, branch-free (clamped address, padding selected afterwards): a conditional load makes the compiler
   // wait for each one before the next is issued -- twenty serialised trips to HBM
@@ -1339,35 +1340,56 @@ __global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0,
     pk[i][0] = q.x;
     pk[i][1] = q.y;
   }
-  u32 minpix = 0xFFFFFFFFu, maxpix = 0;
+  u32 minpix = 0xFFFFFFFFu, maxpix = 0, sumpix = 0;
 #pragma unroll
   for (int i = 0; i < MCH; ++i) {
     const bool in = tid + i * NT_MED < nchunk;
     const u32 v0 = pk[i][0] & 0xFFFFu, v1 = pk[i][0] >> 16, v2 = pk[i][1] & 0xFFFFu, v3 = pk[i][1] >> 16;
     minpix = in ? min(min(minpix, v0), min(v1, min(v2, v3))) : minpix;
     maxpix = in ? max(max(maxpix, v0), max(v1, max(v2, v3))) : maxpix;
+    sumpix += in ? (v0 + v1) + (v2 + v3) : 0u;
     pk[i][0] = in ? pk[i][0] : 0xFFFFFFFFu;  // padding: 65535, never below a bisection candidate
     pk[i][1] = in ? pk[i][1] : 0xFFFFFFFFu;
   }
   minpix = wave_min(minpix);
   maxpix = wave_max(maxpix);
+  sumpix = wave_sum(sumpix);
   if (lane == 0) {
     s_mm[wave] = minpix;
     s_mm[NW_MED + wave] = maxpix;
+    s_mm[2 * NW_MED + wave] = sumpix;
   }
   __syncthreads();
-  u32 lo = 0xFFFFFFFFu, hi = 0;
+  u32 lo = 0xFFFFFFFFu, hi = 0, tsum = 0;
 #pragma unroll
   for (int w = 0; w < NW_MED; ++w) {
     lo = min(lo, s_mm[w]);
     hi = max(hi, s_mm[NW_MED + w]);
+    tsum += s_mm[2 * NW_MED + w];
   }
   lo = (u32)uni((int)lo);
   hi = (u32)uni((int)hi);
+  const u32 meanv = (u32)uni((int)(tsum / (u32)P));
   const u32 k1 = (u32)((P - 1) >> 1), k2 = (u32)(P >> 1);
   int par = 0;
+  // Selection of the value of rank k1 in [lo, hi] by counting `value <= mid`, one workgroup-wide count per round.  A thermal frame
+  // is mostly background: its median sits within a few counts of its MEAN, so the first probe is the mean and the bracket is
+  // found by galloping away from it (steps of 2, 8, 32, ...) before it is bisected -- 4-6 rounds where bisecting [min, max]
+  // takes log2(max - min) = 10-14.  Every probe keeps the invariant (rank k1 lies in [lo, hi]); the order of the probes does not
+  // change what is found.
+#ifdef CPX_MED_PLAIN_BISECT   // (experiment switch: bisect [min, max] as rounds 2-5 did)
+  int phase = 3;
+#else
+  int phase = 0;   // 0: probe the mean; 1 / 2: galloping down from hi / up from lo; 3: bisection
+#endif
+  u32 gstep = 2;
   while (lo < hi) {  // uniform: every thread sees the same block totals
-    const u32 mid = (lo + hi) >> 1;
+    if (phase != 0 && hi - lo <= gstep) phase = 3;   // the bracket is narrower than the next step: bisect it (the step stops growing:
+                                                     // grown through sixteen more rounds it would wrap to zero and probe lo - 1 for ever)
+    u32 mid = (lo + hi) >> 1;
+    if (phase == 0) mid = min(max(meanv, lo), hi - 1u);
+    else if (phase == 1) mid = hi - gstep;
+    else if (phase == 2) mid = lo + gstep - 1u;
     u32 cnt = 0;
     // The compare + s_bcnt1 form costs two scalar instructions per value and the CU has ONE scalar unit for its four SIMDs: alone
     // it ran that unit at ~80 % (profiles/r06_track_experiments.md).  So the last MCH - MED_SCALAR registers count on the vector
@@ -1399,8 +1421,17 @@ __global__ __launch_bounds__(NT_MED) void cpx_median_kernel(TrackArgs a, int t0,
     for (int w = 0; w < NW_MED; ++w) tot += s_cnt[par * NW_MED + w];
     tot = (u32)uni((int)tot);
     par ^= 1;
-    if (tot >= k1 + 1) hi = mid;
+    const bool le = tot >= k1 + 1;   // the value of rank k1 is <= mid
+    if (le) hi = mid;
     else lo = mid + 1;
+    if (phase == 0) phase = le ? 1 : 2;
+    else if (phase == 1) {
+      if (le) gstep <<= 2;
+      else phase = 3;
+    } else if (phase == 2) {
+      if (!le) gstep <<= 2;
+      else phase = 3;
+    }
   }
   // lo = value of rank k1; rank k2 is the same value unless exactly k1+1 pixels are <= lo
   u32 cnt = 0, nxt = 0xFFFFFFFFu;

@@ -612,3 +612,31 @@ def test_association_matches_reference_on_busy_scenes(engines, golden_dir):
         idx = {tuple(r[[0, 6]]): i for i, r in enumerate(got)}
         sel = [idx[(int(w[0]), int(w[6]))] for w in want]
         assert np.array_equal(got[sel], want), int(seeds[k])
+
+
+def test_median_of_adversarial_frames(engines):
+    """cpx_median_kernel probes the mean first and gallops away from it before it bisects (round 6): frames whose median is as
+    far from their mean as 16-bit values allow -- two levels split at every third, saturated neighbours, noise over the whole
+    range -- must still select exactly, and terminate (a galloping step that kept growing through the bisection wrapped to
+    zero on exactly such a frame)."""
+    eng = engines("lepton3")
+    H, W = 120, 160
+    rng = np.random.default_rng(77)
+    frames = []
+    for a, b in ((0, 65535), (0, 1), (65534, 65535), (0, 2), (1, 65535), (7, 40000)):
+        for frac in (0.3, 0.5, 0.7):
+            x = np.full(H * W, a, np.uint16)
+            x[int(H * W * frac):] = b
+            frames.append(x.reshape(H, W))
+            y = np.full(H * W, b, np.uint16)
+            y[int(H * W * frac) - 1:] = a
+            frames.append(rng.permutation(y).reshape(H, W))
+    for _ in range(6):
+        frames.append(rng.integers(0, 65536, size=(H, W)).astype(np.uint16))
+        frames.append((rng.integers(0, 65533) + rng.integers(0, 3, size=(H, W))).astype(np.uint16))
+    frames = np.stack(frames)
+    n = frames.shape[0]
+    res = eng.track_batch(eng.upload_frames(frames), np.array([0, n], np.int32), eng.make_meta(n))
+    got = res.info["thermal_median"]
+    for i in range(n):
+        assert float(got[i]) == float(np.float32(np.median(frames[i]))), i
