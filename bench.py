@@ -17,7 +17,7 @@ no data-path collective; the per-track result records are all-gathered once per 
 
 Extra objects on the JSON line:
   roofline      the kernel the step spends most of its time in (its `dominant` field says which and how long).  e2e, default
-                fp16x2 math: cpx_frame_kernel (one launch per step, HBM-bound: 460,800 moved bytes per frame without the label
+                fp16x2 math: cpx_frame_kernel (one launch per step, HBM-bound: 384,000 moved bytes per frame without the label
                 image) -- the convolutions stopped being the largest kernel when the fp16x2 mode halved their products and the
                 stage-2 blocks became one launch each.  Every other kernel above a tenth of the step stands under
                 roofline.kernels: conv_stage3 (conv_bf3w_kernel<..., 2, ...>), conv_block (conv_block32_kernel), conv_stage2
@@ -1120,9 +1120,15 @@ def main():
         # what the kernel really moves: the background is kept as uint16 (a floor of a mean of uint16 frames), so its
         # read + write cost 76,800 B per frame instead of the 153,600 B of SURVEY's int32 count
         moved_per_launch = bytes_per_launch - 76800 * clips_per_launch
+        # round 6: a fresh batch of at most 1023 frames per clip keeps the per-pixel kept-frame count in the window sum's top ten
+        # bits (cpx_frame_kernel<true>): the uint16 count array is neither read nor written -- another 76,800 B per frame less
+        packed_state = T <= 1023 and os.environ.get("CPX_TRACK_PACKED_STATE", "1") != "0"
+        if packed_state:
+            moved_per_launch -= 76800 * clips_per_launch
         hbm_moved = moved_per_launch / avg_launch_s / 1e9
-        # headline fraction: the bytes the kernel moves (uint16 background: 537,600 B per frame, 460,800 without the
-        # label image); the figure on SURVEY section 8(d)'s count (int32 background, 614,400 B) stays beside it
+        # headline fraction: the bytes the kernel moves (uint16 background, count packed into the window sum: 460,800 B per frame,
+        # 384,000 without the label image); the figure on SURVEY section 8(d)'s count (int32 background, a count array: 614,400 B)
+        # stays beside it
         track_roof = {"kernel": "cpx_frame_kernel", "bound": "hbm", "achieved": round(hbm_moved, 1), "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": round(hbm_moved / HBM_PEAK_GBS, 4),
                       "achieved_survey_bytes": round(hbm, 1), "frac_survey_bytes": round(hbm / HBM_PEAK_GBS, 4),
@@ -1133,9 +1139,11 @@ def main():
                       "moved_bytes_per_launch": moved_per_launch, "achieved_moved": round(hbm_moved, 1),
                       "frac_moved": round(hbm_moved / HBM_PEAK_GBS, 4),
                       "frac_moved_of_achievable": round(hbm_moved / 6290.0, 4),
-                      "note": "achieved / frac count the bytes the kernel moves (uint16 background: the algorithmic "
-                              "bytes of THIS data layout, DESIGN.md section 4); *_survey_bytes count SURVEY section "
-                              "8(d)'s int32 background; 6.29 TB/s is the measured float4-copy rate of the guide"}
+                      "packed_state": packed_state,
+                      "note": "achieved / frac count the bytes the kernel moves (uint16 background, the kept-frame count "
+                              "packed into the window sum: the algorithmic bytes of THIS data layout, DESIGN.md section 4); "
+                              "*_survey_bytes count SURVEY section 8(d)'s int32 background and separate count array; 6.29 TB/s is "
+                              "the measured float4-copy rate of the guide"}
         line = {
             "metric": "CPTV frames/s end-to-end (track+classify) at 160x120" if e2e else
                       "CPTV frames/s (track stage only: background + region-label HIP kernels) at 160x120",

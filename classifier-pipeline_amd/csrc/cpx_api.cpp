@@ -51,6 +51,10 @@ struct cpx_handle {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
   int split_min_clips = 0;  // 0 = never split
+  // the last track call kept the per-pixel kept-frame counts in the window sums' top ten bits (cpx_frame_kernel<true>): whatever
+  // continues from that state, or exports it, unpacks it first (unpack_state)
+  bool state_packed = false;
+  bool packed_state_ok = true;   // CPX_TRACK_PACKED_STATE=0: never pack
   bool fuse_conv1 = true;   // conv1_1 inside the fused first block of stage 2 (CPX_CNN_FUSE_CONV1=0: a launch of its own)
   // CPX_TRACK_DEFER_MEDIANS: the median kernel of the last track call runs on stream2; ev_median marks its end
   bool medians_pending = false;
@@ -308,6 +312,7 @@ int cpx_create(int device_id, const cpx_config* cfg, cpx_handle** out) {
     return CPX_ERR_HIP;
   }
   if (const char* env = std::getenv("CPX_TRACK_SPLIT_MIN_CLIPS")) h->split_min_clips = std::atoi(env);
+  if (const char* env = std::getenv("CPX_TRACK_PACKED_STATE")) h->packed_state_ok = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_FUSE_CONV1")) h->fuse_conv1 = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_TRACK_PER_STEP")) h->track_per_step = std::atoi(env) != 0;
   if (const char* env = std::getenv("CPX_CNN_FUSE_SHORTCUT")) h->fuse_shortcut = std::atoi(env) != 0;
@@ -397,6 +402,7 @@ int cpx_release_memory(cpx_handle* h) {
   h->ws = nullptr;
   h->ws_bytes = 0;
   h->last_B = 0;
+  h->state_packed = false;
   if (h->ws_assoc) hipFree(h->ws_assoc);
   h->ws_assoc = nullptr;
   h->ws_assoc_bytes = 0;
@@ -422,6 +428,19 @@ size_t cpx_track_workspace_bytes(const cpx_handle* h, int B, int total_frames) {
 // Track stage for B clips.  n_prev < 0: whole clips (cpx_track_batch).  n_prev >= 0 (B == 1): the clip's first n_prev
 // frames were consumed by earlier calls on this handle and its state is still in the workspace; only the frames
 // [n_prev, clip_offsets[1]) are processed (cpx_track_frame).
+// the state of the last track call in the layout every path but cpx_frame_kernel<true> reads (see cpx_handle::state_packed)
+static int unpack_state(cpx_handle* h) {
+  if (h->state_packed && h->ws && h->last_B > 0) {
+    const WsLayout lp = ws_layout(h->cfg, h->last_B, h->stream_filt_state);
+    char* base = (char*)h->ws;
+    cpx::launch_unpack_state((uint32_t*)(base + lp.wsum), (uint16_t*)(base + lp.kcnt),
+                             (size_t)h->last_B * h->cfg.width * h->cfg.height, h->stream);
+    CPX_HIP(h, hipGetLastError());
+  }
+  h->state_packed = false;
+  return CPX_OK;
+}
+
 static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* clip_offsets,
                      const cpx_frame_meta* meta, int B, int n_prev, cpx_component* comps_dev,
                      cpx_frame_info* info_dev, int32_t* labels_dev, float* filtered_dev,
@@ -460,6 +479,11 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
       h->staged_bg.clear();  // staged for THIS call: a refused call does not leave them behind for the one after
       return fail(h, CPX_ERR_INVALID, "cpx_set_background: staged clip index outside the batch (staged states dropped)");
     }
+  // a call that continues from the previous call's state reads it in the two-array layout; a fresh one starts its own
+  if (resume || keep) {
+    if (int urc = unpack_state(h)) return urc;
+  }
+  h->state_packed = false;
   h->stream_filt_state = need_filt;
   h->last_B = B;
   if (l.total > h->ws_bytes) {
@@ -496,6 +520,8 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
   a.bg = (uint16_t*)(base + l.bg);
   a.wsum = (uint32_t*)(base + l.wsum);
   a.kcnt = (uint16_t*)(base + l.kcnt);
+  // a fresh batch of at most 1023 processed frames per clip: the kept-frame counts ride in the window sums (cpx_track.hip, PK)
+  a.packed_state = (h->packed_state_ok && !resume && !keep && h->staged_bg.empty() && max_proc <= 1023 && c.window <= 64) ? 1 : 0;
   a.filt_state = need_filt ? (float*)(base + l.filt) : nullptr;
   a.cstate = (cpx::ClipState*)(base + l.cstate);
   a.u8_state = (unsigned char*)(base + l.u8);
@@ -579,6 +605,7 @@ static int track_run(cpx_handle* h, const uint16_t* frames_dev, const int32_t* c
     CPX_HIP(h, hipEventRecord(h->ev_median, h->stream2));
     h->medians_pending = true;
   }
+  h->state_packed = a.packed_state != 0;
   h->last_launches = launches;
   h->timing_valid = true;
   if (background_dev) cpx::launch_export_background(a, B, background_dev, h->stream);
@@ -677,6 +704,7 @@ int cpx_get_background(cpx_handle* h, int clip, float* background, double* weigh
   const size_t P = (size_t)W * H;
   const WsLayout l = ws_layout(c, h->last_B, h->stream_filt_state);
   char* base = (char*)h->ws;
+  if (int urc = unpack_state(h)) return urc;
   CPX_HIP(h, hipStreamSynchronize(h->stream));
   cpx::ClipState st;
   CPX_HIP(h, hipMemcpy(&st, base + l.cstate + (size_t)clip * sizeof(cpx::ClipState), sizeof(st), hipMemcpyDeviceToHost));

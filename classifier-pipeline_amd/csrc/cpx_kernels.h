@@ -79,6 +79,7 @@ struct TrackArgs {
                             // floor of a mean of uint16 frames, so 16 bits hold it exactly
   uint32_t* wsum;           // [B][P] sum of the last <= window frames
   uint16_t* kcnt;           // [B][P] consecutive "background kept" count -> weight = wtab[k]
+  int packed_state;         // 1: this call keeps that count in wsum's top ten bits and leaves kcnt alone (cpx_frame_kernel<true>)
   float* filt_state;        // [B][2][P] ping-pong filtered (only when filtered_out == nullptr)
   ClipState* cstate;        // [B]
   unsigned char* u8_state;  // [B][P] normalised uint8 image between front / NLM / back (denoise only)
@@ -385,6 +386,7 @@ int track_max_pixels();
 int track_lds_components();
 int frame_kernel_attr_setup();
 void launch_init(const TrackArgs& a, int B, int keep, hipStream_t s);
+void launch_unpack_state(uint32_t* wsum, uint16_t* kcnt, size_t n, hipStream_t s);
 void launch_frame(const TrackArgs& a, int B, int t0, int t1, int mode, hipStream_t s);  // processed frames [t0, t1) of every clip
 void launch_nlm(const TrackArgs& a, int B, int t, hipStream_t s);
 void launch_median(const TrackArgs& a, int B, int t0, int t1, hipStream_t s);  // thermal medians of processed frames [t0, t1) -> FrameInfo

@@ -26,6 +26,7 @@
 //   phase 7  per-run statistics -> components, 2x2-block raster ordering
 //   phase 8  label image (optional), one wave per component delta-variance
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <stdint.h>
@@ -291,6 +292,11 @@ __device__ __forceinline__ ClipState uniform_state(const ClipState& s) {
 }
 // (the arguments are read through the kernel-argument segment, see the kernel below)
 typedef __attribute__((address_space(4))) const TrackArgs KernArgs;
+// PK (round 6): the per-pixel count of consecutive kept frames rides in the top ten bits of the pixel's window sum (22 bits: 64
+// frames x 65535 at most) instead of in an array of its own -- 2 B read and 2 B written per pixel and frame less, a sixth of what
+// this HBM-bound kernel moves.  Only for a fresh batch of at most 1023 processed frames per clip (the count cannot outgrow ten
+// bits); the host unpacks the state (cpx_unpack_state_kernel) before anything continues from it (cpx_api.cpp: track_run).
+template <bool PK>
 __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int pbase, const int t, const int mode,
                                            ClipState& cs, unsigned char* smem) {
   const int W = a.W, H = a.H, P = W * H, e = a.edge;
@@ -470,7 +476,8 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       }
       q.old = *reinterpret_cast<const u32*>(at_off(Osafe, p0u << 1));
       q.ws = *reinterpret_cast<const uint2*>(at_off(ws, p0u << 2));
-      q.kc = *reinterpret_cast<const u32*>(at_off(kc, p0u << 1));
+      if constexpr (PK) q.kc = 0u;
+      else q.kc = *reinterpret_cast<const u32*>(at_off(kc, p0u << 1));
       return q;
     };
     auto step = [&](const Coord& q0, const Pair& cur) {
@@ -490,6 +497,13 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       const int oldp[2] = {(int)(oldq & 0xFFFFu), (int)(oldq >> 16)};
       u32 wsv[2] = {cur.ws.x, cur.ws.y};
       int kv[2] = {(int)(cur.kc & 0xFFFFu), (int)(cur.kc >> 16)};
+      if constexpr (PK) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          kv[j] = (int)(wsv[j] >> 22);
+          wsv[j] &= 0x3FFFFFu;
+        }
+      }
       int nb[2];
       float fo[2];
       u32 xs2[2];
@@ -563,9 +577,10 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
       *reinterpret_cast<u32*>(s_tmp + p0) = (xs2[0] & 0xFFFFu) | (xs2[1] << 16);
       *reinterpret_cast<uint16_t*>(s_u8 + p0) = (uint16_t)((xs2[0] >> 16) | ((xs2[1] >> 16) << 8));
       *reinterpret_cast<float2*>(at_off(filt_cur, p0u << 2)) = make_float2(fo[0], fo[1]);
-      *reinterpret_cast<uint2*>(at_off(ws, p0u << 2)) = make_uint2(wsv[0], wsv[1]);
+      if constexpr (PK) *reinterpret_cast<uint2*>(at_off(ws, p0u << 2)) = make_uint2(wsv[0] | ((u32)kv[0] << 22), wsv[1] | ((u32)kv[1] << 22));
+      else *reinterpret_cast<uint2*>(at_off(ws, p0u << 2)) = make_uint2(wsv[0], wsv[1]);
       *reinterpret_cast<u32*>(at_off(bg_new, p0u << 1)) = ((u32)nb[0] & 0xFFFFu) | ((u32)nb[1] << 16);
-      *reinterpret_cast<u32*>(at_off(kc, p0u << 1)) = ((u32)kv[0] & 0xFFFFu) | ((u32)kv[1] << 16);
+      if constexpr (!PK) *reinterpret_cast<u32*>(at_off(kc, p0u << 1)) = ((u32)kv[0] & 0xFFFFu) | ((u32)kv[1] << 16);
     };
     // Full rounds (every lane has a pair) run pipelined and without any predicate around a memory operation, so that
     // the wait before a step's arithmetic counts exactly: the four loads of the next step and the four stores of the
@@ -1269,6 +1284,7 @@ __device__ __forceinline__ void frame_step(KernArgs& a, const int b, const int p
 // neighbour on the CU instead of every workgroup of a per-frame launch moving through the same phase at once.
 // a.order (optional) lists the clips by falling length: the dispatcher hands out workgroups in index order.
 // The split forms (mode 1 / 2, around the NLM kernel or on two streams) are launched one step at a time.
+template <bool PK>
 __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_kernel(TrackArgs a, int t0, int t1, int mode) {
   const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int pbase = a.proc_off[b];
@@ -1291,7 +1307,7 @@ __global__ __launch_bounds__(NT, CPX_TRACK_MIN_WAVES_PER_SIMD) void cpx_frame_ke
   KernArgs* ap = (KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   for (int t = t0; t < tend; ++t) {
     asm volatile("" : "+s"(ap));
-    frame_step(*ap, b, pbase, t, mode, cs, smem);
+    frame_step<PK>(*ap, b, pbase, t, mode, cs, smem);
     if (t + 1 < tend) {
       // the next frame reads what other threads of this workgroup wrote (clamped background edges, the previous
       // filtered frame under a bounding box) and reuses the LDS image.  Workgroup scope is all it takes: the waves
@@ -1961,7 +1977,21 @@ void launch_init(const TrackArgs& a, int B, int keep, hipStream_t s) {
   hipLaunchKernelGGL(cpx_init_kernel, dim3(B), dim3(256), 0, s, a, keep);
 }
 void launch_frame(const TrackArgs& a, int B, int t0, int t1, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(cpx_frame_kernel, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t0, t1, mode);
+  if (a.packed_state) hipLaunchKernelGGL(cpx_frame_kernel<true>, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t0, t1, mode);
+  else hipLaunchKernelGGL(cpx_frame_kernel<false>, dim3(B), dim3(NT), track_lds_bytes(a.W, a.H), s, a, t0, t1, mode);
+}
+// the state a packed call left (count in the window sum's top ten bits) -> the two arrays every other path reads
+__global__ __launch_bounds__(256) void cpx_unpack_state_kernel(uint32_t* wsum, uint16_t* kcnt, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t v = wsum[i];
+    kcnt[i] = (uint16_t)(v >> 22);
+    wsum[i] = v & 0x3FFFFFu;
+  }
+}
+void launch_unpack_state(uint32_t* wsum, uint16_t* kcnt, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 65535u * 16u);
+  hipLaunchKernelGGL(cpx_unpack_state_kernel, dim3(blocks), dim3(256), 0, s, wsum, kcnt, n);
 }
 void launch_median(const TrackArgs& a, int B, int t0, int t1, hipStream_t s) {
   if (t1 <= t0) return;
@@ -1973,7 +2003,9 @@ void launch_export_background(const TrackArgs& a, int B, float* out, hipStream_t
 int track_max_pixels() { return 4 * NCH * NT; }
 int track_lds_components() { return CAP; }
 int frame_kernel_attr_setup() {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+  const int r0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_frame_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+  const int r1 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(cpx_frame_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+  return r0 != 0 ? r0 : r1;
 }
 
 }  // namespace cpx
